@@ -1,0 +1,270 @@
+#!/usr/bin/env python
+"""bench.py -- kriged grid-points/sec (z + sigma^2) of the HIP execute() path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4|5] [--no-cpu]
+
+One "step" = one pass of the hot path over the workload with inputs already resident in HBM:
+kriging-matrix assembly + inverse (K1, K2) [+ RCCL broadcast of the inverse when N > 1] + RHS assembly
+and contraction (K3) for every grid point of this rank's shard; z and sigma^2 stay in HBM.
+Default workload = BASELINE.json configs[1]: OrdinaryKriging 2D, N=5000 stations, 1000x1000 grid,
+exponential variogram [1.0, 0.3, 0.0], fp64, synthetic stations (seed 2).
+N > 1 (launched by torch.distributed.run, one rank per GPU): WEAK scaling -- every rank kriges its own
+1000x1000 slab of a 1000 x (1000 N) grid against the same stations; rank 0 assembles + inverts and the
+inverse is broadcast over RCCL/xGMI by the library (mik_bcast_factor); no other collective.
+torch is imported only for N > 1 (rendezvous, barrier, max-over-ranks of the time) -- plumbing.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X FP64 matrix peak (public spec; = 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz).
+# The local microarch guide lists no FP64 row; tools/ubench_f64.hip measures the achievable rate (profiles/).
+
+CONFIGS = {
+    # name: (ndim, seed, n, axes sizes (x, y[, z]), model, user params, drift)
+    2: dict(name="OK2D N=5000 1000x1000 exponential", ndim=2, seed=2, n=5000, grid=(1000, 1000), model="exponential",
+            params=[1.0, 0.3, 0.0]),
+    3: dict(name="OK3D N=2000 200x200x50 gaussian", ndim=3, seed=3, n=2000, grid=(200, 200, 50), model="gaussian",
+            params=[1.0, 0.4, 0.02]),
+    4: dict(name="UK2D N=4000 1024x1024 exponential regional_linear+point_log", ndim=2, seed=4, n=4000,
+            grid=(1024, 1024), model="exponential", params=[1.0, 0.3, 0.01], rl=True,
+            wells=[[0.3137, 0.7219, 1.0], [0.6621, 0.2483, -0.5], [0.8412, 0.8127, 2.0]]),
+    5: dict(name="OK2D N=8000 4096x4096 spherical (per-GPU shard = 4096x512 rows)", ndim=2, seed=5, n=8000,
+            grid=(4096, 512), model="spherical", params=[1.0, 0.2, 0.01]),
+}
+
+
+def synth(seed, n, ndim):
+    rng = np.random.default_rng(seed)
+    c = [rng.random(n) for _ in range(ndim)]
+    v = np.sin(6 * c[0]) * np.cos(4 * c[1])
+    if ndim == 3:
+        v = v * np.cos(3 * c[2])
+    return c, v + 0.1 * rng.standard_normal(n)
+
+
+def internal_params(model, p):
+    return [p[0] - p[2], p[1], p[2]] if model in ("gaussian", "spherical", "exponential", "hole-effect") else list(p)
+
+
+def shard_points(cfg, rank, world):
+    """This rank's slab of the (weak-scaled) grid, flattened in the reference's meshgrid order."""
+    g = cfg["grid"]
+    if cfg["ndim"] == 2:
+        nx, ny = g
+        gx = np.linspace(0.0, 1.0, nx)
+        gy_all = np.linspace(0.0, 1.0, ny * world)
+        gy = gy_all[rank * ny:(rank + 1) * ny]
+        X, Y = np.meshgrid(gx, gy)
+        return [X.ravel(), Y.ravel()]
+    nx, ny, nz = g
+    gx, gy = np.linspace(0.0, 1.0, nx), np.linspace(0.0, 1.0, ny)
+    gz_all = np.linspace(0.0, 1.0, nz * world)
+    gz = gz_all[rank * nz:(rank + 1) * nz]
+    Z, Y, X = np.meshgrid(gz, gy, gx, indexing="ij")
+    return [X.ravel(), Y.ravel(), Z.ravel()]
+
+
+def cpu_baseline(cfg, coords, values, sample_pts):
+    """The reference's own backend='C' native loop (oracle/_ref, compiled from /root/reference's
+    lib/cok.pyx) -- or, if that build is absent, the numpy oracle -- on a bounded sample of the workload."""
+    from oracle import kriging_oracle as ko
+    from oracle import ref_c_loop as rc
+
+    ndim = cfg["ndim"]
+    st = ko.KrigingState(ndim=ndim, coords_orig=np.stack(coords, 1), values=values, model=cfg["model"],
+                         params=internal_params(cfg["model"], cfg["params"]), scaling=[1.0] * (ndim - 1),
+                         angle=[0.0] * (2 * ndim - 3), regional_linear=bool(cfg.get("rl")),
+                         point_log=np.array(cfg["wells"]) if cfg.get("wells") else None)
+    rng = np.random.default_rng(99)
+    pts = rng.random((sample_pts, ndim))
+    try:
+        import threadpoolctl
+
+        cores = max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] or [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    use_c = rc.available() and ndim == 2 and not cfg.get("rl") and cfg["model"] != "hole-effect"
+    t0 = time.perf_counter()
+    if use_c:
+        z, ss, _ = rc.c_backend(st, pts)
+        kind = "reference"
+        what = "PyKrige lib/cok.pyx _c_exec_loop (backend='C') incl. its scipy.linalg.inv"
+    else:
+        z, ss = ko.solve_points(st, pts)
+        kind = "port"
+        what = "numpy/scipy restatement of backend='vectorized' (oracle/kriging_oracle.py)"
+    dt = time.perf_counter() - t0
+    return dict(value=sample_pts / dt, unit="grid-points/s", cores=int(cores), kind=kind,
+                sample="%d random points of the same workload, %s, matrix assembly + inverse + loop = %.1f s "
+                       "(fixed costs included, so the full-grid rate would be somewhat higher)" % (sample_pts, what, dt),
+                host_cpus=os.cpu_count()), (pts, z, ss)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-sample", type=int, default=8192)
+    ap.add_argument("--symmetric", type=int, default=None)
+    ap.add_argument("--chunk", type=int, default=None)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)  # host-side rendezvous/barrier only
+        torch.cuda.set_device(local_rank)
+
+    from pykrige_amd import _lib  # raises if libmikrige.so is missing: no CPU fallback
+
+    cfg = CONFIGS[args.config]
+    ndim = cfg["ndim"]
+    coords, values = synth(cfg["seed"], cfg["n"], ndim)
+    pts = shard_points(cfg, rank, world)
+    npt = pts[0].size
+
+    h = _lib.Handle(local_rank)
+    if args.symmetric is not None:
+        h.set_option("symmetric", args.symmetric)
+    if args.chunk is not None:
+        h.set_option("chunk", args.chunk)
+    wells = np.array(cfg["wells"]) if cfg.get("wells") else None
+    h.set_problem(ndim=ndim, xs=coords[0], ys=coords[1], zs=coords[2] if ndim == 3 else None, values=values,
+                  model_id=_lib.MODEL_IDS[cfg["model"]], params=internal_params(cfg["model"], cfg["params"]),
+                  regional_linear=bool(cfg.get("rl")), wells=wells)
+    h.set_points(pts[0], pts[1], pts[2] if ndim == 3 else None)
+
+    exchange = "none"
+    if world > 1:
+        exchange = "rccl_bcast"
+        if os.environ.get("MIK_BENCH_BCAST", "1") == "0":
+            exchange = "redundant_factor"
+        else:
+            try:
+                uid = [_lib.Handle.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(uid, src=0)
+                h.comm_init(world, rank, uid[0])
+            except Exception as e:  # RCCL unavailable: every rank factors for itself
+                exchange = "redundant_factor (rccl init failed: %s)" % (str(e)[:80],)
+            flags = [None] * world
+            dist.all_gather_object(flags, exchange)
+            if any(f != "rccl_bcast" for f in flags):
+                exchange = next(f for f in flags if f != "rccl_bcast")
+
+    def sync():
+        if dist is not None:
+            import torch
+
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    tsum = dict(assemble_ms=0.0, invert_ms=0.0, rhs_ms=0.0, contract_ms=0.0, predict_ms=0.0, contract_launches=0,
+                contract_flops_executed=0.0)
+
+    def step(record):
+        if exchange == "rccl_bcast":
+            if rank == 0:
+                h.factor()
+            h.bcast_factor(0)
+        else:
+            h.factor()
+        if record and (rank == 0 or exchange != "rccl_bcast"):
+            t = h.timing()
+            tsum["assemble_ms"] += t["assemble_ms"]
+            tsum["invert_ms"] += t["invert_ms"]
+        h.predict()  # blocking: returns after the stream has drained
+        if record:
+            t = h.timing()
+            for k in ("rhs_ms", "contract_ms", "predict_ms", "contract_launches", "contract_flops_executed"):
+                tsum[k] += t[k]
+            tsum["factor_path"], tsum["symmetric"] = t["factor_path"], t["symmetric"]
+
+    for _ in range(args.warmup):
+        step(False)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        K = args.steps
+        M = cfg["n"] + (ndim if cfg.get("rl") else 0) + (len(cfg["wells"]) if cfg.get("wells") else 0) + 1
+        total_pts = npt * world
+        value = total_pts * K / dt
+        launches = max(1, int(tsum["contract_launches"]))
+        avg_launch_s = tsum["contract_ms"] * 1e-3 / launches
+        pts_per_launch = npt * K / launches
+        algo_flops_per_launch = 2.0 * M * M * pts_per_launch  # 2 M^2 per point for w = A_inv . b
+        achieved = algo_flops_per_launch / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0
+        executed = tsum["contract_flops_executed"] / (tsum["contract_ms"] * 1e-3) / 1e12 if tsum["contract_ms"] > 0 else 0.0
+        out = {
+            "metric": "kriged grid-points/sec (z + sigma^2), OK2D N=5000 on 1000x1000 grid" if args.config == 2
+            else "kriged grid-points/sec (z + sigma^2), " + cfg["name"],
+            "value": value, "unit": "grid-points/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": cfg["name"], "stations": cfg["n"], "matrix_order": M,
+                       "grid_points_per_gpu": npt, "grid_points_total": total_pts, "variogram": cfg["model"],
+                       "variogram_parameters": cfg["params"], "factor_exchange": exchange,
+                       "factor_path": {1: "spd-shift block sweep", 2: "pivoted block gauss-jordan", 3: "host inverse"}.get(
+                           tsum.get("factor_path"), "?"),
+                       "symmetric_contraction": bool(tsum.get("symmetric"))},
+            "roofline": {"bound": "mfma", "kernel": "k_contract", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "executed_tflops": executed, "avg_launch_ms": avg_launch_s * 1e3,
+                         "launches_per_step": launches / K, "algorithmic_flops_per_point": 2.0 * M * M},
+            "phases_ms_per_step": {"assemble": tsum["assemble_ms"] / K, "invert": tsum["invert_ms"] / K,
+                                   "rhs": tsum["rhs_ms"] / K, "contract": tsum["contract_ms"] / K,
+                                   "predict_total": tsum["predict_ms"] / K},
+        }
+        if world == 1 and not args.no_cpu:
+            try:
+                cb, (cp, cz, css) = cpu_baseline(cfg, coords, values, args.cpu_sample)
+                # parity of the GPU path on the very points the CPU baseline kriged
+                h.set_points(*[cp[:, d] for d in range(ndim)])
+                h.predict()
+                gz, gss = h.get_results()
+                cb["gpu_vs_cpu_max_abs_dz"] = float(np.abs(gz - cz).max())
+                cb["gpu_vs_cpu_max_abs_dss"] = float(np.abs(gss - css).max())
+                out["cpu_baseline"] = cb
+            except Exception as e:  # the bench line must still come out
+                out["cpu_baseline"] = {"value": None, "unit": "grid-points/s", "cores": None, "kind": "port",
+                                       "sample": "failed: %r" % (e,)}
+        print(json.dumps(out))
+    h.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

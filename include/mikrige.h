@@ -1,0 +1,128 @@
+/* mikrige.h -- C ABI of libmikrige.so: the MI355X (gfx950) kriging execute() path.
+ *
+ * This is the drop-in boundary for the native half of PyKrige's execute() hot path.  What it
+ * replaces in the reference (paths relative to /root/reference/src/pykrige):
+ *
+ *   lib/cok.pyx:14-96    cpdef _c_exec_loop(a_all, bd_all, mask, n, pars)      -> mik_factor + mik_predict
+ *   lib/cok.pyx:196-203  check_b_vect (|bd| <= eps  ->  b = 0)                 -> inside mik_predict
+ *   lib/variogram_models.pyx:6-84  C variogram kernels selected by name        -> mik_problem.model_id
+ *   ok.py:626-648, uk.py:861-920, ok3d.py:603-622, uk3d.py:688-737
+ *                        _get_kriging_matrix (cdist + -gamma + border)         -> mik_factor (K1 assemble)
+ *   ok.py:663, uk.py:935, ok3d.py:637, uk3d.py:752, cok.pyx:53
+ *                        scipy.linalg.inv(a)                                    -> mik_factor (K2 invert)
+ *   ok.py:989, uk.py:1293, ok3d.py:899, uk3d.py:1122   cdist(points, data)      -> inside mik_predict
+ *   ok.py:650-683, uk.py:922-1009, ok3d.py:624-657, uk3d.py:739-811
+ *                        _exec_vector (b build, A_inv.b, z / sigma^2 sums)      -> mik_predict (K3)
+ *
+ * Differences from _c_exec_loop's signature, on purpose: the library takes COORDINATES, not the
+ * npt x N distance matrix `bd` (40 GB at N=5000 / 1000x1000; it never exists here), and the kriging
+ * matrix is assembled and inverted on the device instead of being passed in.
+ *
+ * Conventions: every pointer is a host pointer to C-contiguous float64 (int8 for the mask), borrowed
+ * for the duration of the call only.  Outputs are caller-allocated.  All calls are blocking.  A
+ * handle is bound to one HIP device and is not thread-safe; distinct handles are independent.
+ * Return value 0 = success; negative = error (mik_last_error() has the text for this thread).
+ */
+#ifndef MIKRIGE_H
+#define MIKRIGE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIK_OK          0
+#define MIK_EINVAL     (-1) /* bad argument            -> Python ValueError                  */
+#define MIK_ESINGULAR  (-2) /* singular kriging matrix -> numpy.linalg.LinAlgError (what scipy.linalg.inv raises) */
+#define MIK_EHIP       (-3) /* HIP runtime failure     -> RuntimeError                       */
+#define MIK_ERCCL      (-4) /* RCCL failure            -> RuntimeError                       */
+#define MIK_ESTATE     (-5) /* call order violated (e.g. predict before factor) -> RuntimeError */
+
+/* variogram_models.py:25-81 / lib/variogram_models.pyx:25-84 (hole-effect exists only in the .py) */
+#define MIK_MODEL_LINEAR      0 /* params = [slope, nugget]            */
+#define MIK_MODEL_POWER       1 /* params = [scale, exponent, nugget]  */
+#define MIK_MODEL_GAUSSIAN    2 /* params = [psill, range, nugget]     */
+#define MIK_MODEL_SPHERICAL   3
+#define MIK_MODEL_EXPONENTIAL 4
+#define MIK_MODEL_HOLE_EFFECT 5
+
+typedef struct mik_handle mik_handle;
+
+/* What a constructed kriging object carries into execute() (the `pars` dict of ok.py:916-927 plus
+ * the adjusted station coordinates and the drift description of uk.py:861-920). */
+typedef struct mik_problem {
+  int32_t ndim;             /* 2 or 3 */
+  int32_t model_id;         /* MIK_MODEL_* */
+  int64_t n;                /* number of stations */
+  const double *xs, *ys, *zs; /* anisotropy-ADJUSTED station coordinates (X_ADJUSTED...), zs NULL if ndim==2 */
+  const double *values;     /* self.Z / self.VALUES, length n */
+  double params[3];         /* variogram_model_parameters (internal form: psill, not sill) */
+  double eps;               /* self.eps (1e-10) */
+  int32_t exact_values;     /* self.exact_values */
+  int32_t regional_linear;  /* UK: drift columns x, y[, z] (uk.py:877-883, uk3d.py:708-717) */
+  int32_t n_wells;          /* UK 2D point_log wells (uk.py:884-896) */
+  int32_t n_extra;          /* host-evaluated drift terms: external_Z, specified, functional (in that order) */
+  const double *wells;      /* n_wells x 3 row-major: adjusted x, adjusted y, strength */
+  const double *extra_cols; /* n_extra x n row-major: those drift terms evaluated at the stations */
+  const double *a_inv;      /* optional (M x M, M = n + ndrift + 1): inverse supplied by the host
+                               (pseudo_inv=True: P_INV[type](a), core.py:33); NULL = invert on device */
+} mik_problem;
+
+/* The prediction points handed to _exec_vector: adjusted coordinates (SoA), mask, drift rows. */
+typedef struct mik_points {
+  int64_t npt;
+  const double *px, *py, *pz; /* anisotropy-ADJUSTED point coordinates; pz NULL if ndim==2 */
+  const int8_t *mask;         /* nullable; nonzero = skip the point (outputs stay 0.0, cok.pyx:25-26,57-58) */
+  const double *extra_rows;   /* n_extra x npt row-major: host-evaluated drift terms at the points; nullable if n_extra==0 */
+} mik_points;
+
+/* Per-phase device times of the last mik_factor / mik_predict (HIP events on the handle's stream). */
+typedef struct mik_timing {
+  double assemble_ms;     /* K1: kriging-matrix assembly */
+  double invert_ms;       /* K2: block inverse (all launches) */
+  double rhs_ms;          /* K3a: RHS/variogram assembly launches, summed */
+  double contract_ms;     /* K3b: the dense contraction kernel (dominant), summed over launches */
+  double predict_ms;      /* whole mik_predict on the stream */
+  int64_t contract_launches;
+  double contract_flops_executed; /* flops the contraction kernel really executed (symmetric form: ~M^2/pt) */
+  int32_t factor_path;    /* 1 = unpivoted symmetric block sweep on the SPD-shifted matrix, 2 = pivoted block Gauss-Jordan, 3 = host-supplied inverse */
+  int32_t symmetric;      /* 1 = contraction used the symmetric half product */
+} mik_timing;
+
+int  mik_device_count(void);
+int  mik_create(int device, mik_handle **out);
+void mik_destroy(mik_handle *h);
+
+/* options: "factor" 0=auto 1=sweep 2=pivoted ; "symmetric" 0/1 (contraction uses A_inv symmetry) ;
+ * "chunk" = points per contraction launch (multiple of 128) */
+int  mik_set_option(mik_handle *h, const char *key, double value);
+
+int  mik_set_problem(mik_handle *h, const mik_problem *p); /* H2D of stations/values/drifts            */
+int  mik_factor(mik_handle *h);                            /* K1 + K2 (+ c = A_inv[:, :n].Z) on device   */
+int  mik_set_points(mik_handle *h, const mik_points *g);   /* H2D of the (unmasked) points              */
+int  mik_predict(mik_handle *h);                           /* K3 over the resident points; results stay in HBM */
+int  mik_get_results(mik_handle *h, double *z_out, double *ss_out); /* D2H, scattered through the mask  */
+
+/* One-shot convenience: create + set_problem + factor + set_points + predict + get_results + destroy. */
+int  mik_krige_execute(int device, const mik_problem *p, const mik_points *g, double *z_out, double *ss_out);
+
+/* Test/diagnostic access: which = 0 -> kriging matrix A as assembled (only valid right after
+ * mik_assemble_only), 1 -> A_inv after mik_factor.  out is M x M row-major. */
+int  mik_assemble_only(mik_handle *h);
+int  mik_get_matrix(mik_handle *h, int which, double *out);
+int64_t mik_matrix_order(mik_handle *h); /* M = n + ndrift + 1 */
+int  mik_get_timing(mik_handle *h, mik_timing *out);
+int  mik_selftest_mfma(int device); /* 0 if v_mfma_f64_16x16x4_f64 fragment layout is what the kernels assume */
+
+/* Multi-GPU (one process per GPU): grid points are sharded by the caller; the factored matrix is
+ * broadcast from `root` over RCCL/xGMI.  The 128-byte id is an ncclUniqueId made on rank 0 and
+ * carried to the other ranks by the host launcher. */
+int  mik_comm_unique_id(char id_out[128]);
+int  mik_comm_init(mik_handle *h, int nranks, int rank, const char id[128]);
+int  mik_bcast_factor(mik_handle *h, int root); /* ranks != root need mik_set_problem first, not mik_factor */
+
+const char *mik_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

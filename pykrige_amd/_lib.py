@@ -1,0 +1,236 @@
+"""ctypes binding of libmikrige.so (include/mikrige.h).  NumPy + ctypes only -- no torch.
+
+There is deliberately no CPU fallback here: if the HIP library is missing or no GPU is visible the
+calls raise.  (oracle/ is test infrastructure and is never imported from this package.)
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmikrige.so")
+
+MIK_OK, MIK_EINVAL, MIK_ESINGULAR, MIK_EHIP, MIK_ERCCL, MIK_ESTATE = 0, -1, -2, -3, -4, -5
+MODEL_IDS = {"linear": 0, "power": 1, "gaussian": 2, "spherical": 3, "exponential": 4, "hole-effect": 5}
+
+_dp = C.POINTER(C.c_double)
+
+
+class MikProblem(C.Structure):
+    _fields_ = [
+        ("ndim", C.c_int32), ("model_id", C.c_int32), ("n", C.c_int64),
+        ("xs", _dp), ("ys", _dp), ("zs", _dp), ("values", _dp),
+        ("params", C.c_double * 3), ("eps", C.c_double),
+        ("exact_values", C.c_int32), ("regional_linear", C.c_int32), ("n_wells", C.c_int32), ("n_extra", C.c_int32),
+        ("wells", _dp), ("extra_cols", _dp), ("a_inv", _dp),
+    ]
+
+
+class MikPoints(C.Structure):
+    _fields_ = [
+        ("npt", C.c_int64), ("px", _dp), ("py", _dp), ("pz", _dp),
+        ("mask", C.POINTER(C.c_int8)), ("extra_rows", _dp),
+    ]
+
+
+class MikTiming(C.Structure):
+    _fields_ = [
+        ("assemble_ms", C.c_double), ("invert_ms", C.c_double), ("rhs_ms", C.c_double),
+        ("contract_ms", C.c_double), ("predict_ms", C.c_double), ("contract_launches", C.c_int64),
+        ("contract_flops_executed", C.c_double), ("factor_path", C.c_int32), ("symmetric", C.c_int32),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+_lib = None
+
+# every entry point include/mikrige.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "mik_device_count": (C.c_int, []),
+    "mik_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "mik_destroy": (None, [C.c_void_p]),
+    "mik_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double]),
+    "mik_set_problem": (C.c_int, [C.c_void_p, C.POINTER(MikProblem)]),
+    "mik_factor": (C.c_int, [C.c_void_p]),
+    "mik_set_points": (C.c_int, [C.c_void_p, C.POINTER(MikPoints)]),
+    "mik_predict": (C.c_int, [C.c_void_p]),
+    "mik_get_results": (C.c_int, [C.c_void_p, _dp, _dp]),
+    "mik_krige_execute": (C.c_int, [C.c_int, C.POINTER(MikProblem), C.POINTER(MikPoints), _dp, _dp]),
+    "mik_assemble_only": (C.c_int, [C.c_void_p]),
+    "mik_get_matrix": (C.c_int, [C.c_void_p, C.c_int, _dp]),
+    "mik_matrix_order": (C.c_int64, [C.c_void_p]),
+    "mik_get_timing": (C.c_int, [C.c_void_p, C.POINTER(MikTiming)]),
+    "mik_selftest_mfma": (C.c_int, [C.c_int]),
+    "mik_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "mik_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_char_p]),
+    "mik_bcast_factor": (C.c_int, [C.c_void_p, C.c_int]),
+    "mik_last_error": (C.c_char_p, []),
+}
+
+
+def load():
+    """dlopen the library and declare the signatures.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "pykrige_amd: %s is missing -- build it with `python -m pykrige_amd.build` "
+            "(needs hipcc; there is no CPU fallback)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return (load().mik_last_error() or b"").decode("utf-8", "replace")
+
+
+def check(rc):
+    if rc == MIK_OK:
+        return
+    msg = last_error()
+    if rc == MIK_EINVAL:
+        raise ValueError(msg)
+    if rc == MIK_ESINGULAR:
+        raise np.linalg.LinAlgError(msg or "singular matrix")
+    raise RuntimeError("libmikrige: %s (code %d)" % (msg, rc))
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_dp) if a is not None else None
+
+
+class Handle:
+    """A device context of the library: one HIP device, one stream, cached device buffers."""
+
+    def __init__(self, device=None):
+        lib = load()
+        if device is None:
+            device = int(os.environ.get("MIK_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+            if lib.mik_device_count() == 1:
+                device = 0
+        self._lib = lib
+        self._h = C.c_void_p()
+        check(lib.mik_create(int(device), C.byref(self._h)))
+        self.device = int(device)
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.mik_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, key, value):
+        check(self._lib.mik_set_option(self._h, key.encode(), float(value)))
+
+    def set_problem(self, ndim, xs, ys, zs, values, model_id, params, eps=1e-10, exact_values=True,
+                    regional_linear=False, wells=None, extra_cols=None, a_inv=None):
+        p = MikProblem()
+        xs, ys, values = _f64(xs), _f64(ys), _f64(values)
+        zs = _f64(zs) if zs is not None else None
+        wells = _f64(wells).reshape(-1, 3) if wells is not None and np.size(wells) else None
+        extra_cols = _f64(extra_cols).reshape(-1, xs.size) if extra_cols is not None and np.size(extra_cols) else None
+        a_inv = _f64(a_inv) if a_inv is not None else None
+        if not (xs.size == ys.size == values.size) or (zs is not None and zs.size != xs.size):
+            raise ValueError("station arrays must have the same length")
+        p.ndim, p.model_id, p.n = int(ndim), int(model_id), xs.size
+        p.xs, p.ys, p.zs, p.values = _ptr(xs), _ptr(ys), _ptr(zs), _ptr(values)
+        pr = list(params) + [0.0] * (3 - len(params))
+        if int(model_id) == 0:  # linear [slope, nugget]
+            pr = [params[0], params[1], 0.0]
+        p.params = (C.c_double * 3)(*[float(v) for v in pr])
+        p.eps, p.exact_values, p.regional_linear = float(eps), int(bool(exact_values)), int(bool(regional_linear))
+        p.n_wells = 0 if wells is None else wells.shape[0]
+        p.n_extra = 0 if extra_cols is None else extra_cols.shape[0]
+        p.wells, p.extra_cols, p.a_inv = _ptr(wells), _ptr(extra_cols), _ptr(a_inv)
+        self._keep = [xs, ys, zs, values, wells, extra_cols, a_inv]
+        check(self._lib.mik_set_problem(self._h, C.byref(p)))
+        self._keep = []
+
+    def assemble_only(self):
+        check(self._lib.mik_assemble_only(self._h))
+
+    def factor(self):
+        check(self._lib.mik_factor(self._h))
+
+    @property
+    def order(self):
+        return int(self._lib.mik_matrix_order(self._h))
+
+    def get_matrix(self, which):
+        m = self.order
+        out = np.empty((m, m), dtype=np.float64)
+        check(self._lib.mik_get_matrix(self._h, int(which), _ptr(out)))
+        return out
+
+    def set_points(self, px, py, pz=None, mask=None, extra_rows=None):
+        g = MikPoints()
+        px, py = _f64(px), _f64(py)
+        pz = _f64(pz) if pz is not None else None
+        if px.size != py.size or (pz is not None and pz.size != px.size):
+            raise ValueError("point arrays must have the same length")
+        m8 = None
+        if mask is not None:
+            m8 = np.ascontiguousarray(np.asarray(mask).astype(np.int8).ravel())
+            if m8.size != px.size:
+                raise ValueError("mask length must equal the number of points")
+        er = None
+        if extra_rows is not None and np.size(extra_rows):
+            er = _f64(extra_rows).reshape(-1, px.size)
+        g.npt = px.size
+        g.px, g.py, g.pz = _ptr(px), _ptr(py), _ptr(pz)
+        g.mask = m8.ctypes.data_as(C.POINTER(C.c_int8)) if m8 is not None else None
+        g.extra_rows = _ptr(er)
+        self._npt = px.size
+        check(self._lib.mik_set_points(self._h, C.byref(g)))
+
+    def predict(self):
+        check(self._lib.mik_predict(self._h))
+
+    def get_results(self):
+        z = np.empty(self._npt, dtype=np.float64)
+        ss = np.empty(self._npt, dtype=np.float64)
+        check(self._lib.mik_get_results(self._h, _ptr(z), _ptr(ss)))
+        return z, ss
+
+    def timing(self):
+        t = MikTiming()
+        check(self._lib.mik_get_timing(self._h, C.byref(t)))
+        return t.as_dict()
+
+    # --- multi-GPU -------------------------------------------------------------------------
+    @staticmethod
+    def comm_unique_id():
+        buf = C.create_string_buffer(128)
+        check(load().mik_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, nranks, rank, uid):
+        if len(uid) != 128:
+            raise ValueError("unique id must be 128 bytes")
+        check(self._lib.mik_comm_init(self._h, int(nranks), int(rank), C.create_string_buffer(uid, 128)))
+
+    def bcast_factor(self, root=0):
+        check(self._lib.mik_bcast_factor(self._h, int(root)))
+
+
+def selftest_mfma(device=0):
+    check(load().mik_selftest_mfma(int(device)))

@@ -1,0 +1,121 @@
+"""Host-side helpers of the execute() path (NumPy only): the anisotropy transform applied to every
+grid point, variogram-parameter normalisation, and the bilinear external-Z lookup.
+
+Restated from the reference's behaviour (paths under /root/reference/src/pykrige):
+  core.py:120-193   _adjust_for_anisotropy  (same NumPy calls in the same order, so the adjusted
+                    coordinates -- and with them the |d| <= eps coincidence test -- are bit-identical)
+  core.py:196-376   _make_variogram_parameter_list
+  uk.py:512-628     _calculate_data_point_zscalars
+"""
+import numpy as np
+
+BOUNDED = ("gaussian", "spherical", "exponential", "hole-effect")
+MODELS = ("linear", "power") + BOUNDED
+
+
+def adjust_for_anisotropy(X, center, scaling, angle):
+    """(n, d) coordinates -> anisotropy-adjusted coordinates; d in {2, 3}.  X is not modified."""
+    X = np.array(X, dtype=np.float64, copy=True)
+    if X.ndim != 2 or X.shape[1] not in (2, 3):
+        raise ValueError("coordinates must be (n, 2) or (n, 3)")
+    ctr = np.asarray(center, dtype=np.float64)[None, :]
+    ang = np.asarray(angle, dtype=np.float64) * np.pi / 180
+    X -= ctr
+    if X.shape[1] == 2:
+        stretch = np.array([[1, 0], [0, scaling[0]]])
+        c, s = np.cos(-ang[0]), np.sin(-ang[0])
+        rot = np.array([[c, -s], [s, c]])
+    else:
+        stretch = np.array([[1.0, 0.0, 0.0], [0.0, scaling[0], 0.0], [0.0, 0.0, scaling[1]]])
+        cx, sx = np.cos(-ang[0]), np.sin(-ang[0])
+        cy, sy = np.cos(-ang[1]), np.sin(-ang[1])
+        cz, sz = np.cos(-ang[2]), np.sin(-ang[2])
+        rot_x = np.array([[1.0, 0.0, 0.0], [0.0, cx, -sx], [0.0, sx, cx]])
+        rot_y = np.array([[cy, 0.0, sy], [0.0, 1.0, 0.0], [-sy, 0.0, cy]])
+        rot_z = np.array([[cz, -sz, 0.0], [sz, cz, 0.0], [0.0, 0.0, 1.0]])
+        rot = np.dot(rot_z, np.dot(rot_y, rot_x))
+    out = np.dot(stretch, np.dot(rot, X.T)).T
+    out += ctr
+    return out
+
+
+def make_variogram_parameter_list(model, params):
+    """User parameters (list or dict) -> internal list; None stays None (= 'fit it')."""
+    if params is None:
+        return None
+    if model not in MODELS:
+        raise ValueError("Specified variogram model must be one of the following: " + ", ".join(repr(m) for m in MODELS))
+    if type(params) is dict:
+        need = {"linear": ("slope", "nugget"), "power": ("scale", "exponent", "nugget")}.get(model, ("range", "nugget"))
+        missing = [k for k in need if k not in params]
+        if missing:
+            raise KeyError("'%s' variogram model requires %s in the variogram parameter dictionary" % (model, need))
+        if model == "linear":
+            return [params["slope"], params["nugget"]]
+        if model == "power":
+            return [params["scale"], params["exponent"], params["nugget"]]
+        if "sill" in params:
+            return [params["sill"] - params["nugget"], params["range"], params["nugget"]]
+        if "psill" in params:
+            return [params["psill"], params["range"], params["nugget"]]
+        raise KeyError("'%s' variogram model requires either 'sill' or 'psill'" % model)
+    if type(params) is list:
+        want = 2 if model == "linear" else 3
+        if len(params) != want:
+            raise ValueError("Variogram model parameter list must have exactly %d entries for '%s'" % (want, model))
+        if model in BOUNDED:  # the list form carries the FULL sill
+            return [params[0] - params[2], params[1], params[2]]
+        return list(params)
+    raise TypeError("Variogram model parameters must be provided in either a list or a dict")
+
+
+def variogram_value(model, m, d):
+    """Variogram models on the host (variogram_models.py:25-81) -- used only by the constructor-time
+    fit, never by execute()."""
+    d = np.asarray(d, dtype=np.float64)
+    if model == "linear":
+        return float(m[0]) * d + float(m[1])
+    if model == "power":
+        return float(m[0]) * d ** float(m[1]) + float(m[2])
+    psill, rng, nug = float(m[0]), float(m[1]), float(m[2])
+    if model == "gaussian":
+        return psill * (1.0 - np.exp(-(d**2.0) / (rng * 4.0 / 7.0) ** 2.0)) + nug
+    if model == "exponential":
+        return psill * (1.0 - np.exp(-d / (rng / 3.0))) + nug
+    if model == "spherical":
+        return np.where(d <= rng, psill * ((3.0 * d) / (2.0 * rng) - (d**3.0) / (2.0 * rng**3.0)) + nug, psill + nug)
+    if model == "hole-effect":
+        return psill * (1.0 - (1.0 - d / (rng / 3.0)) * np.exp(-d / (rng / 3.0))) + nug
+    raise ValueError("unknown variogram model %r" % (model,))
+
+
+def bilinear_zscalars(zgrid, gx, gy, x, y):
+    """external_Z drift: bilinear interpolation of zgrid (ny, nx) on axes gx, gy at ORIGINAL (unadjusted)
+    coordinates x, y (any shape).  Raises ValueError outside the grid, like the reference."""
+    gx = np.asarray(gx, dtype=np.float64).ravel()
+    gy = np.asarray(gy, dtype=np.float64).ravel()
+    zgrid = np.asarray(zgrid, dtype=np.float64)
+    x = np.asarray(x, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64)
+    if x.size and (x.max() > gx.max() or x.min() < gx.min() or y.max() > gy.max() or y.min() < gy.min()):
+        raise ValueError("External drift array does not cover specified kriging domain.")
+    # the reference takes min{i: g_i >= v} and max{i: g_i <= v}; axes may be in any order, so sort once
+    ox, oy = np.argsort(gx, kind="stable"), np.argsort(gy, kind="stable")
+    sx, sy = gx[ox], gy[oy]
+    xf, yf = x.ravel(), y.ravel()
+    ix2 = np.searchsorted(sx, xf, side="left")
+    ix1 = np.searchsorted(sx, xf, side="right") - 1
+    iy2 = np.searchsorted(sy, yf, side="left")
+    iy1 = np.searchsorted(sy, yf, side="right") - 1
+    x1, x2, y1, y2 = sx[ix1], sx[ix2], sy[iy1], sy[iy2]
+    jx1, jx2, jy1, jy2 = ox[ix1], ox[ix2], oy[iy1], oy[iy2]
+    z11, z12 = zgrid[jy1, jx1], zgrid[jy1, jx2]
+    z21, z22 = zgrid[jy2, jx1], zgrid[jy2, jx2]
+    same_x, same_y = ix1 == ix2, iy1 == iy2
+    with np.errstate(divide="ignore", invalid="ignore"):
+        both = (z11 * (x2 - xf) * (y2 - yf) + z12 * (xf - x1) * (y2 - yf) + z21 * (x2 - xf) * (yf - y1)
+                + z22 * (xf - x1) * (yf - y1)) / ((x2 - x1) * (y2 - y1))
+        only_x = (z11 * (x2 - xf) + z22 * (xf - x1)) / (x2 - x1)   # same y row (reference uses [y2,x2] == [y1,x2])
+        only_y = (z11 * (y2 - yf) + z22 * (yf - y1)) / (y2 - y1)
+    out = np.where(same_y, np.where(same_x, z11, only_x), np.where(same_x, only_y, both))
+    return out.reshape(x.shape)

@@ -1,0 +1,760 @@
+// mik_kernels.h -- gfx950 (CDNA4) device code of the kriging execute() path.  fp64 throughout.
+//
+//   K1  k_assemble   kriging matrix A (or its SPD-shifted form) from station coordinates
+//   K2  k_diag_inv + k_gemm_nt<PANEL/UPDATE>   block Gauss-Jordan ("sweep") inverse, MFMA f64
+//   K3a k_rhs        right-hand sides b_g for a chunk of points (+ z_g = c.b_g), written point-major
+//   K3b k_gemm_nt<PREDICT>   sigma^2_g = -b_g^T A_inv b_g as a dense contraction on v_mfma_f64_16x16x4_f64
+//
+// Reference arithmetic restated (paths under /root/reference/src/pykrige): variogram_models.py:25-81,
+// ok.py:626-683, uk.py:861-1009, ok3d.py:603-657, uk3d.py:688-811, lib/cok.pyx:56-94.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+namespace mik {
+
+// ------------------------------------------------------------------------------------------------
+// variogram functors (variogram_models.py:25-81).  c0 is a host-precomputed constant with the
+// reference's own operation order: gaussian (range*4/7)^2, exponential / hole-effect range/3.
+// ------------------------------------------------------------------------------------------------
+struct Vario {
+  int model;
+  double p0, p1, p2;
+  double c0;
+};
+
+template <int MODEL>
+__device__ __forceinline__ double vario(const Vario& v, double d) {
+  if (MODEL == 0) return v.p0 * d + v.p1;                               // linear   :25-29
+  if (MODEL == 1) return v.p0 * pow(d, v.p1) + v.p2;                    // power    :32-37
+  if (MODEL == 2) return v.p0 * (1.0 - exp(-(d * d) / v.c0)) + v.p2;    // gaussian :40-45
+  if (MODEL == 3) {                                                     // spherical:56-70 (d <= range)
+    const double r = v.p1;
+    if (d <= r) return v.p0 * ((3.0 * d) / (2.0 * r) - (d * d * d) / (2.0 * (r * r * r))) + v.p2;
+    return v.p0 + v.p2;
+  }
+  if (MODEL == 4) return v.p0 * (1.0 - exp(-d / v.c0)) + v.p2;          // exponential :48-53
+  {                                                                     // hole-effect :73-81
+    const double q = d / v.c0;
+    return v.p0 * (1.0 - (1.0 - q) * exp(-q)) + v.p2;
+  }
+}
+
+// point_log drift value incl. the -inf -> -100 rule (uk.py:885-896, 957-966)
+__device__ __forceinline__ double well_drift(double x, double y, const double* __restrict__ w) {
+  const double dx = x - w[0], dy = y - w[1];
+  double ld = log(sqrt(dx * dx + dy * dy));
+  if (isinf(ld)) ld = -100.0;
+  return -w[2] * ld;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: kriging matrix.  T is Mp x Mp (Mp = M rounded up to 128), row-major, ld = Mp.
+//   [i<N, j<N]   -gamma(|X_i - X_j|) + shift, diagonal = 0 + shift   (ok.py:630-644)
+//   [i<N, N+c]   drift c at station i, symmetric                     (uk.py:876-910)
+//   [i<N, M-1]   1 ; lower-right (p+1)x(p+1) block 0                  (ok.py:645-647, uk.py:915-918)
+//   padding      identity (keeps the padded matrix invertible; its inverse is [[A^-1,0],[0,I]])
+// shift = 0 gives the reference matrix itself; shift = s > 0 gives A + s.u.u^T with u = [1_N;0],
+// whose inverse is A^-1 - s.e_last.e_last^T (A.e_last = u), used by the unpivoted sweep.
+// One 64x64 tile per 256-thread block; the tile's row-station coordinates are staged in LDS.
+// ------------------------------------------------------------------------------------------------
+struct AsmArgs {
+  double* T;
+  long ld;
+  int N, p, M, Mp, ndim;
+  const double *xs, *ys, *zs;
+  Vario v;
+  double shift;
+  int rl, nwells, nextra;
+  const double* wells;  // nwells x 3
+  const double* extra;  // nextra x N
+};
+
+__device__ __forceinline__ double station_drift(const AsmArgs& a, int c, int s) {
+  if (a.rl) {
+    if (c < a.ndim) return c == 0 ? a.xs[s] : (c == 1 ? a.ys[s] : a.zs[s]);
+    c -= a.ndim;
+  }
+  if (c < a.nwells) return well_drift(a.xs[s], a.ys[s], a.wells + 3 * c);
+  c -= a.nwells;
+  return a.extra[(long)c * a.N + s];
+}
+
+template <int MODEL, int NDIM>
+__global__ void __launch_bounds__(256) k_assemble(AsmArgs a) {
+  __shared__ double sx[64], sy[64], sz[64];
+  const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int i0 = blockIdx.y * 64;
+  if (threadIdx.x < 64) {
+    const int i = i0 + threadIdx.x;
+    const bool st = i < a.N;
+    sx[threadIdx.x] = st ? a.xs[i] : 0.0;
+    sy[threadIdx.x] = st ? a.ys[i] : 0.0;
+    sz[threadIdx.x] = (st && NDIM == 3) ? a.zs[i] : 0.0;
+  }
+  __syncthreads();
+  double xj = 0.0, yj = 0.0, zj = 0.0;
+  if (j < a.N) {
+    xj = a.xs[j];
+    yj = a.ys[j];
+    if (NDIM == 3) zj = a.zs[j];
+  }
+  for (int r = threadIdx.x >> 6; r < 64; r += 4) {
+    const int i = i0 + r;
+    double val;
+    if (i >= a.M || j >= a.M) {
+      val = (i == j) ? 1.0 : 0.0;
+    } else if (i < a.N && j < a.N) {
+      if (i == j) {
+        val = a.shift;  // np.fill_diagonal(a, 0.0)
+      } else {
+        const double dx = sx[r] - xj, dy = sy[r] - yj;
+        double s2;
+        if (NDIM == 3) {
+          const double dz = sz[r] - zj;
+          s2 = dx * dx + dy * dy + dz * dz;
+        } else {
+          s2 = dx * dx + dy * dy;
+        }
+        val = a.shift - vario<MODEL>(a.v, sqrt(s2));
+      }
+    } else if (i >= a.N && j >= a.N) {
+      val = 0.0;
+    } else {
+      const int s = i < j ? i : j;
+      const int c = (i < j ? j : i) - a.N;
+      val = (c == a.p) ? 1.0 : station_drift(a, c, s);
+    }
+    a.T[(long)i * a.ld + j] = val;
+  }
+}
+
+// T[idx][idx] += v (corner fix after the shifted inverse)
+__global__ void k_add_diag(double* T, long ld, int idx, double v) { T[(long)idx * ld + idx] += v; }
+
+// c_i = sum_{j<N} Ainv[i][j] * Z[j], one wave per row  (z_g = c.b_g; A_inv symmetric)
+__global__ void __launch_bounds__(256) k_cvec(const double* __restrict__ Ainv, long ld, int M, int N,
+                                              const double* __restrict__ Z, double* __restrict__ c, int Mp) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= Mp) return;
+  double s = 0.0;
+  if (row < M) {
+    const double* r = Ainv + (long)row * ld;
+    for (int j = lane; j < N; j += 64) s += r[j] * Z[j];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  }
+  if (lane == 0) c[row] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3a: right-hand sides for a chunk of points, written POINT-MAJOR: Bt[t][j], j contiguous, ld = Mp
+// (this is the reference's `b` array layout, ok.py:669, and the "NT" operand layout of k_gemm_nt).
+//   j <  N      : -gamma(|g_t - X_j|), 0 if |d| <= eps and exact_values  (ok.py:665-672, cok.pyx:196-203)
+//   N <= j < N+p: drift rows  (uk.py:949-979; uk3d.py:767-783)
+//   j == N+p    : 1           (ok.py:673)             j > N+p : 0 (padding)
+// Also z_t = sum_j c_j b_tj (ok.py:680 restated through c = A_inv[:, :n].Z).
+// One block = 8 points; threads stride over j so every store is a coalesced row segment.
+// ------------------------------------------------------------------------------------------------
+#define MIK_TP 8
+struct RhsArgs {
+  double* Bt;
+  long ld;
+  int palloc;  // rows of Bt to fill (multiple of 128)
+  int nvalid;  // points of this chunk that exist
+  const double *px, *py, *pz;  // chunk base pointers
+  int N, p, M, Mp, ndim;
+  const double *xs, *ys, *zs;
+  Vario v;
+  int exact;
+  double eps;
+  int rl, nwells, nextra;
+  const double* wells;
+  const double* extra;  // chunk base, row stride = extra_stride
+  long extra_stride;
+  const double* cvec;
+  double* zout;  // chunk base
+};
+
+template <int MODEL, int NDIM>
+__global__ void __launch_bounds__(256) k_rhs(RhsArgs a) {
+  __shared__ double red[4][MIK_TP];
+  const int t0 = blockIdx.x * MIK_TP;
+  double qx[MIK_TP], qy[MIK_TP], qz[MIK_TP];
+  bool ok[MIK_TP];
+#pragma unroll
+  for (int q = 0; q < MIK_TP; ++q) {
+    ok[q] = (t0 + q) < a.nvalid;
+    const int idx = ok[q] ? t0 + q : 0;
+    qx[q] = a.px[idx];
+    qy[q] = a.py[idx];
+    qz[q] = (NDIM == 3) ? a.pz[idx] : 0.0;
+  }
+  double zacc[MIK_TP];
+#pragma unroll
+  for (int q = 0; q < MIK_TP; ++q) zacc[q] = 0.0;
+
+  for (int j = threadIdx.x; j < a.Mp; j += 256) {
+    double val[MIK_TP];
+    if (j < a.N) {
+      const double sx = a.xs[j], sy = a.ys[j];
+      const double sz = (NDIM == 3) ? a.zs[j] : 0.0;
+#pragma unroll
+      for (int q = 0; q < MIK_TP; ++q) {
+        const double dx = qx[q] - sx, dy = qy[q] - sy;
+        double s2;
+        if (NDIM == 3) {
+          const double dz = qz[q] - sz;
+          s2 = dz * dz + dy * dy + dx * dx;
+        } else {
+          s2 = dx * dx + dy * dy;
+        }
+        const double d = sqrt(s2);
+        double g = -vario<MODEL>(a.v, d);
+        if (a.exact && fabs(d) <= a.eps) g = 0.0;
+        val[q] = g;
+      }
+    } else if (j < a.N + a.p) {
+      int c = j - a.N;
+      int kind = 2;  // 0 regional-linear, 1 well, 2 extra
+      if (a.rl) {
+        if (c < a.ndim) kind = 0; else c -= a.ndim;
+      }
+      if (kind == 2) {
+        if (c < a.nwells) kind = 1; else c -= a.nwells;
+      }
+#pragma unroll
+      for (int q = 0; q < MIK_TP; ++q) {
+        double dv;
+        if (kind == 0) dv = (c == 0) ? qx[q] : (c == 1 ? qy[q] : qz[q]);
+        else if (kind == 1) dv = well_drift(qx[q], qy[q], a.wells + 3 * c);
+        else dv = ok[q] ? a.extra[(long)c * a.extra_stride + t0 + q] : 0.0;
+        val[q] = dv;
+      }
+    } else {
+      const double one = (j == a.N + a.p) ? 1.0 : 0.0;
+#pragma unroll
+      for (int q = 0; q < MIK_TP; ++q) val[q] = one;
+    }
+    const double cj = (j < a.M) ? a.cvec[j] : 0.0;
+#pragma unroll
+    for (int q = 0; q < MIK_TP; ++q) {
+      const double v = ok[q] ? val[q] : 0.0;
+      a.Bt[(long)(t0 + q) * a.ld + j] = v;
+      zacc[q] += cj * v;
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int q = 0; q < MIK_TP; ++q) {
+    double s = zacc[q];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) red[wave][q] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < MIK_TP && (t0 + (int)threadIdx.x) < a.nvalid)
+    a.zout[t0 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// ------------------------------------------------------------------------------------------------
+// The fp64 MFMA "NT" GEMM core:  acc[i][t] += sum_k A[i][k] * B[t][k]   (both operands k-contiguous)
+// Block tile 128 x 128, 4 waves as 2 x 2, wave tile 64 x 64 = 4 x 4 fragments of
+// v_mfma_f64_16x16x4_f64 (A: lane l holds A[l&15][l>>4]; B: lane l holds B[l>>4][l&15];
+// C/D: 4 doubles per lane, col = l&15, row = (l>>4) + 4*reg -- cdna_hip_programming.md:247-251).
+// K is staged in tiles of 16 through double-buffered LDS (global -> registers -> LDS, one barrier per
+// tile).  LDS row stride 18 doubles: 16-byte aligned for ds_write_b128 and conflict-free for the
+// fragment ds_read_b64 (bank = (36*row + 2*k) mod 64 covers all 64 banks once per 32 lanes).
+// ------------------------------------------------------------------------------------------------
+#define MIK_BM 128
+#define MIK_BN 128
+#define MIK_BK 16
+#define MIK_LS 18
+
+struct GemmSmem {
+  double As[2][MIK_BM][MIK_LS];
+  double Bs[2][MIK_BN][MIK_LS];
+};
+
+__device__ __forceinline__ void gemm_core(const double* __restrict__ Ag, long lda, const double* __restrict__ Bg,
+                                          long ldb, int kbeg, int kend, d4 (&acc)[4][4], GemmSmem& sm) {
+  if (kbeg >= kend) return;  // block-uniform
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lrow = tid >> 3, lcol = (tid & 7) * 2;
+  const double* ap = Ag + (long)lrow * lda + lcol;
+  const double* bp = Bg + (long)lrow * ldb + lcol;
+  double2 ra[4], rb[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    ra[p] = *reinterpret_cast<const double2*>(ap + (long)(32 * p) * lda + kbeg);
+    rb[p] = *reinterpret_cast<const double2*>(bp + (long)(32 * p) * ldb + kbeg);
+  }
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    *reinterpret_cast<double2*>(&sm.As[0][lrow + 32 * p][lcol]) = ra[p];
+    *reinterpret_cast<double2*>(&sm.Bs[0][lrow + 32 * p][lcol]) = rb[p];
+  }
+  __syncthreads();
+  int buf = 0;
+  const int ar = wm * 64 + (lane & 15), br = wn * 64 + (lane & 15), kq = lane >> 4;
+  for (int k = kbeg; k < kend; k += MIK_BK) {
+    const bool more = (k + MIK_BK) < kend;
+    if (more) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        ra[p] = *reinterpret_cast<const double2*>(ap + (long)(32 * p) * lda + k + MIK_BK);
+        rb[p] = *reinterpret_cast<const double2*>(bp + (long)(32 * p) * ldb + k + MIK_BK);
+      }
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      double fa[4], fb[4];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        fa[x] = sm.As[buf][ar + 16 * x][kk * 4 + kq];
+        fb[x] = sm.Bs[buf][br + 16 * x][kk * 4 + kq];
+      }
+#pragma unroll
+      for (int ai = 0; ai < 4; ++ai)
+#pragma unroll
+        for (int bi = 0; bi < 4; ++bi)
+          acc[ai][bi] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[ai], fb[bi], acc[ai][bi], 0, 0, 0);
+    }
+    if (more) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        *reinterpret_cast<double2*>(&sm.As[buf ^ 1][lrow + 32 * p][lcol]) = ra[p];
+        *reinterpret_cast<double2*>(&sm.Bs[buf ^ 1][lrow + 32 * p][lcol]) = rb[p];
+      }
+    }
+    __syncthreads();
+    buf ^= 1;
+  }
+}
+
+// XCD-aware tile index: blocks b, b+8, b+16.. run on the same XCD (block b -> XCD b % 8), so give
+// each XCD a contiguous range of logical tiles; neighbours in that range share an operand panel
+// in the XCD's private L2.  Launch 8*ceil(total/8) blocks; returns -1 for the overhang.
+__device__ __forceinline__ long xcd_tile(long total) {
+  const long per = (total + 7) / 8;
+  const long L = (long)(blockIdx.x % 8) * per + blockIdx.x / 8;
+  return L < total ? L : -1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3b: sigma^2 partials.  Tile (iblk, tblk): W = A_inv[iblk rows, :] . B[:, tblk points] on MFMA,
+// then the fused epilogue part[iblk][t] = sum_{i in iblk} b_ti * W_it  (ok.py:681 without the sign;
+// k_ss_reduce applies it).  W itself never leaves registers.
+// SYM: A_inv is symmetric, so b^T A_inv b = sum_I b_I^T (A_II b_I + 2 sum_{J>I} A_IJ b_J): the K loop
+// starts at the diagonal block, which is weighted 1/2 (exact) before the final factor 2.
+// Tile order: tblk slow, iblk fast -> consecutive tiles share the B panel; in SYM mode iblk ascending
+// is also longest-first.
+// ------------------------------------------------------------------------------------------------
+template <bool SYM>
+__global__ void __launch_bounds__(256, 2)
+k_contract(const double* __restrict__ Ainv, long lda, const double* __restrict__ Bt, long ldb,
+           double* __restrict__ part, int palloc, int nIblk, int kend) {
+  __shared__ GemmSmem sm;
+  const long L = xcd_tile((long)nIblk * (palloc / MIK_BN));
+  if (L < 0) return;
+  const int iblk = (int)(L % nIblk), tblk = (int)(L / nIblk);
+  const int i0 = iblk * MIK_BM, t0 = tblk * MIK_BN;
+  d4 acc[4][4];
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int y = 0; y < 4; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
+  const double* Ag = Ainv + (long)i0 * lda;
+  const double* Bg = Bt + (long)t0 * ldb;
+  if (SYM) {
+    const int kd = (i0 + MIK_BM) < kend ? (i0 + MIK_BM) : kend;
+    gemm_core(Ag, lda, Bg, ldb, i0, kd, acc, sm);
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+      for (int y = 0; y < 4; ++y) acc[x][y] *= 0.5;
+    gemm_core(Ag, lda, Bg, ldb, i0 + MIK_BM, kend, acc, sm);
+  } else {
+    gemm_core(Ag, lda, Bg, ldb, 0, kend, acc, sm);
+  }
+  // epilogue: column sums of B .* W over this tile's 128 rows
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1, lq = lane >> 4, lc = lane & 15;
+  double cs[4];
+#pragma unroll
+  for (int bi = 0; bi < 4; ++bi) {
+    const long t = t0 + wn * 64 + bi * 16 + lc;
+    const double* brow = Bt + t * ldb + i0 + wm * 64 + lq;
+    double s = 0.0;
+#pragma unroll
+    for (int ai = 0; ai < 4; ++ai)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s += brow[ai * 16 + 4 * r] * acc[ai][bi][r];
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    cs[bi] = s;
+  }
+  double* red = &sm.As[0][0][0];  // gemm_core ended with a barrier: staging LDS is free
+  if (lq == 0) {
+#pragma unroll
+    for (int bi = 0; bi < 4; ++bi) red[wm * 128 + wn * 64 + bi * 16 + lc] = cs[bi];
+  }
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const double v = red[threadIdx.x] + red[128 + threadIdx.x];
+    part[(long)iblk * palloc + t0 + threadIdx.x] = SYM ? 2.0 * v : v;
+  }
+}
+
+// ss[t] = -sum_iblk part[iblk][t]   (ok.py:681: sigmasq = sum(x * -b))
+__global__ void __launch_bounds__(256) k_ss_reduce(const double* __restrict__ part, int palloc, int nIblk, int nvalid,
+                                                   double* __restrict__ ss) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= nvalid) return;
+  double s = 0.0;
+  for (int b = 0; b < nIblk; ++b) s += part[(long)b * palloc + t];
+  ss[t] = -s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: block Gauss-Jordan inverse, block size 128.  For diagonal block K (rows/cols k0..k0+127):
+//   Dinv = T_KK^-1 (k_diag_inv) ; Cold = T[:,K] ; Cnew = -Cold.Dinv ; Rt = (Dinv.T[K,:])^T
+//   T_ij -= Cold_i . Rt_j^T (i,j not in K) ; T[K,:] = Rt^T ; T[:,K] = Cnew ; T_KK = Dinv
+// After all blocks T = (P.A)^-1.  On the symmetric (shifted, unpivoted) path Rt = -sigma_j * Cnew_j
+// with sigma_j = -1 for already-swept column blocks and +1 otherwise, so no transposes are needed.
+// ------------------------------------------------------------------------------------------------
+
+// Out[i][n] = alpha * sum_m A[i][m] * Bt[n][m],  i over Mp rows, n < 128, m < 128 (one tile column)
+__global__ void __launch_bounds__(256, 2)
+k_panel(const double* __restrict__ A, long lda, const double* __restrict__ Bt, double alpha,
+        double* __restrict__ Out) {
+  __shared__ GemmSmem sm;
+  const int i0 = blockIdx.x * MIK_BM;
+  d4 acc[4][4];
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int y = 0; y < 4; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
+  gemm_core(A + (long)i0 * lda, lda, Bt, 128, 0, 128, acc, sm);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1, lq = lane >> 4, lc = lane & 15;
+#pragma unroll
+  for (int ai = 0; ai < 4; ++ai)
+#pragma unroll
+    for (int bi = 0; bi < 4; ++bi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = i0 + wm * 64 + ai * 16 + lq + 4 * r;
+        const int n = wn * 64 + bi * 16 + lc;
+        Out[(long)i * 128 + n] = alpha * acc[ai][bi][r];
+      }
+}
+
+// Rt[j][:] = -sigma_j * Cnew[j][:]   (symmetric path)
+__global__ void __launch_bounds__(256) k_rt_from_cnew(const double* __restrict__ Cnew, double* __restrict__ Rt, int Mp,
+                                                      int k0) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)Mp * 128) return;
+  const int j = (int)(idx >> 7);
+  Rt[idx] = (j < k0) ? Cnew[idx] : -Cnew[idx];
+}
+
+// trailing update + panel write-back, one 128x128 tile per block
+__global__ void __launch_bounds__(256, 2)
+k_update(double* __restrict__ T, long ld, int nblk, int kb, const double* __restrict__ Cold,
+         const double* __restrict__ Cnew, const double* __restrict__ Rt, const double* __restrict__ Dinv) {
+  __shared__ GemmSmem sm;
+  const long L = xcd_tile((long)nblk * nblk);
+  if (L < 0) return;
+  const int iblk = (int)(L / nblk), jblk = (int)(L % nblk);
+  const int i0 = iblk * MIK_BM, j0 = jblk * MIK_BN, k0 = kb * 128;
+  if (iblk == kb || jblk == kb) {
+    for (int e = threadIdx.x; e < 128 * 128; e += 256) {
+      const int r = e >> 7, c = e & 127;
+      double v;
+      if (iblk == kb && jblk == kb) v = Dinv[e];
+      else if (jblk == kb) v = Cnew[(long)(i0 + r) * 128 + c];
+      else v = Rt[(long)(j0 + c) * 128 + r];
+      T[(long)(i0 + r) * ld + j0 + c] = v;
+    }
+    return;
+  }
+  d4 acc[4][4];
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int y = 0; y < 4; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
+  gemm_core(Cold + (long)i0 * 128, 128, Rt + (long)j0 * 128, 128, 0, 128, acc, sm);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1, lq = lane >> 4, lc = lane & 15;
+#pragma unroll
+  for (int ai = 0; ai < 4; ++ai)
+#pragma unroll
+    for (int bi = 0; bi < 4; ++bi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long i = i0 + wm * 64 + ai * 16 + lq + 4 * r;
+        const long j = j0 + wn * 64 + bi * 16 + lc;
+        T[i * ld + j] -= acc[ai][bi][r];
+      }
+}
+
+// 128x128 in-register Gauss-Jordan inverse of the diagonal block, one 1024-thread workgroup.
+// Thread (w = wave 0..15, lane) owns rows 8w..8w+7, columns lane and lane+64.  Per elimination step
+// the owners publish the pivot row and pivot column through double-buffered LDS; one barrier per step.
+// flag bit0: zero / non-finite pivot (singular); bit1: non-positive pivot inside the station block
+// (the shifted matrix was not positive definite -> the unpivoted path is not trustworthy).
+__global__ void __launch_bounds__(1024) k_diag_inv(const double* __restrict__ T, long ld, int k0, int nspd,
+                                                   double* __restrict__ Dinv, double* __restrict__ DinvT,
+                                                   int* __restrict__ flag) {
+  __shared__ double rowk[2][128], colk[2][128];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  double a[8][2];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    a[r][0] = T[(long)(k0 + w * 8 + r) * ld + k0 + lane];
+    a[r][1] = T[(long)(k0 + w * 8 + r) * ld + k0 + lane + 64];
+  }
+  int bad = 0;
+  for (int k = 0; k < 128; ++k) {
+    const int pb = k & 1;
+    if ((k >> 3) == w) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+        if (r == (k & 7)) {
+          rowk[pb][lane] = a[r][0];
+          rowk[pb][lane + 64] = a[r][1];
+        }
+    }
+    if (lane == (k & 63)) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) colk[pb][w * 8 + r] = (k < 64) ? a[r][0] : a[r][1];
+    }
+    __syncthreads();
+    const double piv = rowk[pb][k];
+    if (!(fabs(piv) > 1e-300) || !isfinite(piv)) bad |= 1;
+    if ((k0 + k) < nspd && !(piv > 0.0)) bad |= 2;
+    const double pinv = 1.0 / piv;
+    const double rk0 = rowk[pb][lane] * pinv, rk1 = rowk[pb][lane + 64] * pinv;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int i = w * 8 + r;
+      const double f = colk[pb][i];
+      if (i == k) {
+        a[r][0] = (lane == k) ? pinv : rk0;
+        a[r][1] = (lane + 64 == k) ? pinv : rk1;
+      } else {
+        a[r][0] = (lane == k) ? -f * pinv : a[r][0] - f * rk0;
+        a[r][1] = (lane + 64 == k) ? -f * pinv : a[r][1] - f * rk1;
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int i = w * 8 + r;
+    Dinv[i * 128 + lane] = a[r][0];
+    Dinv[i * 128 + lane + 64] = a[r][1];
+    DinvT[lane * 128 + i] = a[r][0];
+    DinvT[(lane + 64) * 128 + i] = a[r][1];
+  }
+  if (bad && threadIdx.x == 0) atomicOr(flag, bad);
+}
+
+// Out[j][m] = T[k0+m][j]   (transpose of a 128-row panel; general path)
+__global__ void __launch_bounds__(256) k_transpose_rows(const double* __restrict__ T, long ld, int k0, int Mp,
+                                                        double* __restrict__ Out) {
+  __shared__ double tile[64][65];
+  const int j0 = blockIdx.x * 64, m0 = blockIdx.y * 64;
+  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+    const int m = e >> 6, j = e & 63;
+    tile[m][j] = T[(long)(k0 + m0 + m) * ld + j0 + j];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+    const int j = e >> 6, m = e & 63;
+    Out[(long)(j0 + j) * 128 + m0 + m] = tile[m][j];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pivot search for the pivoted path (partial pivoting, LAPACK dgetf2 order) on a scratch copy of the
+// column panel.  One launch per panel column c; ping-pong buffers Pin -> Pout (Mp x 128, ld 128):
+//   every block first reduces the previous launch's per-block candidates to the pivot row `pr` of
+//   column c, then rewrites its rows with rows (k0+c) and pr exchanged and column c eliminated from
+//   the rows below k0+c, and finally emits its candidate (max |.| over active rows) for column c+1.
+// Rows < k0 (already pivots of earlier blocks) and rows >= M (padding) never take part.
+// ------------------------------------------------------------------------------------------------
+struct PivCand {
+  double v;
+  int row;
+  int pad;
+};
+
+__global__ void __launch_bounds__(256)
+k_piv_first(const double* __restrict__ P, int k0, int M, int Mp, PivCand* __restrict__ cand) {
+  __shared__ double sv[256];
+  __shared__ int sr[256];
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  double v = -1.0;
+  if (row >= k0 && row < M) v = fabs(P[(long)row * 128]);
+  sv[threadIdx.x] = v;
+  sr[threadIdx.x] = row;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      const double v2 = sv[threadIdx.x + o];
+      const int r2 = sr[threadIdx.x + o];
+      if (v2 > sv[threadIdx.x] || (v2 == sv[threadIdx.x] && r2 < sr[threadIdx.x])) {
+        sv[threadIdx.x] = v2;
+        sr[threadIdx.x] = r2;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    cand[blockIdx.x].v = sv[0];
+    cand[blockIdx.x].row = sr[0];
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_piv_step(const double* __restrict__ Pin, double* __restrict__ Pout, int k0, int c, int M, int Mp,
+           const PivCand* __restrict__ cand_in, PivCand* __restrict__ cand_out, int ncand,
+           int* __restrict__ pivrow /* 128 entries of this panel */, int* __restrict__ flag) {
+  __shared__ double sv[256];
+  __shared__ int sr[256];
+  __shared__ double prow[128];
+  __shared__ int s_pr;
+  // 1. pivot row of column c from the candidates
+  {
+    double v = -2.0;
+    int r = 0x7fffffff;
+    for (int e = threadIdx.x; e < ncand; e += 256) {
+      const double v2 = cand_in[e].v;
+      const int r2 = cand_in[e].row;
+      if (v2 > v || (v2 == v && r2 < r)) { v = v2; r = r2; }
+    }
+    sv[threadIdx.x] = v;
+    sr[threadIdx.x] = r;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) {
+        const double v2 = sv[threadIdx.x + o];
+        const int r2 = sr[threadIdx.x + o];
+        if (v2 > sv[threadIdx.x] || (v2 == sv[threadIdx.x] && r2 < sr[threadIdx.x])) {
+          sv[threadIdx.x] = v2;
+          sr[threadIdx.x] = r2;
+        }
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      int pr = sr[0];
+      if (!(sv[0] > 0.0)) {  // nothing usable left in this column: singular (or only padding rows left)
+        pr = k0 + c;
+        if (k0 + c < M) atomicOr(flag, 1);
+      }
+      s_pr = pr;
+      if (blockIdx.x == 0) pivrow[c] = pr;
+    }
+    __syncthreads();
+  }
+  const int pr = s_pr, kr = k0 + c;
+  if (threadIdx.x < 128) prow[threadIdx.x] = Pin[(long)pr * 128 + threadIdx.x];
+  __syncthreads();
+  const double pinv = 1.0 / prow[c];
+  // 2. rewrite this block's 256 rows: 2 threads per row would be finer, 1 thread per row is enough here
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  double nextv = -1.0;
+  if (row < Mp) {
+    const int src = (row == kr) ? pr : ((row == pr) ? kr : row);
+    const double* in = Pin + (long)src * 128;
+    double* out = Pout + (long)row * 128;
+    if (row > kr && row < M && row >= k0) {
+      const double f = in[c] * pinv;
+      for (int m = 0; m < 128; ++m) {
+        const double x = in[m];
+        out[m] = (m > c) ? x - f * prow[m] : ((m == c) ? f : x);
+      }
+      if (c + 1 < 128) nextv = fabs(out[c + 1]);
+    } else {
+      for (int m = 0; m < 128; ++m) out[m] = in[m];
+    }
+  }
+  // 3. candidate for column c+1 over active rows (> kr, < M)
+  sv[threadIdx.x] = nextv;
+  sr[threadIdx.x] = row;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      const double v2 = sv[threadIdx.x + o];
+      const int r2 = sr[threadIdx.x + o];
+      if (v2 > sv[threadIdx.x] || (v2 == sv[threadIdx.x] && r2 < sr[threadIdx.x])) {
+        sv[threadIdx.x] = v2;
+        sr[threadIdx.x] = r2;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    cand_out[blockIdx.x].v = sv[0];
+    cand_out[blockIdx.x].row = sr[0];
+  }
+}
+
+// apply the panel's 128 row interchanges (in order) to all of T; one block per 256 columns
+__global__ void __launch_bounds__(256)
+k_swap_rows(double* __restrict__ T, long ld, int k0, const int* __restrict__ pivrow, int Mp) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= Mp) return;
+  for (int c = 0; c < 128; ++c) {
+    const int pr = pivrow[c], kr = k0 + c;
+    if (pr != kr) {
+      const double a = T[(long)kr * ld + j], b = T[(long)pr * ld + j];
+      T[(long)kr * ld + j] = b;
+      T[(long)pr * ld + j] = a;
+    }
+  }
+}
+
+// undo the row interchanges as column interchanges in reverse order: A^-1 = (P A)^-1 P
+__global__ void __launch_bounds__(256)
+k_swap_cols(double* __restrict__ T, long ld, const int* __restrict__ pivall, int nswap, int Mp) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= Mp) return;
+  double* row = T + (long)i * ld;
+  for (int s = nswap - 1; s >= 0; --s) {
+    const int pr = pivall[s];
+    if (pr != s) {
+      const double a = row[s], b = row[pr];
+      row[s] = b;
+      row[pr] = a;
+    }
+  }
+}
+
+// copy a column panel T[:, k0:k0+128] -> P (Mp x 128)
+__global__ void __launch_bounds__(256) k_copy_panel(const double* __restrict__ T, long ld, int k0, int Mp,
+                                                    double* __restrict__ P) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)Mp * 128) return;
+  const long i = idx >> 7;
+  const int m = (int)(idx & 127);
+  P[idx] = T[i * ld + k0 + m];
+}
+
+// ------------------------------------------------------------------------------------------------
+// fragment-layout self test: D = A(16x4) . B(4x16) with asymmetric integer data
+// ------------------------------------------------------------------------------------------------
+__global__ void k_selftest_mfma(double* out /*16x16 row-major*/) {
+  const int l = threadIdx.x;
+  const double a = (double)((l & 15) * 7 + (l >> 4) * 3 + 1);    // A[i=l&15][k=l>>4]
+  const double b = (double)((l >> 4) * 11 + (l & 15) * 5 + 2);   // B[k=l>>4][j=l&15]
+  d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+  for (int r = 0; r < 4; ++r) out[((l >> 4) + 4 * r) * 16 + (l & 15)] = acc[r];
+}
+
+}  // namespace mik

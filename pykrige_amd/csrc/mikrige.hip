@@ -1,0 +1,744 @@
+// mikrige.hip -- host orchestration + C ABI (include/mikrige.h) of the MI355X kriging execute() path.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Iinclude pykrige_amd/csrc/mikrige.hip -ldl
+// No torch, no BLAS/solver libraries: every kernel is in mik_kernels.h.  RCCL is dlopen()ed on demand.
+#include "mik_kernels.h"
+#include "../../include/mikrige.h"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace mik;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+#define HIPC(x)                                                                                         \
+  do {                                                                                                  \
+    hipError_t e_ = (x);                                                                                \
+    if (e_ != hipSuccess) {                                                                             \
+      char b_[512];                                                                                     \
+      snprintf(b_, sizeof b_, "HIP error '%s' at %s:%d (%s)", hipGetErrorString(e_), __FILE__, __LINE__, #x); \
+      return fail(MIK_EHIP, b_);                                                                        \
+    }                                                                                                   \
+  } while (0)
+#define MIKC(x)            \
+  do {                     \
+    int r_ = (x);          \
+    if (r_ != MIK_OK) return r_; \
+  } while (0)
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  int ensure(size_t need) {
+    if (need <= bytes && p) return MIK_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+    if (need == 0) return MIK_OK;
+    HIPC(hipMalloc(&p, need));
+    bytes = need;
+    return MIK_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  template <class T>
+  T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// --- RCCL, loaded lazily so the single-GPU path has no link-time dependency on it ---------------
+struct RcclApi {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+static RcclApi g_rccl;
+static int rccl_load() {
+  if (g_rccl.lib) return MIK_OK;
+  const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+  void* lib = nullptr;
+  for (const char* n : names) {
+    lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (lib) break;
+  }
+  if (!lib) return fail(MIK_ERCCL, std::string("cannot dlopen librccl.so: ") + dlerror());
+  g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(lib, "ncclGetUniqueId");
+  g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(lib, "ncclCommInitRank");
+  g_rccl.Broadcast = (decltype(g_rccl.Broadcast))dlsym(lib, "ncclBroadcast");
+  g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(lib, "ncclCommDestroy");
+  g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(lib, "ncclGetErrorString");
+  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.Broadcast || !g_rccl.CommDestroy)
+    return fail(MIK_ERCCL, "librccl.so lacks an expected symbol");
+  g_rccl.lib = lib;
+  return MIK_OK;
+}
+#define NCCLC(x)                                                                                   \
+  do {                                                                                             \
+    ncclResult_t r_ = (x);                                                                         \
+    if (r_ != ncclSuccess) {                                                                       \
+      char b_[512];                                                                                \
+      snprintf(b_, sizeof b_, "RCCL error '%s' at %s:%d (%s)",                                     \
+               g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "?", __FILE__, __LINE__, #x);   \
+      return fail(MIK_ERCCL, b_);                                                                  \
+    }                                                                                              \
+  } while (0)
+
+struct mik_handle {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  // problem
+  bool have_problem = false, have_factor = false, have_points = false, have_results = false;
+  int ndim = 2, model = 0, exact = 1, rl = 0, nwells = 0, nextra = 0;
+  int N = 0, p = 0, M = 0, Mp = 0;
+  Vario v{};
+  double eps = 1e-10, shift_guess = 0.0;
+  bool host_inv = false;
+  std::vector<double> host_ainv;
+  DevBuf xs, ys, zs, vals, wells, extra_cols;
+  // factor
+  DevBuf T, cvec, Cold, Cnew, Rt, TKt, Dinv, DinvT, P0, P1, cand0, cand1, pivall, flag;
+  // points
+  long npt_total = 0, npt = 0;
+  std::vector<long> scatter;  // empty = identity
+  DevBuf px, py, pz, extra_rows, z, ss;
+  // work
+  DevBuf Bt, part;
+  // options
+  int opt_factor = 0, opt_sym = 1;
+  long opt_chunk = 65536;
+  mik_timing tm{};
+  std::vector<hipEvent_t> evpool;
+  // comm
+  ncclComm_t comm = nullptr;
+  int nranks = 1, rank = 0;
+};
+
+static int get_events(mik_handle* h, size_t n) {
+  while (h->evpool.size() < n) {
+    hipEvent_t e;
+    HIPC(hipEventCreate(&e));
+    h->evpool.push_back(e);
+  }
+  return MIK_OK;
+}
+
+static double host_vario(const Vario& v, double d) {
+  switch (v.model) {
+    case 0: return v.p0 * d + v.p1;
+    case 1: return v.p0 * std::pow(d, v.p1) + v.p2;
+    case 2: return v.p0 * (1.0 - std::exp(-(d * d) / v.c0)) + v.p2;
+    case 3: return d <= v.p1 ? v.p0 * ((3.0 * d) / (2.0 * v.p1) - (d * d * d) / (2.0 * v.p1 * v.p1 * v.p1)) + v.p2 : v.p0 + v.p2;
+    case 4: return v.p0 * (1.0 - std::exp(-d / v.c0)) + v.p2;
+    default: {
+      double q = d / v.c0;
+      return v.p0 * (1.0 - (1.0 - q) * std::exp(-q)) + v.p2;
+    }
+  }
+}
+
+#define DISPATCH_MODEL_NDIM(model, ndim, KERNEL, grid, block, stream, args)                                 \
+  do {                                                                                                      \
+    if ((ndim) == 3) {                                                                                      \
+      switch (model) {                                                                                      \
+        case 0: hipLaunchKernelGGL((KERNEL<0, 3>), grid, block, 0, stream, args); break;                    \
+        case 1: hipLaunchKernelGGL((KERNEL<1, 3>), grid, block, 0, stream, args); break;                    \
+        case 2: hipLaunchKernelGGL((KERNEL<2, 3>), grid, block, 0, stream, args); break;                    \
+        case 3: hipLaunchKernelGGL((KERNEL<3, 3>), grid, block, 0, stream, args); break;                    \
+        case 4: hipLaunchKernelGGL((KERNEL<4, 3>), grid, block, 0, stream, args); break;                    \
+        default: hipLaunchKernelGGL((KERNEL<5, 3>), grid, block, 0, stream, args); break;                   \
+      }                                                                                                     \
+    } else {                                                                                                \
+      switch (model) {                                                                                      \
+        case 0: hipLaunchKernelGGL((KERNEL<0, 2>), grid, block, 0, stream, args); break;                    \
+        case 1: hipLaunchKernelGGL((KERNEL<1, 2>), grid, block, 0, stream, args); break;                    \
+        case 2: hipLaunchKernelGGL((KERNEL<2, 2>), grid, block, 0, stream, args); break;                    \
+        case 3: hipLaunchKernelGGL((KERNEL<3, 2>), grid, block, 0, stream, args); break;                    \
+        case 4: hipLaunchKernelGGL((KERNEL<4, 2>), grid, block, 0, stream, args); break;                    \
+        default: hipLaunchKernelGGL((KERNEL<5, 2>), grid, block, 0, stream, args); break;                   \
+      }                                                                                                     \
+    }                                                                                                       \
+  } while (0)
+
+extern "C" {
+
+const char* mik_last_error(void) { return g_err.c_str(); }
+
+int mik_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int mik_create(int device, mik_handle** out) {
+  if (!out) return fail(MIK_EINVAL, "mik_create: out is NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) return fail(MIK_EHIP, "mik_create: no HIP device visible (this library has no CPU path)");
+  if (device < 0 || device >= n) return fail(MIK_EINVAL, "mik_create: device index out of range");
+  HIPC(hipSetDevice(device));
+  mik_handle* h = new mik_handle();
+  h->device = device;
+  HIPC(hipStreamCreate(&h->stream));
+  const char* env = getenv("MIK_FACTOR");
+  if (env) h->opt_factor = !strcmp(env, "sweep") ? 1 : (!strcmp(env, "lu") || !strcmp(env, "pivoted")) ? 2 : 0;
+  env = getenv("MIK_SYMMETRIC");
+  if (env) h->opt_sym = atoi(env) ? 1 : 0;
+  env = getenv("MIK_CHUNK");
+  if (env && atol(env) >= 128) h->opt_chunk = (atol(env) / 128) * 128;
+  *out = h;
+  return MIK_OK;
+}
+
+void mik_destroy(mik_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
+  DevBuf* bufs[] = {&h->xs, &h->ys, &h->zs, &h->vals, &h->wells, &h->extra_cols, &h->T, &h->cvec, &h->Cold, &h->Cnew,
+                    &h->Rt, &h->TKt, &h->Dinv, &h->DinvT, &h->P0, &h->P1, &h->cand0, &h->cand1, &h->pivall, &h->flag,
+                    &h->px, &h->py, &h->pz, &h->extra_rows, &h->z, &h->ss, &h->Bt, &h->part};
+  for (DevBuf* b : bufs) b->release();
+  for (hipEvent_t e : h->evpool) (void)hipEventDestroy(e);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int mik_set_option(mik_handle* h, const char* key, double value) {
+  if (!h || !key) return fail(MIK_EINVAL, "mik_set_option: NULL argument");
+  if (!strcmp(key, "factor")) {
+    if (value < 0 || value > 2) return fail(MIK_EINVAL, "factor must be 0 (auto), 1 (sweep) or 2 (pivoted)");
+    h->opt_factor = (int)value;
+  } else if (!strcmp(key, "symmetric")) {
+    h->opt_sym = value != 0.0;
+  } else if (!strcmp(key, "chunk")) {
+    if (value < 128) return fail(MIK_EINVAL, "chunk must be >= 128");
+    h->opt_chunk = ((long)value / 128) * 128;
+  } else {
+    return fail(MIK_EINVAL, std::string("unknown option ") + key);
+  }
+  return MIK_OK;
+}
+
+int64_t mik_matrix_order(mik_handle* h) { return h ? h->M : 0; }
+
+int mik_set_problem(mik_handle* h, const mik_problem* p) {
+  if (!h || !p) return fail(MIK_EINVAL, "mik_set_problem: NULL argument");
+  if (p->ndim != 2 && p->ndim != 3) return fail(MIK_EINVAL, "ndim must be 2 or 3");
+  if (p->n < 1 || p->n > 2000000) return fail(MIK_EINVAL, "n out of range");
+  if (p->model_id < 0 || p->model_id > 5) return fail(MIK_EINVAL, "unknown variogram model id");
+  if (!p->xs || !p->ys || !p->values || (p->ndim == 3 && !p->zs)) return fail(MIK_EINVAL, "station arrays missing");
+  if (p->n_wells < 0 || p->n_extra < 0 || (p->n_wells > 0 && !p->wells) || (p->n_extra > 0 && !p->extra_cols))
+    return fail(MIK_EINVAL, "drift description inconsistent");
+  if (p->n_wells > 0 && p->ndim != 2) return fail(MIK_EINVAL, "point_log drift exists only in 2D (uk.py:884-896)");
+  HIPC(hipSetDevice(h->device));
+  h->ndim = p->ndim;
+  h->model = p->model_id;
+  h->N = (int)p->n;
+  h->rl = p->regional_linear ? 1 : 0;
+  h->nwells = p->n_wells;
+  h->nextra = p->n_extra;
+  h->p = (h->rl ? h->ndim : 0) + h->nwells + h->nextra;
+  h->M = h->N + h->p + 1;
+  h->Mp = ((h->M + 127) / 128) * 128;
+  h->exact = p->exact_values ? 1 : 0;
+  h->eps = p->eps;
+  Vario v{};
+  v.model = p->model_id;
+  v.p0 = p->params[0];
+  v.p1 = p->params[1];
+  v.p2 = p->params[2];
+  v.c0 = 1.0;
+  if (v.model == 2) {
+    const double t = v.p1 * 4.0 / 7.0;
+    v.c0 = t * t;
+  } else if (v.model == 4 || v.model == 5) {
+    v.c0 = v.p1 / 3.0;
+  }
+  h->v = v;
+  const size_t nb = sizeof(double) * (size_t)h->N;
+  MIKC(h->xs.ensure(nb));
+  MIKC(h->ys.ensure(nb));
+  MIKC(h->vals.ensure(nb));
+  HIPC(hipMemcpyAsync(h->xs.p, p->xs, nb, hipMemcpyHostToDevice, h->stream));
+  HIPC(hipMemcpyAsync(h->ys.p, p->ys, nb, hipMemcpyHostToDevice, h->stream));
+  HIPC(hipMemcpyAsync(h->vals.p, p->values, nb, hipMemcpyHostToDevice, h->stream));
+  if (h->ndim == 3) {
+    MIKC(h->zs.ensure(nb));
+    HIPC(hipMemcpyAsync(h->zs.p, p->zs, nb, hipMemcpyHostToDevice, h->stream));
+  }
+  if (h->nwells) {
+    MIKC(h->wells.ensure(sizeof(double) * 3 * h->nwells));
+    HIPC(hipMemcpyAsync(h->wells.p, p->wells, sizeof(double) * 3 * h->nwells, hipMemcpyHostToDevice, h->stream));
+  }
+  if (h->nextra) {
+    MIKC(h->extra_cols.ensure(nb * h->nextra));
+    HIPC(hipMemcpyAsync(h->extra_cols.p, p->extra_cols, nb * h->nextra, hipMemcpyHostToDevice, h->stream));
+  }
+  // shift for the unpivoted sweep: the sill for bounded models, gamma(bounding-box diagonal) otherwise
+  {
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    const double* c[3] = {p->xs, p->ys, p->zs};
+    for (int d = 0; d < h->ndim; ++d)
+      for (long i = 0; i < h->N; ++i) {
+        lo[d] = std::min(lo[d], c[d][i]);
+        hi[d] = std::max(hi[d], c[d][i]);
+      }
+    double diag2 = 0.0;
+    for (int d = 0; d < h->ndim; ++d) diag2 += (hi[d] - lo[d]) * (hi[d] - lo[d]);
+    if (v.model >= 2) h->shift_guess = v.p0 + v.p2;
+    else h->shift_guess = host_vario(v, std::sqrt(diag2));
+    if (!(h->shift_guess > 0.0) || !std::isfinite(h->shift_guess)) h->shift_guess = 1.0;
+  }
+  h->host_inv = p->a_inv != nullptr;
+  if (h->host_inv) h->host_ainv.assign(p->a_inv, p->a_inv + (size_t)h->M * h->M);
+  else h->host_ainv.clear();
+  HIPC(hipStreamSynchronize(h->stream));
+  h->have_problem = true;
+  h->have_factor = false;
+  h->have_results = false;
+  return MIK_OK;
+}
+
+static int launch_assemble(mik_handle* h, double shift) {
+  AsmArgs a{};
+  a.T = h->T.as<double>();
+  a.ld = h->Mp;
+  a.N = h->N;
+  a.p = h->p;
+  a.M = h->M;
+  a.Mp = h->Mp;
+  a.ndim = h->ndim;
+  a.xs = h->xs.as<double>();
+  a.ys = h->ys.as<double>();
+  a.zs = h->zs.as<double>();
+  a.v = h->v;
+  a.shift = shift;
+  a.rl = h->rl;
+  a.nwells = h->nwells;
+  a.nextra = h->nextra;
+  a.wells = h->wells.as<double>();
+  a.extra = h->extra_cols.as<double>();
+  dim3 grid(h->Mp / 64, h->Mp / 64);
+  DISPATCH_MODEL_NDIM(h->model, h->ndim, k_assemble, grid, dim3(256), h->stream, a);
+  HIPC(hipGetLastError());
+  return MIK_OK;
+}
+
+static int ensure_factor_buffers(mik_handle* h) {
+  const size_t Mp = h->Mp;
+  MIKC(h->T.ensure(sizeof(double) * Mp * Mp));
+  MIKC(h->cvec.ensure(sizeof(double) * Mp));
+  return MIK_OK;
+}
+
+// unpivoted (path 1) or pivoted (path 2) block Gauss-Jordan on T in place
+static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_out) {
+  const int Mp = h->Mp, nblk = Mp / 128;
+  const size_t panel = sizeof(double) * (size_t)Mp * 128;
+  MIKC(h->Cold.ensure(panel));
+  MIKC(h->Cnew.ensure(panel));
+  MIKC(h->Rt.ensure(panel));
+  MIKC(h->Dinv.ensure(sizeof(double) * 128 * 128));
+  MIKC(h->DinvT.ensure(sizeof(double) * 128 * 128));
+  MIKC(h->flag.ensure(sizeof(int)));
+  HIPC(hipMemsetAsync(h->flag.p, 0, sizeof(int), h->stream));
+  const int ncand = (Mp + 255) / 256;
+  if (pivoted) {
+    MIKC(h->TKt.ensure(panel));
+    MIKC(h->P0.ensure(panel));
+    MIKC(h->P1.ensure(panel));
+    MIKC(h->cand0.ensure(sizeof(PivCand) * ncand));
+    MIKC(h->cand1.ensure(sizeof(PivCand) * ncand));
+    MIKC(h->pivall.ensure(sizeof(int) * Mp));
+  }
+  double* T = h->T.as<double>();
+  const long ld = Mp;
+  const long tiles = (long)nblk * nblk;
+  const unsigned ugrid = (unsigned)(8 * ((tiles + 7) / 8));
+  const unsigned pgrid = (unsigned)(((long)Mp * 128 + 255) / 256);
+  for (int kb = 0; kb < nblk; ++kb) {
+    const int k0 = kb * 128;
+    if (pivoted) {
+      hipLaunchKernelGGL(k_copy_panel, dim3(pgrid), dim3(256), 0, h->stream, T, ld, k0, Mp, h->P0.as<double>());
+      hipLaunchKernelGGL(k_piv_first, dim3(ncand), dim3(256), 0, h->stream, h->P0.as<double>(), k0, h->M, Mp,
+                         h->cand0.as<PivCand>());
+      for (int c = 0; c < 128; ++c) {
+        const double* Pin = (c & 1) ? h->P1.as<double>() : h->P0.as<double>();
+        double* Pout = (c & 1) ? h->P0.as<double>() : h->P1.as<double>();
+        const PivCand* cin = (c & 1) ? h->cand1.as<PivCand>() : h->cand0.as<PivCand>();
+        PivCand* cout = (c & 1) ? h->cand0.as<PivCand>() : h->cand1.as<PivCand>();
+        hipLaunchKernelGGL(k_piv_step, dim3(ncand), dim3(256), 0, h->stream, Pin, Pout, k0, c, h->M, Mp, cin, cout, ncand,
+                           h->pivall.as<int>() + k0, h->flag.as<int>());
+      }
+      hipLaunchKernelGGL(k_swap_rows, dim3((Mp + 255) / 256), dim3(256), 0, h->stream, T, ld, k0,
+                         (const int*)(h->pivall.as<int>() + k0), Mp);
+    }
+    hipLaunchKernelGGL(k_diag_inv, dim3(1), dim3(1024), 0, h->stream, (const double*)T, ld, k0, nspd,
+                       h->Dinv.as<double>(), h->DinvT.as<double>(), h->flag.as<int>());
+    hipLaunchKernelGGL(k_copy_panel, dim3(pgrid), dim3(256), 0, h->stream, (const double*)T, ld, k0, Mp,
+                       h->Cold.as<double>());
+    hipLaunchKernelGGL(k_panel, dim3(nblk), dim3(256), 0, h->stream, (const double*)h->Cold.as<double>(), 128L,
+                       (const double*)h->DinvT.as<double>(), -1.0, h->Cnew.as<double>());
+    if (pivoted) {
+      hipLaunchKernelGGL(k_transpose_rows, dim3(Mp / 64, 2), dim3(256), 0, h->stream, (const double*)T, ld, k0, Mp,
+                         h->TKt.as<double>());
+      hipLaunchKernelGGL(k_panel, dim3(nblk), dim3(256), 0, h->stream, (const double*)h->TKt.as<double>(), 128L,
+                         (const double*)h->Dinv.as<double>(), 1.0, h->Rt.as<double>());
+    } else {
+      hipLaunchKernelGGL(k_rt_from_cnew, dim3(pgrid), dim3(256), 0, h->stream, (const double*)h->Cnew.as<double>(),
+                         h->Rt.as<double>(), Mp, k0);
+    }
+    hipLaunchKernelGGL(k_update, dim3(ugrid), dim3(256), 0, h->stream, T, ld, nblk, kb,
+                       (const double*)h->Cold.as<double>(), (const double*)h->Cnew.as<double>(),
+                       (const double*)h->Rt.as<double>(), (const double*)h->Dinv.as<double>());
+  }
+  if (pivoted)
+    hipLaunchKernelGGL(k_swap_cols, dim3((Mp + 255) / 256), dim3(256), 0, h->stream, T, ld,
+                       (const int*)h->pivall.as<int>(), Mp, Mp);
+  HIPC(hipGetLastError());
+  int flag = 0;
+  HIPC(hipMemcpyAsync(&flag, h->flag.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPC(hipStreamSynchronize(h->stream));
+  *flag_out = flag;
+  return MIK_OK;
+}
+
+static int finish_factor(mik_handle* h) {
+  hipLaunchKernelGGL(k_cvec, dim3((h->Mp + 3) / 4), dim3(256), 0, h->stream, (const double*)h->T.as<double>(),
+                     (long)h->Mp, h->M, h->N, (const double*)h->vals.as<double>(), h->cvec.as<double>(), h->Mp);
+  HIPC(hipGetLastError());
+  HIPC(hipStreamSynchronize(h->stream));
+  h->have_factor = true;
+  h->have_results = false;
+  return MIK_OK;
+}
+
+int mik_assemble_only(mik_handle* h) {
+  if (!h || !h->have_problem) return fail(MIK_ESTATE, "mik_assemble_only: no problem set");
+  HIPC(hipSetDevice(h->device));
+  MIKC(ensure_factor_buffers(h));
+  MIKC(launch_assemble(h, 0.0));
+  HIPC(hipStreamSynchronize(h->stream));
+  h->have_factor = false;
+  return MIK_OK;
+}
+
+int mik_factor(mik_handle* h) {
+  if (!h || !h->have_problem) return fail(MIK_ESTATE, "mik_factor: no problem set");
+  HIPC(hipSetDevice(h->device));
+  MIKC(ensure_factor_buffers(h));
+  MIKC(get_events(h, 4));
+  h->tm.assemble_ms = h->tm.invert_ms = 0.0;
+  if (h->host_inv) {
+    HIPC(hipMemsetAsync(h->T.p, 0, h->T.bytes, h->stream));
+    HIPC(hipMemcpy2DAsync(h->T.p, sizeof(double) * h->Mp, h->host_ainv.data(), sizeof(double) * h->M,
+                          sizeof(double) * h->M, h->M, hipMemcpyHostToDevice, h->stream));
+    h->tm.factor_path = 3;
+    return finish_factor(h);
+  }
+  // bounded models (proper covariances after the shift) -> unpivoted symmetric sweep; linear/power -> pivoted
+  bool try_sweep = h->opt_factor == 1 || (h->opt_factor == 0 && h->model >= 2);
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    const bool pivoted = !try_sweep;
+    const double shift = pivoted ? 0.0 : h->shift_guess;
+    HIPC(hipEventRecord(h->evpool[0], h->stream));
+    MIKC(launch_assemble(h, shift));
+    HIPC(hipEventRecord(h->evpool[1], h->stream));
+    int flag = 0;
+    MIKC(run_block_inverse(h, pivoted, pivoted ? 0 : h->N, &flag));
+    if (!pivoted) hipLaunchKernelGGL(k_add_diag, dim3(1), dim3(1), 0, h->stream, h->T.as<double>(), (long)h->Mp, h->M - 1, shift);
+    HIPC(hipEventRecord(h->evpool[2], h->stream));
+    HIPC(hipStreamSynchronize(h->stream));
+    float ms = 0.f;
+    HIPC(hipEventElapsedTime(&ms, h->evpool[0], h->evpool[1]));
+    h->tm.assemble_ms += ms;
+    HIPC(hipEventElapsedTime(&ms, h->evpool[1], h->evpool[2]));
+    h->tm.invert_ms += ms;
+    h->tm.factor_path = pivoted ? 2 : 1;
+    if (flag == 0) return finish_factor(h);
+    if (!pivoted && h->opt_factor == 0) {  // shifted matrix not positive definite: redo with pivoting
+      try_sweep = false;
+      continue;
+    }
+    return fail(MIK_ESINGULAR, pivoted ? "singular matrix" : "singular matrix (unpivoted sweep hit a bad pivot; use factor=auto or pivoted)");
+  }
+  return fail(MIK_ESINGULAR, "singular matrix");
+}
+
+int mik_get_matrix(mik_handle* h, int which, double* out) {
+  if (!h || !out) return fail(MIK_EINVAL, "mik_get_matrix: NULL argument");
+  if (!h->T.p) return fail(MIK_ESTATE, "mik_get_matrix: nothing assembled");
+  if (which == 1 && !h->have_factor) return fail(MIK_ESTATE, "mik_get_matrix: not factored");
+  HIPC(hipSetDevice(h->device));
+  HIPC(hipMemcpy2D(out, sizeof(double) * h->M, h->T.p, sizeof(double) * h->Mp, sizeof(double) * h->M, h->M,
+                   hipMemcpyDeviceToHost));
+  return MIK_OK;
+}
+
+int mik_set_points(mik_handle* h, const mik_points* g) {
+  if (!h || !g) return fail(MIK_EINVAL, "mik_set_points: NULL argument");
+  if (!h->have_problem) return fail(MIK_ESTATE, "mik_set_points: set the problem first");
+  if (g->npt < 0) return fail(MIK_EINVAL, "npt < 0");
+  if (g->npt > 0 && (!g->px || !g->py || (h->ndim == 3 && !g->pz))) return fail(MIK_EINVAL, "point arrays missing");
+  if (h->nextra > 0 && g->npt > 0 && !g->extra_rows) return fail(MIK_EINVAL, "extra_rows missing for host-evaluated drifts");
+  HIPC(hipSetDevice(h->device));
+  h->npt_total = g->npt;
+  h->scatter.clear();
+  const double* src[3] = {g->px, g->py, g->pz};
+  std::vector<double> tmp;
+  long n = g->npt;
+  if (g->mask) {  // np.nonzero(~mask) (ok.py:700) / `if mask[i]: continue` (cok.pyx:57-58)
+    for (long i = 0; i < g->npt; ++i)
+      if (!g->mask[i]) h->scatter.push_back(i);
+    n = (long)h->scatter.size();
+    if (n == g->npt) h->scatter.clear();
+  }
+  h->npt = n;
+  DevBuf* dst[3] = {&h->px, &h->py, &h->pz};
+  for (int d = 0; d < h->ndim; ++d) {
+    MIKC(dst[d]->ensure(sizeof(double) * std::max<long>(n, 1)));
+    if (n == 0) continue;
+    if (h->scatter.empty()) {
+      HIPC(hipMemcpyAsync(dst[d]->p, src[d], sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+    } else {
+      tmp.resize(n);
+      for (long i = 0; i < n; ++i) tmp[i] = src[d][h->scatter[i]];
+      HIPC(hipMemcpyAsync(dst[d]->p, tmp.data(), sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+      HIPC(hipStreamSynchronize(h->stream));
+    }
+  }
+  if (h->nextra && n > 0) {
+    MIKC(h->extra_rows.ensure(sizeof(double) * n * h->nextra));
+    for (int k = 0; k < h->nextra; ++k) {
+      const double* row = g->extra_rows + (size_t)k * g->npt;
+      if (h->scatter.empty()) {
+        HIPC(hipMemcpyAsync(h->extra_rows.as<double>() + (size_t)k * n, row, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+      } else {
+        tmp.resize(n);
+        for (long i = 0; i < n; ++i) tmp[i] = row[h->scatter[i]];
+        HIPC(hipMemcpyAsync(h->extra_rows.as<double>() + (size_t)k * n, tmp.data(), sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+        HIPC(hipStreamSynchronize(h->stream));
+      }
+    }
+  }
+  MIKC(h->z.ensure(sizeof(double) * std::max<long>(n, 1)));
+  MIKC(h->ss.ensure(sizeof(double) * std::max<long>(n, 1)));
+  HIPC(hipStreamSynchronize(h->stream));
+  h->have_points = true;
+  h->have_results = false;
+  return MIK_OK;
+}
+
+int mik_predict(mik_handle* h) {
+  if (!h || !h->have_factor) return fail(MIK_ESTATE, "mik_predict: factor first");
+  if (!h->have_points) return fail(MIK_ESTATE, "mik_predict: set points first");
+  HIPC(hipSetDevice(h->device));
+  const long npt = h->npt;
+  const int Mp = h->Mp, nIblk = Mp / 128;
+  h->tm.rhs_ms = h->tm.contract_ms = h->tm.predict_ms = 0.0;
+  h->tm.contract_launches = 0;
+  h->tm.contract_flops_executed = 0.0;
+  h->tm.symmetric = h->opt_sym;
+  if (npt == 0) {
+    h->have_results = true;
+    return MIK_OK;
+  }
+  long chunk = std::min<long>(h->opt_chunk, ((npt + 127) / 128) * 128);
+  // keep the RHS panel under ~1/8 of device memory
+  size_t freeb = 0, totalb = 0;
+  HIPC(hipMemGetInfo(&freeb, &totalb));
+  while (chunk > 128 && (size_t)chunk * Mp * sizeof(double) > std::max(freeb, h->Bt.bytes) / 2) chunk = ((chunk / 2 + 127) / 128) * 128;
+  MIKC(h->Bt.ensure(sizeof(double) * (size_t)chunk * Mp));
+  MIKC(h->part.ensure(sizeof(double) * (size_t)chunk * nIblk));
+  const long nchunks = (npt + chunk - 1) / chunk;
+  MIKC(get_events(h, 2 + 3 * (size_t)nchunks));
+  const int kend = ((h->M + MIK_BK - 1) / MIK_BK) * MIK_BK;
+  HIPC(hipEventRecord(h->evpool[0], h->stream));
+  for (long c = 0; c < nchunks; ++c) {
+    const long t0 = c * chunk;
+    const int nvalid = (int)std::min<long>(chunk, npt - t0);
+    const int palloc = ((nvalid + 127) / 128) * 128;
+    RhsArgs a{};
+    a.Bt = h->Bt.as<double>();
+    a.ld = Mp;
+    a.palloc = palloc;
+    a.nvalid = nvalid;
+    a.px = h->px.as<double>() + t0;
+    a.py = h->py.as<double>() + t0;
+    a.pz = h->ndim == 3 ? h->pz.as<double>() + t0 : nullptr;
+    a.N = h->N;
+    a.p = h->p;
+    a.M = h->M;
+    a.Mp = Mp;
+    a.ndim = h->ndim;
+    a.xs = h->xs.as<double>();
+    a.ys = h->ys.as<double>();
+    a.zs = h->zs.as<double>();
+    a.v = h->v;
+    a.exact = h->exact;
+    a.eps = h->eps;
+    a.rl = h->rl;
+    a.nwells = h->nwells;
+    a.nextra = h->nextra;
+    a.wells = h->wells.as<double>();
+    a.extra = h->nextra ? h->extra_rows.as<double>() + t0 : nullptr;
+    a.extra_stride = npt;
+    a.cvec = h->cvec.as<double>();
+    a.zout = h->z.as<double>() + t0;
+    hipEvent_t e0 = h->evpool[2 + 3 * c], e1 = h->evpool[3 + 3 * c], e2 = h->evpool[4 + 3 * c];
+    HIPC(hipEventRecord(e0, h->stream));
+    DISPATCH_MODEL_NDIM(h->model, h->ndim, k_rhs, dim3(palloc / MIK_TP), dim3(256), h->stream, a);
+    HIPC(hipEventRecord(e1, h->stream));
+    const long tiles = (long)nIblk * (palloc / 128);
+    const unsigned grid = (unsigned)(8 * ((tiles + 7) / 8));
+    if (h->opt_sym)
+      hipLaunchKernelGGL(k_contract<true>, dim3(grid), dim3(256), 0, h->stream, (const double*)h->T.as<double>(), (long)Mp,
+                         (const double*)h->Bt.as<double>(), (long)Mp, h->part.as<double>(), palloc, nIblk, kend);
+    else
+      hipLaunchKernelGGL(k_contract<false>, dim3(grid), dim3(256), 0, h->stream, (const double*)h->T.as<double>(), (long)Mp,
+                         (const double*)h->Bt.as<double>(), (long)Mp, h->part.as<double>(), palloc, nIblk, kend);
+    HIPC(hipEventRecord(e2, h->stream));
+    hipLaunchKernelGGL(k_ss_reduce, dim3((nvalid + 255) / 256), dim3(256), 0, h->stream, (const double*)h->part.as<double>(),
+                       palloc, nIblk, nvalid, h->ss.as<double>() + t0);
+    // executed flops of this launch: per tile 2*128*128*(k extent)
+    double kext = 0.0;
+    for (int ib = 0; ib < nIblk; ++ib) kext += h->opt_sym ? std::max(0, kend - ib * 128) : kend;
+    h->tm.contract_flops_executed += 2.0 * 128.0 * 128.0 * kext * (palloc / 128);
+  }
+  HIPC(hipGetLastError());
+  HIPC(hipEventRecord(h->evpool[1], h->stream));
+  HIPC(hipStreamSynchronize(h->stream));
+  float ms = 0.f;
+  HIPC(hipEventElapsedTime(&ms, h->evpool[0], h->evpool[1]));
+  h->tm.predict_ms = ms;
+  for (long c = 0; c < nchunks; ++c) {
+    HIPC(hipEventElapsedTime(&ms, h->evpool[2 + 3 * c], h->evpool[3 + 3 * c]));
+    h->tm.rhs_ms += ms;
+    HIPC(hipEventElapsedTime(&ms, h->evpool[3 + 3 * c], h->evpool[4 + 3 * c]));
+    h->tm.contract_ms += ms;
+  }
+  h->tm.contract_launches = nchunks;
+  h->have_results = true;
+  return MIK_OK;
+}
+
+int mik_get_results(mik_handle* h, double* z_out, double* ss_out) {
+  if (!h || !z_out || !ss_out) return fail(MIK_EINVAL, "mik_get_results: NULL argument");
+  if (!h->have_results) return fail(MIK_ESTATE, "mik_get_results: predict first");
+  HIPC(hipSetDevice(h->device));
+  const long n = h->npt;
+  if (h->scatter.empty() && n == h->npt_total) {
+    if (n) {
+      HIPC(hipMemcpy(z_out, h->z.p, sizeof(double) * n, hipMemcpyDeviceToHost));
+      HIPC(hipMemcpy(ss_out, h->ss.p, sizeof(double) * n, hipMemcpyDeviceToHost));
+    }
+    return MIK_OK;
+  }
+  std::vector<double> tz(n), ts(n);
+  if (n) {
+    HIPC(hipMemcpy(tz.data(), h->z.p, sizeof(double) * n, hipMemcpyDeviceToHost));
+    HIPC(hipMemcpy(ts.data(), h->ss.p, sizeof(double) * n, hipMemcpyDeviceToHost));
+  }
+  for (long i = 0; i < h->npt_total; ++i) z_out[i] = ss_out[i] = 0.0;  // cok.pyx:25-26
+  for (long i = 0; i < n; ++i) {
+    z_out[h->scatter[i]] = tz[i];
+    ss_out[h->scatter[i]] = ts[i];
+  }
+  return MIK_OK;
+}
+
+int mik_get_timing(mik_handle* h, mik_timing* out) {
+  if (!h || !out) return fail(MIK_EINVAL, "mik_get_timing: NULL argument");
+  *out = h->tm;
+  return MIK_OK;
+}
+
+int mik_krige_execute(int device, const mik_problem* p, const mik_points* g, double* z_out, double* ss_out) {
+  mik_handle* h = nullptr;
+  int r = mik_create(device, &h);
+  if (r != MIK_OK) return r;
+  r = mik_set_problem(h, p);
+  if (r == MIK_OK) r = mik_factor(h);
+  if (r == MIK_OK) r = mik_set_points(h, g);
+  if (r == MIK_OK) r = mik_predict(h);
+  if (r == MIK_OK) r = mik_get_results(h, z_out, ss_out);
+  std::string keep = g_err;
+  mik_destroy(h);
+  g_err = keep;
+  return r;
+}
+
+int mik_selftest_mfma(int device) {
+  HIPC(hipSetDevice(device));
+  double* d = nullptr;
+  HIPC(hipMalloc(&d, sizeof(double) * 256));
+  hipLaunchKernelGGL(k_selftest_mfma, dim3(1), dim3(64), 0, 0, d);
+  double out[256];
+  HIPC(hipMemcpy(out, d, sizeof out, hipMemcpyDeviceToHost));
+  (void)hipFree(d);
+  for (int i = 0; i < 16; ++i)
+    for (int j = 0; j < 16; ++j) {
+      double ref = 0.0;
+      for (int k = 0; k < 4; ++k) ref += (double)(i * 7 + k * 3 + 1) * (double)(k * 11 + j * 5 + 2);
+      if (out[i * 16 + j] != ref) {
+        char b[200];
+        snprintf(b, sizeof b, "mfma_f64_16x16x4 layout mismatch at (%d,%d): got %g want %g", i, j, out[i * 16 + j], ref);
+        return fail(MIK_EHIP, b);
+      }
+    }
+  return MIK_OK;
+}
+
+// ---- multi-GPU ---------------------------------------------------------------------------------
+int mik_comm_unique_id(char id_out[128]) {
+  MIKC(rccl_load());
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  ncclUniqueId id;
+  NCCLC(g_rccl.GetUniqueId(&id));
+  memcpy(id_out, &id, 128);
+  return MIK_OK;
+}
+
+int mik_comm_init(mik_handle* h, int nranks, int rank, const char id[128]) {
+  if (!h || !id || nranks < 1 || rank < 0 || rank >= nranks) return fail(MIK_EINVAL, "mik_comm_init: bad argument");
+  MIKC(rccl_load());
+  HIPC(hipSetDevice(h->device));
+  ncclUniqueId uid;
+  memcpy(&uid, id, 128);
+  NCCLC(g_rccl.CommInitRank(&h->comm, nranks, uid, rank));
+  h->nranks = nranks;
+  h->rank = rank;
+  return MIK_OK;
+}
+
+int mik_bcast_factor(mik_handle* h, int root) {
+  if (!h || !h->comm) return fail(MIK_ESTATE, "mik_bcast_factor: no communicator");
+  if (!h->have_problem) return fail(MIK_ESTATE, "mik_bcast_factor: set the problem on every rank first");
+  if (h->rank == root && !h->have_factor) return fail(MIK_ESTATE, "mik_bcast_factor: root has not factored");
+  HIPC(hipSetDevice(h->device));
+  MIKC(ensure_factor_buffers(h));
+  const size_t Mp = h->Mp;
+  NCCLC(g_rccl.Broadcast(h->T.p, h->T.p, Mp * Mp, ncclDouble, root, h->comm, h->stream));
+  NCCLC(g_rccl.Broadcast(h->cvec.p, h->cvec.p, Mp, ncclDouble, root, h->comm, h->stream));
+  HIPC(hipStreamSynchronize(h->stream));
+  h->have_factor = true;
+  h->have_results = false;
+  return MIK_OK;
+}
+
+}  // extern "C"

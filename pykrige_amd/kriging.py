@@ -1,0 +1,551 @@
+"""Host-side mirror of the reference's kriging classes for the execute() path.
+
+Same class names, constructor keywords, ``execute`` signatures, return shapes and exceptions as
+PyKrige 1.7.3 (/root/reference/src/pykrige: ok.py:187-206,760-1020; uk.py:220-244,1090-1328;
+ok3d.py:198-219,735-932; uk3d.py:215-239,877-1146).  Everything between
+``a = self._get_kriging_matrix(n)`` and ``return zvalues, sigmasq`` runs on the MI355X through
+libmikrige.so (include/mikrige.h); this module only does the front/back matter the reference does in
+Python: argument checks, meshgrid order, mask transposition, anisotropy adjustment, host-evaluated
+drift terms, output shaping.
+
+``backend``: the reference's values 'vectorized', 'loop' (and 'C' for OrdinaryKriging) are accepted
+and all run the same device path -- they keep only their return-type convention ('vectorized' returns
+MaskedArrays in every style, the others plain ndarrays unless style='masked').  'hip' is an explicit
+alias with the 'loop'/'C' convention.  There is no CPU path in this package.
+"""
+import warnings
+
+import numpy as np
+
+from . import _lib
+from . import core
+
+_UNSUPPORTED = (
+    "pykrige_amd implements the execute() hot path on the GPU; %s is outside that path "
+    "(see DESIGN.md, 'out of scope')."
+)
+
+
+class _KrigingBase:
+    eps = 1.0e-10  # ok.py:177, uk.py:210
+    UNBIAS = True  # uk.py:208
+    _ndim = 2
+    _universal = False
+    _backends = ("vectorized", "loop", "hip")
+    _label = "kriging"
+
+    # ---------------------------------------------------------------- construction helpers
+    def _init_common(self, variogram_model, variogram_parameters, variogram_function, exact_values, pseudo_inv,
+                     pseudo_inv_type, verbose, enable_plotting):
+        self.pseudo_inv = bool(pseudo_inv)
+        self.pseudo_inv_type = str(pseudo_inv_type)
+        if self.pseudo_inv_type not in ("pinv", "pinvh"):  # core.py:33 P_INV keys
+            raise ValueError("pseudo inv type not valid: " + str(pseudo_inv_type))
+        if hasattr(variogram_model, "pykrige_kwargs"):
+            raise NotImplementedError(_UNSUPPORTED % "a GSTools covariance model (arbitrary Python callable)")
+        self.variogram_model = variogram_model
+        if variogram_model == "custom":
+            if variogram_function is None or not callable(variogram_function):
+                raise ValueError("Must specify callable function for custom variogram model.")
+            raise NotImplementedError(_UNSUPPORTED % "a custom variogram function (no device functor for Python callables)")
+        if variogram_model not in core.MODELS:
+            raise ValueError("Specified variogram model '%s' is not supported." % variogram_model)
+        if not isinstance(exact_values, bool):
+            raise ValueError("exact_values has to be boolean True or False")
+        self.exact_values = exact_values
+        self.verbose = verbose
+        self.enable_plotting = enable_plotting
+        self._user_parameters = variogram_parameters
+        self._handle = None
+
+    def _set_variogram_parameters(self, variogram_parameters, nlags, weight):
+        plist = core.make_variogram_parameter_list(self.variogram_model, variogram_parameters)
+        if plist is None:
+            from . import variogram_fit  # constructor-time only; never on the execute() path
+
+            self.lags, self.semivariance, plist = variogram_fit.fit(
+                self._coords_adj, self._values(), self.variogram_model, nlags, weight)
+        else:
+            self.lags, self.semivariance = None, None
+        self.variogram_model_parameters = [float(v) for v in plist]
+        if self.verbose:
+            print("Using '%s' Variogram Model" % self.variogram_model)
+            print("Parameters:", self.variogram_model_parameters, "\n")
+
+    def update_variogram_model(self, variogram_model, variogram_parameters=None, variogram_function=None, nlags=6,
+                               weight=False, **anisotropy):
+        """Changes the variogram model (and optionally the anisotropy) -- ok.py:379-545 without the
+        statistics pass, which execute() never reads."""
+        if variogram_model == "custom" or hasattr(variogram_model, "pykrige_kwargs"):
+            raise NotImplementedError(_UNSUPPORTED % "a custom variogram function")
+        if variogram_model not in core.MODELS:
+            raise ValueError("Specified variogram model '%s' is not supported." % variogram_model)
+        self.variogram_model = variogram_model
+        if anisotropy:
+            self._update_anisotropy(**anisotropy)
+        self._set_variogram_parameters(variogram_parameters, nlags, weight)
+
+    # ---------------------------------------------------------------- device plumbing
+    def _get_handle(self):
+        if self._handle is None:
+            self._handle = _lib.Handle()
+        return self._handle
+
+    def _values(self):
+        return self.VALUES if self._ndim == 3 else self.Z
+
+    def _station_extra_cols(self):
+        return None
+
+    def _wells(self):
+        return None
+
+    def _regional_linear(self):
+        return False
+
+    def _upload_and_factor(self):
+        """K1 + K2 on the device (or the host pseudo-inverse when pseudo_inv=True)."""
+        h = self._get_handle()
+        ca = self._coords_adj
+        kw = dict(
+            ndim=self._ndim, xs=ca[:, 0], ys=ca[:, 1], zs=ca[:, 2] if self._ndim == 3 else None,
+            values=self._values(), model_id=_lib.MODEL_IDS[self.variogram_model],
+            params=self.variogram_model_parameters, eps=self.eps, exact_values=self.exact_values,
+            regional_linear=self._regional_linear(), wells=self._wells(), extra_cols=self._station_extra_cols(),
+        )
+        if self.pseudo_inv:
+            # ok.py:660-661: a_inv = P_INV[self.pseudo_inv_type](a).  The matrix is assembled on the
+            # device (K1), the SVD-based pseudo-inverse is the host's (SciPy), the result is uploaded.
+            import scipy.linalg
+
+            h.set_problem(**kw)
+            h.assemble_only()
+            a = h.get_matrix(0)
+            pinv = {"pinv": scipy.linalg.pinv, "pinvh": scipy.linalg.pinvh}[self.pseudo_inv_type](a)
+            h.set_problem(a_inv=pinv, **kw)
+        else:
+            h.set_problem(**kw)
+        h.factor()
+        return h
+
+    def _solve(self, pts_adj, mask, extra_rows):
+        h = self._upload_and_factor()
+        h.set_points(pts_adj[:, 0], pts_adj[:, 1], pts_adj[:, 2] if self._ndim == 3 else None,
+                     mask=mask, extra_rows=extra_rows)
+        h.predict()
+        self.last_timing = h.timing()
+        return h.get_results()
+
+    # ---------------------------------------------------------------- execute front / back matter
+    def _check_backend(self, backend, n_closest_points):
+        if backend not in self._backends:
+            raise ValueError("Specified backend {} is not supported for {}.".format(backend, self._label))
+        if n_closest_points is not None:
+            if n_closest_points <= 1:
+                raise ValueError("n_closest_points has to be at least two!")
+            raise NotImplementedError(_UNSUPPORTED % "moving-window kriging (n_closest_points)")
+
+    def _points_from(self, style, axes, mask):
+        """Reference meshgrid order and mask handling (ok.py:849-878; ok3d.py:841-876)."""
+        if style != "grid" and style != "masked" and style != "points":
+            raise ValueError("style argument must be 'grid', 'points', or 'masked'")
+        # the reference does not cast (integer grids crash in its in-place subtract); cast to fp64 here
+        axes = [np.atleast_1d(np.squeeze(np.array(a, copy=True, dtype=np.float64))) for a in axes]
+        sizes = [a.size for a in axes]
+        if style in ("grid", "masked"):
+            shape = tuple(reversed(sizes))  # (ny, nx) / (nz, ny, nx)
+            if style == "masked":
+                if mask is None:
+                    raise IOError("Must specify boolean masking array when style is 'masked'.")
+                mask = np.asarray(mask)
+                if self._ndim == 3 and mask.ndim != 3:
+                    raise ValueError("Mask is not three-dimensional.")
+                if mask.ndim != self._ndim:
+                    raise ValueError("Mask dimensions do not match specified grid dimensions.")
+                if mask.shape != shape:
+                    if mask.shape == tuple(sizes):
+                        mask = mask.T if self._ndim == 2 else mask.swapaxes(0, 2)
+                    else:
+                        raise ValueError("Mask dimensions do not match specified grid dimensions.")
+                mask = mask.flatten().astype(bool)
+            if self._ndim == 2:
+                gx, gy = np.meshgrid(axes[0], axes[1])
+                pts = np.stack((gx.ravel(), gy.ravel()), axis=1)
+            else:
+                gz, gy, gx = np.meshgrid(axes[2], axes[1], axes[0], indexing="ij")
+                pts = np.stack((gx.ravel(), gy.ravel(), gz.ravel()), axis=1)
+        else:
+            if len(set(sizes)) != 1:
+                raise ValueError("xpoints and ypoints%s must have same dimensions when treated as listing "
+                                 "discrete points." % (", zpoints" if self._ndim == 3 else ""))
+            shape = (sizes[0],)
+            pts = np.stack(axes, axis=1)
+            mask = None
+        return pts, shape, mask
+
+    def _finish(self, z, ss, style, shape, mask, backend):
+        if style == "masked":
+            z = np.ma.array(z, mask=mask)
+            ss = np.ma.array(ss, mask=mask)
+        elif backend == "vectorized":
+            # reference quirk: _exec_vector returns MaskedArrays (all-False mask) in every style
+            z = np.ma.array(z, mask=np.zeros(z.shape, dtype=bool))
+            ss = np.ma.array(ss, mask=np.zeros(ss.shape, dtype=bool))
+        return z.reshape(shape), ss.reshape(shape)
+
+    def _spec_rows(self, style, shape, npt, specified_drift_arrays):
+        """uk.py:1217-1274 / uk3d.py:1030-1095: validate + flatten the per-point specified-drift arrays."""
+        if specified_drift_arrays is None:
+            specified_drift_arrays = []
+        rows = []
+        if self.specified_drift:
+            if len(specified_drift_arrays) == 0:
+                raise ValueError("Must provide drift values for kriging points when using 'specified' drift capability.")
+            if type(specified_drift_arrays) is not list:
+                raise TypeError("Arrays for specified drift terms must be encapsulated in a list.")
+            for spec in specified_drift_arrays:
+                spec = np.asarray(spec)
+                if style in ("grid", "masked"):
+                    if spec.ndim < self._ndim:
+                        raise ValueError("Dimensions of drift values array do not match specified grid dimensions.")
+                    if spec.shape != shape:
+                        if spec.shape == tuple(reversed(shape)):
+                            spec = spec.T if self._ndim == 2 else spec.swapaxes(0, 2)
+                        else:
+                            raise ValueError("Dimensions of drift values array do not match specified grid dimensions.")
+                else:
+                    if spec.ndim != 1:
+                        raise ValueError("Dimensions of drift values array do not match specified grid dimensions.")
+                    if spec.shape[0] != npt:
+                        raise ValueError("Number of supplied drift values in array do not match specified number of kriging points.")
+                rows.append(np.asarray(spec, dtype=np.float64).ravel())
+            if len(rows) != len(self.specified_drift_data_arrays):
+                raise ValueError("Inconsistent number of specified drift terms supplied.")
+        elif len(specified_drift_arrays) != 0:
+            warnings.warn("Provided specified drift values, but 'specified' drift was not initialized during "
+                          "instantiation of %s class." % type(self).__name__, RuntimeWarning)
+        return rows
+
+
+# =====================================================================================================
+class OrdinaryKriging(_KrigingBase):
+    """2D ordinary kriging (ok.py:41).  ``execute`` runs on the GPU."""
+
+    _ndim = 2
+    _backends = ("vectorized", "loop", "C", "hip")
+    _label = "2D ordinary kriging"
+
+    def __init__(self, x, y, z, variogram_model="linear", variogram_parameters=None, variogram_function=None, nlags=6,
+                 weight=False, anisotropy_scaling=1.0, anisotropy_angle=0.0, verbose=False, enable_plotting=False,
+                 enable_statistics=False, coordinates_type="euclidean", exact_values=True, pseudo_inv=False,
+                 pseudo_inv_type="pinv"):
+        self._init_common(variogram_model, variogram_parameters, variogram_function, exact_values, pseudo_inv,
+                          pseudo_inv_type, verbose, enable_plotting)
+        if coordinates_type == "geographic":
+            raise NotImplementedError(_UNSUPPORTED % "coordinates_type='geographic'")
+        if coordinates_type != "euclidean":
+            raise ValueError("Only 'euclidean' and 'geographic' are valid values for coordinates-keyword.")
+        self.coordinates_type = coordinates_type
+        if enable_statistics:
+            raise NotImplementedError(_UNSUPPORTED % "enable_statistics (variogram-fit statistics)")
+        self.X_ORIG = np.atleast_1d(np.squeeze(np.array(x, copy=True, dtype=np.float64)))
+        self.Y_ORIG = np.atleast_1d(np.squeeze(np.array(y, copy=True, dtype=np.float64)))
+        self.Z = np.atleast_1d(np.squeeze(np.array(z, copy=True, dtype=np.float64)))
+        self.XCENTER = (np.amax(self.X_ORIG) + np.amin(self.X_ORIG)) / 2.0
+        self.YCENTER = (np.amax(self.Y_ORIG) + np.amin(self.Y_ORIG)) / 2.0
+        self.anisotropy_scaling = anisotropy_scaling
+        self.anisotropy_angle = anisotropy_angle
+        self._adjust_stations()
+        self._set_variogram_parameters(variogram_parameters, nlags, weight)
+        self.delta = self.sigma = self.epsilon = self.Q1 = self.Q2 = self.cR = None
+
+    def _center(self):
+        return [self.XCENTER, self.YCENTER]
+
+    def _scaling(self):
+        return [self.anisotropy_scaling]
+
+    def _angle(self):
+        return [self.anisotropy_angle]
+
+    def _adjust_stations(self):
+        self._coords_adj = core.adjust_for_anisotropy(np.vstack((self.X_ORIG, self.Y_ORIG)).T, self._center(),
+                                                      self._scaling(), self._angle())
+        self.X_ADJUSTED, self.Y_ADJUSTED = self._coords_adj.T
+
+    def _update_anisotropy(self, anisotropy_scaling=None, anisotropy_angle=None):
+        if anisotropy_scaling is not None:
+            self.anisotropy_scaling = anisotropy_scaling
+        if anisotropy_angle is not None:
+            self.anisotropy_angle = anisotropy_angle
+        self._adjust_stations()
+
+    def execute(self, style, xpoints, ypoints, mask=None, backend="vectorized", n_closest_points=None):
+        """Kriged values and variances at a grid / masked grid / list of points (ok.py:760-1020)."""
+        if self.verbose:
+            print("Executing Ordinary Kriging...\n")
+        if style != "grid" and style != "masked" and style != "points":
+            raise ValueError("style argument must be 'grid', 'points', or 'masked'")
+        self._check_backend(backend, n_closest_points)
+        pts, shape, mask = self._points_from(style, (xpoints, ypoints), mask)
+        pts_adj = core.adjust_for_anisotropy(pts, self._center(), self._scaling(), self._angle())
+        z, ss = self._solve(pts_adj, mask, None)
+        return self._finish(z, ss, style, shape, mask, backend)
+
+
+# =====================================================================================================
+class UniversalKriging(OrdinaryKriging):
+    """2D universal kriging (uk.py:39): regional_linear and point_log drifts are evaluated on the
+    device; external_Z, specified and functional drifts are evaluated here (they are O(npt) lookups or
+    user callables) and passed as extra matrix columns / RHS rows."""
+
+    _universal = True
+    _backends = ("vectorized", "loop", "hip")
+    _label = "2D universal kriging"
+
+    def __init__(self, x, y, z, variogram_model="linear", variogram_parameters=None, variogram_function=None, nlags=6,
+                 weight=False, anisotropy_scaling=1.0, anisotropy_angle=0.0, drift_terms=None, point_drift=None,
+                 external_drift=None, external_drift_x=None, external_drift_y=None, specified_drift=None,
+                 functional_drift=None, verbose=False, enable_plotting=False, exact_values=True, pseudo_inv=False,
+                 pseudo_inv_type="pinv"):
+        OrdinaryKriging.__init__(self, x, y, z, variogram_model=variogram_model,
+                                 variogram_parameters=variogram_parameters, variogram_function=variogram_function,
+                                 nlags=nlags, weight=weight, anisotropy_scaling=anisotropy_scaling,
+                                 anisotropy_angle=anisotropy_angle, verbose=verbose, enable_plotting=enable_plotting,
+                                 exact_values=exact_values, pseudo_inv=pseudo_inv, pseudo_inv_type=pseudo_inv_type)
+        if drift_terms is None:
+            drift_terms = []
+        self.regional_linear_drift = "regional_linear" in drift_terms
+        self.external_Z_drift = "external_Z" in drift_terms
+        if self.external_Z_drift:
+            if external_drift is None:
+                raise ValueError("Must specify external Z drift terms.")
+            if external_drift_x is None or external_drift_y is None:
+                raise ValueError("Must specify coordinates of external Z drift terms.")
+            external_drift = np.asarray(external_drift)
+            ex, ey = np.asarray(external_drift_x), np.asarray(external_drift_y)
+            if external_drift.shape[0] != ey.shape[0] or external_drift.shape[1] != ex.shape[0]:
+                if external_drift.shape[0] == ex.shape[0] and external_drift.shape[1] == ey.shape[0]:
+                    self.external_Z_array = np.array(external_drift.T)
+                else:
+                    raise ValueError("External drift dimensions do not match provided x- and y-coordinate dimensions.")
+            else:
+                self.external_Z_array = np.array(external_drift)
+            self.external_Z_array_x = np.array(ex).flatten()
+            self.external_Z_array_y = np.array(ey).flatten()
+            self.z_scalars = self._calculate_data_point_zscalars(self.X_ORIG, self.Y_ORIG)
+        self.point_log_drift = "point_log" in drift_terms
+        if self.point_log_drift:
+            if point_drift is None:
+                raise ValueError("Must specify location(s) and strength(s) of point drift terms.")
+            point_log = np.atleast_2d(np.squeeze(np.array(point_drift, copy=True, dtype=np.float64)))
+            self._point_log_user = point_log
+            self._adjust_wells()
+        self.specified_drift = "specified" in drift_terms
+        if self.specified_drift:
+            if type(specified_drift) is not list:
+                raise TypeError("Arrays for specified drift terms must be encapsulated in a list.")
+            if len(specified_drift) == 0:
+                raise ValueError("Must provide at least one drift-value array when using the 'specified' drift capability.")
+            self.specified_drift_data_arrays = []
+            for term in specified_drift:
+                specified = np.squeeze(np.array(term, copy=True))
+                if specified.size != self.X_ORIG.size:
+                    raise ValueError("Must specify the drift values for each data point when using the "
+                                     "'specified' drift capability.")
+                self.specified_drift_data_arrays.append(specified)
+        self.functional_drift = "functional" in drift_terms
+        if self.functional_drift:
+            if type(functional_drift) is not list:
+                raise TypeError("Callables for functional drift terms must be encapsulated in a list.")
+            if len(functional_drift) == 0:
+                raise ValueError("Must provide at least one callable object when using the 'functional' drift capability.")
+            self.functional_drift_terms = functional_drift
+
+    def _adjust_wells(self):
+        pl = self._point_log_user
+        self.point_log_array = np.zeros(pl.shape)
+        self.point_log_array[:, 2] = pl[:, 2]
+        self.point_log_array[:, :2] = core.adjust_for_anisotropy(np.vstack((pl[:, 0], pl[:, 1])).T, self._center(),
+                                                                 self._scaling(), self._angle())
+
+    def _update_anisotropy(self, anisotropy_scaling=None, anisotropy_angle=None):
+        OrdinaryKriging._update_anisotropy(self, anisotropy_scaling, anisotropy_angle)
+        if getattr(self, "point_log_drift", False):
+            self._adjust_wells()
+
+    def _calculate_data_point_zscalars(self, x, y, type_="array"):
+        return core.bilinear_zscalars(self.external_Z_array, self.external_Z_array_x, self.external_Z_array_y, x, y)
+
+    def _regional_linear(self):
+        return self.regional_linear_drift
+
+    def _wells(self):
+        return self.point_log_array if self.point_log_drift else None
+
+    def _station_extra_cols(self):
+        cols = []  # reference order after regional_linear and point_log: external_Z, specified, functional
+        if self.external_Z_drift:
+            cols.append(self.z_scalars)
+        if self.specified_drift:
+            cols.extend(self.specified_drift_data_arrays)
+        if self.functional_drift:
+            cols.extend(f(self.X_ADJUSTED, self.Y_ADJUSTED) for f in self.functional_drift_terms)
+        return np.array(cols, dtype=np.float64) if cols else None
+
+    def execute(self, style, xpoints, ypoints, mask=None, backend="vectorized", specified_drift_arrays=None):
+        """uk.py:1090-1328."""
+        if self.verbose:
+            print("Executing Universal Kriging...\n")
+        if style != "grid" and style != "masked" and style != "points":
+            raise ValueError("style argument must be 'grid', 'points', or 'masked'")
+        self._check_backend(backend, None)
+        pts, shape, mask = self._points_from(style, (xpoints, ypoints), mask)
+        rows = []
+        if self.external_Z_drift:  # on ORIGINAL coordinates (uk.py:967-971)
+            rows.append(self._calculate_data_point_zscalars(pts[:, 0], pts[:, 1]))
+        rows.extend(self._spec_rows(style, shape, pts.shape[0], specified_drift_arrays))
+        pts_adj = core.adjust_for_anisotropy(pts, self._center(), self._scaling(), self._angle())
+        if self.functional_drift:
+            rows.extend(np.asarray(f(pts_adj[:, 0], pts_adj[:, 1]), dtype=np.float64) for f in self.functional_drift_terms)
+        extra = np.array(rows, dtype=np.float64) if rows else None
+        z, ss = self._solve(pts_adj, mask, extra)
+        return self._finish(z, ss, style, shape, mask, backend)
+
+
+# =====================================================================================================
+class OrdinaryKriging3D(_KrigingBase):
+    """3D ordinary kriging (ok3d.py:40)."""
+
+    _ndim = 3
+    _label = "3D ordinary kriging"
+
+    def __init__(self, x, y, z, val, variogram_model="linear", variogram_parameters=None, variogram_function=None,
+                 nlags=6, weight=False, anisotropy_scaling_y=1.0, anisotropy_scaling_z=1.0, anisotropy_angle_x=0.0,
+                 anisotropy_angle_y=0.0, anisotropy_angle_z=0.0, verbose=False, enable_plotting=False,
+                 exact_values=True, pseudo_inv=False, pseudo_inv_type="pinv"):
+        self._init_common(variogram_model, variogram_parameters, variogram_function, exact_values, pseudo_inv,
+                          pseudo_inv_type, verbose, enable_plotting)
+        self.X_ORIG = np.atleast_1d(np.squeeze(np.array(x, copy=True, dtype=np.float64)))
+        self.Y_ORIG = np.atleast_1d(np.squeeze(np.array(y, copy=True, dtype=np.float64)))
+        self.Z_ORIG = np.atleast_1d(np.squeeze(np.array(z, copy=True, dtype=np.float64)))
+        self.VALUES = np.atleast_1d(np.squeeze(np.array(val, copy=True, dtype=np.float64)))
+        self.XCENTER = (np.amax(self.X_ORIG) + np.amin(self.X_ORIG)) / 2.0
+        self.YCENTER = (np.amax(self.Y_ORIG) + np.amin(self.Y_ORIG)) / 2.0
+        self.ZCENTER = (np.amax(self.Z_ORIG) + np.amin(self.Z_ORIG)) / 2.0
+        self.anisotropy_scaling_y = anisotropy_scaling_y
+        self.anisotropy_scaling_z = anisotropy_scaling_z
+        self.anisotropy_angle_x = anisotropy_angle_x
+        self.anisotropy_angle_y = anisotropy_angle_y
+        self.anisotropy_angle_z = anisotropy_angle_z
+        self._adjust_stations()
+        self._set_variogram_parameters(variogram_parameters, nlags, weight)
+        self.delta = self.sigma = self.epsilon = self.Q1 = self.Q2 = self.cR = None
+
+    def _center(self):
+        return [self.XCENTER, self.YCENTER, self.ZCENTER]
+
+    def _scaling(self):
+        return [self.anisotropy_scaling_y, self.anisotropy_scaling_z]
+
+    def _angle(self):
+        return [self.anisotropy_angle_x, self.anisotropy_angle_y, self.anisotropy_angle_z]
+
+    def _adjust_stations(self):
+        self._coords_adj = core.adjust_for_anisotropy(np.vstack((self.X_ORIG, self.Y_ORIG, self.Z_ORIG)).T,
+                                                      self._center(), self._scaling(), self._angle())
+        self.X_ADJUSTED, self.Y_ADJUSTED, self.Z_ADJUSTED = self._coords_adj.T
+
+    def _update_anisotropy(self, anisotropy_scaling_y=None, anisotropy_scaling_z=None, anisotropy_angle_x=None,
+                           anisotropy_angle_y=None, anisotropy_angle_z=None):
+        for k, v in (("anisotropy_scaling_y", anisotropy_scaling_y), ("anisotropy_scaling_z", anisotropy_scaling_z),
+                     ("anisotropy_angle_x", anisotropy_angle_x), ("anisotropy_angle_y", anisotropy_angle_y),
+                     ("anisotropy_angle_z", anisotropy_angle_z)):
+            if v is not None:
+                setattr(self, k, v)
+        self._adjust_stations()
+
+    def execute(self, style, xpoints, ypoints, zpoints, mask=None, backend="vectorized", n_closest_points=None):
+        """ok3d.py:735-932.  Output shape (nz, ny, nx) for grids."""
+        if self.verbose:
+            print("Executing Ordinary Kriging...\n")
+        if style != "grid" and style != "masked" and style != "points":
+            raise ValueError("style argument must be 'grid', 'points', or 'masked'")
+        self._check_backend(backend, n_closest_points)
+        pts, shape, mask = self._points_from(style, (xpoints, ypoints, zpoints), mask)
+        pts_adj = core.adjust_for_anisotropy(pts, self._center(), self._scaling(), self._angle())
+        z, ss = self._solve(pts_adj, mask, None)
+        return self._finish(z, ss, style, shape, mask, backend)
+
+
+# =====================================================================================================
+class UniversalKriging3D(OrdinaryKriging3D):
+    """3D universal kriging (uk3d.py:39): regional_linear on the device, specified / functional drifts
+    evaluated on the host."""
+
+    _universal = True
+    _label = "3D universal kriging"
+
+    def __init__(self, x, y, z, val, variogram_model="linear", variogram_parameters=None, variogram_function=None,
+                 nlags=6, weight=False, anisotropy_scaling_y=1.0, anisotropy_scaling_z=1.0, anisotropy_angle_x=0.0,
+                 anisotropy_angle_y=0.0, anisotropy_angle_z=0.0, drift_terms=None, specified_drift=None,
+                 functional_drift=None, verbose=False, enable_plotting=False, exact_values=True, pseudo_inv=False,
+                 pseudo_inv_type="pinv"):
+        OrdinaryKriging3D.__init__(self, x, y, z, val, variogram_model=variogram_model,
+                                   variogram_parameters=variogram_parameters, variogram_function=variogram_function,
+                                   nlags=nlags, weight=weight, anisotropy_scaling_y=anisotropy_scaling_y,
+                                   anisotropy_scaling_z=anisotropy_scaling_z, anisotropy_angle_x=anisotropy_angle_x,
+                                   anisotropy_angle_y=anisotropy_angle_y, anisotropy_angle_z=anisotropy_angle_z,
+                                   verbose=verbose, enable_plotting=enable_plotting, exact_values=exact_values,
+                                   pseudo_inv=pseudo_inv, pseudo_inv_type=pseudo_inv_type)
+        if drift_terms is None:
+            drift_terms = []
+        self.regional_linear_drift = "regional_linear" in drift_terms
+        self.specified_drift = "specified" in drift_terms
+        if self.specified_drift:
+            if type(specified_drift) is not list:
+                raise TypeError("Arrays for specified drift terms must be encapsulated in a list.")
+            if len(specified_drift) == 0:
+                raise ValueError("Must provide at least one drift-value array when using the 'specified' drift capability.")
+            self.specified_drift_data_arrays = []
+            for term in specified_drift:
+                specified = np.squeeze(np.array(term, copy=True))
+                if specified.size != self.X_ORIG.size:
+                    raise ValueError("Must specify the drift values for each data point when using the "
+                                     "'specified' drift capability.")
+                self.specified_drift_data_arrays.append(specified)
+        self.functional_drift = "functional" in drift_terms
+        if self.functional_drift:
+            if type(functional_drift) is not list:
+                raise TypeError("Callables for functional drift terms must be encapsulated in a list.")
+            if len(functional_drift) == 0:
+                raise ValueError("Must provide at least one callable object when using the 'functional' drift capability.")
+            self.functional_drift_terms = functional_drift
+
+    def _regional_linear(self):
+        return self.regional_linear_drift
+
+    def _station_extra_cols(self):
+        cols = []
+        if self.specified_drift:
+            cols.extend(self.specified_drift_data_arrays)
+        if self.functional_drift:
+            cols.extend(f(self.X_ADJUSTED, self.Y_ADJUSTED, self.Z_ADJUSTED) for f in self.functional_drift_terms)
+        return np.array(cols, dtype=np.float64) if cols else None
+
+    def execute(self, style, xpoints, ypoints, zpoints, mask=None, backend="vectorized", specified_drift_arrays=None):
+        """uk3d.py:877-1146."""
+        if self.verbose:
+            print("Executing Universal Kriging...\n")
+        if style != "grid" and style != "masked" and style != "points":
+            raise ValueError("style argument must be 'grid', 'points', or 'masked'")
+        self._check_backend(backend, None)
+        pts, shape, mask = self._points_from(style, (xpoints, ypoints, zpoints), mask)
+        rows = self._spec_rows(style, shape, pts.shape[0], specified_drift_arrays)
+        pts_adj = core.adjust_for_anisotropy(pts, self._center(), self._scaling(), self._angle())
+        if self.functional_drift:
+            rows.extend(np.asarray(f(pts_adj[:, 0], pts_adj[:, 1], pts_adj[:, 2]), dtype=np.float64)
+                        for f in self.functional_drift_terms)
+        extra = np.array(rows, dtype=np.float64) if rows else None
+        z, ss = self._solve(pts_adj, mask, extra)
+        return self._finish(z, ss, style, shape, mask, backend)

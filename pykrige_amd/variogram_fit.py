@@ -1,0 +1,55 @@
+"""Constructor-time variogram estimation (host, SciPy) -- NOT on the execute() path.
+
+Used only when a kriging object is built without explicit variogram parameters.  Restates the
+behaviour of the reference's _initialize_variogram_model / _calculate_variogram_model
+(/root/reference/src/pykrige/core.py:379-651): equal-width lag bins over the pairwise distances,
+bin means of distance and semivariance, then a bounded soft-L1 least-squares fit of the model.
+SURVEY.md section 8(f) rank 4 lists moving the O(N^2) pair reduction to the GPU as a later step.
+"""
+import numpy as np
+from scipy.optimize import least_squares
+from scipy.spatial.distance import pdist
+
+from . import core
+
+
+def experimental_variogram(coords, values, nlags):
+    d = pdist(coords, metric="euclidean")
+    g = 0.5 * pdist(np.asarray(values, dtype=np.float64)[:, None], metric="sqeuclidean")
+    dmin, dmax = np.amin(d), np.amax(d)
+    width = (dmax - dmin) / nlags
+    edges = [dmin + k * width for k in range(nlags)] + [dmax + 0.001]
+    lags, semis = [], []
+    for k in range(nlags):
+        sel = (d >= edges[k]) & (d < edges[k + 1])
+        if sel.any():
+            lags.append(np.mean(d[sel]))
+            semis.append(np.mean(g[sel]))
+    return np.array(lags), np.array(semis)
+
+
+def _residuals(params, lags, semis, model, weight):
+    r = core.variogram_value(model, params, lags) - semis
+    if weight:  # logistic weights centred at 70 % of the lag range
+        span = np.amax(lags) - np.amin(lags)
+        k = 2.1972 / (0.1 * span)
+        x0 = 0.7 * span + np.amin(lags)
+        w = 1.0 / (1.0 + np.exp(-k * (x0 - lags)))
+        r = r * (w / np.sum(w))
+    return r
+
+
+def fit(coords, values, model, nlags=6, weight=False):
+    lags, semis = experimental_variogram(coords, values, nlags)
+    smax, smin, lmax, lmin = np.amax(semis), np.amin(semis), np.amax(lags), np.amin(lags)
+    if model == "linear":
+        x0 = [(smax - smin) / (lmax - lmin), smin]
+        bounds = ([0.0, 0.0], [np.inf, smax])
+    elif model == "power":
+        x0 = [(smax - smin) / (lmax - lmin), 1.1, smin]
+        bounds = ([0.0, 0.001, 0.0], [np.inf, 1.999, smax])
+    else:
+        x0 = [smax - smin, 0.25 * lmax, smin]
+        bounds = ([0.0, 0.0, 0.0], [10.0 * smax, lmax, smax])
+    res = least_squares(_residuals, x0, bounds=bounds, loss="soft_l1", args=(lags, semis, model, weight))
+    return lags, semis, list(res.x)

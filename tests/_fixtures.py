@@ -48,3 +48,55 @@ def grid_args(g):
     if "gridz" in g:
         return (g["gridx"], g["gridy"], g["gridz"])
     return (g["gridx"], g["gridy"])
+
+
+def amd_model_from(name, g):
+    """pykrige_amd kriging object for a golden fixture (same constructor keywords as the reference)."""
+    import pykrige_amd as pa
+
+    ndim = 3 if "zc" in g else 2
+    model = str(g["model"])
+    params = [float(v) for v in g["params_user"].tolist()]
+    exact = bool(g["exact"]) if "exact" in g else True
+    rl = bool(g["regional_linear"]) if "regional_linear" in g else name in ("uk2d_spec_func", "uk3d_rl_func")
+    terms = []
+    kw = {}
+    if rl:
+        terms.append("regional_linear")
+    if "wells" in g:
+        terms.append("point_log")
+        kw["point_drift"] = g["wells"]
+    if "spec_data" in g:
+        terms.append("specified")
+        kw["specified_drift"] = [g["spec_data"]]
+    if name in FUNCS:
+        terms.append("functional")
+        kw["functional_drift"] = FUNCS[name]
+    if ndim == 2:
+        aniso = dict(anisotropy_scaling=float(g["scaling"]) if "scaling" in g else 1.0,
+                     anisotropy_angle=float(g["angle"]) if "angle" in g else 0.0)
+        if terms:
+            return pa.UniversalKriging(g["x"], g["y"], g["v"], variogram_model=model, variogram_parameters=params,
+                                       drift_terms=terms, exact_values=exact, **aniso, **kw)
+        return pa.OrdinaryKriging(g["x"], g["y"], g["v"], variogram_model=model, variogram_parameters=params,
+                                  exact_values=exact, **aniso)
+    sc = np.atleast_1d(g["scaling"]).tolist() if "scaling" in g else [1.0, 1.0]
+    an = np.atleast_1d(g["angle"]).tolist() if "angle" in g else [0.0, 0.0, 0.0]
+    aniso = dict(anisotropy_scaling_y=sc[0], anisotropy_scaling_z=sc[1], anisotropy_angle_x=an[0],
+                 anisotropy_angle_y=an[1], anisotropy_angle_z=an[2])
+    if terms:
+        return pa.UniversalKriging3D(g["x"], g["y"], g["zc"], g["v"], variogram_model=model, variogram_parameters=params,
+                                     drift_terms=terms, exact_values=exact, **aniso, **kw)
+    return pa.OrdinaryKriging3D(g["x"], g["y"], g["zc"], g["v"], variogram_model=model, variogram_parameters=params,
+                                exact_values=exact, **aniso)
+
+
+def synth(seed, n, ndim):
+    """SURVEY.md 8(d) synthetic stations: uniform in the unit square/cube, smooth field + noise."""
+    rng = np.random.default_rng(seed)
+    c = [rng.random(n) for _ in range(ndim)]
+    v = np.sin(6 * c[0]) * np.cos(4 * c[1])
+    if ndim == 3:
+        v = v * np.cos(3 * c[2])
+    v = v + 0.1 * rng.standard_normal(n)
+    return c, v

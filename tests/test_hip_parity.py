@@ -1,0 +1,251 @@
+"""GPU parity tests: the HIP path (through the C ABI, via the pykrige_amd classes or the raw handle)
+against (a) golden vectors computed by the real reference (tests/golden, PyKrige 1.7.3
+backend='vectorized') and (b) the CPU oracle on seeded synthetic inputs.
+
+Tolerances are BASELINE.json's: |dz| <= 1e-8 and |dsigma^2| <= 1e-6 (absolute, on O(1) fields; for the
+two reference fixtures whose values are O(100-1000) the z tolerance is scaled by max|z|)."""
+import numpy as np
+import pytest
+
+from oracle import kriging_oracle as ko
+from tests import _fixtures as fx
+
+pytestmark = pytest.mark.gpu
+
+Z_TOL, SS_TOL = 1e-8, 1e-6
+
+
+def _lib():
+    from pykrige_amd import _lib
+
+    return _lib
+
+
+def test_library_sees_a_gpu_and_mfma_layout():
+    lib = _lib()
+    assert lib.load().mik_device_count() >= 1
+    lib.selftest_mfma(0)  # raises on a fragment-layout mismatch
+
+
+def _handle_for(st, **opts):
+    lib = _lib()
+    h = lib.Handle(0)
+    for k, v in opts.items():
+        h.set_option(k, v)
+    wells = st.wells_adj
+    extra = []
+    extra += list(st.specified_data)
+    extra += [f(*[st.coords_adj[:, k] for k in range(st.ndim)]) for f in st.functional]
+    h.set_problem(ndim=st.ndim, xs=st.coords_adj[:, 0], ys=st.coords_adj[:, 1],
+                  zs=st.coords_adj[:, 2] if st.ndim == 3 else None, values=st.values,
+                  model_id=lib.MODEL_IDS[st.model], params=st.params, exact_values=st.exact_values,
+                  regional_linear=st.regional_linear, wells=wells, extra_cols=np.array(extra) if extra else None)
+    return h
+
+
+@pytest.mark.parametrize("name", [n for n in fx.names() if "A" in fx.load(n)])
+def test_kriging_matrix_matches_reference(name):
+    g = fx.load(name)
+    st = fx.state_from(name, g)
+    h = _handle_for(st)
+    h.assemble_only()
+    a = h.get_matrix(0)
+    np.testing.assert_allclose(a, g["A"], rtol=0, atol=1e-12 * max(1.0, np.abs(g["A"]).max()))
+
+
+@pytest.mark.parametrize("factor", [1, 2])
+@pytest.mark.parametrize("name", ["ok2d_exponential_exact", "ok2d_spherical_exact", "uk2d_rl_pl", "ok3d_gaussian_aniso",
+                                  "ok2d_n2000"])
+def test_device_inverse_matches_lapack(name, factor):
+    import scipy.linalg
+
+    g = fx.load(name)
+    st = fx.state_from(name, g)
+    h = _handle_for(st, factor=factor)
+    h.factor()
+    assert h.timing()["factor_path"] == factor
+    ainv = h.get_matrix(1)
+    a = ko.kriging_matrix(st)
+    ref = scipy.linalg.inv(a)
+    # forward error of an inverse ~ cond * eps * |A^-1|
+    scale = np.abs(ref).max()
+    assert np.abs(ainv - ref).max() <= 1e-9 * scale
+    resid = np.abs(a @ ainv - np.eye(a.shape[0])).max()
+    assert resid <= 1e-8
+
+
+@pytest.mark.parametrize("name", ["ok2d_linear_exact", "ok2d_power_exact"])
+def test_unbounded_models_take_the_pivoted_path_by_default(name):
+    g = fx.load(name)
+    m = fx.amd_model_from(name, g)
+    z, ss = m.execute("grid", *fx.grid_args(g), backend="loop")
+    assert m.last_timing["factor_path"] == 2
+    np.testing.assert_allclose(z, g["z"], rtol=0, atol=Z_TOL)
+    np.testing.assert_allclose(ss, g["ss"], rtol=0, atol=SS_TOL)
+
+
+@pytest.mark.parametrize("name", [n for n in fx.names() if "z" in fx.load(n)])
+def test_execute_grid_matches_reference(name):
+    g = fx.load(name)
+    m = fx.amd_model_from(name, g)
+    kw = {}
+    if "spec_grid" in g:
+        kw["specified_drift_arrays"] = [g["spec_grid"]]
+    z, ss = m.execute("grid", *fx.grid_args(g), backend="vectorized", **kw)
+    assert isinstance(z, np.ma.MaskedArray) and z.shape == g["z"].shape  # the reference's 'vectorized' return type
+    zscale = max(1.0, float(np.abs(g["z"]).max()))
+    sscale = max(1.0, float(np.abs(g["ss"]).max()))
+    np.testing.assert_allclose(np.ma.getdata(z), g["z"], rtol=0, atol=Z_TOL * zscale)
+    np.testing.assert_allclose(np.ma.getdata(ss), g["ss"], rtol=0, atol=SS_TOL * sscale)
+    z2, ss2 = m.execute("grid", *fx.grid_args(g), backend="loop", **kw)
+    assert type(z2) is np.ndarray
+    np.testing.assert_array_equal(z2, np.ma.getdata(z))
+
+
+def test_external_known_answers():
+    """KT3D_H2O / KT3D grids the reference's own tests pin (tests/test_core.py:490-507, 707-725, 1914-1989)."""
+    g = fx.load("ref_test_ok")
+    z, _ = fx.amd_model_from("ref_test_ok", g).execute("grid", g["gridx"], g["gridy"], backend="loop")
+    np.testing.assert_allclose(z, g["answer"], rtol=1e-5, atol=1e-8)
+    g = fx.load("ref_test_uk")
+    z, _ = fx.amd_model_from("ref_test_uk", g).execute("grid", g["gridx"], g["gridy"], backend="loop")
+    np.testing.assert_allclose(z, g["answer"], rtol=1e-5, atol=1e-8)
+    g = fx.load("ref_test_ok3d")
+    z, ss = fx.amd_model_from("ref_test_ok3d", g).execute("grid", g["gridx"], g["gridy"], g["gridz"], backend="loop")
+    np.testing.assert_allclose(z, g["answer_z"], rtol=1e-3, atol=1e-8)
+    np.testing.assert_allclose(ss, g["answer_ss"], rtol=1e-3, atol=1e-8)
+
+
+def test_masked_and_points_styles():
+    g = fx.load("ok2d_masked_points")
+    m = fx.amd_model_from("ok2d_masked_points", g)
+    z, ss = m.execute("masked", g["gridx"], g["gridy"], mask=g["mask"], backend="loop")
+    assert isinstance(z, np.ma.MaskedArray) and z.shape == g["mask"].shape
+    keep = ~g["mask"]
+    np.testing.assert_allclose(np.ma.getdata(z)[keep], g["z_masked"][keep], rtol=0, atol=Z_TOL)
+    np.testing.assert_allclose(np.ma.getdata(ss)[keep], g["ss_masked"][keep], rtol=0, atol=SS_TOL)
+    assert np.all(np.ma.getdata(z)[g["mask"]] == 0.0) and z[g["mask"]].mask.all()
+    zt, _ = m.execute("masked", g["gridx"], g["gridy"], mask=g["mask"].T, backend="loop")  # auto-transpose
+    np.testing.assert_array_equal(np.ma.getdata(zt), np.ma.getdata(z))
+    zp, ssp = m.execute("points", g["px"], g["py"], backend="C")
+    np.testing.assert_allclose(zp, g["z_points"], rtol=0, atol=Z_TOL)
+    np.testing.assert_allclose(ssp, g["ss_points"], rtol=0, atol=SS_TOL)
+    # first four points sit on stations: exact interpolation
+    np.testing.assert_allclose(zp[:4], g["v"][:4], rtol=0, atol=Z_TOL)
+    assert np.all(np.abs(ssp[:4]) <= SS_TOL)
+    g3 = fx.load("ok3d_gaussian_aniso")
+    m3 = fx.amd_model_from("ok3d_gaussian_aniso", g3)
+    z3, ss3 = m3.execute("masked", g3["gridx"], g3["gridy"], g3["gridz"], mask=g3["mask"], backend="loop")
+    keep = ~g3["mask"]
+    np.testing.assert_allclose(np.ma.getdata(z3)[keep], g3["z_masked"][keep], rtol=0, atol=Z_TOL)
+    np.testing.assert_allclose(np.ma.getdata(ss3)[keep], g3["ss_masked"][keep], rtol=0, atol=SS_TOL)
+
+
+def test_errors_mirror_the_reference():
+    import pykrige_amd as pa
+
+    (x, y), v = fx.synth(7, 30, 2)
+    ok = pa.OrdinaryKriging(x, y, v, variogram_model="exponential", variogram_parameters=[1.0, 0.3, 0.0])
+    with pytest.raises(ValueError):
+        ok.execute("blurg", [0.0, 1.0], [0.0, 1.0])
+    with pytest.raises(IOError):
+        ok.execute("masked", [0.0, 1.0], [0.0, 1.0])
+    with pytest.raises(ValueError):
+        ok.execute("masked", [0.0, 1.0], [0.0, 1.0, 2.0], mask=np.zeros((5, 5), bool))
+    with pytest.raises(ValueError):
+        ok.execute("points", [0.0, 1.0], [0.0, 1.0, 2.0])
+    with pytest.raises(ValueError):
+        ok.execute("grid", [0.0, 1.0], [0.0, 1.0], backend="mystery")
+    z, ss = ok.execute("grid", np.arange(3), np.arange(2), backend="loop")  # integer axes are cast, not a crash
+    assert z.shape == (2, 3)
+    dup = pa.OrdinaryKriging([0.0, 0.0, 1.0], [0.0, 0.0, 1.0], [1.0, 1.0, 2.0], variogram_model="linear",
+                             variogram_parameters=[1.0, 0.0])
+    with pytest.raises(np.linalg.LinAlgError):  # duplicate stations: scipy.linalg.inv raises LinAlgError
+        dup.execute("grid", [0.5], [0.5], backend="loop")
+    pin = pa.OrdinaryKriging([0.0, 0.0, 1.0, 2.0], [0.0, 0.0, 1.0, 0.5], [1.0, 1.0, 2.0, 3.0], variogram_model="linear",
+                             variogram_parameters=[1.0, 0.0], pseudo_inv=True)
+    z, ss = pin.execute("grid", [0.5], [0.5], backend="loop")  # test_core.py:2913-2929: pinv averages duplicates
+    assert np.isfinite(z).all()
+
+
+@pytest.mark.parametrize("cfg", ["ok2d_exp", "ok2d_sph", "ok3d_gau", "uk2d_rl_pl"])
+def test_synthetic_n1500_against_oracle(cfg):
+    """Seeded SURVEY 8(d)-style inputs at a size the oracle finishes in seconds, with grid nodes on
+    stations (eps rule), several contraction chunks (chunk=1024) and both symmetric settings."""
+    import pykrige_amd as pa
+
+    n = 1500
+    if cfg == "ok3d_gau":
+        (x, y, zc), v = fx.synth(3, n, 3)
+        axes = [np.linspace(0, 1, 21), np.linspace(0, 1, 17), np.linspace(0, 1, 9)]
+        for k in range(8):
+            x[k], y[k], zc[k] = axes[0][2 * k], axes[1][k], axes[2][k]
+        m = pa.OrdinaryKriging3D(x, y, zc, v, variogram_model="gaussian", variogram_parameters=[1.0, 0.4, 0.02])
+        st = ko.KrigingState(ndim=3, coords_orig=np.stack([x, y, zc], 1), values=v, model="gaussian",
+                             params=ko.internal_parameters("gaussian", [1.0, 0.4, 0.02]), scaling=[1.0, 1.0],
+                             angle=[0.0, 0.0, 0.0])
+    else:
+        (x, y), v = fx.synth(2, n, 2)
+        axes = [np.linspace(0, 1, 61), np.linspace(0, 1, 53)]
+        for k in range(8):
+            x[k], y[k] = axes[0][5 * k + 1], axes[1][3 * k + 2]
+        if cfg == "uk2d_rl_pl":
+            wells = [[0.3137, 0.7219, 1.0], [0.6621, 0.2483, -0.5], [0.8412, 0.8127, 2.0]]
+            m = pa.UniversalKriging(x, y, v, variogram_model="exponential", variogram_parameters=[1.0, 0.3, 0.01],
+                                    drift_terms=["regional_linear", "point_log"], point_drift=wells)
+            st = ko.KrigingState(ndim=2, coords_orig=np.stack([x, y], 1), values=v, model="exponential",
+                                 params=ko.internal_parameters("exponential", [1.0, 0.3, 0.01]), regional_linear=True,
+                                 point_log=np.array(wells))
+        else:
+            model, par = ("exponential", [1.0, 0.3, 0.0]) if cfg == "ok2d_exp" else ("spherical", [1.0, 0.2, 0.01])
+            m = pa.OrdinaryKriging(x, y, v, variogram_model=model, variogram_parameters=par)
+            st = ko.KrigingState(ndim=2, coords_orig=np.stack([x, y], 1), values=v, model=model,
+                                 params=ko.internal_parameters(model, par))
+    zr, sr = ko.execute(st, "grid", *axes)
+    h = m._get_handle()
+    outs = []
+    for sym in (1, 0):
+        h.set_option("symmetric", sym)
+        h.set_option("chunk", 1024)
+        z, ss = m.execute("grid", *axes, backend="loop")
+        assert m.last_timing["contract_launches"] >= 3
+        np.testing.assert_allclose(z, zr, rtol=0, atol=Z_TOL)
+        np.testing.assert_allclose(ss, sr, rtol=0, atol=SS_TOL)
+        outs.append((z, ss))
+    np.testing.assert_allclose(outs[0][1], outs[1][1], rtol=0, atol=1e-9)
+    # exact-hit nodes: z == datum, sigma^2 == 0 (tests/test_core.py:1510-1834 semantics)
+    pts = m.execute("points", x[:8], y[:8], *([zc[:8]] if cfg == "ok3d_gau" else []), backend="loop")
+    np.testing.assert_allclose(pts[0], v[:8], rtol=0, atol=Z_TOL)
+    assert np.all(np.abs(pts[1]) <= SS_TOL)
+
+
+def test_full_size_config2_properties():
+    """BASELINE config 2 at full size (N=5000, 1000x1000 grid, exponential [1,0.3,0]): size-independent
+    properties + one 4096-point slab against the oracle."""
+    import pykrige_amd as pa
+
+    n = 5000
+    (x, y), v = fx.synth(2, n, 2)
+    gx = gy = np.linspace(0.0, 1.0, 1000)
+    for k in range(8):
+        x[k], y[k] = gx[100 * k + 7], gy[90 * k + 11]
+    ok = pa.OrdinaryKriging(x, y, v, variogram_model="exponential", variogram_parameters=[1.0, 0.3, 0.0])
+    z, ss = ok.execute("grid", gx, gy, backend="loop")
+    assert z.shape == (1000, 1000) and np.isfinite(z).all() and np.isfinite(ss).all()
+    # (1) exact interpolation at the 8 nodes that coincide with stations
+    for k in range(8):
+        assert abs(z[90 * k + 11, 100 * k + 7] - v[k]) <= Z_TOL
+        assert abs(ss[90 * k + 11, 100 * k + 7]) <= SS_TOL
+    # (2) kriging variance bounds: 0 <= sigma^2 <= sill + |mu| slack ; here simply within [ -tol, 2*sill ]
+    assert ss.min() >= -SS_TOL and ss.max() <= 2.0
+    # (3) linearity in the data: z(v + c) = z(v) + c for a constant shift (weights sum to one)
+    ok2 = pa.OrdinaryKriging(x, y, v + 3.25, variogram_model="exponential", variogram_parameters=[1.0, 0.3, 0.0])
+    zs, sss = ok2.execute("grid", gx, gy[500:504], backend="loop")
+    np.testing.assert_allclose(zs, z[500:504] + 3.25, rtol=0, atol=Z_TOL)
+    np.testing.assert_allclose(sss, ss[500:504], rtol=0, atol=1e-9)
+    # (4) a 4-row slab against the CPU oracle
+    st = ko.KrigingState(ndim=2, coords_orig=np.stack([x, y], 1), values=v, model="exponential",
+                         params=ko.internal_parameters("exponential", [1.0, 0.3, 0.0]))
+    zr, sr = ko.execute(st, "grid", gx, gy[500:504])
+    np.testing.assert_allclose(z[500:504], zr, rtol=0, atol=Z_TOL)
+    np.testing.assert_allclose(ss[500:504], sr, rtol=0, atol=SS_TOL)
