@@ -119,6 +119,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=8192)
     ap.add_argument("--symmetric", type=int, default=None)
     ap.add_argument("--chunk", type=int, default=None)
+    ap.add_argument("--engine", choices=["mfma", "valu"], default=None)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -150,6 +151,8 @@ def main():
         h.set_option("symmetric", args.symmetric)
     if args.chunk is not None:
         h.set_option("chunk", args.chunk)
+    if args.engine is not None:
+        h.set_option("engine", 1 if args.engine == "valu" else 0)
     wells = np.array(cfg["wells"]) if cfg.get("wells") else None
     h.set_problem(ndim=ndim, xs=coords[0], ys=coords[1], zs=coords[2] if ndim == 3 else None, values=values,
                   model_id=_lib.MODEL_IDS[cfg["model"]], params=internal_params(cfg["model"], cfg["params"]),
@@ -199,7 +202,7 @@ def main():
             t = h.timing()
             for k in ("rhs_ms", "contract_ms", "predict_ms", "contract_launches", "contract_flops_executed"):
                 tsum[k] += t[k]
-            tsum["factor_path"], tsum["symmetric"] = t["factor_path"], t["symmetric"]
+            tsum["factor_path"], tsum["symmetric"], tsum["engine"] = t["factor_path"], t["symmetric"], t["engine"]
 
     for _ in range(args.warmup):
         step(False)
@@ -239,7 +242,7 @@ def main():
                        "factor_path": {1: "spd-shift block sweep", 2: "pivoted block gauss-jordan", 3: "host inverse"}.get(
                            tsum.get("factor_path"), "?"),
                        "symmetric_contraction": bool(tsum.get("symmetric"))},
-            "roofline": {"bound": "mfma", "kernel": "k_contract", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
+            "roofline": {"bound": "mfma", "kernel": "k_contract_valu" if tsum.get("engine") else "k_contract", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
                          "executed_tflops": executed, "avg_launch_ms": avg_launch_s * 1e3,
                          "launches_per_step": launches / K, "algorithmic_flops_per_point": 2.0 * M * M},

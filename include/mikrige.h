@@ -86,6 +86,8 @@ typedef struct mik_timing {
   double contract_flops_executed; /* flops the contraction kernel really executed (symmetric form: ~M^2/pt) */
   int32_t factor_path;    /* 1 = unpivoted symmetric block sweep on the SPD-shifted matrix, 2 = pivoted block Gauss-Jordan, 3 = host-supplied inverse */
   int32_t symmetric;      /* 1 = contraction used the symmetric half product */
+  int32_t engine;         /* 0 = v_mfma_f64_16x16x4_f64 contraction, 1 = v_fma_f64 register-tiled contraction */
+  int32_t reserved;
 } mik_timing;
 
 int  mik_device_count(void);
@@ -93,6 +95,7 @@ int  mik_create(int device, mik_handle **out);
 void mik_destroy(mik_handle *h);
 
 /* options: "factor" 0=auto 1=sweep 2=pivoted ; "symmetric" 0/1 (contraction uses A_inv symmetry) ;
+ * "engine" 0 = MFMA f64 contraction, 1 = VALU (v_fma_f64) contraction ;
  * "chunk" = points per contraction launch (multiple of 128) */
 int  mik_set_option(mik_handle *h, const char *key, double value);
 

@@ -39,6 +39,7 @@ class MikTiming(C.Structure):
         ("assemble_ms", C.c_double), ("invert_ms", C.c_double), ("rhs_ms", C.c_double),
         ("contract_ms", C.c_double), ("predict_ms", C.c_double), ("contract_launches", C.c_int64),
         ("contract_flops_executed", C.c_double), ("factor_path", C.c_int32), ("symmetric", C.c_int32),
+        ("engine", C.c_int32), ("reserved", C.c_int32),
     ]
 
     def as_dict(self):

@@ -260,76 +260,98 @@ __global__ void __launch_bounds__(256) k_rhs(RhsArgs a) {
 
 // ------------------------------------------------------------------------------------------------
 // The fp64 MFMA "NT" GEMM core:  acc[i][t] += sum_k A[i][k] * B[t][k]   (both operands k-contiguous)
-// Block tile 128 x 128, 4 waves as 2 x 2, wave tile 64 x 64 = 4 x 4 fragments of
-// v_mfma_f64_16x16x4_f64 (A: lane l holds A[l&15][l>>4]; B: lane l holds B[l>>4][l&15];
-// C/D: 4 doubles per lane, col = l&15, row = (l>>4) + 4*reg -- cdna_hip_programming.md:247-251).
-// K is staged in tiles of 16 through double-buffered LDS (global -> registers -> LDS, one barrier per
-// tile).  LDS row stride 18 doubles: 16-byte aligned for ds_write_b128 and conflict-free for the
-// fragment ds_read_b64 (bank = (36*row + 2*k) mod 64 covers all 64 banks once per 32 lanes).
+// Block tile 128 x 128, 4 waves as 2 x 2, wave tile 64 x 64.  The matrix instruction is
+// v_mfma_f64_4x4x4_4b_f64 (4 independent 4x4x4 blocks, 512 flop, ONE accumulator double per lane):
+// measured 73 TFLOP/s from one wave per SIMD (16 cycles/instruction) against 47-49 TFLOP/s for
+// v_mfma_f64_16x16x4_f64 (~100 cycles for 2048 flop) -- tools/ubench_f64.hip, profiles/.  Its lane
+// mapping was probed on the device (tools/probe_mfma4.hip): A lane (k=l>>4, blk=(l>>2)&3, i=l&3),
+// B lane (k, blk, j=l&3), D lane (i=l>>4, blk, j=l&3).  The 64 accumulator doubles of a lane are kept as
+// acc[ai][bi][r] <-> row 16*ai + 4*r + (l>>4), column 16*bi + (l&15) of the wave tile.
+// K is staged in tiles of 16 through double-buffered LDS by LDS-DMA, one barrier per tile.
 // ------------------------------------------------------------------------------------------------
 #define MIK_BM 128
 #define MIK_BN 128
 #define MIK_BK 16
-#define MIK_LS 18
 
+// K tiles of 128 rows x 16 doubles, UNPADDED (row = 128 B = 8 slots of 16 B) so that the image is
+// lane-linear and can be filled by LDS-DMA (global_load_lds_dwordx4: LDS address = wave base + 16*lane,
+// no staging VGPRs, no ds_write).  Bank conflicts of the fragment reads are removed by an XOR swizzle
+// applied to the per-lane SOURCE address and to the reads: element (row r, k) lives in 16-byte slot
+// ((k>>1) ^ swz(r)) of row r, swz = r & 2 for the A tile and (r>>1) & 7 for the B tile.
 struct GemmSmem {
-  double As[2][MIK_BM][MIK_LS];
-  double Bs[2][MIK_BN][MIK_LS];
+  double As[2][MIK_BM][MIK_BK];
+  double Bs[2][MIK_BN][MIK_BK];
 };
+
+typedef __attribute__((address_space(1))) const void* mik_gptr_t;
+typedef __attribute__((address_space(3))) void* mik_lptr_t;
+
+__device__ __forceinline__ void glds16(const double* g, double* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((mik_gptr_t)g, (mik_lptr_t)lds_wave_base, 16, 0, 0);
+}
 
 __device__ __forceinline__ void gemm_core(const double* __restrict__ Ag, long lda, const double* __restrict__ Bg,
                                           long ldb, int kbeg, int kend, d4 (&acc)[4][4], GemmSmem& sm) {
   if (kbeg >= kend) return;  // block-uniform
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int lrow = tid >> 3, lcol = (tid & 7) * 2;
-  const double* ap = Ag + (long)lrow * lda + lcol;
-  const double* bp = Bg + (long)lrow * ldb + lcol;
-  double2 ra[4], rb[4];
+  // staging: thread -> (row lrow + 32p, 16-byte slot tid&7); the SOURCE k-pair is the slot XOR the row's swizzle
+  // (A tile: r & 2; B tile: (r>>1) & 7 -- see the fragment reads below).  Both are pass-independent.
+  const int lrow = tid >> 3, slot = tid & 7;
+  const double* ap = Ag + (long)lrow * lda + ((slot ^ (lrow & 2)) << 1);
+  const double* bp = Bg + (long)lrow * ldb + ((slot ^ ((lrow >> 1) & 7)) << 1);
+  const long a32 = 32 * lda, b32 = 32 * ldb;
+  const int wrow = wave * 8;  // this wave's 8 rows (1 KiB) inside each 32-row pass
+  // Fragment reads are ds_read_b128: lane group kq = lane>>4 owns the k PAIR c = 4m + kq of the 16-wide
+  // tile (m = 0, 1), i.e. MFMA step t = 2m + h contracts k = 8m + 2kq + h -- the same bijection of k on
+  // both operands.  A: row wm*64 + 4x + i (i = lane&3), identical for the 4 blocks (broadcast);
+  // B: row wn*64 + 16x + j (j = lane&15).  With the swizzles above both patterns are bank-conflict
+  // free in every 16-lane ds_read_b128 service group.
+  const int kq = lane >> 4, ia = lane & 3, jb = lane & 15;
+  int aoff[2], boff[2];
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    ra[p] = *reinterpret_cast<const double2*>(ap + (long)(32 * p) * lda + kbeg);
-    rb[p] = *reinterpret_cast<const double2*>(bp + (long)(32 * p) * ldb + kbeg);
+  for (int m = 0; m < 2; ++m) {
+    aoff[m] = (wm * 64 + ia) * MIK_BK + (((4 * m + kq) ^ (ia & 2)) << 1);
+    boff[m] = (wn * 64 + jb) * MIK_BK + (((4 * m + kq) ^ ((jb >> 1) & 7)) << 1);
   }
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
-    *reinterpret_cast<double2*>(&sm.As[0][lrow + 32 * p][lcol]) = ra[p];
-    *reinterpret_cast<double2*>(&sm.Bs[0][lrow + 32 * p][lcol]) = rb[p];
+    glds16(ap + p * a32 + kbeg, &sm.As[0][wrow + 32 * p][0]);
+    glds16(bp + p * b32 + kbeg, &sm.Bs[0][wrow + 32 * p][0]);
   }
   __syncthreads();
   int buf = 0;
-  const int ar = wm * 64 + (lane & 15), br = wn * 64 + (lane & 15), kq = lane >> 4;
   for (int k = kbeg; k < kend; k += MIK_BK) {
-    const bool more = (k + MIK_BK) < kend;
-    if (more) {
+    if ((k + MIK_BK) < kend) {
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
-        ra[p] = *reinterpret_cast<const double2*>(ap + (long)(32 * p) * lda + k + MIK_BK);
-        rb[p] = *reinterpret_cast<const double2*>(bp + (long)(32 * p) * ldb + k + MIK_BK);
+        glds16(ap + p * a32 + k + MIK_BK, &sm.As[buf ^ 1][wrow + 32 * p][0]);
+        glds16(bp + p * b32 + k + MIK_BK, &sm.Bs[buf ^ 1][wrow + 32 * p][0]);
       }
     }
+    const double* as = &sm.As[buf][0][0];
+    const double* bs = &sm.Bs[buf][0][0];
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      double fa[4], fb[4];
+    for (int m = 0; m < 2; ++m) {
+      // v_mfma_f64_4x4x4_4b_f64: A lane (k=l>>4, blk=(l>>2)&3, i=l&3), B lane (k, blk, j=l&3), D lane (i=l>>4, blk, j).
+      // A fragments are replicated over the 4 blocks, B fragments put 4 column groups in the 4 blocks, so
+      // MFMA (ra, bi) yields rows 4*ra + (l>>4), columns 16*bi + (l&15) of the wave tile.
+      double2 fa[16], fb[4];
 #pragma unroll
-      for (int x = 0; x < 4; ++x) {
-        fa[x] = sm.As[buf][ar + 16 * x][kk * 4 + kq];
-        fb[x] = sm.Bs[buf][br + 16 * x][kk * 4 + kq];
-      }
+      for (int x = 0; x < 16; ++x) fa[x] = *reinterpret_cast<const double2*>(as + aoff[m] + 4 * x * MIK_BK);
+#pragma unroll
+      for (int x = 0; x < 4; ++x) fb[x] = *reinterpret_cast<const double2*>(bs + boff[m] + 16 * x * MIK_BK);
 #pragma unroll
       for (int ai = 0; ai < 4; ++ai)
 #pragma unroll
-        for (int bi = 0; bi < 4; ++bi)
-          acc[ai][bi] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[ai], fb[bi], acc[ai][bi], 0, 0, 0);
-    }
-    if (more) {
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        *reinterpret_cast<double2*>(&sm.As[buf ^ 1][lrow + 32 * p][lcol]) = ra[p];
-        *reinterpret_cast<double2*>(&sm.Bs[buf ^ 1][lrow + 32 * p][lcol]) = rb[p];
-      }
+          for (int bi = 0; bi < 4; ++bi) {
+            acc[ai][bi][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa[4 * ai + r].x, fb[bi].x, acc[ai][bi][r], 0, 0, 0);
+            acc[ai][bi][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa[4 * ai + r].y, fb[bi].y, acc[ai][bi][r], 0, 0, 0);
+          }
     }
-    __syncthreads();
+    __syncthreads();  // hipcc drains the outstanding LDS-DMA (vmcnt(0)) before the barrier
     buf ^= 1;
   }
 }
@@ -404,6 +426,150 @@ k_contract(const double* __restrict__ Ainv, long lda, const double* __restrict__
   __syncthreads();
   if (threadIdx.x < 128) {
     const double v = red[threadIdx.x] + red[128 + threadIdx.x];
+    part[(long)iblk * palloc + t0 + threadIdx.x] = SYM ? 2.0 * v : v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3b, VALU engine.  On gfx950 the fp64 vector FMA pipe sustains more than the fp64 matrix pipe
+// (tools/ubench_f64.hip, profiles/: v_fma_f64 64-72 TFLOP/s at 2-8 waves/SIMD vs 47-49 for
+// v_mfma_f64_16x16x4_f64), so the same contraction is also available as a classic register-tiled
+// FMA kernel: 256 threads as 16 x 16, each owning an 8 x 8 micro-tile of the 128 x 128 block tile,
+// interleaved in 16-byte chunks (rows ty*2 + 32a + {0,1}, columns tx*2 + 32b + {0,1}) so every
+// fragment read is a conflict-free ds_read_b128.  LDS holds the K tile TRANSPOSED (k-major):
+// As[k][i], Bs[k][t]; global -> LDS staging is one row per lane (conflict-free ds_write_b64).
+// Per k step and thread: 8 ds_read_b128 feed 64 v_fma_f64.
+// ------------------------------------------------------------------------------------------------
+#define MIK_VS 128  // LDS row stride (doubles) of the k-major tiles
+struct ValuSmem {  // one spare k row per tile: the register pipeline reads one row past the end (never used)
+  double As[2][MIK_BK + 1][MIK_VS];
+  double Bs[2][MIK_BK + 1][MIK_VS];
+};
+
+__device__ __forceinline__ void valu_core(const double* __restrict__ Ag, long lda, const double* __restrict__ Bg,
+                                          long ldb, int kbeg, int kend, double (&acc)[8][8], ValuSmem& sm) {
+  if (kbeg >= kend) return;  // block-uniform
+  const int tid = threadIdx.x;
+  const int tx = tid & 15, ty = tid >> 4;
+  const int srow = tid & 127, sk = (tid >> 7) * 8;  // staging: row srow, k offsets sk .. sk+7
+  const double* ap = Ag + (long)srow * lda + sk;
+  const double* bp = Bg + (long)srow * ldb + sk;
+  double2 ra[4], rb[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    ra[p] = *reinterpret_cast<const double2*>(ap + kbeg + 2 * p);
+    rb[p] = *reinterpret_cast<const double2*>(bp + kbeg + 2 * p);
+  }
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    sm.As[0][sk + 2 * p][srow] = ra[p].x;
+    sm.As[0][sk + 2 * p + 1][srow] = ra[p].y;
+    sm.Bs[0][sk + 2 * p][srow] = rb[p].x;
+    sm.Bs[0][sk + 2 * p + 1][srow] = rb[p].y;
+  }
+  __syncthreads();
+  int buf = 0;
+  for (int k = kbeg; k < kend; k += MIK_BK) {
+    const bool more = (k + MIK_BK) < kend;
+    if (more) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        ra[p] = *reinterpret_cast<const double2*>(ap + k + MIK_BK + 2 * p);
+        rb[p] = *reinterpret_cast<const double2*>(bp + k + MIK_BK + 2 * p);
+      }
+    }
+    {
+      // fragments double-buffered in registers: the reads of step kk+1 are in flight behind the 64 FMAs of step kk
+      const double* asrc = &sm.As[buf][0][ty * 2];
+      const double* bsrc = &sm.Bs[buf][0][tx * 2];
+      double2 a0[4], b0[4], a1[4], b1[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        a0[c] = *reinterpret_cast<const double2*>(asrc + 32 * c);
+        b0[c] = *reinterpret_cast<const double2*>(bsrc + 32 * c);
+      }
+#pragma unroll 1
+      for (int kk = 0; kk < MIK_BK; kk += 2) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          a1[c] = *reinterpret_cast<const double2*>(asrc + (kk + 1) * MIK_VS + 32 * c);
+          b1[c] = *reinterpret_cast<const double2*>(bsrc + (kk + 1) * MIK_VS + 32 * c);
+        }
+#pragma unroll
+        for (int x = 0; x < 8; ++x)
+#pragma unroll
+          for (int y = 0; y < 8; ++y)
+            acc[x][y] = __builtin_fma((x & 1) ? a0[x >> 1].y : a0[x >> 1].x, (y & 1) ? b0[y >> 1].y : b0[y >> 1].x, acc[x][y]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {  // kk + 2 == MIK_BK reads the spare row; those values are discarded
+          a0[c] = *reinterpret_cast<const double2*>(asrc + (kk + 2) * MIK_VS + 32 * c);
+          b0[c] = *reinterpret_cast<const double2*>(bsrc + (kk + 2) * MIK_VS + 32 * c);
+        }
+#pragma unroll
+        for (int x = 0; x < 8; ++x)
+#pragma unroll
+          for (int y = 0; y < 8; ++y)
+            acc[x][y] = __builtin_fma((x & 1) ? a1[x >> 1].y : a1[x >> 1].x, (y & 1) ? b1[y >> 1].y : b1[y >> 1].x, acc[x][y]);
+      }
+    }
+    if (more) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        sm.As[buf ^ 1][sk + 2 * p][srow] = ra[p].x;
+        sm.As[buf ^ 1][sk + 2 * p + 1][srow] = ra[p].y;
+        sm.Bs[buf ^ 1][sk + 2 * p][srow] = rb[p].x;
+        sm.Bs[buf ^ 1][sk + 2 * p + 1][srow] = rb[p].y;
+      }
+    }
+    __syncthreads();
+    buf ^= 1;
+  }
+}
+
+template <bool SYM>
+__global__ void __launch_bounds__(256, 2)
+k_contract_valu(const double* __restrict__ Ainv, long lda, const double* __restrict__ Bt, long ldb,
+                double* __restrict__ part, int palloc, int nIblk, int kend) {
+  __shared__ ValuSmem sm;
+  const long L = xcd_tile((long)nIblk * (palloc / MIK_BN));
+  if (L < 0) return;
+  const int iblk = (int)(L % nIblk), tblk = (int)(L / nIblk);
+  const int i0 = iblk * MIK_BM, t0 = tblk * MIK_BN;
+  double acc[8][8];
+#pragma unroll
+  for (int x = 0; x < 8; ++x)
+#pragma unroll
+    for (int y = 0; y < 8; ++y) acc[x][y] = 0.0;
+  const double* Ag = Ainv + (long)i0 * lda;
+  const double* Bg = Bt + (long)t0 * ldb;
+  if (SYM) {
+    const int kd = (i0 + MIK_BM) < kend ? (i0 + MIK_BM) : kend;
+    valu_core(Ag, lda, Bg, ldb, i0, kd, acc, sm);
+#pragma unroll
+    for (int x = 0; x < 8; ++x)
+#pragma unroll
+      for (int y = 0; y < 8; ++y) acc[x][y] *= 0.5;
+    valu_core(Ag, lda, Bg, ldb, i0 + MIK_BM, kend, acc, sm);
+  } else {
+    valu_core(Ag, lda, Bg, ldb, 0, kend, acc, sm);
+  }
+  // epilogue: thread (ty,tx) holds rows i0 + ty*2 + 32*(x>>1) + (x&1), columns t0 + tx*2 + 32*(y>>1) + (y&1)
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  double* red = &sm.As[0][0][0];  // 16 x 128 doubles, free after the core's final barrier
+#pragma unroll
+  for (int y = 0; y < 8; ++y) {
+    const int tc = tx * 2 + 32 * (y >> 1) + (y & 1);
+    const double* brow = Bt + (long)(t0 + tc) * ldb + i0 + ty * 2;
+    double s = 0.0;
+#pragma unroll
+    for (int x = 0; x < 8; ++x) s += brow[32 * (x >> 1) + (x & 1)] * acc[x][y];
+    red[ty * 128 + tc] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    double v = 0.0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v += red[r * 128 + threadIdx.x];
     part[(long)iblk * palloc + t0 + threadIdx.x] = SYM ? 2.0 * v : v;
   }
 }
@@ -511,53 +677,54 @@ __global__ void __launch_bounds__(1024) k_diag_inv(const double* __restrict__ T,
                                                    int* __restrict__ flag) {
   __shared__ double rowk[2][128], colk[2][128];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  double a[8][2];
+  double al[8], ah[8];  // columns lane / lane+64 of this thread's 8 rows (two arrays: never indexed dynamically)
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
-    a[r][0] = T[(long)(k0 + w * 8 + r) * ld + k0 + lane];
-    a[r][1] = T[(long)(k0 + w * 8 + r) * ld + k0 + lane + 64];
+    al[r] = T[(long)(k0 + w * 8 + r) * ld + k0 + lane];
+    ah[r] = T[(long)(k0 + w * 8 + r) * ld + k0 + lane + 64];
   }
   int bad = 0;
-  for (int k = 0; k < 128; ++k) {
-    const int pb = k & 1;
-    if ((k >> 3) == w) {
+  // k = 8*kb + kr with kr unrolled: the pivot row's owner is wave kb and its local row index kr is a
+  // compile-time constant, so a[][] is only ever indexed statically (no scratch).
+#pragma unroll 1
+  for (int kb = 0; kb < 16; ++kb) {
 #pragma unroll
-      for (int r = 0; r < 8; ++r)
-        if (r == (k & 7)) {
-          rowk[pb][lane] = a[r][0];
-          rowk[pb][lane + 64] = a[r][1];
-        }
-    }
-    if (lane == (k & 63)) {
+    for (int kr = 0; kr < 8; ++kr) {
+      const int k = kb * 8 + kr;
+      const int pb = kr & 1;
+      if (kb == w) {
+        rowk[pb][lane] = al[kr];
+        rowk[pb][lane + 64] = ah[kr];
+      }
+      if (lane == (k & 63)) {
 #pragma unroll
-      for (int r = 0; r < 8; ++r) colk[pb][w * 8 + r] = (k < 64) ? a[r][0] : a[r][1];
-    }
-    __syncthreads();
-    const double piv = rowk[pb][k];
-    if (!(fabs(piv) > 1e-300) || !isfinite(piv)) bad |= 1;
-    if ((k0 + k) < nspd && !(piv > 0.0)) bad |= 2;
-    const double pinv = 1.0 / piv;
-    const double rk0 = rowk[pb][lane] * pinv, rk1 = rowk[pb][lane + 64] * pinv;
+        for (int r = 0; r < 8; ++r) colk[pb][w * 8 + r] = (kb < 8) ? al[r] : ah[r];
+      }
+      __syncthreads();
+      const double piv = rowk[pb][k];
+      if (!(fabs(piv) > 1e-300) || !isfinite(piv)) bad |= 1;
+      if ((k0 + k) < nspd && !(piv > 0.0)) bad |= 2;
+      const double pinv = 1.0 / piv;
+      const double rk0 = rowk[pb][lane] * pinv, rk1 = rowk[pb][lane + 64] * pinv;
+      const bool c0 = (lane == k), c1 = (lane + 64 == k);
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const int i = w * 8 + r;
-      const double f = colk[pb][i];
-      if (i == k) {
-        a[r][0] = (lane == k) ? pinv : rk0;
-        a[r][1] = (lane + 64 == k) ? pinv : rk1;
-      } else {
-        a[r][0] = (lane == k) ? -f * pinv : a[r][0] - f * rk0;
-        a[r][1] = (lane + 64 == k) ? -f * pinv : a[r][1] - f * rk1;
+      for (int r = 0; r < 8; ++r) {
+        const double f = colk[pb][w * 8 + r];
+        const double n0 = c0 ? -f * pinv : al[r] - f * rk0;
+        const double n1 = c1 ? -f * pinv : ah[r] - f * rk1;
+        const bool prow = (kb == w) && (r == kr);
+        al[r] = prow ? (c0 ? pinv : rk0) : n0;
+        ah[r] = prow ? (c1 ? pinv : rk1) : n1;
       }
     }
   }
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
     const int i = w * 8 + r;
-    Dinv[i * 128 + lane] = a[r][0];
-    Dinv[i * 128 + lane + 64] = a[r][1];
-    DinvT[lane * 128 + i] = a[r][0];
-    DinvT[(lane + 64) * 128 + i] = a[r][1];
+    Dinv[i * 128 + lane] = al[r];
+    Dinv[i * 128 + lane + 64] = ah[r];
+    DinvT[lane * 128 + i] = al[r];
+    DinvT[(lane + 64) * 128 + i] = ah[r];
   }
   if (bad && threadIdx.x == 0) atomicOr(flag, bad);
 }
@@ -755,6 +922,16 @@ __global__ void k_selftest_mfma(double* out /*16x16 row-major*/) {
   d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
   acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
   for (int r = 0; r < 4; ++r) out[((l >> 4) + 4 * r) * 16 + (l & 15)] = acc[r];
+}
+
+
+// v_mfma_f64_4x4x4_4b_f64 as the kernels use it: A replicated over blocks, B = 4 x 16 columns
+__global__ void k_selftest_mfma4(double* out /*4x16 row-major*/) {
+  const int l = threadIdx.x;
+  const double a = (double)((l & 3) * 7 + (l >> 4) * 3 + 1);    // A[i=l&3][k=l>>4], same for every block
+  const double b = (double)((l >> 4) * 11 + (l & 15) * 5 + 2);  // B[k=l>>4][col=l&15]
+  const double d = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, 0.0, 0, 0, 0);
+  out[(l >> 4) * 16 + (l & 15)] = d;                            // D[i=l>>4][col=l&15]
 }
 
 }  // namespace mik

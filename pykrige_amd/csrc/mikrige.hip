@@ -120,7 +120,7 @@ struct mik_handle {
   // work
   DevBuf Bt, part;
   // options
-  int opt_factor = 0, opt_sym = 1;
+  int opt_factor = 0, opt_sym = 1, opt_engine = 0;  // engine: 0 = v_mfma_f64 contraction, 1 = v_fma_f64 (VALU) contraction
   long opt_chunk = 65536;
   mik_timing tm{};
   std::vector<hipEvent_t> evpool;
@@ -199,6 +199,8 @@ int mik_create(int device, mik_handle** out) {
   if (env) h->opt_factor = !strcmp(env, "sweep") ? 1 : (!strcmp(env, "lu") || !strcmp(env, "pivoted")) ? 2 : 0;
   env = getenv("MIK_SYMMETRIC");
   if (env) h->opt_sym = atoi(env) ? 1 : 0;
+  env = getenv("MIK_ENGINE");
+  if (env) h->opt_engine = (!strcmp(env, "valu") || !strcmp(env, "1")) ? 1 : 0;
   env = getenv("MIK_CHUNK");
   if (env && atol(env) >= 128) h->opt_chunk = (atol(env) / 128) * 128;
   *out = h;
@@ -225,6 +227,9 @@ int mik_set_option(mik_handle* h, const char* key, double value) {
     h->opt_factor = (int)value;
   } else if (!strcmp(key, "symmetric")) {
     h->opt_sym = value != 0.0;
+  } else if (!strcmp(key, "engine")) {
+    if (value != 0.0 && value != 1.0) return fail(MIK_EINVAL, "engine must be 0 (mfma) or 1 (valu)");
+    h->opt_engine = (int)value;
   } else if (!strcmp(key, "chunk")) {
     if (value < 128) return fail(MIK_EINVAL, "chunk must be >= 128");
     h->opt_chunk = ((long)value / 128) * 128;
@@ -554,6 +559,7 @@ int mik_predict(mik_handle* h) {
   h->tm.contract_launches = 0;
   h->tm.contract_flops_executed = 0.0;
   h->tm.symmetric = h->opt_sym;
+  h->tm.engine = h->opt_engine;
   if (npt == 0) {
     h->have_results = true;
     return MIK_OK;
@@ -606,12 +612,19 @@ int mik_predict(mik_handle* h) {
     HIPC(hipEventRecord(e1, h->stream));
     const long tiles = (long)nIblk * (palloc / 128);
     const unsigned grid = (unsigned)(8 * ((tiles + 7) / 8));
-    if (h->opt_sym)
-      hipLaunchKernelGGL(k_contract<true>, dim3(grid), dim3(256), 0, h->stream, (const double*)h->T.as<double>(), (long)Mp,
-                         (const double*)h->Bt.as<double>(), (long)Mp, h->part.as<double>(), palloc, nIblk, kend);
-    else
-      hipLaunchKernelGGL(k_contract<false>, dim3(grid), dim3(256), 0, h->stream, (const double*)h->T.as<double>(), (long)Mp,
-                         (const double*)h->Bt.as<double>(), (long)Mp, h->part.as<double>(), palloc, nIblk, kend);
+    {
+      const double* Ai = h->T.as<double>();
+      const double* Bi = h->Bt.as<double>();
+      double* pp = h->part.as<double>();
+      const long ldm = Mp;
+      if (h->opt_engine == 1) {
+        if (h->opt_sym) hipLaunchKernelGGL(k_contract_valu<true>, dim3(grid), dim3(256), 0, h->stream, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend);
+        else hipLaunchKernelGGL(k_contract_valu<false>, dim3(grid), dim3(256), 0, h->stream, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend);
+      } else {
+        if (h->opt_sym) hipLaunchKernelGGL(k_contract<true>, dim3(grid), dim3(256), 0, h->stream, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend);
+        else hipLaunchKernelGGL(k_contract<false>, dim3(grid), dim3(256), 0, h->stream, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend);
+      }
+    }
     HIPC(hipEventRecord(e2, h->stream));
     hipLaunchKernelGGL(k_ss_reduce, dim3((nvalid + 255) / 256), dim3(256), 0, h->stream, (const double*)h->part.as<double>(),
                        palloc, nIblk, nvalid, h->ss.as<double>() + t0);
@@ -690,7 +703,6 @@ int mik_selftest_mfma(int device) {
   hipLaunchKernelGGL(k_selftest_mfma, dim3(1), dim3(64), 0, 0, d);
   double out[256];
   HIPC(hipMemcpy(out, d, sizeof out, hipMemcpyDeviceToHost));
-  (void)hipFree(d);
   for (int i = 0; i < 16; ++i)
     for (int j = 0; j < 16; ++j) {
       double ref = 0.0;
@@ -698,6 +710,20 @@ int mik_selftest_mfma(int device) {
       if (out[i * 16 + j] != ref) {
         char b[200];
         snprintf(b, sizeof b, "mfma_f64_16x16x4 layout mismatch at (%d,%d): got %g want %g", i, j, out[i * 16 + j], ref);
+        (void)hipFree(d);
+        return fail(MIK_EHIP, b);
+      }
+    }
+  hipLaunchKernelGGL(k_selftest_mfma4, dim3(1), dim3(64), 0, 0, d);
+  HIPC(hipMemcpy(out, d, sizeof(double) * 64, hipMemcpyDeviceToHost));
+  (void)hipFree(d);
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 16; ++j) {
+      double ref = 0.0;
+      for (int k = 0; k < 4; ++k) ref += (double)(i * 7 + k * 3 + 1) * (double)(k * 11 + j * 5 + 2);
+      if (out[i * 16 + j] != ref) {
+        char b[200];
+        snprintf(b, sizeof b, "mfma_f64_4x4x4_4b layout mismatch at (%d,%d): got %g want %g", i, j, out[i * 16 + j], ref);
         return fail(MIK_EHIP, b);
       }
     }

@@ -204,11 +204,12 @@ def test_synthetic_n1500_against_oracle(cfg):
     zr, sr = ko.execute(st, "grid", *axes)
     h = m._get_handle()
     outs = []
-    for sym in (1, 0):
+    for sym, engine in ((1, 0), (0, 0), (1, 1), (0, 1)):  # symmetric half product on/off x MFMA / VALU contraction
         h.set_option("symmetric", sym)
+        h.set_option("engine", engine)
         h.set_option("chunk", 1024)
         z, ss = m.execute("grid", *axes, backend="loop")
-        assert m.last_timing["contract_launches"] >= 3
+        assert m.last_timing["contract_launches"] >= 3 and m.last_timing["engine"] == engine
         np.testing.assert_allclose(z, zr, rtol=0, atol=Z_TOL)
         np.testing.assert_allclose(ss, sr, rtol=0, atol=SS_TOL)
         outs.append((z, ss))

@@ -1,0 +1,63 @@
+// Standalone timing of the library's kernels on BASELINE config-2 shapes (M=5001 -> Mp=5120) with
+// HIP events.  Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I pykrige_amd/csrc tools/kernel_bench.hip -o tools/kernel_bench
+#include "mik_kernels.h"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+using namespace mik;
+#define CK(x) do{hipError_t e=(x); if(e!=hipSuccess){printf("HIP error %s at %d\n",hipGetErrorString(e),__LINE__);return 1;}}while(0)
+template<class F> float timeit(F f, int reps){
+  hipEvent_t e0,e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  f(); hipDeviceSynchronize();
+  hipEventRecord(e0); for(int i=0;i<reps;i++) f(); hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms,e0,e1); return ms/reps;
+}
+int main(int argc,char**argv){
+  const int Mp = argc>1? atoi(argv[1]) : 5120, P = argc>2? atoi(argv[2]) : 32768;
+  const int nblk = Mp/128, kend = Mp;
+  double *T,*Bt,*part,*Dinv,*DinvT,*Cold,*Cnew,*Rt; int* flag;
+  CK(hipMalloc(&T,sizeof(double)*(size_t)Mp*Mp)); CK(hipMalloc(&Bt,sizeof(double)*(size_t)P*Mp));
+  CK(hipMalloc(&part,sizeof(double)*(size_t)P*nblk)); CK(hipMalloc(&Dinv,131072)); CK(hipMalloc(&DinvT,131072));
+  CK(hipMalloc(&Cold,sizeof(double)*(size_t)Mp*128)); CK(hipMalloc(&Cnew,sizeof(double)*(size_t)Mp*128)); CK(hipMalloc(&Rt,sizeof(double)*(size_t)Mp*128));
+  CK(hipMalloc(&flag,4));
+  { std::vector<double> h((size_t)Mp*Mp); srand(1);
+    for(size_t i=0;i<h.size();++i) h[i]=(rand()/(double)RAND_MAX-0.5)*0.01;
+    for(int i=0;i<Mp;++i) h[(size_t)i*Mp+i]=1.0+0.1*(i%7);
+    for(int i=0;i<Mp;++i) for(int j=0;j<i;++j) h[(size_t)i*Mp+j]=h[(size_t)j*Mp+i];
+    CK(hipMemcpy(T,h.data(),h.size()*8,hipMemcpyHostToDevice));
+    std::vector<double> b((size_t)P*Mp); for(size_t i=0;i<b.size();++i) b[i]=rand()/(double)RAND_MAX-0.5;
+    CK(hipMemcpy(Bt,b.data(),b.size()*8,hipMemcpyHostToDevice));
+    CK(hipMemcpy(Cold,b.data(),(size_t)Mp*128*8,hipMemcpyHostToDevice)); CK(hipMemcpy(Cnew,b.data()+Mp*128,(size_t)Mp*128*8,hipMemcpyHostToDevice));
+    CK(hipMemcpy(Rt,b.data()+2*Mp*128,(size_t)Mp*128*8,hipMemcpyHostToDevice)); }
+  const long tiles=(long)nblk*(P/128); const unsigned grid=(unsigned)(8*((tiles+7)/8));
+  double kext_sym=0; for(int ib=0;ib<nblk;++ib) kext_sym+= kend-ib*128;
+  const double fl_full=2.0*128*128*(double)kend*nblk*(P/128), fl_sym=2.0*128*128*kext_sym*(P/128);
+  // warm the clocks
+  for(int w=0;w<2;++w) hipLaunchKernelGGL(k_contract<true>,dim3(grid),dim3(256),0,0,(const double*)T,(long)Mp,(const double*)Bt,(long)Mp,part,P,nblk,kend);
+  hipDeviceSynchronize();
+  float ms;
+  ms=timeit([&]{hipLaunchKernelGGL(k_contract<true>,dim3(grid),dim3(256),0,0,(const double*)T,(long)Mp,(const double*)Bt,(long)Mp,part,P,nblk,kend);},3);
+  printf("k_contract<sym>  mfma : %.3f ms  executed %.2f TF/s  effective(2M^2) %.2f TF/s\n",ms,fl_sym/ms*1e-9,fl_full/ms*1e-9);
+  std::vector<double> ref((size_t)P*nblk), got((size_t)P*nblk);
+  CK(hipMemcpy(ref.data(),part,ref.size()*8,hipMemcpyDeviceToHost));
+  ms=timeit([&]{hipLaunchKernelGGL(k_contract<false>,dim3(grid),dim3(256),0,0,(const double*)T,(long)Mp,(const double*)Bt,(long)Mp,part,P,nblk,kend);},2);
+  printf("k_contract<full> mfma : %.3f ms  executed %.2f TF/s\n",ms,fl_full/ms*1e-9);
+  ms=timeit([&]{hipLaunchKernelGGL(k_contract_valu<true>,dim3(grid),dim3(256),0,0,(const double*)T,(long)Mp,(const double*)Bt,(long)Mp,part,P,nblk,kend);},3);
+  printf("k_contract<sym>  valu : %.3f ms  executed %.2f TF/s  effective(2M^2) %.2f TF/s\n",ms,fl_sym/ms*1e-9,fl_full/ms*1e-9);
+  CK(hipMemcpy(got.data(),part,got.size()*8,hipMemcpyDeviceToHost));
+  { double md=0, mx=0; for(size_t i=0;i<ref.size();++i){ md=fmax(md,fabs(ref[i]-got[i])); mx=fmax(mx,fabs(ref[i])); } printf("   valu vs mfma partials: max|diff| %.3e (max|ref| %.3e)\n",md,mx); }
+  ms=timeit([&]{hipLaunchKernelGGL(k_contract_valu<false>,dim3(grid),dim3(256),0,0,(const double*)T,(long)Mp,(const double*)Bt,(long)Mp,part,P,nblk,kend);},2);
+  printf("k_contract<full> valu : %.3f ms  executed %.2f TF/s\n",ms,fl_full/ms*1e-9);
+  // inverse pieces
+  ms=timeit([&]{hipLaunchKernelGGL(k_diag_inv,dim3(1),dim3(1024),0,0,(const double*)T,(long)Mp,0,0,Dinv,DinvT,flag);},10);
+  printf("k_diag_inv (1024 thr) back-to-back: %.1f us\n",ms*1e3);
+  const long ut=(long)nblk*nblk; const unsigned ug=(unsigned)(8*((ut+7)/8));
+  ms=timeit([&]{hipLaunchKernelGGL(k_update,dim3(ug),dim3(256),0,0,T,(long)Mp,nblk,1,(const double*)Cold,(const double*)Cnew,(const double*)Rt,(const double*)Dinv);},5);
+  printf("k_update: %.1f us  %.2f TF/s\n",ms*1e3, 2.0*Mp*(double)Mp*128/ms*1e-9);
+  ms=timeit([&]{hipLaunchKernelGGL(k_diag_inv,dim3(1),dim3(1024),0,0,(const double*)T,(long)Mp,0,0,Dinv,DinvT,flag);
+               hipLaunchKernelGGL(k_update,dim3(ug),dim3(256),0,0,T,(long)Mp,nblk,1,(const double*)Cold,(const double*)Cnew,(const double*)Rt,(const double*)Dinv);},5);
+  printf("k_diag_inv + k_update interleaved: %.1f us per pair\n",ms*1e3);
+  ms=timeit([&]{hipLaunchKernelGGL(k_panel,dim3(nblk),dim3(256),0,0,(const double*)Cold,128L,(const double*)DinvT,-1.0,Cnew);},5);
+  printf("k_panel: %.1f us\n",ms*1e3);
+  return 0;
+}

@@ -54,6 +54,37 @@ __global__ void __launch_bounds__(512) k_mixed(double* out, int iters, double a0
   }
   out[blockIdx.x*blockDim.x+threadIdx.x]=s;
 }
+// v_mfma_f64_4x4x4_4b_f64: 4 blocks of 4x4x4, one accumulator double per lane (512 flop per instruction)
+template<int NACC>
+__global__ void __launch_bounds__(256) k_mfma4(double* out, int iters, double a0, double b0){
+  double acc[NACC];
+  for(int i=0;i<NACC;i++) acc[i]=0.0;
+  double a=a0+threadIdx.x*1e-9, b=b0;
+  for(int it=0;it<iters;it++){
+#pragma unroll
+    for(int i=0;i<NACC;i++) acc[i]=__builtin_amdgcn_mfma_f64_4x4x4f64(a,b,acc[i],0,0,0);
+  }
+  double s=0; for(int i=0;i<NACC;i++) s+=acc[i];
+  out[blockIdx.x*blockDim.x+threadIdx.x]=s;
+}
+// the SAME wave issues 1 MFMA 16x16x4 then R independent v_fma_f64: do the two fp64 pipes overlap inside one wave?
+template<int R>
+__global__ void __launch_bounds__(256) k_inwave(double* out, int iters, double a0, double b0){
+  d4 acc[4]; for(int i=0;i<4;i++) acc[i]=(d4){0,0,0,0};
+  double v[16]; for(int i=0;i<16;i++) v[i]=i;
+  double a=a0+threadIdx.x*1e-9, b=b0;
+  for(int it=0;it<iters;it++){
+#pragma unroll
+    for(int i=0;i<4;i++){
+      acc[i]=__builtin_amdgcn_mfma_f64_16x16x4f64(a,b,acc[i],0,0,0);
+#pragma unroll
+      for(int r=0;r<R;r++) v[(i*R+r)&15]=__builtin_fma(a,v[(i*R+r)&15],b);
+    }
+  }
+  double s=0; for(int i=0;i<4;i++) s+=acc[i][0]+acc[i][1]+acc[i][2]+acc[i][3];
+  for(int i=0;i<16;i++) s+=v[i];
+  out[blockIdx.x*blockDim.x+threadIdx.x]=s;
+}
 __global__ void __launch_bounds__(256) k_exp(double* out, int iters, double x0){
   double x=x0+threadIdx.x*1e-3; double s=0;
   for(int it=0;it<iters;it++){
@@ -106,6 +137,24 @@ int main(){
     float ms=timeit([&]{hipLaunchKernelGGL(k_mixed,dim3(grid),dim3(512),0,0,out,iters,1.0,1.0,r);});
     double flm=(double)grid*4*iters*8*2048.0; double flv=(double)grid*4*64*(double)(iters*r/2)*16*2.0;
     printf("mixed (1 mfma wave + 1 fma wave per SIMD) fma_per_mfma=%d: %.3f ms  mfma %.2f TF + valu %.2f TF = %.2f TF\n",r,ms,flm/ms*1e-9,flv/ms*1e-9,(flm+flv)/ms*1e-9);
+  }
+  for(int bpc: {1,2,4,8}){
+    int grid=256*bpc;
+    float ms=timeit([&]{hipLaunchKernelGGL(k_mfma4<8>,dim3(grid),dim3(256),0,0,out,iters,1.0,1.0);});
+    double fl=(double)grid*4*iters*8*512.0;
+    printf("mfma_f64_4x4x4_4b nacc=8 waves/SIMD=%d: %.3f ms  %.2f TFLOP/s  cyc/mfma/SIMD@2.4GHz=%.1f\n",bpc,ms,fl/ms*1e-9, ms*1e-3*2.4e9/(iters*8.0*bpc));
+  }
+  for(int bpc: {1,2}){
+    int grid=256*bpc;
+    float ms=timeit([&]{hipLaunchKernelGGL(k_inwave<4>,dim3(grid),dim3(256),0,0,out,iters,1.0,1.0);});
+    double flm=(double)grid*4*iters*4*2048.0, flv=(double)grid*256*(double)iters*16*2.0;
+    printf("in-wave 1 mfma + 4 fma  waves/SIMD=%d: %.3f ms  mfma %.2f + valu %.2f = %.2f TF\n",bpc,ms,flm/ms*1e-9,flv/ms*1e-9,(flm+flv)/ms*1e-9);
+    ms=timeit([&]{hipLaunchKernelGGL(k_inwave<8>,dim3(grid),dim3(256),0,0,out,iters,1.0,1.0);});
+    flv*=2;
+    printf("in-wave 1 mfma + 8 fma  waves/SIMD=%d: %.3f ms  mfma %.2f + valu %.2f = %.2f TF\n",bpc,ms,flm/ms*1e-9,flv/ms*1e-9,(flm+flv)/ms*1e-9);
+    ms=timeit([&]{hipLaunchKernelGGL(k_inwave<16>,dim3(grid),dim3(256),0,0,out,iters,1.0,1.0);});
+    flv*=2;
+    printf("in-wave 1 mfma + 16 fma waves/SIMD=%d: %.3f ms  mfma %.2f + valu %.2f = %.2f TF\n",bpc,ms,flm/ms*1e-9,flv/ms*1e-9,(flm+flv)/ms*1e-9);
   }
   for(int bpc: {1,4}){
     int grid=256*bpc;
