@@ -314,19 +314,21 @@ __device__ __forceinline__ void gemm_core(const double* __restrict__ Ag, long ld
     aoff[m] = (wm * 64 + ia) * MIK_BK + (((4 * m + kq) ^ (ia & 2)) << 1);
     boff[m] = (wn * 64 + jb) * MIK_BK + (((4 * m + kq) ^ ((jb >> 1) & 7)) << 1);
   }
+  // K runs DOWNWARDS (kend-16, kend-32, .. kbeg): in the symmetric contraction every tile then starts at
+  // the same k = kend, so the tiles of a supertile stream the same operand panels in near lockstep (L2 reuse).
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
-    glds16(ap + p * a32 + kbeg, &sm.As[0][wrow + 32 * p][0]);
-    glds16(bp + p * b32 + kbeg, &sm.Bs[0][wrow + 32 * p][0]);
+    glds16(ap + p * a32 + (kend - MIK_BK), &sm.As[0][wrow + 32 * p][0]);
+    glds16(bp + p * b32 + (kend - MIK_BK), &sm.Bs[0][wrow + 32 * p][0]);
   }
   __syncthreads();
   int buf = 0;
-  for (int k = kbeg; k < kend; k += MIK_BK) {
-    if ((k + MIK_BK) < kend) {
+  for (int k = kend - MIK_BK; k >= kbeg; k -= MIK_BK) {
+    if (k > kbeg) {
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
-        glds16(ap + p * a32 + k + MIK_BK, &sm.As[buf ^ 1][wrow + 32 * p][0]);
-        glds16(bp + p * b32 + k + MIK_BK, &sm.Bs[buf ^ 1][wrow + 32 * p][0]);
+        glds16(ap + p * a32 + k - MIK_BK, &sm.As[buf ^ 1][wrow + 32 * p][0]);
+        glds16(bp + p * b32 + k - MIK_BK, &sm.Bs[buf ^ 1][wrow + 32 * p][0]);
       }
     }
     const double* as = &sm.As[buf][0][0];
@@ -341,15 +343,21 @@ __device__ __forceinline__ void gemm_core(const double* __restrict__ Ag, long ld
       for (int x = 0; x < 16; ++x) fa[x] = *reinterpret_cast<const double2*>(as + aoff[m] + 4 * x * MIK_BK);
 #pragma unroll
       for (int x = 0; x < 4; ++x) fb[x] = *reinterpret_cast<const double2*>(bs + boff[m] + 16 * x * MIK_BK);
+      // all 64 accumulators once (first k of the pair), then all 64 again: dependent MFMAs are 64 issues apart
 #pragma unroll
       for (int ai = 0; ai < 4; ++ai)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-          for (int bi = 0; bi < 4; ++bi) {
+          for (int bi = 0; bi < 4; ++bi)
             acc[ai][bi][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa[4 * ai + r].x, fb[bi].x, acc[ai][bi][r], 0, 0, 0);
+#pragma unroll
+      for (int ai = 0; ai < 4; ++ai)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int bi = 0; bi < 4; ++bi)
             acc[ai][bi][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa[4 * ai + r].y, fb[bi].y, acc[ai][bi][r], 0, 0, 0);
-          }
     }
     __syncthreads();  // hipcc drains the outstanding LDS-DMA (vmcnt(0)) before the barrier
     buf ^= 1;
@@ -363,6 +371,35 @@ __device__ __forceinline__ long xcd_tile(long total) {
   const long per = (total + 7) / 8;
   const long L = (long)(blockIdx.x % 8) * per + blockIdx.x / 8;
   return L < total ? L : -1;
+}
+
+// Supertile order for the contraction: each XCD's contiguous range of logical tiles is cut into
+// supertiles of MIK_SI row blocks x MIK_ST point blocks = 64 tiles = what 32 CUs x 2 blocks hold at once.
+// The co-resident tiles share MIK_SI A row-panels and MIK_ST B point-panels through the XCD's L2.  The row
+// blocks of a supertile are adjacent, so in the symmetric form their K extents differ by at most
+// MIK_SI-1 blocks and (K running downwards from kend) they stream the panels in near lockstep.
+// False = padding slot.
+#define MIK_SI 4
+#define MIK_ST 16
+__host__ __device__ inline long super_tiles_total(int nIblk, int nTblk) {
+  return (long)((nIblk + MIK_SI - 1) / MIK_SI) * ((nTblk + MIK_ST - 1) / MIK_ST) * 64;
+}
+__host__ __device__ inline long super_grid(int nIblk, int nTblk) {  // blocks to launch
+  return 8 * ((((super_tiles_total(nIblk, nTblk) / 64) + 7) / 8) * 64);
+}
+__device__ __forceinline__ bool super_tile(int nIblk, int nTblk, int& iblk, int& tblk) {
+  const long nsuper = super_tiles_total(nIblk, nTblk) / 64;
+  // block b runs on XCD b % 8; its position in that XCD's dispatch sequence is b / 8.  64 consecutive
+  // positions of one XCD form one supertile; supertiles are dealt to the XCDs round-robin in global order
+  // (row-block groups ascending = longest tiles first in symmetric mode, so a launch ends with its shortest tiles).
+  const long seq = blockIdx.x / 8;
+  const long s = (seq >> 6) * 8 + (blockIdx.x % 8);
+  if (s >= nsuper) return false;
+  const int r = (int)(seq & 63);
+  const int nTg = (nTblk + MIK_ST - 1) / MIK_ST;
+  iblk = (int)(s / nTg) * MIK_SI + (r % MIK_SI);
+  tblk = (int)(s % nTg) * MIK_ST + (r / MIK_SI);
+  return iblk < nIblk && tblk < nTblk;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -379,54 +416,69 @@ __global__ void __launch_bounds__(256, 2)
 k_contract(const double* __restrict__ Ainv, long lda, const double* __restrict__ Bt, long ldb,
            double* __restrict__ part, int palloc, int nIblk, int kend) {
   __shared__ GemmSmem sm;
-  const long L = xcd_tile((long)nIblk * (palloc / MIK_BN));
-  if (L < 0) return;
-  const int iblk = (int)(L % nIblk), tblk = (int)(L / nIblk);
-  const int i0 = iblk * MIK_BM, t0 = tblk * MIK_BN;
-  d4 acc[4][4];
-#pragma unroll
-  for (int x = 0; x < 4; ++x)
-#pragma unroll
-    for (int y = 0; y < 4; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
-  const double* Ag = Ainv + (long)i0 * lda;
+  int iblk, tblk;
+  if (!super_tile(nIblk, palloc / MIK_BN, iblk, tblk)) return;
+  const int t0 = tblk * MIK_BN;
   const double* Bg = Bt + (long)t0 * ldb;
-  if (SYM) {
-    const int kd = (i0 + MIK_BM) < kend ? (i0 + MIK_BM) : kend;
-    gemm_core(Ag, lda, Bg, ldb, i0, kd, acc, sm);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1, lq = lane >> 4, lc = lane & 15;
+  {
+    const int i0 = iblk * MIK_BM;
+    d4 acc[4][4];
 #pragma unroll
     for (int x = 0; x < 4; ++x)
 #pragma unroll
-      for (int y = 0; y < 4; ++y) acc[x][y] *= 0.5;
-    gemm_core(Ag, lda, Bg, ldb, i0 + MIK_BM, kend, acc, sm);
-  } else {
-    gemm_core(Ag, lda, Bg, ldb, 0, kend, acc, sm);
-  }
-  // epilogue: column sums of B .* W over this tile's 128 rows
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = wave >> 1, wn = wave & 1, lq = lane >> 4, lc = lane & 15;
-  double cs[4];
+      for (int y = 0; y < 4; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
+    const double* Ag = Ainv + (long)i0 * lda;
+    if (SYM) {  // result = diag + 2 * offdiag: off-diagonal K blocks first (downwards from kend), then the diagonal block
+      const int kd = (i0 + MIK_BM) < kend ? (i0 + MIK_BM) : kend;
+      gemm_core(Ag, lda, Bg, ldb, kd, kend, acc, sm);
 #pragma unroll
-  for (int bi = 0; bi < 4; ++bi) {
-    const long t = t0 + wn * 64 + bi * 16 + lc;
-    const double* brow = Bt + t * ldb + i0 + wm * 64 + lq;
-    double s = 0.0;
+      for (int x = 0; x < 4; ++x)
 #pragma unroll
-    for (int ai = 0; ai < 4; ++ai)
+        for (int y = 0; y < 4; ++y) acc[x][y] *= 2.0;
+      gemm_core(Ag, lda, Bg, ldb, i0, kd, acc, sm);
+    } else {
+      gemm_core(Ag, lda, Bg, ldb, 0, kend, acc, sm);
+    }
+    // epilogue: column sums of B .* W over this tile's 128 rows
+    double cs[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) s += brow[ai * 16 + 4 * r] * acc[ai][bi][r];
-    s += __shfl_xor(s, 16);
-    s += __shfl_xor(s, 32);
-    cs[bi] = s;
-  }
-  double* red = &sm.As[0][0][0];  // gemm_core ended with a barrier: staging LDS is free
-  if (lq == 0) {
+    for (int bp = 0; bp < 2; ++bp) {
+      // 32 independent loads in flight per batch (the fragment registers are dead here); without the
+      // scheduling barriers hipcc serialises load -> wait -> fma 64 times (~1 us each) per tile
+      double bv[2][16];
 #pragma unroll
-    for (int bi = 0; bi < 4; ++bi) red[wm * 128 + wn * 64 + bi * 16 + lc] = cs[bi];
-  }
-  __syncthreads();
-  if (threadIdx.x < 128) {
-    const double v = red[threadIdx.x] + red[128 + threadIdx.x];
-    part[(long)iblk * palloc + t0 + threadIdx.x] = SYM ? 2.0 * v : v;
+      for (int b2 = 0; b2 < 2; ++b2) {
+        const long t = t0 + wn * 64 + (2 * bp + b2) * 16 + lc;
+        const double* brow = Bt + t * ldb + i0 + wm * 64 + lq;
+#pragma unroll
+        for (int ai = 0; ai < 4; ++ai)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) bv[b2][ai * 4 + r] = brow[ai * 16 + 4 * r];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int b2 = 0; b2 < 2; ++b2) {
+        const int bi = 2 * bp + b2;
+        double s = 0.0;
+#pragma unroll
+        for (int ai = 0; ai < 4; ++ai)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s += bv[b2][ai * 4 + r] * acc[ai][bi][r];
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        cs[bi] = s;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    double* red = &sm.As[0][0][0];  // gemm_core ended with a barrier: staging LDS is free
+    if (lq == 0) {
+#pragma unroll
+      for (int bi = 0; bi < 4; ++bi) red[wm * 128 + wn * 64 + bi * 16 + lc] = cs[bi];
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) part[(long)iblk * palloc + t0 + threadIdx.x] = red[threadIdx.x] + red[128 + threadIdx.x];
   }
 }
 
@@ -557,13 +609,27 @@ k_contract_valu(const double* __restrict__ Ainv, long lda, const double* __restr
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   double* red = &sm.As[0][0][0];  // 16 x 128 doubles, free after the core's final barrier
 #pragma unroll
-  for (int y = 0; y < 8; ++y) {
-    const int tc = tx * 2 + 32 * (y >> 1) + (y & 1);
-    const double* brow = Bt + (long)(t0 + tc) * ldb + i0 + ty * 2;
-    double s = 0.0;
+  for (int yp = 0; yp < 2; ++yp) {
+    double2 bv[4][4];
 #pragma unroll
-    for (int x = 0; x < 8; ++x) s += brow[32 * (x >> 1) + (x & 1)] * acc[x][y];
-    red[ty * 128 + tc] = s;
+    for (int y4 = 0; y4 < 4; ++y4) {
+      const int y = 4 * yp + y4;
+      const int tc = tx * 2 + 32 * (y >> 1) + (y & 1);
+      const double* brow = Bt + (long)(t0 + tc) * ldb + i0 + ty * 2;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) bv[y4][c] = *reinterpret_cast<const double2*>(brow + 32 * c);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int y4 = 0; y4 < 4; ++y4) {
+      const int y = 4 * yp + y4;
+      const int tc = tx * 2 + 32 * (y >> 1) + (y & 1);
+      double s = 0.0;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) s += bv[y4][c].x * acc[2 * c][y] + bv[y4][c].y * acc[2 * c + 1][y];
+      red[ty * 128 + tc] = s;
+    }
+    __builtin_amdgcn_sched_barrier(0);
   }
   __syncthreads();
   if (threadIdx.x < 128) {
@@ -656,15 +722,20 @@ k_update(double* __restrict__ T, long ld, int nblk, int kb, const double* __rest
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 1, wn = wave & 1, lq = lane >> 4, lc = lane & 15;
 #pragma unroll
-  for (int ai = 0; ai < 4; ++ai)
+  for (int ai = 0; ai < 4; ++ai) {  // read-modify-write in batches of 16 independent loads (see k_contract's epilogue)
+    double tv[4][4];
+    double* tp = T + (long)(i0 + wm * 64 + ai * 16 + lq) * ld + j0 + wn * 64 + lc;
 #pragma unroll
     for (int bi = 0; bi < 4; ++bi)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const long i = i0 + wm * 64 + ai * 16 + lq + 4 * r;
-        const long j = j0 + wn * 64 + bi * 16 + lc;
-        T[i * ld + j] -= acc[ai][bi][r];
-      }
+      for (int r = 0; r < 4; ++r) tv[bi][r] = tp[(long)(4 * r) * ld + bi * 16];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int bi = 0; bi < 4; ++bi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tp[(long)(4 * r) * ld + bi * 16] = tv[bi][r] - acc[ai][bi][r];
+    __builtin_amdgcn_sched_barrier(0);
+  }
 }
 
 // 128x128 in-register Gauss-Jordan inverse of the diagonal block, one 1024-thread workgroup.

@@ -121,7 +121,7 @@ struct mik_handle {
   DevBuf Bt, part;
   // options
   int opt_factor = 0, opt_sym = 1, opt_engine = 0;  // engine: 0 = v_mfma_f64 contraction, 1 = v_fma_f64 (VALU) contraction
-  long opt_chunk = 65536;
+  long opt_chunk = 131072;
   mik_timing tm{};
   std::vector<hipEvent_t> evpool;
   // comm
@@ -617,12 +617,13 @@ int mik_predict(mik_handle* h) {
       const double* Bi = h->Bt.as<double>();
       double* pp = h->part.as<double>();
       const long ldm = Mp;
+      const unsigned sgrid = (unsigned)super_grid(nIblk, palloc / 128);
       if (h->opt_engine == 1) {
         if (h->opt_sym) hipLaunchKernelGGL(k_contract_valu<true>, dim3(grid), dim3(256), 0, h->stream, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend);
         else hipLaunchKernelGGL(k_contract_valu<false>, dim3(grid), dim3(256), 0, h->stream, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend);
       } else {
-        if (h->opt_sym) hipLaunchKernelGGL(k_contract<true>, dim3(grid), dim3(256), 0, h->stream, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend);
-        else hipLaunchKernelGGL(k_contract<false>, dim3(grid), dim3(256), 0, h->stream, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend);
+        if (h->opt_sym) hipLaunchKernelGGL(k_contract<true>, dim3(sgrid), dim3(256), 0, h->stream, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend);
+        else hipLaunchKernelGGL(k_contract<false>, dim3(sgrid), dim3(256), 0, h->stream, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend);
       }
     }
     HIPC(hipEventRecord(e2, h->stream));

@@ -143,6 +143,14 @@ int main(){
     float ms=timeit([&]{hipLaunchKernelGGL(k_mfma4<8>,dim3(grid),dim3(256),0,0,out,iters,1.0,1.0);});
     double fl=(double)grid*4*iters*8*512.0;
     printf("mfma_f64_4x4x4_4b nacc=8 waves/SIMD=%d: %.3f ms  %.2f TFLOP/s  cyc/mfma/SIMD@2.4GHz=%.1f\n",bpc,ms,fl/ms*1e-9, ms*1e-3*2.4e9/(iters*8.0*bpc));
+    if(bpc<=2){
+      ms=timeit([&]{hipLaunchKernelGGL(k_mfma4<1>,dim3(grid),dim3(256),0,0,out,iters,1.0,1.0);});
+      printf("mfma_f64_4x4x4_4b nacc=1 (dependent) waves/SIMD=%d: %.2f TFLOP/s cyc/mfma=%.1f\n",bpc,(double)grid*4*iters*1*512.0/ms*1e-9, ms*1e-3*2.4e9/(iters*1.0*bpc));
+      ms=timeit([&]{hipLaunchKernelGGL(k_mfma4<2>,dim3(grid),dim3(256),0,0,out,iters,1.0,1.0);});
+      printf("mfma_f64_4x4x4_4b nacc=2 waves/SIMD=%d: %.2f TFLOP/s cyc/mfma=%.1f\n",bpc,(double)grid*4*iters*2*512.0/ms*1e-9, ms*1e-3*2.4e9/(iters*2.0*bpc));
+      ms=timeit([&]{hipLaunchKernelGGL(k_mfma4<4>,dim3(grid),dim3(256),0,0,out,iters,1.0,1.0);});
+      printf("mfma_f64_4x4x4_4b nacc=4 waves/SIMD=%d: %.2f TFLOP/s cyc/mfma=%.1f\n",bpc,(double)grid*4*iters*4*512.0/ms*1e-9, ms*1e-3*2.4e9/(iters*4.0*bpc));
+    }
   }
   for(int bpc: {1,2}){
     int grid=256*bpc;
