@@ -230,6 +230,14 @@ def main():
         algo_flops_per_launch = 2.0 * M * M * pts_per_launch  # 2 M^2 per point for w = A_inv . b
         achieved = algo_flops_per_launch / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0
         executed = tsum["contract_flops_executed"] / (tsum["contract_ms"] * 1e-3) / 1e12 if tsum["contract_ms"] > 0 else 0.0
+        traffic, traffic_note = None, None
+        try:  # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (not collected live)
+            tj = json.load(open(os.path.join(ROOT, "profiles", "k_contract_traffic.json")))
+            if tj["workload"] == cfg["name"] and not tsum.get("engine") and tsum.get("symmetric"):
+                traffic = tj["hbm_bytes_per_launch"] * (pts_per_launch / tj["points_per_launch"])
+                traffic_note = tj["source"]
+        except Exception:
+            pass
         out = {
             "metric": "kriged grid-points/sec (z + sigma^2), OK2D N=5000 on 1000x1000 grid" if args.config == 2
             else "kriged grid-points/sec (z + sigma^2), " + cfg["name"],
@@ -243,7 +251,8 @@ def main():
                            tsum.get("factor_path"), "?"),
                        "symmetric_contraction": bool(tsum.get("symmetric"))},
             "roofline": {"bound": "mfma", "kernel": "k_contract_valu" if tsum.get("engine") else "k_contract", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "traffic_unit": "bytes per launch (HBM-side, PMC)", "traffic_source": traffic_note,
                          "executed_tflops": executed, "avg_launch_ms": avg_launch_s * 1e3,
                          "launches_per_step": launches / K, "algorithmic_flops_per_point": 2.0 * M * M},
             "phases_ms_per_step": {"assemble": tsum["assemble_ms"] / K, "invert": tsum["invert_ms"] / K,

@@ -1,0 +1,75 @@
+"""Second batch of golden vectors from the REAL reference (PyKrige 1.7.3 at /root/reference/src):
+  ref_test_uk_external ... test_uk_with_external_drift (tests/test_core.py:1479-1507): DEM drift, KT3D-style answer grid
+  uk2d_external_z ....... synthetic external_Z + regional_linear, off-node points (bilinear lookup parity)
+  fit_<model> ........... constructor-time variogram fit (lags, semivariance, fitted parameters)
+  pseudo_dup ............ duplicate stations with pseudo_inv (tests/test_core.py:2913-2949)
+TEST INFRASTRUCTURE; run in the build container only:  python oracle/make_golden_extra.py"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from make_golden import OUT, REF_DATA, _import_reference, synth  # noqa: E402
+
+
+def main():
+    _import_reference(False)
+    import pykrige.kriging_tools as kt
+    from pykrige.ok import OrdinaryKriging
+    from pykrige.ok3d import OrdinaryKriging3D
+    from pykrige.uk import UniversalKriging
+
+    def arr(x):
+        return np.ma.getdata(x).astype(np.float64)
+
+    data = np.genfromtxt(os.path.join(REF_DATA, "test_data.txt"))
+    dem, demx, demy, _, _ = kt.read_asc_grid(os.path.join(REF_DATA, "test3_dem.asc"))
+    ans, gridx, gridy, _, _ = kt.read_asc_grid(os.path.join(REF_DATA, "test3_answer.asc"))
+    uk = UniversalKriging(data[:, 0], data[:, 1], data[:, 2], variogram_model="spherical",
+                          variogram_parameters=[500.0, 3000.0, 0.0], drift_terms=["external_Z"], external_drift=dem,
+                          external_drift_x=demx, external_drift_y=demy)
+    z, ss = uk.execute("grid", gridx, gridy, backend="vectorized")
+    np.savez_compressed(os.path.join(OUT, "ref_test_uk_external.npz"), x=data[:, 0], y=data[:, 1], v=data[:, 2],
+                        model="spherical", params_user=[500.0, 3000.0, 0.0], dem=dem, demx=demx, demy=demy,
+                        gridx=gridx, gridy=gridy, z=arr(z), ss=arr(ss), answer=ans)
+    # synthetic external_Z + regional_linear; kriging points off the DEM nodes
+    (x, y), v = synth(77, 150, 2)
+    ex, ey = np.linspace(-0.1, 1.1, 25), np.linspace(-0.2, 1.2, 31)
+    EX, EY = np.meshgrid(ex, ey)
+    edem = np.sin(2 * EX) + EY**2
+    uk = UniversalKriging(x, y, v, variogram_model="exponential", variogram_parameters=[1.0, 0.3, 0.02],
+                          drift_terms=["regional_linear", "external_Z"], external_drift=edem, external_drift_x=ex,
+                          external_drift_y=ey)
+    gx_, gy_ = np.linspace(0, 1, 17), np.linspace(0, 1, 13)
+    z, ss = uk.execute("grid", gx_, gy_, backend="vectorized")
+    np.savez_compressed(os.path.join(OUT, "uk2d_external_z.npz"), x=x, y=y, v=v, model="exponential",
+                        params_user=[1.0, 0.3, 0.02], dem=edem, demx=ex, demy=ey, gridx=gx_, gridy=gy_, z=arr(z),
+                        ss=arr(ss), regional_linear=True, z_scalars=uk.z_scalars)
+    # variogram fits
+    (x, y), v = synth(78, 200, 2)
+    (x3, y3, z3), v3 = synth(79, 150, 3)
+    fits = {}
+    for model in ("linear", "power", "gaussian", "spherical", "exponential", "hole-effect"):
+        for weight in (False, True):
+            ok = OrdinaryKriging(x, y, v, variogram_model=model, nlags=8, weight=weight, anisotropy_scaling=2.0,
+                                 anisotropy_angle=30.0)
+            key = "%s_%d" % (model.replace("-", ""), int(weight))
+            fits["lags_" + key], fits["semi_" + key] = ok.lags, ok.semivariance
+            fits["par_" + key] = np.asarray(ok.variogram_model_parameters, dtype=np.float64)
+    ok3 = OrdinaryKriging3D(x3, y3, z3, v3, variogram_model="spherical", nlags=6)
+    fits["lags_3d"], fits["semi_3d"], fits["par_3d"] = ok3.lags, ok3.semivariance, np.asarray(ok3.variogram_model_parameters)
+    np.savez_compressed(os.path.join(OUT, "fit_variograms.npz"), x=x, y=y, v=v, x3=x3, y3=y3, z3=z3, v3=v3, **fits)
+    # pseudo-inverse with duplicated stations
+    d = np.array([[0.0, 0.0, 1.0], [0.0, 0.0, 3.0], [1.0, 0.0, 6.0], [0.3, 0.8, 2.0]])
+    out = {}
+    for p_type in ("pinv", "pinvh"):
+        ok = OrdinaryKriging(d[:, 0], d[:, 1], d[:, 2], variogram_parameters=[1.0, 0.0], pseudo_inv=True, pseudo_inv_type=p_type)
+        z, ss = ok.execute("grid", np.linspace(0, 1, 5), np.linspace(0, 1, 4), backend="vectorized")
+        out["z_" + p_type], out["ss_" + p_type] = arr(z), arr(ss)
+    np.savez_compressed(os.path.join(OUT, "pseudo_dup.npz"), d=d, **out)
+    print("wrote extra fixtures")
+
+
+if __name__ == "__main__":
+    main()

@@ -103,9 +103,8 @@ class _KrigingBase:
     def _regional_linear(self):
         return False
 
-    def _upload_and_factor(self):
-        """K1 + K2 on the device (or the host pseudo-inverse when pseudo_inv=True)."""
-        h = self._get_handle()
+    def _set_problem(self, h):
+        """H2D of the stations / drift description (and, for pseudo_inv=True, of the host pseudo-inverse)."""
         ca = self._coords_adj
         kw = dict(
             ndim=self._ndim, xs=ca[:, 0], ys=ca[:, 1], zs=ca[:, 2] if self._ndim == 3 else None,
@@ -125,6 +124,11 @@ class _KrigingBase:
             h.set_problem(a_inv=pinv, **kw)
         else:
             h.set_problem(**kw)
+
+    def _upload_and_factor(self):
+        """K1 + K2 on the device (or the host pseudo-inverse when pseudo_inv=True)."""
+        h = self._get_handle()
+        self._set_problem(h)
         h.factor()
         return h
 
@@ -135,6 +139,11 @@ class _KrigingBase:
         h.predict()
         self.last_timing = h.timing()
         return h.get_results()
+
+    def _prepare_points(self, style, axes, mask, specified_drift_arrays=None):
+        """Everything execute() does on the host before the solve: returns (pts_adj, shape, mask, extra_rows)."""
+        pts, shape, mask = self._points_from(style, axes, mask)
+        return core.adjust_for_anisotropy(pts, self._center(), self._scaling(), self._angle()), shape, mask, None
 
     # ---------------------------------------------------------------- execute front / back matter
     def _check_backend(self, backend, n_closest_points):
@@ -287,9 +296,8 @@ class OrdinaryKriging(_KrigingBase):
         if style != "grid" and style != "masked" and style != "points":
             raise ValueError("style argument must be 'grid', 'points', or 'masked'")
         self._check_backend(backend, n_closest_points)
-        pts, shape, mask = self._points_from(style, (xpoints, ypoints), mask)
-        pts_adj = core.adjust_for_anisotropy(pts, self._center(), self._scaling(), self._angle())
-        z, ss = self._solve(pts_adj, mask, None)
+        pts_adj, shape, mask, extra = self._prepare_points(style, (xpoints, ypoints), mask)
+        z, ss = self._solve(pts_adj, mask, extra)
         return self._finish(z, ss, style, shape, mask, backend)
 
 
@@ -400,7 +408,12 @@ class UniversalKriging(OrdinaryKriging):
         if style != "grid" and style != "masked" and style != "points":
             raise ValueError("style argument must be 'grid', 'points', or 'masked'")
         self._check_backend(backend, None)
-        pts, shape, mask = self._points_from(style, (xpoints, ypoints), mask)
+        pts_adj, shape, mask, extra = self._prepare_points(style, (xpoints, ypoints), mask, specified_drift_arrays)
+        z, ss = self._solve(pts_adj, mask, extra)
+        return self._finish(z, ss, style, shape, mask, backend)
+
+    def _prepare_points(self, style, axes, mask, specified_drift_arrays=None):
+        pts, shape, mask = self._points_from(style, axes, mask)
         rows = []
         if self.external_Z_drift:  # on ORIGINAL coordinates (uk.py:967-971)
             rows.append(self._calculate_data_point_zscalars(pts[:, 0], pts[:, 1]))
@@ -408,9 +421,7 @@ class UniversalKriging(OrdinaryKriging):
         pts_adj = core.adjust_for_anisotropy(pts, self._center(), self._scaling(), self._angle())
         if self.functional_drift:
             rows.extend(np.asarray(f(pts_adj[:, 0], pts_adj[:, 1]), dtype=np.float64) for f in self.functional_drift_terms)
-        extra = np.array(rows, dtype=np.float64) if rows else None
-        z, ss = self._solve(pts_adj, mask, extra)
-        return self._finish(z, ss, style, shape, mask, backend)
+        return pts_adj, shape, mask, (np.array(rows, dtype=np.float64) if rows else None)
 
 
 # =====================================================================================================
@@ -472,9 +483,8 @@ class OrdinaryKriging3D(_KrigingBase):
         if style != "grid" and style != "masked" and style != "points":
             raise ValueError("style argument must be 'grid', 'points', or 'masked'")
         self._check_backend(backend, n_closest_points)
-        pts, shape, mask = self._points_from(style, (xpoints, ypoints, zpoints), mask)
-        pts_adj = core.adjust_for_anisotropy(pts, self._center(), self._scaling(), self._angle())
-        z, ss = self._solve(pts_adj, mask, None)
+        pts_adj, shape, mask, extra = self._prepare_points(style, (xpoints, ypoints, zpoints), mask)
+        z, ss = self._solve(pts_adj, mask, extra)
         return self._finish(z, ss, style, shape, mask, backend)
 
 
@@ -540,12 +550,15 @@ class UniversalKriging3D(OrdinaryKriging3D):
         if style != "grid" and style != "masked" and style != "points":
             raise ValueError("style argument must be 'grid', 'points', or 'masked'")
         self._check_backend(backend, None)
-        pts, shape, mask = self._points_from(style, (xpoints, ypoints, zpoints), mask)
+        pts_adj, shape, mask, extra = self._prepare_points(style, (xpoints, ypoints, zpoints), mask, specified_drift_arrays)
+        z, ss = self._solve(pts_adj, mask, extra)
+        return self._finish(z, ss, style, shape, mask, backend)
+
+    def _prepare_points(self, style, axes, mask, specified_drift_arrays=None):
+        pts, shape, mask = self._points_from(style, axes, mask)
         rows = self._spec_rows(style, shape, pts.shape[0], specified_drift_arrays)
         pts_adj = core.adjust_for_anisotropy(pts, self._center(), self._scaling(), self._angle())
         if self.functional_drift:
             rows.extend(np.asarray(f(pts_adj[:, 0], pts_adj[:, 1], pts_adj[:, 2]), dtype=np.float64)
                         for f in self.functional_drift_terms)
-        extra = np.array(rows, dtype=np.float64) if rows else None
-        z, ss = self._solve(pts_adj, mask, extra)
-        return self._finish(z, ss, style, shape, mask, backend)
+        return pts_adj, shape, mask, (np.array(rows, dtype=np.float64) if rows else None)

@@ -15,8 +15,21 @@ FUNCS = {
 }
 
 
+NON_EXECUTE = ("fit_variograms", "pseudo_dup")  # fixtures that are not (stations, grid) -> (z, ss) cases
+
+
 def names():
-    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
+    return sorted(n for n in (os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
+                  if n not in NON_EXECUTE)
+
+
+def external_z(g, x, y):
+    """external_Z drift values by an implementation independent of the product's: SciPy's linear
+    RegularGridInterpolator on the (demy, demx) grid = bilinear interpolation (uk.py:512-628)."""
+    from scipy.interpolate import RegularGridInterpolator
+
+    f = RegularGridInterpolator((g["demy"], g["demx"]), g["dem"], method="linear")
+    return f(np.stack([np.ravel(y), np.ravel(x)], axis=1)).reshape(np.shape(x))
 
 
 def load(name):
@@ -39,9 +52,20 @@ def state_from(name, g):
         exact_values=bool(g["exact"]) if "exact" in g else True,
         regional_linear=rl,
         point_log=g["wells"] if "wells" in g else None,
-        specified_data=[g["spec_data"]] if "spec_data" in g else [],
+        specified_data=([external_z(g, g["x"], g["y"])] if "dem" in g else []) + ([g["spec_data"]] if "spec_data" in g else []),
         functional=FUNCS.get(name, []),
     )
+
+
+def spec_point_arrays(g):
+    """Per-point drift arrays the ORACLE needs (external_Z evaluated on the grid, then specified)."""
+    out = []
+    if "dem" in g:
+        GX, GY = np.meshgrid(g["gridx"], g["gridy"])
+        out.append(external_z(g, GX, GY))
+    if "spec_grid" in g:
+        out.append(g["spec_grid"])
+    return out
 
 
 def grid_args(g):
@@ -66,6 +90,9 @@ def amd_model_from(name, g):
     if "wells" in g:
         terms.append("point_log")
         kw["point_drift"] = g["wells"]
+    if "dem" in g:
+        terms.append("external_Z")
+        kw.update(external_drift=g["dem"], external_drift_x=g["demx"], external_drift_y=g["demy"])
     if "spec_data" in g:
         terms.append("specified")
         kw["specified_drift"] = [g["spec_data"]]

@@ -1,0 +1,160 @@
+"""CPU-side checks: the C-ABI library builds/loads and exports every entry point include/mikrige.h declares
+(no compute call is made), the ctypes mirror agrees with the header, and the host-side logic
+(parameter handling, anisotropy, bilinear external-Z lookup, argument validation) behaves like the
+reference.  None of this needs a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import kriging_oracle as ko
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    text = open(os.path.join(ROOT, "include", "mikrige.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mik_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from pykrige_amd import _lib, build
+
+    build.build_library()  # no-op when up to date; cross-compiles for gfx950 without a GPU
+    lib = _lib.load()
+    names = _header_functions()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), "libmikrige.so does not export %s" % n
+    assert set(_lib.SIGNATURES) == set(names)
+
+
+def test_ctypes_structs_match_header_layout():
+    from pykrige_amd import _lib
+
+    # mik_problem: 2 x int32, int64, 4 pointers, 3 doubles, double, 4 x int32, 3 pointers = 120 bytes on LP64
+    assert ctypes.sizeof(_lib.MikProblem) == 4 + 4 + 8 + 4 * 8 + 3 * 8 + 8 + 4 * 4 + 3 * 8
+    assert ctypes.sizeof(_lib.MikPoints) == 8 + 5 * 8
+    assert ctypes.sizeof(_lib.MikTiming) == 5 * 8 + 8 + 8 + 4 * 4
+
+
+def test_no_gpu_means_a_loud_error_not_a_fallback():
+    import pykrige_amd as pa
+    from pykrige_amd import _lib
+
+    if _lib.load().mik_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    ok = pa.OrdinaryKriging([0.0, 1.0, 2.0], [0.0, 1.0, 0.5], [1.0, 2.0, 3.0], variogram_model="linear",
+                            variogram_parameters=[1.0, 0.1])
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        ok.execute("grid", [0.0, 1.0], [0.0, 1.0])
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "pykrige_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", text, flags=re.M), f
+                assert "kriging_oracle" not in text, f
+
+
+def test_parameter_list_rules():
+    from pykrige_amd import core
+
+    assert core.make_variogram_parameter_list("spherical", [1.0, 0.5, 0.1]) == [0.9, 0.5, 0.1]  # list form = FULL sill
+    assert core.make_variogram_parameter_list("gaussian", {"psill": 2.0, "range": 3.0, "nugget": 0.5}) == [2.0, 3.0, 0.5]
+    assert core.make_variogram_parameter_list("exponential", {"sill": 2.0, "range": 3.0, "nugget": 0.5}) == [1.5, 3.0, 0.5]
+    assert core.make_variogram_parameter_list("linear", {"slope": 2.0, "nugget": 0.5}) == [2.0, 0.5]
+    assert core.make_variogram_parameter_list("power", [1.0, 1.5, 0.0]) == [1.0, 1.5, 0.0]
+    assert core.make_variogram_parameter_list("linear", None) is None
+    with pytest.raises(ValueError):
+        core.make_variogram_parameter_list("linear", [1.0, 2.0, 3.0])
+    with pytest.raises(KeyError):
+        core.make_variogram_parameter_list("spherical", {"range": 1.0, "nugget": 0.0})
+    with pytest.raises(TypeError):
+        core.make_variogram_parameter_list("spherical", (1.0, 2.0, 3.0))
+
+
+def test_host_anisotropy_is_bit_identical_to_the_oracle_restatement():
+    from pykrige_amd import core
+
+    rng = np.random.default_rng(0)
+    X2, X3 = rng.random((500, 2)) * 7 - 3, rng.random((500, 3)) * 7 - 3
+    a = core.adjust_for_anisotropy(X2, [0.3, -0.2], [3.0], [45.0])
+    b = ko.adjust_for_anisotropy(X2, [0.3, -0.2], [3.0], [45.0])
+    assert np.array_equal(a, b)
+    a = core.adjust_for_anisotropy(X3, [0.3, -0.2, 1.0], [1.5, 2.0], [10.0, 20.0, 30.0])
+    b = ko.adjust_for_anisotropy(X3, [0.3, -0.2, 1.0], [1.5, 2.0], [10.0, 20.0, 30.0])
+    assert np.array_equal(a, b)
+    # known answers of tests/test_core.py:83-111
+    x = np.array([1.0, 0.0, -1.0, 0.0])
+    y = np.array([0.0, 1.0, 0.0, -1.0])
+    r = core.adjust_for_anisotropy(np.vstack((x, y)).T, [0.0, 0.0], [2.0], [90.0])
+    np.testing.assert_allclose(r[:, 0], [0.0, 1.0, 0.0, -1.0], atol=1e-12)
+    np.testing.assert_allclose(r[:, 1], [-2.0, 0.0, 2.0, 0.0], atol=1e-12)
+
+
+def test_bilinear_external_z():
+    from pykrige_amd import core
+
+    gx, gy = np.array([0.0, 1.0, 2.0, 4.0]), np.array([10.0, 20.0, 40.0])
+    zg = np.add.outer(gy * 0.5, gx * 2.0)  # plane: bilinear interpolation is exact
+    x = np.array([0.0, 0.5, 2.0, 3.3, 4.0, 1.0])
+    y = np.array([10.0, 12.0, 40.0, 25.0, 20.0, 20.0])
+    np.testing.assert_allclose(core.bilinear_zscalars(zg, gx, gy, x, y), y * 0.5 + x * 2.0, rtol=1e-13)
+    with pytest.raises(ValueError):
+        core.bilinear_zscalars(zg, gx, gy, np.array([5.0]), np.array([10.0]))
+
+
+def test_constructor_and_execute_argument_validation():
+    import pykrige_amd as pa
+
+    x, y, v = [0.0, 1.0, 2.0, 0.5], [0.0, 1.0, 0.5, 2.0], [1.0, 2.0, 3.0, 0.0]
+    with pytest.raises(ValueError):
+        pa.OrdinaryKriging(x, y, v, variogram_model="blurg")
+    with pytest.raises(ValueError):
+        pa.OrdinaryKriging(x, y, v, variogram_model="linear", variogram_parameters=[1.0, 0.0], exact_values="blurg")
+    with pytest.raises(ValueError):
+        pa.OrdinaryKriging(x, y, v, variogram_model="linear", variogram_parameters=[1.0, 0.0], pseudo_inv_type="qr")
+    with pytest.raises(ValueError):
+        pa.UniversalKriging(x, y, v, variogram_model="linear", variogram_parameters=[1.0, 0.0], drift_terms=["point_log"])
+    with pytest.raises(TypeError):
+        pa.UniversalKriging(x, y, v, variogram_model="linear", variogram_parameters=[1.0, 0.0], drift_terms=["specified"],
+                            specified_drift=np.zeros(4))
+    ok = pa.OrdinaryKriging(x, y, v, variogram_model="linear", variogram_parameters=[1.0, 0.0])
+    for bad in (dict(style="blurg"), dict(style="grid", backend="mystery")):
+        with pytest.raises(ValueError):
+            ok.execute(bad.get("style", "grid"), [0.0, 1.0], [0.0, 1.0], backend=bad.get("backend", "vectorized"))
+    with pytest.raises(IOError):
+        ok.execute("masked", [0.0, 1.0], [0.0, 1.0])
+    with pytest.raises(ValueError):
+        ok.execute("points", [0.0, 1.0], [0.0])
+    with pytest.raises(ValueError):
+        ok.execute("grid", [0.0], [0.0], n_closest_points=1)
+    fit = pa.OrdinaryKriging(np.random.default_rng(1).random(40), np.random.default_rng(2).random(40),
+                             np.random.default_rng(3).random(40), variogram_model="spherical")
+    assert len(fit.variogram_model_parameters) == 3 and all(np.isfinite(fit.variogram_model_parameters))
+
+
+def test_variogram_fit_matches_reference_fits():
+    """Constructor-time fit (host, not the hot path) against parameters the real reference fitted
+    (tests/golden/fit_variograms.npz, oracle/make_golden_extra.py)."""
+    import pykrige_amd as pa
+    from tests import _fixtures as fx
+
+    g = fx.load("fit_variograms")
+    for model in ("linear", "power", "gaussian", "spherical", "exponential", "hole-effect"):
+        for weight in (False, True):
+            key = "%s_%d" % (model.replace("-", ""), int(weight))
+            ok = pa.OrdinaryKriging(g["x"], g["y"], g["v"], variogram_model=model, nlags=8, weight=weight,
+                                    anisotropy_scaling=2.0, anisotropy_angle=30.0)
+            np.testing.assert_allclose(ok.lags, g["lags_" + key], rtol=1e-12)
+            np.testing.assert_allclose(ok.semivariance, g["semi_" + key], rtol=1e-12)
+            np.testing.assert_allclose(ok.variogram_model_parameters, g["par_" + key], rtol=1e-6, atol=1e-9)
+    ok3 = pa.OrdinaryKriging3D(g["x3"], g["y3"], g["z3"], g["v3"], variogram_model="spherical", nlags=6)
+    np.testing.assert_allclose(ok3.variogram_model_parameters, g["par_3d"], rtol=1e-6, atol=1e-9)

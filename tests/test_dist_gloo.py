@@ -1,0 +1,123 @@
+"""world_size-2 test of the multi-GPU host path on CPU (gloo): slab partition, unique-id exchange with the
+RCCL-unavailable fallback, per-rank solve, gather.  The device handle is replaced by a stand-in that
+computes with the CPU oracle (tests may do that; the product never does)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_slab_bounds_cover_everything():
+    from pykrige_amd.dist import slab_bounds
+
+    for n in (0, 1, 7, 8, 1000, 1001):
+        for world in (1, 2, 3, 8):
+            spans = [slab_bounds(n, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        slab_bounds(10, 2, 2)
+
+
+class OracleHandle:
+    """Stand-in for _lib.Handle with the same methods, backed by the CPU oracle."""
+
+    def __init__(self):
+        self.calls = []
+
+    def set_problem(self, **kw):
+        from oracle import kriging_oracle as ko
+
+        self.kw = kw
+        nd = kw["ndim"]
+        coords = np.stack([kw["xs"], kw["ys"]] + ([kw["zs"]] if nd == 3 else []), 1)
+        inv_model = {v: k for k, v in __import__("pykrige_amd")._lib.MODEL_IDS.items()}[kw["model_id"]]
+        self.st = ko.KrigingState(ndim=nd, coords_orig=coords, values=kw["values"], model=inv_model,
+                                  params=list(kw["params"]), scaling=[1.0] * (nd - 1), angle=[0.0] * (2 * nd - 3),
+                                  exact_values=kw["exact_values"], regional_linear=kw["regional_linear"])
+        self.calls.append("set_problem")
+
+    def factor(self):
+        self.calls.append("factor")
+
+    def comm_init(self, world, rank, uid):
+        raise RuntimeError("no RCCL on a CPU box")
+
+    def bcast_factor(self, root):
+        raise AssertionError("must not be reached after the RCCL fallback")
+
+    def set_points(self, px, py, pz=None, mask=None, extra_rows=None):
+        self.pts = np.stack([px, py] + ([pz] if pz is not None else []), 1)
+        self.mask = mask
+
+    def predict(self):
+        self.calls.append("predict")
+
+    def get_results(self):
+        from oracle import kriging_oracle as ko
+
+        z, ss = np.zeros(len(self.pts)), np.zeros(len(self.pts))
+        keep = np.ones(len(self.pts), bool) if self.mask is None else ~np.asarray(self.mask, bool)
+        if keep.any():
+            z[keep], ss[keep] = ko.solve_points(self.st, self.pts[keep])
+        return z, ss
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    import pykrige_amd as pa
+    from oracle import kriging_oracle as ko
+    from pykrige_amd.dist import ShardedExecutor
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(5)
+        x, y, v = rng.random(60), rng.random(60), rng.random(60)
+        ok = pa.OrdinaryKriging(x, y, v, variogram_model="exponential", variogram_parameters=[1.0, 0.3, 0.01])
+        hdl = OracleHandle()
+        ex = ShardedExecutor(ok, handle_factory=lambda: hdl)
+        assert ex.exchange.startswith("redundant_factor"), ex.exchange  # RCCL init failed on every rank -> fallback
+        gx, gy = np.linspace(0, 1, 13), np.linspace(0, 1, 9)
+        z, ss = ex.execute("grid", gx, gy, backend="loop")
+        mask = rng.random((9, 13)) < 0.3
+        zm, ssm = ex.execute("masked", gx, gy, mask=mask, backend="loop")
+        st = ko.KrigingState(ndim=2, coords_orig=np.stack([x, y], 1), values=v, model="exponential",
+                             params=ko.internal_parameters("exponential", [1.0, 0.3, 0.01]))
+        zr, sr = ko.execute(st, "grid", gx, gy)
+        ok_grid = bool(np.allclose(z, zr, atol=1e-12) and np.allclose(ss, sr, atol=1e-12) and z.shape == (9, 13))
+        ok_mask = bool(np.allclose(np.ma.getdata(zm)[~mask], zr[~mask], atol=1e-12) and np.all(np.ma.getdata(zm)[mask] == 0.0)
+                       and isinstance(zm, np.ma.MaskedArray))
+        q.put((rank, ok_grid, ok_mask, len(hdl.pts), hdl.calls.count("factor")))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_execute_world2_gloo():
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [o[0] for o in out] == [0, 1]
+    assert all(o[1] and o[2] for o in out), out
+    assert sum(o[3] for o in out) == 13 * 9  # the last execute's slabs partition the grid
+    assert all(o[4] == 2 for o in out)       # redundant factorisation: each rank factored in each execute

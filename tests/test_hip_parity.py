@@ -34,7 +34,7 @@ def _handle_for(st, **opts):
         h.set_option(k, v)
     wells = st.wells_adj
     extra = []
-    extra += list(st.specified_data)
+    extra += list(st.specified_data)  # for "dem" fixtures the first entry is the external_Z drift at the stations
     extra += [f(*[st.coords_adj[:, k] for k in range(st.ndim)]) for f in st.functional]
     h.set_problem(ndim=st.ndim, xs=st.coords_adj[:, 0], ys=st.coords_adj[:, 1],
                   zs=st.coords_adj[:, 2] if st.ndim == 3 else None, values=st.values,
@@ -114,6 +114,47 @@ def test_external_known_answers():
     z, ss = fx.amd_model_from("ref_test_ok3d", g).execute("grid", g["gridx"], g["gridy"], g["gridz"], backend="loop")
     np.testing.assert_allclose(z, g["answer_z"], rtol=1e-3, atol=1e-8)
     np.testing.assert_allclose(ss, g["answer_ss"], rtol=1e-3, atol=1e-8)
+
+
+def test_external_drift_known_answer_and_pseudo_inverse():
+    g = fx.load("ref_test_uk_external")  # tests/test_core.py:1479-1507
+    z, _ = fx.amd_model_from("ref_test_uk_external", g).execute("grid", g["gridx"], g["gridy"], backend="loop")
+    np.testing.assert_allclose(z, g["answer"], rtol=1e-5, atol=1e-8)
+    import pykrige_amd as pa
+
+    g = fx.load("pseudo_dup")  # duplicated stations (tests/test_core.py:2913-2949); reference outputs for both P_INV types
+    d = g["d"]
+    for p_type in ("pinv", "pinvh"):
+        ok = pa.OrdinaryKriging(d[:, 0], d[:, 1], d[:, 2], variogram_parameters=[1.0, 0.0], pseudo_inv=True,
+                                pseudo_inv_type=p_type)
+        z, ss = ok.execute("grid", np.linspace(0, 1, 5), np.linspace(0, 1, 4), backend="loop")
+        assert ok.last_timing["factor_path"] == 3
+        np.testing.assert_allclose(z, g["z_" + p_type], rtol=0, atol=1e-8)
+        np.testing.assert_allclose(ss, g["ss_" + p_type], rtol=0, atol=1e-6)
+        z1, _ = ok.execute("points", 0.0, 0.0, backend="loop")
+        assert np.isclose(z1.item(), 2.0)  # mean of the redundant data
+
+
+def test_rccl_single_rank_broadcast_path():
+    """The multi-GPU exchange with world size 1: dlopen(librccl), ncclCommInitRank, ncclBroadcast of the
+    inverse + c on the handle's stream.  (More ranks cannot be had on a 1-GPU box; tests/test_dist_gloo.py
+    covers the host protocol with world size 2.)"""
+    lib = _lib()
+    g = fx.load("ok2d_n2000")
+    st = fx.state_from("ok2d_n2000", g)
+    h = _handle_for(st)
+    h.comm_init(1, 0, lib.Handle.comm_unique_id())
+    h.factor()
+    ref = h.get_matrix(1)
+    h.bcast_factor(0)
+    np.testing.assert_array_equal(h.get_matrix(1), ref)
+    GX, GY = np.meshgrid(g["gridx"], g["gridy"])
+    pts = ko.adjust_for_anisotropy(np.stack([GX.ravel(), GY.ravel()], 1), st.center, st.scaling, st.angle)
+    h.set_points(pts[:, 0], pts[:, 1])
+    h.predict()
+    z, ss = h.get_results()
+    np.testing.assert_allclose(z, g["z"].ravel(), rtol=0, atol=Z_TOL)
+    np.testing.assert_allclose(ss, g["ss"].ravel(), rtol=0, atol=SS_TOL)
 
 
 def test_masked_and_points_styles():
