@@ -22,22 +22,33 @@ namespace mik {
 struct Vario {
   int model;
   double p0, p1, p2;
-  double c0;
+  double c0;     // gaussian (range*4/7)^2 ; exponential / hole-effect range/3
+  double c0inv;  // 1 / c0
+  double sa, sb; // spherical: 3/(2 range), 1/(2 range^3)
 };
 
-template <int MODEL>
-__device__ __forceinline__ double vario(const Vario& v, double d) {
+// FAST = the per-point right-hand-side path (5e9 evaluations at config 2, VALU-bound): divisions by
+// the model constants become multiplications by their host-computed reciprocals (<= 1 ulp change of the
+// exp argument; 1e-16 relative on gamma, tolerance is 1e-8).  FAST = false keeps the reference's operation
+// order and is used where it is free (the N x N matrix assembly).
+template <int MODEL, bool FAST>
+__device__ __forceinline__ double vario(const Vario& v, double d, double d2) {
   if (MODEL == 0) return v.p0 * d + v.p1;                               // linear   :25-29
   if (MODEL == 1) return v.p0 * pow(d, v.p1) + v.p2;                    // power    :32-37
-  if (MODEL == 2) return v.p0 * (1.0 - exp(-(d * d) / v.c0)) + v.p2;    // gaussian :40-45
+  if (MODEL == 2) {                                                     // gaussian :40-45 (needs d^2 only)
+    return v.p0 * (1.0 - exp(FAST ? -d2 * v.c0inv : -d2 / v.c0)) + v.p2;
+  }
   if (MODEL == 3) {                                                     // spherical:56-70 (d <= range)
     const double r = v.p1;
-    if (d <= r) return v.p0 * ((3.0 * d) / (2.0 * r) - (d * d * d) / (2.0 * (r * r * r))) + v.p2;
+    if (d <= r) {
+      if (FAST) return v.p0 * (d * v.sa - (d2 * d) * v.sb) + v.p2;
+      return v.p0 * ((3.0 * d) / (2.0 * r) - (d * d * d) / (2.0 * (r * r * r))) + v.p2;
+    }
     return v.p0 + v.p2;
   }
-  if (MODEL == 4) return v.p0 * (1.0 - exp(-d / v.c0)) + v.p2;          // exponential :48-53
+  if (MODEL == 4) return v.p0 * (1.0 - exp(FAST ? -d * v.c0inv : -d / v.c0)) + v.p2;  // exponential :48-53
   {                                                                     // hole-effect :73-81
-    const double q = d / v.c0;
+    const double q = FAST ? d * v.c0inv : d / v.c0;
     return v.p0 * (1.0 - (1.0 - q) * exp(-q)) + v.p2;
   }
 }
@@ -118,7 +129,7 @@ __global__ void __launch_bounds__(256) k_assemble(AsmArgs a) {
         } else {
           s2 = dx * dx + dy * dy;
         }
-        val = a.shift - vario<MODEL>(a.v, sqrt(s2));
+        val = a.shift - vario<MODEL, false>(a.v, sqrt(s2), s2);
       }
     } else if (i >= a.N && j >= a.N) {
       val = 0.0;
@@ -211,9 +222,10 @@ __global__ void __launch_bounds__(256) k_rhs(RhsArgs a) {
         } else {
           s2 = dx * dx + dy * dy;
         }
-        const double d = sqrt(s2);
-        double g = -vario<MODEL>(a.v, d);
-        if (a.exact && fabs(d) <= a.eps) g = 0.0;
+        // gaussian needs only d^2: no sqrt, and |d| <= eps becomes d^2 <= eps^2 (ok.py:665: abs(bd) <= eps)
+        const double d = (MODEL == 2) ? 0.0 : sqrt(s2);
+        double g = -vario<MODEL, true>(a.v, d, s2);
+        if (a.exact && ((MODEL == 2) ? (s2 <= a.eps * a.eps) : (d <= a.eps))) g = 0.0;
         val[q] = g;
       }
     } else if (j < a.N + a.p) {
@@ -290,9 +302,16 @@ __device__ __forceinline__ void glds16(const double* g, double* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((mik_gptr_t)g, (mik_lptr_t)lds_wave_base, 16, 0, 0);
 }
 
+// NAI = 16-row groups per wave: 4 -> wave tile 64 x 64, 4 waves (256 threads); 2 -> wave tile 32 x 64,
+// 8 waves (512 threads).  The block tile is 128 x 128 either way.
+template <int NAI>
 __device__ __forceinline__ void gemm_core(const double* __restrict__ Ag, long lda, const double* __restrict__ Bg,
-                                          long ldb, int kbeg, int kend, d4 (&acc)[4][4], GemmSmem& sm) {
+                                          long ldb, int kbeg, int kend, d4 (&acc)[NAI][4], GemmSmem& sm) {
   if (kbeg >= kend) return;  // block-uniform
+  constexpr int WROWS = 16 * NAI;            // rows of the wave tile
+  constexpr int NTHR = 64 * 2 * (128 / WROWS);
+  constexpr int PROWS = NTHR / 8;            // rows staged per pass (8 threads x 16 B per 128-B row)
+  constexpr int NPASS = 128 / PROWS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   // staging: thread -> (row lrow + 32p, 16-byte slot tid&7); the SOURCE k-pair is the slot XOR the row's swizzle
@@ -300,8 +319,8 @@ __device__ __forceinline__ void gemm_core(const double* __restrict__ Ag, long ld
   const int lrow = tid >> 3, slot = tid & 7;
   const double* ap = Ag + (long)lrow * lda + ((slot ^ (lrow & 2)) << 1);
   const double* bp = Bg + (long)lrow * ldb + ((slot ^ ((lrow >> 1) & 7)) << 1);
-  const long a32 = 32 * lda, b32 = 32 * ldb;
-  const int wrow = wave * 8;  // this wave's 8 rows (1 KiB) inside each 32-row pass
+  const long a32 = PROWS * lda, b32 = PROWS * ldb;
+  const int wrow = wave * 8;  // this wave's 8 rows (1 KiB) inside each pass
   // Fragment reads are ds_read_b128: lane group kq = lane>>4 owns the k PAIR c = 4m + kq of the 16-wide
   // tile (m = 0, 1), i.e. MFMA step t = 2m + h contracts k = 8m + 2kq + h -- the same bijection of k on
   // both operands.  A: row wm*64 + 4x + i (i = lane&3), identical for the 4 blocks (broadcast);
@@ -311,24 +330,24 @@ __device__ __forceinline__ void gemm_core(const double* __restrict__ Ag, long ld
   int aoff[2], boff[2];
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
-    aoff[m] = (wm * 64 + ia) * MIK_BK + (((4 * m + kq) ^ (ia & 2)) << 1);
+    aoff[m] = (wm * WROWS + ia) * MIK_BK + (((4 * m + kq) ^ (ia & 2)) << 1);
     boff[m] = (wn * 64 + jb) * MIK_BK + (((4 * m + kq) ^ ((jb >> 1) & 7)) << 1);
   }
   // K runs DOWNWARDS (kend-16, kend-32, .. kbeg): in the symmetric contraction every tile then starts at
   // the same k = kend, so the tiles of a supertile stream the same operand panels in near lockstep (L2 reuse).
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    glds16(ap + p * a32 + (kend - MIK_BK), &sm.As[0][wrow + 32 * p][0]);
-    glds16(bp + p * b32 + (kend - MIK_BK), &sm.Bs[0][wrow + 32 * p][0]);
+  for (int p = 0; p < NPASS; ++p) {
+    glds16(ap + p * a32 + (kend - MIK_BK), &sm.As[0][wrow + PROWS * p][0]);
+    glds16(bp + p * b32 + (kend - MIK_BK), &sm.Bs[0][wrow + PROWS * p][0]);
   }
   __syncthreads();
   int buf = 0;
   for (int k = kend - MIK_BK; k >= kbeg; k -= MIK_BK) {
     if (k > kbeg) {
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        glds16(ap + p * a32 + k - MIK_BK, &sm.As[buf ^ 1][wrow + 32 * p][0]);
-        glds16(bp + p * b32 + k - MIK_BK, &sm.Bs[buf ^ 1][wrow + 32 * p][0]);
+      for (int p = 0; p < NPASS; ++p) {
+        glds16(ap + p * a32 + k - MIK_BK, &sm.As[buf ^ 1][wrow + PROWS * p][0]);
+        glds16(bp + p * b32 + k - MIK_BK, &sm.Bs[buf ^ 1][wrow + PROWS * p][0]);
       }
     }
     const double* as = &sm.As[buf][0][0];
@@ -338,21 +357,21 @@ __device__ __forceinline__ void gemm_core(const double* __restrict__ Ag, long ld
       // v_mfma_f64_4x4x4_4b_f64: A lane (k=l>>4, blk=(l>>2)&3, i=l&3), B lane (k, blk, j=l&3), D lane (i=l>>4, blk, j).
       // A fragments are replicated over the 4 blocks, B fragments put 4 column groups in the 4 blocks, so
       // MFMA (ra, bi) yields rows 4*ra + (l>>4), columns 16*bi + (l&15) of the wave tile.
-      double2 fa[16], fb[4];
+      double2 fa[4 * NAI], fb[4];
 #pragma unroll
-      for (int x = 0; x < 16; ++x) fa[x] = *reinterpret_cast<const double2*>(as + aoff[m] + 4 * x * MIK_BK);
+      for (int x = 0; x < 4 * NAI; ++x) fa[x] = *reinterpret_cast<const double2*>(as + aoff[m] + 4 * x * MIK_BK);
 #pragma unroll
       for (int x = 0; x < 4; ++x) fb[x] = *reinterpret_cast<const double2*>(bs + boff[m] + 16 * x * MIK_BK);
-      // all 64 accumulators once (first k of the pair), then all 64 again: dependent MFMAs are 64 issues apart
+      // all accumulators once (first k of the pair), then all again: dependent MFMAs are >= 32 issues apart
 #pragma unroll
-      for (int ai = 0; ai < 4; ++ai)
+      for (int ai = 0; ai < NAI; ++ai)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
           for (int bi = 0; bi < 4; ++bi)
             acc[ai][bi][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa[4 * ai + r].x, fb[bi].x, acc[ai][bi][r], 0, 0, 0);
 #pragma unroll
-      for (int ai = 0; ai < 4; ++ai)
+      for (int ai = 0; ai < NAI; ++ai)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -411,74 +430,77 @@ __device__ __forceinline__ bool super_tile(int nIblk, int nTblk, int& iblk, int&
 // Tile order: tblk slow, iblk fast -> consecutive tiles share the B panel; in SYM mode iblk ascending
 // is also longest-first.
 // ------------------------------------------------------------------------------------------------
-template <bool SYM>
-__global__ void __launch_bounds__(256, 2)
+template <bool SYM, int NAI>
+__global__ void __launch_bounds__(64 * 2 * (8 / NAI), 2 * (4 / NAI))
 k_contract(const double* __restrict__ Ainv, long lda, const double* __restrict__ Bt, long ldb,
            double* __restrict__ part, int palloc, int nIblk, int kend) {
+  constexpr int WROWS = 16 * NAI, NWM = 128 / WROWS;
   __shared__ GemmSmem sm;
   int iblk, tblk;
   if (!super_tile(nIblk, palloc / MIK_BN, iblk, tblk)) return;
-  const int t0 = tblk * MIK_BN;
+  const int i0 = iblk * MIK_BM, t0 = tblk * MIK_BN;
+  const double* Ag = Ainv + (long)i0 * lda;
   const double* Bg = Bt + (long)t0 * ldb;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 1, wn = wave & 1, lq = lane >> 4, lc = lane & 15;
-  {
-    const int i0 = iblk * MIK_BM;
-    d4 acc[4][4];
+  d4 acc[NAI][4];
 #pragma unroll
-    for (int x = 0; x < 4; ++x)
+  for (int x = 0; x < NAI; ++x)
 #pragma unroll
-      for (int y = 0; y < 4; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
-    const double* Ag = Ainv + (long)i0 * lda;
-    if (SYM) {  // result = diag + 2 * offdiag: off-diagonal K blocks first (downwards from kend), then the diagonal block
-      const int kd = (i0 + MIK_BM) < kend ? (i0 + MIK_BM) : kend;
-      gemm_core(Ag, lda, Bg, ldb, kd, kend, acc, sm);
+    for (int y = 0; y < 4; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
+  if (SYM) {  // result = diag + 2 * offdiag: off-diagonal K blocks first (downwards from kend), then the diagonal block
+    const int kd = (i0 + MIK_BM) < kend ? (i0 + MIK_BM) : kend;
+    gemm_core<NAI>(Ag, lda, Bg, ldb, kd, kend, acc, sm);
 #pragma unroll
-      for (int x = 0; x < 4; ++x)
+    for (int x = 0; x < NAI; ++x)
 #pragma unroll
-        for (int y = 0; y < 4; ++y) acc[x][y] *= 2.0;
-      gemm_core(Ag, lda, Bg, ldb, i0, kd, acc, sm);
-    } else {
-      gemm_core(Ag, lda, Bg, ldb, 0, kend, acc, sm);
+      for (int y = 0; y < 4; ++y) acc[x][y] *= 2.0;
+    gemm_core<NAI>(Ag, lda, Bg, ldb, i0, kd, acc, sm);
+  } else {
+    gemm_core<NAI>(Ag, lda, Bg, ldb, 0, kend, acc, sm);
+  }
+  // epilogue: column sums of B .* W over this wave's rows; independent loads issued in batches
+  // (the fragment registers are dead here); without the scheduling barriers hipcc serialises
+  // load -> wait -> fma once per element (~1 us each)
+  double cs[4];
+#pragma unroll
+  for (int bp = 0; bp < 2; ++bp) {
+    double bv[2][4 * NAI];
+#pragma unroll
+    for (int b2 = 0; b2 < 2; ++b2) {
+      const long t = t0 + wn * 64 + (2 * bp + b2) * 16 + lc;
+      const double* brow = Bt + t * ldb + i0 + wm * WROWS + lq;
+#pragma unroll
+      for (int ai = 0; ai < NAI; ++ai)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[b2][ai * 4 + r] = brow[ai * 16 + 4 * r];
     }
-    // epilogue: column sums of B .* W over this tile's 128 rows
-    double cs[4];
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int bp = 0; bp < 2; ++bp) {
-      // 32 independent loads in flight per batch (the fragment registers are dead here); without the
-      // scheduling barriers hipcc serialises load -> wait -> fma 64 times (~1 us each) per tile
-      double bv[2][16];
+    for (int b2 = 0; b2 < 2; ++b2) {
+      const int bi = 2 * bp + b2;
+      double s = 0.0;
 #pragma unroll
-      for (int b2 = 0; b2 < 2; ++b2) {
-        const long t = t0 + wn * 64 + (2 * bp + b2) * 16 + lc;
-        const double* brow = Bt + t * ldb + i0 + wm * 64 + lq;
+      for (int ai = 0; ai < NAI; ++ai)
 #pragma unroll
-        for (int ai = 0; ai < 4; ++ai)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) bv[b2][ai * 4 + r] = brow[ai * 16 + 4 * r];
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int b2 = 0; b2 < 2; ++b2) {
-        const int bi = 2 * bp + b2;
-        double s = 0.0;
-#pragma unroll
-        for (int ai = 0; ai < 4; ++ai)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) s += bv[b2][ai * 4 + r] * acc[ai][bi][r];
-        s += __shfl_xor(s, 16);
-        s += __shfl_xor(s, 32);
-        cs[bi] = s;
-      }
-      __builtin_amdgcn_sched_barrier(0);
+        for (int r = 0; r < 4; ++r) s += bv[b2][ai * 4 + r] * acc[ai][bi][r];
+      s += __shfl_xor(s, 16);
+      s += __shfl_xor(s, 32);
+      cs[bi] = s;
     }
-    double* red = &sm.As[0][0][0];  // gemm_core ended with a barrier: staging LDS is free
-    if (lq == 0) {
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  double* red = &sm.As[0][0][0];  // gemm_core ended with a barrier: staging LDS is free
+  if (lq == 0) {
 #pragma unroll
-      for (int bi = 0; bi < 4; ++bi) red[wm * 128 + wn * 64 + bi * 16 + lc] = cs[bi];
-    }
-    __syncthreads();
-    if (threadIdx.x < 128) part[(long)iblk * palloc + t0 + threadIdx.x] = red[threadIdx.x] + red[128 + threadIdx.x];
+    for (int bi = 0; bi < 4; ++bi) red[wm * 128 + wn * 64 + bi * 16 + lc] = cs[bi];
+  }
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    double v = 0.0;
+#pragma unroll
+    for (int w = 0; w < NWM; ++w) v += red[w * 128 + threadIdx.x];
+    part[(long)iblk * palloc + t0 + threadIdx.x] = v;
   }
 }
 
@@ -669,7 +691,7 @@ k_panel(const double* __restrict__ A, long lda, const double* __restrict__ Bt, d
   for (int x = 0; x < 4; ++x)
 #pragma unroll
     for (int y = 0; y < 4; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
-  gemm_core(A + (long)i0 * lda, lda, Bt, 128, 0, 128, acc, sm);
+  gemm_core<4>(A + (long)i0 * lda, lda, Bt, 128, 0, 128, acc, sm);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 1, wn = wave & 1, lq = lane >> 4, lc = lane & 15;
 #pragma unroll
@@ -718,7 +740,7 @@ k_update(double* __restrict__ T, long ld, int nblk, int kb, const double* __rest
   for (int x = 0; x < 4; ++x)
 #pragma unroll
     for (int y = 0; y < 4; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
-  gemm_core(Cold + (long)i0 * 128, 128, Rt + (long)j0 * 128, 128, 0, 128, acc, sm);
+  gemm_core<4>(Cold + (long)i0 * 128, 128, Rt + (long)j0 * 128, 128, 0, 128, acc, sm);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 1, wn = wave & 1, lq = lane >> 4, lc = lane & 15;
 #pragma unroll

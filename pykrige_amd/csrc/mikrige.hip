@@ -120,6 +120,7 @@ struct mik_handle {
   // work
   DevBuf Bt, part;
   // options
+  int opt_waves = 8;  // waves per contraction block: 4 (wave tile 64x64) or 8 (32x64)
   int opt_factor = 0, opt_sym = 1, opt_engine = 0;  // engine: 0 = v_mfma_f64 contraction, 1 = v_fma_f64 (VALU) contraction
   long opt_chunk = 131072;
   mik_timing tm{};
@@ -201,6 +202,8 @@ int mik_create(int device, mik_handle** out) {
   if (env) h->opt_sym = atoi(env) ? 1 : 0;
   env = getenv("MIK_ENGINE");
   if (env) h->opt_engine = (!strcmp(env, "valu") || !strcmp(env, "1")) ? 1 : 0;
+  env = getenv("MIK_WAVES");
+  if (env && (atoi(env) == 4 || atoi(env) == 8)) h->opt_waves = atoi(env);
   env = getenv("MIK_CHUNK");
   if (env && atol(env) >= 128) h->opt_chunk = (atol(env) / 128) * 128;
   *out = h;
@@ -230,6 +233,9 @@ int mik_set_option(mik_handle* h, const char* key, double value) {
   } else if (!strcmp(key, "engine")) {
     if (value != 0.0 && value != 1.0) return fail(MIK_EINVAL, "engine must be 0 (mfma) or 1 (valu)");
     h->opt_engine = (int)value;
+  } else if (!strcmp(key, "waves")) {
+    if (value != 4.0 && value != 8.0) return fail(MIK_EINVAL, "waves must be 4 or 8");
+    h->opt_waves = (int)value;
   } else if (!strcmp(key, "chunk")) {
     if (value < 128) return fail(MIK_EINVAL, "chunk must be >= 128");
     h->opt_chunk = ((long)value / 128) * 128;
@@ -273,6 +279,12 @@ int mik_set_problem(mik_handle* h, const mik_problem* p) {
     v.c0 = t * t;
   } else if (v.model == 4 || v.model == 5) {
     v.c0 = v.p1 / 3.0;
+  }
+  v.c0inv = 1.0 / v.c0;
+  v.sa = v.sb = 0.0;
+  if (v.model == 3) {
+    v.sa = 3.0 / (2.0 * v.p1);
+    v.sb = 1.0 / (2.0 * (v.p1 * v.p1 * v.p1));
   }
   h->v = v;
   const size_t nb = sizeof(double) * (size_t)h->N;
@@ -622,8 +634,13 @@ int mik_predict(mik_handle* h) {
         if (h->opt_sym) hipLaunchKernelGGL(k_contract_valu<true>, dim3(grid), dim3(256), 0, h->stream, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend);
         else hipLaunchKernelGGL(k_contract_valu<false>, dim3(grid), dim3(256), 0, h->stream, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend);
       } else {
-        if (h->opt_sym) hipLaunchKernelGGL(k_contract<true>, dim3(sgrid), dim3(256), 0, h->stream, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend);
-        else hipLaunchKernelGGL(k_contract<false>, dim3(sgrid), dim3(256), 0, h->stream, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend);
+        if (h->opt_waves == 8) {
+          if (h->opt_sym) hipLaunchKernelGGL((k_contract<true, 2>), dim3(sgrid), dim3(512), 0, h->stream, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend);
+          else hipLaunchKernelGGL((k_contract<false, 2>), dim3(sgrid), dim3(512), 0, h->stream, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend);
+        } else {
+          if (h->opt_sym) hipLaunchKernelGGL((k_contract<true, 4>), dim3(sgrid), dim3(256), 0, h->stream, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend);
+          else hipLaunchKernelGGL((k_contract<false, 4>), dim3(sgrid), dim3(256), 0, h->stream, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend);
+        }
       }
     }
     HIPC(hipEventRecord(e2, h->stream));

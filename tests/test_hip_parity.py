@@ -245,9 +245,11 @@ def test_synthetic_n1500_against_oracle(cfg):
     zr, sr = ko.execute(st, "grid", *axes)
     h = m._get_handle()
     outs = []
-    for sym, engine in ((1, 0), (0, 0), (1, 1), (0, 1)):  # symmetric half product on/off x MFMA / VALU contraction
+    # symmetric half product on/off x MFMA (8- or 4-wave blocks) / VALU contraction
+    for sym, engine, waves in ((1, 0, 8), (0, 0, 8), (1, 0, 4), (0, 0, 4), (1, 1, 4), (0, 1, 4)):
         h.set_option("symmetric", sym)
         h.set_option("engine", engine)
+        h.set_option("waves", waves)
         h.set_option("chunk", 1024)
         z, ss = m.execute("grid", *axes, backend="loop")
         assert m.last_timing["contract_launches"] >= 3 and m.last_timing["engine"] == engine

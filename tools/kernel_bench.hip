@@ -34,15 +34,23 @@ int main(int argc,char**argv){
   double kext_sym=0; for(int ib=0;ib<nblk;++ib) kext_sym+= kend-ib*128;
   const double fl_full=2.0*128*128*(double)kend*nblk*(P/128), fl_sym=2.0*128*128*kext_sym*(P/128);
   // warm the clocks
-  for(int w=0;w<2;++w) hipLaunchKernelGGL(k_contract<true>,dim3(grid),dim3(256),0,0,(const double*)T,(long)Mp,(const double*)Bt,(long)Mp,part,P,nblk,kend);
+  for(int w=0;w<2;++w) hipLaunchKernelGGL((k_contract<true,4>),dim3(grid),dim3(256),0,0,(const double*)T,(long)Mp,(const double*)Bt,(long)Mp,part,P,nblk,kend);
   hipDeviceSynchronize();
   float ms;
-  ms=timeit([&]{hipLaunchKernelGGL(k_contract<true>,dim3(grid),dim3(256),0,0,(const double*)T,(long)Mp,(const double*)Bt,(long)Mp,part,P,nblk,kend);},3);
+  ms=timeit([&]{hipLaunchKernelGGL((k_contract<true,4>),dim3(grid),dim3(256),0,0,(const double*)T,(long)Mp,(const double*)Bt,(long)Mp,part,P,nblk,kend);},3);
   printf("k_contract<sym>  mfma : %.3f ms  executed %.2f TF/s  effective(2M^2) %.2f TF/s\n",ms,fl_sym/ms*1e-9,fl_full/ms*1e-9);
   std::vector<double> ref((size_t)P*nblk), got((size_t)P*nblk);
   CK(hipMemcpy(ref.data(),part,ref.size()*8,hipMemcpyDeviceToHost));
-  ms=timeit([&]{hipLaunchKernelGGL(k_contract<false>,dim3(grid),dim3(256),0,0,(const double*)T,(long)Mp,(const double*)Bt,(long)Mp,part,P,nblk,kend);},2);
+  ms=timeit([&]{hipLaunchKernelGGL((k_contract<false,4>),dim3(grid),dim3(256),0,0,(const double*)T,(long)Mp,(const double*)Bt,(long)Mp,part,P,nblk,kend);},2);
   printf("k_contract<full> mfma : %.3f ms  executed %.2f TF/s\n",ms,fl_full/ms*1e-9);
+  ms=timeit([&]{hipLaunchKernelGGL((k_contract<true,2>),dim3(grid),dim3(512),0,0,(const double*)T,(long)Mp,(const double*)Bt,(long)Mp,part,P,nblk,kend);},3);
+  printf("k_contract<sym>  mfma 8 waves/block (wave tile 32x64): %.3f ms  executed %.2f TF/s  effective %.2f TF/s\n",ms,fl_sym/ms*1e-9,fl_full/ms*1e-9);
+  CK(hipMemcpy(got.data(),part,got.size()*8,hipMemcpyDeviceToHost));
+  { double md=0; for(size_t i=0;i<ref.size();++i) md=fmax(md,fabs(ref[i]-got[i])); printf("   8-wave vs 4-wave partials: max|diff| %.3e\n",md); }
+  ms=timeit([&]{hipLaunchKernelGGL((k_contract<false,2>),dim3(grid),dim3(512),0,0,(const double*)T,(long)Mp,(const double*)Bt,(long)Mp,part,P,nblk,kend);},2);
+  printf("k_contract<full> mfma 8 waves/block: %.3f ms  executed %.2f TF/s\n",ms,fl_full/ms*1e-9);
+  ms=timeit([&]{hipLaunchKernelGGL((k_contract<false,4>),dim3(grid),dim3(256),40960,0,(const double*)T,(long)Mp,(const double*)Bt,(long)Mp,part,P,nblk,kend);},2);
+  printf("k_contract<full> mfma, ONE block per CU (40 KB dummy dynamic LDS): %.3f ms  executed %.2f TF/s\n",ms,fl_full/ms*1e-9);
   ms=timeit([&]{hipLaunchKernelGGL(k_contract_valu<true>,dim3(vgrid),dim3(256),0,0,(const double*)T,(long)Mp,(const double*)Bt,(long)Mp,part,P,nblk,kend);},3);
   printf("k_contract<sym>  valu : %.3f ms  executed %.2f TF/s  effective(2M^2) %.2f TF/s\n",ms,fl_sym/ms*1e-9,fl_full/ms*1e-9);
   CK(hipMemcpy(got.data(),part,got.size()*8,hipMemcpyDeviceToHost));
