@@ -120,6 +120,7 @@ def main():
     ap.add_argument("--symmetric", type=int, default=None)
     ap.add_argument("--chunk", type=int, default=None)
     ap.add_argument("--engine", choices=["mfma", "valu"], default=None)
+    ap.add_argument("--factor", choices=["auto", "sweep", "lu"], default=None, help="force the inverse path")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -153,6 +154,8 @@ def main():
         h.set_option("chunk", args.chunk)
     if args.engine is not None:
         h.set_option("engine", 1 if args.engine == "valu" else 0)
+    if args.factor is not None:
+        h.set_option("factor", {"auto": 0, "sweep": 1, "lu": 2}[args.factor])
     wells = np.array(cfg["wells"]) if cfg.get("wells") else None
     h.set_problem(ndim=ndim, xs=coords[0], ys=coords[1], zs=coords[2] if ndim == 3 else None, values=values,
                   model_id=_lib.MODEL_IDS[cfg["model"]], params=internal_params(cfg["model"], cfg["params"]),

@@ -852,42 +852,36 @@ struct PivCand {
   int pad;
 };
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64)
 k_piv_first(const double* __restrict__ P, int k0, int M, int Mp, PivCand* __restrict__ cand) {
-  __shared__ double sv[256];
-  __shared__ int sr[256];
-  const int row = blockIdx.x * 256 + threadIdx.x;
+  // candidate of column 0 for one block of MIK_PIV_ROWS rows (same block granularity as k_piv_step)
+  const int row = blockIdx.x * 32 + threadIdx.x;
   double v = -1.0;
-  if (row >= k0 && row < M) v = fabs(P[(long)row * 128]);
-  sv[threadIdx.x] = v;
-  sr[threadIdx.x] = row;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) {
-      const double v2 = sv[threadIdx.x + o];
-      const int r2 = sr[threadIdx.x + o];
-      if (v2 > sv[threadIdx.x] || (v2 == sv[threadIdx.x] && r2 < sr[threadIdx.x])) {
-        sv[threadIdx.x] = v2;
-        sr[threadIdx.x] = r2;
-      }
-    }
-    __syncthreads();
+  int r = 0x7fffffff;
+  if (threadIdx.x < 32 && row >= k0 && row < M) { v = fabs(P[(long)row * 128]); r = row; }
+  for (int o = 16; o > 0; o >>= 1) {
+    const double v2 = __shfl_xor(v, o);
+    const int r2 = __shfl_xor(r, o);
+    if (v2 > v || (v2 == v && r2 < r)) { v = v2; r = r2; }
   }
   if (threadIdx.x == 0) {
-    cand[blockIdx.x].v = sv[0];
-    cand[blockIdx.x].row = sr[0];
+    cand[blockIdx.x].v = v;
+    cand[blockIdx.x].row = r;
   }
 }
 
+// One block = 32 rows of the scratch panel; thread (col = tid & 127, ty = tid >> 7) walks the block's rows
+// two at a time, so every access is a coalesced 1-KiB row.  Rows < k0 + c and columns <= c are dead for the
+// pivot search and are not copied.
+#define MIK_PIV_ROWS 32
 __global__ void __launch_bounds__(256)
 k_piv_step(const double* __restrict__ Pin, double* __restrict__ Pout, int k0, int c, int M, int Mp,
            const PivCand* __restrict__ cand_in, PivCand* __restrict__ cand_out, int ncand,
            int* __restrict__ pivrow /* 128 entries of this panel */, int* __restrict__ flag) {
   __shared__ double sv[256];
   __shared__ int sr[256];
-  __shared__ double prow[128];
   __shared__ int s_pr;
-  // 1. pivot row of column c from the candidates
+  // 1. pivot row of column c from the candidates of the previous launch
   {
     double v = -2.0;
     int r = 0x7fffffff;
@@ -922,45 +916,45 @@ k_piv_step(const double* __restrict__ Pin, double* __restrict__ Pout, int k0, in
     __syncthreads();
   }
   const int pr = s_pr, kr = k0 + c;
-  if (threadIdx.x < 128) prow[threadIdx.x] = Pin[(long)pr * 128 + threadIdx.x];
-  __syncthreads();
-  const double pinv = 1.0 / prow[c];
-  // 2. rewrite this block's 256 rows: 2 threads per row would be finer, 1 thread per row is enough here
-  const int row = blockIdx.x * 256 + threadIdx.x;
+  const int col = threadIdx.x & 127, ty = threadIdx.x >> 7;
+  const double pcol = Pin[(long)pr * 128 + col];  // pivot row, this thread's column
+  const double pinv = 1.0 / Pin[(long)pr * 128 + c];
+  // 2. rows of this block: exchange kr <-> pr, eliminate column c from the rows below kr (columns > c only)
   double nextv = -1.0;
-  if (row < Mp) {
+  int nextr = 0x7fffffff;
+  const int r0 = blockIdx.x * MIK_PIV_ROWS;
+  for (int rr = ty; rr < MIK_PIV_ROWS; rr += 2) {
+    const int row = r0 + rr;
+    if (row < kr || row >= Mp) continue;
     const int src = (row == kr) ? pr : ((row == pr) ? kr : row);
-    const double* in = Pin + (long)src * 128;
-    double* out = Pout + (long)row * 128;
-    if (row > kr && row < M && row >= k0) {
-      const double f = in[c] * pinv;
-      for (int m = 0; m < 128; ++m) {
-        const double x = in[m];
-        out[m] = (m > c) ? x - f * prow[m] : ((m == c) ? f : x);
+    const double x = Pin[(long)src * 128 + col];
+    double y = x;
+    if (row > kr && row < M) {
+      const double f = Pin[(long)src * 128 + c] * pinv;  // broadcast load
+      if (col > c) y = x - f * pcol;
+      if (col == c + 1) {
+        const double ay = fabs(y);
+        if (ay > nextv) { nextv = ay; nextr = row; }  // rows ascend: the first maximum is kept
       }
-      if (c + 1 < 128) nextv = fabs(out[c + 1]);
-    } else {
-      for (int m = 0; m < 128; ++m) out[m] = in[m];
     }
+    if (col > c || row == kr) Pout[(long)row * 128 + col] = y;
   }
-  // 3. candidate for column c+1 over active rows (> kr, < M)
+  // 3. this block's candidate for column c+1: held by the threads with col == c+1 (one per ty)
   sv[threadIdx.x] = nextv;
-  sr[threadIdx.x] = row;
+  sr[threadIdx.x] = nextr;
   __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) {
-      const double v2 = sv[threadIdx.x + o];
-      const int r2 = sr[threadIdx.x + o];
-      if (v2 > sv[threadIdx.x] || (v2 == sv[threadIdx.x] && r2 < sr[threadIdx.x])) {
-        sv[threadIdx.x] = v2;
-        sr[threadIdx.x] = r2;
+  if (threadIdx.x == 0) {
+    double v = -1.0;
+    int r = 0x7fffffff;
+    if (c + 1 < 128) {
+      for (int t = 0; t < 2; ++t) {
+        const double v2 = sv[t * 128 + c + 1];
+        const int r2 = sr[t * 128 + c + 1];
+        if (v2 > v || (v2 == v && r2 < r)) { v = v2; r = r2; }
       }
     }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    cand_out[blockIdx.x].v = sv[0];
-    cand_out[blockIdx.x].row = sr[0];
+    cand_out[blockIdx.x].v = v;
+    cand_out[blockIdx.x].row = r;
   }
 }
 

@@ -374,7 +374,7 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
   MIKC(h->DinvT.ensure(sizeof(double) * 128 * 128));
   MIKC(h->flag.ensure(sizeof(int)));
   HIPC(hipMemsetAsync(h->flag.p, 0, sizeof(int), h->stream));
-  const int ncand = (Mp + 255) / 256;
+  const int ncand = Mp / 32;  // one candidate per 32-row block of the pivot-search panel (MIK_PIV_ROWS)
   if (pivoted) {
     MIKC(h->TKt.ensure(panel));
     MIKC(h->P0.ensure(panel));
@@ -392,7 +392,7 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
     const int k0 = kb * 128;
     if (pivoted) {
       hipLaunchKernelGGL(k_copy_panel, dim3(pgrid), dim3(256), 0, h->stream, T, ld, k0, Mp, h->P0.as<double>());
-      hipLaunchKernelGGL(k_piv_first, dim3(ncand), dim3(256), 0, h->stream, h->P0.as<double>(), k0, h->M, Mp,
+      hipLaunchKernelGGL(k_piv_first, dim3(ncand), dim3(64), 0, h->stream, h->P0.as<double>(), k0, h->M, Mp,
                          h->cand0.as<PivCand>());
       for (int c = 0; c < 128; ++c) {
         const double* Pin = (c & 1) ? h->P1.as<double>() : h->P0.as<double>();
@@ -468,8 +468,10 @@ int mik_factor(mik_handle* h) {
     h->tm.factor_path = 3;
     return finish_factor(h);
   }
-  // bounded models (proper covariances after the shift) -> unpivoted symmetric sweep; linear/power -> pivoted
-  bool try_sweep = h->opt_factor == 1 || (h->opt_factor == 0 && h->model >= 2);
+  // auto: every model first tries the unpivoted sweep on the shifted matrix s.11^T - Gamma (s = sill for the
+  // bounded models, gamma(bounding-box diagonal) for linear/power); a non-positive station pivot (matrix not
+  // positive definite, e.g. hole-effect in 2-D) sends the attempt to the pivoted path below.
+  bool try_sweep = h->opt_factor == 1 || h->opt_factor == 0;
   for (int attempt = 0; attempt < 2; ++attempt) {
     const bool pivoted = !try_sweep;
     const double shift = pivoted ? 0.0 : h->shift_guess;
