@@ -4,6 +4,7 @@
  * replaces in the reference (paths relative to /root/reference/src/pykrige):
  *
  *   lib/cok.pyx:14-96    cpdef _c_exec_loop(a_all, bd_all, mask, n, pars)      -> mik_factor + mik_predict
+ *   lib/cok.pyx:98-193   cpdef _c_exec_loop_moving_window(...) + cKDTree.query  -> mik_predict_moving_window
  *   lib/cok.pyx:196-203  check_b_vect (|bd| <= eps  ->  b = 0)                 -> inside mik_predict
  *   lib/variogram_models.pyx:6-84  C variogram kernels selected by name        -> mik_problem.model_id
  *   ok.py:626-648, uk.py:861-920, ok3d.py:603-622, uk3d.py:688-737
@@ -104,6 +105,11 @@ int  mik_factor(mik_handle *h);                            /* K1 + K2 (+ c = A_i
 int  mik_set_points(mik_handle *h, const mik_points *g);   /* H2D of the (unmasked) points              */
 int  mik_predict(mik_handle *h);                           /* K3 over the resident points; results stay in HBM */
 int  mik_get_results(mik_handle *h, double *z_out, double *ss_out); /* D2H, scattered through the mask  */
+
+/* Moving-window ordinary kriging (n_closest_points): replaces cKDTree.query + _c_exec_loop_moving_window
+ * (ok.py:929-986, lib/cok.pyx:98-193; ok3d.py:901-912, 697-733).  Needs mik_set_problem + mik_set_points
+ * (no mik_factor: each point solves its own (k+1)x(k+1) system).  Results as for mik_predict. */
+int  mik_predict_moving_window(mik_handle *h, int n_closest_points);
 
 /* One-shot convenience: create + set_problem + factor + set_points + predict + get_results + destroy. */
 int  mik_krige_execute(int device, const mik_problem *p, const mik_points *g, double *z_out, double *ss_out);

@@ -222,6 +222,33 @@ def solve_points(st: KrigingState, pts_adj: np.ndarray, spec_pts: Sequence[np.nd
     return z, ss
 
 
+def solve_points_moving_window(st: KrigingState, pts_adj: np.ndarray, n_closest_points: int):
+    """Moving-window ordinary kriging: cKDTree.query (ok.py:957-960; ok3d.py:901-904) then, per point,
+    the (k+1)x(k+1) system cut out of the full kriging matrix (ok.py:722-758, ok3d.py:697-733)."""
+    from scipy.spatial import cKDTree
+
+    if st.n_drift:
+        raise ValueError("moving window exists for ordinary kriging only")
+    rev = slice(None, None, -1) if st.ndim == 3 else slice(None)
+    tree = cKDTree(st.coords_adj[:, rev])
+    bd_all, bd_idx = tree.query(pts_adj[:, rev], k=n_closest_points, eps=0.0)
+    a_all = kriging_matrix(st)
+    n = n_closest_points
+    z, ss = np.zeros(pts_adj.shape[0]), np.zeros(pts_adj.shape[0])
+    for i in range(pts_adj.shape[0]):
+        sel = np.concatenate((bd_idx[i], [a_all.shape[0] - 1]))
+        a = a_all[sel[:, None], sel]
+        b = np.zeros(n + 1)
+        b[:n] = -variogram(st.model, st.params, bd_all[i])
+        if st.exact_values:
+            b[:n][np.absolute(bd_all[i]) <= EPS] = 0.0
+        b[n] = 1.0
+        x = scipy.linalg.solve(a, b)
+        z[i] = x[:n].dot(st.values[bd_idx[i]])
+        ss[i] = -x.dot(b)
+    return z, ss
+
+
 def execute(st: KrigingState, style: str, xpoints, ypoints, zpoints=None, mask=None,
             specified_drift_arrays: Sequence[np.ndarray] = (), a_inv=None):
     """Front/back matter of the four ``execute`` methods + the solve.  Returns plain

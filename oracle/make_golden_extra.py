@@ -71,5 +71,54 @@ def main():
     print("wrote extra fixtures")
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--mw" not in sys.argv:
     main()
+
+
+def moving_window():
+    """n_closest_points fixtures: OK2D backend='loop' and (if oracle/_ref is built) 'C'; OK3D backend='loop'."""
+    import pykrige.lib
+
+    with_c = os.path.isdir(os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "pykrige_lib"))
+    if with_c:
+        pykrige.lib.__path__.append(os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "pykrige_lib"))
+    from pykrige.ok import OrdinaryKriging
+    from pykrige.ok3d import OrdinaryKriging3D
+
+    def arr(x):
+        return np.ma.getdata(x).astype(np.float64)
+
+    (x, y), v = synth(90, 400, 2)
+    gx_, gy_ = np.linspace(0, 1, 21), np.linspace(0, 1, 17)
+    x[:5], y[:5] = gx_[[3, 7, 11, 15, 19]], gy_[[2, 5, 8, 11, 14]]
+    out = dict(x=x, y=y, v=v, model="spherical", params_user=[1.0, 0.4, 0.05], gridx=gx_, gridy=gy_, scaling=2.0, angle=20.0)
+    ok = OrdinaryKriging(x, y, v, variogram_model="spherical", variogram_parameters=[1.0, 0.4, 0.05],
+                         anisotropy_scaling=2.0, anisotropy_angle=20.0)
+    rng = np.random.default_rng(91)
+    mask = rng.random((17, 21)) < 0.25
+    for k in (2, 10, 31, 70):
+        z, ss = ok.execute("grid", gx_, gy_, backend="loop", n_closest_points=k)
+        out["z_k%d" % k], out["ss_k%d" % k] = arr(z), arr(ss)
+        if with_c:
+            zc, ssc = ok.execute("grid", gx_, gy_, backend="C", n_closest_points=k)
+            out["zc_k%d" % k], out["ssc_k%d" % k] = arr(zc), arr(ssc)
+    zm, ssm = ok.execute("masked", gx_, gy_, mask=mask, backend="loop", n_closest_points=10)
+    out.update(mask=mask, zm_k10=arr(zm), ssm_k10=arr(ssm))
+    np.savez_compressed(os.path.join(OUT, "mw_ok2d.npz"), **out)
+    (x, y, zc), v = synth(92, 300, 3)
+    g3x, g3y, g3z = np.linspace(0, 1, 9), np.linspace(0, 1, 7), np.linspace(0, 1, 5)
+    k3 = OrdinaryKriging3D(x, y, zc, v, variogram_model="exponential", variogram_parameters=[1.0, 0.5, 0.02],
+                           anisotropy_scaling_y=1.5, anisotropy_scaling_z=2.0, anisotropy_angle_x=10.0,
+                           anisotropy_angle_y=20.0, anisotropy_angle_z=30.0)
+    out = dict(x=x, y=y, zc=zc, v=v, model="exponential", params_user=[1.0, 0.5, 0.02], gridx=g3x, gridy=g3y, gridz=g3z,
+               scaling=[1.5, 2.0], angle=[10.0, 20.0, 30.0])
+    for k in (8, 20):
+        z, ss = k3.execute("grid", g3x, g3y, g3z, backend="loop", n_closest_points=k)
+        out["z_k%d" % k], out["ss_k%d" % k] = arr(z), arr(ss)
+    np.savez_compressed(os.path.join(OUT, "mw_ok3d.npz"), **out)
+    print("wrote moving-window fixtures (C backend: %s)" % with_c)
+
+
+if __name__ == "__main__" and "--mw" in sys.argv:
+    _import_reference(False)
+    moving_window()

@@ -59,6 +59,7 @@ SIGNATURES = {
     "mik_set_points": (C.c_int, [C.c_void_p, C.POINTER(MikPoints)]),
     "mik_predict": (C.c_int, [C.c_void_p]),
     "mik_get_results": (C.c_int, [C.c_void_p, _dp, _dp]),
+    "mik_predict_moving_window": (C.c_int, [C.c_void_p, C.c_int]),
     "mik_krige_execute": (C.c_int, [C.c_int, C.POINTER(MikProblem), C.POINTER(MikPoints), _dp, _dp]),
     "mik_assemble_only": (C.c_int, [C.c_void_p]),
     "mik_get_matrix": (C.c_int, [C.c_void_p, C.c_int, _dp]),
@@ -205,6 +206,9 @@ class Handle:
 
     def predict(self):
         check(self._lib.mik_predict(self._h))
+
+    def predict_moving_window(self, n_closest_points):
+        check(self._lib.mik_predict_moving_window(self._h, int(n_closest_points)))
 
     def get_results(self):
         z = np.empty(self._npt, dtype=np.float64)

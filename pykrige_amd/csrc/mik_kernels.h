@@ -1021,4 +1021,171 @@ __global__ void k_selftest_mfma4(double* out /*4x16 row-major*/) {
   out[(l >> 4) * 16 + (l & 15)] = d;                            // D[i=l>>4][col=l&15]
 }
 
+// ------------------------------------------------------------------------------------------------
+// Moving-window kriging (n_closest_points; ok.py:929-986, 722-758, cok.pyx:98-193, ok3d.py:697-733).
+//   k_mw_knn   : the k nearest stations of every point, ascending distance (cKDTree.query(k=..., eps=0)),
+//                brute force -- one thread per point, all lanes walk the stations in the same order so the
+//                station coordinates are wave-uniform (scalar) loads; sorted insertion is rare after warm-up.
+//   k_mw_solve : per point the (k+1) x (k+1) system gathered from the assembled kriging matrix
+//                (a_all[sel][:, sel], ones border, zero corner -- cok.pyx:138-147), right-hand side
+//                -gamma(bd) with the eps rule, solved by Gauss-Jordan elimination with partial pivoting
+//                (dgesv's pivot order) in LDS by a group of TPP threads; z = x.Z[sel], ss = -x.b.
+// ------------------------------------------------------------------------------------------------
+#define MIK_MW_KMAX 127
+
+template <int NDIM>
+__global__ void __launch_bounds__(256)
+k_mw_knn(const double* __restrict__ px, const double* __restrict__ py, const double* __restrict__ pz, int npt,
+         const double* __restrict__ xs, const double* __restrict__ ys, const double* __restrict__ zs, int N, int K,
+         int* __restrict__ idx_out, double* __restrict__ dist_out) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= npt) return;
+  const double qx = px[t], qy = py[t], qz = (NDIM == 3) ? pz[t] : 0.0;
+  double bd[MIK_MW_KMAX + 1];
+  int bi[MIK_MW_KMAX + 1];
+  int cnt = 0;
+  double worst = 1e300;
+  for (int j = 0; j < N; ++j) {
+    const double dx = qx - xs[j], dy = qy - ys[j];
+    double d2 = dx * dx + dy * dy;
+    if (NDIM == 3) {
+      const double dz = qz - zs[j];
+      d2 += dz * dz;
+    }
+    if (cnt < K || d2 < worst) {
+      int p = (cnt < K) ? cnt : K - 1;
+      while (p > 0 && bd[p - 1] > d2) {
+        bd[p] = bd[p - 1];
+        bi[p] = bi[p - 1];
+        --p;
+      }
+      bd[p] = d2;
+      bi[p] = j;
+      if (cnt < K) ++cnt;
+      if (cnt == K) worst = bd[K - 1];
+    }
+  }
+  for (int q = 0; q < K; ++q) {
+    idx_out[(long)t * K + q] = bi[q];
+    dist_out[(long)t * K + q] = sqrt(bd[q]);
+  }
+}
+
+struct MwArgs {
+  const double* A;  // assembled kriging matrix (shift 0), ld
+  long ld;
+  int K, npt;
+  const int* idx;
+  const double* dist;
+  const double* Z;
+  Vario v;
+  int exact;
+  double eps;
+  double* z;
+  double* ss;
+  int* flag;
+};
+
+template <int MODEL, int TPP>
+__global__ void __launch_bounds__(256) k_mw_solve(MwArgs a) {
+  extern __shared__ double mw_lds[];
+  constexpr int PPB = 256 / TPP;
+  const int g = threadIdx.x / TPP, l = threadIdx.x % TPP;
+  const int K = a.K, nb = K + 1, st = nb + 1;  // augmented row stride (column nb = right-hand side)
+  const int per = nb * st + 2 * nb + nb;       // aug, b copy, multipliers, selection (ints stored as doubles' space)
+  double* aug = mw_lds + (long)g * per;
+  double* bcp = aug + nb * st;
+  double* mul = bcp + nb;
+  int* sel = reinterpret_cast<int*>(mul + nb);
+  __shared__ double redv[4][PPB > 4 ? PPB : 4];
+  __shared__ int redr[4][PPB > 4 ? PPB : 4];
+  const long pt = (long)blockIdx.x * PPB + g;
+  const bool live = pt < a.npt;
+  if (live) {
+    for (int r = l; r < K; r += TPP) sel[r] = a.idx[pt * K + r];
+  }
+  __syncthreads();
+  if (live) {
+    for (int e = l; e < nb * nb; e += TPP) {
+      const int r = e / nb, c = e - r * nb;
+      double v;
+      if (r < K && c < K) v = (r == c) ? 0.0 : a.A[(long)sel[r] * a.ld + sel[c]];
+      else v = (r == K && c == K) ? 0.0 : 1.0;
+      aug[r * st + c] = v;
+    }
+    for (int r = l; r < nb; r += TPP) {
+      double b = 1.0;
+      if (r < K) {
+        const double d = a.dist[pt * K + r];
+        b = -vario<MODEL, false>(a.v, d, d * d);
+        if (a.exact && d <= a.eps) b = 0.0;  // check_b_vect, cok.pyx:196-203
+      }
+      aug[r * st + nb] = b;
+      bcp[r] = b;
+    }
+  }
+  __syncthreads();
+  int bad = 0;
+  for (int c = 0; c < nb; ++c) {
+    // partial pivoting: max |aug[r][c]| over r >= c, first maximum wins (idamax)
+    double bv = -1.0;
+    int br = 0x7fffffff;
+    if (live)
+      for (int r = c + l; r < nb; r += TPP) {
+        const double v = fabs(aug[r * st + c]);
+        if (v > bv) { bv = v; br = r; }
+      }
+    constexpr int W = TPP < 64 ? TPP : 64;
+#pragma unroll
+    for (int o = W / 2; o > 0; o >>= 1) {
+      const double v2 = __shfl_xor(bv, o, W);
+      const int r2 = __shfl_xor(br, o, W);
+      if (v2 > bv || (v2 == bv && r2 < br)) { bv = v2; br = r2; }
+    }
+    if (TPP > 64) {
+      const int wv = threadIdx.x >> 6;
+      if ((threadIdx.x & 63) == 0) { redv[wv][0] = bv; redr[wv][0] = br; }
+      __syncthreads();
+      bv = redv[0][0];
+      br = redr[0][0];
+#pragma unroll
+      for (int w = 1; w < 4; ++w)
+        if (redv[w][0] > bv || (redv[w][0] == bv && redr[w][0] < br)) { bv = redv[w][0]; br = redr[w][0]; }
+    }
+    if (live && !(bv > 0.0)) bad = 1;
+    // swap rows c <-> br (columns >= c and the right-hand side), then publish the multipliers
+    if (live && br != c && br < nb)
+      for (int j = c + l; j <= nb; j += TPP) {
+        const double t0 = aug[c * st + j];
+        aug[c * st + j] = aug[br * st + j];
+        aug[br * st + j] = t0;
+      }
+    __syncthreads();
+    if (live) {
+      const double pinv = 1.0 / aug[c * st + c];
+      for (int r = l; r < nb; r += TPP) mul[r] = (r == c) ? 0.0 : aug[r * st + c] * pinv;
+    }
+    __syncthreads();
+    if (live) {
+      const int w = nb - c;  // columns c+1 .. nb (incl. RHS)
+      for (int e = l; e < nb * w; e += TPP) {
+        const int r = e / w, j = c + 1 + (e - r * w);
+        aug[r * st + j] -= mul[r] * aug[c * st + j];  // row c itself has multiplier 0
+      }
+    }
+    __syncthreads();
+  }
+  if (live && l == 0) {
+    double zz = 0.0, s2 = 0.0;
+    for (int r = 0; r < nb; ++r) {
+      const double x = aug[r * st + nb] / aug[r * st + r];
+      if (r < K) zz += x * a.Z[sel[r]];
+      s2 += x * bcp[r];
+    }
+    a.z[pt] = zz;
+    a.ss[pt] = -s2;
+    if (bad) atomicOr(a.flag, 1);
+  }
+}
+
 }  // namespace mik

@@ -118,7 +118,8 @@ struct mik_handle {
   std::vector<long> scatter;  // empty = identity
   DevBuf px, py, pz, extra_rows, z, ss;
   // work
-  DevBuf Bt, part;
+  DevBuf Bt, part, mw_idx, mw_dist;
+  int t_state = 0;  // what T holds: 0 nothing, 1 the kriging matrix A (shift 0), 2 its inverse
   // options
   int opt_waves = 8;  // waves per contraction block: 4 (wave tile 64x64) or 8 (32x64)
   int opt_factor = 0, opt_sym = 1, opt_engine = 0;  // engine: 0 = v_mfma_f64 contraction, 1 = v_fma_f64 (VALU) contraction
@@ -216,7 +217,7 @@ void mik_destroy(mik_handle* h) {
   if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
   DevBuf* bufs[] = {&h->xs, &h->ys, &h->zs, &h->vals, &h->wells, &h->extra_cols, &h->T, &h->cvec, &h->Cold, &h->Cnew,
                     &h->Rt, &h->TKt, &h->Dinv, &h->DinvT, &h->P0, &h->P1, &h->cand0, &h->cand1, &h->pivall, &h->flag,
-                    &h->px, &h->py, &h->pz, &h->extra_rows, &h->z, &h->ss, &h->Bt, &h->part};
+                    &h->px, &h->py, &h->pz, &h->extra_rows, &h->z, &h->ss, &h->Bt, &h->part, &h->mw_idx, &h->mw_dist};
   for (DevBuf* b : bufs) b->release();
   for (hipEvent_t e : h->evpool) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -327,6 +328,7 @@ int mik_set_problem(mik_handle* h, const mik_problem* p) {
   HIPC(hipStreamSynchronize(h->stream));
   h->have_problem = true;
   h->have_factor = false;
+  h->t_state = 0;
   h->have_results = false;
   return MIK_OK;
 }
@@ -441,6 +443,7 @@ static int finish_factor(mik_handle* h) {
   HIPC(hipGetLastError());
   HIPC(hipStreamSynchronize(h->stream));
   h->have_factor = true;
+  h->t_state = 2;
   h->have_results = false;
   return MIK_OK;
 }
@@ -452,12 +455,15 @@ int mik_assemble_only(mik_handle* h) {
   MIKC(launch_assemble(h, 0.0));
   HIPC(hipStreamSynchronize(h->stream));
   h->have_factor = false;
+  h->t_state = 1;
   return MIK_OK;
 }
 
 int mik_factor(mik_handle* h) {
   if (!h || !h->have_problem) return fail(MIK_ESTATE, "mik_factor: no problem set");
   HIPC(hipSetDevice(h->device));
+  h->t_state = 0;
+  h->have_factor = false;
   MIKC(ensure_factor_buffers(h));
   MIKC(get_events(h, 4));
   h->tm.assemble_ms = h->tm.invert_ms = 0.0;
@@ -670,6 +676,103 @@ int mik_predict(mik_handle* h) {
   return MIK_OK;
 }
 
+
+#define MW_LAUNCH(MODEL, TPP)                                                                                  \
+  do {                                                                                                         \
+    HIPC(hipFuncSetAttribute((const void*)k_mw_solve<MODEL, TPP>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                             (int)lds));                                                                       \
+    hipLaunchKernelGGL((k_mw_solve<MODEL, TPP>), dim3(grid), dim3(256), lds, h->stream, a);                    \
+  } while (0)
+#define MW_DISPATCH_TPP(MODEL)                 \
+  do {                                         \
+    if (tpp == 16) MW_LAUNCH(MODEL, 16);       \
+    else if (tpp == 32) MW_LAUNCH(MODEL, 32);  \
+    else if (tpp == 64) MW_LAUNCH(MODEL, 64);  \
+    else MW_LAUNCH(MODEL, 256);                \
+  } while (0)
+
+int mik_predict_moving_window(mik_handle* h, int n_closest) {
+  if (!h || !h->have_problem) return fail(MIK_ESTATE, "mik_predict_moving_window: set the problem first");
+  if (!h->have_points) return fail(MIK_ESTATE, "mik_predict_moving_window: set points first");
+  if (h->p != 0) return fail(MIK_EINVAL, "moving-window kriging exists for ordinary kriging only (ok.py:929, ok3d.py:901)");
+  if (h->host_inv) return fail(MIK_EINVAL, "moving-window kriging does not use pseudo_inv");
+  if (n_closest < 2) return fail(MIK_EINVAL, "n_closest_points has to be at least two!");
+  if (n_closest > h->N) return fail(MIK_EINVAL, "n_closest_points exceeds the number of stations");
+  if (n_closest > MIK_MW_KMAX) return fail(MIK_EINVAL, "n_closest_points > 127 is not supported by the device path");
+  HIPC(hipSetDevice(h->device));
+  MIKC(ensure_factor_buffers(h));
+  MIKC(get_events(h, 2));
+  const long npt = h->npt;
+  const int K = n_closest;
+  h->tm.rhs_ms = h->tm.contract_ms = h->tm.predict_ms = 0.0;
+  h->tm.contract_launches = 0;
+  h->tm.contract_flops_executed = 0.0;
+  if (npt == 0) {
+    h->have_results = true;
+    return MIK_OK;
+  }
+  HIPC(hipEventRecord(h->evpool[0], h->stream));
+  if (h->t_state != 1) {  // a_all = self._get_kriging_matrix(n): the plain matrix, not its inverse
+    MIKC(launch_assemble(h, 0.0));
+    h->t_state = 1;
+    h->have_factor = false;
+  }
+  MIKC(h->mw_idx.ensure(sizeof(int) * (size_t)npt * K));
+  MIKC(h->mw_dist.ensure(sizeof(double) * (size_t)npt * K));
+  MIKC(h->flag.ensure(sizeof(int)));
+  HIPC(hipMemsetAsync(h->flag.p, 0, sizeof(int), h->stream));
+  const unsigned kgrid = (unsigned)((npt + 255) / 256);
+  if (h->ndim == 3)
+    hipLaunchKernelGGL(k_mw_knn<3>, dim3(kgrid), dim3(256), 0, h->stream, (const double*)h->px.as<double>(),
+                       (const double*)h->py.as<double>(), (const double*)h->pz.as<double>(), (int)npt,
+                       (const double*)h->xs.as<double>(), (const double*)h->ys.as<double>(),
+                       (const double*)h->zs.as<double>(), h->N, K, h->mw_idx.as<int>(), h->mw_dist.as<double>());
+  else
+    hipLaunchKernelGGL(k_mw_knn<2>, dim3(kgrid), dim3(256), 0, h->stream, (const double*)h->px.as<double>(),
+                       (const double*)h->py.as<double>(), (const double*)nullptr, (int)npt,
+                       (const double*)h->xs.as<double>(), (const double*)h->ys.as<double>(), (const double*)nullptr,
+                       h->N, K, h->mw_idx.as<int>(), h->mw_dist.as<double>());
+  MwArgs a{};
+  a.A = h->T.as<double>();
+  a.ld = h->Mp;
+  a.K = K;
+  a.npt = (int)npt;
+  a.idx = h->mw_idx.as<int>();
+  a.dist = h->mw_dist.as<double>();
+  a.Z = h->vals.as<double>();
+  a.v = h->v;
+  a.exact = h->exact;
+  a.eps = h->eps;
+  a.z = h->z.as<double>();
+  a.ss = h->ss.as<double>();
+  a.flag = h->flag.as<int>();
+  const int nb = K + 1;
+  const int tpp = (nb + 1 <= 16) ? 16 : (nb + 1 <= 32) ? 32 : (nb + 1 <= 64) ? 64 : 256;
+  const int ppb = 256 / tpp;
+  const size_t per = (size_t)nb * (nb + 1) + 3 * (size_t)nb;
+  const size_t lds = sizeof(double) * per * ppb;
+  const unsigned grid = (unsigned)((npt + ppb - 1) / ppb);
+  switch (h->model) {
+    case 0: MW_DISPATCH_TPP(0); break;
+    case 1: MW_DISPATCH_TPP(1); break;
+    case 2: MW_DISPATCH_TPP(2); break;
+    case 3: MW_DISPATCH_TPP(3); break;
+    case 4: MW_DISPATCH_TPP(4); break;
+    default: MW_DISPATCH_TPP(5); break;
+  }
+  HIPC(hipGetLastError());
+  int flag = 0;
+  HIPC(hipMemcpyAsync(&flag, h->flag.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPC(hipEventRecord(h->evpool[1], h->stream));
+  HIPC(hipStreamSynchronize(h->stream));
+  float ms = 0.f;
+  HIPC(hipEventElapsedTime(&ms, h->evpool[0], h->evpool[1]));
+  h->tm.predict_ms = ms;
+  if (flag) return fail(MIK_ESINGULAR, "Singular matrix");  // cok.pyx:176-177
+  h->have_results = true;
+  return MIK_OK;
+}
+
 int mik_get_results(mik_handle* h, double* z_out, double* ss_out) {
   if (!h || !z_out || !ss_out) return fail(MIK_EINVAL, "mik_get_results: NULL argument");
   if (!h->have_results) return fail(MIK_ESTATE, "mik_get_results: predict first");
@@ -783,6 +886,7 @@ int mik_bcast_factor(mik_handle* h, int root) {
   NCCLC(g_rccl.Broadcast(h->cvec.p, h->cvec.p, Mp, ncclDouble, root, h->comm, h->stream));
   HIPC(hipStreamSynchronize(h->stream));
   h->have_factor = true;
+  h->t_state = 2;
   h->have_results = false;
   return MIK_OK;
 }

@@ -146,13 +146,29 @@ class _KrigingBase:
         return core.adjust_for_anisotropy(pts, self._center(), self._scaling(), self._angle()), shape, mask, None
 
     # ---------------------------------------------------------------- execute front / back matter
+    _mw_backends = ()  # backends the reference accepts together with n_closest_points
+
     def _check_backend(self, backend, n_closest_points):
+        if n_closest_points is not None and n_closest_points <= 1:
+            raise ValueError("n_closest_points has to be at least two!")  # ok.py:837-840
         if backend not in self._backends:
             raise ValueError("Specified backend {} is not supported for {}.".format(backend, self._label))
-        if n_closest_points is not None:
-            if n_closest_points <= 1:
-                raise ValueError("n_closest_points has to be at least two!")
-            raise NotImplementedError(_UNSUPPORTED % "moving-window kriging (n_closest_points)")
+        if n_closest_points is not None and backend not in self._mw_backends:
+            raise ValueError("Specified backend {} for a moving window is not supported.".format(backend))  # ok.py:982-986
+
+    def _solve_moving_window(self, pts_adj, mask, n_closest_points, backend):
+        """cKDTree.query + _exec_loop_moving_window / _c_exec_loop_moving_window on the device."""
+        h = self._get_handle()
+        self._set_problem(h)
+        h.set_points(pts_adj[:, 0], pts_adj[:, 1], pts_adj[:, 2] if self._ndim == 3 else None, mask=mask)
+        try:
+            h.predict_moving_window(int(n_closest_points))
+        except np.linalg.LinAlgError as e:
+            if backend == "C":  # lib/cok.pyx:176-177 raises ValueError('Singular matrix'); scipy.linalg.solve LinAlgError
+                raise ValueError("Singular matrix") from e
+            raise
+        self.last_timing = h.timing()
+        return h.get_results()
 
     def _points_from(self, style, axes, mask):
         """Reference meshgrid order and mask handling (ok.py:849-878; ok3d.py:841-876)."""
@@ -242,6 +258,7 @@ class OrdinaryKriging(_KrigingBase):
 
     _ndim = 2
     _backends = ("vectorized", "loop", "C", "hip")
+    _mw_backends = ("loop", "C", "hip")
     _label = "2D ordinary kriging"
 
     def __init__(self, x, y, z, variogram_model="linear", variogram_parameters=None, variogram_function=None, nlags=6,
@@ -297,7 +314,10 @@ class OrdinaryKriging(_KrigingBase):
             raise ValueError("style argument must be 'grid', 'points', or 'masked'")
         self._check_backend(backend, n_closest_points)
         pts_adj, shape, mask, extra = self._prepare_points(style, (xpoints, ypoints), mask)
-        z, ss = self._solve(pts_adj, mask, extra)
+        if n_closest_points is not None:
+            z, ss = self._solve_moving_window(pts_adj, mask, n_closest_points, backend)
+        else:
+            z, ss = self._solve(pts_adj, mask, extra)
         return self._finish(z, ss, style, shape, mask, backend)
 
 
@@ -309,6 +329,7 @@ class UniversalKriging(OrdinaryKriging):
 
     _universal = True
     _backends = ("vectorized", "loop", "hip")
+    _mw_backends = ()
     _label = "2D universal kriging"
 
     def __init__(self, x, y, z, variogram_model="linear", variogram_parameters=None, variogram_function=None, nlags=6,
@@ -429,6 +450,7 @@ class OrdinaryKriging3D(_KrigingBase):
     """3D ordinary kriging (ok3d.py:40)."""
 
     _ndim = 3
+    _mw_backends = ("loop", "hip")
     _label = "3D ordinary kriging"
 
     def __init__(self, x, y, z, val, variogram_model="linear", variogram_parameters=None, variogram_function=None,
@@ -484,7 +506,10 @@ class OrdinaryKriging3D(_KrigingBase):
             raise ValueError("style argument must be 'grid', 'points', or 'masked'")
         self._check_backend(backend, n_closest_points)
         pts_adj, shape, mask, extra = self._prepare_points(style, (xpoints, ypoints, zpoints), mask)
-        z, ss = self._solve(pts_adj, mask, extra)
+        if n_closest_points is not None:
+            z, ss = self._solve_moving_window(pts_adj, mask, n_closest_points, backend)
+        else:
+            z, ss = self._solve(pts_adj, mask, extra)
         return self._finish(z, ss, style, shape, mask, backend)
 
 
@@ -494,6 +519,7 @@ class UniversalKriging3D(OrdinaryKriging3D):
     evaluated on the host."""
 
     _universal = True
+    _mw_backends = ()
     _label = "3D universal kriging"
 
     def __init__(self, x, y, z, val, variogram_model="linear", variogram_parameters=None, variogram_function=None,

@@ -303,3 +303,39 @@ def test_full_size_config2_properties():
     zr, sr = ko.execute(st, "grid", gx, gy[500:504])
     np.testing.assert_allclose(z[500:504], zr, rtol=0, atol=Z_TOL)
     np.testing.assert_allclose(ss[500:504], sr, rtol=0, atol=SS_TOL)
+
+
+@pytest.mark.parametrize("name", ["mw_ok2d", "mw_ok3d"])
+def test_moving_window_matches_reference(name):
+    """n_closest_points (ok.py:929-986, cok.pyx:98-193): kNN + per-point (k+1)x(k+1) solve on the device vs the
+    real reference's backend='loop' outputs, for k = 2 .. 70 (16/32/64/256 threads per point)."""
+    g = fx.load(name)
+    m = fx.amd_model_from(name, g)
+    axes = fx.grid_args(g)
+    for key in [k for k in g if k.startswith("z_k")]:
+        k = int(key[3:])
+        for backend in (("loop", "C") if name == "mw_ok2d" else ("loop",)):
+            z, ss = m.execute("grid", *axes, backend=backend, n_closest_points=k)
+            assert type(z) is np.ndarray and z.shape == g[key].shape
+            np.testing.assert_allclose(z, g[key], rtol=0, atol=Z_TOL)
+            np.testing.assert_allclose(ss, g["ss_k%d" % k], rtol=0, atol=SS_TOL)
+    if name == "mw_ok2d":
+        zm, ssm = m.execute("masked", *axes, mask=g["mask"], backend="loop", n_closest_points=10)
+        keep = ~g["mask"]
+        np.testing.assert_allclose(np.ma.getdata(zm)[keep], g["zm_k10"][keep], rtol=0, atol=Z_TOL)
+        np.testing.assert_allclose(np.ma.getdata(ssm)[keep], g["ssm_k10"][keep], rtol=0, atol=SS_TOL)
+        # five stations sit on grid nodes: exact interpolation through the window as well
+        z, ss = m.execute("points", g["x"][:5], g["y"][:5], backend="C", n_closest_points=10)
+        np.testing.assert_allclose(z, g["v"][:5], rtol=0, atol=Z_TOL)
+        assert np.all(np.abs(ss) <= SS_TOL)
+        with pytest.raises(ValueError):  # ok.py:982-986
+            m.execute("grid", *axes, backend="vectorized", n_closest_points=10)
+        with pytest.raises(ValueError):
+            m.execute("grid", *axes, backend="loop", n_closest_points=1)
+        # after a moving-window call the ordinary path must still work (the matrix buffer was reused)
+        z0, _ = m.execute("grid", *axes, backend="loop")
+        zr, _ = ko.execute(fx.state_from(name, g), "grid", *axes)
+        np.testing.assert_allclose(z0, zr, rtol=0, atol=Z_TOL)
+    else:
+        with pytest.raises(ValueError):  # ok3d.py:906-912: only 'loop' takes a moving window
+            m.execute("grid", *axes, backend="vectorized", n_closest_points=8)
