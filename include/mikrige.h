@@ -66,6 +66,9 @@ typedef struct mik_problem {
   const double *extra_cols; /* n_extra x n row-major: those drift terms evaluated at the stations */
   const double *a_inv;      /* optional (M x M, M = n + ndrift + 1): inverse supplied by the host
                                (pseudo_inv=True: P_INV[type](a), core.py:33); NULL = invert on device */
+  int32_t geographic;       /* coordinates_type == 'geographic' (ordinary 2D only): xs/ys and px/py are lon/lat in
+                               degrees, distances are great-circle degrees (core.py:36-97; ok.py:634-640, 990-996) */
+  int32_t reserved;
 } mik_problem;
 
 /* The prediction points handed to _exec_vector: adjusted coordinates (SoA), mask, drift rows. */

@@ -54,6 +54,16 @@ def variogram(model: str, m: Sequence[float], d: np.ndarray) -> np.ndarray:
     raise ValueError("unknown variogram model %r" % (model,))
 
 
+def great_circle_distance(lon1, lat1, lon2, lat2):
+    """core.py:36-97 (arctan form, degrees)."""
+    lat1 = np.array(lat1) * np.pi / 180.0
+    lat2 = np.array(lat2) * np.pi / 180.0
+    dlon = (lon1 - lon2) * np.pi / 180.0
+    c1, s1, c2, s2, cd = np.cos(lat1), np.sin(lat1), np.cos(lat2), np.sin(lat2), np.cos(dlon)
+    return 180.0 / np.pi * np.arctan2(np.sqrt((c2 * np.sin(dlon)) ** 2 + (c1 * s2 - s1 * c2 * cd) ** 2),
+                                      s1 * s2 + c1 * c2 * cd)
+
+
 def internal_parameters(model: str, params: Sequence[float]) -> List[float]:
     """List-form user parameters -> internal list (core.py:330-357): for the four bounded
     models the user gives [sill, range, nugget] and the code stores [sill-nugget, range, nugget]."""
@@ -114,6 +124,7 @@ class KrigingState:
     point_log: Optional[np.ndarray] = None  # (W,3) user x,y,strength (2D only)
     specified_data: List[np.ndarray] = field(default_factory=list)  # values at stations
     functional: List[Callable] = field(default_factory=list)
+    geographic: bool = False  # coordinates_type='geographic' (2D OK only): lon/lat degrees, great-circle distances
     coords_adj: np.ndarray = None
     wells_adj: Optional[np.ndarray] = None
 
@@ -122,7 +133,11 @@ class KrigingState:
         self.values = np.asarray(self.values, dtype=np.float64)
         if self.center is None:  # ok.py:276-277
             self.center = (self.coords_orig.max(axis=0) + self.coords_orig.min(axis=0)) / 2.0
-        self.coords_adj = adjust_for_anisotropy(self.coords_orig, self.center, self.scaling, self.angle)
+        if self.geographic:  # ok.py:289-304: no adjustment
+            self.center = np.zeros(2)
+            self.coords_adj = self.coords_orig.copy()
+        else:
+            self.coords_adj = adjust_for_anisotropy(self.coords_orig, self.center, self.scaling, self.angle)
         if self.point_log is not None:  # uk.py:461-470
             pl = np.atleast_2d(np.asarray(self.point_log, dtype=np.float64))
             self.wells_adj = np.zeros(pl.shape)
@@ -174,7 +189,11 @@ def _drift_columns(st: KrigingState, pts_adj: np.ndarray, spec: Sequence[np.ndar
 def kriging_matrix(st: KrigingState) -> np.ndarray:
     """ok.py:626-648 / uk.py:861-920 / ok3d.py:603-622 / uk3d.py:688-737."""
     n, p = st.n, st.n_drift
-    d = cdist(st.coords_adj, st.coords_adj, "euclidean")
+    if st.geographic:  # ok.py:634-640
+        d = great_circle_distance(st.coords_adj[:, 0][:, None], st.coords_adj[:, 1][:, None], st.coords_adj[:, 0],
+                                  st.coords_adj[:, 1])
+    else:
+        d = cdist(st.coords_adj, st.coords_adj, "euclidean")
     a = np.zeros((n + p + 1, n + p + 1))
     a[:n, :n] = -variogram(st.model, st.params, d)
     np.fill_diagonal(a, 0.0)
@@ -193,7 +212,10 @@ def rhs(st: KrigingState, pts_adj: np.ndarray, spec_pts: Sequence[np.ndarray] = 
     n, p = st.n, st.n_drift
     # 3D execute() feeds cdist columns in (z, y, x) order (ok3d.py:885-899, uk3d.py:1108-1122)
     rev = slice(None, None, -1) if st.ndim == 3 else slice(None)
-    bd = cdist(pts_adj[:, rev], st.coords_adj[:, rev], "euclidean")
+    if st.geographic:  # ok.py:990-996
+        bd = great_circle_distance(pts_adj[:, 0][:, None], pts_adj[:, 1][:, None], st.coords_adj[:, 0], st.coords_adj[:, 1])
+    else:
+        bd = cdist(pts_adj[:, rev], st.coords_adj[:, rev], "euclidean")
     b = np.zeros((pts_adj.shape[0], n + p + 1))
     b[:, :n] = -variogram(st.model, st.params, bd)
     if st.exact_values:
@@ -230,8 +252,17 @@ def solve_points_moving_window(st: KrigingState, pts_adj: np.ndarray, n_closest_
     if st.n_drift:
         raise ValueError("moving window exists for ordinary kriging only")
     rev = slice(None, None, -1) if st.ndim == 3 else slice(None)
-    tree = cKDTree(st.coords_adj[:, rev])
-    bd_all, bd_idx = tree.query(pts_adj[:, rev], k=n_closest_points, eps=0.0)
+    if st.geographic:  # ok.py:930-970: KD-tree on unit-sphere Cartesian coordinates, great-circle distances afterwards
+        def unit(ll):
+            lo, la = ll[:, 0] * np.pi / 180.0, ll[:, 1] * np.pi / 180.0
+            return np.stack([np.cos(lo) * np.cos(la), np.sin(lo) * np.cos(la), np.sin(la)], 1)
+
+        _, bd_idx = cKDTree(unit(st.coords_adj)).query(unit(pts_adj), k=n_closest_points, eps=0.0)
+        bd_all = great_circle_distance(pts_adj[:, 0][:, None], pts_adj[:, 1][:, None], st.coords_adj[bd_idx, 0],
+                                       st.coords_adj[bd_idx, 1])
+    else:
+        tree = cKDTree(st.coords_adj[:, rev])
+        bd_all, bd_idx = tree.query(pts_adj[:, rev], k=n_closest_points, eps=0.0)
     a_all = kriging_matrix(st)
     n = n_closest_points
     z, ss = np.zeros(pts_adj.shape[0]), np.zeros(pts_adj.shape[0])
@@ -296,7 +327,7 @@ def execute(st: KrigingState, style: str, xpoints, ypoints, zpoints=None, mask=N
         pts = np.stack(axes, axis=1)
         spec_pts = [np.asarray(s, dtype=np.float64).ravel() for s in spec_pts]
     npt = pts.shape[0]
-    pts_adj = adjust_for_anisotropy(pts, st.center, st.scaling, st.angle)
+    pts_adj = pts if st.geographic else adjust_for_anisotropy(pts, st.center, st.scaling, st.angle)
     z = np.zeros(npt)
     ss = np.zeros(npt)
     if style == "masked":

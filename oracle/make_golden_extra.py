@@ -71,7 +71,7 @@ def main():
     print("wrote extra fixtures")
 
 
-if __name__ == "__main__" and "--mw" not in sys.argv:
+if __name__ == "__main__" and "--mw" not in sys.argv and "--geo" not in sys.argv:
     main()
 
 
@@ -122,3 +122,45 @@ def moving_window():
 if __name__ == "__main__" and "--mw" in sys.argv:
     _import_reference(False)
     moving_window()
+
+
+def geographic():
+    """coordinates_type='geographic' (ok.py:634-640, 990-996; tests/test_core.py:2750-2881): full-matrix and moving-window."""
+    import pykrige.lib
+
+    refdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "pykrige_lib")
+    with_c = os.path.isdir(refdir)
+    if with_c and refdir not in list(pykrige.lib.__path__):
+        pykrige.lib.__path__.append(refdir)
+    from pykrige.ok import OrdinaryKriging
+
+    def arr(x):
+        return np.ma.getdata(x).astype(np.float64)
+
+    rng = np.random.default_rng(95)
+    n = 300
+    lon = rng.uniform(-30.0, 50.0, n)
+    lat = rng.uniform(-60.0, 75.0, n)
+    v = np.sin(np.radians(lon) * 2) * np.cos(np.radians(lat) * 3) + 0.1 * rng.standard_normal(n)
+    glon, glat = np.linspace(-30.0, 50.0, 19), np.linspace(-60.0, 75.0, 15)
+    lon[:4], lat[:4] = glon[[2, 6, 10, 14]], glat[[1, 4, 8, 12]]
+    out = dict(x=lon, y=lat, v=v, model="exponential", params_user=[1.0, 40.0, 0.05], gridx=glon, gridy=glat, geographic=True)
+    ok = OrdinaryKriging(lon, lat, v, variogram_model="exponential", variogram_parameters=[1.0, 40.0, 0.05],
+                         coordinates_type="geographic")
+    z, ss = ok.execute("grid", glon, glat, backend="vectorized")
+    out.update(z=arr(z), ss=arr(ss), A=ok._get_kriging_matrix(n))
+    for k in (6, 20):
+        zk, ssk = ok.execute("grid", glon, glat, backend="loop", n_closest_points=k)
+        out["z_k%d" % k], out["ss_k%d" % k] = arr(zk), arr(ssk)
+        if with_c:
+            zc, ssc = ok.execute("grid", glon, glat, backend="C", n_closest_points=k)
+            out["zc_k%d" % k], out["ssc_k%d" % k] = arr(zc), arr(ssc)
+    okf = OrdinaryKriging(lon, lat, v, variogram_model="spherical", coordinates_type="geographic", nlags=7)
+    out.update(fit_lags=okf.lags, fit_semi=okf.semivariance, fit_par=np.asarray(okf.variogram_model_parameters))
+    np.savez_compressed(os.path.join(OUT, "geo_ok2d.npz"), **out)
+    print("wrote geographic fixture (C backend: %s)" % with_c)
+
+
+if __name__ == "__main__" and "--geo" in sys.argv:
+    _import_reference(False)
+    geographic()

@@ -39,6 +39,17 @@ def adjust_for_anisotropy(X, center, scaling, angle):
     return out
 
 
+def great_circle_distance(lon1, lat1, lon2, lat2):
+    """Great-circle distance in degrees, arctan form (core.py:36-97) -- host twin of the device functor
+    gc_dist; used by the constructor-time variogram fit only."""
+    lat1 = np.array(lat1) * np.pi / 180.0
+    lat2 = np.array(lat2) * np.pi / 180.0
+    dlon = (lon1 - lon2) * np.pi / 180.0
+    c1, s1, c2, s2, cd = np.cos(lat1), np.sin(lat1), np.cos(lat2), np.sin(lat2), np.cos(dlon)
+    return 180.0 / np.pi * np.arctan2(np.sqrt((c2 * np.sin(dlon)) ** 2 + (c1 * s2 - s1 * c2 * cd) ** 2),
+                                      s1 * s2 + c1 * c2 * cd)
+
+
 def make_variogram_parameter_list(model, params):
     """User parameters (list or dict) -> internal list; None stays None (= 'fit it')."""
     if params is None:

@@ -61,6 +61,18 @@ __device__ __forceinline__ double well_drift(double x, double y, const double* _
   return -w[2] * ld;
 }
 
+// great-circle distance in degrees, arctan form (core.py:36-97), with cos/sin of the latitudes precomputed:
+// point 1 = (lon1, c1 = cos(lat1 pi/180), s1 = sin(lat1 pi/180)), point 2 likewise.  Kernels instantiated
+// with NDIM == 1 use it instead of the Euclidean distance (coordinates_type='geographic', ok.py:634-640, 990-996).
+#define MIK_PI 3.14159265358979323846
+__device__ __forceinline__ double gc_dist(double lon1, double c1, double s1, double lon2, double c2, double s2) {
+  const double dlon = (lon1 - lon2) * MIK_PI / 180.0;
+  double sd, cd;
+  sincos(dlon, &sd, &cd);
+  const double a = c2 * sd, b = c1 * s2 - s1 * c2 * cd;
+  return 180.0 / MIK_PI * atan2(sqrt(a * a + b * b), s1 * s2 + c1 * c2 * cd);
+}
+
 // ------------------------------------------------------------------------------------------------
 // K1: kriging matrix.  T is Mp x Mp (Mp = M rounded up to 128), row-major, ld = Mp.
 //   [i<N, j<N]   -gamma(|X_i - X_j|) + shift, diagonal = 0 + shift   (ok.py:630-644)
@@ -104,6 +116,11 @@ __global__ void __launch_bounds__(256) k_assemble(AsmArgs a) {
     sx[threadIdx.x] = st ? a.xs[i] : 0.0;
     sy[threadIdx.x] = st ? a.ys[i] : 0.0;
     sz[threadIdx.x] = (st && NDIM == 3) ? a.zs[i] : 0.0;
+    if (NDIM == 1) {  // geographic: (lon, cos lat, sin lat)
+      const double lat = sy[threadIdx.x] * MIK_PI / 180.0;
+      sy[threadIdx.x] = cos(lat);
+      sz[threadIdx.x] = sin(lat);
+    }
   }
   __syncthreads();
   double xj = 0.0, yj = 0.0, zj = 0.0;
@@ -111,6 +128,11 @@ __global__ void __launch_bounds__(256) k_assemble(AsmArgs a) {
     xj = a.xs[j];
     yj = a.ys[j];
     if (NDIM == 3) zj = a.zs[j];
+    if (NDIM == 1) {
+      const double lat = yj * MIK_PI / 180.0;
+      yj = cos(lat);
+      zj = sin(lat);
+    }
   }
   for (int r = threadIdx.x >> 6; r < 64; r += 4) {
     const int i = i0 + r;
@@ -121,15 +143,20 @@ __global__ void __launch_bounds__(256) k_assemble(AsmArgs a) {
       if (i == j) {
         val = a.shift;  // np.fill_diagonal(a, 0.0)
       } else {
-        const double dx = sx[r] - xj, dy = sy[r] - yj;
-        double s2;
-        if (NDIM == 3) {
-          const double dz = sz[r] - zj;
-          s2 = dx * dx + dy * dy + dz * dz;
+        if (NDIM == 1) {
+          const double d = gc_dist(sx[r], sy[r], sz[r], xj, yj, zj);
+          val = a.shift - vario<MODEL, false>(a.v, d, d * d);
         } else {
-          s2 = dx * dx + dy * dy;
+          const double dx = sx[r] - xj, dy = sy[r] - yj;
+          double s2;
+          if (NDIM == 3) {
+            const double dz = sz[r] - zj;
+            s2 = dx * dx + dy * dy + dz * dz;
+          } else {
+            s2 = dx * dx + dy * dy;
+          }
+          val = a.shift - vario<MODEL, false>(a.v, sqrt(s2), s2);
         }
-        val = a.shift - vario<MODEL, false>(a.v, sqrt(s2), s2);
       }
     } else if (i >= a.N && j >= a.N) {
       val = 0.0;
@@ -202,6 +229,11 @@ __global__ void __launch_bounds__(256) k_rhs(RhsArgs a) {
     qx[q] = a.px[idx];
     qy[q] = a.py[idx];
     qz[q] = (NDIM == 3) ? a.pz[idx] : 0.0;
+    if (NDIM == 1) {  // geographic: (lon, cos lat, sin lat) of the point
+      const double lat = qy[q] * MIK_PI / 180.0;
+      qy[q] = cos(lat);
+      qz[q] = sin(lat);
+    }
   }
   double zacc[MIK_TP];
 #pragma unroll
@@ -210,22 +242,35 @@ __global__ void __launch_bounds__(256) k_rhs(RhsArgs a) {
   for (int j = threadIdx.x; j < a.Mp; j += 256) {
     double val[MIK_TP];
     if (j < a.N) {
-      const double sx = a.xs[j], sy = a.ys[j];
-      const double sz = (NDIM == 3) ? a.zs[j] : 0.0;
+      const double sx = a.xs[j];
+      double sy = a.ys[j];
+      double sz = (NDIM == 3) ? a.zs[j] : 0.0;
+      if (NDIM == 1) {
+        const double lat = sy * MIK_PI / 180.0;
+        sy = cos(lat);
+        sz = sin(lat);
+      }
 #pragma unroll
       for (int q = 0; q < MIK_TP; ++q) {
-        const double dx = qx[q] - sx, dy = qy[q] - sy;
-        double s2;
-        if (NDIM == 3) {
-          const double dz = qz[q] - sz;
-          s2 = dz * dz + dy * dy + dx * dx;
+        double g;
+        if (NDIM == 1) {
+          const double d = gc_dist(qx[q], qy[q], qz[q], sx, sy, sz);  // point first (ok.py:990-996)
+          g = -vario<MODEL, true>(a.v, d, d * d);
+          if (a.exact && d <= a.eps) g = 0.0;
         } else {
-          s2 = dx * dx + dy * dy;
+          const double dx = qx[q] - sx, dy = qy[q] - sy;
+          double s2;
+          if (NDIM == 3) {
+            const double dz = qz[q] - sz;
+            s2 = dz * dz + dy * dy + dx * dx;
+          } else {
+            s2 = dx * dx + dy * dy;
+          }
+          // gaussian needs only d^2: no sqrt, and |d| <= eps becomes d^2 <= eps^2 (ok.py:665: abs(bd) <= eps)
+          const double d = (MODEL == 2) ? 0.0 : sqrt(s2);
+          g = -vario<MODEL, true>(a.v, d, s2);
+          if (a.exact && ((MODEL == 2) ? (s2 <= a.eps * a.eps) : (d <= a.eps))) g = 0.0;
         }
-        // gaussian needs only d^2: no sqrt, and |d| <= eps becomes d^2 <= eps^2 (ok.py:665: abs(bd) <= eps)
-        const double d = (MODEL == 2) ? 0.0 : sqrt(s2);
-        double g = -vario<MODEL, true>(a.v, d, s2);
-        if (a.exact && ((MODEL == 2) ? (s2 <= a.eps * a.eps) : (d <= a.eps))) g = 0.0;
         val[q] = g;
       }
     } else if (j < a.N + a.p) {
@@ -1186,6 +1231,30 @@ __global__ void __launch_bounds__(256) k_mw_solve(MwArgs a) {
     a.ss[pt] = -s2;
     if (bad) atomicOr(a.flag, 1);
   }
+}
+
+// geographic moving window: the neighbour search runs on unit-sphere Cartesian coordinates (ok.py:934-955), the
+// distances handed to the solve are great-circle again (ok.py:962-970)
+__global__ void __launch_bounds__(256) k_geo_unit(const double* __restrict__ lon, const double* __restrict__ lat, int n,
+                                                  double* __restrict__ ux, double* __restrict__ uy,
+                                                  double* __restrict__ uz) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const double lo = lon[i] * MIK_PI / 180.0, la = lat[i] * MIK_PI / 180.0;
+  ux[i] = cos(lo) * cos(la);
+  uy[i] = sin(lo) * cos(la);
+  uz[i] = sin(la);
+}
+__global__ void __launch_bounds__(256)
+k_mw_geo_dist(const double* __restrict__ plon, const double* __restrict__ plat, long npt, int K,
+              const double* __restrict__ slon, const double* __restrict__ slat, const int* __restrict__ idx,
+              double* __restrict__ dist) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= npt * K) return;
+  const long t = e / K;
+  const int s = idx[e];
+  const double la1 = plat[t] * MIK_PI / 180.0, la2 = slat[s] * MIK_PI / 180.0;
+  dist[e] = gc_dist(plon[t], cos(la1), sin(la1), slon[s], cos(la2), sin(la2));
 }
 
 }  // namespace mik

@@ -105,6 +105,7 @@ struct mik_handle {
   // problem
   bool have_problem = false, have_factor = false, have_points = false, have_results = false;
   int ndim = 2, model = 0, exact = 1, rl = 0, nwells = 0, nextra = 0;
+  int geo = 0;  // coordinates_type == 'geographic' (2-D lon/lat in degrees; kernels are instantiated with NDIM = 1)
   int N = 0, p = 0, M = 0, Mp = 0;
   Vario v{};
   double eps = 1e-10, shift_guess = 0.0;
@@ -156,7 +157,16 @@ static double host_vario(const Vario& v, double d) {
 
 #define DISPATCH_MODEL_NDIM(model, ndim, KERNEL, grid, block, stream, args)                                 \
   do {                                                                                                      \
-    if ((ndim) == 3) {                                                                                      \
+    if ((ndim) == 1) { /* geographic lon/lat */                                                             \
+      switch (model) {                                                                                      \
+        case 0: hipLaunchKernelGGL((KERNEL<0, 1>), grid, block, 0, stream, args); break;                    \
+        case 1: hipLaunchKernelGGL((KERNEL<1, 1>), grid, block, 0, stream, args); break;                    \
+        case 2: hipLaunchKernelGGL((KERNEL<2, 1>), grid, block, 0, stream, args); break;                    \
+        case 3: hipLaunchKernelGGL((KERNEL<3, 1>), grid, block, 0, stream, args); break;                    \
+        case 4: hipLaunchKernelGGL((KERNEL<4, 1>), grid, block, 0, stream, args); break;                    \
+        default: hipLaunchKernelGGL((KERNEL<5, 1>), grid, block, 0, stream, args); break;                   \
+      }                                                                                                     \
+    } else if ((ndim) == 3) {                                                                                      \
       switch (model) {                                                                                      \
         case 0: hipLaunchKernelGGL((KERNEL<0, 3>), grid, block, 0, stream, args); break;                    \
         case 1: hipLaunchKernelGGL((KERNEL<1, 3>), grid, block, 0, stream, args); break;                    \
@@ -257,11 +267,14 @@ int mik_set_problem(mik_handle* h, const mik_problem* p) {
   if (p->n_wells < 0 || p->n_extra < 0 || (p->n_wells > 0 && !p->wells) || (p->n_extra > 0 && !p->extra_cols))
     return fail(MIK_EINVAL, "drift description inconsistent");
   if (p->n_wells > 0 && p->ndim != 2) return fail(MIK_EINVAL, "point_log drift exists only in 2D (uk.py:884-896)");
+  if (p->geographic && (p->ndim != 2 || p->regional_linear || p->n_wells || p->n_extra))
+    return fail(MIK_EINVAL, "geographic coordinates exist for 2D ordinary kriging only (ok.py:634-640)");
   HIPC(hipSetDevice(h->device));
   h->ndim = p->ndim;
   h->model = p->model_id;
   h->N = (int)p->n;
   h->rl = p->regional_linear ? 1 : 0;
+  h->geo = p->geographic ? 1 : 0;
   h->nwells = p->n_wells;
   h->nextra = p->n_extra;
   h->p = (h->rl ? h->ndim : 0) + h->nwells + h->nextra;
@@ -318,6 +331,7 @@ int mik_set_problem(mik_handle* h, const mik_problem* p) {
       }
     double diag2 = 0.0;
     for (int d = 0; d < h->ndim; ++d) diag2 += (hi[d] - lo[d]) * (hi[d] - lo[d]);
+    if (h->geo) diag2 = std::min(diag2, 180.0 * 180.0);  // great-circle distances never exceed 180 degrees
     if (v.model >= 2) h->shift_guess = v.p0 + v.p2;
     else h->shift_guess = host_vario(v, std::sqrt(diag2));
     if (!(h->shift_guess > 0.0) || !std::isfinite(h->shift_guess)) h->shift_guess = 1.0;
@@ -353,7 +367,7 @@ static int launch_assemble(mik_handle* h, double shift) {
   a.wells = h->wells.as<double>();
   a.extra = h->extra_cols.as<double>();
   dim3 grid(h->Mp / 64, h->Mp / 64);
-  DISPATCH_MODEL_NDIM(h->model, h->ndim, k_assemble, grid, dim3(256), h->stream, a);
+  DISPATCH_MODEL_NDIM(h->model, h->geo ? 1 : h->ndim, k_assemble, grid, dim3(256), h->stream, a);
   HIPC(hipGetLastError());
   return MIK_OK;
 }
@@ -628,7 +642,7 @@ int mik_predict(mik_handle* h) {
     a.zout = h->z.as<double>() + t0;
     hipEvent_t e0 = h->evpool[2 + 3 * c], e1 = h->evpool[3 + 3 * c], e2 = h->evpool[4 + 3 * c];
     HIPC(hipEventRecord(e0, h->stream));
-    DISPATCH_MODEL_NDIM(h->model, h->ndim, k_rhs, dim3(palloc / MIK_TP), dim3(256), h->stream, a);
+    DISPATCH_MODEL_NDIM(h->model, h->geo ? 1 : h->ndim, k_rhs, dim3(palloc / MIK_TP), dim3(256), h->stream, a);
     HIPC(hipEventRecord(e1, h->stream));
     const long tiles = (long)nIblk * (palloc / 128);
     const unsigned grid = (unsigned)(8 * ((tiles + 7) / 8));
@@ -722,7 +736,28 @@ int mik_predict_moving_window(mik_handle* h, int n_closest) {
   MIKC(h->flag.ensure(sizeof(int)));
   HIPC(hipMemsetAsync(h->flag.p, 0, sizeof(int), h->stream));
   const unsigned kgrid = (unsigned)((npt + 255) / 256);
-  if (h->ndim == 3)
+  if (h->geo) {
+    // neighbours by chord length on the unit sphere (same ordering as great-circle), distances recomputed below
+    DevBuf su, pu;
+    MIKC(su.ensure(sizeof(double) * 3 * (size_t)h->N));
+    MIKC(pu.ensure(sizeof(double) * 3 * (size_t)npt));
+    double* s3 = su.as<double>();
+    double* p3 = pu.as<double>();
+    hipLaunchKernelGGL(k_geo_unit, dim3((h->N + 255) / 256), dim3(256), 0, h->stream, (const double*)h->xs.as<double>(),
+                       (const double*)h->ys.as<double>(), h->N, s3, s3 + h->N, s3 + 2 * (size_t)h->N);
+    hipLaunchKernelGGL(k_geo_unit, dim3(kgrid), dim3(256), 0, h->stream, (const double*)h->px.as<double>(),
+                       (const double*)h->py.as<double>(), (int)npt, p3, p3 + npt, p3 + 2 * (size_t)npt);
+    hipLaunchKernelGGL(k_mw_knn<3>, dim3(kgrid), dim3(256), 0, h->stream, (const double*)p3, (const double*)(p3 + npt),
+                       (const double*)(p3 + 2 * (size_t)npt), (int)npt, (const double*)s3, (const double*)(s3 + h->N),
+                       (const double*)(s3 + 2 * (size_t)h->N), h->N, K, h->mw_idx.as<int>(), h->mw_dist.as<double>());
+    hipLaunchKernelGGL(k_mw_geo_dist, dim3((unsigned)((npt * K + 255) / 256)), dim3(256), 0, h->stream,
+                       (const double*)h->px.as<double>(), (const double*)h->py.as<double>(), npt, K,
+                       (const double*)h->xs.as<double>(), (const double*)h->ys.as<double>(),
+                       (const int*)h->mw_idx.as<int>(), h->mw_dist.as<double>());
+    HIPC(hipStreamSynchronize(h->stream));  // su / pu are released at scope exit
+    su.release();
+    pu.release();
+  } else if (h->ndim == 3)
     hipLaunchKernelGGL(k_mw_knn<3>, dim3(kgrid), dim3(256), 0, h->stream, (const double*)h->px.as<double>(),
                        (const double*)h->py.as<double>(), (const double*)h->pz.as<double>(), (int)npt,
                        (const double*)h->xs.as<double>(), (const double*)h->ys.as<double>(),

@@ -64,7 +64,8 @@ class _KrigingBase:
             from . import variogram_fit  # constructor-time only; never on the execute() path
 
             self.lags, self.semivariance, plist = variogram_fit.fit(
-                self._coords_adj, self._values(), self.variogram_model, nlags, weight)
+                self._coords_adj, self._values(), self.variogram_model, nlags, weight,
+                getattr(self, "coordinates_type", "euclidean"))
         else:
             self.lags, self.semivariance = None, None
         self.variogram_model_parameters = [float(v) for v in plist]
@@ -111,6 +112,7 @@ class _KrigingBase:
             values=self._values(), model_id=_lib.MODEL_IDS[self.variogram_model],
             params=self.variogram_model_parameters, eps=self.eps, exact_values=self.exact_values,
             regional_linear=self._regional_linear(), wells=self._wells(), extra_cols=self._station_extra_cols(),
+            geographic=getattr(self, "coordinates_type", "euclidean") == "geographic",
         )
         if self.pseudo_inv:
             # ok.py:660-661: a_inv = P_INV[self.pseudo_inv_type](a).  The matrix is assembled on the
@@ -143,6 +145,8 @@ class _KrigingBase:
     def _prepare_points(self, style, axes, mask, specified_drift_arrays=None):
         """Everything execute() does on the host before the solve: returns (pts_adj, shape, mask, extra_rows)."""
         pts, shape, mask = self._points_from(style, axes, mask)
+        if getattr(self, "coordinates_type", "euclidean") == "geographic":
+            return pts, shape, mask, None  # no anisotropy correction in spherical coordinates (ok.py:892-896)
         return core.adjust_for_anisotropy(pts, self._center(), self._scaling(), self._angle()), shape, mask, None
 
     # ---------------------------------------------------------------- execute front / back matter
@@ -267,9 +271,7 @@ class OrdinaryKriging(_KrigingBase):
                  pseudo_inv_type="pinv"):
         self._init_common(variogram_model, variogram_parameters, variogram_function, exact_values, pseudo_inv,
                           pseudo_inv_type, verbose, enable_plotting)
-        if coordinates_type == "geographic":
-            raise NotImplementedError(_UNSUPPORTED % "coordinates_type='geographic'")
-        if coordinates_type != "euclidean":
+        if coordinates_type not in ("euclidean", "geographic"):
             raise ValueError("Only 'euclidean' and 'geographic' are valid values for coordinates-keyword.")
         self.coordinates_type = coordinates_type
         if enable_statistics:
@@ -277,11 +279,20 @@ class OrdinaryKriging(_KrigingBase):
         self.X_ORIG = np.atleast_1d(np.squeeze(np.array(x, copy=True, dtype=np.float64)))
         self.Y_ORIG = np.atleast_1d(np.squeeze(np.array(y, copy=True, dtype=np.float64)))
         self.Z = np.atleast_1d(np.squeeze(np.array(z, copy=True, dtype=np.float64)))
-        self.XCENTER = (np.amax(self.X_ORIG) + np.amin(self.X_ORIG)) / 2.0
-        self.YCENTER = (np.amax(self.Y_ORIG) + np.amin(self.Y_ORIG)) / 2.0
-        self.anisotropy_scaling = anisotropy_scaling
-        self.anisotropy_angle = anisotropy_angle
-        self._adjust_stations()
+        if self.coordinates_type == "euclidean":
+            self.XCENTER = (np.amax(self.X_ORIG) + np.amin(self.X_ORIG)) / 2.0
+            self.YCENTER = (np.amax(self.Y_ORIG) + np.amin(self.Y_ORIG)) / 2.0
+            self.anisotropy_scaling = anisotropy_scaling
+            self.anisotropy_angle = anisotropy_angle
+            self._adjust_stations()
+        else:  # ok.py:289-304: coordinates stay as they are; anisotropy is ambiguous on the sphere
+            if anisotropy_scaling != 1.0:
+                warnings.warn("Anisotropy is not compatible with geographic coordinates. Ignoring user set anisotropy.",
+                              UserWarning)
+            self.XCENTER = self.YCENTER = 0.0
+            self.anisotropy_scaling, self.anisotropy_angle = 1.0, 0.0
+            self.X_ADJUSTED, self.Y_ADJUSTED = self.X_ORIG, self.Y_ORIG
+            self._coords_adj = np.vstack((self.X_ORIG, self.Y_ORIG)).T
         self._set_variogram_parameters(variogram_parameters, nlags, weight)
         self.delta = self.sigma = self.epsilon = self.Q1 = self.Q2 = self.cR = None
 
@@ -300,6 +311,8 @@ class OrdinaryKriging(_KrigingBase):
         self.X_ADJUSTED, self.Y_ADJUSTED = self._coords_adj.T
 
     def _update_anisotropy(self, anisotropy_scaling=None, anisotropy_angle=None):
+        if getattr(self, "coordinates_type", "euclidean") == "geographic":
+            return
         if anisotropy_scaling is not None:
             self.anisotropy_scaling = anisotropy_scaling
         if anisotropy_angle is not None:

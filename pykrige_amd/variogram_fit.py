@@ -13,9 +13,19 @@ from scipy.spatial.distance import pdist
 from . import core
 
 
-def experimental_variogram(coords, values, nlags):
-    d = pdist(coords, metric="euclidean")
-    g = 0.5 * pdist(np.asarray(values, dtype=np.float64)[:, None], metric="sqeuclidean")
+def experimental_variogram(coords, values, nlags, coordinates_type="euclidean"):
+    values = np.asarray(values, dtype=np.float64)
+    if coordinates_type == "geographic":  # core.py:437-451: all pairs i > j of the great-circle distance matrix
+        x1, x2 = np.meshgrid(coords[:, 0], coords[:, 0], sparse=True)
+        y1, y2 = np.meshgrid(coords[:, 1], coords[:, 1], sparse=True)
+        z1, z2 = np.meshgrid(values, values, sparse=True)
+        dm = core.great_circle_distance(x1, y1, x2, y2)
+        gm = 0.5 * (z1 - z2) ** 2.0
+        lower = np.tril_indices(dm.shape[0], -1)
+        d, g = dm[lower], gm[lower]
+    else:
+        d = pdist(coords, metric="euclidean")
+        g = 0.5 * pdist(values[:, None], metric="sqeuclidean")
     dmin, dmax = np.amin(d), np.amax(d)
     width = (dmax - dmin) / nlags
     edges = [dmin + k * width for k in range(nlags)] + [dmax + 0.001]
@@ -39,8 +49,8 @@ def _residuals(params, lags, semis, model, weight):
     return r
 
 
-def fit(coords, values, model, nlags=6, weight=False):
-    lags, semis = experimental_variogram(coords, values, nlags)
+def fit(coords, values, model, nlags=6, weight=False, coordinates_type="euclidean"):
+    lags, semis = experimental_variogram(coords, values, nlags, coordinates_type)
     smax, smin, lmax, lmin = np.amax(semis), np.amin(semis), np.amax(lags), np.amin(lags)
     if model == "linear":
         x0 = [(smax - smin) / (lmax - lmin), smin]

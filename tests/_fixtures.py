@@ -54,6 +54,7 @@ def state_from(name, g):
         point_log=g["wells"] if "wells" in g else None,
         specified_data=([external_z(g, g["x"], g["y"])] if "dem" in g else []) + ([g["spec_data"]] if "spec_data" in g else []),
         functional=FUNCS.get(name, []),
+        geographic=bool(g["geographic"]) if "geographic" in g else False,
     )
 
 
@@ -105,6 +106,9 @@ def amd_model_from(name, g):
         if terms:
             return pa.UniversalKriging(g["x"], g["y"], g["v"], variogram_model=model, variogram_parameters=params,
                                        drift_terms=terms, exact_values=exact, **aniso, **kw)
+        if "geographic" in g and bool(g["geographic"]):
+            return pa.OrdinaryKriging(g["x"], g["y"], g["v"], variogram_model=model, variogram_parameters=params,
+                                      exact_values=exact, coordinates_type="geographic")
         return pa.OrdinaryKriging(g["x"], g["y"], g["v"], variogram_model=model, variogram_parameters=params,
                                   exact_values=exact, **aniso)
     sc = np.atleast_1d(g["scaling"]).tolist() if "scaling" in g else [1.0, 1.0]

@@ -36,7 +36,7 @@ def test_ctypes_structs_match_header_layout():
     from pykrige_amd import _lib
 
     # mik_problem: 2 x int32, int64, 4 pointers, 3 doubles, double, 4 x int32, 3 pointers = 120 bytes on LP64
-    assert ctypes.sizeof(_lib.MikProblem) == 4 + 4 + 8 + 4 * 8 + 3 * 8 + 8 + 4 * 4 + 3 * 8
+    assert ctypes.sizeof(_lib.MikProblem) == 4 + 4 + 8 + 4 * 8 + 3 * 8 + 8 + 4 * 4 + 3 * 8 + 2 * 4
     assert ctypes.sizeof(_lib.MikPoints) == 8 + 5 * 8
     assert ctypes.sizeof(_lib.MikTiming) == 5 * 8 + 8 + 8 + 4 * 4
 
@@ -158,3 +158,16 @@ def test_variogram_fit_matches_reference_fits():
             np.testing.assert_allclose(ok.variogram_model_parameters, g["par_" + key], rtol=1e-6, atol=1e-9)
     ok3 = pa.OrdinaryKriging3D(g["x3"], g["y3"], g["z3"], g["v3"], variogram_model="spherical", nlags=6)
     np.testing.assert_allclose(ok3.variogram_model_parameters, g["par_3d"], rtol=1e-6, atol=1e-9)
+
+
+def test_geographic_variogram_fit_matches_reference():
+    import pykrige_amd as pa
+    from tests import _fixtures as fx
+
+    g = fx.load("geo_ok2d")
+    ok = pa.OrdinaryKriging(g["x"], g["y"], g["v"], variogram_model="spherical", coordinates_type="geographic", nlags=7)
+    np.testing.assert_allclose(ok.lags, g["fit_lags"], rtol=1e-12)
+    np.testing.assert_allclose(ok.semivariance, g["fit_semi"], rtol=1e-12)
+    np.testing.assert_allclose(ok.variogram_model_parameters, g["fit_par"], rtol=1e-6, atol=1e-9)
+    with pytest.raises(ValueError):
+        pa.OrdinaryKriging(g["x"], g["y"], g["v"], variogram_model="linear", variogram_parameters=[1.0, 0.0], coordinates_type="martian")

@@ -39,7 +39,8 @@ def _handle_for(st, **opts):
     h.set_problem(ndim=st.ndim, xs=st.coords_adj[:, 0], ys=st.coords_adj[:, 1],
                   zs=st.coords_adj[:, 2] if st.ndim == 3 else None, values=st.values,
                   model_id=lib.MODEL_IDS[st.model], params=st.params, exact_values=st.exact_values,
-                  regional_linear=st.regional_linear, wells=wells, extra_cols=np.array(extra) if extra else None)
+                  regional_linear=st.regional_linear, wells=wells, extra_cols=np.array(extra) if extra else None,
+                  geographic=st.geographic)
     return h
 
 
@@ -305,7 +306,7 @@ def test_full_size_config2_properties():
     np.testing.assert_allclose(ss[500:504], sr, rtol=0, atol=SS_TOL)
 
 
-@pytest.mark.parametrize("name", ["mw_ok2d", "mw_ok3d"])
+@pytest.mark.parametrize("name", ["mw_ok2d", "mw_ok3d", "geo_ok2d"])
 def test_moving_window_matches_reference(name):
     """n_closest_points (ok.py:929-986, cok.pyx:98-193): kNN + per-point (k+1)x(k+1) solve on the device vs the
     real reference's backend='loop' outputs, for k = 2 .. 70 (16/32/64/256 threads per point)."""
@@ -314,7 +315,7 @@ def test_moving_window_matches_reference(name):
     axes = fx.grid_args(g)
     for key in [k for k in g if k.startswith("z_k")]:
         k = int(key[3:])
-        for backend in (("loop", "C") if name == "mw_ok2d" else ("loop",)):
+        for backend in (("loop", "C") if name != "mw_ok3d" else ("loop",)):
             z, ss = m.execute("grid", *axes, backend=backend, n_closest_points=k)
             assert type(z) is np.ndarray and z.shape == g[key].shape
             np.testing.assert_allclose(z, g[key], rtol=0, atol=Z_TOL)
@@ -336,6 +337,6 @@ def test_moving_window_matches_reference(name):
         z0, _ = m.execute("grid", *axes, backend="loop")
         zr, _ = ko.execute(fx.state_from(name, g), "grid", *axes)
         np.testing.assert_allclose(z0, zr, rtol=0, atol=Z_TOL)
-    else:
+    elif name == "mw_ok3d":
         with pytest.raises(ValueError):  # ok3d.py:906-912: only 'loop' takes a moving window
             m.execute("grid", *axes, backend="vectorized", n_closest_points=8)
