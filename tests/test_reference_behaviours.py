@@ -1,0 +1,187 @@
+"""GPU tests of behaviours the reference's own suite pins with known answers or equivalences
+(/root/reference/tests/test_core.py; line ranges cited per test), restated against pykrige_amd.
+Small systems (3-50 stations): they exercise the padded-matrix / single-tile corners of the device path."""
+import numpy as np
+import pytest
+from pytest import approx
+
+pytestmark = pytest.mark.gpu
+
+
+def _pa():
+    import pykrige_amd as pa
+
+    return pa
+
+
+def test_exact_interpolation_on_a_diagonal_of_three_stations():
+    """test_force_exact (test_core.py:1510-1834): linear [1, 1]; z == datum and sigma^2 == 0 exactly at stations."""
+    pa = _pa()
+    d = np.array([[1.0, 1.0, 2.0], [2.0, 2.0, 1.5], [3.0, 3.0, 1.0]])
+    ok = pa.OrdinaryKriging(d[:, 0], d[:, 1], d[:, 2], variogram_model="linear", variogram_parameters=[1.0, 1.0])
+    for backend in ("vectorized", "loop", "C"):
+        z, ss = ok.execute("grid", [1.0, 2.0, 3.0], [1.0, 2.0, 3.0], backend=backend)
+        for k in range(3):
+            assert z[k, k] == approx(d[k, 2]) and ss[k, k] == approx(0.0, abs=1e-12)
+        assert ss[0, 2] != approx(0.0) and ss[2, 0] != approx(0.0)
+        z, ss = ok.execute("points", [1.0, 2.0, 3.0, 3.0], [2.0, 1.0, 1.0, 3.0], backend=backend)
+        assert all(ss[k] != approx(0.0) for k in range(3))
+        assert z[3] == approx(1.0) and ss[3] == approx(0.0, abs=1e-12)
+        z, ss = ok.execute("grid", np.arange(0.0, 4.0, 0.1), np.arange(0.0, 4.0, 0.1), backend=backend)
+        for k, node in enumerate((10, 20, 30)):
+            assert z[node, node] == approx(d[k, 2]) and ss[node, node] == approx(0.0, abs=1e-12)
+        for a, b in ((0, 0), (15, 15), (10, 0), (0, 10), (20, 10), (10, 20), (30, 20), (20, 30)):
+            assert ss[a, b] != approx(0.0)
+    z, ss = ok.execute("grid", np.arange(0.0, 3.1, 0.1), np.arange(2.1, 3.1, 0.1), backend="vectorized")
+    assert np.any(np.isclose(ss, 0)) and not np.any(np.isclose(ss[:9, :30], 0)) and not np.allclose(z[:9, :30], 0.0)
+    z, ss = ok.execute("grid", np.arange(0.0, 1.9, 0.1), np.arange(2.1, 3.1, 0.1), backend="vectorized")
+    assert not np.any(np.isclose(ss, 0))
+    gx, gy = np.arange(2.5, 3.5, 0.1), np.arange(2.5, 3.5, 0.25)
+    z, ss = ok.execute("masked", gx, gy, backend="vectorized", mask=np.asarray(np.meshgrid(gx, gy)[0] == 0.0))
+    assert np.isclose(ss[2, 5], 0) and not np.allclose(ss, 0.0)
+
+
+def test_exact_interpolation_3d():
+    """test_force_exact_3d (test_core.py:2505-2560)."""
+    pa = _pa()
+    d = np.array([[1.0, 1.0, 1.0, 2.0], [2.0, 2.0, 2.0, 1.5], [3.0, 3.0, 3.0, 1.0]])
+    k3 = pa.OrdinaryKriging3D(d[:, 0], d[:, 1], d[:, 2], d[:, 3], variogram_model="linear", variogram_parameters=[1.0, 1.0])
+    g = [1.0, 2.0, 3.0]
+    for backend in ("vectorized", "loop"):
+        k, ss = k3.execute("grid", g, g, g, backend=backend)
+        for q in range(3):
+            assert k[q, q, q] == approx(d[q, 3]) and ss[q, q, q] == approx(0.0, abs=1e-12)
+        assert ss[2, 0, 0] != approx(0.0) and ss[0, 2, 0] != approx(0.0)
+        k, ss = k3.execute("points", [1.0, 2.0, 3.0, 3.0], [2.0, 1.0, 1.0, 3.0], [1.0, 1.0, 3.0, 3.0], backend=backend)
+        assert k[3] == approx(1.0) and ss[3] == approx(0.0, abs=1e-12) and ss[0] != approx(0.0)
+        ax = np.arange(0.0, 4.0, 0.5)
+        k, ss = k3.execute("grid", ax, ax, ax, backend=backend)
+        assert k.shape == (8, 8, 8) and k[2, 2, 2] == approx(2.0) and ss[4, 4, 4] == approx(0.0, abs=1e-12)
+
+
+def test_exact_values_false_changes_only_the_station_nodes():
+    """test_non_exact (test_core.py:430-487)."""
+    pa = _pa()
+    d = np.array([[0.0, 0.0, 0.47], [1.5, 1.5, 0.56], [3, 3, 0.74], [4.5, 4.5, 1.47]])
+    g = np.arange(0.0, 4.51, 1.5)
+    kw = dict(variogram_model="exponential", variogram_parameters=[500.0, 3000.0, 5.0])
+    z, _ = pa.OrdinaryKriging(d[:, 0], d[:, 1], d[:, 2], **kw).execute("grid", g, g, backend="loop")
+    zn, _ = pa.OrdinaryKriging(d[:, 0], d[:, 1], d[:, 2], exact_values=False, **kw).execute("grid", g, g, backend="loop")
+    np.testing.assert_allclose(np.diag(z), d[:, 2])
+    assert not np.allclose(np.diag(zn), d[:, 2])
+    np.fill_diagonal(z, 0.0)
+    np.fill_diagonal(zn, 0.0)
+    np.testing.assert_allclose(z, zn, rtol=1e-7)
+
+
+def test_ucla_universal_kriging_point():
+    """test_uk_execute_single_point (test_core.py:856-895): lecture-note answer z = 567.54, sigma^2 = 9.044 (rel 0.1)."""
+    pa = _pa()
+    d = np.array([[61.0, 139.0, 477.0], [63.0, 140.0, 696.0], [64.0, 129.0, 227.0], [68.0, 128.0, 646.0],
+                  [71.0, 140.0, 606.0], [73.0, 141.0, 791.0], [75.0, 128.0, 783.0]])
+    uk = pa.UniversalKriging(d[:, 0], d[:, 1], d[:, 2], variogram_model="exponential",
+                             variogram_parameters=[10.0, 9.99, 0.0], drift_terms=["regional_linear"])
+    for backend in ("vectorized", "loop"):
+        z, ss = uk.execute("points", np.array([65.0]), np.array([137.0]), backend=backend)
+        assert 567.54 == approx(z[0], rel=0.1) and 9.044 == approx(ss[0], rel=0.1)
+        z, ss = uk.execute("points", np.array([61.0]), np.array([139.0]), backend=backend)
+        assert z[0] == approx(477.0, rel=1e-3) and ss[0] == approx(0.0, abs=1e-9)
+
+
+def test_kitanidis_example_through_execute():
+    """test_core_krige (test_core.py:378-427), Kitanidis ex. 3.2: z = 1.6364, sigma^2 = 0.4201."""
+    pa = _pa()
+    d = np.array([[9.7, 47.6, 1.22], [43.8, 24.6, 2.822]])
+    ok = pa.OrdinaryKriging(d[:, 0], d[:, 1], d[:, 2], variogram_model="linear", variogram_parameters=[0.006, 0.1])
+    z, ss = ok.execute("points", [18.8, 43.8], [67.9, 24.6], backend="loop")
+    assert z[0] == approx(1.6364, rel=1e-4) and ss[0] == approx(0.4201, rel=1e-4)
+    assert z[1] == approx(2.822, rel=1e-3) and ss[1] == approx(0.0, abs=1e-12)
+    k3 = pa.OrdinaryKriging3D(d[:, 0], d[:, 1], np.ones(2), d[:, 2], variogram_model="linear", variogram_parameters=[0.006, 0.1])
+    z, ss = k3.execute("points", [18.8], [67.9], [1.0], backend="loop")
+    assert z[0] == approx(1.6364, rel=1e-4) and ss[0] == approx(0.4201, rel=1e-4)
+
+
+@pytest.fixture
+def sample():  # the reference's sample_data_2d (test_core.py:45-61)
+    data = np.array([[0.3, 1.2, 0.47], [1.9, 0.6, 0.56], [1.1, 3.2, 0.74], [3.3, 4.4, 1.47], [4.7, 3.8, 1.74]])
+    return data, np.arange(0.0, 6.0, 1.0), np.arange(0.0, 5.5, 0.5)
+
+
+def test_drift_constructions_are_equivalent(sample):
+    """test_ok_uk_produce_same_result, test_uk_specified_drift, test_uk_functional_drift (test_core.py:1020-1066,
+    1257-1476): UK without drift == OK; 'specified' [x, y] == 'functional' [x, y] == regional_linear; a well given as a
+    specified drift == point_log (incl. the -inf -> -100 rule when a grid node sits on the well)."""
+    pa = _pa()
+    data, gx, gy = sample
+    xg, yg = np.meshgrid(gx, gy)
+    x, y, v = data[:, 0], data[:, 1], data[:, 2]
+    kw = dict(variogram_model="linear", variogram_parameters=[1.0, 0.1])
+    z0, s0 = pa.OrdinaryKriging(x, y, v, **kw).execute("grid", gx, gy, backend="loop")
+    z1, s1 = pa.UniversalKriging(x, y, v, **kw).execute("grid", gx, gy, backend="loop")
+    np.testing.assert_allclose(z0, z1, atol=1e-10)
+    np.testing.assert_allclose(s0, s1, atol=1e-10)
+    zl, sl = pa.UniversalKriging(x, y, v, drift_terms=["regional_linear"], **kw).execute("grid", gx, gy, backend="loop")
+    uk_spec = pa.UniversalKriging(x, y, v, drift_terms=["specified"], specified_drift=[x, y], **kw)
+    with pytest.raises(ValueError):
+        uk_spec.execute("grid", gx, gy, specified_drift_arrays=[gx, gy])
+    with pytest.raises(TypeError):
+        uk_spec.execute("grid", gx, gy, specified_drift_arrays=gx)
+    with pytest.raises(ValueError):
+        uk_spec.execute("grid", gx, gy, specified_drift_arrays=[xg])
+    zs, ss_ = uk_spec.execute("grid", gx, gy, specified_drift_arrays=[xg, yg], backend="loop")
+    np.testing.assert_allclose(zs, zl, atol=1e-9)
+    np.testing.assert_allclose(ss_, sl, atol=1e-9)
+    zf, sf = pa.UniversalKriging(x, y, v, drift_terms=["functional"], functional_drift=[lambda a, b: a, lambda a, b: b],
+                                 **kw).execute("grid", gx, gy, backend="loop")
+    np.testing.assert_allclose(zf, zl, atol=1e-9)
+    np.testing.assert_allclose(sf, sl, atol=1e-9)
+    # a well ON a grid node: log distance -inf -> -100 (uk.py:892-895)
+    well = np.array([[1.0, 1.0, -1.0]])
+    with np.errstate(divide="ignore"):
+        pl_grid = -well[0, 2] * np.log(np.sqrt((xg - well[0, 0]) ** 2 + (yg - well[0, 1]) ** 2))
+        pl_data = -well[0, 2] * np.log(np.sqrt((x - well[0, 0]) ** 2 + (y - well[0, 1]) ** 2))
+    pl_grid[np.isinf(pl_grid)] = -100.0 * well[0, 2] * -1.0
+    zw, sw = pa.UniversalKriging(x, y, v, drift_terms=["point_log"], point_drift=well, **kw).execute("grid", gx, gy, backend="loop")
+    zp, sp = pa.UniversalKriging(x, y, v, drift_terms=["specified"], specified_drift=[pl_data], **kw).execute(
+        "grid", gx, gy, specified_drift_arrays=[pl_grid], backend="loop")
+    np.testing.assert_allclose(zw, zp, atol=1e-9)
+    np.testing.assert_allclose(sw, sp, atol=1e-9)
+    with pytest.raises(ValueError):
+        pa.UniversalKriging(x, y, v, drift_terms=["specified"], **dict(kw, variogram_parameters=[1.0, 0.1]), specified_drift=[])
+    with pytest.raises(ValueError):
+        pa.UniversalKriging(x, y, v, drift_terms=["specified"], specified_drift=[x[:2]], **kw)
+
+
+def test_uk3d_drift_equivalences_and_shapes():
+    """test_uk3d_specified_drift / test_uk3d_functional_drift / test_ok3d_uk3d_and_backends_produce_same_results
+    (test_core.py:2563-2688, 2020-2094) and the (nz, ny, nx) output convention (ok3d.py:929-930)."""
+    pa = _pa()
+    rng = np.random.default_rng(12)
+    x, y, zc, v = rng.random(40) * 4, rng.random(40) * 3, rng.random(40) * 2, rng.random(40)
+    gx, gy, gz = np.linspace(0, 4, 6), np.linspace(0, 3, 5), np.linspace(0, 2, 4)
+    kw = dict(variogram_model="exponential", variogram_parameters=[1.0, 2.0, 0.05])
+    k0, s0 = pa.OrdinaryKriging3D(x, y, zc, v, **kw).execute("grid", gx, gy, gz, backend="loop")
+    k1, s1 = pa.UniversalKriging3D(x, y, zc, v, **kw).execute("grid", gx, gy, gz, backend="vectorized")
+    assert k0.shape == (4, 5, 6)
+    np.testing.assert_allclose(k0, np.ma.getdata(k1), atol=1e-10)
+    np.testing.assert_allclose(s0, np.ma.getdata(s1), atol=1e-10)
+    kl, sl = pa.UniversalKriging3D(x, y, zc, v, drift_terms=["regional_linear"], **kw).execute("grid", gx, gy, gz, backend="loop")
+    zg, yg, xg = np.meshgrid(gz, gy, gx, indexing="ij")
+    ks, ss = pa.UniversalKriging3D(x, y, zc, v, drift_terms=["specified"], specified_drift=[x, y, zc], **kw).execute(
+        "grid", gx, gy, gz, specified_drift_arrays=[xg, yg, zg], backend="loop")
+    kf, sf = pa.UniversalKriging3D(x, y, zc, v, drift_terms=["functional"],
+                                   functional_drift=[lambda a, b, c: a, lambda a, b, c: b, lambda a, b, c: c], **kw).execute(
+        "grid", gx, gy, gz, backend="loop")
+    for kk, s_ in ((ks, ss), (kf, sf)):
+        np.testing.assert_allclose(kk, kl, atol=1e-9)
+        np.testing.assert_allclose(s_, sl, atol=1e-9)
+    mask = rng.random((4, 5, 6)) < 0.3
+    km, sm = pa.OrdinaryKriging3D(x, y, zc, v, **kw).execute("masked", gx, gy, gz, mask=mask, backend="loop")
+    kt, _ = pa.OrdinaryKriging3D(x, y, zc, v, **kw).execute("masked", gx, gy, gz, mask=mask.swapaxes(0, 2), backend="loop")
+    assert km[mask].mask.all() and not km[~mask].mask.any()
+    np.testing.assert_array_equal(np.ma.getdata(km), np.ma.getdata(kt))
+    np.testing.assert_allclose(np.ma.getdata(km)[~mask], k0[~mask], atol=1e-12)
+    with pytest.raises(ValueError):
+        pa.OrdinaryKriging3D(x, y, zc, v, **kw).execute("masked", gx, gy, gz, mask=np.zeros((2, 2, 2), bool))
+    with pytest.raises(ValueError):
+        pa.OrdinaryKriging3D(x, y, zc, v, **kw).execute("masked", gx, gy, gz, mask=np.zeros((5, 6), bool))
