@@ -114,6 +114,10 @@ int  mik_get_results(mik_handle *h, double *z_out, double *ss_out); /* D2H, scat
  * (no mik_factor: each point solves its own (k+1)x(k+1) system).  Results as for mik_predict. */
 int  mik_predict_moving_window(mik_handle *h, int n_closest_points);
 
+/* Variogram-fit statistics: replaces core._find_statistics -> core._krige (core.py:759-836, 654-756): for
+ * i = 1..n-1 station i is kriged from stations 0..i-1.  k_out / ss_out have n entries (entry 0 unused = 0). */
+int  mik_statistics(mik_handle *h, double *k_out, double *ss_out);
+
 /* One-shot convenience: create + set_problem + factor + set_points + predict + get_results + destroy. */
 int  mik_krige_execute(int device, const mik_problem *p, const mik_points *g, double *z_out, double *ss_out);
 

@@ -71,7 +71,7 @@ def main():
     print("wrote extra fixtures")
 
 
-if __name__ == "__main__" and "--mw" not in sys.argv and "--geo" not in sys.argv:
+if __name__ == "__main__" and not {"--mw", "--geo", "--stats"} & set(sys.argv):
     main()
 
 
@@ -164,3 +164,33 @@ def geographic():
 if __name__ == "__main__" and "--geo" in sys.argv:
     _import_reference(False)
     geographic()
+
+
+def statistics():
+    """core._find_statistics (core.py:759-836) of the REAL reference: delta, sigma, epsilon, Q1, Q2, cR."""
+    import pykrige.core as core
+    import pykrige.variogram_models as vm
+
+    out = {}
+    (x, y), v = synth(96, 300, 2)
+    X = np.stack([x, y], 1)
+    for tag, fn, par in (("exp", vm.exponential_variogram_model, [0.9, 0.3, 0.1]), ("lin", vm.linear_variogram_model, [1.3, 0.05]),
+                         ("sph", vm.spherical_variogram_model, [0.8, 0.5, 0.05])):
+        d, s, e = core._find_statistics(X, v, fn, par, "euclidean")
+        out.update({"delta_" + tag: d, "sigma_" + tag: s, "eps_" + tag: e,
+                    "q_" + tag: np.array([core.calcQ1(e), core.calcQ2(e), core.calc_cR(core.calcQ2(e), s)])})
+    (x3, y3, z3), v3 = synth(97, 200, 3)
+    d, s, e = core._find_statistics(np.stack([x3, y3, z3], 1), v3, vm.gaussian_variogram_model, [0.9, 0.5, 0.1], "euclidean")
+    out.update(delta_3d=d, sigma_3d=s, eps_3d=e, q_3d=np.array([core.calcQ1(e), core.calcQ2(e), core.calc_cR(core.calcQ2(e), s)]))
+    rng = np.random.default_rng(98)
+    lon, lat = rng.uniform(-20, 40, 150), rng.uniform(-50, 60, 150)
+    vg = np.sin(np.radians(lon)) + 0.1 * rng.standard_normal(150)
+    d, s, e = core._find_statistics(np.stack([lon, lat], 1), vg, vm.exponential_variogram_model, [0.9, 40.0, 0.1], "geographic")
+    out.update(delta_geo=d, sigma_geo=s, eps_geo=e, lon=lon, lat=lat, vg=vg)
+    np.savez_compressed(os.path.join(OUT, "stats_find_statistics.npz"), x=x, y=y, v=v, x3=x3, y3=y3, z3=z3, v3=v3, **out)
+    print("wrote statistics fixture")
+
+
+if __name__ == "__main__" and "--stats" in sys.argv:
+    _import_reference(False)
+    statistics()

@@ -61,6 +61,7 @@ SIGNATURES = {
     "mik_predict": (C.c_int, [C.c_void_p]),
     "mik_get_results": (C.c_int, [C.c_void_p, _dp, _dp]),
     "mik_predict_moving_window": (C.c_int, [C.c_void_p, C.c_int]),
+    "mik_statistics": (C.c_int, [C.c_void_p, _dp, _dp]),
     "mik_krige_execute": (C.c_int, [C.c_int, C.POINTER(MikProblem), C.POINTER(MikPoints), _dp, _dp]),
     "mik_assemble_only": (C.c_int, [C.c_void_p]),
     "mik_get_matrix": (C.c_int, [C.c_void_p, C.c_int, _dp]),
@@ -211,6 +212,12 @@ class Handle:
 
     def predict_moving_window(self, n_closest_points):
         check(self._lib.mik_predict_moving_window(self._h, int(n_closest_points)))
+
+    def statistics(self, n):
+        k = np.zeros(n, dtype=np.float64)
+        ss = np.zeros(n, dtype=np.float64)
+        check(self._lib.mik_statistics(self._h, _ptr(k), _ptr(ss)))
+        return k, ss
 
     def get_results(self):
         z = np.empty(self._npt, dtype=np.float64)

@@ -1257,4 +1257,82 @@ k_mw_geo_dist(const double* __restrict__ plon, const double* __restrict__ plat, 
   dist[e] = gc_dist(plon[t], cos(la1), sin(la1), slon[s], cos(la2), sin(la2));
 }
 
+// ------------------------------------------------------------------------------------------------
+// Variogram-fit statistics (core.py:759-836 _find_statistics -> core.py:654-756 _krige): station i is kriged from
+// stations 0..i-1 for i = 1..N-1.  The reference solves N-1 growing dense systems (O(N^4)); here the inverse
+// of the bordered matrix [[0, 1^T], [1, -Gamma_i]] (Lagrange row FIRST so a new station appends a row/column) is
+// grown by the bordering identity: with u = [1; -gamma(d(i, 0..i-1))] (row i of the assembled matrix),
+// x = Minv u is the kriging solution itself (k_i = x[1:].y, ss_i = -x.u) and
+//   Minv' = [[Minv + x x^T / s, -x / s], [-x^T / s, 1 / s]],  s = 0 - u.x = ss_i
+// so each step is one mat-vec, one tiny reduction and one rank-1 update: O(N^3) flops, 24 N^3 / 3 bytes in total.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_stat_matvec(const double* __restrict__ S, long ld, int m, const double* __restrict__ Trow /* T[i][0..i-1] */,
+              double* __restrict__ x) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= m) return;
+  const double* r = S + (long)row * ld;
+  double s = 0.0;
+  for (int b = lane; b < m; b += 64) s += r[b] * (b == 0 ? 1.0 : Trow[b - 1]);
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) x[row] = s;
+}
+
+// one block: k = sum_j x[1+j] y[j], ss = -(x[0] + sum_j x[1+j] Trow[j]); out[0] = k, out[1] = ss, out[2] = 1/ss
+__global__ void __launch_bounds__(256)
+k_stat_reduce(const double* __restrict__ x, int m, const double* __restrict__ Trow, const double* __restrict__ y,
+              double* __restrict__ kout, double* __restrict__ ssout, double* __restrict__ scal) {
+  __shared__ double sk[256], su[256];
+  double k = 0.0, u = 0.0;
+  for (int j = threadIdx.x; j < m - 1; j += 256) {
+    const double xv = x[1 + j];
+    k += xv * y[j];
+    u += xv * Trow[j];
+  }
+  sk[threadIdx.x] = k;
+  su[threadIdx.x] = u;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      sk[threadIdx.x] += sk[threadIdx.x + o];
+      su[threadIdx.x] += su[threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double ss = -(x[0] + su[0]);
+    *kout = sk[0];
+    *ssout = ss;
+    scal[0] = 1.0 / ss;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_stat_update(double* __restrict__ S, long ld, int m, const double* __restrict__ x, const double* __restrict__ scal) {
+  const int b = blockIdx.x * 64 + (threadIdx.x & 63);
+  const double sinv = scal[0];
+  if (b > m) return;
+  const double xb = (b < m) ? x[b] : 0.0;
+  for (int a = blockIdx.y * 64 + (threadIdx.x >> 6); a < blockIdx.y * 64 + 64 && a <= m; a += 4) {
+    double* p = S + (long)a * ld + b;
+    if (a < m && b < m) *p += x[a] * xb * sinv;
+    else if (a == m && b == m) *p = sinv;
+    else *p = -((a == m) ? xb : x[a]) * sinv;
+  }
+}
+
+// first station pair closer than 1e-10 (the reference's solve would be singular): flag = 1
+template <int NDIM>
+__global__ void __launch_bounds__(256)
+k_stat_dupes(const double* __restrict__ xs, const double* __restrict__ ys, const double* __restrict__ zs, int N,
+             int* __restrict__ flag) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  const double x = xs[i], y = ys[i], z = (NDIM == 3) ? zs[i] : 0.0;
+  for (int j = 0; j < i; ++j) {
+    const double dx = x - xs[j], dy = y - ys[j], dz = (NDIM == 3) ? z - zs[j] : 0.0;
+    if (sqrt(dx * dx + dy * dy + dz * dz) <= 1e-10) { atomicOr(flag, 1); return; }
+  }
+}
+
 }  // namespace mik

@@ -119,7 +119,7 @@ struct mik_handle {
   std::vector<long> scatter;  // empty = identity
   DevBuf px, py, pz, extra_rows, z, ss;
   // work
-  DevBuf Bt, part, mw_idx, mw_dist;
+  DevBuf Bt, part, mw_idx, mw_dist, stat_S, stat_x, stat_out;
   int t_state = 0;  // what T holds: 0 nothing, 1 the kriging matrix A (shift 0), 2 its inverse
   // options
   int opt_waves = 8;  // waves per contraction block: 4 (wave tile 64x64) or 8 (32x64)
@@ -227,7 +227,7 @@ void mik_destroy(mik_handle* h) {
   if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
   DevBuf* bufs[] = {&h->xs, &h->ys, &h->zs, &h->vals, &h->wells, &h->extra_cols, &h->T, &h->cvec, &h->Cold, &h->Cnew,
                     &h->Rt, &h->TKt, &h->Dinv, &h->DinvT, &h->P0, &h->P1, &h->cand0, &h->cand1, &h->pivall, &h->flag,
-                    &h->px, &h->py, &h->pz, &h->extra_rows, &h->z, &h->ss, &h->Bt, &h->part, &h->mw_idx, &h->mw_dist};
+                    &h->px, &h->py, &h->pz, &h->extra_rows, &h->z, &h->ss, &h->Bt, &h->part, &h->mw_idx, &h->mw_dist, &h->stat_S, &h->stat_x, &h->stat_out};
   for (DevBuf* b : bufs) b->release();
   for (hipEvent_t e : h->evpool) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -805,6 +805,62 @@ int mik_predict_moving_window(mik_handle* h, int n_closest) {
   h->tm.predict_ms = ms;
   if (flag) return fail(MIK_ESINGULAR, "Singular matrix");  // cok.pyx:176-177
   h->have_results = true;
+  return MIK_OK;
+}
+
+int mik_statistics(mik_handle* h, double* k_out, double* ss_out) {
+  if (!h || !k_out || !ss_out) return fail(MIK_EINVAL, "mik_statistics: NULL argument");
+  if (!h->have_problem) return fail(MIK_ESTATE, "mik_statistics: set the problem first");
+  if (h->p != 0) return fail(MIK_EINVAL, "statistics use the ordinary-kriging system (core.py:654-756): no drift terms");
+  HIPC(hipSetDevice(h->device));
+  const int N = h->N, Ns = N + 1;
+  const long ld = ((Ns + 63) / 64) * 64;
+  MIKC(ensure_factor_buffers(h));
+  MIKC(h->flag.ensure(sizeof(int)));
+  HIPC(hipMemsetAsync(h->flag.p, 0, sizeof(int), h->stream));
+  if (!h->geo) {  // coincident stations make the growing systems singular (np.linalg.solve would raise)
+    if (h->ndim == 3)
+      hipLaunchKernelGGL(k_stat_dupes<3>, dim3((N + 255) / 256), dim3(256), 0, h->stream, (const double*)h->xs.as<double>(),
+                         (const double*)h->ys.as<double>(), (const double*)h->zs.as<double>(), N, h->flag.as<int>());
+    else
+      hipLaunchKernelGGL(k_stat_dupes<2>, dim3((N + 255) / 256), dim3(256), 0, h->stream, (const double*)h->xs.as<double>(),
+                         (const double*)h->ys.as<double>(), (const double*)nullptr, N, h->flag.as<int>());
+  }
+  if (h->t_state != 1) {
+    MIKC(launch_assemble(h, 0.0));
+    h->t_state = 1;
+    h->have_factor = false;
+  }
+  MIKC(h->stat_S.ensure(sizeof(double) * (size_t)ld * ld));
+  MIKC(h->stat_x.ensure(sizeof(double) * (size_t)ld + 64));
+  MIKC(h->stat_out.ensure(sizeof(double) * 2 * (size_t)N));
+  HIPC(hipMemsetAsync(h->stat_S.p, 0, h->stat_S.bytes, h->stream));
+  HIPC(hipMemsetAsync(h->stat_out.p, 0, h->stat_out.bytes, h->stream));
+  double* S = h->stat_S.as<double>();
+  double* x = h->stat_x.as<double>();
+  double* scal = x + ld;  // 1/s lives behind the vector
+  double* kd = h->stat_out.as<double>();
+  double* sd = kd + N;
+  const double init[4] = {0.0, 1.0, 1.0, 0.0};  // inverse of [[0,1],[1,0]] (Lagrange row + station 0)
+  HIPC(hipMemcpy2DAsync(S, sizeof(double) * ld, init, sizeof(double) * 2, sizeof(double) * 2, 2, hipMemcpyHostToDevice, h->stream));
+  const double* T = h->T.as<double>();
+  for (int i = 1; i < N; ++i) {
+    const int m = i + 1;
+    const double* Trow = T + (long)i * h->Mp;
+    hipLaunchKernelGGL(k_stat_matvec, dim3((m + 3) / 4), dim3(256), 0, h->stream, (const double*)S, ld, m, Trow, x);
+    hipLaunchKernelGGL(k_stat_reduce, dim3(1), dim3(256), 0, h->stream, (const double*)x, m, Trow,
+                       (const double*)h->vals.as<double>(), kd + i, sd + i, scal);
+    if (i + 1 < N)
+      hipLaunchKernelGGL(k_stat_update, dim3((m + 64) / 64, (m + 64) / 64), dim3(256), 0, h->stream, S, ld, m,
+                         (const double*)x, (const double*)scal);
+  }
+  HIPC(hipGetLastError());
+  int flag = 0;
+  HIPC(hipMemcpyAsync(&flag, h->flag.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPC(hipMemcpyAsync(k_out, kd, sizeof(double) * N, hipMemcpyDeviceToHost, h->stream));
+  HIPC(hipMemcpyAsync(ss_out, sd, sizeof(double) * N, hipMemcpyDeviceToHost, h->stream));
+  HIPC(hipStreamSynchronize(h->stream));
+  if (flag) return fail(MIK_ESINGULAR, "Singular matrix");
   return MIK_OK;
 }
 

@@ -66,8 +66,13 @@ class _KrigingBase:
             self.lags, self.semivariance, plist = variogram_fit.fit(
                 self._coords_adj, self._values(), self.variogram_model, nlags, weight,
                 getattr(self, "coordinates_type", "euclidean"))
-        else:
-            self.lags, self.semivariance = None, None
+        else:  # the reference bins the experimental variogram even when parameters are given; here on first use
+            self.__dict__.pop("lags", None)
+            self.__dict__.pop("semivariance", None)
+        self._nlags = nlags
+        for name in self._LAZY_STATS:  # a new variogram invalidates the statistics
+            if self.__dict__.get(name, 0) is not None:
+                self.__dict__.pop(name, None)
         self.variogram_model_parameters = [float(v) for v in plist]
         if self.verbose:
             print("Using '%s' Variogram Model" % self.variogram_model)
@@ -104,17 +109,19 @@ class _KrigingBase:
     def _regional_linear(self):
         return False
 
-    def _set_problem(self, h):
+    def _set_problem(self, h, with_drift=True):
         """H2D of the stations / drift description (and, for pseudo_inv=True, of the host pseudo-inverse)."""
         ca = self._coords_adj
         kw = dict(
             ndim=self._ndim, xs=ca[:, 0], ys=ca[:, 1], zs=ca[:, 2] if self._ndim == 3 else None,
             values=self._values(), model_id=_lib.MODEL_IDS[self.variogram_model],
             params=self.variogram_model_parameters, eps=self.eps, exact_values=self.exact_values,
-            regional_linear=self._regional_linear(), wells=self._wells(), extra_cols=self._station_extra_cols(),
+            regional_linear=self._regional_linear() if with_drift else False,
+            wells=self._wells() if with_drift else None,
+            extra_cols=self._station_extra_cols() if with_drift else None,
             geographic=getattr(self, "coordinates_type", "euclidean") == "geographic",
         )
-        if self.pseudo_inv:
+        if self.pseudo_inv and with_drift:
             # ok.py:660-661: a_inv = P_INV[self.pseudo_inv_type](a).  The matrix is assembled on the
             # device (K1), the SVD-based pseudo-inverse is the host's (SciPy), the result is uploaded.
             import scipy.linalg
@@ -148,6 +155,66 @@ class _KrigingBase:
         if getattr(self, "coordinates_type", "euclidean") == "geographic":
             return pts, shape, mask, None  # no anisotropy correction in spherical coordinates (ok.py:892-896)
         return core.adjust_for_anisotropy(pts, self._center(), self._scaling(), self._angle()), shape, mask, None
+
+    # ---------------------------------------------------------------- variogram-fit statistics (core.py:759-851)
+    _LAZY_STATS = ("delta", "sigma", "epsilon", "Q1", "Q2", "cR")
+
+    def _compute_statistics(self):
+        """_find_statistics on the device (mik_statistics): station i kriged from stations 0..i-1 with the ORDINARY
+        system (core._krige ignores drift terms), then delta / sigma / epsilon and Q1, Q2, cR as the reference."""
+        h = self._get_handle()
+        self._set_problem(h, with_drift=False)
+        y = self._values()
+        k, ss = h.statistics(y.size)
+        delta, sigma = np.zeros(y.shape), np.zeros(y.shape)
+        keep = np.absolute(ss) >= self.eps
+        keep[0] = False
+        with np.errstate(invalid="ignore"):
+            delta[keep] = y[keep] - k[keep]
+            sigma[keep] = np.sqrt(ss[keep])
+        sel = sigma > self.eps
+        self.delta, self.sigma = delta[sel], sigma[sel]
+        self.epsilon = self.delta / self.sigma
+        self.Q1 = abs(np.sum(self.epsilon) / (self.epsilon.shape[0] - 1))
+        self.Q2 = np.sum(self.epsilon**2) / (self.epsilon.shape[0] - 1)
+        self.cR = self.Q2 * np.exp(np.sum(np.log(self.sigma**2)) / self.sigma.shape[0])
+        if self.verbose:
+            print("Q1 =", self.Q1, "\nQ2 =", self.Q2, "\ncR =", self.cR, "\n")
+
+    def __getattr__(self, name):
+        # UK / 3-D constructors of the reference run _find_statistics unconditionally (uk.py:380, ok3d.py:352,
+        # uk3d.py:380); here the same attributes are computed on first use instead of at construction.
+        if name in _KrigingBase._LAZY_STATS and "_handle" in self.__dict__:
+            self._compute_statistics()
+            return self.__dict__[name]
+        if name in ("lags", "semivariance") and "_coords_adj" in self.__dict__:
+            from . import variogram_fit
+
+            self.lags, self.semivariance = variogram_fit.experimental_variogram(
+                self._coords_adj, self._values(), self.__dict__.get("_nlags", 6), getattr(self, "coordinates_type", "euclidean"))
+            return self.__dict__[name]
+        raise AttributeError(name)
+
+    def get_epsilon_residuals(self):
+        return self.epsilon
+
+    def get_statistics(self):
+        return self.Q1, self.Q2, self.cR
+
+    def print_statistics(self):
+        print("Q1 =", self.Q1)
+        print("Q2 =", self.Q2)
+        print("cR =", self.cR)
+
+    def get_variogram_points(self):
+        """(lags, variogram model evaluated at the lags) -- ok.py:569-587."""
+        return self.lags, core.variogram_value(self.variogram_model, self.variogram_model_parameters, self.lags)
+
+    def switch_verbose(self):
+        self.verbose = not self.verbose
+
+    def switch_plotting(self):
+        self.enable_plotting = not self.enable_plotting
 
     # ---------------------------------------------------------------- execute front / back matter
     _mw_backends = ()  # backends the reference accepts together with n_closest_points
@@ -274,8 +341,7 @@ class OrdinaryKriging(_KrigingBase):
         if coordinates_type not in ("euclidean", "geographic"):
             raise ValueError("Only 'euclidean' and 'geographic' are valid values for coordinates-keyword.")
         self.coordinates_type = coordinates_type
-        if enable_statistics:
-            raise NotImplementedError(_UNSUPPORTED % "enable_statistics (variogram-fit statistics)")
+        self._enable_statistics = bool(enable_statistics)
         self.X_ORIG = np.atleast_1d(np.squeeze(np.array(x, copy=True, dtype=np.float64)))
         self.Y_ORIG = np.atleast_1d(np.squeeze(np.array(y, copy=True, dtype=np.float64)))
         self.Z = np.atleast_1d(np.squeeze(np.array(z, copy=True, dtype=np.float64)))
@@ -294,7 +360,10 @@ class OrdinaryKriging(_KrigingBase):
             self.X_ADJUSTED, self.Y_ADJUSTED = self.X_ORIG, self.Y_ORIG
             self._coords_adj = np.vstack((self.X_ORIG, self.Y_ORIG)).T
         self._set_variogram_parameters(variogram_parameters, nlags, weight)
-        self.delta = self.sigma = self.epsilon = self.Q1 = self.Q2 = self.cR = None
+        if type(self) is OrdinaryKriging and not self._enable_statistics:  # ok.py:360-377: statistics only on request
+            self.delta = self.sigma = self.epsilon = self.Q1 = self.Q2 = self.cR = None
+        elif type(self) is OrdinaryKriging:
+            self._compute_statistics()
 
     def _center(self):
         return [self.XCENTER, self.YCENTER]
@@ -486,7 +555,6 @@ class OrdinaryKriging3D(_KrigingBase):
         self.anisotropy_angle_z = anisotropy_angle_z
         self._adjust_stations()
         self._set_variogram_parameters(variogram_parameters, nlags, weight)
-        self.delta = self.sigma = self.epsilon = self.Q1 = self.Q2 = self.cR = None
 
     def _center(self):
         return [self.XCENTER, self.YCENTER, self.ZCENTER]

@@ -340,3 +340,33 @@ def test_moving_window_matches_reference(name):
     elif name == "mw_ok3d":
         with pytest.raises(ValueError):  # ok3d.py:906-912: only 'loop' takes a moving window
             m.execute("grid", *axes, backend="vectorized", n_closest_points=8)
+
+
+def test_variogram_fit_statistics_match_reference():
+    """core._find_statistics (N-1 growing solves on the CPU) vs the O(N^3) bordered-inverse recursion on the device:
+    delta, sigma, epsilon and Q1/Q2/cR computed by the real reference (tests/golden/stats_find_statistics.npz)."""
+    import pykrige_amd as pa
+
+    g = fx.load("stats_find_statistics")
+    cases = (("exp", "exponential", [1.0, 0.3, 0.1]), ("lin", "linear", [1.3, 0.05]), ("sph", "spherical", [0.85, 0.5, 0.05]))
+    for tag, model, user in cases:  # user list form = full sill for the bounded models
+        ok = pa.OrdinaryKriging(g["x"], g["y"], g["v"], variogram_model=model, variogram_parameters=user, enable_statistics=True)
+        np.testing.assert_allclose(ok.delta, g["delta_" + tag], rtol=0, atol=1e-8)
+        np.testing.assert_allclose(ok.sigma, g["sigma_" + tag], rtol=0, atol=1e-8)
+        np.testing.assert_allclose(ok.get_epsilon_residuals(), g["eps_" + tag], rtol=0, atol=1e-7)
+        np.testing.assert_allclose(ok.get_statistics(), g["q_" + tag], rtol=1e-7)
+    # the 3-D / universal classes expose the same attributes (computed on first use, with the ordinary system)
+    k3 = pa.UniversalKriging3D(g["x3"], g["y3"], g["z3"], g["v3"], variogram_model="gaussian", variogram_parameters=[1.0, 0.5, 0.1],
+                               drift_terms=["regional_linear"])
+    np.testing.assert_allclose(k3.sigma, g["sigma_3d"], rtol=0, atol=1e-8)
+    np.testing.assert_allclose([k3.Q1, k3.Q2, k3.cR], g["q_3d"], rtol=1e-7)
+    geo = pa.OrdinaryKriging(g["lon"], g["lat"], g["vg"], variogram_model="exponential", variogram_parameters=[1.0, 40.0, 0.1],
+                             coordinates_type="geographic", enable_statistics=True)
+    np.testing.assert_allclose(geo.delta, g["delta_geo"], rtol=0, atol=1e-8)
+    np.testing.assert_allclose(geo.sigma, g["sigma_geo"], rtol=0, atol=1e-8)
+    plain = pa.OrdinaryKriging(g["x"], g["y"], g["v"], variogram_model="linear", variogram_parameters=[1.3, 0.05])
+    assert plain.Q1 is None and plain.delta is None  # ok.py:376-377: not computed unless enable_statistics
+    dup = pa.OrdinaryKriging([0.0, 0.0, 1.0, 2.0], [0.0, 0.0, 1.0, 0.5], [1.0, 1.0, 2.0, 3.0], variogram_model="linear",
+                             variogram_parameters=[1.0, 0.0])
+    with pytest.raises(np.linalg.LinAlgError):  # coincident stations: np.linalg.solve in core._krige raises
+        dup._compute_statistics()
