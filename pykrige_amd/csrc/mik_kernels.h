@@ -349,7 +349,9 @@ __device__ __forceinline__ void glds16(const double* g, double* lds_wave_base) {
 
 // NAI = 16-row groups per wave: 4 -> wave tile 64 x 64, 4 waves (256 threads); 2 -> wave tile 32 x 64,
 // 8 waves (512 threads).  The block tile is 128 x 128 either way.
-template <int NAI>
+// ABL (tools/kernel_bench only; 0 in the library): 1 = skip the LDS-DMA, 2 = skip the fragment ds_reads,
+// 4 = skip the per-tile barrier, 8 = DMA always re-reads k-tile 0 (cache-resident source).  Results are garbage; the variants exist to price each component.
+template <int NAI, int ABL = 0>
 __device__ __forceinline__ void gemm_core(const double* __restrict__ Ag, long lda, const double* __restrict__ Bg,
                                           long ldb, int kbeg, int kend, d4 (&acc)[NAI][4], GemmSmem& sm) {
   if (kbeg >= kend) return;  // block-uniform
@@ -359,13 +361,43 @@ __device__ __forceinline__ void gemm_core(const double* __restrict__ Ag, long ld
   constexpr int NPASS = 128 / PROWS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  // staging: thread -> (row lrow + 32p, 16-byte slot tid&7); the SOURCE k-pair is the slot XOR the row's swizzle
+  // staging: thread -> (row lrow + PROWS*p, 16-byte slot tid&7); the SOURCE k-pair is the slot XOR the row's swizzle
   // (A tile: r & 2; B tile: (r>>1) & 7 -- see the fragment reads below).  Both are pass-independent.
+  // Addresses are split into a wave-uniform 64-bit base (Ag + k, advanced with scalar adds) and per-lane 32-bit
+  // byte offsets fixed for the whole K loop, and the LDS destinations are wave-uniform integers: the K loop then
+  // carries no 64-bit vector address arithmetic and no v_readfirstlane per LDS-DMA (they cost ~5 % of the MFMA rate).
   const int lrow = tid >> 3, slot = tid & 7;
-  const double* ap = Ag + (long)lrow * lda + ((slot ^ (lrow & 2)) << 1);
-  const double* bp = Bg + (long)lrow * ldb + ((slot ^ ((lrow >> 1) & 7)) << 1);
-  const long a32 = PROWS * lda, b32 = PROWS * ldb;
-  const int wrow = wave * 8;  // this wave's 8 rows (1 KiB) inside each pass
+  unsigned aoffb[NPASS], boffb[NPASS];
+#pragma unroll
+  for (int p = 0; p < NPASS; ++p) {
+    aoffb[p] = (unsigned)(((long)(lrow + PROWS * p) * lda + ((slot ^ (lrow & 2)) << 1)) * 8);
+    boffb[p] = (unsigned)(((long)(lrow + PROWS * p) * ldb + ((slot ^ ((lrow >> 1) & 7)) << 1)) * 8);
+  }
+  const unsigned ldsA = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)&sm.As[0][wave * 8][0]);
+  const unsigned ldsB = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)&sm.Bs[0][wave * 8][0]);
+  constexpr unsigned LDS_PASS = PROWS * MIK_BK * 8, LDS_BUF = MIK_BM * MIK_BK * 8;
+  // LDS-DMA in the saddr form (wave-uniform 64-bit base in SGPRs + 32-bit lane offset), written as inline asm:
+  // the builtin always materialises a 64-bit per-lane address (2 v_lshl_add_u64 + v_readfirstlane per piece).
+  // M0 (LDS destination) is written in the same statement that uses it; hipcc does not count these loads, so the
+  // loop drains them itself (s_waitcnt vmcnt(0)) before each barrier.
+  auto uniform_ptr = [](const double* q) {  // make the wave-uniformity of a block-uniform pointer provable ("s" operand)
+    const unsigned long long v = (unsigned long long)(uintptr_t)q;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<const double*>((uintptr_t)(((unsigned long long)hi << 32) | lo));
+  };
+  const double* Agu = uniform_ptr(Ag);
+  const double* Bgu = uniform_ptr(Bg);
+  auto stage = [&](int k, int b) {
+    const double* abase = uniform_ptr(Agu + k);  // once per K tile (hipcc sometimes does the k arithmetic on the VALU)
+    const double* bbase = uniform_ptr(Bgu + k);
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+      const unsigned la = ldsA + b * LDS_BUF + p * LDS_PASS, lb = ldsB + b * LDS_BUF + p * LDS_PASS;
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(aoffb[p]), "s"(abase), "s"(la) : "memory");
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(boffb[p]), "s"(bbase), "s"(lb) : "memory");
+    }
+  };
+  auto drain = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
   // Fragment reads are ds_read_b128: lane group kq = lane>>4 owns the k PAIR c = 4m + kq of the 16-wide
   // tile (m = 0, 1), i.e. MFMA step t = 2m + h contracts k = 8m + 2kq + h -- the same bijection of k on
   // both operands.  A: row wm*64 + 4x + i (i = lane&3), identical for the 4 blocks (broadcast);
@@ -380,21 +412,12 @@ __device__ __forceinline__ void gemm_core(const double* __restrict__ Ag, long ld
   }
   // K runs DOWNWARDS (kend-16, kend-32, .. kbeg): in the symmetric contraction every tile then starts at
   // the same k = kend, so the tiles of a supertile stream the same operand panels in near lockstep (L2 reuse).
-#pragma unroll
-  for (int p = 0; p < NPASS; ++p) {
-    glds16(ap + p * a32 + (kend - MIK_BK), &sm.As[0][wrow + PROWS * p][0]);
-    glds16(bp + p * b32 + (kend - MIK_BK), &sm.Bs[0][wrow + PROWS * p][0]);
-  }
+  stage(kend - MIK_BK, 0);
+  drain();
   __syncthreads();
   int buf = 0;
   for (int k = kend - MIK_BK; k >= kbeg; k -= MIK_BK) {
-    if (k > kbeg) {
-#pragma unroll
-      for (int p = 0; p < NPASS; ++p) {
-        glds16(ap + p * a32 + k - MIK_BK, &sm.As[buf ^ 1][wrow + PROWS * p][0]);
-        glds16(bp + p * b32 + k - MIK_BK, &sm.Bs[buf ^ 1][wrow + PROWS * p][0]);
-      }
-    }
+    if (k > kbeg && !(ABL & 1)) stage((ABL & 8) ? 0 : k - MIK_BK, buf ^ 1);
     const double* as = &sm.As[buf][0][0];
     const double* bs = &sm.Bs[buf][0][0];
 #pragma unroll
@@ -403,10 +426,17 @@ __device__ __forceinline__ void gemm_core(const double* __restrict__ Ag, long ld
       // A fragments are replicated over the 4 blocks, B fragments put 4 column groups in the 4 blocks, so
       // MFMA (ra, bi) yields rows 4*ra + (l>>4), columns 16*bi + (l&15) of the wave tile.
       double2 fa[4 * NAI], fb[4];
+      if (ABL & 2) {
 #pragma unroll
-      for (int x = 0; x < 4 * NAI; ++x) fa[x] = *reinterpret_cast<const double2*>(as + aoff[m] + 4 * x * MIK_BK);
+        for (int x = 0; x < 4 * NAI; ++x) fa[x] = make_double2(1.0 + x + k, 2.0 - x);
 #pragma unroll
-      for (int x = 0; x < 4; ++x) fb[x] = *reinterpret_cast<const double2*>(bs + boff[m] + 16 * x * MIK_BK);
+        for (int x = 0; x < 4; ++x) fb[x] = make_double2(0.5 + x, 1.5 * x - k);
+      } else {
+#pragma unroll
+        for (int x = 0; x < 4 * NAI; ++x) fa[x] = *reinterpret_cast<const double2*>(as + aoff[m] + 4 * x * MIK_BK);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) fb[x] = *reinterpret_cast<const double2*>(bs + boff[m] + 16 * x * MIK_BK);
+      }
       // all accumulators once (first k of the pair), then all again: dependent MFMAs are >= 32 issues apart
 #pragma unroll
       for (int ai = 0; ai < NAI; ++ai)
@@ -423,7 +453,8 @@ __device__ __forceinline__ void gemm_core(const double* __restrict__ Ag, long ld
           for (int bi = 0; bi < 4; ++bi)
             acc[ai][bi][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa[4 * ai + r].y, fb[bi].y, acc[ai][bi][r], 0, 0, 0);
     }
-    __syncthreads();  // hipcc drains the outstanding LDS-DMA (vmcnt(0)) before the barrier
+    drain();  // the tile staged at the top of this iteration has had the whole compute phase to land
+    if (!(ABL & 4)) __syncthreads();
     buf ^= 1;
   }
 }
@@ -1333,6 +1364,28 @@ k_stat_dupes(const double* __restrict__ xs, const double* __restrict__ ys, const
     const double dx = x - xs[j], dy = y - ys[j], dz = (NDIM == 3) ? z - zs[j] : 0.0;
     if (sqrt(dx * dx + dy * dy + dz * dz) <= 1e-10) { atomicOr(flag, 1); return; }
   }
+}
+
+// tools/kernel_bench only: the full (non-symmetric) contraction loop with components removed (see gemm_core ABL)
+template <int NAI, int ABL>
+__global__ void __launch_bounds__(64 * 2 * (8 / NAI), 2 * (4 / NAI))
+k_contract_ablate(const double* __restrict__ Ainv, long lda, const double* __restrict__ Bt, long ldb,
+                  double* __restrict__ part, int palloc, int nIblk, int kend) {
+  __shared__ GemmSmem sm;
+  int iblk, tblk;
+  if (!super_tile(nIblk, palloc / MIK_BN, iblk, tblk)) return;
+  d4 acc[NAI][4];
+#pragma unroll
+  for (int x = 0; x < NAI; ++x)
+#pragma unroll
+    for (int y = 0; y < 4; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
+  gemm_core<NAI, ABL>(Ainv + (long)iblk * MIK_BM * lda, lda, Bt + (long)tblk * MIK_BN * ldb, ldb, 0, kend, acc, sm);
+  double s = 0.0;
+#pragma unroll
+  for (int x = 0; x < NAI; ++x)
+#pragma unroll
+    for (int y = 0; y < 4; ++y) s += acc[x][y][0] + acc[x][y][1] + acc[x][y][2] + acc[x][y][3];
+  if (s == 1.2345e-300) part[(long)iblk * palloc + tblk * MIK_BN + threadIdx.x % 128] = s;
 }
 
 }  // namespace mik

@@ -57,6 +57,22 @@ int main(int argc,char**argv){
   { double md=0, mx=0; for(size_t i=0;i<ref.size();++i){ md=fmax(md,fabs(ref[i]-got[i])); mx=fmax(mx,fabs(ref[i])); } printf("   valu vs mfma partials: max|diff| %.3e (max|ref| %.3e)\n",md,mx); }
   ms=timeit([&]{hipLaunchKernelGGL(k_contract_valu<false>,dim3(vgrid),dim3(256),0,0,(const double*)T,(long)Mp,(const double*)Bt,(long)Mp,part,P,nblk,kend);},2);
   printf("k_contract<full> valu : %.3f ms  executed %.2f TF/s\n",ms,fl_full/ms*1e-9);
+  // ablations of the main loop (full form): what each component costs
+#define ABLATE(NAI, ABL, NT, label) ms=timeit([&]{hipLaunchKernelGGL((k_contract_ablate<NAI,ABL>),dim3(grid),dim3(NT),0,0,(const double*)T,(long)Mp,(const double*)Bt,(long)Mp,part,P,nblk,kend);},2); \
+  printf("ablate %-44s: %.3f ms  %.2f TF/s\n",label,ms,fl_full/ms*1e-9);
+  ABLATE(4,0,256,"4-wave, nothing removed");
+  ABLATE(4,1,256,"4-wave, no LDS-DMA");
+  ABLATE(4,2,256,"4-wave, no fragment ds_reads");
+  ABLATE(4,4,256,"4-wave, no barrier");
+  ABLATE(4,3,256,"4-wave, no DMA + no ds_reads");
+  ABLATE(4,7,256,"4-wave, MFMA only");
+  ABLATE(4,8,256,"4-wave, DMA source always k-tile 0 (cached)");
+  ABLATE(2,8,512,"8-wave, DMA source always k-tile 0 (cached)");
+  ABLATE(2,0,512,"8-wave, nothing removed");
+  ABLATE(2,1,512,"8-wave, no LDS-DMA");
+  ABLATE(2,2,512,"8-wave, no fragment ds_reads");
+  ABLATE(2,4,512,"8-wave, no barrier");
+  ABLATE(2,7,512,"8-wave, MFMA only");
   // inverse pieces
   ms=timeit([&]{hipLaunchKernelGGL(k_diag_inv,dim3(1),dim3(1024),0,0,(const double*)T,(long)Mp,0,0,Dinv,DinvT,flag);},10);
   printf("k_diag_inv (1024 thr) back-to-back: %.1f us\n",ms*1e3);
