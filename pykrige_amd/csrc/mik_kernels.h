@@ -351,9 +351,12 @@ __device__ __forceinline__ void glds16(const double* g, double* lds_wave_base) {
 // 8 waves (512 threads).  The block tile is 128 x 128 either way.
 // ABL (tools/kernel_bench only; 0 in the library): 1 = skip the LDS-DMA, 2 = skip the fragment ds_reads,
 // 4 = skip the per-tile barrier, 8 = DMA always re-reads k-tile 0 (cache-resident source).  Results are garbage; the variants exist to price each component.
+// kscale: the accumulators are doubled just before the K tile that starts at kscale is contracted (symmetric
+// form: everything above the diagonal block counts twice); pass a value that is never a tile start to disable.
 template <int NAI, int ABL = 0>
 __device__ __forceinline__ void gemm_core(const double* __restrict__ Ag, long lda, const double* __restrict__ Bg,
-                                          long ldb, int kbeg, int kend, d4 (&acc)[NAI][4], GemmSmem& sm) {
+                                          long ldb, int kbeg, int kend, d4 (&acc)[NAI][4], GemmSmem& sm,
+                                          int kscale = -1) {
   if (kbeg >= kend) return;  // block-uniform
   constexpr int WROWS = 16 * NAI;            // rows of the wave tile
   constexpr int NTHR = 64 * 2 * (128 / WROWS);
@@ -420,6 +423,12 @@ __device__ __forceinline__ void gemm_core(const double* __restrict__ Ag, long ld
     if (k > kbeg && !(ABL & 1)) stage((ABL & 8) ? 0 : k - MIK_BK, buf ^ 1);
     const double* as = &sm.As[buf][0][0];
     const double* bs = &sm.Bs[buf][0][0];
+    if (k == kscale) {
+#pragma unroll
+      for (int x = 0; x < NAI; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) acc[x][y] *= 2.0;
+    }
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
       // v_mfma_f64_4x4x4_4b_f64: A lane (k=l>>4, blk=(l>>2)&3, i=l&3), B lane (k, blk, j=l&3), D lane (i=l>>4, blk, j).
@@ -524,14 +533,10 @@ k_contract(const double* __restrict__ Ainv, long lda, const double* __restrict__
   for (int x = 0; x < NAI; ++x)
 #pragma unroll
     for (int y = 0; y < 4; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
-  if (SYM) {  // result = diag + 2 * offdiag: off-diagonal K blocks first (downwards from kend), then the diagonal block
+  if (SYM) {  // result = diag + 2 * offdiag: one K loop downwards from kend; the off-diagonal part is doubled
+              // when the loop enters the diagonal block (k < i0 + 128), which is contracted last
     const int kd = (i0 + MIK_BM) < kend ? (i0 + MIK_BM) : kend;
-    gemm_core<NAI>(Ag, lda, Bg, ldb, kd, kend, acc, sm);
-#pragma unroll
-    for (int x = 0; x < NAI; ++x)
-#pragma unroll
-      for (int y = 0; y < 4; ++y) acc[x][y] *= 2.0;
-    gemm_core<NAI>(Ag, lda, Bg, ldb, i0, kd, acc, sm);
+    gemm_core<NAI>(Ag, lda, Bg, ldb, i0, kend, acc, sm, kd - MIK_BK);
   } else {
     gemm_core<NAI>(Ag, lda, Bg, ldb, 0, kend, acc, sm);
   }

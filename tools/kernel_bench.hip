@@ -14,7 +14,7 @@ template<class F> float timeit(F f, int reps){
 }
 int main(int argc,char**argv){
   const int Mp = argc>1? atoi(argv[1]) : 5120, P = argc>2? atoi(argv[2]) : 32768;
-  const int nblk = Mp/128, kend = Mp;
+  const int nblk = Mp/128, kend = argc>3? atoi(argv[3]) : Mp;
   double *T,*Bt,*part,*Dinv,*DinvT,*Cold,*Cnew,*Rt; int* flag;
   CK(hipMalloc(&T,sizeof(double)*(size_t)Mp*Mp)); CK(hipMalloc(&Bt,sizeof(double)*(size_t)P*Mp));
   CK(hipMalloc(&part,sizeof(double)*(size_t)P*nblk)); CK(hipMalloc(&Dinv,131072)); CK(hipMalloc(&DinvT,131072));
@@ -32,6 +32,7 @@ int main(int argc,char**argv){
   const long tiles=(long)nblk*(P/128); const unsigned vgrid=(unsigned)(8*((tiles+7)/8));
   const unsigned grid=(unsigned)super_grid(nblk,P/128);
   double kext_sym=0; for(int ib=0;ib<nblk;++ib) kext_sym+= kend-ib*128;
+  if(argc>3){ kext_sym=0; for(int ib=0;ib<nblk;++ib) kext_sym+= (kend-ib*128>0? kend-ib*128:0); }
   const double fl_full=2.0*128*128*(double)kend*nblk*(P/128), fl_sym=2.0*128*128*kext_sym*(P/128);
   // warm the clocks
   for(int w=0;w<2;++w) hipLaunchKernelGGL((k_contract<true,4>),dim3(grid),dim3(256),0,0,(const double*)T,(long)Mp,(const double*)Bt,(long)Mp,part,P,nblk,kend);
