@@ -186,7 +186,24 @@ def main():
             try:
                 uid = [_lib.Handle.comm_unique_id() if rank == 0 else None]
                 dist.broadcast_object_list(uid, src=0)
-                h.comm_init(world, rank, uid[0])
+                # ncclCommInitRank blocks until every rank has joined; run it in a thread so that a wedged
+                # bootstrap degrades to redundant factorisation instead of hanging the benchmark
+                import threading
+
+                box = {}
+
+                def _init():
+                    try:
+                        h.comm_init(world, rank, uid[0])
+                        box["ok"] = True
+                    except Exception as e:  # noqa: BLE001
+                        box["err"] = str(e)[:80]
+
+                th = threading.Thread(target=_init, daemon=True)
+                th.start()
+                th.join(float(os.environ.get("MIK_RCCL_INIT_TIMEOUT", "120")))
+                if not box.get("ok"):
+                    raise RuntimeError(box.get("err", "timed out"))
             except Exception as e:  # RCCL unavailable: every rank factors for itself
                 exchange = "redundant_factor (rccl init failed: %s)" % (str(e)[:80],)
             flags = [None] * world

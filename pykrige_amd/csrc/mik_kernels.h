@@ -396,8 +396,13 @@ __device__ __forceinline__ void gemm_core(const double* __restrict__ Ag, long ld
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
       const unsigned la = ldsA + b * LDS_BUF + p * LDS_PASS, lb = ldsB + b * LDS_BUF + p * LDS_PASS;
-      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(aoffb[p]), "s"(abase), "s"(la) : "memory");
-      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(boffb[p]), "s"(bbase), "s"(lb) : "memory");
+      if (p == 0) {  // the bases come straight from v_readfirstlane: VALU-written SGPR -> VMEM address needs 5 wait states
+        asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(aoffb[p]), "s"(abase), "s"(la) : "memory");
+        asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(boffb[p]), "s"(bbase), "s"(lb) : "memory");
+      } else {
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(aoffb[p]), "s"(abase), "s"(la) : "memory");
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(boffb[p]), "s"(bbase), "s"(lb) : "memory");
+      }
     }
   };
   auto drain = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
