@@ -116,7 +116,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--cpu-sample", type=int, default=8192)
+    ap.add_argument("--cpu-sample", type=int, default=3072)
     ap.add_argument("--symmetric", type=int, default=None)
     ap.add_argument("--chunk", type=int, default=None)
     ap.add_argument("--engine", choices=["mfma", "valu"], default=None)

@@ -419,3 +419,42 @@ def test_one_shot_c_entry_point_and_degenerate_inputs():
     zro, sro = ko.solve_points(ko.KrigingState(ndim=2, coords_orig=np.array([[0.5, 0.5]]), values=np.array([3.0]), model="linear",
                                                params=[1.0, 0.2]), np.array([[0.0, 0.0], [0.5, 0.5]]))
     np.testing.assert_allclose(so, sro, atol=1e-12)
+
+
+@pytest.mark.parametrize("cfg", [3, 4, 5])
+def test_baseline_configs_at_full_station_count(cfg):
+    """BASELINE configs 3-5 with their full station counts (N = 2000 / 4000 / 8000, SURVEY 8(d) seeds and variogram
+    parameters) on a 1536-point sample of their grids, against the oracle; 8 sample points coincide with stations."""
+    import pykrige_amd as pa
+
+    rng = np.random.default_rng(100 + cfg)
+    if cfg == 3:
+        (x, y, zc), v = fx.synth(3, 2000, 3)
+        m = pa.OrdinaryKriging3D(x, y, zc, v, variogram_model="gaussian", variogram_parameters=[1.0, 0.4, 0.02])
+        st = ko.KrigingState(ndim=3, coords_orig=np.stack([x, y, zc], 1), values=v, model="gaussian",
+                             params=ko.internal_parameters("gaussian", [1.0, 0.4, 0.02]), scaling=[1.0, 1.0], angle=[0.0] * 3)
+        pts = rng.random((1536, 3))
+        pts[:8] = np.stack([x[:8], y[:8], zc[:8]], 1)
+        z, ss = m.execute("points", pts[:, 0], pts[:, 1], pts[:, 2], backend="loop")
+    else:
+        n = 4000 if cfg == 4 else 8000
+        (x, y), v = fx.synth(cfg, n, 2)
+        pts = rng.random((1536, 2))
+        pts[:8] = np.stack([x[:8], y[:8]], 1)
+        if cfg == 4:
+            wells = [[0.3137, 0.7219, 1.0], [0.6621, 0.2483, -0.5], [0.8412, 0.8127, 2.0]]
+            m = pa.UniversalKriging(x, y, v, variogram_model="exponential", variogram_parameters=[1.0, 0.3, 0.01],
+                                    drift_terms=["regional_linear", "point_log"], point_drift=wells)
+            st = ko.KrigingState(ndim=2, coords_orig=np.stack([x, y], 1), values=v, model="exponential",
+                                 params=ko.internal_parameters("exponential", [1.0, 0.3, 0.01]), regional_linear=True,
+                                 point_log=np.array(wells))
+        else:
+            m = pa.OrdinaryKriging(x, y, v, variogram_model="spherical", variogram_parameters=[1.0, 0.2, 0.01])
+            st = ko.KrigingState(ndim=2, coords_orig=np.stack([x, y], 1), values=v, model="spherical",
+                                 params=ko.internal_parameters("spherical", [1.0, 0.2, 0.01]))
+        z, ss = m.execute("points", pts[:, 0], pts[:, 1], backend="loop")
+    zr, sr = ko.solve_points(st, pts)
+    np.testing.assert_allclose(z, zr, rtol=0, atol=Z_TOL)
+    np.testing.assert_allclose(ss, sr, rtol=0, atol=SS_TOL)
+    np.testing.assert_allclose(z[:8], v[:8], rtol=0, atol=Z_TOL)
+    assert np.all(np.abs(ss[:8]) <= SS_TOL) and m.last_timing["factor_path"] == 1
