@@ -118,6 +118,11 @@ int  mik_predict_moving_window(mik_handle *h, int n_closest_points);
  * i = 1..n-1 station i is kriged from stations 0..i-1.  k_out / ss_out have n entries (entry 0 unused = 0). */
 int  mik_statistics(mik_handle *h, double *k_out, double *ss_out);
 
+/* Experimental semivariogram of the constructor: replaces pdist + the lag-bin loop of
+ * core._initialize_variogram_model (core.py:432-505).  lags_out / semi_out hold up to nlags entries (empty bins are
+ * dropped); *n_out = number written.  Needs mik_set_problem only. */
+int  mik_experimental_variogram(mik_handle *h, int nlags, double *lags_out, double *semi_out, int32_t *n_out);
+
 /* One-shot convenience: create + set_problem + factor + set_points + predict + get_results + destroy. */
 int  mik_krige_execute(int device, const mik_problem *p, const mik_points *g, double *z_out, double *ss_out);
 

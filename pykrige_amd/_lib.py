@@ -62,6 +62,7 @@ SIGNATURES = {
     "mik_get_results": (C.c_int, [C.c_void_p, _dp, _dp]),
     "mik_predict_moving_window": (C.c_int, [C.c_void_p, C.c_int]),
     "mik_statistics": (C.c_int, [C.c_void_p, _dp, _dp]),
+    "mik_experimental_variogram": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, C.POINTER(C.c_int32)]),
     "mik_krige_execute": (C.c_int, [C.c_int, C.POINTER(MikProblem), C.POINTER(MikPoints), _dp, _dp]),
     "mik_assemble_only": (C.c_int, [C.c_void_p]),
     "mik_get_matrix": (C.c_int, [C.c_void_p, C.c_int, _dp]),
@@ -218,6 +219,13 @@ class Handle:
         ss = np.zeros(n, dtype=np.float64)
         check(self._lib.mik_statistics(self._h, _ptr(k), _ptr(ss)))
         return k, ss
+
+    def experimental_variogram(self, nlags):
+        lags = np.zeros(int(nlags), dtype=np.float64)
+        semi = np.zeros(int(nlags), dtype=np.float64)
+        n = C.c_int32(0)
+        check(self._lib.mik_experimental_variogram(self._h, int(nlags), _ptr(lags), _ptr(semi), C.byref(n)))
+        return lags[:n.value].copy(), semi[:n.value].copy()
 
     def get_results(self):
         z = np.empty(self._npt, dtype=np.float64)

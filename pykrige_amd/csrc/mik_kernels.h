@@ -1398,4 +1398,100 @@ k_contract_ablate(const double* __restrict__ Ainv, long lda, const double* __res
   if (s == 1.2345e-300) part[(long)iblk * palloc + tblk * MIK_BN + threadIdx.x % 128] = s;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Experimental semivariogram of the constructor (core.py:432-505): all station pairs i < j, distance d_ij and
+// g_ij = (z_i - z_j)^2 / 2, equal-width lag bins between min d and max d + 0.001.  Pass 1: min / max of d per block;
+// pass 2: per-block sums of d, g and counts per bin (LDS atomics), reduced on the host.  One 64 x 64 pair tile per block.
+// ------------------------------------------------------------------------------------------------
+template <int NDIM>
+__device__ __forceinline__ double pair_dist(const double* xs, const double* ys, const double* zs, int i, int j) {
+  if (NDIM == 1) {
+    const double la1 = ys[i] * MIK_PI / 180.0, la2 = ys[j] * MIK_PI / 180.0;
+    // core.py:441-451: great_circle_distance(x1, y1, x2, y2) on meshgrids, pairs kept where row > column, i.e.
+    // point 1 = the smaller station index, point 2 = the larger
+    return gc_dist(xs[i], cos(la1), sin(la1), xs[j], cos(la2), sin(la2));
+  }
+  const double dx = xs[i] - xs[j], dy = ys[i] - ys[j];
+  double s2 = dx * dx + dy * dy;
+  if (NDIM == 3) {
+    const double dz = zs[i] - zs[j];
+    s2 += dz * dz;
+  }
+  return sqrt(s2);
+}
+
+template <int NDIM>
+__global__ void __launch_bounds__(256)
+k_vg_minmax(const double* __restrict__ xs, const double* __restrict__ ys, const double* __restrict__ zs, int N,
+            double* __restrict__ out /* 2 per block */) {
+  __shared__ double smin[256], smax[256];
+  double lo = 1e300, hi = -1e300;
+  if (blockIdx.x <= blockIdx.y) {  // tile (rows i of blockIdx.x, columns j of blockIdx.y), pairs i < j
+    const int j = blockIdx.y * 64 + (threadIdx.x & 63);
+    for (int r = threadIdx.x >> 6; r < 64; r += 4) {
+      const int i = blockIdx.x * 64 + r;
+      if (i < j && j < N) {
+        const double d = pair_dist<NDIM>(xs, ys, zs, i, j);
+        lo = d < lo ? d : lo;
+        hi = d > hi ? d : hi;
+      }
+    }
+  }
+  smin[threadIdx.x] = lo;
+  smax[threadIdx.x] = hi;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      smin[threadIdx.x] = fmin(smin[threadIdx.x], smin[threadIdx.x + o]);
+      smax[threadIdx.x] = fmax(smax[threadIdx.x], smax[threadIdx.x + o]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const long b = (long)blockIdx.y * gridDim.x + blockIdx.x;
+    out[2 * b] = smin[0];
+    out[2 * b + 1] = smax[0];
+  }
+}
+
+#define MIK_VG_MAXLAGS 64
+template <int NDIM>
+__global__ void __launch_bounds__(256)
+k_vg_bin(const double* __restrict__ xs, const double* __restrict__ ys, const double* __restrict__ zs,
+         const double* __restrict__ vals, int N, int nlags, const double* __restrict__ edges /* nlags + 1 */,
+         double* __restrict__ out /* per block: nlags x 3 */) {
+  __shared__ double sd[MIK_VG_MAXLAGS], sg[MIK_VG_MAXLAGS], sc[MIK_VG_MAXLAGS], se[MIK_VG_MAXLAGS + 1];
+  if (threadIdx.x < nlags) sd[threadIdx.x] = sg[threadIdx.x] = sc[threadIdx.x] = 0.0;
+  if (threadIdx.x <= nlags) se[threadIdx.x] = edges[threadIdx.x];
+  __syncthreads();
+  if (blockIdx.x <= blockIdx.y) {
+    const int j = blockIdx.y * 64 + (threadIdx.x & 63);
+    const double inv = (se[1] > se[0]) ? 1.0 / (se[1] - se[0]) : 0.0;
+    for (int r = threadIdx.x >> 6; r < 64; r += 4) {
+      const int i = blockIdx.x * 64 + r;
+      if (i < j && j < N) {
+        const double d = pair_dist<NDIM>(xs, ys, zs, i, j);
+        const double dz = vals[i] - vals[j];
+        int b = (int)((d - se[0]) * inv);
+        b = b < 0 ? 0 : (b > nlags - 1 ? nlags - 1 : b);
+        while (b > 0 && d < se[b]) --b;                  // the reference's own tests: bins[n] <= d < bins[n+1]
+        while (b < nlags - 1 && d >= se[b + 1]) ++b;
+        if (d >= se[b] && d < se[b + 1]) {
+          atomicAdd(&sd[b], d);
+          atomicAdd(&sg[b], 0.5 * dz * dz);
+          atomicAdd(&sc[b], 1.0);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < nlags) {
+    const long blk = (long)blockIdx.y * gridDim.x + blockIdx.x;
+    double* o = out + blk * 3 * nlags;
+    o[threadIdx.x] = sd[threadIdx.x];
+    o[nlags + threadIdx.x] = sg[threadIdx.x];
+    o[2 * nlags + threadIdx.x] = sc[threadIdx.x];
+  }
+}
+
 }  // namespace mik

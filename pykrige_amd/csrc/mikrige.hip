@@ -864,6 +864,67 @@ int mik_statistics(mik_handle* h, double* k_out, double* ss_out) {
   return MIK_OK;
 }
 
+int mik_experimental_variogram(mik_handle* h, int nlags, double* lags_out, double* semi_out, int32_t* n_out) {
+  if (!h || !lags_out || !semi_out || !n_out) return fail(MIK_EINVAL, "mik_experimental_variogram: NULL argument");
+  if (!h->have_problem) return fail(MIK_ESTATE, "mik_experimental_variogram: set the problem first");
+  if (nlags < 1 || nlags > MIK_VG_MAXLAGS) return fail(MIK_EINVAL, "nlags must be in 1..64");
+  if (h->N < 2) return fail(MIK_EINVAL, "need at least two stations");
+  HIPC(hipSetDevice(h->device));
+  const int N = h->N, nt = (N + 63) / 64;
+  const long nblocks = (long)nt * nt;
+  DevBuf mm, edges, part;
+  MIKC(mm.ensure(sizeof(double) * 2 * nblocks));
+  MIKC(edges.ensure(sizeof(double) * (nlags + 1)));
+  MIKC(part.ensure(sizeof(double) * 3 * nlags * nblocks));
+  const double *xs = h->xs.as<double>(), *ys = h->ys.as<double>(), *zs = h->zs.as<double>(), *vv = h->vals.as<double>();
+  const int kd = h->geo ? 1 : h->ndim;
+  dim3 grid(nt, nt);
+  if (kd == 1) hipLaunchKernelGGL(k_vg_minmax<1>, grid, dim3(256), 0, h->stream, xs, ys, zs, N, mm.as<double>());
+  else if (kd == 3) hipLaunchKernelGGL(k_vg_minmax<3>, grid, dim3(256), 0, h->stream, xs, ys, zs, N, mm.as<double>());
+  else hipLaunchKernelGGL(k_vg_minmax<2>, grid, dim3(256), 0, h->stream, xs, ys, zs, N, mm.as<double>());
+  std::vector<double> hmm(2 * nblocks);
+  HIPC(hipMemcpyAsync(hmm.data(), mm.p, sizeof(double) * 2 * nblocks, hipMemcpyDeviceToHost, h->stream));
+  HIPC(hipStreamSynchronize(h->stream));
+  double dmin = 1e300, dmax = -1e300;
+  for (long b = 0; b < nblocks; ++b) {
+    dmin = std::min(dmin, hmm[2 * b]);
+    dmax = std::max(dmax, hmm[2 * b + 1]);
+  }
+  // core.py:466-471: bins = [dmin + n*dd for n in range(nlags)] + [dmax + 0.001]
+  const double dd = (dmax - dmin) / nlags;
+  std::vector<double> he(nlags + 1);
+  for (int n = 0; n < nlags; ++n) he[n] = dmin + n * dd;
+  he[nlags] = dmax + 0.001;
+  HIPC(hipMemcpyAsync(edges.p, he.data(), sizeof(double) * (nlags + 1), hipMemcpyHostToDevice, h->stream));
+  if (kd == 1) hipLaunchKernelGGL(k_vg_bin<1>, grid, dim3(256), 0, h->stream, xs, ys, zs, vv, N, nlags, (const double*)edges.as<double>(), part.as<double>());
+  else if (kd == 3) hipLaunchKernelGGL(k_vg_bin<3>, grid, dim3(256), 0, h->stream, xs, ys, zs, vv, N, nlags, (const double*)edges.as<double>(), part.as<double>());
+  else hipLaunchKernelGGL(k_vg_bin<2>, grid, dim3(256), 0, h->stream, xs, ys, zs, vv, N, nlags, (const double*)edges.as<double>(), part.as<double>());
+  HIPC(hipGetLastError());
+  std::vector<double> hp((size_t)3 * nlags * nblocks);
+  HIPC(hipMemcpyAsync(hp.data(), part.p, sizeof(double) * hp.size(), hipMemcpyDeviceToHost, h->stream));
+  HIPC(hipStreamSynchronize(h->stream));
+  mm.release();
+  edges.release();
+  part.release();
+  int nv = 0;
+  for (int n = 0; n < nlags; ++n) {
+    double sdv = 0.0, sgv = 0.0, scv = 0.0;
+    for (long b = 0; b < nblocks; ++b) {
+      const double* o = hp.data() + (size_t)b * 3 * nlags;
+      sdv += o[n];
+      sgv += o[nlags + n];
+      scv += o[2 * nlags + n];
+    }
+    if (scv > 0.0) {  // empty bins are dropped (core.py:498-499)
+      lags_out[nv] = sdv / scv;
+      semi_out[nv] = sgv / scv;
+      ++nv;
+    }
+  }
+  *n_out = nv;
+  return MIK_OK;
+}
+
 int mik_get_results(mik_handle* h, double* z_out, double* ss_out) {
   if (!h || !z_out || !ss_out) return fail(MIK_EINVAL, "mik_get_results: NULL argument");
   if (!h->have_results) return fail(MIK_ESTATE, "mik_get_results: predict first");

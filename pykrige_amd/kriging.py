@@ -13,6 +13,7 @@ and all run the same device path -- they keep only their return-type convention 
 MaskedArrays in every style, the others plain ndarrays unless style='masked').  'hip' is an explicit
 alias with the 'loop'/'C' convention.  There is no CPU path in this package.
 """
+import os as _os
 import warnings
 
 import numpy as np
@@ -65,7 +66,7 @@ class _KrigingBase:
 
             self.lags, self.semivariance, plist = variogram_fit.fit(
                 self._coords_adj, self._values(), self.variogram_model, nlags, weight,
-                getattr(self, "coordinates_type", "euclidean"))
+                getattr(self, "coordinates_type", "euclidean"), binned=self._device_variogram(nlags))
         else:  # the reference bins the experimental variogram even when parameters are given; here on first use
             self.__dict__.pop("lags", None)
             self.__dict__.pop("semivariance", None)
@@ -77,6 +78,24 @@ class _KrigingBase:
         if self.verbose:
             print("Using '%s' Variogram Model" % self.variogram_model)
             print("Parameters:", self.variogram_model_parameters, "\n")
+
+    def _device_variogram(self, nlags):
+        """Experimental semivariogram on the GPU (mik_experimental_variogram) when one is visible and the O(N^2) pair
+        reduction is worth a launch; None -> the caller bins on the host with SciPy (same numbers to 1e-12).  This is
+        constructor-time work, outside the execute() path, so a host route is legitimate here."""
+        if self._values().size < int(_os.environ.get("MIK_DEVICE_VARIOGRAM_MIN_N", "512")) or nlags > 64:
+            return None
+        try:
+            if _lib.load().mik_device_count() < 1:
+                return None
+        except ImportError:
+            return None
+        h = self._get_handle()
+        ca = self._coords_adj
+        h.set_problem(ndim=self._ndim, xs=ca[:, 0], ys=ca[:, 1], zs=ca[:, 2] if self._ndim == 3 else None,
+                      values=self._values(), model_id=0, params=[1.0, 0.0],
+                      geographic=getattr(self, "coordinates_type", "euclidean") == "geographic")
+        return h.experimental_variogram(nlags)
 
     def update_variogram_model(self, variogram_model, variogram_parameters=None, variogram_function=None, nlags=6,
                                weight=False, **anisotropy):
@@ -190,8 +209,10 @@ class _KrigingBase:
         if name in ("lags", "semivariance") and "_coords_adj" in self.__dict__:
             from . import variogram_fit
 
-            self.lags, self.semivariance = variogram_fit.experimental_variogram(
-                self._coords_adj, self._values(), self.__dict__.get("_nlags", 6), getattr(self, "coordinates_type", "euclidean"))
+            nl = self.__dict__.get("_nlags", 6)
+            binned = self._device_variogram(nl)
+            self.lags, self.semivariance = binned if binned is not None else variogram_fit.experimental_variogram(
+                self._coords_adj, self._values(), nl, getattr(self, "coordinates_type", "euclidean"))
             return self.__dict__[name]
         raise AttributeError(name)
 

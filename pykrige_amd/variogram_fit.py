@@ -49,8 +49,9 @@ def _residuals(params, lags, semis, model, weight):
     return r
 
 
-def fit(coords, values, model, nlags=6, weight=False, coordinates_type="euclidean"):
-    lags, semis = experimental_variogram(coords, values, nlags, coordinates_type)
+def fit(coords, values, model, nlags=6, weight=False, coordinates_type="euclidean", binned=None):
+    """binned = (lags, semivariance) already computed (on the device); None -> bin here on the host."""
+    lags, semis = binned if binned is not None else experimental_variogram(coords, values, nlags, coordinates_type)
     smax, smin, lmax, lmin = np.amax(semis), np.amin(semis), np.amax(lags), np.amin(lags)
     if model == "linear":
         x0 = [(smax - smin) / (lmax - lmin), smin]

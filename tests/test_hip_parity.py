@@ -458,3 +458,37 @@ def test_baseline_configs_at_full_station_count(cfg):
     np.testing.assert_allclose(ss, sr, rtol=0, atol=SS_TOL)
     np.testing.assert_allclose(z[:8], v[:8], rtol=0, atol=Z_TOL)
     assert np.all(np.abs(ss[:8]) <= SS_TOL) and m.last_timing["factor_path"] == 1
+
+
+def test_device_experimental_variogram_matches_reference_binning():
+    """mik_experimental_variogram (pair distances + lag bins on the GPU) vs lags / semivariances the real reference
+    computed (fit_variograms.npz, geo_ok2d.npz), and the fit that follows from them."""
+    import pykrige_amd as pa
+    from pykrige_amd import core
+
+    lib = _lib()
+    g = fx.load("fit_variograms")
+    xy = core.adjust_for_anisotropy(np.stack([g["x"], g["y"]], 1), [(g["x"].max() + g["x"].min()) / 2, (g["y"].max() + g["y"].min()) / 2],
+                                    [2.0], [30.0])
+    h = lib.Handle(0)
+    h.set_problem(ndim=2, xs=xy[:, 0], ys=xy[:, 1], zs=None, values=g["v"], model_id=0, params=[1.0, 0.0])
+    lags, semi = h.experimental_variogram(8)
+    np.testing.assert_allclose(lags, g["lags_linear_0"], rtol=1e-12)
+    np.testing.assert_allclose(semi, g["semi_linear_0"], rtol=1e-12)
+    gg = fx.load("geo_ok2d")
+    h.set_problem(ndim=2, xs=gg["x"], ys=gg["y"], zs=None, values=gg["v"], model_id=0, params=[1.0, 0.0], geographic=True)
+    lags, semi = h.experimental_variogram(7)
+    np.testing.assert_allclose(lags, gg["fit_lags"], rtol=1e-11)
+    np.testing.assert_allclose(semi, gg["fit_semi"], rtol=1e-11)
+    import os
+
+    os.environ["MIK_DEVICE_VARIOGRAM_MIN_N"] = "100"  # route the constructor's binning through the device
+    try:
+        ok = pa.OrdinaryKriging(g["x"], g["y"], g["v"], variogram_model="spherical", nlags=8, anisotropy_scaling=2.0,
+                                anisotropy_angle=30.0)
+        np.testing.assert_allclose(ok.variogram_model_parameters, g["par_spherical_0"], rtol=1e-6, atol=1e-9)
+        k3 = pa.OrdinaryKriging3D(g["x3"], g["y3"], g["z3"], g["v3"], variogram_model="spherical", nlags=6)
+        np.testing.assert_allclose(k3.variogram_model_parameters, g["par_3d"], rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(k3.lags, g["lags_3d"], rtol=1e-12)
+    finally:
+        del os.environ["MIK_DEVICE_VARIOGRAM_MIN_N"]
