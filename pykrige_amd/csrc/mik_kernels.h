@@ -1,9 +1,15 @@
 // mik_kernels.h -- gfx950 (CDNA4) device code of the kriging execute() path.  fp64 throughout.
 //
-//   K1  k_assemble   kriging matrix A (or its SPD-shifted form) from station coordinates
-//   K2  k_diag_inv + k_gemm_nt<PANEL/UPDATE>   block Gauss-Jordan ("sweep") inverse, MFMA f64
-//   K3a k_rhs        right-hand sides b_g for a chunk of points (+ z_g = c.b_g), written point-major
-//   K3b k_gemm_nt<PREDICT>   sigma^2_g = -b_g^T A_inv b_g as a dense contraction on v_mfma_f64_16x16x4_f64
+//   K1  k_assemble            kriging matrix A (or its SPD-shifted form) from station coordinates
+//   K2  k_diag_inv, k_panel, k_update (+ k_piv_* for the pivoted path)   block Gauss-Jordan inverse, in place
+//   K3a k_rhs                 right-hand sides b_g for a chunk of points (+ z_g = c.b_g), written point-major
+//   K3b k_contract            sigma^2_g = -b_g^T A_inv b_g as a dense contraction on v_mfma_f64_4x4x4_4b_f64
+//       (k_contract_valu: the same contraction on v_fma_f64, kept as an independent second engine)
+//   gemm_core                 the shared MFMA tile loop: LDS-DMA staging, XOR-swizzled LDS, ds_read_b128 fragments
+//   k_mw_knn, k_mw_solve      moving-window kriging (n_closest_points)
+//   k_stat_*                  variogram-fit statistics (bordered-inverse recursion)
+//   k_vg_minmax, k_vg_bin     experimental semivariogram of the constructor
+//   NDIM template value 1 = geographic lon/lat (great-circle distance), 2 / 3 = Euclidean
 //
 // Reference arithmetic restated (paths under /root/reference/src/pykrige): variogram_models.py:25-81,
 // ok.py:626-683, uk.py:861-1009, ok3d.py:603-657, uk3d.py:688-811, lib/cok.pyx:56-94.
@@ -342,10 +348,6 @@ struct GemmSmem {
 
 typedef __attribute__((address_space(1))) const void* mik_gptr_t;
 typedef __attribute__((address_space(3))) void* mik_lptr_t;
-
-__device__ __forceinline__ void glds16(const double* g, double* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((mik_gptr_t)g, (mik_lptr_t)lds_wave_base, 16, 0, 0);
-}
 
 // NAI = 16-row groups per wave: 4 -> wave tile 64 x 64, 4 waves (256 threads); 2 -> wave tile 32 x 64,
 // 8 waves (512 threads).  The block tile is 128 x 128 either way.
