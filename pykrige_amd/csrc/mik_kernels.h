@@ -344,6 +344,7 @@ __global__ void __launch_bounds__(256) k_rhs(RhsArgs a) {
 struct GemmSmem {
   double As[2][MIK_BM][MIK_BK];
   double Bs[2][MIK_BN][MIK_BK];
+  long next;  // persistent kernels: the queue position broadcast to the block (kept inside the one LDS object)
 };
 
 typedef __attribute__((address_space(1))) const void* mik_gptr_t;
@@ -498,6 +499,18 @@ __host__ __device__ inline long super_tiles_total(int nIblk, int nTblk) {
 __host__ __device__ inline long super_grid(int nIblk, int nTblk) {  // blocks to launch
   return 8 * ((((super_tiles_total(nIblk, nTblk) / 64) + 7) / 8) * 64);
 }
+// queue form: position `seq` of XCD `xcd`'s tile sequence; returns 0 = tile, 1 = padding slot, 2 = sequence exhausted
+__device__ __forceinline__ int super_tile_at(int nIblk, int nTblk, int xcd, long seq, int& iblk, int& tblk) {
+  const long nsuper = super_tiles_total(nIblk, nTblk) / 64;
+  const long s = (seq >> 6) * 8 + xcd;
+  if (s >= nsuper) return 2;
+  const int r = (int)(seq & 63);
+  const int nTg = (nTblk + MIK_ST - 1) / MIK_ST;
+  iblk = (int)(s / nTg) * MIK_SI + (r % MIK_SI);
+  tblk = (int)(s % nTg) * MIK_ST + (r / MIK_SI);
+  return (iblk < nIblk && tblk < nTblk) ? 0 : 1;
+}
+
 __device__ __forceinline__ bool super_tile(int nIblk, int nTblk, int& iblk, int& tblk) {
   const long nsuper = super_tiles_total(nIblk, nTblk) / 64;
   // block b runs on XCD b % 8; its position in that XCD's dispatch sequence is b / 8.  64 consecutive
@@ -522,19 +535,39 @@ __device__ __forceinline__ bool super_tile(int nIblk, int nTblk, int& iblk, int&
 // Tile order: tblk slow, iblk fast -> consecutive tiles share the B panel; in SYM mode iblk ascending
 // is also longest-first.
 // ------------------------------------------------------------------------------------------------
-template <bool SYM, int NAI>
+// PERSISTENT: the launch is 2 blocks per CU; each block pops tiles from the tile sequence of the XCD it runs on
+// (one relaxed device-scope atomicAdd per tile, the XCD id read from HW_REG_XCC_ID) until that sequence is
+// exhausted.  With one block per tile the in-order workgroup dispatcher stalls behind whichever XCD is still
+// busy once tile lengths differ (symmetric form: 1..nIblk K blocks): measured 8 % of the MFMA rate.
+// PERSIST = false is the one-block-per-tile form (grid = super_grid(), queue unused), kept for A/B measurements.
+template <bool SYM, int NAI, bool PERSIST = true>
 __global__ void __launch_bounds__(64 * 2 * (8 / NAI), 2 * (4 / NAI))
 k_contract(const double* __restrict__ Ainv, long lda, const double* __restrict__ Bt, long ldb,
-           double* __restrict__ part, int palloc, int nIblk, int kend) {
+           double* __restrict__ part, int palloc, int nIblk, int kend, unsigned long long* __restrict__ queue) {
   constexpr int WROWS = 16 * NAI, NWM = 128 / WROWS;
   __shared__ GemmSmem sm;
+  unsigned xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  const int xcd = (int)(xcc & 7);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1, lq = lane >> 4, lc = lane & 15;
+  for (;;) {
   int iblk, tblk;
-  if (!super_tile(nIblk, palloc / MIK_BN, iblk, tblk)) return;
+  if (PERSIST) {
+    if (threadIdx.x == 0)
+      sm.next = (long)__hip_atomic_fetch_add(&queue[xcd], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const long seq = sm.next;
+    const int kind = super_tile_at(nIblk, palloc / MIK_BN, xcd, seq, iblk, tblk);
+    __syncthreads();  // everyone has read sm.next (and the previous tile's `red`) before anything is overwritten
+    if (kind == 2) return;
+    if (kind == 1) continue;
+  } else if (!super_tile(nIblk, palloc / MIK_BN, iblk, tblk)) {
+    return;
+  }
   const int i0 = iblk * MIK_BM, t0 = tblk * MIK_BN;
   const double* Ag = Ainv + (long)i0 * lda;
   const double* Bg = Bt + (long)t0 * ldb;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = wave >> 1, wn = wave & 1, lq = lane >> 4, lc = lane & 15;
   d4 acc[NAI][4];
 #pragma unroll
   for (int x = 0; x < NAI; ++x)
@@ -590,6 +623,8 @@ k_contract(const double* __restrict__ Ainv, long lda, const double* __restrict__
     for (int w = 0; w < NWM; ++w) v += red[w * 128 + threadIdx.x];
     part[(long)iblk * palloc + t0 + threadIdx.x] = v;
   }
+  if (!PERSIST) return;
+  }  // for (;;): next tile of this XCD's sequence
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1391,7 +1426,9 @@ k_contract_ablate(const double* __restrict__ Ainv, long lda, const double* __res
   for (int x = 0; x < NAI; ++x)
 #pragma unroll
     for (int y = 0; y < 4; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
-  gemm_core<NAI, ABL>(Ainv + (long)iblk * MIK_BM * lda, lda, Bt + (long)tblk * MIK_BN * ldb, ldb, 0, kend, acc, sm);
+  // ABL & 16: ragged K range as in the symmetric form (k >= i0), without the doubling step
+  gemm_core<NAI, (ABL & 15)>(Ainv + (long)iblk * MIK_BM * lda, lda, Bt + (long)tblk * MIK_BN * ldb, ldb,
+                             (ABL & 16) ? iblk * MIK_BM : 0, kend, acc, sm);
   double s = 0.0;
 #pragma unroll
   for (int x = 0; x < NAI; ++x)

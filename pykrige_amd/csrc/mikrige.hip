@@ -119,7 +119,8 @@ struct mik_handle {
   std::vector<long> scatter;  // empty = identity
   DevBuf px, py, pz, extra_rows, z, ss;
   // work
-  DevBuf Bt, part, mw_idx, mw_dist, stat_S, stat_x, stat_out;
+  DevBuf Bt, part, mw_idx, mw_dist, stat_S, stat_x, stat_out, queue;
+  int n_cu = 256;
   int t_state = 0;  // what T holds: 0 nothing, 1 the kriging matrix A (shift 0), 2 its inverse
   // options
   int opt_waves = 8;  // waves per contraction block: 4 (wave tile 64x64) or 8 (32x64)
@@ -207,6 +208,10 @@ int mik_create(int device, mik_handle** out) {
   mik_handle* h = new mik_handle();
   h->device = device;
   HIPC(hipStreamCreate(&h->stream));
+  {
+    int ncu = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) h->n_cu = ncu;
+  }
   const char* env = getenv("MIK_FACTOR");
   if (env) h->opt_factor = !strcmp(env, "sweep") ? 1 : (!strcmp(env, "lu") || !strcmp(env, "pivoted")) ? 2 : 0;
   env = getenv("MIK_SYMMETRIC");
@@ -227,7 +232,7 @@ void mik_destroy(mik_handle* h) {
   if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
   DevBuf* bufs[] = {&h->xs, &h->ys, &h->zs, &h->vals, &h->wells, &h->extra_cols, &h->T, &h->cvec, &h->Cold, &h->Cnew,
                     &h->Rt, &h->TKt, &h->Dinv, &h->DinvT, &h->P0, &h->P1, &h->cand0, &h->cand1, &h->pivall, &h->flag,
-                    &h->px, &h->py, &h->pz, &h->extra_rows, &h->z, &h->ss, &h->Bt, &h->part, &h->mw_idx, &h->mw_dist, &h->stat_S, &h->stat_x, &h->stat_out};
+                    &h->px, &h->py, &h->pz, &h->extra_rows, &h->z, &h->ss, &h->Bt, &h->part, &h->mw_idx, &h->mw_dist, &h->stat_S, &h->stat_x, &h->stat_out, &h->queue};
   for (DevBuf* b : bufs) b->release();
   for (hipEvent_t e : h->evpool) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -656,12 +661,17 @@ int mik_predict(mik_handle* h) {
         if (h->opt_sym) hipLaunchKernelGGL(k_contract_valu<true>, dim3(grid), dim3(256), 0, h->stream, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend);
         else hipLaunchKernelGGL(k_contract_valu<false>, dim3(grid), dim3(256), 0, h->stream, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend);
       } else {
+        // persistent launch: 2 blocks per CU pop tiles from per-XCD sequences (8 counters, zeroed per launch)
+        MIKC(h->queue.ensure(8 * sizeof(unsigned long long)));
+        HIPC(hipMemsetAsync(h->queue.p, 0, 8 * sizeof(unsigned long long), h->stream));
+        unsigned long long* qp = h->queue.as<unsigned long long>();
+        const unsigned pgrid = (unsigned)std::min<long>(2L * h->n_cu, (long)sgrid);
         if (h->opt_waves == 8) {
-          if (h->opt_sym) hipLaunchKernelGGL((k_contract<true, 2>), dim3(sgrid), dim3(512), 0, h->stream, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend);
-          else hipLaunchKernelGGL((k_contract<false, 2>), dim3(sgrid), dim3(512), 0, h->stream, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend);
+          if (h->opt_sym) hipLaunchKernelGGL((k_contract<true, 2>), dim3(pgrid), dim3(512), 0, h->stream, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend, qp);
+          else hipLaunchKernelGGL((k_contract<false, 2>), dim3(pgrid), dim3(512), 0, h->stream, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend, qp);
         } else {
-          if (h->opt_sym) hipLaunchKernelGGL((k_contract<true, 4>), dim3(sgrid), dim3(256), 0, h->stream, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend);
-          else hipLaunchKernelGGL((k_contract<false, 4>), dim3(sgrid), dim3(256), 0, h->stream, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend);
+          if (h->opt_sym) hipLaunchKernelGGL((k_contract<true, 4>), dim3(pgrid), dim3(256), 0, h->stream, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend, qp);
+          else hipLaunchKernelGGL((k_contract<false, 4>), dim3(pgrid), dim3(256), 0, h->stream, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend, qp);
         }
       }
     }

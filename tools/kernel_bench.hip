@@ -15,7 +15,8 @@ template<class F> float timeit(F f, int reps){
 int main(int argc,char**argv){
   const int Mp = argc>1? atoi(argv[1]) : 5120, P = argc>2? atoi(argv[2]) : 32768;
   const int nblk = Mp/128, kend = argc>3? atoi(argv[3]) : Mp;
-  double *T,*Bt,*part,*Dinv,*DinvT,*Cold,*Cnew,*Rt; int* flag;
+  double *T,*Bt,*part,*Dinv,*DinvT,*Cold,*Cnew,*Rt; int* flag; unsigned long long* queue; CK(hipMalloc(&queue,64));
+  const unsigned pgrid = 512;
   CK(hipMalloc(&T,sizeof(double)*(size_t)Mp*Mp)); CK(hipMalloc(&Bt,sizeof(double)*(size_t)P*Mp));
   CK(hipMalloc(&part,sizeof(double)*(size_t)P*nblk)); CK(hipMalloc(&Dinv,131072)); CK(hipMalloc(&DinvT,131072));
   CK(hipMalloc(&Cold,sizeof(double)*(size_t)Mp*128)); CK(hipMalloc(&Cnew,sizeof(double)*(size_t)Mp*128)); CK(hipMalloc(&Rt,sizeof(double)*(size_t)Mp*128));
@@ -35,22 +36,32 @@ int main(int argc,char**argv){
   if(argc>3){ kext_sym=0; for(int ib=0;ib<nblk;++ib) kext_sym+= (kend-ib*128>0? kend-ib*128:0); }
   const double fl_full=2.0*128*128*(double)kend*nblk*(P/128), fl_sym=2.0*128*128*kext_sym*(P/128);
   // warm the clocks
-  for(int w=0;w<2;++w) hipLaunchKernelGGL((k_contract<true,4>),dim3(grid),dim3(256),0,0,(const double*)T,(long)Mp,(const double*)Bt,(long)Mp,part,P,nblk,kend);
+  for(int w=0;w<2;++w) hipMemsetAsync(queue,0,64,0); hipLaunchKernelGGL((k_contract<true,4>),dim3(pgrid),dim3(256),0,0,(const double*)T,(long)Mp,(const double*)Bt,(long)Mp,part,P,nblk,kend,queue);
   hipDeviceSynchronize();
   float ms;
-  ms=timeit([&]{hipLaunchKernelGGL((k_contract<true,4>),dim3(grid),dim3(256),0,0,(const double*)T,(long)Mp,(const double*)Bt,(long)Mp,part,P,nblk,kend);},3);
+  ms=timeit([&]{hipMemsetAsync(queue,0,64,0); hipLaunchKernelGGL((k_contract<true,4>),dim3(pgrid),dim3(256),0,0,(const double*)T,(long)Mp,(const double*)Bt,(long)Mp,part,P,nblk,kend,queue);},3);
   printf("k_contract<sym>  mfma : %.3f ms  executed %.2f TF/s  effective(2M^2) %.2f TF/s\n",ms,fl_sym/ms*1e-9,fl_full/ms*1e-9);
+  for(int rep=0;rep<2;++rep){
+    ms=timeit([&]{hipLaunchKernelGGL((k_contract<true,2,false>),dim3(grid),dim3(512),0,0,(const double*)T,(long)Mp,(const double*)Bt,(long)Mp,part,P,nblk,kend,queue);},3);
+    printf("A/B sym 8-wave one block per tile : %.3f ms  executed %.2f TF/s\n",ms,fl_sym/ms*1e-9);
+    ms=timeit([&]{hipMemsetAsync(queue,0,64,0); hipLaunchKernelGGL((k_contract<true,2,true>),dim3(pgrid),dim3(512),0,0,(const double*)T,(long)Mp,(const double*)Bt,(long)Mp,part,P,nblk,kend,queue);},3);
+    printf("A/B sym 8-wave persistent (512 blks): %.3f ms  executed %.2f TF/s\n",ms,fl_sym/ms*1e-9);
+    ms=timeit([&]{hipLaunchKernelGGL((k_contract<false,2,false>),dim3(grid),dim3(512),0,0,(const double*)T,(long)Mp,(const double*)Bt,(long)Mp,part,P,nblk,kend,queue);},2);
+    printf("A/B full 8-wave one block per tile: %.3f ms  executed %.2f TF/s\n",ms,fl_full/ms*1e-9);
+    ms=timeit([&]{hipMemsetAsync(queue,0,64,0); hipLaunchKernelGGL((k_contract<false,2,true>),dim3(pgrid),dim3(512),0,0,(const double*)T,(long)Mp,(const double*)Bt,(long)Mp,part,P,nblk,kend,queue);},2);
+    printf("A/B full 8-wave persistent         : %.3f ms  executed %.2f TF/s\n",ms,fl_full/ms*1e-9);
+  }
   std::vector<double> ref((size_t)P*nblk), got((size_t)P*nblk);
   CK(hipMemcpy(ref.data(),part,ref.size()*8,hipMemcpyDeviceToHost));
-  ms=timeit([&]{hipLaunchKernelGGL((k_contract<false,4>),dim3(grid),dim3(256),0,0,(const double*)T,(long)Mp,(const double*)Bt,(long)Mp,part,P,nblk,kend);},2);
+  ms=timeit([&]{hipMemsetAsync(queue,0,64,0); hipLaunchKernelGGL((k_contract<false,4>),dim3(pgrid),dim3(256),0,0,(const double*)T,(long)Mp,(const double*)Bt,(long)Mp,part,P,nblk,kend,queue);},2);
   printf("k_contract<full> mfma : %.3f ms  executed %.2f TF/s\n",ms,fl_full/ms*1e-9);
-  ms=timeit([&]{hipLaunchKernelGGL((k_contract<true,2>),dim3(grid),dim3(512),0,0,(const double*)T,(long)Mp,(const double*)Bt,(long)Mp,part,P,nblk,kend);},3);
+  ms=timeit([&]{hipMemsetAsync(queue,0,64,0); hipLaunchKernelGGL((k_contract<true,2>),dim3(pgrid),dim3(512),0,0,(const double*)T,(long)Mp,(const double*)Bt,(long)Mp,part,P,nblk,kend,queue);},3);
   printf("k_contract<sym>  mfma 8 waves/block (wave tile 32x64): %.3f ms  executed %.2f TF/s  effective %.2f TF/s\n",ms,fl_sym/ms*1e-9,fl_full/ms*1e-9);
   CK(hipMemcpy(got.data(),part,got.size()*8,hipMemcpyDeviceToHost));
   { double md=0; for(size_t i=0;i<ref.size();++i) md=fmax(md,fabs(ref[i]-got[i])); printf("   8-wave vs 4-wave partials: max|diff| %.3e\n",md); }
-  ms=timeit([&]{hipLaunchKernelGGL((k_contract<false,2>),dim3(grid),dim3(512),0,0,(const double*)T,(long)Mp,(const double*)Bt,(long)Mp,part,P,nblk,kend);},2);
+  ms=timeit([&]{hipMemsetAsync(queue,0,64,0); hipLaunchKernelGGL((k_contract<false,2>),dim3(pgrid),dim3(512),0,0,(const double*)T,(long)Mp,(const double*)Bt,(long)Mp,part,P,nblk,kend,queue);},2);
   printf("k_contract<full> mfma 8 waves/block: %.3f ms  executed %.2f TF/s\n",ms,fl_full/ms*1e-9);
-  ms=timeit([&]{hipLaunchKernelGGL((k_contract<false,4>),dim3(grid),dim3(256),40960,0,(const double*)T,(long)Mp,(const double*)Bt,(long)Mp,part,P,nblk,kend);},2);
+  ms=timeit([&]{hipMemsetAsync(queue,0,64,0); hipLaunchKernelGGL((k_contract<false,4>),dim3(pgrid),dim3(256),40960,0,(const double*)T,(long)Mp,(const double*)Bt,(long)Mp,part,P,nblk,kend,queue);},2);
   printf("k_contract<full> mfma, ONE block per CU (40 KB dummy dynamic LDS): %.3f ms  executed %.2f TF/s\n",ms,fl_full/ms*1e-9);
   ms=timeit([&]{hipLaunchKernelGGL(k_contract_valu<true>,dim3(vgrid),dim3(256),0,0,(const double*)T,(long)Mp,(const double*)Bt,(long)Mp,part,P,nblk,kend);},3);
   printf("k_contract<sym>  valu : %.3f ms  executed %.2f TF/s  effective(2M^2) %.2f TF/s\n",ms,fl_sym/ms*1e-9,fl_full/ms*1e-9);
@@ -67,6 +78,10 @@ int main(int argc,char**argv){
   ABLATE(4,4,256,"4-wave, no barrier");
   ABLATE(4,3,256,"4-wave, no DMA + no ds_reads");
   ABLATE(4,7,256,"4-wave, MFMA only");
+  { ms=timeit([&]{hipLaunchKernelGGL((k_contract_ablate<2,16>),dim3(grid),dim3(512),0,0,(const double*)T,(long)Mp,(const double*)Bt,(long)Mp,part,P,nblk,kend);},3);
+    printf("ablate %-44s: %.3f ms  %.2f TF/s (executed, ragged flop count)\n","8-wave, ragged K (k >= i0), no doubling, no epilogue",ms,fl_sym/ms*1e-9); }
+  { ms=timeit([&]{hipLaunchKernelGGL((k_contract_ablate<2,17>),dim3(grid),dim3(512),0,0,(const double*)T,(long)Mp,(const double*)Bt,(long)Mp,part,P,nblk,kend);},3);
+    printf("ablate %-44s: %.3f ms  %.2f TF/s (executed, ragged flop count)\n","8-wave, ragged K, no LDS-DMA",ms,fl_sym/ms*1e-9); }
   ABLATE(4,8,256,"4-wave, DMA source always k-tile 0 (cached)");
   ABLATE(2,8,512,"8-wave, DMA source always k-tile 0 (cached)");
   ABLATE(2,0,512,"8-wave, nothing removed");
