@@ -537,7 +537,7 @@ __device__ __forceinline__ bool super_tile(int nIblk, int nTblk, int& iblk, int&
 // ------------------------------------------------------------------------------------------------
 // PERSISTENT: the launch is 2 blocks per CU; each block pops tiles from the tile sequence of the XCD it runs on
 // (one relaxed device-scope atomicAdd per tile, the XCD id read from HW_REG_XCC_ID) until that sequence is
-// exhausted.  With one block per tile the in-order workgroup dispatcher stalls behind whichever XCD is still
+// exhausted, then helps with the other XCDs' sequences.  With one block per tile the in-order workgroup dispatcher stalls behind whichever XCD is still
 // busy once tile lengths differ (symmetric form: 1..nIblk K blocks): measured 8 % of the MFMA rate.
 // PERSIST = false is the one-block-per-tile form (grid = super_grid(), queue unused), kept for A/B measurements.
 template <bool SYM, int NAI, bool PERSIST = true>
@@ -551,16 +551,21 @@ k_contract(const double* __restrict__ Ainv, long lda, const double* __restrict__
   const int xcd = (int)(xcc & 7);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 1, wn = wave & 1, lq = lane >> 4, lc = lane & 15;
+  int steal = 0;  // 0 = own XCD's sequence; then the other seven in turn: every tile is done whatever the placement
   for (;;) {
   int iblk, tblk;
   if (PERSIST) {
+    const int xq = (xcd + steal) & 7;
     if (threadIdx.x == 0)
-      sm.next = (long)__hip_atomic_fetch_add(&queue[xcd], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      sm.next = (long)__hip_atomic_fetch_add(&queue[xq], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     const long seq = sm.next;
-    const int kind = super_tile_at(nIblk, palloc / MIK_BN, xcd, seq, iblk, tblk);
+    const int kind = super_tile_at(nIblk, palloc / MIK_BN, xq, seq, iblk, tblk);
     __syncthreads();  // everyone has read sm.next (and the previous tile's `red`) before anything is overwritten
-    if (kind == 2) return;
+    if (kind == 2) {  // this sequence is exhausted: help the next XCD's (correctness never depends on XCC_ID)
+      if (++steal == 8) return;
+      continue;
+    }
     if (kind == 1) continue;
   } else if (!super_tile(nIblk, palloc / MIK_BN, iblk, tblk)) {
     return;
