@@ -492,3 +492,37 @@ def test_device_experimental_variogram_matches_reference_binning():
         np.testing.assert_allclose(k3.lags, g["lags_3d"], rtol=1e-12)
     finally:
         del os.environ["MIK_DEVICE_VARIOGRAM_MIN_N"]
+
+
+@pytest.mark.parametrize("n", [2, 3, 14, 15, 16, 17, 110, 126, 127, 128, 129, 254, 255, 256, 257, 383, 384, 385])
+def test_matrix_orders_around_tile_boundaries(n):
+    """M = n + 1 (OK) and n + 4 (UK with regional_linear + one well) straddle the 16-wide K tile and the 128-wide
+    block boundaries of the device kernels; every factor path and both contraction forms against the oracle."""
+    import pykrige_amd as pa
+
+    (x, y), v = fx.synth(1000 + n, n, 2)
+    rng = np.random.default_rng(n)
+    pts = rng.random((131, 2))
+    pts[0] = [x[0], y[0]]
+    st = ko.KrigingState(ndim=2, coords_orig=np.stack([x, y], 1), values=v, model="spherical",
+                         params=ko.internal_parameters("spherical", [1.0, 0.6, 0.05]))
+    zr, sr = ko.solve_points(st, ko.adjust_for_anisotropy(pts, st.center, st.scaling, st.angle))
+    ok = pa.OrdinaryKriging(x, y, v, variogram_model="spherical", variogram_parameters=[1.0, 0.6, 0.05])
+    h = ok._get_handle()
+    for factor, sym in ((0, 1), (2, 0), (1, 0), (2, 1)):
+        h.set_option("factor", factor)
+        h.set_option("symmetric", sym)
+        z, ss = ok.execute("points", pts[:, 0], pts[:, 1], backend="loop")
+        np.testing.assert_allclose(z, zr, rtol=0, atol=Z_TOL)
+        np.testing.assert_allclose(ss, sr, rtol=0, atol=SS_TOL)
+    if n >= 14:
+        well = [[0.37, 0.61, 1.5]]
+        uk = pa.UniversalKriging(x, y, v, variogram_model="exponential", variogram_parameters=[1.0, 0.5, 0.02],
+                                 drift_terms=["regional_linear", "point_log"], point_drift=well)
+        stu = ko.KrigingState(ndim=2, coords_orig=np.stack([x, y], 1), values=v, model="exponential",
+                              params=ko.internal_parameters("exponential", [1.0, 0.5, 0.02]), regional_linear=True,
+                              point_log=np.array(well))
+        zu, su = uk.execute("points", pts[:, 0], pts[:, 1], backend="loop")
+        zru, sru = ko.solve_points(stu, ko.adjust_for_anisotropy(pts, stu.center, stu.scaling, stu.angle))
+        np.testing.assert_allclose(zu, zru, rtol=0, atol=Z_TOL)
+        np.testing.assert_allclose(su, sru, rtol=0, atol=SS_TOL)
