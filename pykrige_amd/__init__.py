@@ -5,7 +5,7 @@ kriging-matrix assembly, dense inverse, per-point right-hand sides and the z / s
 as hand-written HIP kernels in ``libmikrige.so`` (C ABI: include/mikrige.h), called through ctypes.
 """
 from .kriging import OrdinaryKriging, OrdinaryKriging3D, UniversalKriging, UniversalKriging3D  # noqa: F401
-from . import _lib, core  # noqa: F401
+from . import _lib, core, variogram_models  # noqa: F401
 
 __all__ = ["OrdinaryKriging", "UniversalKriging", "OrdinaryKriging3D", "UniversalKriging3D"]
 __version__ = "0.1.0"

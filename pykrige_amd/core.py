@@ -130,3 +130,84 @@ def bilinear_zscalars(zgrid, gx, gy, x, y):
         only_y = (z11 * (y2 - yf) + z22 * (yf - y1)) / (y2 - y1)
     out = np.where(same_y, np.where(same_x, z11, only_x), np.where(same_x, only_y, both))
     return out.reshape(x.shape)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# Device-backed twins of core._krige / core._find_statistics (core.py:654-836).  Same signatures; the variogram
+# is identified by the function's __name__ (as lib/variogram_models.pyx:6-22 does), arbitrary callables are refused.
+# ----------------------------------------------------------------------------------------------------------
+_eps = 1.0e-10  # core.py:30
+
+
+def _model_of(variogram_function):
+    from . import variogram_models as vm
+
+    name = getattr(variogram_function, "__name__", None)
+    if name not in vm.MODEL_OF_FUNCTION:
+        raise NotImplementedError("only the six named variogram models have a device functor (got %r)" % (name,))
+    return vm.MODEL_OF_FUNCTION[name]
+
+
+def _problem_handle(X, y, variogram_function, variogram_model_parameters, coordinates_type):
+    from . import _lib
+
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    if coordinates_type not in ("euclidean", "geographic"):
+        raise ValueError("Specified coordinate type '%s' is not supported." % coordinates_type)
+    if coordinates_type == "geographic" and X.shape[1] != 2:
+        raise ValueError("Geographic coordinate type only supported for 2D datasets.")
+    model = _model_of(variogram_function)
+    h = _lib.Handle()
+    h.set_problem(ndim=X.shape[1], xs=X[:, 0], ys=X[:, 1], zs=X[:, 2] if X.shape[1] == 3 else None, values=y,
+                  model_id=_lib.MODEL_IDS[model], params=[float(v) for v in variogram_model_parameters], eps=_eps,
+                  exact_values=True, geographic=coordinates_type == "geographic")
+    return h
+
+
+def _krige(X, y, coords, variogram_function, variogram_model_parameters, coordinates_type, pseudo_inv=False):
+    """Ordinary kriging of ONE point from the stations X (the single-point form of the execute() solve)."""
+    if pseudo_inv:
+        raise NotImplementedError("pseudo_inv in _krige uses numpy.linalg.lstsq on the host; not on the device path")
+    coords = np.asarray(coords, dtype=np.float64).ravel()
+    h = _problem_handle(X, y, variogram_function, variogram_model_parameters, coordinates_type)
+    try:
+        h.factor()
+        h.set_points(coords[0:1], coords[1:2], coords[2:3] if coords.size == 3 else None)
+        h.predict()
+        z, ss = h.get_results()
+    finally:
+        h.close()
+    return float(z[0]), float(ss[0])
+
+
+def _find_statistics(X, y, variogram_function, variogram_model_parameters, coordinates_type, pseudo_inv=False):
+    """delta, sigma, epsilon of the variogram fit (station i kriged from stations 0..i-1) on the device."""
+    if pseudo_inv:
+        raise NotImplementedError("pseudo_inv statistics are outside the device path")
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    h = _problem_handle(X, y, variogram_function, variogram_model_parameters, coordinates_type)
+    try:
+        k, ss = h.statistics(y.size)
+    finally:
+        h.close()
+    delta, sigma = np.zeros(y.shape), np.zeros(y.shape)
+    keep = np.absolute(ss) >= _eps
+    keep[0] = False
+    with np.errstate(invalid="ignore"):
+        delta[keep] = y[keep] - k[keep]
+        sigma[keep] = np.sqrt(ss[keep])
+    sel = sigma > _eps
+    delta, sigma = delta[sel], sigma[sel]
+    return delta, sigma, delta / sigma
+
+
+def calcQ1(epsilon):
+    return abs(np.sum(epsilon) / (epsilon.shape[0] - 1))
+
+
+def calcQ2(epsilon):
+    return np.sum(epsilon**2) / (epsilon.shape[0] - 1)
+
+
+def calc_cR(Q2, sigma):
+    return Q2 * np.exp(np.sum(np.log(sigma**2)) / sigma.shape[0])

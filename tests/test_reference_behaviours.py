@@ -185,3 +185,27 @@ def test_uk3d_drift_equivalences_and_shapes():
         pa.OrdinaryKriging3D(x, y, zc, v, **kw).execute("masked", gx, gy, gz, mask=np.zeros((2, 2, 2), bool))
     with pytest.raises(ValueError):
         pa.OrdinaryKriging3D(x, y, zc, v, **kw).execute("masked", gx, gy, gz, mask=np.zeros((5, 6), bool))
+
+
+def test_core_krige_and_find_statistics_function_twins():
+    """core._krige (test_core.py:378-427, Kitanidis ex. 3.2) and core._find_statistics with the reference's signatures,
+    variogram given as a named function."""
+    from pykrige_amd import core, variogram_models
+    from tests import _fixtures as fx
+
+    d = np.array([[9.7, 47.6, 1.22], [43.8, 24.6, 2.822]])
+    z, ss = core._krige(d[:, :2], d[:, 2], np.array([18.8, 67.9]), variogram_models.linear_variogram_model, [0.006, 0.1], "euclidean")
+    assert z == approx(1.6364, rel=1e-4) and ss == approx(0.4201, rel=1e-4)
+    z, ss = core._krige(d[:, :2], d[:, 2], np.array([43.8, 24.6]), variogram_models.linear_variogram_model, [0.006, 0.1], "euclidean")
+    assert z == approx(2.822, rel=1e-3) and ss == approx(0.0, abs=1e-12)
+    d3 = np.array([[9.7, 47.6, 1.0, 1.22], [43.8, 24.6, 1.0, 2.822]])
+    z, ss = core._krige(d3[:, :3], d3[:, 3], np.array([18.8, 67.9, 1.0]), variogram_models.linear_variogram_model, [0.006, 0.1], "euclidean")
+    assert z == approx(1.6364, rel=1e-4) and ss == approx(0.4201, rel=1e-4)
+    g = fx.load("stats_find_statistics")
+    delta, sigma, eps = core._find_statistics(np.stack([g["x"], g["y"]], 1), g["v"], variogram_models.exponential_variogram_model,
+                                              [0.9, 0.3, 0.1], "euclidean")
+    np.testing.assert_allclose(delta, g["delta_exp"], atol=1e-8)
+    np.testing.assert_allclose(sigma, g["sigma_exp"], atol=1e-8)
+    np.testing.assert_allclose([core.calcQ1(eps), core.calcQ2(eps), core.calc_cR(core.calcQ2(eps), sigma)], g["q_exp"], rtol=1e-7)
+    with pytest.raises(NotImplementedError):
+        core._krige(d[:, :2], d[:, 2], np.array([1.0, 1.0]), lambda m, x: x, [1.0], "euclidean")
