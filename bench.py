@@ -11,7 +11,8 @@ exponential variogram [1.0, 0.3, 0.0], fp64, synthetic stations (SURVEY.md 8(d),
 N > 1 (launched by torch.distributed.run, one rank per GPU): WEAK scaling -- every rank kriges its own
 1000x1000 slab of a 1000 x (1000 N) grid against the same stations; rank 0 assembles + inverts and the
 inverse is broadcast over RCCL/xGMI by the library (mik_bcast_factor); no other collective.
-torch is imported only for N > 1 (rendezvous, barrier, max-over-ranks of the time) -- plumbing.
+The host-side rendezvous / barrier / max-over-ranks of the time go through pykrige_amd.dist.SocketGroup (TCP, from the
+launcher's RANK/WORLD_SIZE/MASTER_* environment); torch is not imported unless that fails (then: its gloo group).
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -144,14 +145,24 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
         args.gpus = world
-    dist = None
+    pg = None
     if world > 1:
-        import torch
-        import torch.distributed as dist
+        # Host-side rendezvous / barrier / max-over-ranks only.  The launcher's env (RANK, WORLD_SIZE, MASTER_*) is used
+        # through a small TCP group so that the process holds ONE HIP runtime and ONE RCCL (the ROCm install's, the ones
+        # libmikrige.so links and dlopens); torch's gloo group is the fallback if that rendezvous cannot be set up.
+        from pykrige_amd.dist import SocketGroup, _TorchGroup
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)  # host-side rendezvous/barrier only
-        torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
+        try:
+            if os.environ.get("MIK_BENCH_HOSTPG", "socket") != "socket":
+                raise RuntimeError("torch group requested")
+            pg = SocketGroup(rank=rank, world=world)
+        except Exception as e:  # noqa: BLE001
+            print("bench: socket group unavailable (%r); using torch.distributed gloo" % (e,), file=sys.stderr)
+            import torch.distributed as tdist
+
+            tdist.init_process_group(backend="gloo", rank=rank, world_size=world)
+            pg = _TorchGroup()
 
     from pykrige_amd import _lib  # raises if libmikrige.so is missing: no CPU fallback
 
@@ -179,44 +190,17 @@ def main():
 
     exchange = "none"
     if world > 1:
-        exchange = "rccl_bcast"
         if os.environ.get("MIK_BENCH_BCAST", "1") == "0":
             exchange = "redundant_factor"
         else:
-            try:
-                uid = [_lib.Handle.comm_unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(uid, src=0)
-                # ncclCommInitRank blocks until every rank has joined; run it in a thread so that a wedged
-                # bootstrap degrades to redundant factorisation instead of hanging the benchmark
-                import threading
+            from pykrige_amd.dist import init_rccl
 
-                box = {}
-
-                def _init():
-                    try:
-                        h.comm_init(world, rank, uid[0])
-                        box["ok"] = True
-                    except Exception as e:  # noqa: BLE001
-                        box["err"] = str(e)[:80]
-
-                th = threading.Thread(target=_init, daemon=True)
-                th.start()
-                th.join(float(os.environ.get("MIK_RCCL_INIT_TIMEOUT", "120")))
-                if not box.get("ok"):
-                    raise RuntimeError(box.get("err", "timed out"))
-            except Exception as e:  # RCCL unavailable: every rank factors for itself
-                exchange = "redundant_factor (rccl init failed: %s)" % (str(e)[:80],)
-            flags = [None] * world
-            dist.all_gather_object(flags, exchange)
-            if any(f != "rccl_bcast" for f in flags):
-                exchange = next(f for f in flags if f != "rccl_bcast")
+            exchange = init_rccl(h, pg)  # "rccl_bcast", or "redundant_factor (...)": every rank factors for itself
 
     def sync():
-        if dist is not None:
-            import torch
-
-            torch.cuda.synchronize()
-            dist.barrier()
+        h.synchronize()  # device idle (mik_predict / mik_bcast_factor already block; this is the explicit bracket)
+        if pg is not None:
+            pg.barrier()
 
     tsum = dict(assemble_ms=0.0, invert_ms=0.0, rhs_ms=0.0, contract_ms=0.0, predict_ms=0.0, contract_launches=0,
                 contract_flops_executed=0.0)
@@ -252,12 +236,8 @@ def main():
         step(True)
     sync()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-
-        tt = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    if pg is not None:
+        dt = pg.all_reduce_max(dt)
 
     if rank == 0:
         K = args.steps
@@ -284,9 +264,9 @@ def main():
                               "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": dt / K * 1e3,
                               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
                               "data": "synthetic", "config": {"workload": cfg["name"], "n_closest_points": args.moving_window}}))
+            if pg is not None:
+                pg.barrier()
             h.close()
-            if dist is not None:
-                dist.destroy_process_group()
             return
         out = {
             "metric": "kriged grid-points/sec (z + sigma^2), OK2D N=5000 on 1000x1000 grid" if args.config == 2
@@ -332,9 +312,9 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "grid-points/s", "cores": None, "kind": "port",
                                        "sample": "failed: %r" % (e,)}
         emit(json.dumps(out))
+    if pg is not None:
+        pg.barrier()  # nobody tears its communicator down while another rank is still inside a collective
     h.close()
-    if dist is not None:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -108,6 +108,8 @@ int  mik_factor(mik_handle *h);                            /* K1 + K2 (+ c = A_i
 int  mik_set_points(mik_handle *h, const mik_points *g);   /* H2D of the (unmasked) points              */
 int  mik_predict(mik_handle *h);                           /* K3 over the resident points; results stay in HBM */
 int  mik_get_results(mik_handle *h, double *z_out, double *ss_out); /* D2H, scattered through the mask  */
+int  mik_synchronize(mik_handle *h);                       /* wait until the handle's stream is idle (every call above
+                                                              already blocks; this is the explicit bracket for timing) */
 
 /* Moving-window ordinary kriging (n_closest_points): replaces cKDTree.query + _c_exec_loop_moving_window
  * (ok.py:929-986, lib/cok.pyx:98-193; ok3d.py:901-912, 697-733).  Needs mik_set_problem + mik_set_points

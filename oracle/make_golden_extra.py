@@ -71,7 +71,7 @@ def main():
     print("wrote extra fixtures")
 
 
-if __name__ == "__main__" and not {"--mw", "--geo", "--stats"} & set(sys.argv):
+if __name__ == "__main__" and not {"--mw", "--geo", "--stats", "--sk"} & set(sys.argv):
     main()
 
 
@@ -194,3 +194,58 @@ def statistics():
 if __name__ == "__main__" and "--stats" in sys.argv:
     _import_reference(False)
     statistics()
+
+
+def sklearn_callers():
+    """The scikit-learn side callers of the path, run on the REAL reference: compat.Krige (compat.py:97-291) for the four
+    methods, rk.RegressionKriging (rk.py:106-166), ck.ClassificationKriging (ck.py:107-192).  The learners are
+    deterministic scikit-learn models, so the product (same scikit-learn) must reproduce the numbers."""
+    from pykrige.ck import ClassificationKriging
+    from pykrige.compat import Krige
+    from pykrige.rk import RegressionKriging
+    from sklearn.linear_model import LinearRegression
+    from sklearn.naive_bayes import GaussianNB  # closed form: the same probabilities on every host (lbfgs-fitted learners are not)
+
+    out = {}
+    rng = np.random.default_rng(2024)
+    X3 = rng.random((160, 3))
+    y = np.sin(5 * X3[:, 0]) * np.cos(3 * X3[:, 1]) + 0.5 * X3[:, 2] + 0.05 * rng.standard_normal(160)
+    Q3 = rng.random((50, 3))
+    out.update(X3=X3, y=y, Q3=Q3)
+    cases = {"ordinary": dict(variogram_model="exponential", n_closest_points=8, nlags=6),
+             "universal": dict(variogram_model="linear", drift_terms=["regional_linear"]),
+             "ordinary3d": dict(variogram_model="spherical", n_closest_points=12, anisotropy_scaling=(1.5, 0.7)),
+             "universal3d": dict(variogram_model="gaussian", variogram_parameters=[1.0, 0.8, 0.05],
+                                 drift_terms=["regional_linear"])}
+    for method, kw in cases.items():
+        d = 3 if method.endswith("3d") else 2
+        k = Krige(method=method, **kw)
+        k.fit(X3[:, :d], y)
+        pts = k._dimensionality_check(Q3[:, :d], ext="points")
+        pred, var = k.execute(pts)
+        out["krige_%s_pred" % method], out["krige_%s_var" % method] = np.asarray(pred), np.asarray(var)
+        out["krige_%s_par" % method] = np.asarray(k.model.variogram_model_parameters)
+    P = np.column_stack([X3[:, 0] ** 2, X3[:, 1], np.cos(X3[:, 2])]) + 0.01 * rng.standard_normal((160, 3))
+    PQ = np.column_stack([Q3[:, 0] ** 2, Q3[:, 1], np.cos(Q3[:, 2])])
+    out.update(P=P, PQ=PQ)
+    rk = RegressionKriging(regression_model=LinearRegression(), method="ordinary", variogram_model="spherical", n_closest_points=10)
+    rk.fit(P, X3[:, :2], y)
+    out["rk_pred"] = np.asarray(rk.predict(PQ, Q3[:, :2]))
+    out["rk_score"] = np.array(rk.score(P[:40], X3[:40, :2] + 0.01, y[:40]))
+    labels = np.digitize(y, np.quantile(y, [0.33, 0.66])).reshape(-1, 1)
+    ck = ClassificationKriging(classification_model=GaussianNB(), method="ordinary",
+                               variogram_model="exponential", variogram_parameters=[450.0, 0.4, 5.0], n_closest_points=10)
+    # (explicit parameters: the automatic fit of the second ilr coordinate has a weakly determined nugget, and
+    #  scipy.optimize.least_squares then lands on host-dependent parameters -- seen 4.3e-2 here vs 5.0e-2 on the GPU box)
+    ck.fit(P, X3[:, :2], labels)
+    out["labels"] = labels
+    out["ck_par"] = np.array([k.model.variogram_model_parameters for k in ck.krige])
+    out["ck_residual"] = np.asarray(ck.krige_residual(Q3[:, :2]))
+    out["ck_pred"] = np.asarray(ck.predict(PQ, Q3[:, :2]))
+    np.savez_compressed(os.path.join(OUT, "sk_callers.npz"), **out)
+    print("wrote sklearn-callers fixture")
+
+
+if __name__ == "__main__" and "--sk" in sys.argv:
+    _import_reference(False)
+    sklearn_callers()

@@ -60,6 +60,7 @@ SIGNATURES = {
     "mik_set_points": (C.c_int, [C.c_void_p, C.POINTER(MikPoints)]),
     "mik_predict": (C.c_int, [C.c_void_p]),
     "mik_get_results": (C.c_int, [C.c_void_p, _dp, _dp]),
+    "mik_synchronize": (C.c_int, [C.c_void_p]),
     "mik_predict_moving_window": (C.c_int, [C.c_void_p, C.c_int]),
     "mik_statistics": (C.c_int, [C.c_void_p, _dp, _dp]),
     "mik_experimental_variogram": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, C.POINTER(C.c_int32)]),
@@ -226,6 +227,9 @@ class Handle:
         n = C.c_int32(0)
         check(self._lib.mik_experimental_variogram(self._h, int(nlags), _ptr(lags), _ptr(semi), C.byref(n)))
         return lags[:n.value].copy(), semi[:n.value].copy()
+
+    def synchronize(self):
+        check(self._lib.mik_synchronize(self._h))
 
     def get_results(self):
         z = np.empty(self._npt, dtype=np.float64)

@@ -935,6 +935,13 @@ int mik_experimental_variogram(mik_handle* h, int nlags, double* lags_out, doubl
   return MIK_OK;
 }
 
+int mik_synchronize(mik_handle* h) {
+  if (!h) return fail(MIK_EINVAL, "mik_synchronize: NULL handle");
+  HIPC(hipSetDevice(h->device));
+  HIPC(hipStreamSynchronize(h->stream));
+  return MIK_OK;
+}
+
 int mik_get_results(mik_handle* h, double* z_out, double* ss_out) {
   if (!h || !z_out || !ss_out) return fail(MIK_EINVAL, "mik_get_results: NULL argument");
   if (!h->have_results) return fail(MIK_ESTATE, "mik_get_results: predict first");

@@ -171,3 +171,41 @@ def test_geographic_variogram_fit_matches_reference():
     np.testing.assert_allclose(ok.variogram_model_parameters, g["fit_par"], rtol=1e-6, atol=1e-9)
     with pytest.raises(ValueError):
         pa.OrdinaryKriging(g["x"], g["y"], g["v"], variogram_model="linear", variogram_parameters=[1.0, 0.0], coordinates_type="martian")
+
+
+def test_sklearn_side_host_pieces_without_a_gpu():
+    """compat / rk / ck host logic that needs no device: method validation, keyword routing per method (compat.py:37-74,
+    196-229), the ilr transformation pair (ck.py:215-291), learner type checks (compat.py:294-307)."""
+    pytest.importorskip("sklearn")
+    from sklearn.linear_model import LinearRegression, LogisticRegression
+
+    from pykrige_amd import ck, compat, rk
+
+    with pytest.raises(ValueError):
+        compat.Krige(method="nope")
+    k = compat.Krige(method="universal3d", anisotropy_scaling=(2.0, 3.0), anisotropy_angle=(10.0, 20.0, 30.0), drift_terms=["regional_linear"])
+    kw = k._method_specific()
+    assert kw == dict(anisotropy_scaling_y=2.0, anisotropy_scaling_z=3.0, anisotropy_angle_x=10.0, anisotropy_angle_y=20.0,
+                      anisotropy_angle_z=30.0, drift_terms=["regional_linear"], functional_drift=None)
+    assert set(compat.Krige(method="ordinary")._method_specific()) == {"anisotropy_scaling", "anisotropy_angle", "enable_statistics", "coordinates_type"}
+    assert set(k.get_params()) >= {"method", "n_closest_points", "ext_drift_grid", "pseudo_inv_type"}  # sklearn cloning works
+    with pytest.raises(ValueError):
+        k._dimensionality_check(np.zeros((4, 2)))
+    assert list(compat.Krige()._dimensionality_check(np.ones((4, 2)), ext="points")) == ["xpoints", "ypoints"]
+    with pytest.raises(Exception, match="Not trained"):
+        compat.Krige().predict(np.zeros((2, 2)))
+    rng = np.random.default_rng(0)
+    comp = ck.closure(rng.random((20, 4)) + 0.05)
+    assert np.allclose(comp.sum(1), 1.0)
+    coords = ck.ilr_transformation(comp)
+    assert coords.shape == (20, 3) and np.allclose(ck.inverse_ilr_transformation(coords), comp, atol=1e-13)
+    onehot = np.eye(3)[[0, 2, 1]]
+    assert np.all(np.isfinite(ck.ilr_transformation(onehot)))  # zeros are lifted to eps, not -inf
+    compat.check_sklearn_model(LinearRegression())
+    compat.check_sklearn_model(LogisticRegression(), task="classification")
+    with pytest.raises(RuntimeError):
+        compat.check_sklearn_model(LinearRegression(), task="classification")
+    with pytest.raises(RuntimeError):
+        rk.RegressionKriging(regression_model=object())
+    with pytest.raises(ValueError):
+        ck.ClassificationKriging(classification_model=LogisticRegression(), method="bad")

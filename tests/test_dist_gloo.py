@@ -101,6 +101,55 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def _sock_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import pykrige_amd as pa
+    from oracle import kriging_oracle as ko
+    from pykrige_amd.dist import ShardedExecutor, SocketGroup
+
+    pg = SocketGroup(rank=rank, world=world, addr="127.0.0.1", port=port)
+    try:
+        assert pg.all_gather_object(rank * 10) == [0, 10, 20][:world]
+        assert pg.broadcast_object(b"x" * 128 if rank == 0 else None) == b"x" * 128
+        assert pg.all_reduce_max(1.0 + rank) == float(world)
+        pg.barrier()
+        rng = np.random.default_rng(6)
+        x, y, zc, v = rng.random(50), rng.random(50), rng.random(50), rng.random(50)
+        k3 = pa.OrdinaryKriging3D(x, y, zc, v, variogram_model="spherical", variogram_parameters=[1.0, 0.7, 0.05])
+        hdl = OracleHandle()
+        ex = ShardedExecutor(k3, group=pg, handle_factory=lambda: hdl)
+        assert ex.exchange.startswith("redundant_factor")
+        g = [np.linspace(0, 1, 5), np.linspace(0, 1, 4), np.linspace(0, 1, 3)]
+        z, ss = ex.execute("grid", *g, backend="loop")
+        st = ko.KrigingState(ndim=3, coords_orig=np.stack([x, y, zc], 1), values=v, model="spherical",
+                             params=ko.internal_parameters("spherical", [1.0, 0.7, 0.05]), scaling=[1.0, 1.0], angle=[0.0] * 3)
+        zr, sr = ko.execute(st, "grid", *g)
+        q.put((rank, bool(np.allclose(z, zr, atol=1e-12) and np.allclose(ss, sr, atol=1e-12) and z.shape == (3, 4, 5)), len(hdl.pts)))
+    finally:
+        pg.close()
+
+
+def test_socket_group_world3_sharded_execute():
+    """The torch-free host process group (used by bench.py under torchrun): 3 ranks, collectives + a sharded 3-D execute."""
+    import multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sock_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [o[0] for o in out] == [0, 1, 2] and all(o[1] for o in out)
+    assert sum(o[2] for o in out) == 5 * 4 * 3 and max(o[2] for o in out) - min(o[2] for o in out) <= 1
+
+
 def test_sharded_execute_world2_gloo():
     import torch.multiprocessing as mp
 

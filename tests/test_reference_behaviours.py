@@ -209,3 +209,54 @@ def test_core_krige_and_find_statistics_function_twins():
     np.testing.assert_allclose([core.calcQ1(eps), core.calcQ2(eps), core.calc_cR(core.calcQ2(eps), sigma)], g["q_exp"], rtol=1e-7)
     with pytest.raises(NotImplementedError):
         core._krige(d[:, :2], d[:, 2], np.array([1.0, 1.0]), lambda m, x: x, [1.0], "euclidean")
+
+
+def test_sklearn_side_callers_match_the_reference():
+    """compat.Krige for the four methods, rk.RegressionKriging and ck.ClassificationKriging against what the REAL reference
+    returned for the same calls (tests/golden/sk_callers.npz <- oracle/make_golden_extra.py --sk; reference tests:
+    test_api.py:15-30, test_regression_krige.py:33-64, test_classification_krige.py:30-64).  Krige.execute defaults to
+    backend="loop" with n_closest_points, i.e. the device moving-window path for the ordinary methods."""
+    pytest.importorskip("sklearn")
+    from sklearn.linear_model import LinearRegression, LogisticRegression
+
+    from tests import _fixtures as fx
+    from pykrige_amd.ck import ClassificationKriging
+    from pykrige_amd.compat import Krige
+    from pykrige_amd.rk import RegressionKriging
+
+    g = fx.load("sk_callers")
+    X3, y, Q3 = g["X3"], g["y"], g["Q3"]
+    cases = {"ordinary": dict(variogram_model="exponential", n_closest_points=8, nlags=6),
+             "universal": dict(variogram_model="linear", drift_terms=["regional_linear"]),
+             "ordinary3d": dict(variogram_model="spherical", n_closest_points=12, anisotropy_scaling=(1.5, 0.7)),
+             "universal3d": dict(variogram_model="gaussian", variogram_parameters=[1.0, 0.8, 0.05],
+                                 drift_terms=["regional_linear"])}
+    for method, kw in cases.items():
+        d = 3 if method.endswith("3d") else 2
+        k = Krige(method=method, **kw)
+        k.fit(X3[:, :d].copy(), y)
+        np.testing.assert_allclose(k.model.variogram_model_parameters, g["krige_%s_par" % method], rtol=1e-6, atol=1e-9)
+        pred, var = k.execute(k._dimensionality_check(Q3[:, :d].copy(), ext="points"))
+        # the fitted variogram parameters agree to ~1e-7 relative (iterative fit), so the kriged values do to ~1e-6
+        np.testing.assert_allclose(pred, g["krige_%s_pred" % method], rtol=0, atol=2e-6, err_msg=method)
+        np.testing.assert_allclose(var, g["krige_%s_var" % method], rtol=0, atol=2e-6, err_msg=method)
+        np.testing.assert_allclose(k.predict(Q3[:, :d].copy()), pred, rtol=0, atol=0)
+    with pytest.raises(ValueError):
+        Krige(method="simple")
+    with pytest.raises(ValueError):
+        Krige(method="ordinary3d").fit(X3[:, :2], y)
+    rk = RegressionKriging(regression_model=LinearRegression(), method="ordinary", variogram_model="spherical", n_closest_points=10)
+    rk.fit(g["P"], X3[:, :2].copy(), y)
+    np.testing.assert_allclose(rk.predict(g["PQ"], Q3[:, :2].copy()), g["rk_pred"], rtol=0, atol=2e-6)
+    assert rk.score(g["P"][:40], X3[:40, :2] + 0.01, y[:40]) == approx(float(g["rk_score"]), abs=1e-6)
+    with pytest.raises(RuntimeError):
+        RegressionKriging(regression_model=LogisticRegression())
+    from sklearn.naive_bayes import GaussianNB  # closed-form learner: identical probabilities on every host
+
+    ck = ClassificationKriging(classification_model=GaussianNB(), method="ordinary",
+                               variogram_model="exponential", variogram_parameters=[450.0, 0.4, 5.0], n_closest_points=10)
+    ck.fit(g["P"], X3[:, :2].copy(), g["labels"])
+    got_par = np.array([k.model.variogram_model_parameters for k in ck.krige])
+    np.testing.assert_allclose(got_par, g["ck_par"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(ck.krige_residual(Q3[:, :2].copy()), g["ck_residual"], rtol=0, atol=5e-6)
+    assert np.array_equal(ck.predict(g["PQ"], Q3[:, :2].copy()), g["ck_pred"])
