@@ -96,7 +96,7 @@ def moving_window():
                          anisotropy_scaling=2.0, anisotropy_angle=20.0)
     rng = np.random.default_rng(91)
     mask = rng.random((17, 21)) < 0.25
-    for k in (2, 10, 31, 70):
+    for k in (2, 10, 31, 70, 128, 200, 400):  # > 127: the HBM-resident device variant; 400 = every station
         z, ss = ok.execute("grid", gx_, gy_, backend="loop", n_closest_points=k)
         out["z_k%d" % k], out["ss_k%d" % k] = arr(z), arr(ss)
         if with_c:
@@ -112,7 +112,7 @@ def moving_window():
                            anisotropy_angle_y=20.0, anisotropy_angle_z=30.0)
     out = dict(x=x, y=y, zc=zc, v=v, model="exponential", params_user=[1.0, 0.5, 0.02], gridx=g3x, gridy=g3y, gridz=g3z,
                scaling=[1.5, 2.0], angle=[10.0, 20.0, 30.0])
-    for k in (8, 20):
+    for k in (8, 20, 150):
         z, ss = k3.execute("grid", g3x, g3y, g3z, backend="loop", n_closest_points=k)
         out["z_k%d" % k], out["ss_k%d" % k] = arr(z), arr(ss)
     np.savez_compressed(os.path.join(OUT, "mw_ok3d.npz"), **out)
@@ -149,7 +149,7 @@ def geographic():
                          coordinates_type="geographic")
     z, ss = ok.execute("grid", glon, glat, backend="vectorized")
     out.update(z=arr(z), ss=arr(ss), A=ok._get_kriging_matrix(n))
-    for k in (6, 20):
+    for k in (6, 20, 140):
         zk, ssk = ok.execute("grid", glon, glat, backend="loop", n_closest_points=k)
         out["z_k%d" % k], out["ss_k%d" % k] = arr(zk), arr(ssk)
         if with_c:

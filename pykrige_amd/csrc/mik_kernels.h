@@ -1316,6 +1316,155 @@ __global__ void __launch_bounds__(256) k_mw_solve(MwArgs a) {
   }
 }
 
+// ---- n_closest_points > MIK_MW_KMAX: the same two steps with their working sets in HBM instead of registers / LDS ----
+// k_mw_knn_big : one thread per point; its ascending candidate list lives in a [rank][point] work array (neighbouring
+//                threads touch neighbouring addresses while they are at the same rank) and is copied to the usual
+//                [point][rank] layout at the end.
+// k_mw_solve_big: one 256-thread block per point (grid-strided over the chunk); the augmented (k+1) x (k+2) system sits in
+//                a per-block HBM/L2 scratch slot; LU forward elimination with partial pivoting (dgesv's pivot order,
+//                cok.pyx:165) + column-oriented back substitution.
+template <int NDIM>
+__global__ void __launch_bounds__(256)
+k_mw_knn_big(const double* __restrict__ px, const double* __restrict__ py, const double* __restrict__ pz, int npt,
+             const double* __restrict__ xs, const double* __restrict__ ys, const double* __restrict__ zs, int N, int K,
+             double* __restrict__ wd, int* __restrict__ wi, int* __restrict__ idx_out, double* __restrict__ dist_out) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= npt) return;
+  const long P = npt;
+  const double qx = px[t], qy = py[t], qz = (NDIM == 3) ? pz[t] : 0.0;
+  int cnt = 0;
+  double worst = 1e300;
+  for (int j = 0; j < N; ++j) {
+    const double dx = qx - xs[j], dy = qy - ys[j];
+    double d2 = dx * dx + dy * dy;
+    if (NDIM == 3) {
+      const double dz = qz - zs[j];
+      d2 += dz * dz;
+    }
+    if (cnt < K || d2 < worst) {
+      int p = (cnt < K) ? cnt : K - 1;
+      while (p > 0) {
+        const double prev = wd[(long)(p - 1) * P + t];
+        if (!(prev > d2)) break;
+        wd[(long)p * P + t] = prev;
+        wi[(long)p * P + t] = wi[(long)(p - 1) * P + t];
+        --p;
+      }
+      wd[(long)p * P + t] = d2;
+      wi[(long)p * P + t] = j;
+      if (cnt < K) ++cnt;
+      if (cnt == K) worst = wd[(long)(K - 1) * P + t];
+    }
+  }
+  for (int q = 0; q < K; ++q) {
+    idx_out[(long)t * K + q] = wi[(long)q * P + t];
+    dist_out[(long)t * K + q] = sqrt(wd[(long)q * P + t]);
+  }
+}
+
+template <int MODEL>
+__global__ void __launch_bounds__(256) k_mw_solve_big(MwArgs a, double* __restrict__ scratch) {
+  extern __shared__ double mwb_lds[];  // mul[nb] | x[nb] | sel[nb] (ints)
+  const int K = a.K, nb = K + 1, st = nb + 1, l = threadIdx.x;
+  double* mul = mwb_lds;
+  double* xv = mul + nb;
+  int* sel = reinterpret_cast<int*>(xv + nb);
+  double* aug = scratch + (long)blockIdx.x * nb * st;
+  __shared__ double redv[4];
+  __shared__ int redr[4];
+  int bad = 0;
+  for (long pt = blockIdx.x; pt < a.npt; pt += gridDim.x) {
+    __syncthreads();
+    for (int r = l; r < K; r += 256) sel[r] = a.idx[pt * K + r];
+    __syncthreads();
+    for (long e = l; e < (long)nb * nb; e += 256) {
+      const int r = (int)(e / nb), c = (int)(e - (long)r * nb);
+      double v;
+      if (r < K && c < K) v = (r == c) ? 0.0 : a.A[(long)sel[r] * a.ld + sel[c]];
+      else v = (r == K && c == K) ? 0.0 : 1.0;
+      aug[(long)r * st + c] = v;
+    }
+    for (int r = l; r < nb; r += 256) {
+      double b = 1.0;
+      if (r < K) {
+        const double d = a.dist[pt * K + r];
+        b = -vario<MODEL, false>(a.v, d, d * d);
+        if (a.exact && d <= a.eps) b = 0.0;
+      }
+      aug[(long)r * st + nb] = b;
+      xv[r] = b;  // kept for ss = -x.b; overwritten by x only after the dot product below uses a copy
+    }
+    __syncthreads();
+    for (int c = 0; c < nb; ++c) {
+      double bv = -1.0;
+      int br = 0x7fffffff;
+      for (int r = c + l; r < nb; r += 256) {
+        const double v = fabs(aug[(long)r * st + c]);
+        if (v > bv) { bv = v; br = r; }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const double v2 = __shfl_xor(bv, o, 64);
+        const int r2 = __shfl_xor(br, o, 64);
+        if (v2 > bv || (v2 == bv && r2 < br)) { bv = v2; br = r2; }
+      }
+      if ((l & 63) == 0) { redv[l >> 6] = bv; redr[l >> 6] = br; }
+      __syncthreads();
+      bv = redv[0];
+      br = redr[0];
+#pragma unroll
+      for (int w = 1; w < 4; ++w)
+        if (redv[w] > bv || (redv[w] == bv && redr[w] < br)) { bv = redv[w]; br = redr[w]; }
+      if (!(bv > 0.0)) bad = 1;
+      if (br != c && br < nb)
+        for (int j = c + l; j <= nb; j += 256) {
+          const double t0 = aug[(long)c * st + j];
+          aug[(long)c * st + j] = aug[(long)br * st + j];
+          aug[(long)br * st + j] = t0;
+        }
+      __syncthreads();
+      const double pinv = 1.0 / aug[(long)c * st + c];
+      for (int r = c + 1 + l; r < nb; r += 256) mul[r] = aug[(long)r * st + c] * pinv;
+      __syncthreads();
+      const int w = nb - c;         // columns c+1 .. nb (incl. the right-hand side)
+      const int rows = nb - c - 1;  // rows below the pivot
+      for (long e = l; e < (long)rows * w; e += 256) {
+        const int r = c + 1 + (int)(e / w), j = c + 1 + (int)(e - (long)(r - c - 1) * w);
+        aug[(long)r * st + j] -= mul[r] * aug[(long)c * st + j];
+      }
+      __syncthreads();
+    }
+    // back substitution, column oriented: x[r] = rhs[r] / U[r][r]; rhs[0..r-1] -= U[0..r-1][r] * x[r]
+    for (int r = nb - 1; r >= 0; --r) {
+      const double x = aug[(long)r * st + nb] / aug[(long)r * st + r];
+      __syncthreads();  // everybody has read rhs[r] before row r-1.. are updated again
+      for (int i = l; i < r; i += 256) aug[(long)i * st + nb] -= aug[(long)i * st + r] * x;
+      if (l == 0) aug[(long)r * st + nb] = x;  // store the solution in place of rhs[r]
+      __syncthreads();
+    }
+    // z = x[:K].Z[sel], ss = -x.b  (block reduction)
+    double zz = 0.0, s2 = 0.0;
+    for (int r = l; r < nb; r += 256) {
+      const double x = aug[(long)r * st + nb];
+      if (r < K) zz += x * a.Z[sel[r]];
+      s2 += x * xv[r];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      zz += __shfl_xor(zz, o, 64);
+      s2 += __shfl_xor(s2, o, 64);
+    }
+    __shared__ double rz[4], rs[4];
+    if ((l & 63) == 0) { rz[l >> 6] = zz; rs[l >> 6] = s2; }
+    __syncthreads();
+    if (l == 0) {
+      a.z[pt] = rz[0] + rz[1] + rz[2] + rz[3];
+      a.ss[pt] = -(rs[0] + rs[1] + rs[2] + rs[3]);
+    }
+  }
+  if (bad && l == 0) atomicOr(a.flag, 1);
+}
+
 // geographic moving window: the neighbour search runs on unit-sphere Cartesian coordinates (ok.py:934-955), the
 // distances handed to the solve are great-circle again (ok.py:962-970)
 __global__ void __launch_bounds__(256) k_geo_unit(const double* __restrict__ lon, const double* __restrict__ lat, int n,

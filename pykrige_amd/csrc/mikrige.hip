@@ -40,6 +40,10 @@ static int fail(int code, const std::string& msg) {
 struct DevBuf {
   void* p = nullptr;
   size_t bytes = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { release(); }
   int ensure(size_t need) {
     if (need <= bytes && p) return MIK_OK;
     if (p) (void)hipFree(p);
@@ -722,7 +726,6 @@ int mik_predict_moving_window(mik_handle* h, int n_closest) {
   if (h->host_inv) return fail(MIK_EINVAL, "moving-window kriging does not use pseudo_inv");
   if (n_closest < 2) return fail(MIK_EINVAL, "n_closest_points has to be at least two!");
   if (n_closest > h->N) return fail(MIK_EINVAL, "n_closest_points exceeds the number of stations");
-  if (n_closest > MIK_MW_KMAX) return fail(MIK_EINVAL, "n_closest_points > 127 is not supported by the device path");
   HIPC(hipSetDevice(h->device));
   MIKC(ensure_factor_buffers(h));
   MIKC(get_events(h, 2));
@@ -741,75 +744,124 @@ int mik_predict_moving_window(mik_handle* h, int n_closest) {
     h->t_state = 1;
     h->have_factor = false;
   }
-  MIKC(h->mw_idx.ensure(sizeof(int) * (size_t)npt * K));
-  MIKC(h->mw_dist.ensure(sizeof(double) * (size_t)npt * K));
+  // K <= MIK_MW_KMAX: candidate lists in registers, systems in LDS, all points in one pass.  Larger K: working sets in
+  // HBM, points in chunks that bound those work arrays to ~2 GB.
+  const bool big = K > MIK_MW_KMAX;
+  const int nb = K + 1;
+  long chunk = npt;
+  if (big) {
+    chunk = ((long)(2e9 / (24.0 * K)) / 256) * 256;
+    if (chunk < 256) chunk = 256;
+    if (chunk > npt) chunk = npt;
+  }
+  MIKC(h->mw_idx.ensure(sizeof(int) * (size_t)chunk * K));
+  MIKC(h->mw_dist.ensure(sizeof(double) * (size_t)chunk * K));
   MIKC(h->flag.ensure(sizeof(int)));
   HIPC(hipMemsetAsync(h->flag.p, 0, sizeof(int), h->stream));
-  const unsigned kgrid = (unsigned)((npt + 255) / 256);
+  DevBuf su, pu, wd, wi, sysbuf;
+  const double *sx = h->xs.as<double>(), *sy = h->ys.as<double>(), *sz = h->zs.as<double>();
+  const double *qx = h->px.as<double>(), *qy = h->py.as<double>(), *qz = h->pz.as<double>();
   if (h->geo) {
     // neighbours by chord length on the unit sphere (same ordering as great-circle), distances recomputed below
-    DevBuf su, pu;
     MIKC(su.ensure(sizeof(double) * 3 * (size_t)h->N));
     MIKC(pu.ensure(sizeof(double) * 3 * (size_t)npt));
     double* s3 = su.as<double>();
     double* p3 = pu.as<double>();
-    hipLaunchKernelGGL(k_geo_unit, dim3((h->N + 255) / 256), dim3(256), 0, h->stream, (const double*)h->xs.as<double>(),
-                       (const double*)h->ys.as<double>(), h->N, s3, s3 + h->N, s3 + 2 * (size_t)h->N);
-    hipLaunchKernelGGL(k_geo_unit, dim3(kgrid), dim3(256), 0, h->stream, (const double*)h->px.as<double>(),
-                       (const double*)h->py.as<double>(), (int)npt, p3, p3 + npt, p3 + 2 * (size_t)npt);
-    hipLaunchKernelGGL(k_mw_knn<3>, dim3(kgrid), dim3(256), 0, h->stream, (const double*)p3, (const double*)(p3 + npt),
-                       (const double*)(p3 + 2 * (size_t)npt), (int)npt, (const double*)s3, (const double*)(s3 + h->N),
-                       (const double*)(s3 + 2 * (size_t)h->N), h->N, K, h->mw_idx.as<int>(), h->mw_dist.as<double>());
-    hipLaunchKernelGGL(k_mw_geo_dist, dim3((unsigned)((npt * K + 255) / 256)), dim3(256), 0, h->stream,
-                       (const double*)h->px.as<double>(), (const double*)h->py.as<double>(), npt, K,
-                       (const double*)h->xs.as<double>(), (const double*)h->ys.as<double>(),
-                       (const int*)h->mw_idx.as<int>(), h->mw_dist.as<double>());
-    HIPC(hipStreamSynchronize(h->stream));  // su / pu are released at scope exit
-    su.release();
-    pu.release();
-  } else if (h->ndim == 3)
-    hipLaunchKernelGGL(k_mw_knn<3>, dim3(kgrid), dim3(256), 0, h->stream, (const double*)h->px.as<double>(),
-                       (const double*)h->py.as<double>(), (const double*)h->pz.as<double>(), (int)npt,
-                       (const double*)h->xs.as<double>(), (const double*)h->ys.as<double>(),
-                       (const double*)h->zs.as<double>(), h->N, K, h->mw_idx.as<int>(), h->mw_dist.as<double>());
-  else
-    hipLaunchKernelGGL(k_mw_knn<2>, dim3(kgrid), dim3(256), 0, h->stream, (const double*)h->px.as<double>(),
-                       (const double*)h->py.as<double>(), (const double*)nullptr, (int)npt,
-                       (const double*)h->xs.as<double>(), (const double*)h->ys.as<double>(), (const double*)nullptr,
-                       h->N, K, h->mw_idx.as<int>(), h->mw_dist.as<double>());
-  MwArgs a{};
-  a.A = h->T.as<double>();
-  a.ld = h->Mp;
-  a.K = K;
-  a.npt = (int)npt;
-  a.idx = h->mw_idx.as<int>();
-  a.dist = h->mw_dist.as<double>();
-  a.Z = h->vals.as<double>();
-  a.v = h->v;
-  a.exact = h->exact;
-  a.eps = h->eps;
-  a.z = h->z.as<double>();
-  a.ss = h->ss.as<double>();
-  a.flag = h->flag.as<int>();
-  const int nb = K + 1;
-  const int tpp = (nb + 1 <= 16) ? 16 : (nb + 1 <= 32) ? 32 : (nb + 1 <= 64) ? 64 : 256;
-  const int ppb = 256 / tpp;
-  const size_t per = (size_t)nb * (nb + 1) + 3 * (size_t)nb;
-  const size_t lds = sizeof(double) * per * ppb;
-  const unsigned grid = (unsigned)((npt + ppb - 1) / ppb);
-  switch (h->model) {
-    case 0: MW_DISPATCH_TPP(0); break;
-    case 1: MW_DISPATCH_TPP(1); break;
-    case 2: MW_DISPATCH_TPP(2); break;
-    case 3: MW_DISPATCH_TPP(3); break;
-    case 4: MW_DISPATCH_TPP(4); break;
-    default: MW_DISPATCH_TPP(5); break;
+    hipLaunchKernelGGL(k_geo_unit, dim3((h->N + 255) / 256), dim3(256), 0, h->stream, sx, sy, h->N, s3, s3 + h->N,
+                       s3 + 2 * (size_t)h->N);
+    hipLaunchKernelGGL(k_geo_unit, dim3((unsigned)((npt + 255) / 256)), dim3(256), 0, h->stream, qx, qy, (int)npt, p3,
+                       p3 + npt, p3 + 2 * (size_t)npt);
+    sx = s3, sy = s3 + h->N, sz = s3 + 2 * (size_t)h->N;
+    qx = p3, qy = p3 + npt, qz = p3 + 2 * (size_t)npt;
   }
-  HIPC(hipGetLastError());
+  const bool three = h->geo || h->ndim == 3;
+  int sgrid = 0;
+  if (big) {
+    MIKC(wd.ensure(sizeof(double) * (size_t)chunk * K));
+    MIKC(wi.ensure(sizeof(int) * (size_t)chunk * K));
+    const double per = 8.0 * nb * (nb + 1.0);
+    long g = (long)(4e9 / per);  // per-block scratch systems, <= ~4 GB in total
+    if (g > 4L * h->n_cu) g = 4L * h->n_cu;
+    if (g > chunk) g = chunk;
+    if (g < 1) g = 1;
+    sgrid = (int)g;
+    MIKC(sysbuf.ensure((size_t)per * (size_t)sgrid));
+  }
+  for (long p0 = 0; p0 < npt; p0 += chunk) {
+    const long pc = (npt - p0 < chunk) ? npt - p0 : chunk;
+    const unsigned kgrid = (unsigned)((pc + 255) / 256);
+    int* idx = h->mw_idx.as<int>();
+    double* dist = h->mw_dist.as<double>();
+    if (big) {
+      if (three)
+        hipLaunchKernelGGL(k_mw_knn_big<3>, dim3(kgrid), dim3(256), 0, h->stream, qx + p0, qy + p0, qz + p0, (int)pc, sx, sy, sz,
+                           h->N, K, wd.as<double>(), wi.as<int>(), idx, dist);
+      else
+        hipLaunchKernelGGL(k_mw_knn_big<2>, dim3(kgrid), dim3(256), 0, h->stream, qx + p0, qy + p0, (const double*)nullptr,
+                           (int)pc, sx, sy, (const double*)nullptr, h->N, K, wd.as<double>(), wi.as<int>(), idx, dist);
+    } else if (three)
+      hipLaunchKernelGGL(k_mw_knn<3>, dim3(kgrid), dim3(256), 0, h->stream, qx + p0, qy + p0, qz + p0, (int)pc, sx, sy, sz,
+                         h->N, K, idx, dist);
+    else
+      hipLaunchKernelGGL(k_mw_knn<2>, dim3(kgrid), dim3(256), 0, h->stream, qx + p0, qy + p0, (const double*)nullptr, (int)pc,
+                         sx, sy, (const double*)nullptr, h->N, K, idx, dist);
+    if (h->geo)
+      hipLaunchKernelGGL(k_mw_geo_dist, dim3((unsigned)((pc * K + 255) / 256)), dim3(256), 0, h->stream,
+                         (const double*)h->px.as<double>() + p0, (const double*)h->py.as<double>() + p0, pc, K,
+                         (const double*)h->xs.as<double>(), (const double*)h->ys.as<double>(), (const int*)idx, dist);
+    MwArgs a{};
+    a.A = h->T.as<double>();
+    a.ld = h->Mp;
+    a.K = K;
+    a.npt = (int)pc;
+    a.idx = idx;
+    a.dist = dist;
+    a.Z = h->vals.as<double>();
+    a.v = h->v;
+    a.exact = h->exact;
+    a.eps = h->eps;
+    a.z = h->z.as<double>() + p0;
+    a.ss = h->ss.as<double>() + p0;
+    a.flag = h->flag.as<int>();
+    if (big) {
+      const size_t lds = sizeof(double) * 2 * (size_t)nb + sizeof(int) * (size_t)nb;
+      if (lds > 150 * 1024) return fail(MIK_EINVAL, "n_closest_points too large for the device path (> ~7600)");
+      const int grid = (int)(pc < sgrid ? pc : sgrid);
+#define MW_BIG(MODEL)                                                                                                \
+  do {                                                                                                               \
+    HIPC(hipFuncSetAttribute((const void*)k_mw_solve_big<MODEL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL((k_mw_solve_big<MODEL>), dim3(grid), dim3(256), lds, h->stream, a, sysbuf.as<double>());      \
+  } while (0)
+      switch (h->model) {
+        case 0: MW_BIG(0); break;
+        case 1: MW_BIG(1); break;
+        case 2: MW_BIG(2); break;
+        case 3: MW_BIG(3); break;
+        case 4: MW_BIG(4); break;
+        default: MW_BIG(5); break;
+      }
+#undef MW_BIG
+    } else {
+      const int tpp = (nb + 1 <= 16) ? 16 : (nb + 1 <= 32) ? 32 : (nb + 1 <= 64) ? 64 : 256;
+      const int ppb = 256 / tpp;
+      const size_t per = (size_t)nb * (nb + 1) + 3 * (size_t)nb;
+      const size_t lds = sizeof(double) * per * ppb;
+      const unsigned grid = (unsigned)((pc + ppb - 1) / ppb);
+      switch (h->model) {
+        case 0: MW_DISPATCH_TPP(0); break;
+        case 1: MW_DISPATCH_TPP(1); break;
+        case 2: MW_DISPATCH_TPP(2); break;
+        case 3: MW_DISPATCH_TPP(3); break;
+        case 4: MW_DISPATCH_TPP(4); break;
+        default: MW_DISPATCH_TPP(5); break;
+      }
+    }
+    HIPC(hipGetLastError());
+  }
   int flag = 0;
   HIPC(hipMemcpyAsync(&flag, h->flag.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIPC(hipEventRecord(h->evpool[1], h->stream));
-  HIPC(hipStreamSynchronize(h->stream));
+  HIPC(hipStreamSynchronize(h->stream));  // also: the scoped work buffers are released only after the stream drained
   float ms = 0.f;
   HIPC(hipEventElapsedTime(&ms, h->evpool[0], h->evpool[1]));
   h->tm.predict_ms = ms;

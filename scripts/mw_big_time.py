@@ -1,0 +1,21 @@
+"""Time the moving-window path for a few window sizes on config-2 stations (GPU box)."""
+import sys, time
+import numpy as np
+sys.path.insert(0, ".")
+from bench import CONFIGS, synth, internal_params
+from pykrige_amd import _lib
+
+cfg = CONFIGS[2]
+coords, values = synth(cfg["seed"], cfg["n"], 2)
+h = _lib.Handle(0)
+h.set_problem(ndim=2, xs=coords[0], ys=coords[1], zs=None, values=values, model_id=_lib.MODEL_IDS[cfg["model"]],
+              params=internal_params(cfg["model"], cfg["params"]))
+rng = np.random.default_rng(0)
+for k, npt in ((10, 1000000), (100, 1000000), (127, 100000), (128, 100000), (200, 100000), (500, 20000), (1000, 4000)):
+    px, py = rng.random(npt), rng.random(npt)
+    h.set_points(px, py, None)
+    h.predict_moving_window(k)
+    t0 = time.perf_counter()
+    h.predict_moving_window(k)
+    dt = time.perf_counter() - t0
+    print("k=%4d  npt=%8d  %9.2f ms  %10.0f points/s" % (k, npt, dt * 1e3, npt / dt), flush=True)
