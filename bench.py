@@ -173,29 +173,86 @@ def main():
     npt = pts[0].size
 
     ndev = _lib.load().mik_device_count()
-    h = _lib.Handle(local_rank % max(ndev, 1))  # one GPU per rank on a real node; wraps only on a 1-GPU test box
-    if args.symmetric is not None:
-        h.set_option("symmetric", args.symmetric)
-    if args.chunk is not None:
-        h.set_option("chunk", args.chunk)
-    if args.engine is not None:
-        h.set_option("engine", 1 if args.engine == "valu" else 0)
-    if args.factor is not None:
-        h.set_option("factor", {"auto": 0, "sweep": 1, "lu": 2}[args.factor])
     wells = np.array(cfg["wells"]) if cfg.get("wells") else None
-    h.set_problem(ndim=ndim, xs=coords[0], ys=coords[1], zs=coords[2] if ndim == 3 else None, values=values,
-                  model_id=_lib.MODEL_IDS[cfg["model"]], params=internal_params(cfg["model"], cfg["params"]),
-                  regional_linear=bool(cfg.get("rl")), wells=wells)
-    h.set_points(pts[0], pts[1], pts[2] if ndim == 3 else None)
 
-    exchange = "none"
-    if world > 1:
-        if os.environ.get("MIK_BENCH_BCAST", "1") == "0":
+    def make_handle():
+        hh = _lib.Handle(local_rank % max(ndev, 1))  # one GPU per rank on a real node; wraps only on a 1-GPU test box
+        if args.symmetric is not None:
+            hh.set_option("symmetric", args.symmetric)
+        if args.chunk is not None:
+            hh.set_option("chunk", args.chunk)
+        if args.engine is not None:
+            hh.set_option("engine", 1 if args.engine == "valu" else 0)
+        if args.factor is not None:
+            hh.set_option("factor", {"auto": 0, "sweep": 1, "lu": 2}[args.factor])
+        hh.set_problem(ndim=ndim, xs=coords[0], ys=coords[1], zs=coords[2] if ndim == 3 else None, values=values,
+                       model_id=_lib.MODEL_IDS[cfg["model"]], params=internal_params(cfg["model"], cfg["params"]),
+                       regional_linear=bool(cfg.get("rl")), wells=wells)
+        hh.set_points(pts[0], pts[1], pts[2] if ndim == 3 else None)
+        return hh
+
+    h = make_handle()
+
+    # How the factored matrix reaches every rank is decided by measurement, outside the timed region: (A) rank 0 factors
+    # and the library broadcasts T and c over RCCL/xGMI, or (B) every rank factors for itself (no collective at all).
+    # Ranks != 0 wait for rank 0's factorisation in (A) anyway, so (A) wins only if the broadcast beats nothing -- it
+    # usually does not, and the trial says so in the JSON.  Every RCCL call of the trial runs under a watchdog: a wedged
+    # bootstrap or collective degrades to (B) on a fresh handle instead of hanging the benchmark.
+    exchange, trial, leaked = "none", None, False
+    if world > 1 and not args.moving_window:
+        mode = os.environ.get("MIK_BENCH_EXCHANGE", "auto")  # auto | rccl | redundant
+        if mode == "redundant":
             exchange = "redundant_factor"
         else:
+            import threading
+
             from pykrige_amd.dist import init_rccl
 
-            exchange = init_rccl(h, pg)  # "rccl_bcast", or "redundant_factor (...)": every rank factors for itself
+            exchange = init_rccl(h, pg)  # "rccl_bcast", or "redundant_factor (...)"
+            if exchange == "rccl_bcast":
+                def watchdog(fn, limit):
+                    box = {}
+
+                    def run():
+                        try:
+                            fn()
+                            box["ok"] = True
+                        except Exception as e:  # noqa: BLE001
+                            box["err"] = repr(e)[:120]
+
+                    th = threading.Thread(target=run, daemon=True)
+                    t0 = time.perf_counter()
+                    th.start()
+                    th.join(limit)
+                    return box.get("ok", False), time.perf_counter() - t0, box.get("err"), th.is_alive()
+
+                def via_bcast():
+                    if rank == 0:
+                        h.factor()
+                    h.bcast_factor(0)
+
+                limit = float(os.environ.get("MIK_RCCL_BCAST_TIMEOUT", "60"))
+                ta = tb = None
+                for _ in range(2):  # first round pays RCCL's lazy channel set-up and the buffer allocations
+                    pg.barrier()
+                    ok, ta, err, hung = watchdog(via_bcast, limit)
+                    res = pg.all_gather_object((ok, ta, err))
+                    if not all(r[0] for r in res):
+                        why = next((r[2] for r in res if r[2]), "broadcast did not finish within %.0f s" % limit)
+                        exchange = "redundant_factor (rccl broadcast failed: %s)" % why
+                        if hung:  # this rank's stream is stuck behind the collective: abandon the handle
+                            leaked = True
+                            h = make_handle()
+                        break
+                    ta = max(r[1] for r in res)
+                    pg.barrier()
+                    t0 = time.perf_counter()
+                    h.factor()
+                    tb = pg.all_reduce_max(time.perf_counter() - t0)
+                if exchange == "rccl_bcast":
+                    trial = {"rccl_bcast_ms": ta * 1e3, "redundant_factor_ms": tb * 1e3}
+                    if mode != "rccl" and tb <= ta:
+                        exchange = "redundant_factor (measured faster than rank-0 factor + RCCL broadcast)"
 
     def sync():
         h.synchronize()  # device idle (mik_predict / mik_bcast_factor already block; this is the explicit bracket)
@@ -276,7 +333,7 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": cfg["name"], "stations": cfg["n"], "matrix_order": M,
                        "grid_points_per_gpu": npt, "grid_points_total": total_pts, "variogram": cfg["model"],
-                       "variogram_parameters": cfg["params"], "factor_exchange": exchange,
+                       "variogram_parameters": cfg["params"], "factor_exchange": exchange, "factor_exchange_trial": trial,
                        "factor_path": {1: "spd-shift block sweep", 2: "pivoted block gauss-jordan", 3: "host inverse"}.get(
                            tsum.get("factor_path"), "?"),
                        "symmetric_contraction": bool(tsum.get("symmetric"))},
@@ -314,6 +371,10 @@ def main():
         emit(json.dumps(out))
     if pg is not None:
         pg.barrier()  # nobody tears its communicator down while another rank is still inside a collective
+    if leaked:  # a handle was abandoned behind a stuck collective: skip every destructor
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
     h.close()
 
 

@@ -158,7 +158,11 @@ def slab_bounds(n, world, rank):
 class ShardedExecutor:
     """execute() of a pykrige_amd kriging object with the points sharded over the ranks of a process group
     (a `SocketGroup`, or a torch.distributed group / None = torch's default group).  Every rank must call execute()
-    with the same arguments; every rank gets the full result."""
+    with the same arguments; every rank gets the full result.
+
+    use_rccl=True: rank 0 factors the kriging matrix and the library broadcasts it over RCCL/xGMI (the other ranks do not
+    repeat the O(M^3) work but wait for it); use_rccl=False: every rank factors for itself and there is no collective on
+    the data path -- never slower in wall-clock on identical GPUs (bench.py measures both and picks)."""
 
     def __init__(self, model, group=None, use_rccl=True, handle_factory=None):
         self.pg = group if isinstance(group, SocketGroup) else _TorchGroup(group)
