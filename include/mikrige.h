@@ -100,7 +100,8 @@ void mik_destroy(mik_handle *h);
 
 /* options: "factor" 0=auto 1=sweep 2=pivoted ; "symmetric" 0/1 (contraction uses A_inv symmetry) ;
  * "engine" 0 = MFMA f64 contraction, 1 = VALU (v_fma_f64) contraction ;
- * "chunk" = points per contraction launch (multiple of 128) */
+ * "chunk" = points per contraction launch (multiple of 128) ;
+ * "mw_lds_cap" = largest moving-window candidate buffer kept in LDS (entries, default 8192; 0 forces the HBM lists) */
 int  mik_set_option(mik_handle *h, const char *key, double value);
 
 int  mik_set_problem(mik_handle *h, const mik_problem *p); /* H2D of stations/values/drifts            */

@@ -1152,50 +1152,104 @@ __global__ void k_selftest_mfma4(double* out /*4x16 row-major*/) {
 // ------------------------------------------------------------------------------------------------
 // Moving-window kriging (n_closest_points; ok.py:929-986, 722-758, cok.pyx:98-193, ok3d.py:697-733).
 //   k_mw_knn   : the k nearest stations of every point, ascending distance (cKDTree.query(k=..., eps=0)),
-//                brute force -- one thread per point, all lanes walk the stations in the same order so the
-//                station coordinates are wave-uniform (scalar) loads; sorted insertion is rare after warm-up.
+//                brute force, one wavefront per point (threshold filter + LDS bitonic cuts, see below).
+//   k_mw_rhs   : right-hand sides -gamma(bd) with the eps rule, in place over the distances.
 //   k_mw_solve : per point the (k+1) x (k+1) system gathered from the assembled kriging matrix
-//                (a_all[sel][:, sel], ones border, zero corner -- cok.pyx:138-147), right-hand side
-//                -gamma(bd) with the eps rule, solved by Gauss-Jordan elimination with partial pivoting
-//                (dgesv's pivot order) in LDS by a group of TPP threads; z = x.Z[sel], ss = -x.b.
+//                (a_all[sel][:, sel], ones border, zero corner -- cok.pyx:138-147), solved by Gauss-Jordan
+//                elimination with partial pivoting (dgesv's pivot choice) in the registers of a G x G thread
+//                grid; z = x.Z[sel], ss = -x.b.
 // ------------------------------------------------------------------------------------------------
 #define MIK_MW_KMAX 127
 
+// One wavefront per point.  The 64 lanes take 64 stations at a time; squared distances below the current K-th best
+// (tau) are appended to an LDS candidate buffer by ballot + prefix count; when the buffer is about to overflow it is
+// bitonic-sorted in LDS and cut back to the best K, which tightens tau.  After the first cut few stations pass the test,
+// so a point costs ~N/64 cheap batches plus two or three small sorts -- no per-lane divergent insertion.
+// CAP (a power of two, >= K + 256) candidates: keys[CAP] doubles then vals[CAP] ints of dynamic LDS.
 template <int NDIM>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64)
 k_mw_knn(const double* __restrict__ px, const double* __restrict__ py, const double* __restrict__ pz, int npt,
-         const double* __restrict__ xs, const double* __restrict__ ys, const double* __restrict__ zs, int N, int K,
+         const double* __restrict__ xs, const double* __restrict__ ys, const double* __restrict__ zs, int N, int K, int CAP,
          int* __restrict__ idx_out, double* __restrict__ dist_out) {
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= npt) return;
-  const double qx = px[t], qy = py[t], qz = (NDIM == 3) ? pz[t] : 0.0;
-  double bd[MIK_MW_KMAX + 1];
-  int bi[MIK_MW_KMAX + 1];
-  int cnt = 0;
-  double worst = 1e300;
-  for (int j = 0; j < N; ++j) {
-    const double dx = qx - xs[j], dy = qy - ys[j];
-    double d2 = dx * dx + dy * dy;
-    if (NDIM == 3) {
-      const double dz = qz - zs[j];
-      d2 += dz * dz;
-    }
-    if (cnt < K || d2 < worst) {
-      int p = (cnt < K) ? cnt : K - 1;
-      while (p > 0 && bd[p - 1] > d2) {
-        bd[p] = bd[p - 1];
-        bi[p] = bi[p - 1];
-        --p;
+  extern __shared__ double knn_lds[];
+  double* keys = knn_lds;
+  int* vals = reinterpret_cast<int*>(keys + CAP);
+  const int l = threadIdx.x;
+  const unsigned long long below = (l == 0) ? 0ull : (~0ull >> (64 - l));
+  // cut back to the best K as soon as ~2K candidates are in (an early, small sort tightens tau for the rest of the scan),
+  // at the latest when the next trip's 256 stations might not fit
+  const int cut_at = min(CAP - 256, max(2 * K, 192));
+  for (long t = blockIdx.x; t < npt; t += gridDim.x) {
+    const double qx = px[t], qy = py[t], qz = (NDIM == 3) ? pz[t] : 0.0;
+    int cnt = 0;
+    double tau = 1e300;
+    for (int j0 = 0;; j0 += 256) {  // the trip after the last batch of stations is the final cut
+      const bool last = j0 >= N;
+      if (!last) {
+        // four batches of 64 stations per trip: their coordinate loads are issued together (the loop is otherwise a
+        // chain of dependent L2 round trips), the appends stay in station order
+        double d2[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int j = j0 + u * 64 + l;
+          d2[u] = 1e300;
+          if (j < N) {
+            const double dx = qx - xs[j], dy = qy - ys[j];
+            d2[u] = dx * dx + dy * dy;
+            if (NDIM == 3) {
+              const double dz = qz - zs[j];
+              d2[u] += dz * dz;
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int j = j0 + u * 64 + l;
+          const bool take = (j < N) && (d2[u] < tau);
+          const unsigned long long m = __ballot(take);
+          if (take) {
+            const int pos = cnt + __popcll(m & below);
+            keys[pos] = d2[u];
+            vals[pos] = j;
+          }
+          cnt += __popcll(m);
+        }
       }
-      bd[p] = d2;
-      bi[p] = j;
-      if (cnt < K) ++cnt;
-      if (cnt == K) worst = bd[K - 1];
+      if (last || cnt > cut_at) {
+        // sort the first S = pow2 >= cnt entries ascending by (distance, station index), keep the best K
+        int S = 64;
+        while (S < cnt) S <<= 1;
+        for (int i = cnt + l; i < S; i += 64) {
+          keys[i] = 1e300;
+          vals[i] = 0x7fffffff;
+        }
+        __syncthreads();
+        for (int k = 2; k <= S; k <<= 1)
+          for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = l; i < (S >> 1); i += 64) {
+              const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1)), hi = lo | j;
+              const double ka = keys[lo], kb = keys[hi];
+              const int va = vals[lo], vb = vals[hi];
+              const bool gt = (ka > kb) || (ka == kb && va > vb);
+              if (gt == ((lo & k) == 0)) {
+                keys[lo] = kb;
+                keys[hi] = ka;
+                vals[lo] = vb;
+                vals[hi] = va;
+              }
+            }
+            __syncthreads();
+          }
+        if (cnt > K) cnt = K;
+        if (cnt == K) tau = keys[K - 1];
+      }
+      if (last) break;
     }
-  }
-  for (int q = 0; q < K; ++q) {
-    idx_out[(long)t * K + q] = bi[q];
-    dist_out[(long)t * K + q] = sqrt(bd[q]);
+    for (int q = l; q < K; q += 64) {
+      idx_out[t * K + q] = vals[q];
+      dist_out[t * K + q] = sqrt(keys[q]);
+    }
+    __syncthreads();  // the buffer is reused by the next point
   }
 }
 
@@ -1214,102 +1268,176 @@ struct MwArgs {
   int* flag;
 };
 
-template <int MODEL, int TPP>
+// right-hand sides in place: dist[e] (distance to the e-th selected station) -> b = -gamma(d), 0 on an exact hit
+// (cok.pyx:150-158 with check_b_vect, cok.pyx:196-203)
+template <int MODEL>
+__global__ void __launch_bounds__(256) k_mw_rhs(double* __restrict__ dist, long n, Vario v, int exact, double eps) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  const double d = dist[e];
+  double b = -vario<MODEL, false>(v, d, d * d);
+  if (exact && d <= eps) b = 0.0;
+  dist[e] = b;
+}
+
+// Per-point solve, register tiled.  A point is worked on by a GY x GX thread grid; thread (ty, tx) keeps the elements
+// (ty + GY i, tx + GX j), i < RI, j < CJ, of the augmented (k+1) x (k+2) system in registers (cyclic distribution: the work
+// stays balanced while the elimination shrinks).  Gauss-Jordan with implicit partial pivoting: at step c the pivot is
+// the largest |a[r][c]| over the rows not used yet (the rows dgesv would look at), the pivot row and the multiplier
+// column go through LDS once (RI + CJ reads per thread for RI x CJ FMAs), rows are never moved, columns <= c are left
+// alone.  Two barriers per step.  x[c] = rhs[perm[c]] / pivot[c] at the end; z = x.Z[sel], ss = -x.b.
+template <int GY, int GX, int RI, int CJ>
 __global__ void __launch_bounds__(256) k_mw_solve(MwArgs a) {
   extern __shared__ double mw_lds[];
-  constexpr int PPB = 256 / TPP;
-  const int g = threadIdx.x / TPP, l = threadIdx.x % TPP;
-  const int K = a.K, nb = K + 1, st = nb + 1;  // augmented row stride (column nb = right-hand side)
-  const int per = nb * st + 2 * nb + nb;       // aug, b copy, multipliers, selection (ints stored as doubles' space)
-  double* aug = mw_lds + (long)g * per;
-  double* bcp = aug + nb * st;
-  double* mul = bcp + nb;
-  int* sel = reinterpret_cast<int*>(mul + nb);
-  __shared__ double redv[4][PPB > 4 ? PPB : 4];
-  __shared__ int redr[4][PPB > 4 ? PPB : 4];
+  constexpr int T = GY * GX, PPB = 256 / T, W = T < 64 ? T : 64, NW = T / W, CJP = (CJ + 1) & ~1;
+  static_assert(RI % 2 == 0 && GY * RI <= 255 && GY <= 16, "row tile");
+  const int K = a.K, nb = K + 1;
+  const int g = threadIdx.x / T, lt = threadIdx.x % T, ty = lt / GX, tx = lt % GX;
+  const int per = (GX * CJP + GY * RI + 16 + 2 * nb + (2 * nb + 1) / 2 + 1) & ~1;
+  // LDS of this point's thread grid.  prow / pcol are stored per owner thread ([tx][j], [ty][i]) so that a thread's
+  // RI + CJ reads per step are contiguous: LDS bandwidth is shared by every wave of the CU and is what bounds this kernel.
+  double* prow = mw_lds + (long)g * per;
+  double* pcol = prow + GX * CJP;
+  unsigned long long* cand = reinterpret_cast<unsigned long long*>(pcol + GY * RI);
+  double* pivv = reinterpret_cast<double*>(cand + 16);
+  double* bvec = pivv + nb;
+  int* perm = reinterpret_cast<int*>(bvec + nb);
+  int* sel = perm + nb;
   const long pt = (long)blockIdx.x * PPB + g;
   const bool live = pt < a.npt;
   if (live) {
-    for (int r = l; r < K; r += TPP) sel[r] = a.idx[pt * K + r];
+    for (int r = lt; r < K; r += T) sel[r] = a.idx[pt * K + r];
+    for (int r = lt; r < nb; r += T) bvec[r] = (r < K) ? a.dist[pt * K + r] : 1.0;  // dist holds b (k_mw_rhs)
   }
   __syncthreads();
-  if (live) {
-    for (int e = l; e < nb * nb; e += TPP) {
-      const int r = e / nb, c = e - r * nb;
-      double v;
-      if (r < K && c < K) v = (r == c) ? 0.0 : a.A[(long)sel[r] * a.ld + sel[c]];
-      else v = (r == K && c == K) ? 0.0 : 1.0;
-      aug[r * st + c] = v;
-    }
-    for (int r = l; r < nb; r += TPP) {
-      double b = 1.0;
-      if (r < K) {
-        const double d = a.dist[pt * K + r];
-        b = -vario<MODEL, false>(a.v, d, d * d);
-        if (a.exact && d <= a.eps) b = 0.0;  // check_b_vect, cok.pyx:196-203
+  double m[RI][CJ];
+  unsigned used = 0;
+#pragma unroll
+  for (int i = 0; i < RI; ++i) {
+    const int row = ty + GY * i;
+    if (row >= nb) used |= 1u << i;  // padding rows never pivot
+#pragma unroll
+    for (int j = 0; j < CJ; ++j) {
+      const int col = tx + GX * j;
+      double v = 0.0;
+      if (live && row < nb && col <= nb) {
+        if (col == nb) v = bvec[row];
+        else if (row < K && col < K) v = (row == col) ? 0.0 : a.A[(long)sel[row] * a.ld + sel[col]];
+        else v = (row == K && col == K) ? 0.0 : 1.0;
       }
-      aug[r * st + nb] = b;
-      bcp[r] = b;
+      m[i][j] = v;
     }
   }
-  __syncthreads();
   int bad = 0;
   for (int c = 0; c < nb; ++c) {
-    // partial pivoting: max |aug[r][c]| over r >= c, first maximum wins (idamax)
-    double bv = -1.0;
-    int br = 0x7fffffff;
-    if (live)
-      for (int r = c + l; r < nb; r += TPP) {
-        const double v = fabs(aug[r * st + c]);
-        if (v > bv) { bv = v; br = r; }
-      }
-    constexpr int W = TPP < 64 ? TPP : 64;
+    const int jj = c / GX, cx = c - jj * GX;  // block-uniform
+    if (tx == cx) {
+      // pivot candidates of this thread's part of column c: one 64-bit key = |value| (low 8 mantissa bits dropped) with
+      // 255 - row in the low byte, so that the maximum key is the largest magnitude and, among equals, the first row
+      unsigned long long best = 0ull;
 #pragma unroll
-    for (int o = W / 2; o > 0; o >>= 1) {
-      const double v2 = __shfl_xor(bv, o, W);
-      const int r2 = __shfl_xor(br, o, W);
-      if (v2 > bv || (v2 == bv && r2 < br)) { bv = v2; br = r2; }
-    }
-    if (TPP > 64) {
-      const int wv = threadIdx.x >> 6;
-      if ((threadIdx.x & 63) == 0) { redv[wv][0] = bv; redr[wv][0] = br; }
-      __syncthreads();
-      bv = redv[0][0];
-      br = redr[0][0];
+      for (int j = 0; j < CJ; ++j)
+        if (j == jj) {
 #pragma unroll
-      for (int w = 1; w < 4; ++w)
-        if (redv[w][0] > bv || (redv[w][0] == bv && redr[w][0] < br)) { bv = redv[w][0]; br = redr[w][0]; }
+          for (int i = 0; i < RI; ++i) {
+            const unsigned long long key = ((unsigned long long)__double_as_longlong(fabs(m[i][j])) & ~0xFFull) |
+                                           (unsigned long long)(255 - (ty + GY * i));
+            if (!((used >> i) & 1u) && key > best) best = key;
+          }
+        }
+      cand[ty] = best;
     }
-    if (live && !(bv > 0.0)) bad = 1;
-    // swap rows c <-> br (columns >= c and the right-hand side), then publish the multipliers
-    if (live && br != c && br < nb)
-      for (int j = c + l; j <= nb; j += TPP) {
-        const double t0 = aug[c * st + j];
-        aug[c * st + j] = aug[br * st + j];
-        aug[br * st + j] = t0;
+    __syncthreads();
+    unsigned long long kb = cand[0];
+#pragma unroll
+    for (int q = 1; q < GY; ++q) {
+      const unsigned long long k2 = cand[q];
+      if (k2 > kb) kb = k2;
+    }
+    if (live && (kb >> 8) == 0ull) bad = 1;
+    const int p = 255 - (int)(kb & 0xFFull);
+    const int ii = p / GY, py = p - ii * GY;
+    if (ty == py) {
+#pragma unroll
+      for (int i = 0; i < RI; ++i)
+        if (i == ii) {
+#pragma unroll
+          for (int j = 0; j < CJ; ++j) prow[tx * CJP + j] = m[i][j];
+        }
+    }
+    if (tx == cx) {
+#pragma unroll
+      for (int j = 0; j < CJ; ++j)
+        if (j == jj) {
+#pragma unroll
+          for (int i = 0; i < RI; ++i) pcol[ty * RI + i] = m[i][j];
+        }
+    }
+    if (lt == 0) perm[c] = p;
+    __syncthreads();
+    double pr[CJ], pc[RI];
+#pragma unroll
+    for (int j = 0; j < CJ; ++j) pr[j] = prow[tx * CJP + j];
+#pragma unroll
+    for (int i = 0; i < RI; ++i) pc[i] = pcol[ty * RI + i];
+    const double pv = prow[cx * CJP + jj], inv = 1.0 / pv;
+    if (lt == 0) pivv[c] = pv;
+    double mul[RI];
+#pragma unroll
+    for (int i = 0; i < RI; ++i) mul[i] = (ty + GY * i == p) ? 0.0 : pc[i] * inv;
+    // columns <= c are done: whole tiles j < jj (block-uniform branch per tile), and in tile jj the threads with tx <= cx
+#pragma unroll
+    for (int j = 0; j < CJ; ++j) {
+      if (j > jj) {
+#pragma unroll
+        for (int i = 0; i < RI; ++i) m[i][j] -= mul[i] * pr[j];
+      } else if (j == jj) {
+        const double prj = (tx > cx) ? pr[j] : 0.0;
+#pragma unroll
+        for (int i = 0; i < RI; ++i) m[i][j] -= mul[i] * prj;
       }
-    __syncthreads();
-    if (live) {
-      const double pinv = 1.0 / aug[c * st + c];
-      for (int r = l; r < nb; r += TPP) mul[r] = (r == c) ? 0.0 : aug[r * st + c] * pinv;
     }
-    __syncthreads();
-    if (live) {
-      const int w = nb - c;  // columns c+1 .. nb (incl. RHS)
-      for (int e = l; e < nb * w; e += TPP) {
-        const int r = e / w, j = c + 1 + (e - r * w);
-        aug[r * st + j] -= mul[r] * aug[c * st + j];  // row c itself has multiplier 0
-      }
-    }
-    __syncthreads();
+    if (ty == py) used |= 1u << ii;
   }
-  if (live && l == 0) {
-    double zz = 0.0, s2 = 0.0;
-    for (int r = 0; r < nb; ++r) {
-      const double x = aug[r * st + nb] / aug[r * st + r];
-      if (r < K) zz += x * a.Z[sel[r]];
-      s2 += x * bcp[r];
+  __syncthreads();
+  {  // solution: the right-hand-side column (col nb) through LDS, indexed by original row
+    const int jn = nb / GX, cn = nb - jn * GX;
+    if (tx == cn) {
+#pragma unroll
+      for (int j = 0; j < CJ; ++j)
+        if (j == jn) {
+#pragma unroll
+          for (int i = 0; i < RI; ++i) pcol[ty * RI + i] = m[i][j];
+        }
     }
+  }
+  __syncthreads();
+  double zz = 0.0, s2 = 0.0;
+  if (live)
+    for (int c = lt; c < nb; c += T) {
+      const int p = perm[c];
+      const double x = pcol[(p % GY) * RI + p / GY] / pivv[c];
+      if (c < K) zz += x * a.Z[sel[c]];
+      s2 += x * bvec[c];
+    }
+#pragma unroll
+  for (int o = W / 2; o > 0; o >>= 1) {
+    zz += __shfl_xor(zz, o, W);
+    s2 += __shfl_xor(s2, o, W);
+  }
+  if (T > 64) {
+    __syncthreads();
+    if ((lt & 63) == 0) { pivv[lt >> 6] = zz; prow[lt >> 6] = s2; }
+    __syncthreads();
+    zz = pivv[0];
+    s2 = prow[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) {
+      zz += pivv[w];
+      s2 += prow[w];
+    }
+  }
+  if (live && lt == 0) {
     a.z[pt] = zz;
     a.ss[pt] = -s2;
     if (bad) atomicOr(a.flag, 1);
@@ -1362,7 +1490,6 @@ k_mw_knn_big(const double* __restrict__ px, const double* __restrict__ py, const
   }
 }
 
-template <int MODEL>
 __global__ void __launch_bounds__(256) k_mw_solve_big(MwArgs a, double* __restrict__ scratch) {
   extern __shared__ double mwb_lds[];  // mul[nb] | x[nb] | sel[nb] (ints)
   const int K = a.K, nb = K + 1, st = nb + 1, l = threadIdx.x;
@@ -1385,14 +1512,9 @@ __global__ void __launch_bounds__(256) k_mw_solve_big(MwArgs a, double* __restri
       aug[(long)r * st + c] = v;
     }
     for (int r = l; r < nb; r += 256) {
-      double b = 1.0;
-      if (r < K) {
-        const double d = a.dist[pt * K + r];
-        b = -vario<MODEL, false>(a.v, d, d * d);
-        if (a.exact && d <= a.eps) b = 0.0;
-      }
+      const double b = (r < K) ? a.dist[pt * K + r] : 1.0;  // dist holds b (k_mw_rhs)
       aug[(long)r * st + nb] = b;
-      xv[r] = b;  // kept for ss = -x.b; overwritten by x only after the dot product below uses a copy
+      xv[r] = b;  // kept for ss = -x.b
     }
     __syncthreads();
     for (int c = 0; c < nb; ++c) {

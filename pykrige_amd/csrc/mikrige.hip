@@ -130,6 +130,7 @@ struct mik_handle {
   int opt_waves = 8;  // waves per contraction block: 4 (wave tile 64x64) or 8 (32x64)
   int opt_factor = 0, opt_sym = 1, opt_engine = 0;  // engine: 0 = v_mfma_f64 contraction, 1 = v_fma_f64 (VALU) contraction
   long opt_chunk = 131072;
+  int opt_mw_lds_cap = 8192;  // largest candidate buffer the moving-window neighbour search keeps in LDS
   mik_timing tm{};
   std::vector<hipEvent_t> evpool;
   // comm
@@ -191,6 +192,31 @@ static double host_vario(const Vario& v, double d) {
       }                                                                                                     \
     }                                                                                                       \
   } while (0)
+
+template <int GY, int GX, int RI, int CJ>
+static int launch_mw_solve(mik_handle* h, const MwArgs& a, long pc) {
+  constexpr int T = GY * GX, PPB = 256 / T, CJP = (CJ + 1) & ~1;
+  const int nb = a.K + 1;
+  if (nb > GY * RI || nb + 1 > GX * CJ) return fail(MIK_EINVAL, "moving-window solve class too small for this window");
+  const size_t per = ((size_t)GX * CJP + (size_t)GY * RI + 16 + 2 * (size_t)nb + (2 * (size_t)nb + 1) / 2 + 1) & ~(size_t)1;
+  const size_t lds = sizeof(double) * per * PPB;
+  HIPC(hipFuncSetAttribute((const void*)k_mw_solve<GY, GX, RI, CJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL((k_mw_solve<GY, GX, RI, CJ>), dim3((unsigned)((pc + PPB - 1) / PPB)), dim3(256), lds, h->stream, a);
+  return MIK_OK;
+}
+
+// thread-grid / register-tile classes of k_mw_solve, {GY, GX, RI, CJ} covers nb <= GY*RI and nb + 1 <= GX*CJ.  Measured
+// on MI355X (scripts/mw_classes.py history in DESIGN.md): the classes whose tile fits the VGPR file without AGPR spills
+// win, and among those the one with the fewest threads per point.
+static int dispatch_mw_solve(mik_handle* h, const MwArgs& a, long pc) {
+  const int nb = a.K + 1;
+  if (nb <= 16) return launch_mw_solve<4, 4, 4, 5>(h, a, pc);   // 16 threads per point
+  if (nb <= 32) return launch_mw_solve<8, 8, 4, 5>(h, a, pc);   // 64
+  if (nb <= 48) return launch_mw_solve<8, 8, 6, 7>(h, a, pc);   // 64
+  if (nb <= 64) return launch_mw_solve<8, 8, 8, 9>(h, a, pc);   // 64
+  if (nb <= 96) return launch_mw_solve<16, 16, 6, 7>(h, a, pc); // 256
+  return launch_mw_solve<16, 16, 8, 9>(h, a, pc);               // 256, nb <= 128
+}
 
 extern "C" {
 
@@ -259,6 +285,9 @@ int mik_set_option(mik_handle* h, const char* key, double value) {
   } else if (!strcmp(key, "chunk")) {
     if (value < 128) return fail(MIK_EINVAL, "chunk must be >= 128");
     h->opt_chunk = ((long)value / 128) * 128;
+  } else if (!strcmp(key, "mw_lds_cap")) {
+    if (value < 0 || value > 8192) return fail(MIK_EINVAL, "mw_lds_cap must be in 0..8192");
+    h->opt_mw_lds_cap = (int)value;
   } else {
     return fail(MIK_EINVAL, std::string("unknown option ") + key);
   }
@@ -705,20 +734,6 @@ int mik_predict(mik_handle* h) {
 }
 
 
-#define MW_LAUNCH(MODEL, TPP)                                                                                  \
-  do {                                                                                                         \
-    HIPC(hipFuncSetAttribute((const void*)k_mw_solve<MODEL, TPP>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                             (int)lds));                                                                       \
-    hipLaunchKernelGGL((k_mw_solve<MODEL, TPP>), dim3(grid), dim3(256), lds, h->stream, a);                    \
-  } while (0)
-#define MW_DISPATCH_TPP(MODEL)                 \
-  do {                                         \
-    if (tpp == 16) MW_LAUNCH(MODEL, 16);       \
-    else if (tpp == 32) MW_LAUNCH(MODEL, 32);  \
-    else if (tpp == 64) MW_LAUNCH(MODEL, 64);  \
-    else MW_LAUNCH(MODEL, 256);                \
-  } while (0)
-
 int mik_predict_moving_window(mik_handle* h, int n_closest) {
   if (!h || !h->have_problem) return fail(MIK_ESTATE, "mik_predict_moving_window: set the problem first");
   if (!h->have_points) return fail(MIK_ESTATE, "mik_predict_moving_window: set points first");
@@ -776,9 +791,14 @@ int mik_predict_moving_window(mik_handle* h, int n_closest) {
   }
   const bool three = h->geo || h->ndim == 3;
   int sgrid = 0;
-  if (big) {
+  int cap = 512;  // candidate buffer of the wave-per-point neighbour search: a power of two >= K + 256
+  while (cap < K + 256) cap <<= 1;
+  const bool wave_knn = cap <= h->opt_mw_lds_cap;  // default 8192 = 96 KB of LDS; beyond that the lists live in HBM
+  if (!wave_knn) {
     MIKC(wd.ensure(sizeof(double) * (size_t)chunk * K));
     MIKC(wi.ensure(sizeof(int) * (size_t)chunk * K));
+  }
+  if (big) {
     const double per = 8.0 * nb * (nb + 1.0);
     long g = (long)(4e9 / per);  // per-block scratch systems, <= ~4 GB in total
     if (g > 4L * h->n_cu) g = 4L * h->n_cu;
@@ -792,19 +812,27 @@ int mik_predict_moving_window(mik_handle* h, int n_closest) {
     const unsigned kgrid = (unsigned)((pc + 255) / 256);
     int* idx = h->mw_idx.as<int>();
     double* dist = h->mw_dist.as<double>();
-    if (big) {
+    if (!wave_knn) {
       if (three)
         hipLaunchKernelGGL(k_mw_knn_big<3>, dim3(kgrid), dim3(256), 0, h->stream, qx + p0, qy + p0, qz + p0, (int)pc, sx, sy, sz,
                            h->N, K, wd.as<double>(), wi.as<int>(), idx, dist);
       else
         hipLaunchKernelGGL(k_mw_knn_big<2>, dim3(kgrid), dim3(256), 0, h->stream, qx + p0, qy + p0, (const double*)nullptr,
                            (int)pc, sx, sy, (const double*)nullptr, h->N, K, wd.as<double>(), wi.as<int>(), idx, dist);
-    } else if (three)
-      hipLaunchKernelGGL(k_mw_knn<3>, dim3(kgrid), dim3(256), 0, h->stream, qx + p0, qy + p0, qz + p0, (int)pc, sx, sy, sz,
-                         h->N, K, idx, dist);
-    else
-      hipLaunchKernelGGL(k_mw_knn<2>, dim3(kgrid), dim3(256), 0, h->stream, qx + p0, qy + p0, (const double*)nullptr, (int)pc,
-                         sx, sy, (const double*)nullptr, h->N, K, idx, dist);
+    } else {
+      const long wg = 32L * h->n_cu;
+      const unsigned wgrid = (unsigned)(pc < wg ? pc : wg);
+      const size_t klds = (size_t)cap * (sizeof(double) + sizeof(int));
+      if (three) {
+        HIPC(hipFuncSetAttribute((const void*)k_mw_knn<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)klds));
+        hipLaunchKernelGGL(k_mw_knn<3>, dim3(wgrid), dim3(64), klds, h->stream, qx + p0, qy + p0, qz + p0, (int)pc, sx, sy, sz,
+                           h->N, K, cap, idx, dist);
+      } else {
+        HIPC(hipFuncSetAttribute((const void*)k_mw_knn<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)klds));
+        hipLaunchKernelGGL(k_mw_knn<2>, dim3(wgrid), dim3(64), klds, h->stream, qx + p0, qy + p0, (const double*)nullptr,
+                           (int)pc, sx, sy, (const double*)nullptr, h->N, K, cap, idx, dist);
+      }
+    }
     if (h->geo)
       hipLaunchKernelGGL(k_mw_geo_dist, dim3((unsigned)((pc * K + 255) / 256)), dim3(256), 0, h->stream,
                          (const double*)h->px.as<double>() + p0, (const double*)h->py.as<double>() + p0, pc, K,
@@ -823,38 +851,26 @@ int mik_predict_moving_window(mik_handle* h, int n_closest) {
     a.z = h->z.as<double>() + p0;
     a.ss = h->ss.as<double>() + p0;
     a.flag = h->flag.as<int>();
+    {  // right-hand sides in place over the distances
+      const long ne = pc * K;
+      const unsigned rg = (unsigned)((ne + 255) / 256);
+      switch (h->model) {
+        case 0: hipLaunchKernelGGL(k_mw_rhs<0>, dim3(rg), dim3(256), 0, h->stream, dist, ne, h->v, h->exact, h->eps); break;
+        case 1: hipLaunchKernelGGL(k_mw_rhs<1>, dim3(rg), dim3(256), 0, h->stream, dist, ne, h->v, h->exact, h->eps); break;
+        case 2: hipLaunchKernelGGL(k_mw_rhs<2>, dim3(rg), dim3(256), 0, h->stream, dist, ne, h->v, h->exact, h->eps); break;
+        case 3: hipLaunchKernelGGL(k_mw_rhs<3>, dim3(rg), dim3(256), 0, h->stream, dist, ne, h->v, h->exact, h->eps); break;
+        case 4: hipLaunchKernelGGL(k_mw_rhs<4>, dim3(rg), dim3(256), 0, h->stream, dist, ne, h->v, h->exact, h->eps); break;
+        default: hipLaunchKernelGGL(k_mw_rhs<5>, dim3(rg), dim3(256), 0, h->stream, dist, ne, h->v, h->exact, h->eps); break;
+      }
+    }
     if (big) {
       const size_t lds = sizeof(double) * 2 * (size_t)nb + sizeof(int) * (size_t)nb;
       if (lds > 150 * 1024) return fail(MIK_EINVAL, "n_closest_points too large for the device path (> ~7600)");
       const int grid = (int)(pc < sgrid ? pc : sgrid);
-#define MW_BIG(MODEL)                                                                                                \
-  do {                                                                                                               \
-    HIPC(hipFuncSetAttribute((const void*)k_mw_solve_big<MODEL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-    hipLaunchKernelGGL((k_mw_solve_big<MODEL>), dim3(grid), dim3(256), lds, h->stream, a, sysbuf.as<double>());      \
-  } while (0)
-      switch (h->model) {
-        case 0: MW_BIG(0); break;
-        case 1: MW_BIG(1); break;
-        case 2: MW_BIG(2); break;
-        case 3: MW_BIG(3); break;
-        case 4: MW_BIG(4); break;
-        default: MW_BIG(5); break;
-      }
-#undef MW_BIG
+      HIPC(hipFuncSetAttribute((const void*)k_mw_solve_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(k_mw_solve_big, dim3(grid), dim3(256), lds, h->stream, a, sysbuf.as<double>());
     } else {
-      const int tpp = (nb + 1 <= 16) ? 16 : (nb + 1 <= 32) ? 32 : (nb + 1 <= 64) ? 64 : 256;
-      const int ppb = 256 / tpp;
-      const size_t per = (size_t)nb * (nb + 1) + 3 * (size_t)nb;
-      const size_t lds = sizeof(double) * per * ppb;
-      const unsigned grid = (unsigned)((pc + ppb - 1) / ppb);
-      switch (h->model) {
-        case 0: MW_DISPATCH_TPP(0); break;
-        case 1: MW_DISPATCH_TPP(1); break;
-        case 2: MW_DISPATCH_TPP(2); break;
-        case 3: MW_DISPATCH_TPP(3); break;
-        case 4: MW_DISPATCH_TPP(4); break;
-        default: MW_DISPATCH_TPP(5); break;
-      }
+      MIKC(dispatch_mw_solve(h, a, pc));
     }
     HIPC(hipGetLastError());
   }

@@ -321,6 +321,24 @@ def test_moving_window_matches_reference(name):
             np.testing.assert_allclose(z, g[key], rtol=0, atol=Z_TOL)
             np.testing.assert_allclose(ss, g["ss_k%d" % k], rtol=0, atol=SS_TOL)
     if name == "mw_ok2d":
+        # the HBM-resident neighbour lists (taken on their own only when k + 256 > 8192) forced for small windows as well
+        from pykrige_amd import _lib as lib
+
+        old = lib.Handle.set_problem
+
+        def forced(self, *a, **kw):
+            self.set_option("mw_lds_cap", 0)
+            return old(self, *a, **kw)
+
+        lib.Handle.set_problem = forced
+        try:
+            m2 = fx.amd_model_from(name, g)
+            for k in (10, 200):
+                z, ss = m2.execute("grid", *axes, backend="loop", n_closest_points=k)
+                np.testing.assert_allclose(z, g["z_k%d" % k], rtol=0, atol=Z_TOL)
+                np.testing.assert_allclose(ss, g["ss_k%d" % k], rtol=0, atol=SS_TOL)
+        finally:
+            lib.Handle.set_problem = old
         zm, ssm = m.execute("masked", *axes, mask=g["mask"], backend="loop", n_closest_points=10)
         keep = ~g["mask"]
         np.testing.assert_allclose(np.ma.getdata(zm)[keep], g["zm_k10"][keep], rtol=0, atol=Z_TOL)
