@@ -1154,8 +1154,8 @@ __global__ void k_selftest_mfma4(double* out /*4x16 row-major*/) {
 //   k_mw_knn   : the k nearest stations of every point, ascending distance (cKDTree.query(k=..., eps=0)),
 //                brute force, one wavefront per point (threshold filter + LDS bitonic cuts, see below).
 //   k_mw_rhs   : right-hand sides -gamma(bd) with the eps rule, in place over the distances.
-//   k_mw_solve : per point the (k+1) x (k+1) system gathered from the assembled kriging matrix
-//                (a_all[sel][:, sel], ones border, zero corner -- cok.pyx:138-147), solved by Gauss-Jordan
+//   k_mw_solve : per point the (k+1) x (k+1) system (a_all[sel][:, sel] computed from the selected stations'
+//                coordinates, ones border, zero corner -- cok.pyx:138-147), solved by Gauss-Jordan
 //                elimination with partial pivoting (dgesv's pivot choice) in the registers of a G x G thread
 //                grid; z = x.Z[sel], ss = -x.b.
 // ------------------------------------------------------------------------------------------------
@@ -1254,8 +1254,8 @@ k_mw_knn(const double* __restrict__ px, const double* __restrict__ py, const dou
 }
 
 struct MwArgs {
-  const double* A;  // assembled kriging matrix (shift 0), ld
-  long ld;
+  const double *sx, *sy, *sz;  // station coordinates (adjusted); geographic: lon, lat in degrees
+  int mode;                    // 2 / 3 = Euclidean dimension, 1 = geographic (great-circle degrees)
   int K, npt;
   const int* idx;
   const double* dist;
@@ -1267,6 +1267,34 @@ struct MwArgs {
   double* ss;
   int* flag;
 };
+
+// variogram selected at run time (a wave-uniform switch; the moving-window kernels are not instantiated per model)
+__device__ __forceinline__ double vario_dyn(const Vario& v, double d, double d2) {
+  switch (v.model) {
+    case 0: return vario<0, false>(v, d, d2);
+    case 1: return vario<1, false>(v, d, d2);
+    case 2: return vario<2, false>(v, d, d2);
+    case 3: return vario<3, false>(v, d, d2);
+    case 4: return vario<4, false>(v, d, d2);
+    default: return vario<5, false>(v, d, d2);
+  }
+}
+// entry (r, c), r != c, of a point's local kriging matrix: -gamma(distance between two selected stations), the value
+// a_all[sel[r], sel[c]] of the reference (ok.py:626-648 then cok.pyx:138-147) computed from the coordinates, so that the
+// moving window needs no N x N matrix.  (x, y, z) = adjusted coordinates, or (lon, cos lat, sin lat) when geographic.
+__device__ __forceinline__ double mw_entry(const Vario& v, int mode, double x1, double y1, double z1, double x2, double y2,
+                                           double z2) {
+  double d, d2;
+  if (mode == 1) {
+    d = gc_dist(x1, y1, z1, x2, y2, z2);
+    d2 = d * d;
+  } else {
+    const double dx = x1 - x2, dy = y1 - y2, dz = z1 - z2;  // z = 0 in 2-D
+    d2 = dx * dx + dy * dy + dz * dz;
+    d = sqrt(d2);
+  }
+  return -vario_dyn(v, d, d2);
+}
 
 // right-hand sides in place: dist[e] (distance to the e-th selected station) -> b = -gamma(d), 0 on an exact hit
 // (cok.pyx:150-158 with check_b_vect, cok.pyx:196-203)
@@ -1293,7 +1321,7 @@ __global__ void __launch_bounds__(256) k_mw_solve(MwArgs a) {
   static_assert(RI % 2 == 0 && GY * RI <= 255 && GY <= 16, "row tile");
   const int K = a.K, nb = K + 1;
   const int g = threadIdx.x / T, lt = threadIdx.x % T, ty = lt / GX, tx = lt % GX;
-  const int per = (GX * CJP + GY * RI + 16 + 2 * nb + (2 * nb + 1) / 2 + 1) & ~1;
+  const int per = (GX * CJP + GY * RI + 16 + 5 * nb + (2 * nb + 1) / 2 + 1) & ~1;
   // LDS of this point's thread grid.  prow / pcol are stored per owner thread ([tx][j], [ty][i]) so that a thread's
   // RI + CJ reads per step are contiguous: LDS bandwidth is shared by every wave of the CU and is what bounds this kernel.
   double* prow = mw_lds + (long)g * per;
@@ -1301,12 +1329,27 @@ __global__ void __launch_bounds__(256) k_mw_solve(MwArgs a) {
   unsigned long long* cand = reinterpret_cast<unsigned long long*>(pcol + GY * RI);
   double* pivv = reinterpret_cast<double*>(cand + 16);
   double* bvec = pivv + nb;
-  int* perm = reinterpret_cast<int*>(bvec + nb);
+  double* csx = bvec + nb;  // coordinates of the selected stations
+  double* csy = csx + nb;
+  double* csz = csy + nb;
+  int* perm = reinterpret_cast<int*>(csz + nb);
   int* sel = perm + nb;
   const long pt = (long)blockIdx.x * PPB + g;
   const bool live = pt < a.npt;
   if (live) {
-    for (int r = lt; r < K; r += T) sel[r] = a.idx[pt * K + r];
+    for (int r = lt; r < K; r += T) {
+      const int st = a.idx[pt * K + r];
+      sel[r] = st;
+      double y = a.sy[st], z = (a.mode == 3) ? a.sz[st] : 0.0;
+      if (a.mode == 1) {
+        const double lat = y * MIK_PI / 180.0;
+        y = cos(lat);
+        z = sin(lat);
+      }
+      csx[r] = a.sx[st];
+      csy[r] = y;
+      csz[r] = z;
+    }
     for (int r = lt; r < nb; r += T) bvec[r] = (r < K) ? a.dist[pt * K + r] : 1.0;  // dist holds b (k_mw_rhs)
   }
   __syncthreads();
@@ -1322,7 +1365,8 @@ __global__ void __launch_bounds__(256) k_mw_solve(MwArgs a) {
       double v = 0.0;
       if (live && row < nb && col <= nb) {
         if (col == nb) v = bvec[row];
-        else if (row < K && col < K) v = (row == col) ? 0.0 : a.A[(long)sel[row] * a.ld + sel[col]];
+        else if (row < K && col < K)
+          v = (row == col) ? 0.0 : mw_entry(a.v, a.mode, csx[row], csy[row], csz[row], csx[col], csy[col], csz[col]);
         else v = (row == K && col == K) ? 0.0 : 1.0;
       }
       m[i][j] = v;
@@ -1507,8 +1551,20 @@ __global__ void __launch_bounds__(256) k_mw_solve_big(MwArgs a, double* __restri
     for (long e = l; e < (long)nb * nb; e += 256) {
       const int r = (int)(e / nb), c = (int)(e - (long)r * nb);
       double v;
-      if (r < K && c < K) v = (r == c) ? 0.0 : a.A[(long)sel[r] * a.ld + sel[c]];
-      else v = (r == K && c == K) ? 0.0 : 1.0;
+      if (r < K && c < K) {
+        v = 0.0;
+        if (r != c) {
+          const int s1 = sel[r], s2 = sel[c];
+          double y1 = a.sy[s1], y2 = a.sy[s2], z1 = (a.mode == 3) ? a.sz[s1] : 0.0, z2 = (a.mode == 3) ? a.sz[s2] : 0.0;
+          if (a.mode == 1) {
+            const double la1 = y1 * MIK_PI / 180.0, la2 = y2 * MIK_PI / 180.0;
+            y1 = cos(la1), z1 = sin(la1), y2 = cos(la2), z2 = sin(la2);
+          }
+          v = mw_entry(a.v, a.mode, a.sx[s1], y1, z1, a.sx[s2], y2, z2);
+        }
+      } else {
+        v = (r == K && c == K) ? 0.0 : 1.0;
+      }
       aug[(long)r * st + c] = v;
     }
     for (int r = l; r < nb; r += 256) {

@@ -198,7 +198,7 @@ static int launch_mw_solve(mik_handle* h, const MwArgs& a, long pc) {
   constexpr int T = GY * GX, PPB = 256 / T, CJP = (CJ + 1) & ~1;
   const int nb = a.K + 1;
   if (nb > GY * RI || nb + 1 > GX * CJ) return fail(MIK_EINVAL, "moving-window solve class too small for this window");
-  const size_t per = ((size_t)GX * CJP + (size_t)GY * RI + 16 + 2 * (size_t)nb + (2 * (size_t)nb + 1) / 2 + 1) & ~(size_t)1;
+  const size_t per = ((size_t)GX * CJP + (size_t)GY * RI + 16 + 5 * (size_t)nb + (2 * (size_t)nb + 1) / 2 + 1) & ~(size_t)1;
   const size_t lds = sizeof(double) * per * PPB;
   HIPC(hipFuncSetAttribute((const void*)k_mw_solve<GY, GX, RI, CJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL((k_mw_solve<GY, GX, RI, CJ>), dim3((unsigned)((pc + PPB - 1) / PPB)), dim3(256), lds, h->stream, a);
@@ -742,7 +742,6 @@ int mik_predict_moving_window(mik_handle* h, int n_closest) {
   if (n_closest < 2) return fail(MIK_EINVAL, "n_closest_points has to be at least two!");
   if (n_closest > h->N) return fail(MIK_EINVAL, "n_closest_points exceeds the number of stations");
   HIPC(hipSetDevice(h->device));
-  MIKC(ensure_factor_buffers(h));
   MIKC(get_events(h, 2));
   const long npt = h->npt;
   const int K = n_closest;
@@ -754,11 +753,9 @@ int mik_predict_moving_window(mik_handle* h, int n_closest) {
     return MIK_OK;
   }
   HIPC(hipEventRecord(h->evpool[0], h->stream));
-  if (h->t_state != 1) {  // a_all = self._get_kriging_matrix(n): the plain matrix, not its inverse
-    MIKC(launch_assemble(h, 0.0));
-    h->t_state = 1;
-    h->have_factor = false;
-  }
+  // The reference cuts each point's system out of a_all = self._get_kriging_matrix(n); here its entries are computed
+  // from the selected stations' coordinates, so no N x N matrix exists on this path (and a factor held by the handle
+  // stays valid).
   // K <= MIK_MW_KMAX: candidate lists in registers, systems in LDS, all points in one pass.  Larger K: working sets in
   // HBM, points in chunks that bound those work arrays to ~2 GB.
   const bool big = K > MIK_MW_KMAX;
@@ -838,8 +835,10 @@ int mik_predict_moving_window(mik_handle* h, int n_closest) {
                          (const double*)h->px.as<double>() + p0, (const double*)h->py.as<double>() + p0, pc, K,
                          (const double*)h->xs.as<double>(), (const double*)h->ys.as<double>(), (const int*)idx, dist);
     MwArgs a{};
-    a.A = h->T.as<double>();
-    a.ld = h->Mp;
+    a.sx = h->xs.as<double>();
+    a.sy = h->ys.as<double>();
+    a.sz = h->zs.as<double>();
+    a.mode = h->geo ? 1 : h->ndim;
     a.K = K;
     a.npt = (int)pc;
     a.idx = idx;
