@@ -1161,17 +1161,32 @@ __global__ void k_selftest_mfma4(double* out /*4x16 row-major*/) {
 // ------------------------------------------------------------------------------------------------
 #define MIK_MW_KMAX 127
 
-// One wavefront per point.  The 64 lanes take 64 stations at a time; squared distances below the current K-th best
-// (tau) are appended to an LDS candidate buffer by ballot + prefix count; when the buffer is about to overflow it is
-// bitonic-sorted in LDS and cut back to the best K, which tightens tau.  After the first cut few stations pass the test,
-// so a point costs ~N/64 cheap batches plus two or three small sorts -- no per-lane divergent insertion.
+// One wavefront per point over a uniform grid of station cells (stations sorted by cell on the host, cstart[] = first
+// sorted position of every cell).  Rings of cells around the point's cell are visited outwards; a ring row is one
+// contiguous range of sorted stations.  The 64 lanes take 64 stations at a time; squared distances not above the current
+// K-th best (tau) are appended to an LDS candidate buffer by ballot + prefix count; the buffer is bitonic-sorted in LDS
+// and cut back to the best K when it is about to overflow and at the end of every ring that has >= K candidates, which
+// tightens tau.  Any station outside rings 0..r is at least r * cell away, so the search stops as soon as
+// tau <= (r * cell)^2: the work per point follows K, not N.  A 1-cell grid is the plain brute-force scan.
+// Ties are broken by station index (what a scan in index order would keep).
 // CAP (a power of two, >= K + 256) candidates: keys[CAP] doubles then vals[CAP] ints of dynamic LDS.
+struct KnnArgs {
+  const double *px, *py, *pz;  // points (this chunk)
+  int npt;
+  const double *gx, *gy, *gz;  // stations sorted by cell
+  const int* orig;             // sorted position -> station index
+  const int* cstart;           // ncell + 1
+  int N, K, CAP;
+  int nx, ny, nz;
+  double x0, y0, z0, inv_cell, cell2;  // grid origin, 1 / cell edge, cell edge squared
+  int* idx_out;
+  double* dist_out;
+};
+
 template <int NDIM>
-__global__ void __launch_bounds__(64)
-k_mw_knn(const double* __restrict__ px, const double* __restrict__ py, const double* __restrict__ pz, int npt,
-         const double* __restrict__ xs, const double* __restrict__ ys, const double* __restrict__ zs, int N, int K, int CAP,
-         int* __restrict__ idx_out, double* __restrict__ dist_out) {
+__global__ void __launch_bounds__(64) k_mw_knn(KnnArgs a) {
   extern __shared__ double knn_lds[];
+  const int K = a.K, CAP = a.CAP;
   double* keys = knn_lds;
   int* vals = reinterpret_cast<int*>(keys + CAP);
   const int l = threadIdx.x;
@@ -1179,75 +1194,105 @@ k_mw_knn(const double* __restrict__ px, const double* __restrict__ py, const dou
   // cut back to the best K as soon as ~2K candidates are in (an early, small sort tightens tau for the rest of the scan),
   // at the latest when the next trip's 256 stations might not fit
   const int cut_at = min(CAP - 256, max(2 * K, 192));
-  for (long t = blockIdx.x; t < npt; t += gridDim.x) {
-    const double qx = px[t], qy = py[t], qz = (NDIM == 3) ? pz[t] : 0.0;
+  for (long t = blockIdx.x; t < a.npt; t += gridDim.x) {
+    const double qx = a.px[t], qy = a.py[t], qz = (NDIM == 3) ? a.pz[t] : 0.0;
     int cnt = 0;
     double tau = 1e300;
-    for (int j0 = 0;; j0 += 256) {  // the trip after the last batch of stations is the final cut
-      const bool last = j0 >= N;
-      if (!last) {
-        // four batches of 64 stations per trip: their coordinate loads are issued together (the loop is otherwise a
-        // chain of dependent L2 round trips), the appends stay in station order
+    // sort the first S = pow2 >= cnt entries ascending by (distance, station index), keep the best K
+    auto cut = [&]() {
+      int S = 64;
+      while (S < cnt) S <<= 1;
+      for (int i = cnt + l; i < S; i += 64) {
+        keys[i] = 1e300;
+        vals[i] = 0x7fffffff;
+      }
+      __syncthreads();
+      for (int k = 2; k <= S; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+          for (int i = l; i < (S >> 1); i += 64) {
+            const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1)), hi = lo | j;
+            const double ka = keys[lo], kb = keys[hi];
+            const int va = vals[lo], vb = vals[hi];
+            const bool gt = (ka > kb) || (ka == kb && va > vb);
+            if (gt == ((lo & k) == 0)) {
+              keys[lo] = kb;
+              keys[hi] = ka;
+              vals[lo] = vb;
+              vals[hi] = va;
+            }
+          }
+          __syncthreads();
+        }
+      if (cnt > K) cnt = K;
+      if (cnt == K) tau = keys[K - 1];
+    };
+    // candidates from the sorted stations [beg, end)
+    auto scan = [&](int beg, int end) {
+      for (int j0 = beg; j0 < end; j0 += 256) {
+        // four batches of 64 stations per trip: their coordinate loads are issued together
         double d2[4];
+        int id[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int j = j0 + u * 64 + l;
           d2[u] = 1e300;
-          if (j < N) {
-            const double dx = qx - xs[j], dy = qy - ys[j];
+          id[u] = 0;
+          if (j < end) {
+            const double dx = qx - a.gx[j], dy = qy - a.gy[j];
             d2[u] = dx * dx + dy * dy;
             if (NDIM == 3) {
-              const double dz = qz - zs[j];
+              const double dz = qz - a.gz[j];
               d2[u] += dz * dz;
             }
+            id[u] = a.orig[j];
           }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const int j = j0 + u * 64 + l;
-          const bool take = (j < N) && (d2[u] < tau);
+          const bool take = (j0 + u * 64 + l < end) && (d2[u] <= tau);
           const unsigned long long m = __ballot(take);
           if (take) {
             const int pos = cnt + __popcll(m & below);
             keys[pos] = d2[u];
-            vals[pos] = j;
+            vals[pos] = id[u];
           }
           cnt += __popcll(m);
+          if (j0 + (u + 1) * 64 >= end) break;  // wave-uniform
         }
+        if (cnt > cut_at) cut();
       }
-      if (last || cnt > cut_at) {
-        // sort the first S = pow2 >= cnt entries ascending by (distance, station index), keep the best K
-        int S = 64;
-        while (S < cnt) S <<= 1;
-        for (int i = cnt + l; i < S; i += 64) {
-          keys[i] = 1e300;
-          vals[i] = 0x7fffffff;
-        }
-        __syncthreads();
-        for (int k = 2; k <= S; k <<= 1)
-          for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = l; i < (S >> 1); i += 64) {
-              const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1)), hi = lo | j;
-              const double ka = keys[lo], kb = keys[hi];
-              const int va = vals[lo], vb = vals[hi];
-              const bool gt = (ka > kb) || (ka == kb && va > vb);
-              if (gt == ((lo & k) == 0)) {
-                keys[lo] = kb;
-                keys[hi] = ka;
-                vals[lo] = vb;
-                vals[hi] = va;
-              }
-            }
-            __syncthreads();
+    };
+    const int cx = min(a.nx - 1, max(0, (int)floor((qx - a.x0) * a.inv_cell)));
+    const int cy = min(a.ny - 1, max(0, (int)floor((qy - a.y0) * a.inv_cell)));
+    const int cz = (NDIM == 3) ? min(a.nz - 1, max(0, (int)floor((qz - a.z0) * a.inv_cell))) : 0;
+    for (int r = 0;; ++r) {
+      const int zr = (NDIM == 3) ? r : 0;
+      for (int dz = -zr; dz <= zr; ++dz) {
+        const int z = cz + dz;
+        if (z < 0 || z >= a.nz) continue;
+        for (int dy = -r; dy <= r; ++dy) {
+          const int y = cy + dy;
+          if (y < 0 || y >= a.ny) continue;
+          const long row = ((long)z * a.ny + y) * a.nx;
+          const bool shell = (dy == -r || dy == r || (NDIM == 3 && (dz == -r || dz == r)));
+          if (shell) {  // the whole row of the block is new
+            const int xa = max(0, cx - r), xb = min(a.nx - 1, cx + r);
+            scan(a.cstart[row + xa], a.cstart[row + xb + 1]);
+          } else {      // only its two end cells are
+            if (cx - r >= 0) scan(a.cstart[row + cx - r], a.cstart[row + cx - r + 1]);
+            if (cx + r < a.nx) scan(a.cstart[row + cx + r], a.cstart[row + cx + r + 1]);
           }
-        if (cnt > K) cnt = K;
-        if (cnt == K) tau = keys[K - 1];
+        }
       }
-      if (last) break;
+      const bool all = cx - r <= 0 && cx + r >= a.nx - 1 && cy - r <= 0 && cy + r >= a.ny - 1 &&
+                       (NDIM != 3 || (cz - r <= 0 && cz + r >= a.nz - 1));
+      if (cnt >= K || all) cut();
+      const double reach = (double)r * (double)r * a.cell2;
+      if (all || (cnt == K && tau <= reach)) break;
     }
     for (int q = l; q < K; q += 64) {
-      idx_out[t * K + q] = vals[q];
-      dist_out[t * K + q] = sqrt(keys[q]);
+      a.idx_out[t * K + q] = vals[q];
+      a.dist_out[t * K + q] = sqrt(keys[q]);
     }
     __syncthreads();  // the buffer is reused by the next point
   }

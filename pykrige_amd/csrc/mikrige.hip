@@ -116,6 +116,14 @@ struct mik_handle {
   bool host_inv = false;
   std::vector<double> host_ainv;
   DevBuf xs, ys, zs, vals, wells, extra_cols;
+  std::vector<double> hxs, hys, hzs;  // host copies of the station coordinates (the moving-window cell grid is built on the host)
+  // moving-window neighbour search: stations sorted into a uniform grid of cells
+  struct MwGrid {
+    int target = -1;  // stations-per-cell target the grid was built for (-1 = none)
+    int nx = 1, ny = 1, nz = 1;
+    double x0 = 0, y0 = 0, z0 = 0, cell = 1;
+    DevBuf gx, gy, gz, orig, cstart;
+  } grid;
   // factor
   DevBuf T, cvec, Cold, Cnew, Rt, TKt, Dinv, DinvT, P0, P1, cand0, cand1, pivall, flag;
   // points
@@ -202,6 +210,88 @@ static int launch_mw_solve(mik_handle* h, const MwArgs& a, long pc) {
   const size_t lds = sizeof(double) * per * PPB;
   HIPC(hipFuncSetAttribute((const void*)k_mw_solve<GY, GX, RI, CJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL((k_mw_solve<GY, GX, RI, CJ>), dim3((unsigned)((pc + PPB - 1) / PPB)), dim3(256), lds, h->stream, a);
+  return MIK_OK;
+}
+
+// Sort the stations into a uniform grid of cells for the moving-window neighbour search (counting sort on the host, O(N)).
+// The cell edge aims at `target` stations per cell; geographic problems are binned by their unit-sphere vectors.
+static int build_mw_grid(mik_handle* h, int target) {
+  if (h->grid.target == target) return MIK_OK;
+  const int N = h->N, D = (h->geo || h->ndim == 3) ? 3 : 2;
+  std::vector<double> c[3];
+  if (h->geo) {
+    for (int d = 0; d < 3; ++d) c[d].resize(N);
+    for (int i = 0; i < N; ++i) {  // k_geo_unit's formula
+      const double lo = h->hxs[i] * MIK_PI / 180.0, la = h->hys[i] * MIK_PI / 180.0;
+      c[0][i] = cos(lo) * cos(la);
+      c[1][i] = sin(lo) * cos(la);
+      c[2][i] = sin(la);
+    }
+  } else {
+    c[0] = h->hxs;
+    c[1] = h->hys;
+    if (D == 3) c[2] = h->hzs;
+  }
+  double lo[3] = {0, 0, 0}, ext[3] = {0, 0, 0};
+  double vol = 1.0;
+  int live = 0;
+  for (int d = 0; d < D; ++d) {
+    const auto mm = std::minmax_element(c[d].begin(), c[d].end());
+    lo[d] = *mm.first;
+    ext[d] = *mm.second - *mm.first;
+    if (ext[d] > 0.0 && std::isfinite(ext[d])) {
+      vol *= ext[d];
+      ++live;
+    }
+  }
+  int n[3] = {1, 1, 1};
+  double cell = 1.0;
+  if (live > 0 && N > 4 * target) {
+    cell = pow(vol * (double)target / (double)N, 1.0 / live);
+    for (;;) {  // keep the grid below ~4M cells
+      double cells = 1.0;
+      for (int d = 0; d < D; ++d) cells *= (ext[d] > 0.0 && std::isfinite(ext[d])) ? std::max(1.0, ceil(ext[d] / cell)) : 1.0;
+      if (cells <= 4.0e6) break;
+      cell *= 1.5;
+    }
+    for (int d = 0; d < D; ++d)
+      if (ext[d] > 0.0 && std::isfinite(ext[d])) n[d] = (int)std::max(1.0, ceil(ext[d] / cell));
+  }
+  const long ncell = (long)n[0] * n[1] * n[2];
+  std::vector<int> cellof(N), start(ncell + 1, 0), orig(N);
+  for (int i = 0; i < N; ++i) {
+    long id[3] = {0, 0, 0};
+    for (int d = 0; d < D; ++d)
+      if (n[d] > 1) id[d] = std::min<long>(n[d] - 1, std::max<long>(0, (long)floor((c[d][i] - lo[d]) / cell)));
+    const long ci = (id[2] * n[1] + id[1]) * n[0] + id[0];
+    cellof[i] = (int)ci;
+    ++start[ci + 1];
+  }
+  for (long k = 0; k < ncell; ++k) start[k + 1] += start[k];
+  std::vector<int> fill(start.begin(), start.end() - 1);
+  std::vector<double> g[3];
+  for (int d = 0; d < D; ++d) g[d].resize(N);
+  for (int i = 0; i < N; ++i) {  // stable: stations of a cell stay in index order
+    const int pos = fill[cellof[i]]++;
+    orig[pos] = i;
+    for (int d = 0; d < D; ++d) g[d][pos] = c[d][i];
+  }
+  auto& G = h->grid;
+  MIKC(G.gx.ensure(sizeof(double) * N));
+  MIKC(G.gy.ensure(sizeof(double) * N));
+  MIKC(G.gz.ensure(sizeof(double) * N));
+  MIKC(G.orig.ensure(sizeof(int) * N));
+  MIKC(G.cstart.ensure(sizeof(int) * (size_t)(ncell + 1)));
+  HIPC(hipMemcpyAsync(G.gx.p, g[0].data(), sizeof(double) * N, hipMemcpyHostToDevice, h->stream));
+  HIPC(hipMemcpyAsync(G.gy.p, g[1].data(), sizeof(double) * N, hipMemcpyHostToDevice, h->stream));
+  if (D == 3) HIPC(hipMemcpyAsync(G.gz.p, g[2].data(), sizeof(double) * N, hipMemcpyHostToDevice, h->stream));
+  HIPC(hipMemcpyAsync(G.orig.p, orig.data(), sizeof(int) * N, hipMemcpyHostToDevice, h->stream));
+  HIPC(hipMemcpyAsync(G.cstart.p, start.data(), sizeof(int) * (size_t)(ncell + 1), hipMemcpyHostToDevice, h->stream));
+  HIPC(hipStreamSynchronize(h->stream));  // the host vectors go out of scope
+  G.nx = n[0], G.ny = n[1], G.nz = n[2];
+  G.x0 = lo[0], G.y0 = lo[1], G.z0 = lo[2];
+  G.cell = cell;
+  G.target = target;
   return MIK_OK;
 }
 
@@ -343,6 +433,11 @@ int mik_set_problem(mik_handle* h, const mik_problem* p) {
   MIKC(h->xs.ensure(nb));
   MIKC(h->ys.ensure(nb));
   MIKC(h->vals.ensure(nb));
+  h->hxs.assign(p->xs, p->xs + h->N);
+  h->hys.assign(p->ys, p->ys + h->N);
+  if (p->ndim == 3) h->hzs.assign(p->zs, p->zs + h->N);
+  else h->hzs.clear();
+  h->grid.target = -1;
   HIPC(hipMemcpyAsync(h->xs.p, p->xs, nb, hipMemcpyHostToDevice, h->stream));
   HIPC(hipMemcpyAsync(h->ys.p, p->ys, nb, hipMemcpyHostToDevice, h->stream));
   HIPC(hipMemcpyAsync(h->vals.p, p->values, nb, hipMemcpyHostToDevice, h->stream));
@@ -775,15 +870,10 @@ int mik_predict_moving_window(mik_handle* h, int n_closest) {
   const double *qx = h->px.as<double>(), *qy = h->py.as<double>(), *qz = h->pz.as<double>();
   if (h->geo) {
     // neighbours by chord length on the unit sphere (same ordering as great-circle), distances recomputed below
-    MIKC(su.ensure(sizeof(double) * 3 * (size_t)h->N));
     MIKC(pu.ensure(sizeof(double) * 3 * (size_t)npt));
-    double* s3 = su.as<double>();
     double* p3 = pu.as<double>();
-    hipLaunchKernelGGL(k_geo_unit, dim3((h->N + 255) / 256), dim3(256), 0, h->stream, sx, sy, h->N, s3, s3 + h->N,
-                       s3 + 2 * (size_t)h->N);
     hipLaunchKernelGGL(k_geo_unit, dim3((unsigned)((npt + 255) / 256)), dim3(256), 0, h->stream, qx, qy, (int)npt, p3,
                        p3 + npt, p3 + 2 * (size_t)npt);
-    sx = s3, sy = s3 + h->N, sz = s3 + 2 * (size_t)h->N;
     qx = p3, qy = p3 + npt, qz = p3 + 2 * (size_t)npt;
   }
   const bool three = h->geo || h->ndim == 3;
@@ -791,9 +881,18 @@ int mik_predict_moving_window(mik_handle* h, int n_closest) {
   int cap = 512;  // candidate buffer of the wave-per-point neighbour search: a power of two >= K + 256
   while (cap < K + 256) cap <<= 1;
   const bool wave_knn = cap <= h->opt_mw_lds_cap;  // default 8192 = 96 KB of LDS; beyond that the lists live in HBM
-  if (!wave_knn) {
+  if (wave_knn) {
+    MIKC(build_mw_grid(h, std::max(8, std::min(K, 256))));
+  } else {
     MIKC(wd.ensure(sizeof(double) * (size_t)chunk * K));
     MIKC(wi.ensure(sizeof(int) * (size_t)chunk * K));
+    if (h->geo) {  // station unit vectors for the plain scan
+      MIKC(su.ensure(sizeof(double) * 3 * (size_t)h->N));
+      double* s3 = su.as<double>();
+      hipLaunchKernelGGL(k_geo_unit, dim3((h->N + 255) / 256), dim3(256), 0, h->stream, sx, sy, h->N, s3, s3 + h->N,
+                         s3 + 2 * (size_t)h->N);
+      sx = s3, sy = s3 + h->N, sz = s3 + 2 * (size_t)h->N;
+    }
   }
   if (big) {
     const double per = 8.0 * nb * (nb + 1.0);
@@ -820,14 +919,29 @@ int mik_predict_moving_window(mik_handle* h, int n_closest) {
       const long wg = 32L * h->n_cu;
       const unsigned wgrid = (unsigned)(pc < wg ? pc : wg);
       const size_t klds = (size_t)cap * (sizeof(double) + sizeof(int));
+      KnnArgs ka{};
+      ka.px = qx + p0;
+      ka.py = qy + p0;
+      ka.pz = three ? qz + p0 : nullptr;
+      ka.npt = (int)pc;
+      ka.gx = h->grid.gx.as<double>();
+      ka.gy = h->grid.gy.as<double>();
+      ka.gz = h->grid.gz.as<double>();
+      ka.orig = h->grid.orig.as<int>();
+      ka.cstart = h->grid.cstart.as<int>();
+      ka.N = h->N, ka.K = K, ka.CAP = cap;
+      ka.nx = h->grid.nx, ka.ny = h->grid.ny, ka.nz = h->grid.nz;
+      ka.x0 = h->grid.x0, ka.y0 = h->grid.y0, ka.z0 = h->grid.z0;
+      ka.inv_cell = 1.0 / h->grid.cell;
+      ka.cell2 = h->grid.cell * h->grid.cell;
+      ka.idx_out = idx;
+      ka.dist_out = dist;
       if (three) {
         HIPC(hipFuncSetAttribute((const void*)k_mw_knn<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)klds));
-        hipLaunchKernelGGL(k_mw_knn<3>, dim3(wgrid), dim3(64), klds, h->stream, qx + p0, qy + p0, qz + p0, (int)pc, sx, sy, sz,
-                           h->N, K, cap, idx, dist);
+        hipLaunchKernelGGL(k_mw_knn<3>, dim3(wgrid), dim3(64), klds, h->stream, ka);
       } else {
         HIPC(hipFuncSetAttribute((const void*)k_mw_knn<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)klds));
-        hipLaunchKernelGGL(k_mw_knn<2>, dim3(wgrid), dim3(64), klds, h->stream, qx + p0, qy + p0, (const double*)nullptr,
-                           (int)pc, sx, sy, (const double*)nullptr, h->N, K, cap, idx, dist);
+        hipLaunchKernelGGL(k_mw_knn<2>, dim3(wgrid), dim3(64), klds, h->stream, ka);
       }
     }
     if (h->geo)

@@ -19,3 +19,17 @@ for k, npt in ((10, 1000000), (100, 1000000), (127, 100000), (128, 100000), (200
     h.predict_moving_window(k)
     dt = time.perf_counter() - t0
     print("k=%4d  npt=%8d  %9.2f ms  %10.0f points/s" % (k, npt, dt * 1e3, npt / dt), flush=True)
+
+# many stations: only coordinates live on the device (no N x N matrix on this path)
+for n, k in ((100000, 10), (1000000, 10), (1000000, 32)):
+    rs = np.random.default_rng(n + k)
+    sx, sy = rs.random(n), rs.random(n)
+    h.set_problem(ndim=2, xs=sx, ys=sy, zs=None, values=np.sin(7 * sx) + sy, model_id=_lib.MODEL_IDS["exponential"],
+                  params=internal_params("exponential", [1.0, 0.02, 0.0]))
+    npt = 1000000
+    h.set_points(rs.random(npt), rs.random(npt), None)
+    h.predict_moving_window(k)
+    t0 = time.perf_counter()
+    h.predict_moving_window(k)
+    dt = time.perf_counter() - t0
+    print("N=%8d stations  k=%3d  npt=%8d  %9.2f ms  %10.0f points/s" % (n, k, npt, dt * 1e3, npt / dt), flush=True)

@@ -544,3 +544,88 @@ def test_matrix_orders_around_tile_boundaries(n):
         zru, sru = ko.solve_points(stu, ko.adjust_for_anisotropy(pts, stu.center, stu.scaling, stu.angle))
         np.testing.assert_allclose(zu, zru, rtol=0, atol=Z_TOL)
         np.testing.assert_allclose(su, sru, rtol=0, atol=SS_TOL)
+
+
+@pytest.mark.parametrize("case", ["clustered2d", "line2d", "outside2d", "large2d", "clustered3d", "flat3d", "k_eq_n"])
+def test_moving_window_cell_grid_against_kdtree(case):
+    """The neighbour search walks rings of station cells and stops at tau <= (ring * cell)^2; this pins it against the
+    oracle's cKDTree query (ok.py:957-960) where that logic is stressed: very uneven station density, stations on a line
+    (one grid dimension degenerate), points far outside the stations' bounding box, many cells, 3-D, a flat 3-D cloud,
+    and a window that holds every station.  The local systems are computed from coordinates (no N x N matrix), the
+    oracle cuts them out of the full matrix as the reference does."""
+    import pykrige_amd as pa
+
+    rng = np.random.default_rng({"clustered2d": 11, "line2d": 12, "outside2d": 13, "large2d": 14, "clustered3d": 15, "flat3d": 16, "k_eq_n": 17}[case])
+    ndim, model, user = 2, "exponential", [1.0, 0.4, 0.02]
+    if case == "clustered2d":
+        n, k = 1500, 12
+        c = np.concatenate([0.02 * rng.standard_normal((1300, 2)) + [0.2, 0.7], rng.random((200, 2))])
+        pts = np.concatenate([rng.random((300, 2)), 0.05 * rng.standard_normal((100, 2)) + [0.2, 0.7]])
+    elif case == "line2d":
+        n, k = 600, 9
+        c = np.stack([rng.random(n), np.full(n, 0.5)], 1)
+        pts = rng.random((200, 2))
+    elif case == "outside2d":
+        n, k = 900, 20
+        c = rng.random((n, 2))
+        pts = np.concatenate([rng.random((50, 2)) * 40 - 20, [[-5.0, 0.5], [0.5, 9.0], [100.0, 100.0], [0.0, 0.0], [1.0, 1.0]]])
+    elif case == "large2d":
+        n, k = 8000, 16
+        c = rng.random((n, 2))
+        pts = rng.random((400, 2))
+    elif case == "clustered3d":
+        ndim, n, k, model, user = 3, 2500, 14, "spherical", [1.0, 0.6, 0.05]
+        c = np.concatenate([0.03 * rng.standard_normal((2000, 3)) + [0.5, 0.5, 0.2], rng.random((500, 3))])
+        pts = rng.random((300, 3))
+    elif case == "flat3d":
+        ndim, n, k, model, user = 3, 800, 10, "gaussian", [1.0, 0.5, 0.05]
+        c = np.concatenate([rng.random((n, 2)), np.full((n, 1), 0.25)], 1)
+        pts = rng.random((200, 3))
+    else:  # k_eq_n
+        n, k = 150, 150
+        c = rng.random((n, 2))
+        pts = rng.random((64, 2))
+    n = c.shape[0]
+    v = np.sin(5 * c[:, 0]) + np.cos(3 * c[:, 1]) + 0.1 * rng.standard_normal(n)
+    st = ko.KrigingState(ndim=ndim, coords_orig=c, values=v, model=model, params=ko.internal_parameters(model, user),
+                         scaling=[1.0] * (ndim - 1), angle=[0.0] * (2 * ndim - 3))
+    zr, sr = ko.solve_points_moving_window(st, ko.adjust_for_anisotropy(pts.copy(), st.center, st.scaling, st.angle), k)
+    if ndim == 2:
+        m = pa.OrdinaryKriging(c[:, 0], c[:, 1], v, variogram_model=model, variogram_parameters=user)
+        z, ss = m.execute("points", pts[:, 0], pts[:, 1], backend="loop", n_closest_points=k)
+    else:
+        m = pa.OrdinaryKriging3D(c[:, 0], c[:, 1], c[:, 2], v, variogram_model=model, variogram_parameters=user)
+        z, ss = m.execute("points", pts[:, 0], pts[:, 1], pts[:, 2], backend="loop", n_closest_points=k)
+    np.testing.assert_allclose(z, zr, rtol=0, atol=1e-7)   # far-outside points: the systems are ill-conditioned there
+    np.testing.assert_allclose(ss, sr, rtol=0, atol=1e-6)
+
+
+def test_moving_window_many_stations_without_the_full_matrix():
+    """300 000 stations: the reference's moving window would first build a 720 GB kriging matrix (ok.py:975); here the
+    neighbour search runs on the cell grid and each point's system comes from coordinates.  Checked on 256 points against
+    cKDTree + a dense solve of the same (k+1) x (k+1) systems written out in NumPy."""
+    import scipy.linalg
+    from scipy.spatial import cKDTree
+
+    import pykrige_amd as pa
+
+    rng = np.random.default_rng(2025)
+    n, k = 300000, 12
+    x, y = rng.random(n), rng.random(n)
+    v = np.sin(9 * x) * np.cos(7 * y) + 0.05 * rng.standard_normal(n)
+    user = [1.0, 0.05, 0.01]
+    ok = pa.OrdinaryKriging(x, y, v, variogram_model="exponential", variogram_parameters=user)
+    px, py = rng.random(20000), rng.random(20000)
+    z, ss = ok.execute("points", px, py, backend="loop", n_closest_points=k)
+    par = ko.internal_parameters("exponential", user)
+    d, idx = cKDTree(np.stack([x, y], 1)).query(np.stack([px[:256], py[:256]], 1), k=k)
+    for i in range(256):
+        sel = idx[i]
+        c = np.stack([x[sel], y[sel]], 1)
+        a = np.zeros((k + 1, k + 1))
+        a[:k, :k] = -ko.variogram("exponential", par, np.linalg.norm(c[:, None] - c[None], axis=2))
+        np.fill_diagonal(a, 0.0)
+        a[k, :k] = a[:k, k] = 1.0
+        b = np.append(-ko.variogram("exponential", par, d[i]), 1.0)
+        w = scipy.linalg.solve(a, b)
+        assert abs(z[i] - w[:k] @ v[sel]) <= Z_TOL and abs(ss[i] + w @ b) <= SS_TOL
