@@ -71,7 +71,7 @@ def main():
     print("wrote extra fixtures")
 
 
-if __name__ == "__main__" and not {"--mw", "--geo", "--stats", "--sk"} & set(sys.argv):
+if __name__ == "__main__" and not {"--mw", "--geo", "--stats", "--sk", "--tools"} & set(sys.argv):
     main()
 
 
@@ -249,3 +249,39 @@ def sklearn_callers():
 if __name__ == "__main__" and "--sk" in sys.argv:
     _import_reference(False)
     sklearn_callers()
+
+
+def grid_files():
+    """kriging_tools.py of the REAL reference: files it writes (kept as text fixtures) and what it reads back."""
+    import pykrige.kriging_tools as kt
+
+    d = os.path.join(OUT, "tools")
+    os.makedirs(d, exist_ok=True)
+    rng = np.random.default_rng(314)
+    x, y = np.linspace(10.0, 55.0, 10), np.linspace(-3.0, 9.0, 7)
+    xs, ys = np.linspace(10.0, 55.0, 10), np.linspace(-3.0, 27.0, 7)  # square cells for style 2
+    z = rng.standard_normal((7, 10)) * 1000.0
+    z[3, 3] = 123456.789
+    mask = rng.random(z.shape) < 0.2
+    zz = z.copy()
+    zz[2, 3], zz[0, 0], zz[1, 1] = np.nan, 1.5e7, -2.5e120
+    out = dict(x=x, y=y, xs=xs, ys=ys, z=z, mask=mask, zz=zz)
+    kt.write_asc_grid(x, y, z, os.path.join(d, "style1.asc"), style=1)
+    kt.write_asc_grid(xs, ys, np.ma.array(z, mask=mask), os.path.join(d, "style2_masked.asc"), no_data=-9999.0, style=2)
+    kt.write_zmap_grid(x, y, np.ma.array(zz, mask=mask), os.path.join(d, "masked.zmap"), coord_sys="EPSG:1234")
+    with open(os.path.join(d, "variant_header.asc"), "w") as f:  # lower-case keys, cell_size / nodatavalue, two footer lines
+        f.write("ncols 4\nnrows 3\nxllcorner 100.0\nyllcorner 200.0\ncell_size 2.5\nnodatavalue -1\n"
+                "1 2 3 4\n5 6 7 8\n9 10 11 12\nfooter line\nanother one\n")
+    for tag, args in (("style1", ("style1.asc",)), ("style2", ("style2_masked.asc",)), ("variant", ("variant_header.asc", 2))):
+        g, gx, gy, cell, nod = kt.read_asc_grid(os.path.join(d, args[0]), *args[1:])
+        out.update({tag + "_grid": g, tag + "_x": gx, tag + "_y": gy, tag + "_cell": np.atleast_1d(np.asarray(cell, dtype=float)),
+                    tag + "_nodata": nod})
+    g, gx, gy, cell, nod, cs = kt.read_zmap_grid(os.path.join(d, "masked.zmap"))
+    out.update(zmap_grid=g, zmap_x=gx, zmap_y=gy, zmap_cell=np.asarray(cell), zmap_nodata=nod, zmap_cs=cs)
+    np.savez_compressed(os.path.join(OUT, "tools_grid_files.npz"), **out)
+    print("wrote grid-file fixtures")
+
+
+if __name__ == "__main__" and "--tools" in sys.argv:
+    _import_reference(False)
+    grid_files()

@@ -209,3 +209,40 @@ def test_sklearn_side_host_pieces_without_a_gpu():
         rk.RegressionKriging(regression_model=object())
     with pytest.raises(ValueError):
         ck.ClassificationKriging(classification_model=LogisticRegression(), method="bad")
+
+
+def test_kriging_tools_grid_files_match_the_reference(tmp_path):
+    """kriging_tools (reference kriging_tools.py:23-459): files written here are byte-identical to the ones the real
+    reference wrote (tests/golden/tools/, oracle/make_golden_extra.py --tools; ZMAP date / file-name comment lines aside),
+    and both readers return what the reference's readers returned, header variants and footer skipping included."""
+    from pykrige_amd import kriging_tools as kt
+
+    gdir = os.path.join(ROOT, "tests", "golden", "tools")
+    g = np.load(os.path.join(ROOT, "tests", "golden", "tools_grid_files.npz"))
+    x, y, xs, ys, z, mask, zz = (g[k] for k in ("x", "y", "xs", "ys", "z", "mask", "zz"))
+    kt.write_asc_grid(x, y, z, str(tmp_path / "a.asc"), style=1)
+    assert open(tmp_path / "a.asc").read() == open(os.path.join(gdir, "style1.asc")).read()
+    kt.write_asc_grid(xs, ys, np.ma.array(z, mask=mask), str(tmp_path / "b.asc"), no_data=-9999.0, style=2)
+    assert open(tmp_path / "b.asc").read() == open(os.path.join(gdir, "style2_masked.asc")).read()
+    kt.write_zmap_grid(x, y, np.ma.array(zz, mask=mask), str(tmp_path / "masked.zmap"), coord_sys="EPSG:1234")
+
+    def stable(path):
+        return [line for line in open(path) if "CREATION" not in line]
+
+    assert stable(tmp_path / "masked.zmap") == stable(os.path.join(gdir, "masked.zmap"))
+    for tag, args in (("style1", ("style1.asc",)), ("style2", ("style2_masked.asc",)), ("variant", ("variant_header.asc", 2))):
+        grid, gx, gy, cell, nod = kt.read_asc_grid(os.path.join(gdir, args[0]), *args[1:])
+        assert np.array_equal(grid, g[tag + "_grid"]) and np.array_equal(gx, g[tag + "_x"]) and np.array_equal(gy, g[tag + "_y"])
+        assert np.array_equal(np.atleast_1d(np.asarray(cell, dtype=float)), g[tag + "_cell"]) and nod == float(g[tag + "_nodata"])
+    grid, gx, gy, cell, nod, cs = kt.read_zmap_grid(os.path.join(gdir, "masked.zmap"))
+    assert np.array_equal(grid, g["zmap_grid"]) and np.array_equal(gx, g["zmap_x"]) and np.array_equal(gy, g["zmap_y"])
+    assert np.array_equal(np.asarray(cell), g["zmap_cell"]) and nod == float(g["zmap_nodata"]) and cs == str(g["zmap_cs"])
+    with pytest.raises(ValueError):  # irregular spacing, bad style, non-square cells for style 2
+        kt.write_asc_grid([0.0, 1.0, 3.0], y, np.zeros((7, 3)), str(tmp_path / "c.asc"))
+    with pytest.raises(ValueError):
+        kt.write_asc_grid(x, y, z, str(tmp_path / "c.asc"), style=3)
+    with pytest.raises(ValueError):
+        kt.write_asc_grid(x, y, z, str(tmp_path / "c.asc"), style=2)
+    with pytest.raises(IOError):
+        open(tmp_path / "bad.asc", "w").write("ncols 2\nbogus 3\n")
+        kt.read_asc_grid(str(tmp_path / "bad.asc"))
