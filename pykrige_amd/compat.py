@@ -65,25 +65,11 @@ class Krige(RegressorMixin, BaseEstimator):
                  enable_statistics=False, coordinates_type="euclidean", drift_terms=None, point_drift=None,
                  ext_drift_grid=(None, None, None), functional_drift=None):
         validate_method(method)
-        self.method = method
-        self.variogram_model = variogram_model
-        self.nlags = nlags
-        self.weight = weight
-        self.n_closest_points = n_closest_points
-        self.verbose = verbose
-        self.exact_values = exact_values
-        self.pseudo_inv = pseudo_inv
-        self.pseudo_inv_type = pseudo_inv_type
-        self.variogram_parameters = variogram_parameters
-        self.variogram_function = variogram_function
-        self.anisotropy_scaling = anisotropy_scaling
-        self.anisotropy_angle = anisotropy_angle
-        self.enable_statistics = enable_statistics
-        self.coordinates_type = coordinates_type
-        self.drift_terms = drift_terms
-        self.point_drift = point_drift
-        self.ext_drift_grid = ext_drift_grid
-        self.functional_drift = functional_drift
+        given = dict(locals())
+        for name in ("self", "__class__"):
+            given.pop(name, None)
+        for name, value in given.items():  # scikit-learn's get_params / clone contract: stored under the argument names
+            setattr(self, name, value)
         self.model = None  # set by fit()
 
     def _method_specific(self):
