@@ -175,21 +175,26 @@ class ShardedExecutor:
 
     def execute(self, style, *axes, mask=None, backend="vectorized", **kw):
         m, h = self.model, self._handle
-        m._check_backend(backend, kw.pop("n_closest_points", None))
+        window = kw.pop("n_closest_points", None)
+        m._check_backend(backend, window)
         pts_adj, shape, fmask, extra = m._prepare_points(style, axes, mask, **kw) if kw else m._prepare_points(style, axes, mask)
         npt = pts_adj.shape[0]
         lo, hi = slab_bounds(npt, self.world, self.rank)
         m._set_problem(h)
-        if self.exchange == "rccl_bcast":
-            if self.rank == 0:
+        if window is None:
+            if self.exchange == "rccl_bcast":
+                if self.rank == 0:
+                    h.factor()
+                h.bcast_factor(0)
+            else:
                 h.factor()
-            h.bcast_factor(0)
-        else:
-            h.factor()
         sl = slice(lo, hi)
         h.set_points(pts_adj[sl, 0], pts_adj[sl, 1], pts_adj[sl, 2] if m._ndim == 3 else None,
                      mask=None if fmask is None else fmask[sl], extra_rows=None if extra is None else extra[:, sl])
-        h.predict()
+        if window is None:
+            h.predict()
+        else:  # moving window: every point needs only its own neighbours -- no factor, no exchange of any kind
+            h.predict_moving_window(int(window))
         z, ss = h.get_results()
         parts = self.pg.all_gather_object((lo, z, ss))
         zf, sf = np.zeros(npt), np.zeros(npt)

@@ -58,6 +58,11 @@ class OracleHandle:
 
     def predict(self):
         self.calls.append("predict")
+        self.window = None
+
+    def predict_moving_window(self, k):
+        self.calls.append("predict_moving_window")
+        self.window = k
 
     def get_results(self):
         from oracle import kriging_oracle as ko
@@ -65,7 +70,10 @@ class OracleHandle:
         z, ss = np.zeros(len(self.pts)), np.zeros(len(self.pts))
         keep = np.ones(len(self.pts), bool) if self.mask is None else ~np.asarray(self.mask, bool)
         if keep.any():
-            z[keep], ss[keep] = ko.solve_points(self.st, self.pts[keep])
+            if getattr(self, "window", None):
+                z[keep], ss[keep] = ko.solve_points_moving_window(self.st, self.pts[keep], self.window)
+            else:
+                z[keep], ss[keep] = ko.solve_points(self.st, self.pts[keep])
         return z, ss
 
 
@@ -124,7 +132,11 @@ def _sock_worker(rank, world, port, q):
         st = ko.KrigingState(ndim=3, coords_orig=np.stack([x, y, zc], 1), values=v, model="spherical",
                              params=ko.internal_parameters("spherical", [1.0, 0.7, 0.05]), scaling=[1.0, 1.0], angle=[0.0] * 3)
         zr, sr = ko.execute(st, "grid", *g)
-        q.put((rank, bool(np.allclose(z, zr, atol=1e-12) and np.allclose(ss, sr, atol=1e-12) and z.shape == (3, 4, 5)), len(hdl.pts)))
+        zw, sw = ex.execute("grid", *g, backend="loop", n_closest_points=7)  # sharded moving window: no factor at all
+        zwr, swr = ko.solve_points_moving_window(st, np.stack([a.ravel() for a in np.meshgrid(g[2], g[1], g[0], indexing="ij")][::-1], 1), 7)
+        okw = np.allclose(zw.ravel(), zwr, atol=1e-12) and np.allclose(sw.ravel(), swr, atol=1e-12) and hdl.calls[-1] == "predict_moving_window" \
+            and hdl.calls.count("factor") == 1
+        q.put((rank, bool(okw and np.allclose(z, zr, atol=1e-12) and np.allclose(ss, sr, atol=1e-12) and z.shape == (3, 4, 5)), len(hdl.pts)))
     finally:
         pg.close()
 
