@@ -357,7 +357,7 @@ def main():
             "config": {"workload": cfg["name"], "stations": cfg["n"], "matrix_order": M,
                        "grid_points_per_gpu": npt, "grid_points_total": total_pts, "variogram": cfg["model"],
                        "variogram_parameters": cfg["params"], "factor_exchange": exchange, "factor_exchange_trial": trial,
-                       "factor_path": {1: "spd-shift block sweep", 2: "pivoted block gauss-jordan", 3: "host inverse"}.get(
+                       "factor_path": {1: "spd-shift block sweep", 2: "pivoted block gauss-jordan", 3: "caller-supplied inverse", 4: "device pseudo-inverse"}.get(
                            tsum.get("factor_path"), "?"),
                        "symmetric_contraction": bool(tsum.get("symmetric"))},
             "roofline": {"bound": "mfma", "kernel": "k_contract_valu" if tsum.get("engine") else "k_contract", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,

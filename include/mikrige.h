@@ -64,11 +64,12 @@ typedef struct mik_problem {
   int32_t n_extra;          /* host-evaluated drift terms: external_Z, specified, functional (in that order) */
   const double *wells;      /* n_wells x 3 row-major: adjusted x, adjusted y, strength */
   const double *extra_cols; /* n_extra x n row-major: those drift terms evaluated at the stations */
-  const double *a_inv;      /* optional (M x M, M = n + ndrift + 1): inverse supplied by the host
-                               (pseudo_inv=True: P_INV[type](a), core.py:33); NULL = invert on device */
+  const double *a_inv;      /* optional (M x M, M = n + ndrift + 1): an inverse supplied by the caller, used as is;
+                               NULL = invert on device */
   int32_t geographic;       /* coordinates_type == 'geographic' (ordinary 2D only): xs/ys and px/py are lon/lat in
                                degrees, distances are great-circle degrees (core.py:36-97; ok.py:634-640, 990-996) */
-  int32_t reserved;
+  int32_t pseudo_inv;       /* self.pseudo_inv: 0 = inverse; 1 = 'pinv', 2 = 'pinvh' (core.py:33 P_INV): Moore-Penrose
+                               pseudo-inverse on the device (one-sided Jacobi; the two types coincide on a symmetric matrix) */
 } mik_problem;
 
 /* The prediction points handed to _exec_vector: adjusted coordinates (SoA), mask, drift rows. */
@@ -88,7 +89,7 @@ typedef struct mik_timing {
   double predict_ms;      /* whole mik_predict on the stream */
   int64_t contract_launches;
   double contract_flops_executed; /* flops the contraction kernel really executed (symmetric form: ~M^2/pt) */
-  int32_t factor_path;    /* 1 = unpivoted symmetric block sweep on the SPD-shifted matrix, 2 = pivoted block Gauss-Jordan, 3 = host-supplied inverse */
+  int32_t factor_path;    /* 1 = unpivoted symmetric block sweep on the SPD-shifted matrix, 2 = pivoted block Gauss-Jordan, 3 = caller-supplied inverse, 4 = device pseudo-inverse */
   int32_t symmetric;      /* 1 = contraction used the symmetric half product */
   int32_t engine;         /* 0 = v_mfma_f64_16x16x4_f64 contraction, 1 = v_fma_f64 register-tiled contraction */
   int32_t reserved;

@@ -24,7 +24,7 @@ class MikProblem(C.Structure):
         ("params", C.c_double * 3), ("eps", C.c_double),
         ("exact_values", C.c_int32), ("regional_linear", C.c_int32), ("n_wells", C.c_int32), ("n_extra", C.c_int32),
         ("wells", _dp), ("extra_cols", _dp), ("a_inv", _dp),
-        ("geographic", C.c_int32), ("reserved", C.c_int32),
+        ("geographic", C.c_int32), ("pseudo_inv", C.c_int32),
     ]
 
 
@@ -148,7 +148,7 @@ class Handle:
         check(self._lib.mik_set_option(self._h, key.encode(), float(value)))
 
     def set_problem(self, ndim, xs, ys, zs, values, model_id, params, eps=1e-10, exact_values=True,
-                    regional_linear=False, wells=None, extra_cols=None, a_inv=None, geographic=False):
+                    regional_linear=False, wells=None, extra_cols=None, a_inv=None, geographic=False, pseudo_inv=0):
         p = MikProblem()
         xs, ys, values = _f64(xs), _f64(ys), _f64(values)
         zs = _f64(zs) if zs is not None else None
@@ -168,6 +168,7 @@ class Handle:
         p.n_extra = 0 if extra_cols is None else extra_cols.shape[0]
         p.wells, p.extra_cols, p.a_inv = _ptr(wells), _ptr(extra_cols), _ptr(a_inv)
         p.geographic = int(bool(geographic))
+        p.pseudo_inv = int(pseudo_inv)
         self._keep = [xs, ys, zs, values, wells, extra_cols, a_inv]
         check(self._lib.mik_set_problem(self._h, C.byref(p)))
         self._keep = []

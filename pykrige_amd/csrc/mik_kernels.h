@@ -1150,6 +1150,148 @@ __global__ void k_selftest_mfma4(double* out /*4x16 row-major*/) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Pseudo-inverse of the kriging matrix (pseudo_inv=True: P_INV[type](a), core.py:33 -> scipy.linalg.pinv / pinvh), for
+// matrices made singular by duplicated stations.  One-sided (Hestenes) Jacobi on the ROWS of the symmetric matrix:
+// plane rotations W = prod J make the rows of B = W A mutually orthogonal, so A = W^T diag(sigma) Q^T with q_i = b_i/sigma_i
+// and pinv(A) = sum_{sigma_i > cut} b_i^T w_i / sigma_i^2 = B^T D W, cut = M eps sigma_max (SciPy's default rtol for
+// both pinv and pinvh; on a symmetric matrix the two coincide: singular values = |eigenvalues|).
+//   k_jac_step  : one round of the round-robin tournament: block b rotates rows (p, q) of B and W (disjoint pairs);
+//                 rows below dead2 = (0.1 M eps)^2 |A|_F^2 / M (<= a hundredth of the cut-off, squared) are left alone
+//   k_rownorm2  : sigma_i^2
+//   k_pinv_gemm : out = B^T diag(d) W, 64 x 64 tiles
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_set_identity(double* __restrict__ W, long ld, int n) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long)n * ld) return;
+  const long r = e / ld, c = e - r * ld;
+  W[e] = (r == c) ? 1.0 : 0.0;
+}
+
+__global__ void __launch_bounds__(256)
+k_jac_step(double* __restrict__ B, double* __restrict__ W, long ld, int n, int m, int step, double dead2,
+           unsigned long long* maxoff) {
+  // tournament over m (even) players: player m-1 stays, the others rotate; round `step` pairs (step+b) with (step-b)
+  const int b = blockIdx.x;
+  int i = step, j = m - 1;
+  if (b > 0) {
+    i = (step + b) % (m - 1);
+    j = (step - b + (m - 1)) % (m - 1);
+  }
+  const int p = i < j ? i : j, q = i < j ? j : i;
+  if (q >= n) return;  // the padding player of an odd n
+  double* bp = B + (long)p * ld;
+  double* bq = B + (long)q * ld;
+  double al = 0.0, be = 0.0, ga = 0.0;
+  for (long c = threadIdx.x; c < ld; c += 256) {
+    const double x = bp[c], y = bq[c];
+    al += x * x;
+    be += y * y;
+    ga += x * y;
+  }
+  __shared__ double red[3][4];
+  __shared__ double cs[2];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    al += __shfl_xor(al, o, 64);
+    be += __shfl_xor(be, o, 64);
+    ga += __shfl_xor(ga, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = al;
+    red[1][threadIdx.x >> 6] = be;
+    red[2][threadIdx.x >> 6] = ga;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    al = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    be = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    ga = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+    double c = 1.0, sn = 0.0;
+    const double scale = sqrt(al * be);
+    // rows whose norm has fallen far below the pseudo-inverse cut-off are numerically zero (the null space of a
+    // rank-deficient matrix): their direction is rounding noise, rotating against them would never settle
+    if (al > dead2 && be > dead2 && fabs(ga) > 1e-17 * scale) {
+      const double off = fabs(ga) / scale;
+      atomicMax(maxoff, (unsigned long long)__double_as_longlong(off));
+      const double zeta = (be - al) / (2.0 * ga);
+      const double t = ((zeta >= 0.0) ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+      c = 1.0 / sqrt(1.0 + t * t);
+      sn = c * t;
+    }
+    cs[0] = c;
+    cs[1] = sn;
+  }
+  __syncthreads();
+  const double c = cs[0], sn = cs[1];
+  if (sn == 0.0) return;
+  double* wp = W + (long)p * ld;
+  double* wq = W + (long)q * ld;
+  for (long k = threadIdx.x; k < ld; k += 256) {
+    const double x = bp[k], y = bq[k];
+    bp[k] = c * x - sn * y;
+    bq[k] = sn * x + c * y;
+    const double u = wp[k], v = wq[k];
+    wp[k] = c * u - sn * v;
+    wq[k] = sn * u + c * v;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_rownorm2(const double* __restrict__ B, long ld, int n, double* __restrict__ out) {
+  const int r = blockIdx.x;
+  double acc = 0.0;
+  for (long c = threadIdx.x; c < ld; c += 256) {
+    const double x = B[(long)r * ld + c];
+    acc += x * x;
+  }
+  __shared__ double red[4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[r] = red[0] + red[1] + red[2] + red[3];
+}
+
+// out[i][j] = sum_k B[k][i] d[k] W[k][j]  (i, j < n); both operands are read along their contiguous rows
+__global__ void __launch_bounds__(256)
+k_pinv_gemm(const double* __restrict__ B, const double* __restrict__ W, const double* __restrict__ d, long ld, int n,
+            double* __restrict__ out) {
+  __shared__ double sb[16][64], sw[16][64];
+  const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;  // 16 x 16 threads, 4 x 4 outputs each
+  double acc[4][4] = {};
+  for (int k0 = 0; k0 < n; k0 += 16) {
+    for (int e = threadIdx.x; e < 16 * 64; e += 256) {
+      const int kk = e >> 6, c = e & 63, k = k0 + kk;
+      const bool in = k < n;
+      sb[kk][c] = (in && i0 + c < n) ? B[(long)k * ld + i0 + c] * d[k] : 0.0;
+      sw[kk][c] = (in && j0 + c < n) ? W[(long)k * ld + j0 + c] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      double a[4], b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a[u] = sb[kk][ty * 4 + u];
+        b[u] = sw[kk][tx * 4 + u];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) acc[u][w] += a[u] * b[w];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const int i = i0 + ty * 4 + u, j = j0 + tx * 4 + w;
+      if (i < n && j < n) out[(long)i * ld + j] = acc[u][w];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Moving-window kriging (n_closest_points; ok.py:929-986, 722-758, cok.pyx:98-193, ok3d.py:697-733).
 //   k_mw_knn   : the k nearest stations of every point, ascending distance (cKDTree.query(k=..., eps=0)),
 //                brute force, one wavefront per point (threshold filter + LDS bitonic cuts, see below).

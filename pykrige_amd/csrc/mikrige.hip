@@ -114,6 +114,7 @@ struct mik_handle {
   Vario v{};
   double eps = 1e-10, shift_guess = 0.0;
   bool host_inv = false;
+  int pinv = 0;  // pseudo_inv: 0 no, 1 'pinv', 2 'pinvh'
   std::vector<double> host_ainv;
   DevBuf xs, ys, zs, vals, wells, extra_cols;
   std::vector<double> hxs, hys, hzs;  // host copies of the station coordinates (the moving-window cell grid is built on the host)
@@ -210,6 +211,59 @@ static int launch_mw_solve(mik_handle* h, const MwArgs& a, long pc) {
   const size_t lds = sizeof(double) * per * PPB;
   HIPC(hipFuncSetAttribute((const void*)k_mw_solve<GY, GX, RI, CJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL((k_mw_solve<GY, GX, RI, CJ>), dim3((unsigned)((pc + PPB - 1) / PPB)), dim3(256), lds, h->stream, a);
+  return MIK_OK;
+}
+
+// Moore-Penrose pseudo-inverse of the assembled matrix in T (leading M x M block, row length Mp; the padding columns of
+// those rows are zero), in place.  Cyclic one-sided Jacobi until every row pair is orthogonal to 1e-15, then B^T D W.
+static int run_pseudo_inverse(mik_handle* h) {
+  const int n = h->M, m = n + (n & 1);
+  const long ld = h->Mp;
+  DevBuf W, out, sig, maxoff;
+  MIKC(W.ensure(sizeof(double) * (size_t)n * ld));
+  MIKC(out.ensure(sizeof(double) * (size_t)n * ld));
+  MIKC(sig.ensure(sizeof(double) * (size_t)n));
+  MIKC(maxoff.ensure(sizeof(unsigned long long)));
+  double* B = h->T.as<double>();
+  hipLaunchKernelGGL(k_set_identity, dim3((unsigned)(((long)n * ld + 255) / 256)), dim3(256), 0, h->stream, W.as<double>(), ld, n);
+  std::vector<double> s2(n), d(n);
+  hipLaunchKernelGGL(k_rownorm2, dim3(n), dim3(256), 0, h->stream, (const double*)B, ld, n, sig.as<double>());
+  HIPC(hipMemcpyAsync(s2.data(), sig.p, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+  HIPC(hipStreamSynchronize(h->stream));
+  double fro2 = 0.0;
+  for (double v : s2) fro2 += v;  // |A|_F^2 = sum sigma_i^2, invariant under the rotations; sigma_max^2 >= fro2 / n
+  const double eps = 2.220446049250313e-16;
+  const double dead2 = 0.01 * ((double)n * eps) * ((double)n * eps) * fro2 / (double)n;
+  bool converged = false;
+  for (int sweep = 0; sweep < 40 && !converged; ++sweep) {
+    HIPC(hipMemsetAsync(maxoff.p, 0, sizeof(unsigned long long), h->stream));
+    for (int step = 0; step < m - 1; ++step)
+      hipLaunchKernelGGL(k_jac_step, dim3(m / 2), dim3(256), 0, h->stream, B, W.as<double>(), ld, n, m, step, dead2,
+                         maxoff.as<unsigned long long>());
+    unsigned long long bits = 0;
+    HIPC(hipMemcpyAsync(&bits, maxoff.p, sizeof bits, hipMemcpyDeviceToHost, h->stream));
+    HIPC(hipStreamSynchronize(h->stream));
+    double off;
+    memcpy(&off, &bits, sizeof off);
+    converged = off < 1e-15;
+  }
+  if (!converged) return fail(MIK_ESINGULAR, "pseudo-inverse: Jacobi iteration did not converge");
+  hipLaunchKernelGGL(k_rownorm2, dim3(n), dim3(256), 0, h->stream, (const double*)B, ld, n, sig.as<double>());
+  HIPC(hipMemcpyAsync(s2.data(), sig.p, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+  HIPC(hipStreamSynchronize(h->stream));
+  double smax = 0.0;
+  for (double v : s2) smax = std::max(smax, sqrt(v));
+  const double cut = (double)n * eps * smax;  // scipy.linalg.pinv / pinvh: rtol = max(M, N) * eps
+  for (int i = 0; i < n; ++i) d[i] = (sqrt(s2[i]) > cut) ? 1.0 / s2[i] : 0.0;
+  HIPC(hipMemcpyAsync(sig.p, d.data(), sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+  const unsigned tiles = (unsigned)((n + 63) / 64);
+  hipLaunchKernelGGL(k_pinv_gemm, dim3(tiles, tiles), dim3(256), 0, h->stream, (const double*)B, (const double*)W.as<double>(),
+                     (const double*)sig.as<double>(), ld, n, out.as<double>());
+  HIPC(hipMemsetAsync(h->T.p, 0, h->T.bytes, h->stream));
+  HIPC(hipMemcpy2DAsync(h->T.p, sizeof(double) * ld, out.p, sizeof(double) * ld, sizeof(double) * n, n, hipMemcpyDeviceToDevice,
+                        h->stream));
+  HIPC(hipStreamSynchronize(h->stream));  // W / out / sig are released at scope exit
+  HIPC(hipGetLastError());
   return MIK_OK;
 }
 
@@ -470,6 +524,8 @@ int mik_set_problem(mik_handle* h, const mik_problem* p) {
     if (!(h->shift_guess > 0.0) || !std::isfinite(h->shift_guess)) h->shift_guess = 1.0;
   }
   h->host_inv = p->a_inv != nullptr;
+  if (p->pseudo_inv < 0 || p->pseudo_inv > 2) return fail(MIK_EINVAL, "pseudo_inv must be 0, 1 ('pinv') or 2 ('pinvh')");
+  h->pinv = p->pseudo_inv;
   if (h->host_inv) h->host_ainv.assign(p->a_inv, p->a_inv + (size_t)h->M * h->M);
   else h->host_ainv.clear();
   HIPC(hipStreamSynchronize(h->stream));
@@ -619,6 +675,21 @@ int mik_factor(mik_handle* h) {
     HIPC(hipMemcpy2DAsync(h->T.p, sizeof(double) * h->Mp, h->host_ainv.data(), sizeof(double) * h->M,
                           sizeof(double) * h->M, h->M, hipMemcpyHostToDevice, h->stream));
     h->tm.factor_path = 3;
+    return finish_factor(h);
+  }
+  if (h->pinv) {
+    HIPC(hipEventRecord(h->evpool[0], h->stream));
+    MIKC(launch_assemble(h, 0.0));
+    HIPC(hipEventRecord(h->evpool[1], h->stream));
+    MIKC(run_pseudo_inverse(h));
+    HIPC(hipEventRecord(h->evpool[2], h->stream));
+    HIPC(hipStreamSynchronize(h->stream));
+    float ms = 0.f;
+    HIPC(hipEventElapsedTime(&ms, h->evpool[0], h->evpool[1]));
+    h->tm.assemble_ms = ms;
+    HIPC(hipEventElapsedTime(&ms, h->evpool[1], h->evpool[2]));
+    h->tm.invert_ms = ms;
+    h->tm.factor_path = 4;
     return finish_factor(h);
   }
   // auto: every model first tries the unpivoted sweep on the shifted matrix s.11^T - Gamma (s = sill for the
@@ -833,7 +904,6 @@ int mik_predict_moving_window(mik_handle* h, int n_closest) {
   if (!h || !h->have_problem) return fail(MIK_ESTATE, "mik_predict_moving_window: set the problem first");
   if (!h->have_points) return fail(MIK_ESTATE, "mik_predict_moving_window: set points first");
   if (h->p != 0) return fail(MIK_EINVAL, "moving-window kriging exists for ordinary kriging only (ok.py:929, ok3d.py:901)");
-  if (h->host_inv) return fail(MIK_EINVAL, "moving-window kriging does not use pseudo_inv");
   if (n_closest < 2) return fail(MIK_EINVAL, "n_closest_points has to be at least two!");
   if (n_closest > h->N) return fail(MIK_EINVAL, "n_closest_points exceeds the number of stations");
   HIPC(hipSetDevice(h->device));

@@ -129,7 +129,7 @@ class _KrigingBase:
         return False
 
     def _set_problem(self, h, with_drift=True):
-        """H2D of the stations / drift description (and, for pseudo_inv=True, of the host pseudo-inverse)."""
+        """H2D of the stations / drift description."""
         ca = self._coords_adj
         kw = dict(
             ndim=self._ndim, xs=ca[:, 0], ys=ca[:, 1], zs=ca[:, 2] if self._ndim == 3 else None,
@@ -141,20 +141,12 @@ class _KrigingBase:
             geographic=getattr(self, "coordinates_type", "euclidean") == "geographic",
         )
         if self.pseudo_inv and with_drift:
-            # ok.py:660-661: a_inv = P_INV[self.pseudo_inv_type](a).  The matrix is assembled on the
-            # device (K1), the SVD-based pseudo-inverse is the host's (SciPy), the result is uploaded.
-            import scipy.linalg
-
-            h.set_problem(**kw)
-            h.assemble_only()
-            a = h.get_matrix(0)
-            pinv = {"pinv": scipy.linalg.pinv, "pinvh": scipy.linalg.pinvh}[self.pseudo_inv_type](a)
-            h.set_problem(a_inv=pinv, **kw)
-        else:
-            h.set_problem(**kw)
+            # ok.py:660-661: a_inv = P_INV[self.pseudo_inv_type](a) -- on the device (mik_problem.pseudo_inv)
+            kw["pseudo_inv"] = {"pinv": 1, "pinvh": 2}[self.pseudo_inv_type]
+        h.set_problem(**kw)
 
     def _upload_and_factor(self):
-        """K1 + K2 on the device (or the host pseudo-inverse when pseudo_inv=True)."""
+        """K1 + K2 on the device (inverse, or pseudo-inverse when pseudo_inv=True)."""
         h = self._get_handle()
         self._set_problem(h)
         h.factor()

@@ -139,11 +139,42 @@ def test_external_drift_known_answer_and_pseudo_inverse():
         ok = pa.OrdinaryKriging(d[:, 0], d[:, 1], d[:, 2], variogram_parameters=[1.0, 0.0], pseudo_inv=True,
                                 pseudo_inv_type=p_type)
         z, ss = ok.execute("grid", np.linspace(0, 1, 5), np.linspace(0, 1, 4), backend="loop")
-        assert ok.last_timing["factor_path"] == 3
+        assert ok.last_timing["factor_path"] == 4  # pseudo-inverse on the device (one-sided Jacobi), not a host SVD
         np.testing.assert_allclose(z, g["z_" + p_type], rtol=0, atol=1e-8)
         np.testing.assert_allclose(ss, g["ss_" + p_type], rtol=0, atol=1e-6)
         z1, _ = ok.execute("points", 0.0, 0.0, backend="loop")
         assert np.isclose(z1.item(), 2.0)  # mean of the redundant data
+
+
+@pytest.mark.parametrize("n,drift", [(301, False), (257, True)])
+def test_device_pseudo_inverse_against_scipy(n, drift):
+    """mik_problem.pseudo_inv: the Moore-Penrose pseudo-inverse computed on the device (cyclic one-sided Jacobi, cut-off
+    M eps sigma_max) against scipy.linalg.pinv of the same kriging matrix -- odd matrix orders (tournament padding),
+    several duplicated stations (rank deficiency > 1), with and without drift rows -- and the kriging through it
+    against the oracle fed with SciPy's pseudo-inverse (ok.py:660-661, uk.py:932-933)."""
+    import scipy.linalg
+
+    import pykrige_amd as pa
+
+    (x, y), v = fx.synth(4000 + n, n, 2)
+    x[-6:], y[-6:] = x[:6], y[:6]  # six duplicated stations with different values
+    rng = np.random.default_rng(n)
+    pts = rng.random((200, 2))
+    user = [1.0, 0.5, 0.0]
+    kw = dict(variogram_model="exponential", variogram_parameters=user, pseudo_inv=True, pseudo_inv_type="pinv")
+    m = pa.UniversalKriging(x, y, v, drift_terms=["regional_linear"], **kw) if drift else pa.OrdinaryKriging(x, y, v, **kw)
+    z, ss = m.execute("points", pts[:, 0], pts[:, 1], backend="loop")
+    assert m.last_timing["factor_path"] == 4
+    st = ko.KrigingState(ndim=2, coords_orig=np.stack([x, y], 1), values=v, model="exponential",
+                         params=ko.internal_parameters("exponential", user), regional_linear=drift)
+    a = ko.kriging_matrix(st)
+    assert np.linalg.matrix_rank(a) <= a.shape[0] - 6
+    pinv = scipy.linalg.pinv(a)
+    got = m._get_handle().get_matrix(1)
+    assert np.abs(got - pinv).max() <= 1e-9 * np.abs(pinv).max()
+    zr, sr = ko.solve_points(st, ko.adjust_for_anisotropy(pts.copy(), st.center, st.scaling, st.angle), a_inv=pinv)
+    np.testing.assert_allclose(z, zr, rtol=0, atol=Z_TOL)
+    np.testing.assert_allclose(ss, sr, rtol=0, atol=SS_TOL)
 
 
 def test_rccl_single_rank_broadcast_path():
