@@ -78,6 +78,8 @@ class _KrigingBase:
         if self.verbose:
             print("Using '%s' Variogram Model" % self.variogram_model)
             print("Parameters:", self.variogram_model_parameters, "\n")
+        if getattr(self, "enable_plotting", False):  # ok.py:355-356, 534-535
+            self.display_variogram_model()
 
     def _device_variogram(self, nlags):
         """Experimental semivariogram on the GPU (mik_experimental_variogram) when one is visible and the O(N^2) pair
@@ -222,6 +224,34 @@ class _KrigingBase:
     def get_variogram_points(self):
         """(lags, variogram model evaluated at the lags) -- ok.py:569-587."""
         return self.lags, core.variogram_value(self.variogram_model, self.variogram_model_parameters, self.lags)
+
+    def display_variogram_model(self):
+        """Binned semivariances and the model curve (ok.py:555-567); needs matplotlib."""
+        import matplotlib.pyplot as plt
+
+        lags, model = self.get_variogram_points()
+        ax = plt.figure().add_subplot(111)
+        ax.plot(lags, self.semivariance, "r*")
+        ax.plot(lags, model, "k-")
+        plt.show()
+
+    def plot_epsilon_residuals(self):
+        """Scatter of the variogram-fit epsilon residuals (ok.py:601-609); needs matplotlib."""
+        import matplotlib.pyplot as plt
+
+        eps = self.epsilon
+        ax = plt.figure().add_subplot(111)
+        ax.scatter(range(eps.size), eps, c="k", marker="*")
+        ax.axhline(y=0.0)
+        plt.show()
+
+    def _get_kriging_matrix(self, n=None):
+        """The kriging matrix as the reference's method of the same name returns it (ok.py:626-648, uk.py:861-920,
+        3-D twins), assembled by K1 on the device and copied back -- for inspection; execute() never brings it to the host."""
+        h = self._get_handle()
+        self._set_problem(h)
+        h.assemble_only()
+        return h.get_matrix(0)
 
     def switch_verbose(self):
         self.verbose = not self.verbose

@@ -246,3 +246,29 @@ def test_kriging_tools_grid_files_match_the_reference(tmp_path):
     with pytest.raises(IOError):
         open(tmp_path / "bad.asc", "w").write("ncols 2\nbogus 3\n")
         kt.read_asc_grid(str(tmp_path / "bad.asc"))
+
+
+def test_plot_helpers_and_enable_plotting_without_a_gpu(monkeypatch):
+    """display_variogram_model / plot_epsilon_residuals / enable_plotting (ok.py:355-356, 555-567, 601-609): host-side
+    matplotlib calls; the constructor shows the variogram when enable_plotting is set."""
+    matplotlib = pytest.importorskip("matplotlib")
+    matplotlib.use("Agg")
+    import matplotlib.pyplot as plt
+
+    import pykrige_amd as pa
+
+    shown = []
+    monkeypatch.setattr(plt, "show", lambda *a, **k: shown.append(len(plt.gcf().axes[0].lines) + len(plt.gcf().axes[0].collections)))
+    rng = np.random.default_rng(1)
+    x, y, v = rng.random(40), rng.random(40), rng.random(40)
+    ok = pa.OrdinaryKriging(x, y, v, variogram_model="spherical", enable_plotting=True)
+    assert shown == [2]  # binned points + model curve, once, from the constructor
+    ok.switch_plotting()
+    ok.update_variogram_model("exponential")
+    assert shown == [2]
+    ok.display_variogram_model()
+    assert shown == [2, 2]
+    ok.__dict__["epsilon"] = rng.standard_normal(39)  # the statistics themselves need the device
+    ok.plot_epsilon_residuals()
+    assert shown == [2, 2, 2]  # scatter + zero line
+    plt.close("all")

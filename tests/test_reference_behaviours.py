@@ -260,3 +260,28 @@ def test_sklearn_side_callers_match_the_reference():
     np.testing.assert_allclose(got_par, g["ck_par"], rtol=1e-6, atol=1e-9)
     np.testing.assert_allclose(ck.krige_residual(Q3[:, :2].copy()), g["ck_residual"], rtol=0, atol=5e-6)
     assert np.array_equal(ck.predict(g["PQ"], Q3[:, :2].copy()), g["ck_pred"])
+
+
+def test_get_kriging_matrix_method():
+    """ok._get_kriging_matrix(n) / uk._get_kriging_matrix(n) (ok.py:626-648, uk.py:861-920): the device-assembled matrix
+    copied back equals the oracle's restatement, drift columns and borders included."""
+    from oracle import kriging_oracle as ko
+    from tests import _fixtures as fx
+
+    pa = _pa()
+    (x, y), v = fx.synth(31, 60, 2)
+    ok = pa.OrdinaryKriging(x, y, v, variogram_model="gaussian", variogram_parameters=[1.0, 0.4, 0.05], anisotropy_scaling=1.7,
+                            anisotropy_angle=25.0)
+    st = ko.KrigingState(ndim=2, coords_orig=np.stack([x, y], 1), values=v, model="gaussian",
+                         params=ko.internal_parameters("gaussian", [1.0, 0.4, 0.05]), scaling=[1.7], angle=[25.0])
+    a = ok._get_kriging_matrix(60)
+    assert a.shape == (61, 61)
+    np.testing.assert_allclose(a, ko.kriging_matrix(st), rtol=0, atol=1e-13)
+    wells = [[0.3, 0.6, 1.0]]
+    uk = pa.UniversalKriging(x, y, v, variogram_model="linear", variogram_parameters=[1.2, 0.1],
+                             drift_terms=["regional_linear", "point_log"], point_drift=wells)
+    stu = ko.KrigingState(ndim=2, coords_orig=np.stack([x, y], 1), values=v, model="linear", params=[1.2, 0.1],
+                          regional_linear=True, point_log=np.array(wells))
+    au = uk._get_kriging_matrix(60)
+    assert au.shape == (64, 64)
+    np.testing.assert_allclose(au, ko.kriging_matrix(stu), rtol=0, atol=1e-12)
