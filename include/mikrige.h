@@ -45,6 +45,7 @@ extern "C" {
 #define MIK_MODEL_SPHERICAL   3
 #define MIK_MODEL_EXPONENTIAL 4
 #define MIK_MODEL_HOLE_EFFECT 5
+#define MIK_MODEL_CUSTOM      6 /* variogram_model='custom': gamma is a host callable (mik_set_custom_variogram) */
 
 typedef struct mik_handle mik_handle;
 
@@ -104,6 +105,13 @@ void mik_destroy(mik_handle *h);
  * "chunk" = points per contraction launch (multiple of 128) ;
  * "mw_lds_cap" = largest moving-window candidate buffer kept in LDS (entries, default 8192; 0 forces the HBM lists) */
 int  mik_set_option(mik_handle *h, const char *key, double value);
+
+/* variogram_model='custom' (a Python callable in the reference: ok.py:305-318, core.py:584-586).  Geometry stays on the
+ * device: the kernels write distances (station-station, point-station) into their output slots, the library brings them
+ * to the host, `fn` maps d -> gamma(d) in place over a rows x cols block with row stride ld, and they go back; matrix
+ * borders, drift terms, the eps rule, the inverse and the contraction are the device's as for the named models. */
+typedef void (*mik_variogram_fn)(void *user, double *d_inout, int64_t rows, int64_t cols, int64_t ld);
+int  mik_set_custom_variogram(mik_handle *h, mik_variogram_fn fn, void *user);
 
 int  mik_set_problem(mik_handle *h, const mik_problem *p); /* H2D of stations/values/drifts            */
 int  mik_factor(mik_handle *h);                            /* K1 + K2 (+ c = A_inv[:, :n].Z) on device   */

@@ -71,7 +71,7 @@ def main():
     print("wrote extra fixtures")
 
 
-if __name__ == "__main__" and not {"--mw", "--geo", "--stats", "--sk", "--tools"} & set(sys.argv):
+if __name__ == "__main__" and not {"--mw", "--geo", "--stats", "--sk", "--tools", "--custom"} & set(sys.argv):
     main()
 
 
@@ -285,3 +285,53 @@ def grid_files():
 if __name__ == "__main__" and "--tools" in sys.argv:
     _import_reference(False)
     grid_files()
+
+
+def stable_variogram(m, d):
+    """The custom model of the fixture below: a 'stable' variogram psill (1 - exp(-(d / range)^1.5)) + nugget --
+    not one of the six named models.  Imported by tests/ as the user-supplied callable."""
+    return m[0] * (1.0 - np.exp(-((np.asarray(d) / m[1]) ** 1.5))) + m[2]
+
+
+def custom_variogram():
+    """variogram_model='custom' on the REAL reference (ok.py:247-254, test_core.py test_custom_variogram): OK2D grid + moving
+    window + statistics, UK2D with regional_linear, OK3D."""
+    from pykrige.ok import OrdinaryKriging
+    from pykrige.ok3d import OrdinaryKriging3D
+    from pykrige.uk import UniversalKriging
+
+    def arr(x):
+        return np.ma.getdata(x).astype(np.float64)
+
+    par = [0.9, 0.35, 0.05]
+    (x, y), v = synth(120, 180, 2)
+    gx, gy = np.linspace(0, 1, 13), np.linspace(0, 1, 11)
+    x[:3], y[:3] = gx[[2, 6, 10]], gy[[1, 5, 9]]
+    out = dict(x=x, y=y, v=v, par=par, gx=gx, gy=gy)
+    import pykrige.core as core
+
+    ok = OrdinaryKriging(x, y, v, variogram_model="custom", variogram_parameters=par, variogram_function=stable_variogram,
+                         anisotropy_scaling=1.4, anisotropy_angle=15.0)
+    z, ss = ok.execute("grid", gx, gy, backend="vectorized")
+    zk, ssk = ok.execute("grid", gx, gy, backend="loop", n_closest_points=9)
+    # (_import_reference stubs the constructors' statistics pass; this is the real one, as ok.py:360-371 calls it)
+    delta, sigma, eps = core._find_statistics(np.vstack((ok.X_ADJUSTED, ok.Y_ADJUSTED)).T, ok.Z, ok.variogram_function,
+                                              ok.variogram_model_parameters, "euclidean")
+    out.update(ok_z=arr(z), ok_ss=arr(ss), ok_zk=arr(zk), ok_ssk=arr(ssk), ok_eps=eps,
+               ok_q=np.array([core.calcQ1(eps), core.calcQ2(eps), core.calc_cR(core.calcQ2(eps), sigma)]))
+    uk = UniversalKriging(x, y, v, variogram_model="custom", variogram_parameters=par, variogram_function=stable_variogram,
+                          drift_terms=["regional_linear"])
+    z, ss = uk.execute("grid", gx, gy, backend="vectorized")
+    out.update(uk_z=arr(z), uk_ss=arr(ss))
+    (x3, y3, z3), v3 = synth(121, 150, 3)
+    g3 = [np.linspace(0, 1, 6), np.linspace(0, 1, 5), np.linspace(0, 1, 4)]
+    k3 = OrdinaryKriging3D(x3, y3, z3, v3, variogram_model="custom", variogram_parameters=par, variogram_function=stable_variogram)
+    z, ss = k3.execute("grid", *g3, backend="vectorized")
+    out.update(x3=x3, y3=y3, z3=z3, v3=v3, g3x=g3[0], g3y=g3[1], g3z=g3[2], k3_z=arr(z), k3_ss=arr(ss))
+    np.savez_compressed(os.path.join(OUT, "custom_variogram.npz"), **out)
+    print("wrote custom-variogram fixture")
+
+
+if __name__ == "__main__" and "--custom" in sys.argv:
+    _import_reference(False)
+    custom_variogram()

@@ -12,7 +12,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmikrige.so")
 
 MIK_OK, MIK_EINVAL, MIK_ESINGULAR, MIK_EHIP, MIK_ERCCL, MIK_ESTATE = 0, -1, -2, -3, -4, -5
-MODEL_IDS = {"linear": 0, "power": 1, "gaussian": 2, "spherical": 3, "exponential": 4, "hole-effect": 5}
+MODEL_IDS = {"linear": 0, "power": 1, "gaussian": 2, "spherical": 3, "exponential": 4, "hole-effect": 5, "custom": 6}
+VARIOGRAM_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.c_int64, C.c_int64, C.c_int64)
 
 _dp = C.POINTER(C.c_double)
 
@@ -61,6 +62,7 @@ SIGNATURES = {
     "mik_predict": (C.c_int, [C.c_void_p]),
     "mik_get_results": (C.c_int, [C.c_void_p, _dp, _dp]),
     "mik_synchronize": (C.c_int, [C.c_void_p]),
+    "mik_set_custom_variogram": (C.c_int, [C.c_void_p, VARIOGRAM_FN, C.c_void_p]),
     "mik_predict_moving_window": (C.c_int, [C.c_void_p, C.c_int]),
     "mik_statistics": (C.c_int, [C.c_void_p, _dp, _dp]),
     "mik_experimental_variogram": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, C.POINTER(C.c_int32)]),
@@ -228,6 +230,21 @@ class Handle:
         n = C.c_int32(0)
         check(self._lib.mik_experimental_variogram(self._h, int(nlags), _ptr(lags), _ptr(semi), C.byref(n)))
         return lags[:n.value].copy(), semi[:n.value].copy()
+
+    def set_custom_variogram(self, gamma):
+        """variogram_model='custom': `gamma(d)` maps an array of distances to semivariances (NumPy, on the host -- it is the
+        user's Python code); the library hands it blocks of device-computed distances (mik_set_custom_variogram)."""
+        if gamma is None:
+            self._custom_cb = None
+            check(self._lib.mik_set_custom_variogram(self._h, C.cast(None, VARIOGRAM_FN), None))
+            return
+
+        def _cb(_user, ptr, rows, cols, ld):
+            block = np.ctypeslib.as_array(ptr, shape=(rows * ld,)).reshape(rows, ld)[:, :cols]
+            block[...] = np.asarray(gamma(block), dtype=np.float64)
+
+        self._custom_cb = VARIOGRAM_FN(_cb)  # keep it alive as long as the handle may call it
+        check(self._lib.mik_set_custom_variogram(self._h, self._custom_cb, None))
 
     def synchronize(self):
         check(self._lib.mik_synchronize(self._h))

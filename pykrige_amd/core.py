@@ -53,7 +53,15 @@ def great_circle_distance(lon1, lat1, lon2, lat2):
 def make_variogram_parameter_list(model, params):
     """User parameters (list or dict) -> internal list; None stays None (= 'fit it')."""
     if params is None:
+        if model == "custom":  # core.py:525-529
+            raise ValueError("Variogram parameters must be specified when implementing custom variogram model.")
         return None
+    if model == "custom":  # core.py:309-314, 359-360: a list, handed to the user's function as is
+        if type(params) is dict:
+            raise TypeError("For user-specified custom variogram model, parameters must be specified in a list, not a dict.")
+        if type(params) is list:
+            return list(params)
+        raise TypeError("Variogram model parameters must be provided in either a list or a dict")
     if model not in MODELS:
         raise ValueError("Specified variogram model must be one of the following: " + ", ".join(repr(m) for m in MODELS))
     if type(params) is dict:
@@ -143,9 +151,7 @@ def _model_of(variogram_function):
     from . import variogram_models as vm
 
     name = getattr(variogram_function, "__name__", None)
-    if name not in vm.MODEL_OF_FUNCTION:
-        raise NotImplementedError("only the six named variogram models have a device functor (got %r)" % (name,))
-    return vm.MODEL_OF_FUNCTION[name]
+    return vm.MODEL_OF_FUNCTION.get(name, "custom")  # anything else is a user callable: evaluated on the host
 
 
 def _problem_handle(X, y, variogram_function, variogram_model_parameters, coordinates_type):
@@ -158,8 +164,13 @@ def _problem_handle(X, y, variogram_function, variogram_model_parameters, coordi
         raise ValueError("Geographic coordinate type only supported for 2D datasets.")
     model = _model_of(variogram_function)
     h = _lib.Handle()
+    params = [float(v) for v in variogram_model_parameters]
+    if model == "custom":
+        fn, par = variogram_function, variogram_model_parameters
+        h.set_custom_variogram(lambda d: fn(par, d))
+        params = [0.0, 0.0, 0.0]
     h.set_problem(ndim=X.shape[1], xs=X[:, 0], ys=X[:, 1], zs=X[:, 2] if X.shape[1] == 3 else None, values=y,
-                  model_id=_lib.MODEL_IDS[model], params=[float(v) for v in variogram_model_parameters], eps=_eps,
+                  model_id=_lib.MODEL_IDS[model], params=params, eps=_eps,
                   exact_values=True, geographic=coordinates_type == "geographic")
     return h
 

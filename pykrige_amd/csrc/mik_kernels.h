@@ -149,20 +149,25 @@ __global__ void __launch_bounds__(256) k_assemble(AsmArgs a) {
       if (i == j) {
         val = a.shift;  // np.fill_diagonal(a, 0.0)
       } else {
+        double d, s2;
         if (NDIM == 1) {
-          const double d = gc_dist(sx[r], sy[r], sz[r], xj, yj, zj);
-          val = a.shift - vario<MODEL, false>(a.v, d, d * d);
+          d = gc_dist(sx[r], sy[r], sz[r], xj, yj, zj);
+          s2 = d * d;
         } else {
           const double dx = sx[r] - xj, dy = sy[r] - yj;
-          double s2;
           if (NDIM == 3) {
             const double dz = sz[r] - zj;
             s2 = dx * dx + dy * dy + dz * dz;
           } else {
             s2 = dx * dx + dy * dy;
           }
-          val = a.shift - vario<MODEL, false>(a.v, sqrt(s2), s2);
+          d = sqrt(s2);
         }
+        // MODEL 7 / 6 = the two passes of a custom (host callable) variogram: 7 leaves the distance in the matrix slot,
+        // the host maps d -> gamma(d) over the station block, 6 picks gamma up from the slot
+        if (MODEL == 7) val = d;
+        else if (MODEL == 6) val = a.shift - a.T[(long)i * a.ld + j];
+        else val = a.shift - vario<MODEL, false>(a.v, d, s2);
       }
     } else if (i >= a.N && j >= a.N) {
       val = 0.0;
@@ -259,7 +264,21 @@ __global__ void __launch_bounds__(256) k_rhs(RhsArgs a) {
 #pragma unroll
       for (int q = 0; q < MIK_TP; ++q) {
         double g;
-        if (NDIM == 1) {
+        if (MODEL == 6 || MODEL == 7) {  // custom variogram, see k_assemble: 7 writes d, 6 reads gamma(d) back
+          double d;
+          if (NDIM == 1) {
+            d = gc_dist(qx[q], qy[q], qz[q], sx, sy, sz);
+          } else {
+            const double dx = qx[q] - sx, dy = qy[q] - sy, dz = (NDIM == 3) ? qz[q] - sz : 0.0;
+            d = sqrt(dz * dz + dy * dy + dx * dx);
+          }
+          if (MODEL == 7) {
+            g = d;
+          } else {
+            g = -a.Bt[(long)(t0 + q) * a.ld + j];
+            if (a.exact && d <= a.eps) g = 0.0;
+          }
+        } else if (NDIM == 1) {
           const double d = gc_dist(qx[q], qy[q], qz[q], sx, sy, sz);  // point first (ok.py:990-996)
           g = -vario<MODEL, true>(a.v, d, d * d);
           if (a.exact && d <= a.eps) g = 0.0;
@@ -1443,6 +1462,7 @@ __global__ void __launch_bounds__(64) k_mw_knn(KnnArgs a) {
 struct MwArgs {
   const double *sx, *sy, *sz;  // station coordinates (adjusted); geographic: lon, lat in degrees
   int mode;                    // 2 / 3 = Euclidean dimension, 1 = geographic (great-circle degrees)
+  const double* gtab;          // custom variogram: gamma of the K x K station pairs of every point (host-mapped), else NULL
   int K, npt;
   const int* idx;
   const double* dist;
@@ -1481,6 +1501,36 @@ __device__ __forceinline__ double mw_entry(const Vario& v, int mode, double x1, 
     d = sqrt(d2);
   }
   return -vario_dyn(v, d, d2);
+}
+
+// custom variogram, moving window: distances between the selected stations of every point, [point][row][col]
+__global__ void __launch_bounds__(256)
+k_mw_pairdist(const int* __restrict__ idx, long npt, int K, const double* __restrict__ sx, const double* __restrict__ sy,
+              const double* __restrict__ sz, int mode, double* __restrict__ out) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= npt * K * K) return;
+  const long pt = e / ((long)K * K);
+  const int rc = (int)(e - pt * K * K), r = rc / K, c = rc - r * K;
+  const int s1 = idx[pt * K + r], s2 = idx[pt * K + c];
+  double d = 0.0;
+  if (r != c) {
+    if (mode == 1) {
+      const double la1 = sy[s1] * MIK_PI / 180.0, la2 = sy[s2] * MIK_PI / 180.0;
+      d = gc_dist(sx[s1], cos(la1), sin(la1), sx[s2], cos(la2), sin(la2));
+    } else {
+      const double dx = sx[s1] - sx[s2], dy = sy[s1] - sy[s2], dz = (mode == 3) ? sz[s1] - sz[s2] : 0.0;
+      d = sqrt(dx * dx + dy * dy + dz * dz);
+    }
+  }
+  out[e] = d;
+}
+// custom variogram, moving window: b = -gamma (host-mapped copy of the distances), 0 on an exact hit
+__global__ void __launch_bounds__(256)
+k_mw_rhs_table(double* __restrict__ dist, const double* __restrict__ gam, long n, int exact, double eps) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  const double d = dist[e];
+  dist[e] = (exact && d <= eps) ? 0.0 : -gam[e];
 }
 
 // right-hand sides in place: dist[e] (distance to the e-th selected station) -> b = -gamma(d), 0 on an exact hit
@@ -1553,7 +1603,9 @@ __global__ void __launch_bounds__(256) k_mw_solve(MwArgs a) {
       if (live && row < nb && col <= nb) {
         if (col == nb) v = bvec[row];
         else if (row < K && col < K)
-          v = (row == col) ? 0.0 : mw_entry(a.v, a.mode, csx[row], csy[row], csz[row], csx[col], csy[col], csz[col]);
+          v = (row == col) ? 0.0
+              : a.gtab ? -a.gtab[(pt * K + row) * K + col]
+                       : mw_entry(a.v, a.mode, csx[row], csy[row], csz[row], csx[col], csy[col], csz[col]);
         else v = (row == K && col == K) ? 0.0 : 1.0;
       }
       m[i][j] = v;
@@ -1740,7 +1792,9 @@ __global__ void __launch_bounds__(256) k_mw_solve_big(MwArgs a, double* __restri
       double v;
       if (r < K && c < K) {
         v = 0.0;
-        if (r != c) {
+        if (r != c && a.gtab) {
+          v = -a.gtab[(pt * K + r) * K + c];
+        } else if (r != c) {
           const int s1 = sel[r], s2 = sel[c];
           double y1 = a.sy[s1], y2 = a.sy[s2], z1 = (a.mode == 3) ? a.sz[s1] : 0.0, z2 = (a.mode == 3) ? a.sz[s2] : 0.0;
           if (a.mode == 1) {

@@ -115,6 +115,8 @@ struct mik_handle {
   double eps = 1e-10, shift_guess = 0.0;
   bool host_inv = false;
   int pinv = 0;  // pseudo_inv: 0 no, 1 'pinv', 2 'pinvh'
+  mik_variogram_fn custom_fn = nullptr;  // variogram_model == 'custom' (model 6): host map d -> gamma(d)
+  void* custom_user = nullptr;
   std::vector<double> host_ainv;
   DevBuf xs, ys, zs, vals, wells, extra_cols;
   std::vector<double> hxs, hys, hzs;  // host copies of the station coordinates (the moving-window cell grid is built on the host)
@@ -413,6 +415,13 @@ void mik_destroy(mik_handle* h) {
   delete h;
 }
 
+int mik_set_custom_variogram(mik_handle* h, mik_variogram_fn fn, void* user) {
+  if (!h) return fail(MIK_EINVAL, "mik_set_custom_variogram: NULL handle");
+  h->custom_fn = fn;
+  h->custom_user = user;
+  return MIK_OK;
+}
+
 int mik_set_option(mik_handle* h, const char* key, double value) {
   if (!h || !key) return fail(MIK_EINVAL, "mik_set_option: NULL argument");
   if (!strcmp(key, "factor")) {
@@ -444,7 +453,7 @@ int mik_set_problem(mik_handle* h, const mik_problem* p) {
   if (!h || !p) return fail(MIK_EINVAL, "mik_set_problem: NULL argument");
   if (p->ndim != 2 && p->ndim != 3) return fail(MIK_EINVAL, "ndim must be 2 or 3");
   if (p->n < 1 || p->n > 2000000) return fail(MIK_EINVAL, "n out of range");
-  if (p->model_id < 0 || p->model_id > 5) return fail(MIK_EINVAL, "unknown variogram model id");
+  if (p->model_id < 0 || p->model_id > MIK_MODEL_CUSTOM) return fail(MIK_EINVAL, "unknown variogram model id");
   if (!p->xs || !p->ys || !p->values || (p->ndim == 3 && !p->zs)) return fail(MIK_EINVAL, "station arrays missing");
   if (p->n_wells < 0 || p->n_extra < 0 || (p->n_wells > 0 && !p->wells) || (p->n_extra > 0 && !p->extra_cols))
     return fail(MIK_EINVAL, "drift description inconsistent");
@@ -536,6 +545,27 @@ int mik_set_problem(mik_handle* h, const mik_problem* p) {
   return MIK_OK;
 }
 
+#define DISPATCH_NDIM_FIXED(MODEL, ndim, KERNEL, grid, block, stream, args)                    \
+  do {                                                                                        \
+    if ((ndim) == 1) hipLaunchKernelGGL((KERNEL<MODEL, 1>), grid, block, 0, stream, args);    \
+    else if ((ndim) == 3) hipLaunchKernelGGL((KERNEL<MODEL, 3>), grid, block, 0, stream, args); \
+    else hipLaunchKernelGGL((KERNEL<MODEL, 2>), grid, block, 0, stream, args);                \
+  } while (0)
+
+// custom variogram: bring `rows` rows of a device array (row length ld, `cols` meaningful columns) to the host, let the
+// caller's function turn distances into gamma in place, send them back
+static int custom_roundtrip(mik_handle* h, double* dev, long rows, long cols, long ld) {
+  if (!h->custom_fn) return fail(MIK_ESTATE, "variogram model 'custom' needs mik_set_custom_variogram first");
+  if (rows <= 0) return MIK_OK;
+  std::vector<double> host((size_t)rows * ld);
+  HIPC(hipMemcpyAsync(host.data(), dev, sizeof(double) * host.size(), hipMemcpyDeviceToHost, h->stream));
+  HIPC(hipStreamSynchronize(h->stream));
+  h->custom_fn(h->custom_user, host.data(), rows, cols, ld);
+  HIPC(hipMemcpyAsync(dev, host.data(), sizeof(double) * host.size(), hipMemcpyHostToDevice, h->stream));
+  HIPC(hipStreamSynchronize(h->stream));
+  return MIK_OK;
+}
+
 static int launch_assemble(mik_handle* h, double shift) {
   AsmArgs a{};
   a.T = h->T.as<double>();
@@ -556,7 +586,13 @@ static int launch_assemble(mik_handle* h, double shift) {
   a.wells = h->wells.as<double>();
   a.extra = h->extra_cols.as<double>();
   dim3 grid(h->Mp / 64, h->Mp / 64);
-  DISPATCH_MODEL_NDIM(h->model, h->geo ? 1 : h->ndim, k_assemble, grid, dim3(256), h->stream, a);
+  if (h->model == MIK_MODEL_CUSTOM) {
+    DISPATCH_NDIM_FIXED(7, h->geo ? 1 : h->ndim, k_assemble, grid, dim3(256), h->stream, a);  // distances
+    MIKC(custom_roundtrip(h, a.T, h->N, h->N, a.ld));                                           // d -> gamma on the host
+    DISPATCH_NDIM_FIXED(6, h->geo ? 1 : h->ndim, k_assemble, grid, dim3(256), h->stream, a);  // the matrix proper
+  } else {
+    DISPATCH_MODEL_NDIM(h->model, h->geo ? 1 : h->ndim, k_assemble, grid, dim3(256), h->stream, a);
+  }
   HIPC(hipGetLastError());
   return MIK_OK;
 }
@@ -696,6 +732,7 @@ int mik_factor(mik_handle* h) {
   // bounded models, gamma(bounding-box diagonal) for linear/power); a non-positive station pivot (matrix not
   // positive definite, e.g. hole-effect in 2-D) sends the attempt to the pivoted path below.
   bool try_sweep = h->opt_factor == 1 || h->opt_factor == 0;
+  if (h->model == MIK_MODEL_CUSTOM) try_sweep = false;  // no sill to shift by: pivoted elimination
   for (int attempt = 0; attempt < 2; ++attempt) {
     const bool pivoted = !try_sweep;
     const double shift = pivoted ? 0.0 : h->shift_guess;
@@ -803,6 +840,7 @@ int mik_predict(mik_handle* h) {
     return MIK_OK;
   }
   long chunk = std::min<long>(h->opt_chunk, ((npt + 127) / 128) * 128);
+  if (h->model == MIK_MODEL_CUSTOM) chunk = std::min<long>(chunk, 16384);  // each chunk's distances visit the host
   // keep the RHS panel under ~1/8 of device memory
   size_t freeb = 0, totalb = 0;
   HIPC(hipMemGetInfo(&freeb, &totalb));
@@ -846,7 +884,13 @@ int mik_predict(mik_handle* h) {
     a.zout = h->z.as<double>() + t0;
     hipEvent_t e0 = h->evpool[2 + 3 * c], e1 = h->evpool[3 + 3 * c], e2 = h->evpool[4 + 3 * c];
     HIPC(hipEventRecord(e0, h->stream));
-    DISPATCH_MODEL_NDIM(h->model, h->geo ? 1 : h->ndim, k_rhs, dim3(palloc / MIK_TP), dim3(256), h->stream, a);
+    if (h->model == MIK_MODEL_CUSTOM) {
+      DISPATCH_NDIM_FIXED(7, h->geo ? 1 : h->ndim, k_rhs, dim3(palloc / MIK_TP), dim3(256), h->stream, a);
+      MIKC(custom_roundtrip(h, a.Bt, nvalid, h->N, Mp));
+      DISPATCH_NDIM_FIXED(6, h->geo ? 1 : h->ndim, k_rhs, dim3(palloc / MIK_TP), dim3(256), h->stream, a);
+    } else {
+      DISPATCH_MODEL_NDIM(h->model, h->geo ? 1 : h->ndim, k_rhs, dim3(palloc / MIK_TP), dim3(256), h->stream, a);
+    }
     HIPC(hipEventRecord(e1, h->stream));
     const long tiles = (long)nIblk * (palloc / 128);
     const unsigned grid = (unsigned)(8 * ((tiles + 7) / 8));
@@ -931,11 +975,22 @@ int mik_predict_moving_window(mik_handle* h, int n_closest) {
     if (chunk < 256) chunk = 256;
     if (chunk > npt) chunk = npt;
   }
+  const bool custom = h->model == MIK_MODEL_CUSTOM;
+  if (custom) {  // the K x K pair distances of every point visit the host: bound that table to ~1 GB
+    long cc = ((long)(1e9 / (8.0 * K * (K + 1.0))) / 256) * 256;
+    if (cc < 256) cc = 256;
+    if (chunk > cc) chunk = cc;
+    if (chunk > npt) chunk = npt;
+  }
   MIKC(h->mw_idx.ensure(sizeof(int) * (size_t)chunk * K));
   MIKC(h->mw_dist.ensure(sizeof(double) * (size_t)chunk * K));
   MIKC(h->flag.ensure(sizeof(int)));
   HIPC(hipMemsetAsync(h->flag.p, 0, sizeof(int), h->stream));
-  DevBuf su, pu, wd, wi, sysbuf;
+  DevBuf su, pu, wd, wi, sysbuf, gtab, gvec;
+  if (custom) {
+    MIKC(gtab.ensure(sizeof(double) * (size_t)chunk * K * K));
+    MIKC(gvec.ensure(sizeof(double) * (size_t)chunk * K));
+  }
   const double *sx = h->xs.as<double>(), *sy = h->ys.as<double>(), *sz = h->zs.as<double>();
   const double *qx = h->px.as<double>(), *qy = h->py.as<double>(), *qz = h->pz.as<double>();
   if (h->geo) {
@@ -1037,6 +1092,17 @@ int mik_predict_moving_window(mik_handle* h, int n_closest) {
     {  // right-hand sides in place over the distances
       const long ne = pc * K;
       const unsigned rg = (unsigned)((ne + 255) / 256);
+      if (custom) {
+        // d -> gamma(d) on the host for the point-station distances and for the K x K station pairs of every point
+        HIPC(hipMemcpyAsync(gvec.p, dist, sizeof(double) * ne, hipMemcpyDeviceToDevice, h->stream));
+        MIKC(custom_roundtrip(h, gvec.as<double>(), pc, K, K));
+        hipLaunchKernelGGL(k_mw_rhs_table, dim3(rg), dim3(256), 0, h->stream, dist, (const double*)gvec.as<double>(), ne, h->exact,
+                           h->eps);
+        hipLaunchKernelGGL(k_mw_pairdist, dim3((unsigned)((ne * K + 255) / 256)), dim3(256), 0, h->stream, (const int*)idx, pc, K,
+                           a.sx, a.sy, a.sz, a.mode, gtab.as<double>());
+        MIKC(custom_roundtrip(h, gtab.as<double>(), pc * K, K, K));
+        a.gtab = gtab.as<double>();
+      } else
       switch (h->model) {
         case 0: hipLaunchKernelGGL(k_mw_rhs<0>, dim3(rg), dim3(256), 0, h->stream, dist, ne, h->v, h->exact, h->eps); break;
         case 1: hipLaunchKernelGGL(k_mw_rhs<1>, dim3(rg), dim3(256), 0, h->stream, dist, ne, h->v, h->exact, h->eps); break;

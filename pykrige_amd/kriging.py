@@ -42,14 +42,18 @@ class _KrigingBase:
         self.pseudo_inv_type = str(pseudo_inv_type)
         if self.pseudo_inv_type not in ("pinv", "pinvh"):  # core.py:33 P_INV keys
             raise ValueError("pseudo inv type not valid: " + str(pseudo_inv_type))
+        self.model = None
         if hasattr(variogram_model, "pykrige_kwargs"):
-            raise NotImplementedError(_UNSUPPORTED % "a GSTools covariance model (arbitrary Python callable)")
+            # a GSTools CovModel (ok.py:223-239): it becomes a custom variogram; its anisotropy is taken by the caller
+            self.model = variogram_model
+            variogram_model, variogram_function, variogram_parameters = "custom", variogram_model.pykrige_vario, []
         self.variogram_model = variogram_model
+        self.variogram_function = None
         if variogram_model == "custom":
             if variogram_function is None or not callable(variogram_function):
                 raise ValueError("Must specify callable function for custom variogram model.")
-            raise NotImplementedError(_UNSUPPORTED % "a custom variogram function (no device functor for Python callables)")
-        if variogram_model not in core.MODELS:
+            self.variogram_function = variogram_function  # evaluated on the host (it is Python), geometry stays on the device
+        elif variogram_model not in core.MODELS:
             raise ValueError("Specified variogram model '%s' is not supported." % variogram_model)
         if not isinstance(exact_values, bool):
             raise ValueError("exact_values has to be boolean True or False")
@@ -58,6 +62,7 @@ class _KrigingBase:
         self.enable_plotting = enable_plotting
         self._user_parameters = variogram_parameters
         self._handle = None
+        return variogram_parameters
 
     def _set_variogram_parameters(self, variogram_parameters, nlags, weight):
         plist = core.make_variogram_parameter_list(self.variogram_model, variogram_parameters)
@@ -103,10 +108,17 @@ class _KrigingBase:
                                weight=False, **anisotropy):
         """Changes the variogram model (and optionally the anisotropy) -- ok.py:379-545 without the
         statistics pass, which execute() never reads."""
-        if variogram_model == "custom" or hasattr(variogram_model, "pykrige_kwargs"):
-            raise NotImplementedError(_UNSUPPORTED % "a custom variogram function")
-        if variogram_model not in core.MODELS:
+        if hasattr(variogram_model, "pykrige_kwargs"):
+            self.model = variogram_model
+            variogram_model, variogram_function, variogram_parameters = "custom", variogram_model.pykrige_vario, []
+        if variogram_model == "custom":
+            if variogram_function is None or not callable(variogram_function):
+                raise ValueError("Must specify callable function for custom variogram model.")
+            self.variogram_function = variogram_function
+        elif variogram_model not in core.MODELS:
             raise ValueError("Specified variogram model '%s' is not supported." % variogram_model)
+        else:
+            self.variogram_function = None
         self.variogram_model = variogram_model
         if anisotropy:
             self._update_anisotropy(**anisotropy)
@@ -142,6 +154,10 @@ class _KrigingBase:
             extra_cols=self._station_extra_cols() if with_drift else None,
             geographic=getattr(self, "coordinates_type", "euclidean") == "geographic",
         )
+        if self.variogram_model == "custom":
+            fn, par = self.variogram_function, self.variogram_model_parameters
+            h.set_custom_variogram(lambda d: fn(par, d))
+            kw["params"] = [0.0, 0.0, 0.0]
         if self.pseudo_inv and with_drift:
             # ok.py:660-661: a_inv = P_INV[self.pseudo_inv_type](a) -- on the device (mik_problem.pseudo_inv)
             kw["pseudo_inv"] = {"pinv": 1, "pinvh": 2}[self.pseudo_inv_type]
@@ -223,6 +239,8 @@ class _KrigingBase:
 
     def get_variogram_points(self):
         """(lags, variogram model evaluated at the lags) -- ok.py:569-587."""
+        if self.variogram_model == "custom":
+            return self.lags, self.variogram_function(self.variogram_model_parameters, self.lags)
         return self.lags, core.variogram_value(self.variogram_model, self.variogram_model_parameters, self.lags)
 
     def display_variogram_model(self):
@@ -379,8 +397,14 @@ class OrdinaryKriging(_KrigingBase):
                  weight=False, anisotropy_scaling=1.0, anisotropy_angle=0.0, verbose=False, enable_plotting=False,
                  enable_statistics=False, coordinates_type="euclidean", exact_values=True, pseudo_inv=False,
                  pseudo_inv_type="pinv"):
-        self._init_common(variogram_model, variogram_parameters, variogram_function, exact_values, pseudo_inv,
-                          pseudo_inv_type, verbose, enable_plotting)
+        variogram_parameters = self._init_common(variogram_model, variogram_parameters, variogram_function, exact_values,
+                                                 pseudo_inv, pseudo_inv_type, verbose, enable_plotting)
+        if self.model is not None:  # GSTools CovModel: 2-D only, its own anisotropy (ok.py:228-239)
+            if self.model.field_dim == 3:
+                raise ValueError("GSTools: model dim is not 1 or 2")
+            if self.model.latlon and coordinates_type == "euclidean":
+                raise ValueError("GSTools: latlon models require geographic coordinates")
+            anisotropy_scaling, anisotropy_angle = self.model.pykrige_anis, self.model.pykrige_angle
         if coordinates_type not in ("euclidean", "geographic"):
             raise ValueError("Only 'euclidean' and 'geographic' are valid values for coordinates-keyword.")
         self.coordinates_type = coordinates_type
@@ -582,8 +606,14 @@ class OrdinaryKriging3D(_KrigingBase):
                  nlags=6, weight=False, anisotropy_scaling_y=1.0, anisotropy_scaling_z=1.0, anisotropy_angle_x=0.0,
                  anisotropy_angle_y=0.0, anisotropy_angle_z=0.0, verbose=False, enable_plotting=False,
                  exact_values=True, pseudo_inv=False, pseudo_inv_type="pinv"):
-        self._init_common(variogram_model, variogram_parameters, variogram_function, exact_values, pseudo_inv,
-                          pseudo_inv_type, verbose, enable_plotting)
+        variogram_parameters = self._init_common(variogram_model, variogram_parameters, variogram_function, exact_values,
+                                                 pseudo_inv, pseudo_inv_type, verbose, enable_plotting)
+        if self.model is not None:  # GSTools CovModel: 3-D only here, its own anisotropy (ok3d.py:232-245)
+            if self.model.field_dim < 3:
+                raise ValueError("GSTools: model dim is not 3")
+            anisotropy_scaling_y, anisotropy_scaling_z = self.model.pykrige_anis_y, self.model.pykrige_anis_z
+            anisotropy_angle_x, anisotropy_angle_y, anisotropy_angle_z = (self.model.pykrige_angle_x, self.model.pykrige_angle_y,
+                                                                          self.model.pykrige_angle_z)
         self.X_ORIG = np.atleast_1d(np.squeeze(np.array(x, copy=True, dtype=np.float64)))
         self.Y_ORIG = np.atleast_1d(np.squeeze(np.array(y, copy=True, dtype=np.float64)))
         self.Z_ORIG = np.atleast_1d(np.squeeze(np.array(z, copy=True, dtype=np.float64)))

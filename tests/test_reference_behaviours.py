@@ -207,8 +207,10 @@ def test_core_krige_and_find_statistics_function_twins():
     np.testing.assert_allclose(delta, g["delta_exp"], atol=1e-8)
     np.testing.assert_allclose(sigma, g["sigma_exp"], atol=1e-8)
     np.testing.assert_allclose([core.calcQ1(eps), core.calcQ2(eps), core.calc_cR(core.calcQ2(eps), sigma)], g["q_exp"], rtol=1e-7)
-    with pytest.raises(NotImplementedError):
-        core._krige(d[:, :2], d[:, 2], np.array([1.0, 1.0]), lambda m, x: x, [1.0], "euclidean")
+    # a callable that is not one of the six named functions is a custom variogram: evaluated on the host, same numbers
+    k1, s1 = core._krige(d[:, :2], d[:, 2], np.array([1.0, 1.0]), variogram_models.linear_variogram_model, [1.0, 1.0], "euclidean")
+    k2, s2 = core._krige(d[:, :2], d[:, 2], np.array([1.0, 1.0]), lambda m, x: m[0] * x + m[1], [1.0, 1.0], "euclidean")
+    assert k2 == approx(k1, abs=1e-10) and s2 == approx(s1, abs=1e-10)
 
 
 def test_sklearn_side_callers_match_the_reference():
@@ -285,3 +287,65 @@ def test_get_kriging_matrix_method():
     au = uk._get_kriging_matrix(60)
     assert au.shape == (64, 64)
     np.testing.assert_allclose(au, ko.kriging_matrix(stu), rtol=0, atol=1e-12)
+
+
+def test_custom_variogram_callable_matches_the_reference():
+    """variogram_model='custom' (ok.py:247-254; test_core.py test_custom_variogram): the user's Python callable maps
+    device-computed distances to semivariances on the host (mik_set_custom_variogram), everything else -- geometry,
+    matrix borders and drifts, the eps rule, inverse, contraction, moving window, statistics -- runs on the device.
+    Against the real reference with the same callable (tests/golden/custom_variogram.npz)."""
+    from oracle.make_golden_extra import stable_variogram
+    from tests import _fixtures as fx
+
+    pa = _pa()
+    g = fx.load("custom_variogram")
+    par = [float(p) for p in g["par"]]
+    ok = pa.OrdinaryKriging(g["x"], g["y"], g["v"], variogram_model="custom", variogram_parameters=par,
+                            variogram_function=stable_variogram, anisotropy_scaling=1.4, anisotropy_angle=15.0, enable_statistics=True)
+    z, ss = ok.execute("grid", g["gx"], g["gy"], backend="vectorized")
+    np.testing.assert_allclose(z, g["ok_z"], rtol=0, atol=1e-8)
+    np.testing.assert_allclose(ss, g["ok_ss"], rtol=0, atol=1e-6)
+    assert ok.last_timing["factor_path"] == 2  # no sill to shift by: pivoted elimination
+    zk, ssk = ok.execute("grid", g["gx"], g["gy"], backend="loop", n_closest_points=9)
+    np.testing.assert_allclose(zk, g["ok_zk"], rtol=0, atol=1e-8)
+    np.testing.assert_allclose(ssk, g["ok_ssk"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose([ok.Q1, ok.Q2, ok.cR], g["ok_q"], rtol=1e-7)
+    np.testing.assert_allclose(ok.epsilon, g["ok_eps"], rtol=0, atol=1e-7)
+    uk = pa.UniversalKriging(g["x"], g["y"], g["v"], variogram_model="custom", variogram_parameters=par,
+                             variogram_function=stable_variogram, drift_terms=["regional_linear"])
+    z, ss = uk.execute("grid", g["gx"], g["gy"], backend="loop")
+    np.testing.assert_allclose(z, g["uk_z"], rtol=0, atol=1e-8)
+    np.testing.assert_allclose(ss, g["uk_ss"], rtol=0, atol=1e-6)
+    k3 = pa.OrdinaryKriging3D(g["x3"], g["y3"], g["z3"], g["v3"], variogram_model="custom", variogram_parameters=par,
+                              variogram_function=stable_variogram)
+    z, ss = k3.execute("grid", g["g3x"], g["g3y"], g["g3z"], backend="vectorized")
+    np.testing.assert_allclose(z, g["k3_z"], rtol=0, atol=1e-8)
+    np.testing.assert_allclose(ss, g["k3_ss"], rtol=0, atol=1e-6)
+    lags, curve = ok.get_variogram_points()
+    np.testing.assert_allclose(curve, stable_variogram(par, lags))
+    # the multi-chunk route (every chunk's distances visit the host) and a model switch back to a named variogram
+    ok._get_handle().set_option("chunk", 128)
+    z2, _ = ok.execute("grid", g["gx"], g["gy"], backend="loop")
+    np.testing.assert_allclose(z2, g["ok_z"], rtol=0, atol=1e-8)
+    ok.update_variogram_model("exponential", [1.0, 0.4, 0.02])
+    z3, _ = ok.execute("points", g["x"][:3], g["y"][:3], backend="loop")
+    np.testing.assert_allclose(z3, g["v"][:3], rtol=0, atol=1e-8)
+    with pytest.raises(ValueError):
+        pa.OrdinaryKriging(g["x"], g["y"], g["v"], variogram_model="custom", variogram_parameters=par)  # no callable
+    with pytest.raises(ValueError):
+        pa.OrdinaryKriging(g["x"], g["y"], g["v"], variogram_model="custom", variogram_function=stable_variogram)  # no parameters
+    with pytest.raises(TypeError):
+        pa.OrdinaryKriging(g["x"], g["y"], g["v"], variogram_model="custom", variogram_function=stable_variogram,
+                           variogram_parameters={"sill": 1.0})
+
+    class FakeCovModel:  # the attributes a GSTools CovModel brings (ok.py:223-239); GSTools itself is not installed
+        pykrige_kwargs = {}
+        field_dim, latlon, pykrige_anis, pykrige_angle = 2, False, 1.4, 15.0
+
+        @staticmethod
+        def pykrige_vario(args=None, r=0):
+            return stable_variogram(par, r)
+
+    gs = pa.OrdinaryKriging(g["x"], g["y"], g["v"], variogram_model=FakeCovModel())
+    z, ss = gs.execute("grid", g["gx"], g["gy"], backend="loop")
+    np.testing.assert_allclose(z, g["ok_z"], rtol=0, atol=1e-8)
