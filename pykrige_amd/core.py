@@ -154,7 +154,7 @@ def _model_of(variogram_function):
     return vm.MODEL_OF_FUNCTION.get(name, "custom")  # anything else is a user callable: evaluated on the host
 
 
-def _problem_handle(X, y, variogram_function, variogram_model_parameters, coordinates_type):
+def _problem_handle(X, y, variogram_function, variogram_model_parameters, coordinates_type, pseudo_inv=False):
     from . import _lib
 
     X = np.ascontiguousarray(X, dtype=np.float64)
@@ -171,16 +171,15 @@ def _problem_handle(X, y, variogram_function, variogram_model_parameters, coordi
         params = [0.0, 0.0, 0.0]
     h.set_problem(ndim=X.shape[1], xs=X[:, 0], ys=X[:, 1], zs=X[:, 2] if X.shape[1] == 3 else None, values=y,
                   model_id=_lib.MODEL_IDS[model], params=params, eps=_eps,
-                  exact_values=True, geographic=coordinates_type == "geographic")
+                  exact_values=True, geographic=coordinates_type == "geographic", pseudo_inv=1 if pseudo_inv else 0)
     return h
 
 
 def _krige(X, y, coords, variogram_function, variogram_model_parameters, coordinates_type, pseudo_inv=False):
     """Ordinary kriging of ONE point from the stations X (the single-point form of the execute() solve)."""
-    if pseudo_inv:
-        raise NotImplementedError("pseudo_inv in _krige uses numpy.linalg.lstsq on the host; not on the device path")
     coords = np.asarray(coords, dtype=np.float64).ravel()
-    h = _problem_handle(X, y, variogram_function, variogram_model_parameters, coordinates_type)
+    # pseudo_inv: the reference solves with numpy.linalg.lstsq (core.py:749-750), i.e. the minimum-norm solution pinv(A) b
+    h = _problem_handle(X, y, variogram_function, variogram_model_parameters, coordinates_type, pseudo_inv)
     try:
         h.factor()
         h.set_points(coords[0:1], coords[1:2], coords[2:3] if coords.size == 3 else None)
@@ -194,7 +193,8 @@ def _krige(X, y, coords, variogram_function, variogram_model_parameters, coordin
 def _find_statistics(X, y, variogram_function, variogram_model_parameters, coordinates_type, pseudo_inv=False):
     """delta, sigma, epsilon of the variogram fit (station i kriged from stations 0..i-1) on the device."""
     if pseudo_inv:
-        raise NotImplementedError("pseudo_inv statistics are outside the device path")
+        raise NotImplementedError("statistics with pseudo_inv (N-1 least-squares solves of singular subsets) have no device form; "
+                                  "remove the duplicated stations or use pseudo_inv=False")
     y = np.ascontiguousarray(y, dtype=np.float64)
     h = _problem_handle(X, y, variogram_function, variogram_model_parameters, coordinates_type)
     try:

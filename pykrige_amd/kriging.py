@@ -21,11 +21,6 @@ import numpy as np
 from . import _lib
 from . import core
 
-_UNSUPPORTED = (
-    "pykrige_amd implements the execute() hot path on the GPU; %s is outside that path "
-    "(see DESIGN.md, 'out of scope')."
-)
-
 
 class _KrigingBase:
     eps = 1.0e-10  # ok.py:177, uk.py:210

@@ -211,6 +211,11 @@ def test_core_krige_and_find_statistics_function_twins():
     k1, s1 = core._krige(d[:, :2], d[:, 2], np.array([1.0, 1.0]), variogram_models.linear_variogram_model, [1.0, 1.0], "euclidean")
     k2, s2 = core._krige(d[:, :2], d[:, 2], np.array([1.0, 1.0]), lambda m, x: m[0] * x + m[1], [1.0, 1.0], "euclidean")
     assert k2 == approx(k1, abs=1e-10) and s2 == approx(s1, abs=1e-10)
+    # pseudo_inv: duplicated stations, least-squares solution (core.py:749-750) = device pseudo-inverse; mean of the redundant data
+    dup = np.array([[0.0, 0.0, 1.0], [0.0, 0.0, 3.0], [1.0, 0.0, 6.0], [0.3, 0.8, 2.0]])
+    kz, _ = core._krige(dup[:, :2], dup[:, 2], np.array([0.0, 0.0]), variogram_models.linear_variogram_model, [1.0, 0.0], "euclidean",
+                        pseudo_inv=True)
+    assert kz == approx(2.0, abs=1e-9)
 
 
 def test_sklearn_side_callers_match_the_reference():
