@@ -92,7 +92,7 @@ typedef struct mik_timing {
   double contract_flops_executed; /* flops the contraction kernel really executed (symmetric form: ~M^2/pt) */
   int32_t factor_path;    /* 1 = unpivoted symmetric block sweep on the SPD-shifted matrix, 2 = pivoted block Gauss-Jordan, 3 = caller-supplied inverse, 4 = device pseudo-inverse */
   int32_t symmetric;      /* 1 = contraction used the symmetric half product */
-  int32_t engine;         /* 0 = v_mfma_f64_16x16x4_f64 contraction, 1 = v_fma_f64 register-tiled contraction */
+  int32_t engine;         /* 0 = v_mfma_f64_4x4x4_4b_f64 contraction, 1 = v_fma_f64 register-tiled contraction */
   int32_t reserved;
 } mik_timing;
 
@@ -101,7 +101,7 @@ int  mik_create(int device, mik_handle **out);
 void mik_destroy(mik_handle *h);
 
 /* options: "factor" 0=auto 1=sweep 2=pivoted ; "symmetric" 0/1 (contraction uses A_inv symmetry) ;
- * "engine" 0 = MFMA f64 contraction, 1 = VALU (v_fma_f64) contraction ;
+ * "engine" 0 = MFMA f64 contraction, 1 = VALU (v_fma_f64) contraction ; "waves" 4 | 8 = wavefronts per contraction block ;
  * "chunk" = points per contraction launch (multiple of 128) ;
  * "mw_lds_cap" = largest moving-window candidate buffer kept in LDS (entries, default 8192; 0 forces the HBM lists) */
 int  mik_set_option(mik_handle *h, const char *key, double value);
@@ -144,7 +144,7 @@ int  mik_assemble_only(mik_handle *h);
 int  mik_get_matrix(mik_handle *h, int which, double *out);
 int64_t mik_matrix_order(mik_handle *h); /* M = n + ndrift + 1 */
 int  mik_get_timing(mik_handle *h, mik_timing *out);
-int  mik_selftest_mfma(int device); /* 0 if v_mfma_f64_16x16x4_f64 fragment layout is what the kernels assume */
+int  mik_selftest_mfma(int device); /* 0 if the v_mfma_f64_4x4x4_4b_f64 (and 16x16x4) fragment layouts are what the kernels assume */
 
 /* Multi-GPU (one process per GPU): grid points are sharded by the caller; the factored matrix is
  * broadcast from `root` over RCCL/xGMI.  The 128-byte id is an ncclUniqueId made on rank 0 and
