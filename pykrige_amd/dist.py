@@ -28,6 +28,8 @@ class SocketGroup:
         self.world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else int(world)
         addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
         base = int(port if port is not None else int(os.environ.get("MASTER_PORT", "29500")) + 1017)
+        if base + 16 > 65535:  # stay inside the port range whatever MASTER_PORT is
+            base -= 2 * 1017 + 16
         self._peers = []
         self._sock = None
         if self.world == 1:
