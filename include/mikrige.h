@@ -103,6 +103,8 @@ void mik_destroy(mik_handle *h);
 /* options: "factor" 0=auto 1=sweep 2=pivoted ; "symmetric" 0/1 (contraction uses A_inv symmetry) ;
  * "engine" 0 = MFMA f64 contraction, 1 = VALU (v_fma_f64) contraction ; "waves" 4 | 8 = wavefronts per contraction block ;
  * "chunk" = points per contraction launch (multiple of 128) ;
+ * "lookahead" 0/1/-1 = overlap the next panel's serial chain with the current trailing update in the block sweep
+ *   (default -1: from 24 block columns on) ; "diag" 0..3 = diagonal-block inverse kernel variant (default 1) ;
  * "mw_lds_cap" = largest moving-window candidate buffer kept in LDS (entries, default 8192; 0 forces the HBM lists) */
 int  mik_set_option(mik_handle *h, const char *key, double value);
 

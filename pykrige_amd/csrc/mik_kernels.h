@@ -862,14 +862,24 @@ __global__ void __launch_bounds__(256) k_rt_from_cnew(const double* __restrict__
   Rt[idx] = (j < k0) ? Cnew[idx] : -Cnew[idx];
 }
 
-// trailing update + panel write-back, one 128x128 tile per block
+// trailing update + panel write-back, one 128x128 tile per block.  part = 0: every tile; part = 1: only block column
+// `col` (nblk blocks; the look-ahead launch that frees the next panel early); part = 2: everything but block column `col`.
 __global__ void __launch_bounds__(256, 2)
 k_update(double* __restrict__ T, long ld, int nblk, int kb, const double* __restrict__ Cold,
-         const double* __restrict__ Cnew, const double* __restrict__ Rt, const double* __restrict__ Dinv) {
+         const double* __restrict__ Cnew, const double* __restrict__ Rt, const double* __restrict__ Dinv, int part, int col) {
   __shared__ GemmSmem sm;
-  const long L = xcd_tile((long)nblk * nblk);
-  if (L < 0) return;
-  const int iblk = (int)(L / nblk), jblk = (int)(L % nblk);
+  int iblk, jblk;
+  if (part == 1) {
+    iblk = blockIdx.x;
+    jblk = col;
+    if (iblk >= nblk) return;
+  } else {
+    const long L = xcd_tile((long)nblk * nblk);
+    if (L < 0) return;
+    iblk = (int)(L / nblk);
+    jblk = (int)(L % nblk);
+    if (part == 2 && jblk == col) return;
+  }
   const int i0 = iblk * MIK_BM, j0 = jblk * MIK_BN, k0 = kb * 128;
   if (iblk == kb || jblk == kb) {
     for (int e = threadIdx.x; e < 128 * 128; e += 256) {
@@ -966,6 +976,77 @@ __global__ void __launch_bounds__(1024) k_diag_inv(const double* __restrict__ T,
     DinvT[lane * 128 + i] = al[r];
     DinvT[(lane + 64) * 128 + i] = ah[r];
   }
+  if (bad && threadIdx.x == 0) atomicOr(flag, bad);
+}
+
+// The same 128x128 in-place Gauss-Jordan inverse on a NT-thread workgroup laid out as a GY x GX grid with a cyclic
+// (128/GY) x (128/GX) register tile per thread (rows ty + GY i, columns tx + GX j): fewer wavefronts per barrier and the
+// pivot row / column indices inside a thread are compile-time constants (kb outer, unrolled).  One barrier per step.
+template <int GY, int GX>
+__global__ void __launch_bounds__(GY * GX) k_diag_inv_t(const double* __restrict__ T, long ld, int k0, int nspd,
+                                                         double* __restrict__ Dinv, double* __restrict__ DinvT,
+                                                         int* __restrict__ flag) {
+  constexpr int RI = 128 / GY, CJ = 128 / GX, KBN = GY;  // steps per unrolled group
+  static_assert(GY <= GX && GX % GY == 0, "row groups nest in column groups");
+  __shared__ double rowk[2][128], colk[2][128];
+  const int ty = threadIdx.x / GX, tx = threadIdx.x % GX;
+  double a[RI][CJ];
+#pragma unroll
+  for (int i = 0; i < RI; ++i)
+#pragma unroll
+    for (int j = 0; j < CJ; ++j) a[i][j] = T[(long)(k0 + ty + GY * i) * ld + k0 + tx + GX * j];
+  int bad = 0;
+  // step k = GY * kb + kr: pivot row k is local row kb of the threads with ty == kr; pivot column k is local column
+  // jb = k / GX (constant within the group) of the threads with tx == k % GX
+#pragma unroll
+  for (int kb = 0; kb < 128 / KBN; ++kb) {
+    const int jb = (GY * kb) / GX, cbase = (GY * kb) % GX;  // compile-time after unrolling
+#pragma unroll 1
+    for (int kr = 0; kr < KBN; ++kr) {
+      const int k = KBN * kb + kr, pb = kr & 1;
+      if (ty == kr) {
+#pragma unroll
+        for (int j = 0; j < CJ; ++j) rowk[pb][tx + GX * j] = a[kb][j];
+      }
+      if (tx == cbase + kr) {
+#pragma unroll
+        for (int i = 0; i < RI; ++i) {
+#pragma unroll
+          for (int j = 0; j < CJ; ++j)
+            if (j == jb) colk[pb][ty + GY * i] = a[i][j];
+        }
+      }
+      __syncthreads();
+      const double piv = rowk[pb][k];
+      if (!(fabs(piv) > 1e-300) || !isfinite(piv)) bad |= 1;
+      if ((k0 + k) < nspd && !(piv > 0.0)) bad |= 2;
+      const double pinv = 1.0 / piv;
+      double rk[CJ], ck[RI];
+#pragma unroll
+      for (int j = 0; j < CJ; ++j) rk[j] = rowk[pb][tx + GX * j] * pinv;
+#pragma unroll
+      for (int i = 0; i < RI; ++i) ck[i] = colk[pb][ty + GY * i];
+      const bool prow = (ty == kr), pcol = (tx == cbase + kr);
+#pragma unroll
+      for (int i = 0; i < RI; ++i) {
+#pragma unroll
+        for (int j = 0; j < CJ; ++j) {
+          double v = a[i][j] - ck[i] * rk[j];
+          if (j == jb) v = pcol ? -ck[i] * pinv : v;               // pivot column: -a_ik / a_kk
+          if (i == kb) v = prow ? ((j == jb && pcol) ? pinv : rk[j]) : v;  // pivot row: a_kj / a_kk, corner 1 / a_kk
+          a[i][j] = v;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < RI; ++i)
+#pragma unroll
+    for (int j = 0; j < CJ; ++j) {
+      const int r = ty + GY * i, c = tx + GX * j;
+      Dinv[r * 128 + c] = a[i][j];
+      DinvT[c * 128 + r] = a[i][j];
+    }
   if (bad && threadIdx.x == 0) atomicOr(flag, bad);
 }
 

@@ -129,6 +129,11 @@ struct mik_handle {
   } grid;
   // factor
   DevBuf T, cvec, Cold, Cnew, Rt, TKt, Dinv, DinvT, P0, P1, cand0, cand1, pivall, flag;
+  DevBuf Cold2, Cnew2, Rt2, Dinv2, DinvT2;  // second panel set of the look-ahead sweep
+  hipStream_t stream2 = nullptr;            // the look-ahead branch (next panel) runs here
+  std::vector<hipEvent_t> la_events;
+  int opt_lookahead = -1;  // -1 = where it pays (>= 24 block columns), 0 = off, 1 = on
+  int opt_diag = 1;        // diagonal-block inverse variant: 0 = 1024 threads (16 waves x 8 rows), 1 = 16x16 grid, 2 = 16x32, 3 = 32x32
   // points
   long npt_total = 0, npt = 0;
   std::vector<long> scatter;  // empty = identity
@@ -385,6 +390,11 @@ int mik_create(int device, mik_handle** out) {
   h->device = device;
   HIPC(hipStreamCreate(&h->stream));
   {
+    int lo = 0, hi = 0;  // the look-ahead branch is the critical path: give it the dispatcher's highest priority
+    HIPC(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    HIPC(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, hi));
+  }
+  {
     int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) h->n_cu = ncu;
   }
@@ -411,6 +421,8 @@ void mik_destroy(mik_handle* h) {
                     &h->px, &h->py, &h->pz, &h->extra_rows, &h->z, &h->ss, &h->Bt, &h->part, &h->mw_idx, &h->mw_dist, &h->stat_S, &h->stat_x, &h->stat_out, &h->queue};
   for (DevBuf* b : bufs) b->release();
   for (hipEvent_t e : h->evpool) (void)hipEventDestroy(e);
+  for (hipEvent_t e : h->la_events) (void)hipEventDestroy(e);
+  if (h->stream2) (void)hipStreamDestroy(h->stream2);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -438,6 +450,10 @@ int mik_set_option(mik_handle* h, const char* key, double value) {
   } else if (!strcmp(key, "chunk")) {
     if (value < 128) return fail(MIK_EINVAL, "chunk must be >= 128");
     h->opt_chunk = ((long)value / 128) * 128;
+  } else if (!strcmp(key, "diag")) {
+    h->opt_diag = (int)value;
+  } else if (!strcmp(key, "lookahead")) {
+    h->opt_lookahead = value < 0.0 ? -1 : (value != 0.0);
   } else if (!strcmp(key, "mw_lds_cap")) {
     if (value < 0 || value > 8192) return fail(MIK_EINVAL, "mw_lds_cap must be in 0..8192");
     h->opt_mw_lds_cap = (int)value;
@@ -604,6 +620,16 @@ static int ensure_factor_buffers(mik_handle* h) {
   return MIK_OK;
 }
 
+static void launch_diag_inv(mik_handle* h, hipStream_t st, const double* T, long ld, int k0, int nspd, double* dinv, double* dinvT) {
+  int* flag = h->flag.as<int>();
+  switch (h->opt_diag) {
+    case 1: hipLaunchKernelGGL((k_diag_inv_t<16, 16>), dim3(1), dim3(256), 0, st, T, ld, k0, nspd, dinv, dinvT, flag); break;
+    case 2: hipLaunchKernelGGL((k_diag_inv_t<16, 32>), dim3(1), dim3(512), 0, st, T, ld, k0, nspd, dinv, dinvT, flag); break;
+    case 3: hipLaunchKernelGGL((k_diag_inv_t<32, 32>), dim3(1), dim3(1024), 0, st, T, ld, k0, nspd, dinv, dinvT, flag); break;
+    default: hipLaunchKernelGGL(k_diag_inv, dim3(1), dim3(1024), 0, st, T, ld, k0, nspd, dinv, dinvT, flag); break;
+  }
+}
+
 // unpivoted (path 1) or pivoted (path 2) block Gauss-Jordan on T in place
 static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_out) {
   const int Mp = h->Mp, nblk = Mp / 128;
@@ -629,6 +655,55 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
   const long tiles = (long)nblk * nblk;
   const unsigned ugrid = (unsigned)(8 * ((tiles + 7) / 8));
   const unsigned pgrid = (unsigned)(((long)Mp * 128 + 255) / 256);
+  // measured (scripts/inverse_lookahead_ab.py): +16 % at 16 block columns (the second stream's waits cost more than the
+  // overlap returns), -12 % at 40, -17 % at 63
+  const bool lookahead = h->opt_lookahead < 0 ? nblk >= 24 : h->opt_lookahead != 0;
+  if (!pivoted && nblk > 1 && lookahead) {
+    // Look-ahead sweep.  Step kb's update is split: block column kb+1 first (nblk tiles), then -- on the second stream --
+    // the whole panel chain of step kb+1 (diagonal inverse, panel copy, C_new, R^T; a serial ~160 us on few CUs) runs
+    // while the first stream finishes the other nblk^2 - nblk tiles of step kb.  Two panel sets alternate.
+    MIKC(h->Cold2.ensure(panel));
+    MIKC(h->Cnew2.ensure(panel));
+    MIKC(h->Rt2.ensure(panel));
+    MIKC(h->Dinv2.ensure(sizeof(double) * 128 * 128));
+    MIKC(h->DinvT2.ensure(sizeof(double) * 128 * 128));
+    while (h->la_events.size() < 2 * (size_t)nblk) {
+      hipEvent_t e;
+      HIPC(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      h->la_events.push_back(e);
+    }
+    double* cold[2] = {h->Cold.as<double>(), h->Cold2.as<double>()};
+    double* cnew[2] = {h->Cnew.as<double>(), h->Cnew2.as<double>()};
+    double* rt[2] = {h->Rt.as<double>(), h->Rt2.as<double>()};
+    double* dinv[2] = {h->Dinv.as<double>(), h->Dinv2.as<double>()};
+    double* dinvT[2] = {h->DinvT.as<double>(), h->DinvT2.as<double>()};
+    auto panel_chain = [&](hipStream_t st, int kb, int set) {
+      const int k0 = kb * 128;
+      launch_diag_inv(h, st, (const double*)T, ld, k0, nspd, dinv[set], dinvT[set]);
+      hipLaunchKernelGGL(k_copy_panel, dim3(pgrid), dim3(256), 0, st, (const double*)T, ld, k0, Mp, cold[set]);
+      hipLaunchKernelGGL(k_panel, dim3(nblk), dim3(256), 0, st, (const double*)cold[set], 128L, (const double*)dinvT[set], -1.0,
+                         cnew[set]);
+      hipLaunchKernelGGL(k_rt_from_cnew, dim3(pgrid), dim3(256), 0, st, (const double*)cnew[set], rt[set], Mp, k0);
+    };
+    panel_chain(h->stream, 0, 0);
+    for (int kb = 0; kb < nblk; ++kb) {
+      const int set = kb & 1;
+      if (kb + 1 < nblk) {
+        hipLaunchKernelGGL(k_update, dim3(nblk), dim3(256), 0, h->stream, T, ld, nblk, kb, (const double*)cold[set],
+                           (const double*)cnew[set], (const double*)rt[set], (const double*)dinv[set], 1, kb + 1);
+        HIPC(hipEventRecord(h->la_events[2 * kb], h->stream));
+        HIPC(hipStreamWaitEvent(h->stream2, h->la_events[2 * kb], 0));
+        panel_chain(h->stream2, kb + 1, set ^ 1);
+        HIPC(hipEventRecord(h->la_events[2 * kb + 1], h->stream2));
+        hipLaunchKernelGGL(k_update, dim3(ugrid), dim3(256), 0, h->stream, T, ld, nblk, kb, (const double*)cold[set],
+                           (const double*)cnew[set], (const double*)rt[set], (const double*)dinv[set], 2, kb + 1);
+        HIPC(hipStreamWaitEvent(h->stream, h->la_events[2 * kb + 1], 0));
+      } else {
+        hipLaunchKernelGGL(k_update, dim3(ugrid), dim3(256), 0, h->stream, T, ld, nblk, kb, (const double*)cold[set],
+                           (const double*)cnew[set], (const double*)rt[set], (const double*)dinv[set], 0, 0);
+      }
+    }
+  } else
   for (int kb = 0; kb < nblk; ++kb) {
     const int k0 = kb * 128;
     if (pivoted) {
@@ -646,8 +721,7 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
       hipLaunchKernelGGL(k_swap_rows, dim3((Mp + 255) / 256), dim3(256), 0, h->stream, T, ld, k0,
                          (const int*)(h->pivall.as<int>() + k0), Mp);
     }
-    hipLaunchKernelGGL(k_diag_inv, dim3(1), dim3(1024), 0, h->stream, (const double*)T, ld, k0, nspd,
-                       h->Dinv.as<double>(), h->DinvT.as<double>(), h->flag.as<int>());
+    launch_diag_inv(h, h->stream, (const double*)T, ld, k0, nspd, h->Dinv.as<double>(), h->DinvT.as<double>());
     hipLaunchKernelGGL(k_copy_panel, dim3(pgrid), dim3(256), 0, h->stream, (const double*)T, ld, k0, Mp,
                        h->Cold.as<double>());
     hipLaunchKernelGGL(k_panel, dim3(nblk), dim3(256), 0, h->stream, (const double*)h->Cold.as<double>(), 128L,
@@ -663,7 +737,7 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
     }
     hipLaunchKernelGGL(k_update, dim3(ugrid), dim3(256), 0, h->stream, T, ld, nblk, kb,
                        (const double*)h->Cold.as<double>(), (const double*)h->Cnew.as<double>(),
-                       (const double*)h->Rt.as<double>(), (const double*)h->Dinv.as<double>());
+                       (const double*)h->Rt.as<double>(), (const double*)h->Dinv.as<double>(), 0, 0);
   }
   if (pivoted)
     hipLaunchKernelGGL(k_swap_cols, dim3((Mp + 255) / 256), dim3(256), 0, h->stream, T, ld,
