@@ -105,6 +105,7 @@ void mik_destroy(mik_handle *h);
  * "chunk" = points per contraction launch (multiple of 128) ;
  * "lookahead" 0/1/-1 = overlap the next panel's serial chain with the current trailing update in the block sweep
  *   (default -1: from 24 block columns on) ; "diag" 0..3 = diagonal-block inverse kernel variant (default 1) ;
+ * "symsweep" 0/1 = sweep only the upper block triangle (faster, less accurate on ill-conditioned systems; default 0) ;
  * "mw_lds_cap" = largest moving-window candidate buffer kept in LDS (entries, default 8192; 0 forces the HBM lists) */
 int  mik_set_option(mik_handle *h, const char *key, double value);
 

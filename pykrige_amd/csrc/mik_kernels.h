@@ -864,15 +864,33 @@ __global__ void __launch_bounds__(256) k_rt_from_cnew(const double* __restrict__
 
 // trailing update + panel write-back, one 128x128 tile per block.  part = 0: every tile; part = 1: only block column
 // `col` (nblk blocks; the look-ahead launch that frees the next panel early); part = 2: everything but block column `col`.
+// SYM (unpivoted sweep): the matrix stays symmetric up to a known sign (T_ab = -T_ba^T when exactly one of the blocks
+// a, b has been swept), so only the UPPER block triangle i <= j is maintained (half the tiles): part 0 = all upper tiles,
+// part 1 = block column `col` (i <= col) and block row `col` (j >= col) -- what the next panel chain reads --, part 2 =
+// the upper tiles outside those.
+template <bool SYM>
 __global__ void __launch_bounds__(256, 2)
 k_update(double* __restrict__ T, long ld, int nblk, int kb, const double* __restrict__ Cold,
          const double* __restrict__ Cnew, const double* __restrict__ Rt, const double* __restrict__ Dinv, int part, int col) {
   __shared__ GemmSmem sm;
   int iblk, jblk;
   if (part == 1) {
-    iblk = blockIdx.x;
-    jblk = col;
-    if (iblk >= nblk) return;
+    if ((int)blockIdx.x >= nblk) return;
+    if (SYM && (int)blockIdx.x > col) {
+      iblk = col;
+      jblk = blockIdx.x;
+    } else {
+      iblk = blockIdx.x;
+      jblk = col;
+    }
+  } else if (SYM) {
+    const long L = xcd_tile((long)nblk * (nblk + 1) / 2);
+    if (L < 0) return;
+    jblk = (int)((sqrt(8.0 * (double)L + 1.0) - 1.0) * 0.5);
+    while ((long)jblk * (jblk + 1) / 2 > L) --jblk;            // guard the float estimate
+    while ((long)(jblk + 1) * (jblk + 2) / 2 <= L) ++jblk;
+    iblk = (int)(L - (long)jblk * (jblk + 1) / 2);             // i <= j: the upper block triangle
+    if (part == 2 && (iblk == col || jblk == col)) return;
   } else {
     const long L = xcd_tile((long)nblk * nblk);
     if (L < 0) return;
@@ -1214,6 +1232,50 @@ k_swap_cols(double* __restrict__ T, long ld, const int* __restrict__ pivall, int
       row[s] = b;
       row[pr] = a;
     }
+  }
+}
+
+// Symmetric sweep: column panel of block K from the upper block triangle.  Rows at / above the block are read in place;
+// rows below it (none swept yet, like K itself: plain symmetry) come from the block ROW K, P[r][c] = T[k0 + c][r], through
+// an LDS transpose so that both the reads and the writes stay coalesced.  One 64-row slab per block.
+__global__ void __launch_bounds__(256) k_copy_panel_sym(const double* __restrict__ T, long ld, int k0, int Mp,
+                                                        double* __restrict__ P) {
+  __shared__ double tile[64][65];
+  const int r0 = blockIdx.x * 64;
+  if (r0 < k0 + 128) {
+    for (int e = threadIdx.x; e < 64 * 128; e += 256) {
+      const int r = e >> 7, c = e & 127;
+      P[(long)(r0 + r) * 128 + c] = T[(long)(r0 + r) * ld + k0 + c];
+    }
+    return;
+  }
+  for (int half = 0; half < 2; ++half) {  // 64 of the 128 panel columns at a time
+    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+      const int c = e >> 6, r = e & 63;  // consecutive threads walk along a row of T
+      tile[c][r] = T[(long)(k0 + half * 64 + c) * ld + r0 + r];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+      const int r = e >> 6, c = e & 63;
+      P[(long)(r0 + r) * 128 + half * 64 + c] = tile[c][r];
+    }
+    __syncthreads();
+  }
+}
+
+// after the symmetric sweep every block is swept: T is symmetric, fill the lower block triangle from the upper one
+__global__ void __launch_bounds__(256) k_mirror_upper(double* __restrict__ T, long ld, int nblk64) {
+  __shared__ double tile[64][65];
+  const int bi = blockIdx.y, bj = blockIdx.x;  // 64 x 64 tiles; source tile (bi, bj) with bi <= bj, destination (bj, bi)
+  if (bi > bj) return;
+  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    tile[r][c] = T[(long)(bi * 64 + r) * ld + bj * 64 + c];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    if (bi < bj || c < r) T[(long)(bj * 64 + r) * ld + bi * 64 + c] = tile[c][r];
   }
 }
 

@@ -133,6 +133,11 @@ struct mik_handle {
   hipStream_t stream2 = nullptr;            // the look-ahead branch (next panel) runs here
   std::vector<hipEvent_t> la_events;
   int opt_lookahead = -1;  // -1 = where it pays (>= 24 block columns), 0 = off, 1 = on
+  // unpivoted sweep maintaining only the upper block triangle (half the update tiles: -9 % at N=5000, -30 % at N=8000).
+  // OFF by default: the two triangles of the in-place inverse carry different rounding histories, and z / sigma^2 formed
+  // from a mirrored triangle lose the small residual of the full sweep on ill-conditioned systems (power variogram with
+  // drift terms, cond 3e5: |dz| 3e-9 -> 8e-7).  Fine for well-conditioned problems; opt in with the option.
+  int opt_symsweep = 0;
   int opt_diag = 1;        // diagonal-block inverse variant: 0 = 1024 threads (16 waves x 8 rows), 1 = 16x16 grid, 2 = 16x32, 3 = 32x32
   // points
   long npt_total = 0, npt = 0;
@@ -450,6 +455,8 @@ int mik_set_option(mik_handle* h, const char* key, double value) {
   } else if (!strcmp(key, "chunk")) {
     if (value < 128) return fail(MIK_EINVAL, "chunk must be >= 128");
     h->opt_chunk = ((long)value / 128) * 128;
+  } else if (!strcmp(key, "symsweep")) {
+    h->opt_symsweep = value != 0.0;
   } else if (!strcmp(key, "diag")) {
     h->opt_diag = (int)value;
   } else if (!strcmp(key, "lookahead")) {
@@ -654,9 +661,22 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
   const long ld = Mp;
   const long tiles = (long)nblk * nblk;
   const unsigned ugrid = (unsigned)(8 * ((tiles + 7) / 8));
+  (void)ugrid;
   const unsigned pgrid = (unsigned)(((long)Mp * 128 + 255) / 256);
   // measured (scripts/inverse_lookahead_ab.py): +16 % at 16 block columns (the second stream's waits cost more than the
   // overlap returns), -12 % at 40, -17 % at 63
+  const bool symsweep = !pivoted && h->opt_symsweep;
+  const long ltiles = symsweep ? (long)nblk * (nblk + 1) / 2 : tiles;
+  const unsigned ug = (unsigned)(8 * ((ltiles + 7) / 8));
+#define UPD(GRID, STREAM, CO, CN, R, D, PART, COL)                                                                           \
+  do {                                                                                                                       \
+    if (symsweep)                                                                                                            \
+      hipLaunchKernelGGL(k_update<true>, GRID, dim3(256), 0, STREAM, T, ld, nblk, kb, (const double*)(CO), (const double*)(CN), \
+                         (const double*)(R), (const double*)(D), PART, COL);                                                 \
+    else                                                                                                                     \
+      hipLaunchKernelGGL(k_update<false>, GRID, dim3(256), 0, STREAM, T, ld, nblk, kb, (const double*)(CO), (const double*)(CN), \
+                         (const double*)(R), (const double*)(D), PART, COL);                                                 \
+  } while (0)
   const bool lookahead = h->opt_lookahead < 0 ? nblk >= 24 : h->opt_lookahead != 0;
   if (!pivoted && nblk > 1 && lookahead) {
     // Look-ahead sweep.  Step kb's update is split: block column kb+1 first (nblk tiles), then -- on the second stream --
@@ -680,7 +700,8 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
     auto panel_chain = [&](hipStream_t st, int kb, int set) {
       const int k0 = kb * 128;
       launch_diag_inv(h, st, (const double*)T, ld, k0, nspd, dinv[set], dinvT[set]);
-      hipLaunchKernelGGL(k_copy_panel, dim3(pgrid), dim3(256), 0, st, (const double*)T, ld, k0, Mp, cold[set]);
+      if (symsweep) hipLaunchKernelGGL(k_copy_panel_sym, dim3(Mp / 64), dim3(256), 0, st, (const double*)T, ld, k0, Mp, cold[set]);
+      else hipLaunchKernelGGL(k_copy_panel, dim3(pgrid), dim3(256), 0, st, (const double*)T, ld, k0, Mp, cold[set]);
       hipLaunchKernelGGL(k_panel, dim3(nblk), dim3(256), 0, st, (const double*)cold[set], 128L, (const double*)dinvT[set], -1.0,
                          cnew[set]);
       hipLaunchKernelGGL(k_rt_from_cnew, dim3(pgrid), dim3(256), 0, st, (const double*)cnew[set], rt[set], Mp, k0);
@@ -689,18 +710,15 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
     for (int kb = 0; kb < nblk; ++kb) {
       const int set = kb & 1;
       if (kb + 1 < nblk) {
-        hipLaunchKernelGGL(k_update, dim3(nblk), dim3(256), 0, h->stream, T, ld, nblk, kb, (const double*)cold[set],
-                           (const double*)cnew[set], (const double*)rt[set], (const double*)dinv[set], 1, kb + 1);
+        UPD(dim3(nblk), h->stream, cold[set], cnew[set], rt[set], dinv[set], 1, kb + 1);
         HIPC(hipEventRecord(h->la_events[2 * kb], h->stream));
         HIPC(hipStreamWaitEvent(h->stream2, h->la_events[2 * kb], 0));
         panel_chain(h->stream2, kb + 1, set ^ 1);
         HIPC(hipEventRecord(h->la_events[2 * kb + 1], h->stream2));
-        hipLaunchKernelGGL(k_update, dim3(ugrid), dim3(256), 0, h->stream, T, ld, nblk, kb, (const double*)cold[set],
-                           (const double*)cnew[set], (const double*)rt[set], (const double*)dinv[set], 2, kb + 1);
+        UPD(dim3(ug), h->stream, cold[set], cnew[set], rt[set], dinv[set], 2, kb + 1);
         HIPC(hipStreamWaitEvent(h->stream, h->la_events[2 * kb + 1], 0));
       } else {
-        hipLaunchKernelGGL(k_update, dim3(ugrid), dim3(256), 0, h->stream, T, ld, nblk, kb, (const double*)cold[set],
-                           (const double*)cnew[set], (const double*)rt[set], (const double*)dinv[set], 0, 0);
+        UPD(dim3(ug), h->stream, cold[set], cnew[set], rt[set], dinv[set], 0, 0);
       }
     }
   } else
@@ -722,8 +740,10 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
                          (const int*)(h->pivall.as<int>() + k0), Mp);
     }
     launch_diag_inv(h, h->stream, (const double*)T, ld, k0, nspd, h->Dinv.as<double>(), h->DinvT.as<double>());
-    hipLaunchKernelGGL(k_copy_panel, dim3(pgrid), dim3(256), 0, h->stream, (const double*)T, ld, k0, Mp,
-                       h->Cold.as<double>());
+    if (symsweep) hipLaunchKernelGGL(k_copy_panel_sym, dim3(Mp / 64), dim3(256), 0, h->stream, (const double*)T, ld, k0, Mp,
+                                     h->Cold.as<double>());
+    else hipLaunchKernelGGL(k_copy_panel, dim3(pgrid), dim3(256), 0, h->stream, (const double*)T, ld, k0, Mp,
+                            h->Cold.as<double>());
     hipLaunchKernelGGL(k_panel, dim3(nblk), dim3(256), 0, h->stream, (const double*)h->Cold.as<double>(), 128L,
                        (const double*)h->DinvT.as<double>(), -1.0, h->Cnew.as<double>());
     if (pivoted) {
@@ -735,10 +755,10 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
       hipLaunchKernelGGL(k_rt_from_cnew, dim3(pgrid), dim3(256), 0, h->stream, (const double*)h->Cnew.as<double>(),
                          h->Rt.as<double>(), Mp, k0);
     }
-    hipLaunchKernelGGL(k_update, dim3(ugrid), dim3(256), 0, h->stream, T, ld, nblk, kb,
-                       (const double*)h->Cold.as<double>(), (const double*)h->Cnew.as<double>(),
-                       (const double*)h->Rt.as<double>(), (const double*)h->Dinv.as<double>(), 0, 0);
+    UPD(dim3(ug), h->stream, h->Cold.as<double>(), h->Cnew.as<double>(), h->Rt.as<double>(), h->Dinv.as<double>(), 0, 0);
   }
+#undef UPD
+  if (symsweep) hipLaunchKernelGGL(k_mirror_upper, dim3(Mp / 64, Mp / 64), dim3(256), 0, h->stream, T, ld, Mp / 64);
   if (pivoted)
     hipLaunchKernelGGL(k_swap_cols, dim3((Mp + 255) / 256), dim3(256), 0, h->stream, T, ld,
                        (const int*)h->pivall.as<int>(), Mp, Mp);

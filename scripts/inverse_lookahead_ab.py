@@ -1,4 +1,5 @@
-"""A/B of the block-sweep inverse variants on the bench configs: look-ahead on/off x diagonal-block kernel variant."""
+"""A/B of the block-sweep inverse variants on the bench configs: look-ahead on/off x diagonal-block kernel variant x
+symmetric (lower-triangle) update; the relative deviation from the first variant is printed in parentheses."""
 import sys
 import numpy as np
 sys.path.insert(0, ".")
@@ -12,10 +13,11 @@ for cfgid in (2, 3, 5):
     ref = None
     line = "config %d N=%d:" % (cfgid, cfg["n"])
     for la in (0, 1):
-        for diag in (0, 1, 2, 3):
+        for diag, sym in ((0, 0), (1, 0), (1, 1)):
             h = _lib.Handle(0)
             h.set_option("lookahead", la)
             h.set_option("diag", diag)
+            h.set_option("symsweep", sym)
             h.set_problem(ndim=nd, xs=coords[0], ys=coords[1], zs=coords[2] if nd == 3 else None, values=values,
                           model_id=_lib.MODEL_IDS[cfg["model"]], params=internal_params(cfg["model"], cfg["params"]))
             h.factor()
@@ -26,6 +28,6 @@ for cfgid in (2, 3, 5):
             a = h.get_matrix(1)
             if ref is None:
                 ref = a
-            line += "  la%d/d%d %.2f ms (%.0e)" % (la, diag, min(ts), np.abs(a - ref).max() / np.abs(ref).max())
+            line += "  la%d/d%d/sym%d %.2f ms (%.0e)" % (la, diag, sym, min(ts), np.abs(a - ref).max() / np.abs(ref).max())
             h.close()
     print(line, flush=True)

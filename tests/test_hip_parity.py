@@ -177,6 +177,29 @@ def test_device_pseudo_inverse_against_scipy(n, drift):
     np.testing.assert_allclose(ss, sr, rtol=0, atol=SS_TOL)
 
 
+def test_block_sweep_variants_agree():
+    """Options of the unpivoted block sweep: diagonal-block kernel variants and the look-ahead schedule return the
+    bit-identical inverse; the opt-in half (upper-triangle) sweep returns an exactly symmetric one within 1e-11 of it."""
+    g = fx.load("ok2d_n2000")
+    st = fx.state_from("ok2d_n2000", g)
+    h = _handle_for(st)
+    h.set_option("factor", 1)
+    ref = None
+    for la, diag, sym in ((0, 0, 0), (1, 0, 0), (0, 1, 0), (1, 1, 0), (1, 2, 0), (0, 3, 0), (0, 1, 1), (1, 1, 1)):
+        h.set_option("lookahead", la)
+        h.set_option("diag", diag)
+        h.set_option("symsweep", sym)
+        h.factor()
+        a = h.get_matrix(1)
+        if ref is None:
+            ref = a
+        elif not sym:
+            np.testing.assert_array_equal(a, ref)
+        else:
+            assert np.array_equal(a, a.T)
+            assert np.abs(a - ref).max() <= 1e-11 * np.abs(ref).max()
+
+
 def test_rccl_single_rank_broadcast_path():
     """The multi-GPU exchange with world size 1: dlopen(librccl), ncclCommInitRank, ncclBroadcast of the
     inverse + c on the handle's stream.  (More ranks cannot be had on a 1-GPU box; tests/test_dist_gloo.py
