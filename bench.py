@@ -363,7 +363,9 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "k_contract_valu" if tsum.get("engine") else "k_contract", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
                          "traffic_unit": "bytes per launch (HBM-side, PMC)", "traffic_source": traffic_note,
-                         "executed_tflops": executed, "avg_launch_ms": avg_launch_s * 1e3,
+                         "executed_tflops": executed, "frac_executed": executed / FP64_MFMA_PEAK_TFLOPS,
+                         "note": "achieved / frac use the reference's 2 M^2 flops per point (SURVEY 8d); the kernel executes ~M^2 (symmetric half product), see executed_tflops / frac_executed",
+                         "avg_launch_ms": avg_launch_s * 1e3,
                          "launches_per_step": launches / K, "algorithmic_flops_per_point": 2.0 * M * M},
             "phases_ms_per_step": {"assemble": tsum["assemble_ms"] / K, "invert": tsum["invert_ms"] / K,
                                    "rhs": tsum["rhs_ms"] / K, "contract": tsum["contract_ms"] / K,
