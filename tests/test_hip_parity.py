@@ -683,3 +683,36 @@ def test_moving_window_many_stations_without_the_full_matrix():
         b = np.append(-ko.variogram("exponential", par, d[i]), 1.0)
         w = scipy.linalg.solve(a, b)
         assert abs(z[i] - w[:k] @ v[sel]) <= Z_TOL and abs(ss[i] + w @ b) <= SS_TOL
+
+
+def test_integration_md_stub_runs_as_written():
+    """The ctypes stub INTEGRATION.md shows a PyKrige maintainer (section B) is executed here verbatim -- only the
+    library path is made absolute -- on an object carrying the attributes OrdinaryKriging has at that point of execute()."""
+    import os
+    import re
+    import types
+
+    lib = _lib()
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "INTEGRATION.md")).read()
+    block = next(b for b in re.findall(r"```python\n(.*?)```", text, flags=re.S) if "def _hip_exec" in b)
+    ns = {}
+    exec(block.replace('C.CDLL("libmikrige.so")', "C.CDLL(%r)" % lib.LIB_PATH), ns)
+    g = fx.load("ok2d_spherical_exact")
+    st = fx.state_from("ok2d_spherical_exact", g)
+
+    def spherical_variogram_model(m, d):  # only its __name__ is read, as by lib/variogram_models.pyx
+        return None
+
+    assert st.model == "spherical"
+    fake = types.SimpleNamespace(X_ADJUSTED=st.coords_adj[:, 0], Y_ADJUSTED=st.coords_adj[:, 1], Z=st.values,
+                                 variogram_function=spherical_variogram_model, variogram_model_parameters=list(st.params),
+                                 eps=1e-10, exact_values=st.exact_values, coordinates_type="euclidean", pseudo_inv=False,
+                                 pseudo_inv_type="pinv")
+    rng = np.random.default_rng(3)
+    pts = ko.adjust_for_anisotropy(rng.random((500, 2)), st.center, st.scaling, st.angle)
+    mask = rng.random(500) < 0.2
+    z, ss = ns["_hip_exec"](fake, pts[:, 0], pts[:, 1], mask)
+    zr, sr = ko.solve_points(st, pts[~mask])
+    np.testing.assert_allclose(z[~mask], zr, rtol=0, atol=Z_TOL)
+    np.testing.assert_allclose(ss[~mask], sr, rtol=0, atol=SS_TOL)
+    assert np.all(z[mask] == 0.0) and np.all(ss[mask] == 0.0)
