@@ -371,7 +371,8 @@ typedef __attribute__((address_space(3))) void* mik_lptr_t;
 
 // NAI = 16-row groups per wave: 4 -> wave tile 64 x 64, 4 waves (256 threads); 2 -> wave tile 32 x 64,
 // 8 waves (512 threads).  The block tile is 128 x 128 either way.
-// ABL (tools/kernel_bench only; 0 in the library): 1 = skip the LDS-DMA, 2 = skip the fragment ds_reads,
+// ABL (tools/kernel_bench only; 0 in the library): 32 = generate the B tile on the VALU instead of loading it,
+// 1 = skip the LDS-DMA, 2 = skip the fragment ds_reads,
 // 4 = skip the per-tile barrier, 8 = DMA always re-reads k-tile 0 (cache-resident source).  Results are garbage; the variants exist to price each component.
 // kscale: the accumulators are doubled just before the K tile that starts at kscale is contracted (symmetric
 // form: everything above the diagonal block counts twice); pass a value that is never a tile start to disable.
@@ -420,10 +421,24 @@ __device__ __forceinline__ void gemm_core(const double* __restrict__ Ag, long ld
       const unsigned la = ldsA + b * LDS_BUF + p * LDS_PASS, lb = ldsB + b * LDS_BUF + p * LDS_PASS;
       if (p == 0) {  // the bases come straight from v_readfirstlane: VALU-written SGPR -> VMEM address needs 5 wait states
         asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(aoffb[p]), "s"(abase), "s"(la) : "memory");
-        asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(boffb[p]), "s"(bbase), "s"(lb) : "memory");
+        if (!(ABL & 32)) asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(boffb[p]), "s"(bbase), "s"(lb) : "memory");
       } else {
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(aoffb[p]), "s"(abase), "s"(la) : "memory");
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(boffb[p]), "s"(bbase), "s"(lb) : "memory");
+        if (!(ABL & 32)) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(boffb[p]), "s"(bbase), "s"(lb) : "memory");
+      }
+      if (ABL & 32) {
+        // experiment (tools/kernel_bench): the B tile is not loaded but GENERATED -- per thread and pass two
+        // exponential-variogram values from a point (its row) and two stations (its k pair), as a kernel fused with
+        // the right-hand-side assembly would do -- and written to the slot the DMA would have filled
+        const int row = lrow + PROWS * p;
+        const double qx = 1e-3 * row, qy = 2e-3 * row;
+        const int ks = (k + 2 * slot) & 4094;
+        const double2 sx = *reinterpret_cast<const double2*>(Agu + ks), sy = *reinterpret_cast<const double2*>(Agu + lda + ks);
+        const double dx0 = qx - sx.x, dy0 = qy - sy.x, dx1 = qx - sx.y, dy1 = qy - sy.y;
+        double2 g;
+        g.x = -(1.0 - exp(-sqrt(dx0 * dx0 + dy0 * dy0) * 3.3));
+        g.y = -(1.0 - exp(-sqrt(dx1 * dx1 + dy1 * dy1) * 3.3));
+        *reinterpret_cast<double2*>(&sm.Bs[b][row][slot * 2]) = g;
       }
     }
   };
@@ -2143,7 +2158,7 @@ k_contract_ablate(const double* __restrict__ Ainv, long lda, const double* __res
 #pragma unroll
     for (int y = 0; y < 4; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
   // ABL & 16: ragged K range as in the symmetric form (k >= i0), without the doubling step
-  gemm_core<NAI, (ABL & 15)>(Ainv + (long)iblk * MIK_BM * lda, lda, Bt + (long)tblk * MIK_BN * ldb, ldb,
+  gemm_core<NAI, (ABL & 47)>(Ainv + (long)iblk * MIK_BM * lda, lda, Bt + (long)tblk * MIK_BN * ldb, ldb,
                              (ABL & 16) ? iblk * MIK_BM : 0, kend, acc, sm);
   double s = 0.0;
 #pragma unroll

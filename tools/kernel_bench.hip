@@ -89,6 +89,8 @@ int main(int argc,char**argv){
   ABLATE(2,2,512,"8-wave, no fragment ds_reads");
   ABLATE(2,4,512,"8-wave, no barrier");
   ABLATE(2,7,512,"8-wave, MFMA only");
+  ABLATE(2,32,512,"8-wave, B tile generated on the VALU (exp)");
+  ABLATE(4,32,256,"4-wave, B tile generated on the VALU (exp)");
   // inverse pieces
   ms=timeit([&]{hipLaunchKernelGGL(k_diag_inv,dim3(1),dim3(1024),0,0,(const double*)T,(long)Mp,0,0,Dinv,DinvT,flag);},10);
   printf("k_diag_inv (1024 thr) back-to-back: %.1f us\n",ms*1e3);
