@@ -39,16 +39,27 @@ def _case(seed):
             drift["specified"] = [np.cos(4 * coords[:, 0]) + coords[:, 1]]
         if rng.random() < 0.4:
             drift["functional"] = True
+    geographic = bool(ndim == 2 and not universal and rng.random() < 0.2)
+    if geographic:  # lon / lat in degrees, great-circle distances, no anisotropy (ok.py:289-304)
+        coords = np.column_stack([rng.uniform(-170, 170, n), rng.uniform(-80, 80, n)])
+        values = np.sin(np.radians(coords[:, 0])) * np.cos(np.radians(coords[:, 1])) + 0.1 * rng.standard_normal(n)
+        scaling, angle = [1.0], [0.0]
+        if model not in ("linear", "power"):
+            user[1] = float(rng.uniform(15.0, 70.0))  # range in degrees
+        else:
+            user[0] = float(rng.uniform(0.005, 0.05))
     style = str(rng.choice(["grid", "points", "masked"]))
     sizes = [int(rng.integers(2, 12)) for _ in range(ndim)]
     if style == "points":
-        axes = [rng.uniform(-0.1, 1.1, sizes[0]) for _ in range(ndim)]
+        axes = [rng.uniform(-0.1, 1.1, sizes[0]) for _ in range(ndim)] if not geographic else \
+            [rng.uniform(-175, 175, sizes[0]), rng.uniform(-85, 85, sizes[0])]
         k_hit = min(2, sizes[0], n)
         for d in range(ndim):  # a couple of points on stations: the eps rule
             axes[d][:k_hit] = coords[:k_hit, d]
         shape = (sizes[0],)
     else:
-        axes = [np.linspace(0.0, 1.0, s) for s in sizes]
+        axes = [np.linspace(0.0, 1.0, s) for s in sizes] if not geographic else \
+            [np.linspace(-160.0, 160.0, sizes[0]), np.linspace(-75.0, 75.0, sizes[1])]
         shape = tuple(sizes[::-1])
     mask = (rng.random(shape) < 0.3) if style == "masked" else None
     window = None
@@ -58,7 +69,7 @@ def _case(seed):
         str(rng.choice(["vectorized", "loop", "hip"] + (["C"] if (ndim == 2 and not universal) else [])))
     return dict(seed=seed, ndim=ndim, n=n, model=model, user=user, coords=coords, values=values, scaling=scaling, angle=angle,
                 exact=exact, universal=universal, drift=drift, style=style, axes=axes, shape=shape, mask=mask, window=window,
-                backend=backend)
+                backend=backend, geographic=geographic)
 
 
 def _functional_terms(ndim):
@@ -82,7 +93,8 @@ def test_random_configuration_against_the_oracle(seed):
     st = ko.KrigingState(ndim=ndim, coords_orig=coords, values=values, model=c["model"],
                          params=ko.internal_parameters(c["model"], c["user"]), scaling=c["scaling"], angle=c["angle"],
                          exact_values=c["exact"], regional_linear=bool(c["drift"].get("regional_linear")),
-                         point_log=c["drift"].get("wells"), specified_data=list(spec_st), functional=list(fun))
+                         point_log=c["drift"].get("wells"), specified_data=list(spec_st), functional=list(fun),
+                         geographic=c["geographic"])
     if c["style"] == "points":
         spec_pts = _spec_at_points(c, c["axes"]) if spec_st else []
     else:
@@ -91,6 +103,8 @@ def test_random_configuration_against_the_oracle(seed):
     kw = dict(variogram_model=c["model"], variogram_parameters=list(c["user"]), exact_values=c["exact"])
     if ndim == 2:
         kw.update(anisotropy_scaling=c["scaling"][0], anisotropy_angle=c["angle"][0])
+        if c["geographic"]:
+            kw["coordinates_type"] = "geographic"
         args = (coords[:, 0], coords[:, 1], values)
     else:
         kw.update(anisotropy_scaling_y=c["scaling"][0], anisotropy_scaling_z=c["scaling"][1], anisotropy_angle_x=c["angle"][0],
@@ -125,12 +139,14 @@ def test_random_configuration_against_the_oracle(seed):
         pts = np.stack([g.ravel() for g in (np.meshgrid(*c["axes"]) if ndim == 2 else
                                             np.meshgrid(c["axes"][2], c["axes"][1], c["axes"][0], indexing="ij")[::-1])], 1) \
             if c["style"] != "points" else np.stack(c["axes"], 1)
-        zr, sr = ko.solve_points_moving_window(st, ko.adjust_for_anisotropy(pts.copy(), st.center, st.scaling, st.angle), c["window"])
+        pts_adj = pts.copy() if c["geographic"] else ko.adjust_for_anisotropy(pts.copy(), st.center, st.scaling, st.angle)
+        zr, sr = ko.solve_points_moving_window(st, pts_adj, c["window"])
         zr, sr = zr.reshape(c["shape"]), sr.reshape(c["shape"])
     else:
         zr, sr = ko.execute(st, c["style"], *c["axes"], mask=c["mask"], specified_drift_arrays=spec_pts)
-    tag = "seed %d: %dD n=%d %s %s %s window=%s backend=%s drift=%s" % (
-        seed, ndim, c["n"], c["model"], c["style"], "UK" if c["universal"] else "OK", c["window"], c["backend"], sorted(c["drift"]))
+    tag = "seed %d: %dD%s n=%d %s %s %s window=%s backend=%s drift=%s" % (
+        seed, ndim, " geographic" if c["geographic"] else "", c["n"], c["model"], c["style"], "UK" if c["universal"] else "OK",
+        c["window"], c["backend"], sorted(c["drift"]))
     assert z.shape == c["shape"] and ss.shape == c["shape"], tag
     keep = np.ones(c["shape"], bool) if c["mask"] is None else ~c["mask"]
     cond = np.linalg.cond(ko.kriging_matrix(st)) if not c["window"] else 1.0
