@@ -13,3 +13,4 @@ cp $S/mw_big_time.txt $P/${R}_moving_window_timing.txt
 cp $S/execute_overhead.txt $P/${R}_execute_overhead.txt
 cp $S/prof/ktrace/ktrace_kernel_stats.csv $P/${R}_bench_c2_rocprofv3_kernel_stats.csv
 python scripts/pmc_summary.py $S/prof > $P/${R}_bench_c2_rocprofv3_pmc_per_kernel.csv
+cp $S/prof_mw/mw_kernel_stats.csv $P/${R}_bench_moving_window_k50_rocprofv3_kernel_stats.csv 2>/dev/null || true

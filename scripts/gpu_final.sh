@@ -12,3 +12,4 @@ python scripts/pmc_summary.py $OUT/prof | grep "contract"
 timeout 400 python scripts/mw_big_time.py > $OUT/mw_big_time.txt 2>&1
 timeout 200 python scripts/execute_overhead.py 2>&1 | head -3 > $OUT/execute_overhead.txt
 timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 2 --steps 2 --warmup 1 > $OUT/bench_2rank.json 2> $OUT/bench_2rank.err
+( REPO=$PWD; cd /tmp && export TMPDIR=/tmp; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_mw -o mw -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu --moving-window 50 > $OUT/prof_mw.json 2> $OUT/prof_mw.err )
