@@ -272,3 +272,17 @@ def test_plot_helpers_and_enable_plotting_without_a_gpu(monkeypatch):
     ok.plot_epsilon_residuals()
     assert shown == [2, 2, 2]  # scatter + zero line
     plt.close("all")
+
+
+def test_module_paths_of_the_reference_resolve():
+    """`from pykrige.ok import OrdinaryKriging` etc. keep working with the package name swapped (pykrige/__init__.py:41-45)."""
+    import pykrige_amd
+    from pykrige_amd.ok import OrdinaryKriging
+    from pykrige_amd.ok3d import OrdinaryKriging3D
+    from pykrige_amd.uk import UniversalKriging
+    from pykrige_amd.uk3d import UniversalKriging3D
+
+    assert OrdinaryKriging is pykrige_amd.OrdinaryKriging and UniversalKriging is pykrige_amd.UniversalKriging
+    assert OrdinaryKriging3D is pykrige_amd.OrdinaryKriging3D and UniversalKriging3D is pykrige_amd.UniversalKriging3D
+    assert pykrige_amd.kt.write_asc_grid is pykrige_amd.kriging_tools.write_asc_grid
+    import pykrige_amd.compat, pykrige_amd.core, pykrige_amd.variogram_models  # noqa: F401
