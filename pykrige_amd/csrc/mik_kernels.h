@@ -1610,7 +1610,8 @@ __global__ void __launch_bounds__(64) k_mw_knn(KnnArgs a) {
       if (all || (cnt == K && tau <= reach)) break;
     }
     for (int q = l; q < K; q += 64) {
-      a.idx_out[t * K + q] = vals[q];
+      const int st = vals[q];
+      a.idx_out[t * K + q] = (st >= 0 && st < a.N) ? st : 0;  // fewer than K finite distances (NaN coordinates): stay in bounds
       a.dist_out[t * K + q] = sqrt(keys[q]);
     }
     __syncthreads();  // the buffer is reused by the next point
