@@ -106,6 +106,8 @@ void mik_destroy(mik_handle *h);
  * "lookahead" 0/1/-1 = overlap the next panel's serial chain with the current trailing update in the block sweep
  *   (default -1: from 24 block columns on) ; "diag" 0..3 = diagonal-block inverse kernel variant (default 1) ;
  * "symsweep" 0/1 = sweep only the upper block triangle (faster, less accurate on ill-conditioned systems; default 0) ;
+ * "mw_pivot" 0/1 = always solve the moving-window systems with partial pivoting (default 0: SPD-shifted, no pivot search,
+ *   falling back to pivoting when a local system is not positive definite) ;
  * "mw_lds_cap" = largest moving-window candidate buffer kept in LDS (entries, default 8192; 0 forces the HBM lists) */
 int  mik_set_option(mik_handle *h, const char *key, double value);
 

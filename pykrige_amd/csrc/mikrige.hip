@@ -151,6 +151,8 @@ struct mik_handle {
   int opt_waves = 8;  // waves per contraction block: 4 (wave tile 64x64) or 8 (32x64)
   int opt_factor = 0, opt_sym = 1, opt_engine = 0;  // engine: 0 = v_mfma_f64 contraction, 1 = v_fma_f64 (VALU) contraction
   long opt_chunk = 131072;
+  int opt_mw_pivot = 0;       // 1 = always solve the moving-window systems with partial pivoting
+  bool mw_force_piv = false;
   int opt_mw_lds_cap = 8192;  // largest candidate buffer the moving-window neighbour search keeps in LDS
   mik_timing tm{};
   std::vector<hipEvent_t> evpool;
@@ -215,14 +217,20 @@ static double host_vario(const Vario& v, double d) {
   } while (0)
 
 template <int GY, int GX, int RI, int CJ>
-static int launch_mw_solve(mik_handle* h, const MwArgs& a, long pc) {
+static int launch_mw_solve(mik_handle* h, const MwArgs& a, long pc, bool piv) {
   constexpr int T = GY * GX, PPB = 256 / T, CJP = (CJ + 1) & ~1;
   const int nb = a.K + 1;
   if (nb > GY * RI || nb + 1 > GX * CJ) return fail(MIK_EINVAL, "moving-window solve class too small for this window");
-  const size_t per = ((size_t)GX * CJP + (size_t)GY * RI + 16 + 5 * (size_t)nb + (2 * (size_t)nb + 1) / 2 + 1) & ~(size_t)1;
+  const size_t per = (2 * ((size_t)GX * CJP + (size_t)GY * RI) + 16 + 5 * (size_t)nb + (2 * (size_t)nb + 1) / 2 + 1) & ~(size_t)1;
   const size_t lds = sizeof(double) * per * PPB;
-  HIPC(hipFuncSetAttribute((const void*)k_mw_solve<GY, GX, RI, CJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL((k_mw_solve<GY, GX, RI, CJ>), dim3((unsigned)((pc + PPB - 1) / PPB)), dim3(256), lds, h->stream, a);
+  const dim3 grid((unsigned)((pc + PPB - 1) / PPB));
+  if (piv) {
+    HIPC(hipFuncSetAttribute((const void*)k_mw_solve<GY, GX, RI, CJ, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_mw_solve<GY, GX, RI, CJ, true>), grid, dim3(256), lds, h->stream, a);
+  } else {
+    HIPC(hipFuncSetAttribute((const void*)k_mw_solve<GY, GX, RI, CJ, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_mw_solve<GY, GX, RI, CJ, false>), grid, dim3(256), lds, h->stream, a);
+  }
   return MIK_OK;
 }
 
@@ -364,14 +372,14 @@ static int build_mw_grid(mik_handle* h, int target) {
 // thread-grid / register-tile classes of k_mw_solve, {GY, GX, RI, CJ} covers nb <= GY*RI and nb + 1 <= GX*CJ.  Measured
 // on MI355X (scripts/mw_classes.py history in DESIGN.md): the classes whose tile fits the VGPR file without AGPR spills
 // win, and among those the one with the fewest threads per point.
-static int dispatch_mw_solve(mik_handle* h, const MwArgs& a, long pc) {
+static int dispatch_mw_solve(mik_handle* h, const MwArgs& a, long pc, bool piv) {
   const int nb = a.K + 1;
-  if (nb <= 16) return launch_mw_solve<4, 4, 4, 5>(h, a, pc);   // 16 threads per point
-  if (nb <= 32) return launch_mw_solve<8, 8, 4, 5>(h, a, pc);   // 64
-  if (nb <= 48) return launch_mw_solve<8, 8, 6, 7>(h, a, pc);   // 64
-  if (nb <= 64) return launch_mw_solve<8, 8, 8, 9>(h, a, pc);   // 64
-  if (nb <= 96) return launch_mw_solve<16, 16, 6, 7>(h, a, pc); // 256
-  return launch_mw_solve<16, 16, 8, 9>(h, a, pc);               // 256, nb <= 128
+  if (nb <= 16) return launch_mw_solve<4, 4, 4, 5>(h, a, pc, piv);   // 16 threads per point
+  if (nb <= 32) return launch_mw_solve<8, 8, 4, 5>(h, a, pc, piv);   // 64
+  if (nb <= 48) return launch_mw_solve<8, 8, 6, 7>(h, a, pc, piv);   // 64
+  if (nb <= 64) return launch_mw_solve<8, 8, 8, 9>(h, a, pc, piv);   // 64
+  if (nb <= 96) return launch_mw_solve<16, 16, 6, 7>(h, a, pc, piv); // 256
+  return launch_mw_solve<16, 16, 8, 9>(h, a, pc, piv);               // 256, nb <= 128
 }
 
 extern "C" {
@@ -461,6 +469,8 @@ int mik_set_option(mik_handle* h, const char* key, double value) {
     h->opt_diag = (int)value;
   } else if (!strcmp(key, "lookahead")) {
     h->opt_lookahead = value < 0.0 ? -1 : (value != 0.0);
+  } else if (!strcmp(key, "mw_pivot")) {
+    h->opt_mw_pivot = value != 0.0;
   } else if (!strcmp(key, "mw_lds_cap")) {
     if (value < 0 || value > 8192) return fail(MIK_EINVAL, "mw_lds_cap must be in 0..8192");
     h->opt_mw_lds_cap = (int)value;
@@ -1070,6 +1080,10 @@ int mik_predict_moving_window(mik_handle* h, int n_closest) {
     if (chunk > npt) chunk = npt;
   }
   const bool custom = h->model == MIK_MODEL_CUSTOM;
+  // small windows are solved without a pivot search on the SPD-shifted local system unless the model cannot promise a
+  // positive definite station block (hole-effect), has no device functor for the shift (custom), or a previous attempt
+  // of this call hit a bad pivot
+  const bool mw_piv = custom || h->model == MIK_MODEL_HOLE_EFFECT || h->mw_force_piv || h->opt_mw_pivot;
   if (custom) {  // the K x K pair distances of every point visit the host: bound that table to ~1 GB
     long cc = ((long)(1e9 / (8.0 * K * (K + 1.0))) / 256) * 256;
     if (cc < 256) cc = 256;
@@ -1213,7 +1227,7 @@ int mik_predict_moving_window(mik_handle* h, int n_closest) {
       HIPC(hipFuncSetAttribute((const void*)k_mw_solve_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(k_mw_solve_big, dim3(grid), dim3(256), lds, h->stream, a, sysbuf.as<double>());
     } else {
-      MIKC(dispatch_mw_solve(h, a, pc));
+      MIKC(dispatch_mw_solve(h, a, pc, mw_piv));
     }
     HIPC(hipGetLastError());
   }
@@ -1224,6 +1238,12 @@ int mik_predict_moving_window(mik_handle* h, int n_closest) {
   float ms = 0.f;
   HIPC(hipEventElapsedTime(&ms, h->evpool[0], h->evpool[1]));
   h->tm.predict_ms = ms;
+  if ((flag & 2) && !mw_piv) {  // a local system was not positive definite after the shift: redo with partial pivoting
+    h->mw_force_piv = true;
+    const int rc = mik_predict_moving_window(h, n_closest);
+    h->mw_force_piv = false;
+    return rc;
+  }
   if (flag) return fail(MIK_ESINGULAR, "Singular matrix");  // cok.pyx:176-177
   h->have_results = true;
   return MIK_OK;

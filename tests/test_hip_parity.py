@@ -393,6 +393,13 @@ def test_moving_window_matches_reference(name):
                 np.testing.assert_allclose(ss, g["ss_k%d" % k], rtol=0, atol=SS_TOL)
         finally:
             lib.Handle.set_problem = old
+        # the pivoted variant of the per-point solve (default: SPD-shifted without pivot search) on the same fixtures
+        m._get_handle().set_option("mw_pivot", 1)
+        for k in (2, 10, 31, 70):
+            z, ss = m.execute("grid", *axes, backend="loop", n_closest_points=k)
+            np.testing.assert_allclose(z, g["z_k%d" % k], rtol=0, atol=Z_TOL)
+            np.testing.assert_allclose(ss, g["ss_k%d" % k], rtol=0, atol=SS_TOL)
+        m._get_handle().set_option("mw_pivot", 0)
         zm, ssm = m.execute("masked", *axes, mask=g["mask"], backend="loop", n_closest_points=10)
         keep = ~g["mask"]
         np.testing.assert_allclose(np.ma.getdata(zm)[keep], g["zm_k10"][keep], rtol=0, atol=Z_TOL)
