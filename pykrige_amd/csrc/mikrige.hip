@@ -670,8 +670,6 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
   double* T = h->T.as<double>();
   const long ld = Mp;
   const long tiles = (long)nblk * nblk;
-  const unsigned ugrid = (unsigned)(8 * ((tiles + 7) / 8));
-  (void)ugrid;
   const unsigned pgrid = (unsigned)(((long)Mp * 128 + 255) / 256);
   // measured (scripts/inverse_lookahead_ab.py): +16 % at 16 block columns (the second stream's waits cost more than the
   // overlap returns), -12 % at 40, -17 % at 63
