@@ -1,0 +1,70 @@
+"""Host side of bench.py without a GPU: the workloads are the BASELINE configs, the weak-scaling shards tile the grid in
+the reference's meshgrid order, the synthetic data are deterministic, and the JSON metric is BASELINE.json's."""
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def test_configs_are_the_baseline_ones():
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    txt = base["configs"]
+    c2, c3, c4 = bench.CONFIGS[2], bench.CONFIGS[3], bench.CONFIGS[4]
+    assert "N=5000" in txt[1] and "1000" in txt[1] and "exponential" in txt[1]
+    assert (c2["n"], c2["grid"], c2["model"], c2["seed"]) == (5000, (1000, 1000), "exponential", 2)
+    assert "N=2000" in txt[2] and "gaussian" in txt[2]
+    assert (c3["n"], c3["grid"], c3["model"], c3["ndim"]) == (2000, (200, 200, 50), "gaussian", 3)
+    assert "regional_linear" in txt[3]
+    assert c4["rl"] and len(c4["wells"]) == 3 and c4["n"] == 4000 and c4["grid"] == (1024, 1024)
+    assert bench.CONFIGS[5]["n"] == 8000 and bench.CONFIGS[5]["grid"][0] == 4096
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "kriged grid-points/sec (z + sigma^2), OK2D N=5000 on 1000x1000 grid" in src
+    assert re.sub("[²×]", "", base["metric"]).split(",")[0].startswith("kriged grid-points/sec")
+
+
+def test_synthetic_inputs_are_deterministic_and_as_specified():
+    (x, y), v = bench.synth(2, 5000, 2)
+    (x2, y2), v2 = bench.synth(2, 5000, 2)
+    assert np.array_equal(x, x2) and np.array_equal(v, v2)
+    rng = np.random.default_rng(2)  # x, y = rng.random(N) each; v = sin(6x) cos(4y) + 0.1 N(0,1)
+    xr, yr = rng.random(5000), rng.random(5000)
+    assert np.array_equal(x, xr) and np.array_equal(y, yr)
+    assert np.allclose(v, np.sin(6 * xr) * np.cos(4 * yr) + 0.1 * rng.standard_normal(5000))
+    assert bench.internal_params("exponential", [1.0, 0.3, 0.1]) == [0.9, 0.3, 0.1]
+    assert bench.internal_params("linear", [2.0, 0.1]) == [2.0, 0.1]
+
+
+def test_weak_scaling_shards_tile_the_enlarged_grid():
+    cfg = bench.CONFIGS[2]
+    world = 4
+    shards = [bench.shard_points(cfg, r, world) for r in range(world)]
+    assert all(s[0].size == 1000 * 1000 for s in shards)  # per-GPU work fixed: weak scaling
+    gx, gy = np.linspace(0, 1, 1000), np.linspace(0, 1, 1000 * world)
+    X, Y = np.meshgrid(gx, gy)
+    assert np.array_equal(np.concatenate([s[0] for s in shards]), X.ravel())
+    assert np.array_equal(np.concatenate([s[1] for s in shards]), Y.ravel())
+    c3 = bench.CONFIGS[3]
+    s3 = [bench.shard_points(c3, r, 2) for r in range(2)]
+    assert all(len(s) == 3 and s[0].size == 200 * 200 * 50 for s in s3)
+    assert s3[0][2].max() < s3[1][2].min()  # z slabs stack
+
+
+def test_bench_refuses_to_run_without_a_gpu():
+    """No CPU fallback: on a box without a HIP device bench.py dies with the library's message and prints no JSON line."""
+    try:
+        from pykrige_amd import _lib
+
+        if _lib.load().mik_device_count() > 0:
+            return  # a GPU box: covered by the real bench run
+    except Exception:
+        pass
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "no HIP device" in r.stderr and r.stdout.strip() == ""
