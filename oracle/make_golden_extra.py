@@ -71,7 +71,7 @@ def main():
     print("wrote extra fixtures")
 
 
-if __name__ == "__main__" and not {"--mw", "--geo", "--stats", "--sk", "--tools", "--custom"} & set(sys.argv):
+if __name__ == "__main__" and not {"--mw", "--geo", "--stats", "--sk", "--tools", "--custom", "--aniso"} & set(sys.argv):
     main()
 
 
@@ -335,3 +335,25 @@ def custom_variogram():
 if __name__ == "__main__" and "--custom" in sys.argv:
     _import_reference(False)
     custom_variogram()
+
+
+def anisotropy():
+    """core._adjust_for_anisotropy (core.py:120-193) of the REAL reference on random 2-D / 3-D inputs: the adjusted
+    coordinates decide the `eps` exact-hit rule, so the product's host transform is pinned bit for bit."""
+    import pykrige.core as core
+
+    rng = np.random.default_rng(777)
+    out = {}
+    X2 = rng.random((500, 2)) * 100 - 30
+    c2, s2, a2 = [12.5, -3.25], [2.75], [33.3]
+    out.update(X2=X2, c2=c2, s2=s2, a2=a2, Y2=core._adjust_for_anisotropy(X2.copy(), c2, s2, a2))
+    X3 = rng.random((500, 3)) * 10
+    c3, s3, a3 = [5.0, 4.0, 3.0], [1.5, 0.4], [10.0, -25.0, 70.0]
+    out.update(X3=X3, c3=c3, s3=s3, a3=a3, Y3=core._adjust_for_anisotropy(X3.copy(), c3, s3, a3))
+    np.savez_compressed(os.path.join(OUT, "aniso_adjust.npz"), **out)
+    print("wrote anisotropy fixture")
+
+
+if __name__ == "__main__" and "--aniso" in sys.argv:
+    _import_reference(False)
+    anisotropy()

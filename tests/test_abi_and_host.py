@@ -286,3 +286,17 @@ def test_module_paths_of_the_reference_resolve():
     assert OrdinaryKriging3D is pykrige_amd.OrdinaryKriging3D and UniversalKriging3D is pykrige_amd.UniversalKriging3D
     assert pykrige_amd.kt.write_asc_grid is pykrige_amd.kriging_tools.write_asc_grid
     import pykrige_amd.compat, pykrige_amd.core, pykrige_amd.variogram_models  # noqa: F401
+
+
+def test_anisotropy_adjustment_is_bit_identical_to_the_reference():
+    """core.adjust_for_anisotropy (reference core.py:120-193): same NumPy operations in the same order, so the adjusted
+    coordinates -- which decide the `abs(bd) <= eps` exact-hit rule -- equal the real reference's bit for bit
+    (tests/golden/aniso_adjust.npz); the oracle's own restatement is held to the same."""
+    from oracle import kriging_oracle as ko
+    from pykrige_amd import core
+
+    g = np.load(os.path.join(ROOT, "tests", "golden", "aniso_adjust.npz"))
+    for d in ("2", "3"):
+        X, c, s, a, Y = g["X" + d], list(g["c" + d]), list(g["s" + d]), list(g["a" + d]), g["Y" + d]
+        assert np.array_equal(core.adjust_for_anisotropy(X.copy(), c, s, a), Y)
+        assert np.array_equal(ko.adjust_for_anisotropy(X.copy(), c, s, a), Y)
