@@ -182,3 +182,41 @@ def test_sharded_execute_world2_gloo():
     assert all(o[1] and o[2] for o in out), out
     assert sum(o[3] for o in out) == 13 * 9  # the last execute's slabs partition the grid
     assert all(o[4] == 2 for o in out)       # redundant factorisation: each rank factored in each execute
+
+
+def _sock8_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    from pykrige_amd.dist import SocketGroup, slab_bounds
+
+    pg = SocketGroup(rank=rank, world=world, addr="127.0.0.1", port=port)
+    try:
+        got = pg.all_gather_object((rank, slab_bounds(1000003, world, rank)))
+        uid = pg.broadcast_object(bytes(range(128)) if rank == 0 else None)
+        t = pg.all_reduce_max(0.25 * rank)
+        for _ in range(3):
+            pg.barrier()
+        q.put((rank, got == [(r, slab_bounds(1000003, world, r)) for r in range(world)] and uid == bytes(range(128))
+               and t == 0.25 * (world - 1)))
+    finally:
+        pg.close()
+
+
+def test_socket_group_with_eight_ranks():
+    """The rendezvous bench.py uses under `torch.distributed.run --nproc-per-node 8`: eight processes, the collectives
+    the benchmark needs (gather, the 128-byte id broadcast, max-reduce, barriers)."""
+    import multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sock8_worker, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [o[0] for o in out] == list(range(8)) and all(o[1] for o in out)
