@@ -118,16 +118,26 @@ def bilinear_zscalars(zgrid, gx, gy, x, y):
     y = np.asarray(y, dtype=np.float64)
     if x.size and (x.max() > gx.max() or x.min() < gx.min() or y.max() > gy.max() or y.min() < gy.min()):
         raise ValueError("External drift array does not cover specified kriging domain.")
-    # the reference takes min{i: g_i >= v} and max{i: g_i <= v}; axes may be in any order, so sort once
-    ox, oy = np.argsort(gx, kind="stable"), np.argsort(gy, kind="stable")
-    sx, sy = gx[ox], gy[oy]
+    # The reference brackets with x2 = min{i: g_i >= v} and x1 = max{i: g_i <= v} over the axis AS GIVEN (uk.py:556-559).  On an
+    # ascending axis those are the two neighbours; on a descending or unsorted axis (a north-up raster) they are whatever
+    # indices the rule yields -- usually far-apart nodes -- and the reference interpolates between those.  Same rule here.
+    def bracket(g, v):
+        if g.size < 2 or np.all(np.diff(g) > 0.0):
+            return np.searchsorted(g, v, side="right") - 1, np.searchsorted(g, v, side="left")
+        i1, i2 = np.empty(v.size, dtype=np.intp), np.empty(v.size, dtype=np.intp)
+        step = max(1, (1 << 22) // g.size)
+        for s0 in range(0, v.size, step):
+            vv = v[s0:s0 + step, None]
+            i2[s0:s0 + step] = np.argmax(g[None, :] >= vv, axis=1)
+            i1[s0:s0 + step] = g.size - 1 - np.argmax(g[None, ::-1] <= vv, axis=1)
+        return i1, i2
+
     xf, yf = x.ravel(), y.ravel()
-    ix2 = np.searchsorted(sx, xf, side="left")
-    ix1 = np.searchsorted(sx, xf, side="right") - 1
-    iy2 = np.searchsorted(sy, yf, side="left")
-    iy1 = np.searchsorted(sy, yf, side="right") - 1
+    ix1, ix2 = bracket(gx, xf)
+    iy1, iy2 = bracket(gy, yf)
+    sx, sy = gx, gy
     x1, x2, y1, y2 = sx[ix1], sx[ix2], sy[iy1], sy[iy2]
-    jx1, jx2, jy1, jy2 = ox[ix1], ox[ix2], oy[iy1], oy[iy2]
+    jx1, jx2, jy1, jy2 = ix1, ix2, iy1, iy2
     z11, z12 = zgrid[jy1, jx1], zgrid[jy1, jx2]
     z21, z22 = zgrid[jy2, jx1], zgrid[jy2, jx2]
     same_x, same_y = ix1 == ix2, iy1 == iy2
@@ -154,16 +164,10 @@ def _model_of(variogram_function):
     return vm.MODEL_OF_FUNCTION.get(name, "custom")  # anything else is a user callable: evaluated on the host
 
 
-def _problem_handle(X, y, variogram_function, variogram_model_parameters, coordinates_type, pseudo_inv=False):
+def _set_problem_on(h, X, y, variogram_function, variogram_model_parameters, coordinates_type, pseudo_inv=False):
     from . import _lib
 
-    X = np.ascontiguousarray(X, dtype=np.float64)
-    if coordinates_type not in ("euclidean", "geographic"):
-        raise ValueError("Specified coordinate type '%s' is not supported." % coordinates_type)
-    if coordinates_type == "geographic" and X.shape[1] != 2:
-        raise ValueError("Geographic coordinate type only supported for 2D datasets.")
     model = _model_of(variogram_function)
-    h = _lib.Handle()
     params = [float(v) for v in variogram_model_parameters]
     if model == "custom":
         fn, par = variogram_function, variogram_model_parameters
@@ -172,6 +176,18 @@ def _problem_handle(X, y, variogram_function, variogram_model_parameters, coordi
     h.set_problem(ndim=X.shape[1], xs=X[:, 0], ys=X[:, 1], zs=X[:, 2] if X.shape[1] == 3 else None, values=y,
                   model_id=_lib.MODEL_IDS[model], params=params, eps=_eps,
                   exact_values=True, geographic=coordinates_type == "geographic", pseudo_inv=1 if pseudo_inv else 0)
+
+
+def _problem_handle(X, y, variogram_function, variogram_model_parameters, coordinates_type, pseudo_inv=False):
+    from . import _lib
+
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    if coordinates_type not in ("euclidean", "geographic"):
+        raise ValueError("Specified coordinate type '%s' is not supported." % coordinates_type)
+    if coordinates_type == "geographic" and X.shape[1] != 2:
+        raise ValueError("Geographic coordinate type only supported for 2D datasets.")
+    h = _lib.Handle()
+    _set_problem_on(h, X, y, variogram_function, variogram_model_parameters, coordinates_type, pseudo_inv)
     return h
 
 
@@ -190,25 +206,74 @@ def _krige(X, y, coords, variogram_function, variogram_model_parameters, coordin
     return float(z[0]), float(ss[0])
 
 
-def _find_statistics(X, y, variogram_function, variogram_model_parameters, coordinates_type, pseudo_inv=False):
-    """delta, sigma, epsilon of the variogram fit (station i kriged from stations 0..i-1) on the device."""
-    if pseudo_inv:
-        raise NotImplementedError("statistics with pseudo_inv (N-1 least-squares solves of singular subsets) have no device form; "
-                                  "remove the duplicated stations or use pseudo_inv=False")
-    y = np.ascontiguousarray(y, dtype=np.float64)
-    h = _problem_handle(X, y, variogram_function, variogram_model_parameters, coordinates_type)
-    try:
-        k, ss = h.statistics(y.size)
-    finally:
-        h.close()
+def _statistics_pseudo_inv(h, set_subset, X, y, gamma, geographic):
+    """Statistics with pseudo_inv=True: the reference solves each of the N-1 growing (singular, once a duplicated station has
+    entered) systems with numpy.linalg.lstsq (core.py:749-750), i.e. x = pinv(A_i) b_i.  There is no recursion for that --
+    the bordering identity of mik_statistics needs non-singular leading systems -- so station i is kriged from stations
+    0..i-1 through the device pseudo-inverse (mik_problem.pseudo_inv: one-sided Jacobi, O(i^3) per station, O(N^4) in all,
+    like the reference).  A completeness path for the few-hundred-station data sets that carry duplicates.
+
+    `set_subset(i)` sets the problem on stations 0..i-1 (X[:i], adjusted coordinates); `gamma(d)` is the variogram on the host.
+    core.py:728-730 zeroes b only at the FIRST station that coincides with the kriged one; the device's eps rule zeroes every
+    coincident station (ok.py:665-672).  The two differ only when station i has two or more earlier duplicates and the nugget
+    is non-zero: then the pseudo-inverse comes back from the device and the two dot products are formed here."""
+    n = y.size
+    k, ss = np.zeros(n), np.zeros(n)
+    for i in range(1, n):
+        set_subset(i)
+        h.factor()
+        if geographic:
+            d = great_circle_distance(X[:i, 0], X[:i, 1], X[i, 0] * np.ones(i), X[i, 1] * np.ones(i))
+        else:
+            d = np.sqrt(((X[:i] - X[i]) ** 2).sum(axis=1))
+        hits = np.flatnonzero(np.absolute(d) <= 1e-10)
+        if hits.size >= 2:
+            b = np.append(-np.asarray(gamma(d), dtype=np.float64), 1.0)
+            b[hits[0]] = 0.0
+            x = h.get_matrix(1) @ b
+            k[i], ss[i] = x[:i] @ y[:i], -(x @ b)
+            continue
+        q = X[i]
+        h.set_points(q[0:1], q[1:2], q[2:3] if q.size == 3 else None)
+        h.predict()
+        zi, si = h.get_results()
+        k[i], ss[i] = zi[0], si[0]
+    return k, ss
+
+
+def _delta_sigma(y, k, ss, eps):
     delta, sigma = np.zeros(y.shape), np.zeros(y.shape)
-    keep = np.absolute(ss) >= _eps
+    keep = np.absolute(ss) >= eps
     keep[0] = False
     with np.errstate(invalid="ignore"):
         delta[keep] = y[keep] - k[keep]
         sigma[keep] = np.sqrt(ss[keep])
-    sel = sigma > _eps
-    delta, sigma = delta[sel], sigma[sel]
+    sel = sigma > eps
+    return delta[sel], sigma[sel]
+
+
+def _find_statistics(X, y, variogram_function, variogram_model_parameters, coordinates_type, pseudo_inv=False):
+    """delta, sigma, epsilon of the variogram fit (station i kriged from stations 0..i-1) on the device."""
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    if pseudo_inv:
+        h = _problem_handle(X[:1], y[:1], variogram_function, variogram_model_parameters, coordinates_type, True)
+
+        def subset(i):
+            _set_problem_on(h, X[:i], y[:i], variogram_function, variogram_model_parameters, coordinates_type, True)
+
+        try:
+            k, ss = _statistics_pseudo_inv(h, subset, X, y, lambda d: variogram_function(variogram_model_parameters, d),
+                                           coordinates_type == "geographic")
+        finally:
+            h.close()
+    else:
+        h = _problem_handle(X, y, variogram_function, variogram_model_parameters, coordinates_type)
+        try:
+            k, ss = h.statistics(y.size)
+        finally:
+            h.close()
+    delta, sigma = _delta_sigma(y, k, ss, _eps)
     return delta, sigma, delta / sigma
 
 

@@ -99,12 +99,26 @@ class _KrigingBase:
                       geographic=getattr(self, "coordinates_type", "euclidean") == "geographic")
         return h.experimental_variogram(nlags)
 
-    def update_variogram_model(self, variogram_model, variogram_parameters=None, variogram_function=None, nlags=6,
-                               weight=False, **anisotropy):
-        """Changes the variogram model (and optionally the anisotropy) -- ok.py:379-545 without the
-        statistics pass, which execute() never reads."""
-        if hasattr(variogram_model, "pykrige_kwargs"):
+    def _update_variogram_model(self, variogram_model, variogram_parameters, variogram_function, nlags, weight, anisotropy):
+        """Body shared by the four update_variogram_model signatures (ok.py:379-545, uk.py:630-760, ok3d.py:368-520,
+        uk3d.py:452-600) without the statistics pass, which execute() never reads.  As in the reference the anisotropy
+        keywords DEFAULT to isotropic: omitting them resets the object to scaling 1 / angle 0 and re-adjusts the stations
+        (UniversalKriging's point_log wells keep their construction-time adjustment -- the reference does not touch them)."""
+        self.model = None
+        if hasattr(variogram_model, "pykrige_kwargs"):  # GSTools CovModel: its own anisotropy (ok.py:430-444, ok3d.py:432-445)
             self.model = variogram_model
+            if self._ndim == 2:
+                if self.model.field_dim == 3:
+                    raise ValueError("GSTools: model dim is not 1 or 2")
+                if self.model.latlon and getattr(self, "coordinates_type", "euclidean") == "euclidean":
+                    raise ValueError("GSTools: latlon models require geographic coordinates")
+                anisotropy = dict(anisotropy_scaling=self.model.pykrige_anis, anisotropy_angle=self.model.pykrige_angle)
+            else:
+                if self.model.field_dim < 3:
+                    raise ValueError("GSTools: model dim is not 3")
+                anisotropy = dict(anisotropy_scaling_y=self.model.pykrige_anis_y, anisotropy_scaling_z=self.model.pykrige_anis_z,
+                                  anisotropy_angle_x=self.model.pykrige_angle_x, anisotropy_angle_y=self.model.pykrige_angle_y,
+                                  anisotropy_angle_z=self.model.pykrige_angle_z)
             variogram_model, variogram_function, variogram_parameters = "custom", variogram_model.pykrige_vario, []
         if variogram_model == "custom":
             if variogram_function is None or not callable(variogram_function):
@@ -115,9 +129,21 @@ class _KrigingBase:
         else:
             self.variogram_function = None
         self.variogram_model = variogram_model
-        if anisotropy:
-            self._update_anisotropy(**anisotropy)
+        if getattr(self, "coordinates_type", "euclidean") == "geographic":
+            if anisotropy.get("anisotropy_scaling", 1.0) != 1.0 and anisotropy["anisotropy_scaling"] != self.anisotropy_scaling:
+                warnings.warn("Anisotropy is not compatible with geographic coordinates. Ignoring user set anisotropy.",
+                              UserWarning)  # ok.py:478-487
+        elif any(v != getattr(self, k) for k, v in anisotropy.items()):
+            for k, v in anisotropy.items():
+                setattr(self, k, v)
+            self._adjust_stations()
         self._set_variogram_parameters(variogram_parameters, nlags, weight)
+
+    def update_variogram_model(self, variogram_model, variogram_parameters=None, variogram_function=None, nlags=6,
+                               weight=False, anisotropy_scaling=1.0, anisotropy_angle=0.0):
+        """Changes the variogram model and the anisotropy (ok.py:379-387, uk.py:630-639: same signature, same defaults)."""
+        self._update_variogram_model(variogram_model, variogram_parameters, variogram_function, nlags, weight,
+                                     dict(anisotropy_scaling=anisotropy_scaling, anisotropy_angle=anisotropy_angle))
 
     # ---------------------------------------------------------------- device plumbing
     def _get_handle(self):
@@ -137,12 +163,12 @@ class _KrigingBase:
     def _regional_linear(self):
         return False
 
-    def _set_problem(self, h, with_drift=True):
+    def _set_problem(self, h, with_drift=True, values=None, pseudo_inv=False):
         """H2D of the stations / drift description."""
         ca = self._coords_adj
         kw = dict(
             ndim=self._ndim, xs=ca[:, 0], ys=ca[:, 1], zs=ca[:, 2] if self._ndim == 3 else None,
-            values=self._values(), model_id=_lib.MODEL_IDS[self.variogram_model],
+            values=self._values() if values is None else values, model_id=_lib.MODEL_IDS[self.variogram_model],
             params=self.variogram_model_parameters, eps=self.eps, exact_values=self.exact_values,
             regional_linear=self._regional_linear() if with_drift else False,
             wells=self._wells() if with_drift else None,
@@ -153,7 +179,7 @@ class _KrigingBase:
             fn, par = self.variogram_function, self.variogram_model_parameters
             h.set_custom_variogram(lambda d: fn(par, d))
             kw["params"] = [0.0, 0.0, 0.0]
-        if self.pseudo_inv and with_drift:
+        if self.pseudo_inv and (with_drift or pseudo_inv):
             # ok.py:660-661: a_inv = P_INV[self.pseudo_inv_type](a) -- on the device (mik_problem.pseudo_inv)
             kw["pseudo_inv"] = {"pinv": 1, "pinvh": 2}[self.pseudo_inv_type]
         h.set_problem(**kw)
@@ -187,17 +213,28 @@ class _KrigingBase:
         """_find_statistics on the device (mik_statistics): station i kriged from stations 0..i-1 with the ORDINARY
         system (core._krige ignores drift terms), then delta / sigma / epsilon and Q1, Q2, cR as the reference."""
         h = self._get_handle()
-        self._set_problem(h, with_drift=False)
         y = self._values()
-        k, ss = h.statistics(y.size)
-        delta, sigma = np.zeros(y.shape), np.zeros(y.shape)
-        keep = np.absolute(ss) >= self.eps
-        keep[0] = False
-        with np.errstate(invalid="ignore"):
-            delta[keep] = y[keep] - k[keep]
-            sigma[keep] = np.sqrt(ss[keep])
-        sel = sigma > self.eps
-        self.delta, self.sigma = delta[sel], sigma[sel]
+        if self.pseudo_inv:
+            # core.py:749-750: lstsq per growing subset (duplicated stations); no recursion exists for singular leading
+            # systems, so each station is kriged through the device pseudo-inverse (core._statistics_pseudo_inv)
+            full = self._coords_adj
+
+            def subset(i):
+                self._coords_adj = full[:i]
+                try:
+                    self._set_problem(h, with_drift=False, values=y[:i], pseudo_inv=True)
+                finally:
+                    self._coords_adj = full
+
+            par = self.variogram_model_parameters
+            gamma = ((lambda d: self.variogram_function(par, d)) if self.variogram_model == "custom"
+                     else (lambda d: core.variogram_value(self.variogram_model, par, d)))
+            k, ss = core._statistics_pseudo_inv(h, subset, full, y, gamma,
+                                                getattr(self, "coordinates_type", "euclidean") == "geographic")
+        else:
+            self._set_problem(h, with_drift=False)
+            k, ss = h.statistics(y.size)
+        self.delta, self.sigma = core._delta_sigma(y, k, ss, self.eps)
         self.epsilon = self.delta / self.sigma
         self.Q1 = abs(np.sum(self.epsilon) / (self.epsilon.shape[0] - 1))
         self.Q2 = np.sum(self.epsilon**2) / (self.epsilon.shape[0] - 1)
@@ -320,6 +357,9 @@ class _KrigingBase:
                     else:
                         raise ValueError("Mask dimensions do not match specified grid dimensions.")
                 mask = mask.flatten().astype(bool)
+            else:
+                mask = None  # ok.py:896 / ok3d.py:893: `if style != "masked": mask = np.zeros(npt, dtype="bool")` -- a mask handed
+                # to style="grid" is ignored, every cell is kriged
             if self._ndim == 2:
                 gx, gy = np.meshgrid(axes[0], axes[1])
                 pts = np.stack((gx.ravel(), gy.ravel()), axis=1)
@@ -441,15 +481,6 @@ class OrdinaryKriging(_KrigingBase):
                                                       self._scaling(), self._angle())
         self.X_ADJUSTED, self.Y_ADJUSTED = self._coords_adj.T
 
-    def _update_anisotropy(self, anisotropy_scaling=None, anisotropy_angle=None):
-        if getattr(self, "coordinates_type", "euclidean") == "geographic":
-            return
-        if anisotropy_scaling is not None:
-            self.anisotropy_scaling = anisotropy_scaling
-        if anisotropy_angle is not None:
-            self.anisotropy_angle = anisotropy_angle
-        self._adjust_stations()
-
     def execute(self, style, xpoints, ypoints, mask=None, backend="vectorized", n_closest_points=None):
         """Kriged values and variances at a grid / masked grid / list of points (ok.py:760-1020)."""
         if self.verbose:
@@ -542,11 +573,6 @@ class UniversalKriging(OrdinaryKriging):
         self.point_log_array[:, :2] = core.adjust_for_anisotropy(np.vstack((pl[:, 0], pl[:, 1])).T, self._center(),
                                                                  self._scaling(), self._angle())
 
-    def _update_anisotropy(self, anisotropy_scaling=None, anisotropy_angle=None):
-        OrdinaryKriging._update_anisotropy(self, anisotropy_scaling, anisotropy_angle)
-        if getattr(self, "point_log_drift", False):
-            self._adjust_wells()
-
     def _calculate_data_point_zscalars(self, x, y, type_="array"):
         return core.bilinear_zscalars(self.external_Z_array, self.external_Z_array_x, self.external_Z_array_y, x, y)
 
@@ -638,14 +664,14 @@ class OrdinaryKriging3D(_KrigingBase):
                                                       self._center(), self._scaling(), self._angle())
         self.X_ADJUSTED, self.Y_ADJUSTED, self.Z_ADJUSTED = self._coords_adj.T
 
-    def _update_anisotropy(self, anisotropy_scaling_y=None, anisotropy_scaling_z=None, anisotropy_angle_x=None,
-                           anisotropy_angle_y=None, anisotropy_angle_z=None):
-        for k, v in (("anisotropy_scaling_y", anisotropy_scaling_y), ("anisotropy_scaling_z", anisotropy_scaling_z),
-                     ("anisotropy_angle_x", anisotropy_angle_x), ("anisotropy_angle_y", anisotropy_angle_y),
-                     ("anisotropy_angle_z", anisotropy_angle_z)):
-            if v is not None:
-                setattr(self, k, v)
-        self._adjust_stations()
+    def update_variogram_model(self, variogram_model, variogram_parameters=None, variogram_function=None, nlags=6,
+                               weight=False, anisotropy_scaling_y=1.0, anisotropy_scaling_z=1.0, anisotropy_angle_x=0.0,
+                               anisotropy_angle_y=0.0, anisotropy_angle_z=0.0):
+        """ok3d.py:368-380 / uk3d.py:452-464: same signature, same (isotropic) defaults."""
+        self._update_variogram_model(variogram_model, variogram_parameters, variogram_function, nlags, weight,
+                                     dict(anisotropy_scaling_y=anisotropy_scaling_y, anisotropy_scaling_z=anisotropy_scaling_z,
+                                          anisotropy_angle_x=anisotropy_angle_x, anisotropy_angle_y=anisotropy_angle_y,
+                                          anisotropy_angle_z=anisotropy_angle_z))
 
     def execute(self, style, xpoints, ypoints, zpoints, mask=None, backend="vectorized", n_closest_points=None):
         """ok3d.py:735-932.  Output shape (nz, ny, nx) for grids."""

@@ -15,7 +15,7 @@ FUNCS = {
 }
 
 
-NON_EXECUTE = ("fit_variograms", "pseudo_dup", "mw_ok2d", "mw_ok3d", "stats_find_statistics", "sk_callers", "tools_grid_files", "custom_variogram", "aniso_adjust")  # fixtures that are not (stations, grid) -> (z, ss) cases
+NON_EXECUTE = ("fit_variograms", "pseudo_dup", "mw_ok2d", "mw_ok3d", "stats_find_statistics", "sk_callers", "tools_grid_files", "custom_variogram", "aniso_adjust", "r2_host_rules")  # fixtures that are not (stations, grid) -> (z, ss) cases
 
 
 def names():
