@@ -1,24 +1,35 @@
 #!/usr/bin/env python
 """bench.py -- kriged grid-points/sec (z + sigma^2) of the HIP execute() path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4|5] [--no-cpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4|5] [--no-cpu] [--moving-window K]
 
 One "step" = one pass of the hot path over the workload with inputs already resident in HBM:
-kriging-matrix assembly + inverse (K1, K2) [+ RCCL broadcast of the inverse when N > 1] + RHS assembly
-and contraction (K3) for every grid point of this rank's shard; z and sigma^2 stay in HBM.
+kriging-matrix assembly + inverse (K1, K2) [+ the exchange of the inverse when N > 1] + RHS assembly
+and contraction (K3) for every grid point; z and sigma^2 land in page-locked host memory chunk by chunk while the next chunk
+is computed (the timed region ends when every device AND its result copies are idle).
 Default workload = BASELINE.json configs[1]: OrdinaryKriging 2D, N=5000 stations, 1000x1000 grid,
 exponential variogram [1.0, 0.3, 0.0], fp64, synthetic stations (seed 2).
-N > 1 (launched by torch.distributed.run, one rank per GPU): WEAK scaling -- every rank kriges its own
-1000x1000 slab of a 1000 x (1000 N) grid against the same stations; rank 0 assembles + inverts and the
-inverse is broadcast over RCCL/xGMI by the library (mik_bcast_factor); no other collective.
-The host-side rendezvous / barrier / max-over-ranks of the time go through pykrige_amd.dist.SocketGroup (TCP, from the
-launcher's RANK/WORLD_SIZE/MASTER_* environment); torch is not imported unless that fails (then: its gloo group).
+
+N > 1 is WEAK scaling: the grid grows to 1000 x (1000 N) (config 5: N slabs of 4096 x 512), every GPU kriges one slab
+against the same stations; the leader assembles + inverts and the inverse is broadcast (RCCL over xGMI); no other
+collective.  Two launch forms:
+  * plain `python bench.py --gpus N`: ONE process, the library's device group (mik_set_devices: one handle spans N GPUs,
+    one host thread and one stream per GPU, ncclCommInitAll + grouped ncclBroadcast).  On a box with fewer than N GPUs the
+    group aliases devices (several members on one GPU) so that the path can be exercised anywhere; the JSON says so.
+  * under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`: one process per GPU, rank r kriges slab r,
+    mik_comm_init + mik_bcast_factor; host rendezvous / barrier / max-over-ranks through pykrige_amd.dist.SocketGroup
+    (TCP, from the launcher's RANK/WORLD_SIZE/MASTER_* environment; torch is not imported unless that fails).
 Rank 0 prints ONE JSON line.
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -27,7 +38,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X FP64 matrix peak (public spec; = 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz).
-# The local microarch guide lists no FP64 row; tools/ubench_f64.hip measures the achievable rate (profiles/).
+# The local microarch guide lists no FP64 row; tools/ubench_f64.hip measures what the part sustains:
+FP64_MFMA_MEASURED_TFLOPS = 73.2  # v_mfma_f64_4x4x4_4b_f64, one wave per SIMD issuing back to back (profiles/r01_ubench_f64.txt)
 
 CONFIGS = {
     # name: (ndim, seed, n, axes sizes (x, y[, z]), model, user params, drift)
@@ -41,6 +53,8 @@ CONFIGS = {
     5: dict(name="OK2D N=8000 4096x4096 spherical (per-GPU shard = 4096x512 rows)", ndim=2, seed=5, n=8000,
             grid=(4096, 512), model="spherical", params=[1.0, 0.2, 0.01]),
 }
+EXCHANGE_CODES = {"auto": 0, "rccl": 1, "peer": 2, "redundant": 3}
+EXCHANGE_NAMES = {0: "none", 1: "rccl_bcast", 2: "peer_scatter_allgather", 3: "redundant_factor"}
 
 
 def synth(seed, n, ndim):
@@ -74,9 +88,65 @@ def shard_points(cfg, rank, world):
     return [X.ravel(), Y.ravel(), Z.ravel()]
 
 
-def cpu_baseline(cfg, coords, values, sample_pts):
-    """The reference's own backend='C' native loop (oracle/_ref, compiled from /root/reference's
-    lib/cok.pyx) -- or, if that build is absent, the numpy oracle -- on a bounded sample of the workload."""
+def row_slab(cfg, min_points):
+    """>= min_points points of the config's own grid as whole rows from the middle of it (the
+    reference is timed on row slabs via style='grid' with a y-subrange), in the reference's meshgrid order."""
+    g = cfg["grid"]
+    nx = g[0]
+    if cfg["ndim"] == 2:
+        ny_all = 4096 if cfg["n"] == 8000 else g[1]  # config 5's grid is 4096 x 4096 (CONFIGS holds one GPU's 512 rows)
+        rows = int(np.ceil(min_points / nx))
+        gy = np.linspace(0.0, 1.0, ny_all)[ny_all // 2:ny_all // 2 + rows]
+        X, Y = np.meshgrid(np.linspace(0.0, 1.0, nx), gy)
+        return np.stack([X.ravel(), Y.ravel()], 1)
+    rows = int(np.ceil(min_points / nx))
+    gy = np.linspace(0.0, 1.0, g[1])[g[1] // 4:g[1] // 4 + rows]
+    gz = np.linspace(0.0, 1.0, g[2])[g[2] // 2:g[2] // 2 + 1]
+    Z, Y, X = np.meshgrid(gz, gy, np.linspace(0.0, 1.0, nx), indexing="ij")
+    return np.stack([X.ravel(), Y.ravel(), Z.ravel()], 1)
+
+
+def host_description():
+    """CPU model, logical CPUs, BLAS library / version / threads."""
+    d = {"host_cpus": os.cpu_count(), "numpy": np.__version__}
+    try:
+        import scipy
+
+        d["scipy"] = scipy.__version__
+    except Exception:
+        pass
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                d["cpu_model"] = line.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
+    try:
+        import threadpoolctl
+
+        d["blas"] = [{k: p.get(k) for k in ("user_api", "internal_api", "version", "num_threads", "threading_layer", "architecture")}
+                     for p in threadpoolctl.threadpool_info()]
+    except Exception:
+        d["blas"] = None
+    return d
+
+
+def cpu_baseline(cfg, coords, values, sample_pts, window=None, full=False):
+    """The reference on the GPU box's host cores, next to the GPU number.
+
+    OK2D with a named variogram: the reference's OWN compiled loop (lib/cok.pyx _c_exec_loop / _c_exec_loop_moving_window,
+    built from /root/reference by oracle/build_ref.sh into oracle/_ref/ -- kind "reference"), i.e. backend='C', the >= 10x
+    target.  Beside it (and alone for UK / 3-D, where the reference has no C backend): the NumPy / SciPy restatement of
+    backend='vectorized' (oracle/kriging_oracle.py: same cdist / scipy.linalg.inv / np.dot calls -- kind "port"; the
+    reference's Python package itself does not exist on the GPU box).  Protocol: a row slab of the config's own grid;
+    OpenBLAS thread count swept over {1, 8, 16, 32, 64} on a small slab (dgemv on every core of a 256-thread host is
+    oversubscribed) and the best kept; >= 3 repeats, best-of; fixed costs (matrix, inverse) timed on their own so that the
+    steady-state rate and the full-grid projection can be separated.  Bounded run: `sample_pts` points (about 30 s);
+    --cpu-protocol full: >= 16 384 points."""
+    import scipy.linalg
+    import threadpoolctl
+
     from oracle import kriging_oracle as ko
     from oracle import ref_c_loop as rc
 
@@ -85,52 +155,146 @@ def cpu_baseline(cfg, coords, values, sample_pts):
                          params=internal_params(cfg["model"], cfg["params"]), scaling=[1.0] * (ndim - 1),
                          angle=[0.0] * (2 * ndim - 3), regional_linear=bool(cfg.get("rl")),
                          point_log=np.array(cfg["wells"]) if cfg.get("wells") else None)
-    rng = np.random.default_rng(99)
-    pts = rng.random((sample_pts, ndim))
-    try:
-        import threadpoolctl
-
-        cores = max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] or [1])
-    except Exception:
-        cores = os.cpu_count() or 1
+    n_slab = max(16384, sample_pts) if full else sample_pts
+    pts = row_slab(cfg, n_slab)
+    n_slab = pts.shape[0]
+    repeats = 3
+    host = host_description()
+    ncpu = os.cpu_count() or 1
+    sweep = [t for t in (1, 8, 16, 32, 64) if t <= ncpu] or [1]
     use_c = rc.available() and ndim == 2 and not cfg.get("rl") and cfg["model"] != "hole-effect"
-    # fixed costs timed on their own so that the steady-state (per-point) rates can be separated
-    import scipy.linalg
-
-    t0 = time.perf_counter()
-    a = ko.kriging_matrix(st)
-    t_mat = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    a_inv = scipy.linalg.inv(a)
-    t_inv = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    zv, ssv = ko.solve_points(st, pts, a_inv=a_inv)
-    t_vec = time.perf_counter() - t0
     npt_full = int(np.prod(cfg["grid"]))
-    vec = {"value": sample_pts / (t_mat + t_inv + t_vec), "steady_state": sample_pts / t_vec, "kind": "port",
-           "what": "numpy/scipy restatement of backend='vectorized' (oracle/kriging_oracle.py), 4096-point slabs",
-           "full_grid_projection": npt_full / (t_mat + t_inv + npt_full * t_vec / sample_pts)}
+    out = {"unit": "grid-points/s", "host": host, "slab_points": n_slab, "repeats": repeats,
+           "protocol": "full (BASELINE.md section 3)" if full else "bounded (same protocol on a smaller slab)"}
+
+    def best_of(fn, k):
+        best, res = None, None
+        for _ in range(k):
+            t0 = time.perf_counter()
+            res = fn()
+            dt = time.perf_counter() - t0
+            best = dt if best is None or dt < best else best
+        return best, res
+
+    if window:  # moving window: no N x N inverse, the fixed cost is the KD tree (inside the timed call)
+        if use_c:
+            sweep_res = {}
+            small = pts[:min(n_slab, 2048)]
+            for t in sweep:
+                with threadpoolctl.threadpool_limits(limits=t):
+                    dt, _ = best_of(lambda: rc.c_backend_moving_window(st, small, window), 1)
+                sweep_res[t] = small.shape[0] / dt
+            tbest = max(sweep_res, key=sweep_res.get)
+            with threadpoolctl.threadpool_limits(limits=tbest):
+                dt, (z, ss, _, t_loop) = best_of(lambda: rc.c_backend_moving_window(st, pts, window), repeats)
+            out.update(value=n_slab / dt, cores=tbest, kind="reference", thread_sweep_points_per_s=sweep_res,
+                       sample="%d-point row slab of the same grid, best of %d: cKDTree.query + PyKrige lib/cok.pyx "
+                              "_c_exec_loop_moving_window (backend='C', n_closest_points=%d), %d BLAS threads" % (n_slab, repeats, window, tbest),
+                       steady_state=n_slab / dt, full_grid_projection=n_slab / dt)
+        else:
+            sub = pts[:min(n_slab, 2048)]
+            dt, (z, ss) = best_of(lambda: ko.solve_points_moving_window(st, sub, window), 1)
+            pts = sub
+            out.update(value=sub.shape[0] / dt, cores=1, kind="port",
+                       sample="%d points, Python restatement of backend='loop' with n_closest_points=%d" % (sub.shape[0], window),
+                       steady_state=sub.shape[0] / dt, full_grid_projection=sub.shape[0] / dt)
+        return out, (pts, z, ss)
+
+    # ---- dense path: fixed costs on their own -------------------------------------------------------------------
+    t_mat, a = best_of(lambda: ko.kriging_matrix(st), 1)
+    t_inv, a_inv = best_of(lambda: scipy.linalg.inv(a), 2)
+    out["fixed_costs_s"] = {"matrix": t_mat, "inverse": t_inv}
+    out["cond_1"] = float(np.linalg.norm(a, 1) * np.linalg.norm(a_inv, 1))
+    # vectorized (port)
+    t_vec, (zv, ssv) = best_of(lambda: ko.solve_points(st, pts, a_inv=a_inv), repeats)
+    vec = {"value": n_slab / (t_mat + t_inv + t_vec), "steady_state": n_slab / t_vec, "kind": "port",
+           "cores": max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] or [1]),
+           "what": "NumPy/SciPy restatement of backend='vectorized' (oracle/kriging_oracle.py), 4096-point dgemm slabs, best of %d" % repeats,
+           "full_grid_projection": npt_full / (t_mat + t_inv + npt_full * t_vec / n_slab)}
+    out["vectorized"] = vec
     if use_c:
-        t0 = time.perf_counter()
-        z, ss, t_loop = rc.c_backend(st, pts)  # its native loop runs scipy.linalg.inv itself (cok.pyx:53)
-        dt = time.perf_counter() - t0
-        kind = "reference"
-        what = "PyKrige lib/cok.pyx _c_exec_loop (backend='C') incl. its scipy.linalg.inv"
-        # the separately timed inverse only separates cleanly when the loop dominates; otherwise report no split
-        per_pt = (t_loop - t_inv) / sample_pts if t_loop > 1.5 * t_inv else None
+        # thread sweep on the loop's hot operation itself -- one dgemv of the Fortran-ordered inverse per point
+        # (cok.pyx:41, 71-83) -- so that the choice is not blurred by the inverse the native call repeats every time
+        from scipy.linalg.blas import dgemv
+
+        a_inv_f = np.asfortranarray(a_inv)
+        bvec = np.ones(a_inv.shape[0])
+        sweep_res = {}
+        for t in sweep:
+            with threadpoolctl.threadpool_limits(limits=t):
+                dgemv(1.0, a_inv_f, bvec)
+                reps = 24
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    dgemv(1.0, a_inv_f, bvec)
+                sweep_res[t] = reps / (time.perf_counter() - t0)
+        tbest = max(sweep_res, key=sweep_res.get)
+        del a_inv_f
+        inv_t = {}
+        with threadpoolctl.threadpool_limits(limits=tbest):
+            inv_t[tbest], _ = best_of(lambda: scipy.linalg.inv(a), 2)
+            best_total, best_loop, z, ss = None, None, None, None
+            for _ in range(repeats):
+                t0 = time.perf_counter()
+                z, ss, t_loop = rc.c_backend(st, pts)
+                dt = time.perf_counter() - t0
+                if best_total is None or dt < best_total:
+                    best_total, best_loop = dt, t_loop
+        per_pt = max(best_loop - inv_t[tbest], 1e-9) / n_slab
+        out.update(value=n_slab / (t_mat + best_loop), cores=tbest, kind="reference",
+                   thread_sweep_dgemv_per_s=sweep_res,
+                   sample="%d-point row slab of the same grid, best of %d: PyKrige lib/cok.pyx _c_exec_loop (backend='C') incl. "
+                          "matrix assembly and its scipy.linalg.inv, %d OpenBLAS threads (best of the sweep)" % (n_slab, repeats, tbest),
+                   steady_state=1.0 / per_pt,
+                   full_grid_projection=npt_full / (t_mat + inv_t[tbest] + npt_full * per_pt),
+                   c_vs_vectorized_max_abs_dz=float(np.abs(z - zv).max()),
+                   c_vs_vectorized_max_abs_dss=float(np.abs(ss - ssv).max()))
     else:
-        z, ss, dt = zv, ssv, t_mat + t_inv + t_vec
-        kind = "port"
-        what = vec["what"]
-        per_pt = t_vec / sample_pts
-    return dict(value=sample_pts / dt, unit="grid-points/s", cores=int(cores), kind=kind,
-                sample="%d random points of the same workload, %s, matrix assembly + inverse + loop = %.1f s "
-                       "(fixed costs included)" % (sample_pts, what, dt),
-                steady_state=None if per_pt is None else 1.0 / per_pt,
-                full_grid_projection=None if per_pt is None else npt_full / (t_mat + t_inv + npt_full * per_pt),
-                fixed_costs_s={"matrix": t_mat, "inverse": t_inv}, vectorized=vec,
-                c_vs_vectorized_max_abs_dz=float(np.abs(z - zv).max()), c_vs_vectorized_max_abs_dss=float(np.abs(ss - ssv).max()),
-                host_cpus=os.cpu_count()), (pts, z, ss)
+        z, ss = zv, ssv
+        out.update(value=vec["value"], cores=vec["cores"], kind="port", sample="%d-point row slab of the same grid: %s" % (n_slab, vec["what"]),
+                   steady_state=vec["steady_state"], full_grid_projection=vec["full_grid_projection"])
+    return out, (pts, z, ss)
+
+
+# ------------------------------------------------------------------------------------------------- live PMC traffic
+def collect_traffic_live(argv_tail, kernel_prefix, timeout=240):
+    """HBM-side bytes per launch of the dominant kernel: two rocprofv3 passes (FETCH_SIZE, WRITE_SIZE -- they do not fit
+    one pass, MI355X_MICROARCH.md 'PMC slots') over ONE step of this very benchmark.  gfx950 correction (same guide,
+    HBM section): FETCH_SIZE counts 128-byte requests as 64 bytes -> read bytes = 2 x FETCH_SIZE x 1024 (calibrated in
+    round 1 on k_cvec / k_rhs, profiles/k_contract_traffic.json)."""
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, "rocprofv3 not on PATH"
+    res = {}
+    tmp = tempfile.mkdtemp(prefix="mikpmc_", dir="/tmp")
+    try:
+        env = dict(os.environ, TMPDIR="/tmp", MIK_BENCH_INNER="1")
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "pmc", "--",
+                   sys.executable, os.path.join(ROOT, "bench.py")] + argv_tail
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, "rocprofv3 --pmc %s failed (rc %d): %s" % (ctr, r.returncode, (r.stderr or "")[-200:])
+            tot, n = 0.0, 0
+            for f in files:
+                for row in csv.DictReader(open(f)):
+                    if row["Kernel_Name"].startswith(kernel_prefix) and row["Counter_Name"] == ctr:
+                        tot += float(row["Counter_Value"])
+                        n += 1
+            if n == 0:
+                return None, "no %s dispatches in the %s pass" % (kernel_prefix, ctr)
+            res[ctr] = (tot / n, n)
+    except subprocess.TimeoutExpired:
+        return None, "rocprofv3 pass timed out"
+    except Exception as e:  # noqa: BLE001
+        return None, "live PMC collection failed: %r" % (e,)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    fetch_kb, write_kb = res["FETCH_SIZE"][0], res["WRITE_SIZE"][0]
+    return {"bytes_per_launch": 2.0 * fetch_kb * 1024.0 + write_kb * 1024.0, "FETCH_SIZE_KB_per_launch": fetch_kb,
+            "WRITE_SIZE_KB_per_launch": write_kb, "launches_seen": res["FETCH_SIZE"][1]}, None
 
 
 def main():
@@ -140,7 +304,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--cpu-sample", type=int, default=3072)
+    ap.add_argument("--cpu-sample", type=int, default=4096, help="points of the bounded CPU slab")
+    ap.add_argument("--cpu-protocol", choices=["bounded", "full"], default="bounded",
+                    help="full = BASELINE.md section 3 to the letter (>= 16 384-point slab, 3 repeats): minutes of CPU time")
+    ap.add_argument("--pmc", choices=["auto", "on", "off"], default="auto",
+                    help="collect roofline.traffic live with two rocprofv3 --pmc passes of one step (auto: when N = 1)")
+    ap.add_argument("--exchange", choices=sorted(EXCHANGE_CODES), default=os.environ.get("MIK_BENCH_EXCHANGE", "auto"),
+                    help="how the inverted matrix reaches the other GPUs (auto: RCCL broadcast, else peer copies)")
     ap.add_argument("--symmetric", type=int, default=None)
     ap.add_argument("--chunk", type=int, default=None)
     ap.add_argument("--engine", choices=["mfma", "valu"], default=None)
@@ -148,8 +318,9 @@ def main():
     ap.add_argument("--moving-window", type=int, default=None, metavar="K",
                     help="time moving-window kriging (n_closest_points=K) on the same workload instead (not the headline metric)")
     args = ap.parse_args()
+    inner = os.environ.get("MIK_BENCH_INNER") == "1"  # a rocprofv3 pass of collect_traffic_live: no CPU leg, no recursion
 
-    # Keep stdout clean for the ONE JSON line: gloo / RCCL print banners from C++ to fd 1, so fd 1 points at
+    # Keep stdout clean for the ONE JSON line: RCCL prints banners from C++ to fd 1, so fd 1 points at
     # stderr while the benchmark runs and is restored just before the JSON is printed.
     sys.stdout.flush()
     saved_stdout = os.dup(1)
@@ -161,13 +332,14 @@ def main():
         print(line, flush=True)
         os.dup2(2, 1)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))  # > 1: launched by torch.distributed.run, one process per GPU
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+    group = 1  # devices spanned by this process's handle
+    if world > 1:
         args.gpus = world
+    elif args.gpus > 1:
+        group = args.gpus  # plain `python bench.py --gpus N`: single process, the library's device group
     pg = None
     if world > 1:
         # Host-side rendezvous / barrier / max-over-ranks only.  The launcher's env (RANK, WORLD_SIZE, MASTER_*) is used
@@ -192,14 +364,24 @@ def main():
     cfg = CONFIGS[args.config]
     ndim = cfg["ndim"]
     coords, values = synth(cfg["seed"], cfg["n"], ndim)
-    pts = shard_points(cfg, rank, world)
+    n_gpus = world * group
+    if group > 1:  # the whole weak-scaled grid; the library cuts it into one contiguous slab per device
+        parts = [shard_points(cfg, r, group) for r in range(group)]
+        pts = [np.concatenate([p[d] for p in parts]) for d in range(ndim)]
+        del parts
+    else:
+        pts = shard_points(cfg, rank, world)
     npt = pts[0].size
 
     ndev = _lib.load().mik_device_count()
     wells = np.array(cfg["wells"]) if cfg.get("wells") else None
+    aliased = group > max(ndev, 1)
 
     def make_handle():
         hh = _lib.Handle(local_rank % max(ndev, 1))  # one GPU per rank on a real node; wraps only on a 1-GPU test box
+        if group > 1:
+            hh.set_devices(group, alias=aliased)
+            hh.set_option("exchange", EXCHANGE_CODES[args.exchange])
         if args.symmetric is not None:
             hh.set_option("symmetric", args.symmetric)
         if args.chunk is not None:
@@ -216,15 +398,34 @@ def main():
 
     h = make_handle()
 
-    # How the factored matrix reaches every rank is decided by measurement, outside the timed region: (A) rank 0 factors
-    # and the library broadcasts T and c over RCCL/xGMI, or (B) every rank factors for itself (no collective at all).
-    # Ranks != 0 wait for rank 0's factorisation in (A) anyway, so (A) wins only if the broadcast beats nothing -- it
-    # usually does not, and the trial says so in the JSON.  Every RCCL call of the trial runs under a watchdog: a wedged
-    # bootstrap or collective degrades to (B) on a fresh handle instead of hanging the benchmark.
+    # How the inverted matrix reaches every GPU.  The north_star's design is the default and the one timed: the leader
+    # factors, ONE broadcast over RCCL/xGMI.  The alternatives are measured beside it, outside the timed region, and
+    # printed (factor_exchange_trial): peer copies shaped as scatter + all-gather, and no exchange at all (every GPU
+    # factors the identical matrix; the others wait for the leader's factorisation anyway, so this is a wall-clock tie at
+    # best for the broadcast and costs N-1 redundant O(M^3) factorisations of energy).
     exchange, trial, leaked = "none", None, False
-    if world > 1 and not args.moving_window:
-        mode = os.environ.get("MIK_BENCH_EXCHANGE", "auto")  # auto | rccl | redundant
-        if mode == "redundant":
+    if group > 1 and not args.moving_window:
+        trial = {}
+        for name in ("rccl", "peer", "redundant"):
+            try:
+                h.set_option("exchange", EXCHANGE_CODES[name])
+                best = None
+                for _ in range(2):  # the first round pays RCCL's communicator / stream set-up and the buffer allocations
+                    t0 = time.perf_counter()
+                    h.factor()
+                    dt = time.perf_counter() - t0
+                    best = dt if best is None else min(best, dt)
+                trial[name + "_factor_plus_exchange_ms"] = best * 1e3
+                trial[name + "_exchange_ms"] = h.timing()["exchange_ms"]
+            except Exception as e:  # noqa: BLE001
+                trial[name + "_error"] = repr(e)[:200]
+        h.set_option("exchange", EXCHANGE_CODES[args.exchange])
+        h.factor()
+        exchange = EXCHANGE_NAMES[h.timing()["exchange_path"]]
+        if args.exchange == "auto" and exchange != "rccl_bcast":
+            exchange += " (rccl unavailable: %s)" % trial.get("rccl_error", "?")
+    elif world > 1 and not args.moving_window:
+        if args.exchange == "redundant":
             exchange = "redundant_factor"
         else:
             import threading
@@ -273,25 +474,25 @@ def main():
                     h.factor()
                     tb = pg.all_reduce_max(time.perf_counter() - t0)
                 if exchange == "rccl_bcast":
-                    trial = {"rccl_bcast_ms": ta * 1e3, "redundant_factor_ms": tb * 1e3}
-                    if mode != "rccl" and tb <= ta:
-                        exchange = "redundant_factor (measured faster than rank-0 factor + RCCL broadcast)"
+                    trial = {"rccl_factor_plus_exchange_ms": ta * 1e3, "redundant_factor_plus_exchange_ms": tb * 1e3}
 
     def sync():
-        h.synchronize()  # device idle (mik_predict / mik_bcast_factor already block; this is the explicit bracket)
+        h.synchronize()  # every device of the handle and its result copies idle (the calls already block; explicit bracket)
         if pg is not None:
             pg.barrier()
 
     tsum = dict(assemble_ms=0.0, invert_ms=0.0, rhs_ms=0.0, contract_ms=0.0, predict_ms=0.0, contract_launches=0,
-                contract_flops_executed=0.0)
+                contract_flops_executed=0.0, exchange_ms=0.0)
 
     def step(record):
         if args.moving_window:
             h.predict_moving_window(args.moving_window)
             if record:
-                tsum["predict_ms"] += h.timing()["predict_ms"]
+                t = h.timing()
+                for k in ("rhs_ms", "contract_ms", "predict_ms", "contract_launches"):
+                    tsum[k] += t[k]
             return
-        if exchange == "rccl_bcast":
+        if world > 1 and exchange == "rccl_bcast":
             if rank == 0:
                 h.factor()
             h.bcast_factor(0)
@@ -301,7 +502,8 @@ def main():
             t = h.timing()
             tsum["assemble_ms"] += t["assemble_ms"]
             tsum["invert_ms"] += t["invert_ms"]
-        h.predict()  # blocking: returns after the stream has drained
+            tsum["exchange_ms"] += t["exchange_ms"]
+        h.predict()  # blocking: returns after every device's compute stream has drained
         if record:
             t = h.timing()
             for k in ("rhs_ms", "contract_ms", "predict_ms", "contract_launches", "contract_flops_executed"):
@@ -324,68 +526,113 @@ def main():
         M = cfg["n"] + (ndim if cfg.get("rl") else 0) + (len(cfg["wells"]) if cfg.get("wells") else 0) + 1
         total_pts = npt * world
         value = total_pts * K / dt
-        launches = max(1, int(tsum["contract_launches"]))
+        launches = max(1, int(tsum["contract_launches"]))  # of the leader device (its slab = total / n_gpus points)
         avg_launch_s = tsum["contract_ms"] * 1e-3 / launches
-        pts_per_launch = npt * K / launches
-        algo_flops_per_launch = 2.0 * M * M * pts_per_launch  # 2 M^2 per point for w = A_inv . b
-        achieved = algo_flops_per_launch / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0
-        executed = tsum["contract_flops_executed"] / (tsum["contract_ms"] * 1e-3) / 1e12 if tsum["contract_ms"] > 0 else 0.0
-        traffic, traffic_note = None, None
-        try:  # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (not collected live)
-            tj = json.load(open(os.path.join(ROOT, "profiles", "k_contract_traffic.json")))
-            if tj["workload"] == cfg["name"] and not tsum.get("engine") and tsum.get("symmetric"):
-                traffic = tj["hbm_bytes_per_launch"] * (pts_per_launch / tj["points_per_launch"])
-                traffic_note = tj["source"]
-        except Exception:
-            pass
-        if args.moving_window:
-            emit(json.dumps({"metric": "kriged grid-points/sec (z + sigma^2), moving window n_closest_points=%d, %s"
-                                        % (args.moving_window, cfg["name"]), "value": value, "unit": "grid-points/s",
-                              "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": dt / K * 1e3,
-                              "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-                              "data": "synthetic", "config": {"workload": cfg["name"], "n_closest_points": args.moving_window}}))
-            if pg is not None:
-                pg.barrier()
-            h.close()
-            return
-        out = {
-            "metric": "kriged grid-points/sec (z + sigma^2), OK2D N=5000 on 1000x1000 grid" if args.config == 2
-            else "kriged grid-points/sec (z + sigma^2), " + cfg["name"],
-            "value": value, "unit": "grid-points/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
-            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": cfg["name"], "stations": cfg["n"], "matrix_order": M,
-                       "grid_points_per_gpu": npt, "grid_points_total": total_pts, "variogram": cfg["model"],
-                       "variogram_parameters": cfg["params"], "factor_exchange": exchange, "factor_exchange_trial": trial,
-                       "factor_path": {1: "spd-shift block sweep", 2: "pivoted block gauss-jordan", 3: "caller-supplied inverse", 4: "device pseudo-inverse"}.get(
-                           tsum.get("factor_path"), "?"),
-                       "symmetric_contraction": bool(tsum.get("symmetric"))},
-            "roofline": {"bound": "mfma", "kernel": "k_contract_valu" if tsum.get("engine") else "k_contract", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                         "traffic_unit": "bytes per launch (HBM-side, PMC)", "traffic_source": traffic_note,
-                         "executed_tflops": executed, "frac_executed": executed / FP64_MFMA_PEAK_TFLOPS,
-                         "note": "achieved / frac use the reference's 2 M^2 flops per point (SURVEY 8d); the kernel executes ~M^2 (symmetric half product), see executed_tflops / frac_executed",
-                         "avg_launch_ms": avg_launch_s * 1e3,
-                         "launches_per_step": launches / K, "algorithmic_flops_per_point": 2.0 * M * M},
-            "phases_ms_per_step": {"assemble": tsum["assemble_ms"] / K, "invert": tsum["invert_ms"] / K,
-                                   "rhs": tsum["rhs_ms"] / K, "contract": tsum["contract_ms"] / K,
-                                   "predict_total": tsum["predict_ms"] / K},
-        }
-        if world == 1:  # the same step with host buffers handed over and results copied back (never `value`)
-            t1 = time.perf_counter()
-            h.set_points(pts[0], pts[1], pts[2] if ndim == 3 else None)
-            h.factor()
-            h.predict()
-            zz, sss = h.get_results()
-            out["pcie_inclusive"] = {"value": npt / (time.perf_counter() - t1), "unit": "grid-points/s",
-                                     "includes": "H2D of the point coordinates, assemble+invert, predict, D2H of z and sigma^2"}
-            out["checksum"] = {"z_sum": float(zz.sum()), "ss_sum": float(sss.sum())}
-        if world == 1 and not args.no_cpu:
+        pts_per_launch = (npt / group) * K / launches
+        kw = args.moving_window
+        if kw:
+            # dominant kernel: the per-point (k+1) x (k+1) solves.  Algorithmic work per point = what the reference's dgesv
+            # does (cok.pyx:165): 2/3 n^3 + 2 n^2 flops, n = k + 1; bytes: k x 12 (neighbour index + distance) in, 16 out.
+            nn = kw + 1.0
+            algo_flops_pt = 2.0 / 3.0 * nn ** 3 + 2.0 * nn ** 2
+            achieved = algo_flops_pt * pts_per_launch / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0
+            roof = {"bound": "mfma", "kernel": "k_mw_solve", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                    "note": "fp64 compute roof (vector = matrix rate on this part): %.0f flop per point against %d bytes; the kernel "
+                            "is a register-tiled elimination with one barrier per step -- issue / latency bound, not MFMA work"
+                            % (algo_flops_pt, 12 * kw + 16),
+                    "avg_launch_ms": avg_launch_s * 1e3, "algorithmic_flops_per_point": algo_flops_pt,
+                    "algorithmic_bytes_per_point": 12 * kw + 16}
+            metric = "kriged grid-points/sec (z + sigma^2), moving window n_closest_points=%d, %s" % (kw, cfg["name"])
+            config = {"workload": cfg["name"], "n_closest_points": kw, "stations": cfg["n"], "grid_points_total": total_pts}
+            kernel_prefix = "void mik::k_mw_solve"
+        else:
+            algo_flops_per_launch = 2.0 * M * M * pts_per_launch  # 2 M^2 per point for w = A_inv . b
+            effective = algo_flops_per_launch / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0
+            executed = tsum["contract_flops_executed"] / (tsum["contract_ms"] * 1e-3) / 1e12 if tsum["contract_ms"] > 0 else 0.0
+            roof = {"bound": "mfma", "kernel": "k_contract_valu" if tsum.get("engine") else "k_contract",
+                    "achieved": executed, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": executed / FP64_MFMA_PEAK_TFLOPS,
+                    "peak_measured": FP64_MFMA_MEASURED_TFLOPS, "frac_of_measured_peak": executed / FP64_MFMA_MEASURED_TFLOPS,
+                    "effective_tflops": effective, "effective_frac": effective / FP64_MFMA_PEAK_TFLOPS,
+                    "traffic": None, "traffic_unit": "bytes per launch (HBM-side: 2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction)",
+                    "note": "achieved / frac = flops the kernel EXECUTES (symmetric half product, ~M^2 per point) over the fp64 matrix "
+                            "peak: a true fraction.  effective_* = the reference's 2 M^2 flops per point (SURVEY 8d) over the same "
+                            "time: the rate a full product would need to match this kernel; it can exceed the peak.",
+                    "avg_launch_ms": avg_launch_s * 1e3, "launches_per_step": launches / K,
+                    "algorithmic_flops_per_point": 2.0 * M * M, "executed_flops_per_point": tsum["contract_flops_executed"] / max(1.0, pts_per_launch * launches)}
+            metric = ("kriged grid-points/sec (z + sigma^2), OK2D N=5000 on 1000x1000 grid" if args.config == 2
+                      else "kriged grid-points/sec (z + sigma^2), " + cfg["name"])
+            config = {"workload": cfg["name"], "stations": cfg["n"], "matrix_order": M,
+                      "grid_points_per_gpu": npt // group, "grid_points_total": total_pts, "variogram": cfg["model"],
+                      "variogram_parameters": cfg["params"], "factor_exchange": exchange, "factor_exchange_trial": trial,
+                      "factor_path": {1: "spd-shift block sweep", 2: "pivoted block gauss-jordan", 3: "caller-supplied inverse",
+                                      4: "device pseudo-inverse"}.get(tsum.get("factor_path"), "?"),
+                      "symmetric_contraction": bool(tsum.get("symmetric"))}
+            kernel_prefix = "void mik::k_contract"
+        config["launch"] = ("one process per GPU (torch.distributed.run)" if world > 1 else
+                            "one process, device group of %d%s" % (group, " ALIASED onto %d physical GPU(s)" % ndev if aliased else "")
+                            if group > 1 else "one process, one GPU")
+        out = {"metric": metric, "value": value, "unit": "grid-points/s", "n_gpus": n_gpus, "steps": K, "warmup": args.warmup,
+               "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f64", "data": "synthetic", "config": config, "roofline": roof,
+               "phases_ms_per_step": {"assemble": tsum["assemble_ms"] / K, "invert": tsum["invert_ms"] / K,
+                                      "exchange": tsum["exchange_ms"] / K, "rhs": tsum["rhs_ms"] / K,
+                                      "contract": tsum["contract_ms"] / K, "predict_total": tsum["predict_ms"] / K}}
+        if group > 1:
+            out["per_device_predict_ms"] = [h.device_timing(i)["predict_ms"] for i in range(group)]
+        # ---- roofline.traffic: live PMC passes over one step of this benchmark, else the committed profile (labelled)
+        if n_gpus == 1 and not inner and args.pmc != "off":
+            tail = ["--steps", "1", "--warmup", "0", "--no-cpu", "--pmc", "off", "--config", str(args.config)]
+            if kw:
+                tail += ["--moving-window", str(kw)]
+            for flag, val in (("--symmetric", args.symmetric), ("--chunk", args.chunk), ("--engine", args.engine), ("--factor", args.factor)):
+                if val is not None:
+                    tail += [flag, str(val)]
+            live, why = collect_traffic_live(tail, kernel_prefix)
+            if live:
+                roof["traffic"] = live["bytes_per_launch"]
+                roof["traffic_source"] = "live: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, two passes of one step of this run"
+                roof["traffic_counters"] = live
+            else:
+                roof["traffic_source"] = "live collection failed: " + str(why)
+        if roof.get("traffic") is None and not kw:
             try:
-                cb, (cp, cz, css) = cpu_baseline(cfg, coords, values, args.cpu_sample)
+                tj = json.load(open(os.path.join(ROOT, "profiles", "k_contract_traffic.json")))
+                if tj["workload"] == cfg["name"] and not tsum.get("engine") and tsum.get("symmetric"):
+                    roof["traffic"] = tj["hbm_bytes_per_launch"] * (pts_per_launch / tj["points_per_launch"])
+                    roof["traffic_source"] = ("from_profile (NOT collected in this run): " + tj["source"]
+                                              + ("; " + roof["traffic_source"] if roof.get("traffic_source") else ""))
+            except Exception:
+                pass
+        if not kw:
+            # compulsory bytes of one launch: the inverse once, the RHS panel (8 M per point) in, 8 M/128 partial sums per point out
+            roof["algorithmic_bytes_per_launch"] = 8.0 * (M * M + pts_per_launch * (M + M / 128.0))
+        if n_gpus == 1 and not inner:  # the same step with host buffers handed over and results copied back (never `value`)
+            best = None
+            for _ in range(2):
+                t1 = time.perf_counter()
+                h.set_points(pts[0], pts[1], pts[2] if ndim == 3 else None)
+                if kw:
+                    h.predict_moving_window(kw)
+                else:
+                    h.factor()
+                    h.predict()
+                zz, sss = h.get_results()
+                d1 = time.perf_counter() - t1
+                best = d1 if best is None else min(best, d1)
+            out["pcie_inclusive"] = {"value": npt / best, "unit": "grid-points/s",
+                                     "includes": "H2D of the point coordinates (page-locked staging), assemble+invert, predict with "
+                                                 "overlapped D2H of z and sigma^2, copy into the caller's arrays"}
+            out["checksum"] = {"z_sum": float(zz.sum()), "ss_sum": float(sss.sum())}
+        if n_gpus == 1 and not args.no_cpu and not inner:
+            try:
+                cb, (cp, cz, css) = cpu_baseline(cfg, coords, values, args.cpu_sample, window=kw, full=args.cpu_protocol == "full")
                 # parity of the GPU path on the very points the CPU baseline kriged
-                h.set_points(*[cp[:, d] for d in range(ndim)])
-                h.predict()
+                h.set_points(*[np.ascontiguousarray(cp[:, d]) for d in range(ndim)])
+                if kw:
+                    h.predict_moving_window(kw)
+                else:
+                    h.predict()
                 gz, gss = h.get_results()
                 cb["gpu_vs_cpu_max_abs_dz"] = float(np.abs(gz - cz).max())
                 cb["gpu_vs_cpu_max_abs_dss"] = float(np.abs(gss - css).max())

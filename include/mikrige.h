@@ -21,7 +21,8 @@
  *
  * Conventions: every pointer is a host pointer to C-contiguous float64 (int8 for the mask), borrowed
  * for the duration of the call only.  Outputs are caller-allocated.  All calls are blocking.  A
- * handle is bound to one HIP device and is not thread-safe; distinct handles are independent.
+ * handle is bound to one HIP device (or to a group of them, mik_set_devices) and is not thread-safe; distinct handles
+ * are independent.
  * Return value 0 = success; negative = error (mik_last_error() has the text for this thread).
  */
 #ifndef MIKRIGE_H
@@ -93,12 +94,30 @@ typedef struct mik_timing {
   int32_t factor_path;    /* 1 = unpivoted symmetric block sweep on the SPD-shifted matrix, 2 = pivoted block Gauss-Jordan, 3 = caller-supplied inverse, 4 = device pseudo-inverse */
   int32_t symmetric;      /* 1 = contraction used the symmetric half product */
   int32_t engine;         /* 0 = v_mfma_f64_4x4x4_4b_f64 contraction, 1 = v_fma_f64 register-tiled contraction */
-  int32_t reserved;
+  int32_t reserved;       /* mik_get_device_timing: the HIP device index of that group member */
+  double exchange_ms;     /* device groups: host wall time of the factor exchange of the last mik_factor (0 for one device) */
+  int32_t exchange_path;  /* 0 = none (one device), 1 = RCCL broadcast, 2 = peer copies (scatter + all-gather), 3 = every device factored */
+  int32_t n_devices;      /* members of the handle's device group */
 } mik_timing;
 
 int  mik_device_count(void);
 int  mik_create(int device, mik_handle **out);
 void mik_destroy(mik_handle *h);
+
+/* Single-process multi-GPU.  A handle can span n devices of the node (a "device group": the
+ * handle's own device + the next n-1 visible ones); every call below then works on the group with unchanged signatures,
+ * so OrdinaryKriging.execute() (ok.py:760-768) scales over the node without any change to the caller's script:
+ *   mik_set_problem   stations to every member                    mik_factor   K1 + K2 on the handle's own device, then ONE
+ *   mik_set_points    unmasked points cut into n contiguous slabs              broadcast of the inverted matrix and of c
+ *   mik_predict       every member kriges its slab, own stream                 (RCCL over xGMI: ncclCommInitAll + grouped
+ *   mik_get_results   every member copies its slab into the caller's           ncclBroadcast; or peer copies as scatter +
+ *                     z_out / ss_out at its offset (page-locked staging)       all-gather; or no exchange: all factor)
+ * No cross-GPU reduction, no halo.
+ * mik_set_devices(n): process-wide default for handles created afterwards (n = 0: every visible device; the environment
+ * variable MIK_NGPU = n | "all" sets the same default without touching the script).  mik_handle_set_devices: one handle. */
+int  mik_set_devices(int n);
+int  mik_handle_set_devices(mik_handle *h, int n);
+int  mik_handle_devices(mik_handle *h);          /* members of the handle's device group (1 = single device) */
 
 /* options: "factor" 0=auto 1=sweep 2=pivoted ; "symmetric" 0/1 (contraction uses A_inv symmetry) ;
  * "engine" 0 = MFMA f64 contraction, 1 = VALU (v_fma_f64) contraction ; "waves" 4 | 8 = wavefronts per contraction block ;
@@ -108,7 +127,10 @@ void mik_destroy(mik_handle *h);
  * "symsweep" 0/1 = sweep only the upper block triangle (faster, less accurate on ill-conditioned systems; default 0) ;
  * "mw_pivot" 0/1 = always solve the moving-window systems with partial pivoting (default 0: SPD-shifted, no pivot search,
  *   falling back to pivoting when a local system is not positive definite) ;
- * "mw_lds_cap" = largest moving-window candidate buffer kept in LDS (entries, default 8192; 0 forces the HBM lists) */
+ * "mw_lds_cap" = largest moving-window candidate buffer kept in LDS (entries, default 8192; 0 forces the HBM lists) ;
+ * "exchange" 0..3 = how a device group distributes the inverted matrix: 0 auto (RCCL broadcast, peer copies if RCCL is
+ *   unavailable), 1 RCCL broadcast, 2 peer copies (scatter + all-gather over xGMI), 3 none (every device factors) [MIK_EXCHANGE] ;
+ * "alias_devices" 0/1 = a device group may place several members on one physical GPU (1-GPU test boxes) [MIK_ALIAS_DEVICES] */
 int  mik_set_option(mik_handle *h, const char *key, double value);
 
 /* variogram_model='custom' (a Python callable in the reference: ok.py:305-318, core.py:584-586).  Geometry stays on the
@@ -148,7 +170,8 @@ int  mik_krige_execute(int device, const mik_problem *p, const mik_points *g, do
 int  mik_assemble_only(mik_handle *h);
 int  mik_get_matrix(mik_handle *h, int which, double *out);
 int64_t mik_matrix_order(mik_handle *h); /* M = n + ndrift + 1 */
-int  mik_get_timing(mik_handle *h, mik_timing *out);
+int  mik_get_timing(mik_handle *h, mik_timing *out);   /* device group: the leader's phases, predict_ms = slowest member */
+int  mik_get_device_timing(mik_handle *h, int member, mik_timing *out); /* one member of a device group (0 = the handle's own device) */
 int  mik_selftest_mfma(int device); /* 0 if the v_mfma_f64_4x4x4_4b_f64 (and 16x16x4) fragment layouts are what the kernels assume */
 
 /* Multi-GPU (one process per GPU): grid points are sharded by the caller; the factored matrix is

@@ -59,3 +59,26 @@ def c_backend(st, pts_adj):
     t0 = time.perf_counter()
     z, ss = cok._c_exec_loop(a, bd, np.zeros(pts_adj.shape[0], dtype="int8"), st.n, pars)
     return np.asarray(z), np.asarray(ss), time.perf_counter() - t0
+
+
+def c_backend_moving_window(st, pts_adj, n_closest_points):
+    """backend='C' with n_closest_points (ok.py:929-986): cKDTree.query -> _c_exec_loop_moving_window(a, bd, mask, bd_idx,
+    n, pars).  Returns (z, sigma^2, seconds in cKDTree + the native loop, seconds in the native loop alone)."""
+    import time
+
+    from scipy.spatial import cKDTree
+
+    cok = load_cok()
+    fn = lambda m, d: ko.variogram(st.model, m, d)  # noqa: E731
+    fn.__name__ = _VARIOGRAM_NAMES[st.model]
+    a = ko.kriging_matrix(st)
+    pars = dict(Z=st.values, eps=ko.EPS, variogram_model_parameters=np.asarray(st.params, dtype=np.float64),
+                variogram_function=fn, exact_values=st.exact_values, pseudo_inv=False, pseudo_inv_type="pinv")
+    t0 = time.perf_counter()
+    tree = cKDTree(st.coords_adj)
+    bd, bd_idx = tree.query(pts_adj, k=int(n_closest_points), eps=0.0)
+    t1 = time.perf_counter()
+    z, ss = cok._c_exec_loop_moving_window(a, np.ascontiguousarray(bd), np.zeros(pts_adj.shape[0], dtype="int8"),
+                                           np.ascontiguousarray(bd_idx.astype("long")), st.n, pars)
+    t2 = time.perf_counter()
+    return np.asarray(z), np.asarray(ss), t2 - t0, t2 - t1

@@ -6,6 +6,7 @@ as hand-written HIP kernels in ``libmikrige.so`` (C ABI: include/mikrige.h), cal
 """
 from .kriging import OrdinaryKriging, OrdinaryKriging3D, UniversalKriging, UniversalKriging3D  # noqa: F401
 from . import _lib, core, variogram_models  # noqa: F401
+from ._lib import set_devices  # noqa: F401  (single-process multi-GPU: handles span n GPUs; MIK_NGPU does the same)
 from . import kriging_tools as kt  # noqa: F401  (the reference's alias)
 
 __all__ = ["OrdinaryKriging", "UniversalKriging", "OrdinaryKriging3D", "UniversalKriging3D"]

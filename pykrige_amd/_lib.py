@@ -42,6 +42,7 @@ class MikTiming(C.Structure):
         ("contract_ms", C.c_double), ("predict_ms", C.c_double), ("contract_launches", C.c_int64),
         ("contract_flops_executed", C.c_double), ("factor_path", C.c_int32), ("symmetric", C.c_int32),
         ("engine", C.c_int32), ("reserved", C.c_int32),
+        ("exchange_ms", C.c_double), ("exchange_path", C.c_int32), ("n_devices", C.c_int32),
     ]
 
     def as_dict(self):
@@ -55,6 +56,10 @@ SIGNATURES = {
     "mik_device_count": (C.c_int, []),
     "mik_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "mik_destroy": (None, [C.c_void_p]),
+    "mik_set_devices": (C.c_int, [C.c_int]),
+    "mik_handle_set_devices": (C.c_int, [C.c_void_p, C.c_int]),
+    "mik_handle_devices": (C.c_int, [C.c_void_p]),
+    "mik_get_device_timing": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(MikTiming)]),
     "mik_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double]),
     "mik_set_problem": (C.c_int, [C.c_void_p, C.POINTER(MikProblem)]),
     "mik_factor": (C.c_int, [C.c_void_p]),
@@ -148,6 +153,23 @@ class Handle:
 
     def set_option(self, key, value):
         check(self._lib.mik_set_option(self._h, key.encode(), float(value)))
+
+    # --- single-process multi-GPU: the handle spans n devices (mik_handle_set_devices) -----------------
+    def set_devices(self, n, alias=False):
+        """Let this handle span `n` GPUs of the node (0 = all visible).  alias=True allows more members than GPUs (several
+        logical devices on one physical GPU -- only useful to exercise the multi-device path on a 1-GPU box)."""
+        if alias:
+            self.set_option("alias_devices", 1)
+        check(self._lib.mik_handle_set_devices(self._h, int(n)))
+
+    @property
+    def n_devices(self):
+        return int(self._lib.mik_handle_devices(self._h))
+
+    def device_timing(self, member):
+        t = MikTiming()
+        check(self._lib.mik_get_device_timing(self._h, int(member), C.byref(t)))
+        return t.as_dict()
 
     def set_problem(self, ndim, xs, ys, zs, values, model_id, params, eps=1e-10, exact_values=True,
                     regional_linear=False, wells=None, extra_cols=None, a_inv=None, geographic=False, pseudo_inv=0):
@@ -274,6 +296,12 @@ class Handle:
 
     def bcast_factor(self, root=0):
         check(self._lib.mik_bcast_factor(self._h, int(root)))
+
+
+def set_devices(n):
+    """Process-wide default: every handle created from now on spans `n` GPUs of the node (0 = all visible, 1 = one).  The
+    environment variable MIK_NGPU does the same without touching the script."""
+    check(load().mik_set_devices(int(n)))
 
 
 def selftest_mfma(device=0):

@@ -12,7 +12,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
+#include <map>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace mik;
@@ -63,6 +67,31 @@ struct DevBuf {
   T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+// page-locked host memory: staging of the point coordinates on their way in, landing zone of z / sigma^2 on their way out
+struct PinBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  PinBuf() = default;
+  PinBuf(const PinBuf&) = delete;
+  PinBuf& operator=(const PinBuf&) = delete;
+  ~PinBuf() { release(); }
+  int ensure(size_t need) {
+    if (need <= bytes && p) return MIK_OK;
+    release();
+    if (need == 0) return MIK_OK;
+    HIPC(hipHostMalloc(&p, need, hipHostMallocPortable));
+    bytes = need;
+    return MIK_OK;
+  }
+  void release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  template <class T>
+  T* as() const { return reinterpret_cast<T*>(p); }
+};
+
 // --- RCCL, loaded lazily so the single-GPU path has no link-time dependency on it ---------------
 struct RcclApi {
   void* lib = nullptr;
@@ -71,6 +100,10 @@ struct RcclApi {
   ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  // single-process multi-device use (mik_set_devices): one communicator per device, calls fused in a group
+  ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
 };
 static RcclApi g_rccl;
 static int rccl_load() {
@@ -87,6 +120,9 @@ static int rccl_load() {
   g_rccl.Broadcast = (decltype(g_rccl.Broadcast))dlsym(lib, "ncclBroadcast");
   g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(lib, "ncclCommDestroy");
   g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(lib, "ncclGetErrorString");
+  g_rccl.CommInitAll = (decltype(g_rccl.CommInitAll))dlsym(lib, "ncclCommInitAll");
+  g_rccl.GroupStart = (decltype(g_rccl.GroupStart))dlsym(lib, "ncclGroupStart");
+  g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd))dlsym(lib, "ncclGroupEnd");
   if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.Broadcast || !g_rccl.CommDestroy)
     return fail(MIK_ERCCL, "librccl.so lacks an expected symbol");
   g_rccl.lib = lib;
@@ -141,6 +177,7 @@ struct mik_handle {
   int opt_diag = 1;        // diagonal-block inverse variant: 0 = 1024 threads (16 waves x 8 rows), 1 = 16x16 grid, 2 = 16x32, 3 = 32x32
   // points
   long npt_total = 0, npt = 0;
+  bool masked = false;  // the caller's mask skipped at least one point: outputs are zero-filled before the scatter
   std::vector<long> scatter;  // empty = identity
   DevBuf px, py, pz, extra_rows, z, ss;
   // work
@@ -159,6 +196,23 @@ struct mik_handle {
   // comm
   ncclComm_t comm = nullptr;
   int nranks = 1, rank = 0;
+  // host path: pinned staging in, pinned landing zone out; results leave the device chunk by chunk on their own stream
+  PinBuf pin_in, pin_out;
+  hipStream_t stream_d2h = nullptr;
+  hipEvent_t ev_d2h = nullptr;  // recorded on stream_d2h after the last result copy of a predict
+  bool results_on_host = false;
+  long out_off = 0;  // where this handle's (unmasked) slab starts in the caller's arrays (device groups)
+  // single-process device group (mik_set_devices): this handle is device 0 of the group and owns the others
+  std::vector<mik_handle*> kids;
+  bool is_kid = false;
+  bool alias_ok = false;       // "alias_devices": a group may put several logical devices on one physical GPU (1-GPU test boxes)
+  int opt_exchange = 0;        // "exchange": 0 = auto (RCCL broadcast, else peer copies), 1 = RCCL, 2 = peer copies, 3 = every device factors
+  int exchange_used = 0;       // what the last mik_factor did (same codes; 0 = single device)
+  double exchange_ms = 0.0;
+  std::string exchange_note;
+  std::vector<ncclComm_t> gcomms;                 // one communicator per device of the group (ncclCommInitAll)
+  std::vector<std::vector<hipStream_t>> xstreams; // xstreams[i][k]: stream on device i for the copy to device k (peer exchange)
+  std::vector<hipEvent_t> xevents;
 };
 
 static int get_events(mik_handle* h, size_t n) {
@@ -392,21 +446,19 @@ int mik_device_count(void) {
   return n;
 }
 
-int mik_create(int device, mik_handle** out) {
-  if (!out) return fail(MIK_EINVAL, "mik_create: out is NULL");
-  int n = 0;
-  hipError_t e = hipGetDeviceCount(&n);
-  if (e != hipSuccess || n <= 0) return fail(MIK_EHIP, "mik_create: no HIP device visible (this library has no CPU path)");
-  if (device < 0 || device >= n) return fail(MIK_EINVAL, "mik_create: device index out of range");
-  HIPC(hipSetDevice(device));
-  mik_handle* h = new mik_handle();
+static void destroy_one(mik_handle* h);
+
+static int create_one_body(mik_handle* h, int device) {
   h->device = device;
+  HIPC(hipSetDevice(device));
   HIPC(hipStreamCreate(&h->stream));
   {
     int lo = 0, hi = 0;  // the look-ahead branch is the critical path: give it the dispatcher's highest priority
     HIPC(hipDeviceGetStreamPriorityRange(&lo, &hi));
     HIPC(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, hi));
   }
+  HIPC(hipStreamCreateWithFlags(&h->stream_d2h, hipStreamNonBlocking));
+  HIPC(hipEventCreateWithFlags(&h->ev_d2h, hipEventDisableTiming));
   {
     int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) h->n_cu = ncu;
@@ -421,35 +473,173 @@ int mik_create(int device, mik_handle** out) {
   if (env && (atoi(env) == 4 || atoi(env) == 8)) h->opt_waves = atoi(env);
   env = getenv("MIK_CHUNK");
   if (env && atol(env) >= 128) h->opt_chunk = (atol(env) / 128) * 128;
+  env = getenv("MIK_EXCHANGE");
+  if (env) h->opt_exchange = !strcmp(env, "rccl") ? 1 : !strcmp(env, "peer") ? 2 : !strcmp(env, "redundant") ? 3 : 0;
+  env = getenv("MIK_ALIAS_DEVICES");
+  if (env) h->alias_ok = atoi(env) != 0;
+  return MIK_OK;
+}
+
+static int create_one(int device, mik_handle** out) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) return fail(MIK_EHIP, "mik_create: no HIP device visible (this library has no CPU path)");
+  if (device < 0 || device >= n) return fail(MIK_EINVAL, "mik_create: device index out of range");
+  mik_handle* h = new mik_handle();
+  const int rc = create_one_body(h, device);
+  if (rc != MIK_OK) {  // a HIP call failed half-way: give back what was created
+    const std::string keep = g_err;
+    destroy_one(h);
+    g_err = keep;
+    return rc;
+  }
+  *out = h;
+  return MIK_OK;
+}
+
+static void destroy_one(mik_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->stream_d2h) (void)hipStreamSynchronize(h->stream_d2h);
+  if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
+  for (ncclComm_t c : h->gcomms)
+    if (c && g_rccl.CommDestroy) g_rccl.CommDestroy(c);
+  DevBuf* bufs[] = {&h->xs, &h->ys, &h->zs, &h->vals, &h->wells, &h->extra_cols, &h->T, &h->cvec, &h->Cold, &h->Cnew,
+                    &h->Rt, &h->TKt, &h->Dinv, &h->DinvT, &h->P0, &h->P1, &h->cand0, &h->cand1, &h->pivall, &h->flag,
+                    &h->Cold2, &h->Cnew2, &h->Rt2, &h->Dinv2, &h->DinvT2, &h->grid.gx, &h->grid.gy, &h->grid.gz, &h->grid.orig,
+                    &h->grid.cstart,
+                    &h->px, &h->py, &h->pz, &h->extra_rows, &h->z, &h->ss, &h->Bt, &h->part, &h->mw_idx, &h->mw_dist, &h->stat_S, &h->stat_x, &h->stat_out, &h->queue};
+  for (DevBuf* b : bufs) b->release();
+  h->pin_in.release();
+  h->pin_out.release();
+  for (hipEvent_t e : h->evpool) (void)hipEventDestroy(e);
+  for (hipEvent_t e : h->la_events) (void)hipEventDestroy(e);
+  for (hipEvent_t e : h->xevents) (void)hipEventDestroy(e);
+  if (h->ev_d2h) (void)hipEventDestroy(h->ev_d2h);
+  if (h->stream_d2h) (void)hipStreamDestroy(h->stream_d2h);
+  if (h->stream2) (void)hipStreamDestroy(h->stream2);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+// Process-wide default for the number of devices a new handle spans (mik_set_devices, or MIK_NGPU in the environment):
+// 1 = the handle's own device only; 0 = every visible device.
+static int g_default_devices = -1;  // -1: not set programmatically, read MIK_NGPU
+static int default_devices() {
+  if (g_default_devices >= 0) return g_default_devices;
+  const char* env = getenv("MIK_NGPU");
+  if (!env || !*env) return 1;
+  if (!strcmp(env, "all")) return 0;
+  return std::max(0, atoi(env));
+}
+
+static void release_group(mik_handle* h) {
+  for (size_t i = 0; i < h->xstreams.size(); ++i) {
+    const int dev = i == 0 ? h->device : h->kids[i - 1]->device;
+    (void)hipSetDevice(dev);
+    for (hipStream_t st : h->xstreams[i])
+      if (st) (void)hipStreamDestroy(st);
+  }
+  h->xstreams.clear();
+  for (ncclComm_t c : h->gcomms)
+    if (c && g_rccl.CommDestroy) g_rccl.CommDestroy(c);
+  h->gcomms.clear();
+  for (mik_handle* k : h->kids) destroy_one(k);
+  h->kids.clear();
+  (void)hipSetDevice(h->device);
+}
+
+static int set_group(mik_handle* h, int n) {
+  if (h->is_kid) return fail(MIK_EINVAL, "mik_handle_set_devices: not on a member of a device group");
+  int visible = 0;
+  if (hipGetDeviceCount(&visible) != hipSuccess || visible <= 0) return fail(MIK_EHIP, "no HIP device visible");
+  if (n == 0) n = visible;
+  if (n < 1 || n > 64) return fail(MIK_EINVAL, "number of devices out of range");
+  if (n > visible && !h->alias_ok)
+    return fail(MIK_EINVAL, "more devices requested than are visible (option alias_devices / MIK_ALIAS_DEVICES=1 lets several "
+                            "logical devices share one GPU -- for tests on a 1-GPU box)");
+  if ((int)h->kids.size() + 1 == n) return MIK_OK;
+  release_group(h);
+  for (int i = 1; i < n; ++i) {
+    mik_handle* k = nullptr;
+    const int rc = create_one((h->device + i) % visible, &k);
+    if (rc != MIK_OK) {
+      const std::string keep = g_err;
+      release_group(h);
+      g_err = keep;
+      return rc;
+    }
+    k->is_kid = true;
+    k->opt_factor = h->opt_factor, k->opt_sym = h->opt_sym, k->opt_engine = h->opt_engine, k->opt_waves = h->opt_waves;
+    k->opt_chunk = h->opt_chunk, k->opt_symsweep = h->opt_symsweep, k->opt_diag = h->opt_diag, k->opt_lookahead = h->opt_lookahead;
+    k->opt_mw_pivot = h->opt_mw_pivot, k->opt_mw_lds_cap = h->opt_mw_lds_cap;
+    k->custom_fn = h->custom_fn, k->custom_user = h->custom_user;
+    h->kids.push_back(k);
+  }
+  // the group's data changed hands: whatever the leader held is stale for the new members
+  h->have_problem = h->have_factor = h->have_points = h->have_results = false;
+  h->t_state = 0;
+  HIPC(hipSetDevice(h->device));
+  return MIK_OK;
+}
+
+int mik_create(int device, mik_handle** out) {
+  if (!out) return fail(MIK_EINVAL, "mik_create: out is NULL");
+  mik_handle* h = nullptr;
+  MIKC(create_one(device, &h));
+  const int want = default_devices();
+  if (want != 1) {
+    int visible = 1;
+    (void)hipGetDeviceCount(&visible);
+    const int rc = set_group(h, want == 0 ? visible : want);
+    if (rc != MIK_OK) {
+      const std::string keep = g_err;
+      destroy_one(h);
+      g_err = keep;
+      return rc;
+    }
+  }
   *out = h;
   return MIK_OK;
 }
 
 void mik_destroy(mik_handle* h) {
   if (!h) return;
-  (void)hipSetDevice(h->device);
-  if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
-  DevBuf* bufs[] = {&h->xs, &h->ys, &h->zs, &h->vals, &h->wells, &h->extra_cols, &h->T, &h->cvec, &h->Cold, &h->Cnew,
-                    &h->Rt, &h->TKt, &h->Dinv, &h->DinvT, &h->P0, &h->P1, &h->cand0, &h->cand1, &h->pivall, &h->flag,
-                    &h->px, &h->py, &h->pz, &h->extra_rows, &h->z, &h->ss, &h->Bt, &h->part, &h->mw_idx, &h->mw_dist, &h->stat_S, &h->stat_x, &h->stat_out, &h->queue};
-  for (DevBuf* b : bufs) b->release();
-  for (hipEvent_t e : h->evpool) (void)hipEventDestroy(e);
-  for (hipEvent_t e : h->la_events) (void)hipEventDestroy(e);
-  if (h->stream2) (void)hipStreamDestroy(h->stream2);
-  if (h->stream) (void)hipStreamDestroy(h->stream);
-  delete h;
+  release_group(h);
+  destroy_one(h);
 }
+
+int mik_set_devices(int n) {
+  if (n < 0 || n > 64) return fail(MIK_EINVAL, "mik_set_devices: n must be 0 (all visible devices) or 1..64");
+  g_default_devices = n;
+  return MIK_OK;
+}
+
+int mik_handle_set_devices(mik_handle* h, int n) {
+  if (!h) return fail(MIK_EINVAL, "mik_handle_set_devices: NULL handle");
+  return set_group(h, n);
+}
+
+int mik_handle_devices(mik_handle* h) { return h ? (int)h->kids.size() + 1 : 0; }
 
 int mik_set_custom_variogram(mik_handle* h, mik_variogram_fn fn, void* user) {
   if (!h) return fail(MIK_EINVAL, "mik_set_custom_variogram: NULL handle");
   h->custom_fn = fn;
   h->custom_user = user;
+  for (mik_handle* k : h->kids) k->custom_fn = fn, k->custom_user = user;
   return MIK_OK;
 }
 
 int mik_set_option(mik_handle* h, const char* key, double value) {
   if (!h || !key) return fail(MIK_EINVAL, "mik_set_option: NULL argument");
-  if (!strcmp(key, "factor")) {
+  for (mik_handle* k : h->kids) MIKC(mik_set_option(k, key, value));
+  if (!strcmp(key, "exchange")) {
+    if (value < 0 || value > 3) return fail(MIK_EINVAL, "exchange must be 0 (auto), 1 (rccl), 2 (peer copies) or 3 (redundant factorisation)");
+    h->opt_exchange = (int)value;
+  } else if (!strcmp(key, "alias_devices")) {
+    h->alias_ok = value != 0.0;
+  } else if (!strcmp(key, "factor")) {
     if (value < 0 || value > 2) return fail(MIK_EINVAL, "factor must be 0 (auto), 1 (sweep) or 2 (pivoted)");
     h->opt_factor = (int)value;
   } else if (!strcmp(key, "symmetric")) {
@@ -482,7 +672,7 @@ int mik_set_option(mik_handle* h, const char* key, double value) {
 
 int64_t mik_matrix_order(mik_handle* h) { return h ? h->M : 0; }
 
-int mik_set_problem(mik_handle* h, const mik_problem* p) {
+static int one_set_problem(mik_handle* h, const mik_problem* p) {
   if (!h || !p) return fail(MIK_EINVAL, "mik_set_problem: NULL argument");
   if (p->ndim != 2 && p->ndim != 3) return fail(MIK_EINVAL, "ndim must be 2 or 3");
   if (p->n < 1 || p->n > 2000000) return fail(MIK_EINVAL, "n out of range");
@@ -575,6 +765,12 @@ int mik_set_problem(mik_handle* h, const mik_problem* p) {
   h->have_factor = false;
   h->t_state = 0;
   h->have_results = false;
+  return MIK_OK;
+}
+
+int mik_set_problem(mik_handle* h, const mik_problem* p) {
+  MIKC(one_set_problem(h, p));
+  for (mik_handle* k : h->kids) MIKC(one_set_problem(k, p));  // a few hundred KB of station data per device
   return MIK_OK;
 }
 
@@ -800,7 +996,7 @@ int mik_assemble_only(mik_handle* h) {
   return MIK_OK;
 }
 
-int mik_factor(mik_handle* h) {
+static int one_factor(mik_handle* h) {
   if (!h || !h->have_problem) return fail(MIK_ESTATE, "mik_factor: no problem set");
   HIPC(hipSetDevice(h->device));
   h->t_state = 0;
@@ -862,6 +1058,203 @@ int mik_factor(mik_handle* h) {
   return fail(MIK_ESINGULAR, "singular matrix");
 }
 
+// ---- device groups (mik_set_devices): one host thread per member for the blocking per-device calls ----------------------
+static mik_handle* member(mik_handle* h, int i) { return i == 0 ? h : h->kids[i - 1]; }
+
+extern "C++" {
+template <class F>
+static int for_each_device(mik_handle* h, F fn) {
+  const size_t n = h->kids.size() + 1;
+  if (n == 1) return fn(0, h);
+  std::vector<int> rc(n, MIK_OK);
+  std::vector<std::string> err(n);
+  std::vector<std::thread> th;
+  th.reserve(n - 1);
+  for (size_t i = 1; i < n; ++i)
+    th.emplace_back([&, i] {
+      g_err.clear();
+      rc[i] = fn((int)i, h->kids[i - 1]);
+      if (rc[i] != MIK_OK) err[i] = g_err;
+    });
+  rc[0] = fn(0, h);
+  if (rc[0] != MIK_OK) err[0] = g_err;
+  for (auto& t : th) t.join();
+  (void)hipSetDevice(h->device);
+  for (size_t i = 0; i < n; ++i)
+    if (rc[i] != MIK_OK) return fail(rc[i], "device " + std::to_string(member(h, (int)i)->device) + " (group member " + std::to_string(i) + "): " + err[i]);
+  return MIK_OK;
+}
+}  // extern "C++"
+
+// RCCL communicators of a single-process device group are cached per device list for the life of the process: creating
+// them (ncclCommInitAll) costs seconds on an 8-GPU node, and every kriging object has its own handle.
+static std::mutex g_group_mutex;
+static std::map<std::vector<int>, std::vector<ncclComm_t>> g_group_comms;
+
+static int group_comms(mik_handle* h, std::vector<ncclComm_t>** out) {
+  const int n = (int)h->kids.size() + 1;
+  std::vector<int> devs(n);
+  for (int i = 0; i < n; ++i) devs[i] = member(h, i)->device;
+  {
+    std::vector<int> sorted = devs;
+    std::sort(sorted.begin(), sorted.end());
+    if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end())
+      return fail(MIK_ERCCL, "RCCL needs one distinct GPU per group member (this group aliases a device)");
+  }
+  auto it = g_group_comms.find(devs);
+  if (it == g_group_comms.end()) {
+    MIKC(rccl_load());
+    if (!g_rccl.CommInitAll || !g_rccl.GroupStart || !g_rccl.GroupEnd) return fail(MIK_ERCCL, "librccl.so lacks ncclCommInitAll / ncclGroupStart / ncclGroupEnd");
+    std::vector<ncclComm_t> comms(n, nullptr);
+    NCCLC(g_rccl.CommInitAll(comms.data(), n, devs.data()));
+    it = g_group_comms.emplace(devs, std::move(comms)).first;
+  }
+  *out = &it->second;
+  return MIK_OK;
+}
+
+// the north_star's exchange: ONE ncclBroadcast of the inverted matrix (and one of c) from the leader to every member, all
+// members' calls fused in a group, each on its own device's stream
+static int exchange_rccl(mik_handle* h) {
+  std::lock_guard<std::mutex> lock(g_group_mutex);
+  std::vector<ncclComm_t>* comms = nullptr;
+  MIKC(group_comms(h, &comms));
+  const int n = (int)h->kids.size() + 1;
+  const size_t Mp = h->Mp;
+  for (int i = 1; i < n; ++i) {
+    HIPC(hipSetDevice(member(h, i)->device));
+    MIKC(ensure_factor_buffers(member(h, i)));
+  }
+  NCCLC(g_rccl.GroupStart());
+  for (int i = 0; i < n; ++i) {
+    mik_handle* d = member(h, i);
+    HIPC(hipSetDevice(d->device));
+    NCCLC(g_rccl.Broadcast(d->T.p, d->T.p, Mp * Mp, ncclDouble, 0, (*comms)[i], d->stream));
+    NCCLC(g_rccl.Broadcast(d->cvec.p, d->cvec.p, Mp, ncclDouble, 0, (*comms)[i], d->stream));
+  }
+  NCCLC(g_rccl.GroupEnd());
+  for (int i = 0; i < n; ++i) {
+    HIPC(hipSetDevice(member(h, i)->device));
+    HIPC(hipStreamSynchronize(member(h, i)->stream));
+  }
+  HIPC(hipSetDevice(h->device));
+  return MIK_OK;
+}
+
+static int copy_between(void* dst, int ddev, const void* src, int sdev, size_t bytes, hipStream_t st) {
+  if (bytes == 0) return MIK_OK;
+  if (ddev == sdev) HIPC(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st));
+  else HIPC(hipMemcpyPeerAsync(dst, ddev, src, sdev, bytes, st));
+  return MIK_OK;
+}
+
+// The exchange without RCCL, shaped for xGMI's full mesh (every GPU has its own link to every other one): the leader
+// SCATTERS the matrix in n-1 pieces, one per member, and every member forwards its piece to the other members
+// (ALL-GATHER) as soon as it has arrived.  Every link carries 1/(n-1) of the matrix in each of the two steps, against the
+// whole matrix on each of the leader's links for a direct fan-out: 3.5x less time on 8 GPUs.
+static int exchange_peer(mik_handle* h) {
+  const int n = (int)h->kids.size() + 1;
+  const size_t Mp = h->Mp, S = Mp * Mp;
+  if (h->xstreams.size() != (size_t)n) {
+    h->xstreams.assign(n, std::vector<hipStream_t>(n, nullptr));
+    for (int i = 0; i < n; ++i) {
+      HIPC(hipSetDevice(member(h, i)->device));
+      for (int k = 0; k < n; ++k) {
+        if (k == i) continue;
+        HIPC(hipStreamCreateWithFlags(&h->xstreams[i][k], hipStreamNonBlocking));
+        const int di = member(h, i)->device, dk = member(h, k)->device;
+        int can = 0;
+        if (di != dk && hipDeviceCanAccessPeer(&can, di, dk) == hipSuccess && can) {
+          (void)hipDeviceEnablePeerAccess(dk, 0);  // "already enabled" is fine; without peer access the copies are staged
+          (void)hipGetLastError();
+        }
+      }
+    }
+    while (h->xevents.size() < (size_t)n) {
+      hipEvent_t e;
+      HIPC(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      h->xevents.push_back(e);
+    }
+  }
+  for (int i = 1; i < n; ++i) {
+    HIPC(hipSetDevice(member(h, i)->device));
+    MIKC(ensure_factor_buffers(member(h, i)));
+  }
+  const size_t pieces = (size_t)(n - 1);
+  const size_t per = ((S + pieces - 1) / pieces + 511) / 512 * 512;
+  auto piece = [&](int j, size_t* off, size_t* len) {
+    *off = std::min(S, (size_t)(j - 1) * per);
+    *len = std::min(per, S - *off);
+  };
+  const int d0 = h->device;
+  HIPC(hipSetDevice(d0));
+  for (int j = 1; j < n; ++j) {  // scatter (and c, which is small, to everybody directly)
+    mik_handle* dj = member(h, j);
+    size_t off, len;
+    piece(j, &off, &len);
+    hipStream_t st = h->xstreams[0][j];
+    MIKC(copy_between(dj->T.as<double>() + off, dj->device, h->T.as<double>() + off, d0, sizeof(double) * len, st));
+    MIKC(copy_between(dj->cvec.p, dj->device, h->cvec.p, d0, sizeof(double) * Mp, st));
+    HIPC(hipEventRecord(h->xevents[j], st));
+  }
+  for (int j = 1; j < n; ++j) {  // all-gather among the members
+    mik_handle* dj = member(h, j);
+    size_t off, len;
+    piece(j, &off, &len);
+    HIPC(hipSetDevice(dj->device));
+    for (int k = 1; k < n; ++k) {
+      if (k == j) continue;
+      mik_handle* dk = member(h, k);
+      hipStream_t st = h->xstreams[j][k];
+      HIPC(hipStreamWaitEvent(st, h->xevents[j], 0));
+      MIKC(copy_between(dk->T.as<double>() + off, dk->device, dj->T.as<double>() + off, dj->device, sizeof(double) * len, st));
+    }
+  }
+  for (int i = 0; i < n; ++i) {
+    HIPC(hipSetDevice(member(h, i)->device));
+    for (int k = 0; k < n; ++k)
+      if (h->xstreams[i][k]) HIPC(hipStreamSynchronize(h->xstreams[i][k]));
+  }
+  HIPC(hipSetDevice(h->device));
+  return MIK_OK;
+}
+
+int mik_factor(mik_handle* h) {
+  if (!h) return fail(MIK_ESTATE, "mik_factor: NULL handle");
+  h->exchange_used = 0;
+  h->exchange_ms = 0.0;
+  h->exchange_note.clear();
+  if (h->kids.empty()) return one_factor(h);
+  for (mik_handle* k : h->kids) k->have_factor = false;
+  if (h->opt_exchange == 3) {  // no exchange at all: every member assembles and inverts the (identical) matrix itself
+    h->exchange_used = 3;
+    return for_each_device(h, [](int, mik_handle* d) { return one_factor(d); });
+  }
+  MIKC(one_factor(h));
+  const auto t0 = std::chrono::steady_clock::now();
+  int used = 0;
+  if (h->opt_exchange == 0 || h->opt_exchange == 1) {
+    const int rc = exchange_rccl(h);
+    if (rc == MIK_OK) used = 1;
+    else if (h->opt_exchange == 1) return rc;
+    else h->exchange_note = "rccl unavailable (" + g_err + "); peer copies used";
+  }
+  if (!used) {
+    MIKC(exchange_peer(h));
+    used = 2;
+  }
+  h->exchange_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  h->exchange_used = used;
+  for (mik_handle* k : h->kids) {
+    k->have_factor = true;
+    k->t_state = 2;
+    k->have_results = false;
+    k->tm.factor_path = h->tm.factor_path;
+    k->tm.assemble_ms = k->tm.invert_ms = 0.0;
+  }
+  return MIK_OK;
+}
+
 int mik_get_matrix(mik_handle* h, int which, double* out) {
   if (!h || !out) return fail(MIK_EINVAL, "mik_get_matrix: NULL argument");
   if (!h->T.p) return fail(MIK_ESTATE, "mik_get_matrix: nothing assembled");
@@ -872,61 +1265,89 @@ int mik_get_matrix(mik_handle* h, int which, double* out) {
   return MIK_OK;
 }
 
-int mik_set_points(mik_handle* h, const mik_points* g) {
-  if (!h || !g) return fail(MIK_EINVAL, "mik_set_points: NULL argument");
-  if (!h->have_problem) return fail(MIK_ESTATE, "mik_set_points: set the problem first");
-  if (g->npt < 0) return fail(MIK_EINVAL, "npt < 0");
-  if (g->npt > 0 && (!g->px || !g->py || (h->ndim == 3 && !g->pz))) return fail(MIK_EINVAL, "point arrays missing");
-  if (h->nextra > 0 && g->npt > 0 && !g->extra_rows) return fail(MIK_EINVAL, "extra_rows missing for host-evaluated drifts");
+// Upload points [lo, lo + n) of the sequence of unmasked points to ONE device.  idx == nullptr: that sequence is the caller's
+// arrays themselves; otherwise idx[i] is the position of the i-th unmasked point in them (np.nonzero(~mask), ok.py:700).
+// The coordinates are staged through page-locked memory: the host copy (or mask compaction) of one coordinate overlaps the
+// DMA of the previous one.
+static int one_set_points(mik_handle* h, const mik_points* g, const long* idx, long lo, long n) {
   HIPC(hipSetDevice(h->device));
-  h->npt_total = g->npt;
-  h->scatter.clear();
-  const double* src[3] = {g->px, g->py, g->pz};
-  std::vector<double> tmp;
-  long n = g->npt;
-  if (g->mask) {  // np.nonzero(~mask) (ok.py:700) / `if mask[i]: continue` (cok.pyx:57-58)
-    for (long i = 0; i < g->npt; ++i)
-      if (!g->mask[i]) h->scatter.push_back(i);
-    n = (long)h->scatter.size();
-    if (n == g->npt) h->scatter.clear();
-  }
+  HIPC(hipStreamSynchronize(h->stream_d2h));  // result copies of an earlier predict still read z / ss
   h->npt = n;
+  h->out_off = lo;
+  if (idx) h->scatter.assign(idx + lo, idx + lo + n);
+  else h->scatter.clear();
+  const long cap = std::max<long>(n, 1);
+  const int rows = h->ndim + h->nextra;
+  MIKC(h->pin_in.ensure(sizeof(double) * (size_t)cap * rows));
+  const double* src[3] = {g->px, g->py, g->pz};
   DevBuf* dst[3] = {&h->px, &h->py, &h->pz};
-  for (int d = 0; d < h->ndim; ++d) {
-    MIKC(dst[d]->ensure(sizeof(double) * std::max<long>(n, 1)));
-    if (n == 0) continue;
-    if (h->scatter.empty()) {
-      HIPC(hipMemcpyAsync(dst[d]->p, src[d], sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+  if (h->nextra) MIKC(h->extra_rows.ensure(sizeof(double) * (size_t)cap * h->nextra));
+  for (int r = 0; r < rows; ++r) {
+    const double* from = r < h->ndim ? src[r] : g->extra_rows + (size_t)(r - h->ndim) * g->npt;
+    double* stage = h->pin_in.as<double>() + (size_t)r * cap;
+    double* to;
+    if (r < h->ndim) {
+      MIKC(dst[r]->ensure(sizeof(double) * cap));
+      to = dst[r]->as<double>();
     } else {
-      tmp.resize(n);
-      for (long i = 0; i < n; ++i) tmp[i] = src[d][h->scatter[i]];
-      HIPC(hipMemcpyAsync(dst[d]->p, tmp.data(), sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
-      HIPC(hipStreamSynchronize(h->stream));
+      to = h->extra_rows.as<double>() + (size_t)(r - h->ndim) * n;
     }
-  }
-  if (h->nextra && n > 0) {
-    MIKC(h->extra_rows.ensure(sizeof(double) * n * h->nextra));
-    for (int k = 0; k < h->nextra; ++k) {
-      const double* row = g->extra_rows + (size_t)k * g->npt;
-      if (h->scatter.empty()) {
-        HIPC(hipMemcpyAsync(h->extra_rows.as<double>() + (size_t)k * n, row, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
-      } else {
-        tmp.resize(n);
-        for (long i = 0; i < n; ++i) tmp[i] = row[h->scatter[i]];
-        HIPC(hipMemcpyAsync(h->extra_rows.as<double>() + (size_t)k * n, tmp.data(), sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
-        HIPC(hipStreamSynchronize(h->stream));
-      }
+    if (n == 0) continue;
+    if (idx) {
+      const long* ix = idx + lo;
+      for (long i = 0; i < n; ++i) stage[i] = from[ix[i]];
+    } else {
+      memcpy(stage, from + lo, sizeof(double) * n);
     }
+    HIPC(hipMemcpyAsync(to, stage, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
   }
-  MIKC(h->z.ensure(sizeof(double) * std::max<long>(n, 1)));
-  MIKC(h->ss.ensure(sizeof(double) * std::max<long>(n, 1)));
+  MIKC(h->z.ensure(sizeof(double) * cap));
+  MIKC(h->ss.ensure(sizeof(double) * cap));
+  MIKC(h->pin_out.ensure(sizeof(double) * 2 * (size_t)cap));
   HIPC(hipStreamSynchronize(h->stream));
   h->have_points = true;
   h->have_results = false;
   return MIK_OK;
 }
 
-int mik_predict(mik_handle* h) {
+// contiguous slabs of the n unmasked points, one per group member, cut at multiples of 128 points (the contraction's tile)
+static void slab_of(long n, int members, int i, long* lo, long* cnt) {
+  auto cut = [&](int k) {
+    if (k >= members) return n;
+    const long c = (long)((double)n * k / members);
+    return std::min(n, (c / 128) * 128);
+  };
+  *lo = cut(i);
+  *cnt = cut(i + 1) - *lo;
+}
+
+int mik_set_points(mik_handle* h, const mik_points* g) {
+  if (!h || !g) return fail(MIK_EINVAL, "mik_set_points: NULL argument");
+  if (!h->have_problem) return fail(MIK_ESTATE, "mik_set_points: set the problem first");
+  if (g->npt < 0) return fail(MIK_EINVAL, "npt < 0");
+  if (g->npt > 0 && (!g->px || !g->py || (h->ndim == 3 && !g->pz))) return fail(MIK_EINVAL, "point arrays missing");
+  if (h->nextra > 0 && g->npt > 0 && !g->extra_rows) return fail(MIK_EINVAL, "extra_rows missing for host-evaluated drifts");
+  h->npt_total = g->npt;
+  std::vector<long> idx;
+  long n = g->npt;
+  h->masked = false;
+  if (g->mask) {  // np.nonzero(~mask) (ok.py:700) / `if mask[i]: continue` (cok.pyx:57-58)
+    idx.reserve(g->npt);
+    for (long i = 0; i < g->npt; ++i)
+      if (!g->mask[i]) idx.push_back(i);
+    n = (long)idx.size();
+    h->masked = n != g->npt;
+  }
+  const long* ip = h->masked ? idx.data() : nullptr;
+  const int members = (int)h->kids.size() + 1;
+  return for_each_device(h, [&](int i, mik_handle* d) {
+    long lo, cnt;
+    slab_of(n, members, i, &lo, &cnt);
+    return one_set_points(d, g, ip, lo, cnt);
+  });
+}
+
+static int one_predict(mik_handle* h) {
   if (!h || !h->have_factor) return fail(MIK_ESTATE, "mik_predict: factor first");
   if (!h->have_points) return fail(MIK_ESTATE, "mik_predict: set points first");
   HIPC(hipSetDevice(h->device));
@@ -950,8 +1371,9 @@ int mik_predict(mik_handle* h) {
   MIKC(h->Bt.ensure(sizeof(double) * (size_t)chunk * Mp));
   MIKC(h->part.ensure(sizeof(double) * (size_t)chunk * nIblk));
   const long nchunks = (npt + chunk - 1) / chunk;
-  MIKC(get_events(h, 2 + 3 * (size_t)nchunks));
+  MIKC(get_events(h, 2 + 4 * (size_t)nchunks));
   const int kend = ((h->M + MIK_BK - 1) / MIK_BK) * MIK_BK;
+  HIPC(hipStreamWaitEvent(h->stream, h->ev_d2h, 0));  // an earlier predict's result copies still read z / ss
   HIPC(hipEventRecord(h->evpool[0], h->stream));
   for (long c = 0; c < nchunks; ++c) {
     const long t0 = c * chunk;
@@ -984,7 +1406,7 @@ int mik_predict(mik_handle* h) {
     a.extra_stride = npt;
     a.cvec = h->cvec.as<double>();
     a.zout = h->z.as<double>() + t0;
-    hipEvent_t e0 = h->evpool[2 + 3 * c], e1 = h->evpool[3 + 3 * c], e2 = h->evpool[4 + 3 * c];
+    hipEvent_t e0 = h->evpool[2 + 4 * c], e1 = h->evpool[3 + 4 * c], e2 = h->evpool[4 + 4 * c], e3 = h->evpool[5 + 4 * c];
     HIPC(hipEventRecord(e0, h->stream));
     if (h->model == MIK_MODEL_CUSTOM) {
       DISPATCH_NDIM_FIXED(7, h->geo ? 1 : h->ndim, k_rhs, dim3(palloc / MIK_TP), dim3(256), h->stream, a);
@@ -1023,6 +1445,13 @@ int mik_predict(mik_handle* h) {
     HIPC(hipEventRecord(e2, h->stream));
     hipLaunchKernelGGL(k_ss_reduce, dim3((nvalid + 255) / 256), dim3(256), 0, h->stream, (const double*)h->part.as<double>(),
                        palloc, nIblk, nvalid, h->ss.as<double>() + t0);
+    // this chunk's z and sigma^2 leave for the page-locked landing zone while the next chunk is computed
+    HIPC(hipEventRecord(e3, h->stream));
+    HIPC(hipStreamWaitEvent(h->stream_d2h, e3, 0));
+    HIPC(hipMemcpyAsync(h->pin_out.as<double>() + t0, h->z.as<double>() + t0, sizeof(double) * nvalid, hipMemcpyDeviceToHost,
+                        h->stream_d2h));
+    HIPC(hipMemcpyAsync(h->pin_out.as<double>() + npt + t0, h->ss.as<double>() + t0, sizeof(double) * nvalid,
+                        hipMemcpyDeviceToHost, h->stream_d2h));
     // executed flops of this launch: per tile 2*128*128*(k extent)
     double kext = 0.0;
     for (int ib = 0; ib < nIblk; ++ib) kext += h->opt_sym ? std::max(0, kend - ib * 128) : kend;
@@ -1030,14 +1459,15 @@ int mik_predict(mik_handle* h) {
   }
   HIPC(hipGetLastError());
   HIPC(hipEventRecord(h->evpool[1], h->stream));
+  HIPC(hipEventRecord(h->ev_d2h, h->stream_d2h));
   HIPC(hipStreamSynchronize(h->stream));
   float ms = 0.f;
   HIPC(hipEventElapsedTime(&ms, h->evpool[0], h->evpool[1]));
   h->tm.predict_ms = ms;
   for (long c = 0; c < nchunks; ++c) {
-    HIPC(hipEventElapsedTime(&ms, h->evpool[2 + 3 * c], h->evpool[3 + 3 * c]));
+    HIPC(hipEventElapsedTime(&ms, h->evpool[2 + 4 * c], h->evpool[3 + 4 * c]));
     h->tm.rhs_ms += ms;
-    HIPC(hipEventElapsedTime(&ms, h->evpool[3 + 3 * c], h->evpool[4 + 3 * c]));
+    HIPC(hipEventElapsedTime(&ms, h->evpool[3 + 4 * c], h->evpool[4 + 4 * c]));
     h->tm.contract_ms += ms;
   }
   h->tm.contract_launches = nchunks;
@@ -1045,8 +1475,13 @@ int mik_predict(mik_handle* h) {
   return MIK_OK;
 }
 
+int mik_predict(mik_handle* h) {
+  if (!h) return fail(MIK_ESTATE, "mik_predict: NULL handle");
+  return for_each_device(h, [](int, mik_handle* d) { return one_predict(d); });
+}
 
-int mik_predict_moving_window(mik_handle* h, int n_closest) {
+
+static int one_predict_mw(mik_handle* h, int n_closest) {
   if (!h || !h->have_problem) return fail(MIK_ESTATE, "mik_predict_moving_window: set the problem first");
   if (!h->have_points) return fail(MIK_ESTATE, "mik_predict_moving_window: set points first");
   if (h->p != 0) return fail(MIK_EINVAL, "moving-window kriging exists for ordinary kriging only (ok.py:929, ok3d.py:901)");
@@ -1056,6 +1491,7 @@ int mik_predict_moving_window(mik_handle* h, int n_closest) {
   MIKC(get_events(h, 2));
   const long npt = h->npt;
   const int K = n_closest;
+  long solve_chunks = 0;
   h->tm.rhs_ms = h->tm.contract_ms = h->tm.predict_ms = 0.0;
   h->tm.contract_launches = 0;
   h->tm.contract_flops_executed = 0.0;
@@ -1063,6 +1499,7 @@ int mik_predict_moving_window(mik_handle* h, int n_closest) {
     h->have_results = true;
     return MIK_OK;
   }
+  HIPC(hipStreamWaitEvent(h->stream, h->ev_d2h, 0));
   HIPC(hipEventRecord(h->evpool[0], h->stream));
   // The reference cuts each point's system out of a_all = self._get_kriging_matrix(n); here its entries are computed
   // from the selected stations' coordinates, so no N x N matrix exists on this path (and a factor held by the handle
@@ -1134,6 +1571,7 @@ int mik_predict_moving_window(mik_handle* h, int n_closest) {
     sgrid = (int)g;
     MIKC(sysbuf.ensure((size_t)per * (size_t)sgrid));
   }
+  MIKC(get_events(h, 2 + 2 * (size_t)((npt + chunk - 1) / chunk)));
   for (long p0 = 0; p0 < npt; p0 += chunk) {
     const long pc = (npt - p0 < chunk) ? npt - p0 : chunk;
     const unsigned kgrid = (unsigned)((pc + 255) / 256);
@@ -1218,6 +1656,7 @@ int mik_predict_moving_window(mik_handle* h, int n_closest) {
         default: hipLaunchKernelGGL(k_mw_rhs<5>, dim3(rg), dim3(256), 0, h->stream, dist, ne, h->v, h->exact, h->eps); break;
       }
     }
+    HIPC(hipEventRecord(h->evpool[2 + 2 * solve_chunks], h->stream));
     if (big) {
       const size_t lds = sizeof(double) * 2 * (size_t)nb + sizeof(int) * (size_t)nb;
       if (lds > 150 * 1024) return fail(MIK_EINVAL, "n_closest_points too large for the device path (> ~7600)");
@@ -1227,6 +1666,8 @@ int mik_predict_moving_window(mik_handle* h, int n_closest) {
     } else {
       MIKC(dispatch_mw_solve(h, a, pc, mw_piv));
     }
+    HIPC(hipEventRecord(h->evpool[3 + 2 * solve_chunks], h->stream));
+    ++solve_chunks;
     HIPC(hipGetLastError());
   }
   int flag = 0;
@@ -1236,15 +1677,29 @@ int mik_predict_moving_window(mik_handle* h, int n_closest) {
   float ms = 0.f;
   HIPC(hipEventElapsedTime(&ms, h->evpool[0], h->evpool[1]));
   h->tm.predict_ms = ms;
+  for (long c = 0; c < solve_chunks; ++c) {  // the per-point solves (the dominant kernel of this path) on their own
+    HIPC(hipEventElapsedTime(&ms, h->evpool[2 + 2 * c], h->evpool[3 + 2 * c]));
+    h->tm.contract_ms += ms;
+  }
+  h->tm.contract_launches = solve_chunks;
+  h->tm.rhs_ms = h->tm.predict_ms - h->tm.contract_ms;  // neighbour search + right-hand sides
   if ((flag & 2) && !mw_piv) {  // a local system was not positive definite after the shift: redo with partial pivoting
     h->mw_force_piv = true;
-    const int rc = mik_predict_moving_window(h, n_closest);
+    const int rc = one_predict_mw(h, n_closest);
     h->mw_force_piv = false;
     return rc;
   }
   if (flag) return fail(MIK_ESINGULAR, "Singular matrix");  // cok.pyx:176-177
+  HIPC(hipMemcpyAsync(h->pin_out.as<double>(), h->z.p, sizeof(double) * npt, hipMemcpyDeviceToHost, h->stream_d2h));
+  HIPC(hipMemcpyAsync(h->pin_out.as<double>() + npt, h->ss.p, sizeof(double) * npt, hipMemcpyDeviceToHost, h->stream_d2h));
+  HIPC(hipEventRecord(h->ev_d2h, h->stream_d2h));
   h->have_results = true;
   return MIK_OK;
+}
+
+int mik_predict_moving_window(mik_handle* h, int n_closest) {
+  if (!h) return fail(MIK_ESTATE, "mik_predict_moving_window: NULL handle");
+  return for_each_device(h, [n_closest](int, mik_handle* d) { return one_predict_mw(d, n_closest); });
 }
 
 int mik_statistics(mik_handle* h, double* k_out, double* ss_out) {
@@ -1366,39 +1821,67 @@ int mik_experimental_variogram(mik_handle* h, int nlags, double* lags_out, doubl
 
 int mik_synchronize(mik_handle* h) {
   if (!h) return fail(MIK_EINVAL, "mik_synchronize: NULL handle");
+  for (int i = 0; i <= (int)h->kids.size(); ++i) {
+    mik_handle* d = member(h, i);
+    HIPC(hipSetDevice(d->device));
+    HIPC(hipStreamSynchronize(d->stream));
+    HIPC(hipStreamSynchronize(d->stream_d2h));
+  }
   HIPC(hipSetDevice(h->device));
-  HIPC(hipStreamSynchronize(h->stream));
+  return MIK_OK;
+}
+
+// z and sigma^2 of one device's slab, from its page-locked landing zone (filled chunk by chunk while mik_predict ran) into
+// the caller's arrays at the slab's place
+static int one_get_results(mik_handle* h, double* z_out, double* ss_out) {
+  if (!h->have_results) return fail(MIK_ESTATE, "mik_get_results: predict first");
+  HIPC(hipSetDevice(h->device));
+  HIPC(hipEventSynchronize(h->ev_d2h));
+  const long n = h->npt;
+  const double* hz = h->pin_out.as<double>();
+  const double* hs = hz + n;
+  if (n == 0) return MIK_OK;
+  if (h->scatter.empty()) {
+    memcpy(z_out + h->out_off, hz, sizeof(double) * n);
+    memcpy(ss_out + h->out_off, hs, sizeof(double) * n);
+    return MIK_OK;
+  }
+  const long* ix = h->scatter.data();
+  for (long i = 0; i < n; ++i) {
+    z_out[ix[i]] = hz[i];
+    ss_out[ix[i]] = hs[i];
+  }
   return MIK_OK;
 }
 
 int mik_get_results(mik_handle* h, double* z_out, double* ss_out) {
   if (!h || !z_out || !ss_out) return fail(MIK_EINVAL, "mik_get_results: NULL argument");
   if (!h->have_results) return fail(MIK_ESTATE, "mik_get_results: predict first");
-  HIPC(hipSetDevice(h->device));
-  const long n = h->npt;
-  if (h->scatter.empty() && n == h->npt_total) {
-    if (n) {
-      HIPC(hipMemcpy(z_out, h->z.p, sizeof(double) * n, hipMemcpyDeviceToHost));
-      HIPC(hipMemcpy(ss_out, h->ss.p, sizeof(double) * n, hipMemcpyDeviceToHost));
-    }
-    return MIK_OK;
+  if (h->masked) {  // masked points keep 0.0 (cok.pyx:25-26)
+    memset(z_out, 0, sizeof(double) * h->npt_total);
+    memset(ss_out, 0, sizeof(double) * h->npt_total);
   }
-  std::vector<double> tz(n), ts(n);
-  if (n) {
-    HIPC(hipMemcpy(tz.data(), h->z.p, sizeof(double) * n, hipMemcpyDeviceToHost));
-    HIPC(hipMemcpy(ts.data(), h->ss.p, sizeof(double) * n, hipMemcpyDeviceToHost));
-  }
-  for (long i = 0; i < h->npt_total; ++i) z_out[i] = ss_out[i] = 0.0;  // cok.pyx:25-26
-  for (long i = 0; i < n; ++i) {
-    z_out[h->scatter[i]] = tz[i];
-    ss_out[h->scatter[i]] = ts[i];
-  }
-  return MIK_OK;
+  return for_each_device(h, [=](int, mik_handle* d) { return one_get_results(d, z_out, ss_out); });
 }
 
 int mik_get_timing(mik_handle* h, mik_timing* out) {
   if (!h || !out) return fail(MIK_EINVAL, "mik_get_timing: NULL argument");
   *out = h->tm;
+  out->n_devices = (int)h->kids.size() + 1;
+  out->exchange_path = h->exchange_used;
+  out->exchange_ms = h->exchange_ms;
+  for (mik_handle* k : h->kids) out->predict_ms = std::max(out->predict_ms, k->tm.predict_ms);  // the group's predict = its slowest member
+  return MIK_OK;
+}
+
+int mik_get_device_timing(mik_handle* h, int member_index, mik_timing* out) {
+  if (!h || !out) return fail(MIK_EINVAL, "mik_get_device_timing: NULL argument");
+  if (member_index < 0 || member_index > (int)h->kids.size()) return fail(MIK_EINVAL, "mik_get_device_timing: no such group member");
+  *out = member(h, member_index)->tm;
+  out->n_devices = (int)h->kids.size() + 1;
+  out->exchange_path = h->exchange_used;
+  out->exchange_ms = h->exchange_ms;
+  out->reserved = member(h, member_index)->device;
   return MIK_OK;
 }
 
@@ -1463,6 +1946,7 @@ int mik_comm_unique_id(char id_out[128]) {
 
 int mik_comm_init(mik_handle* h, int nranks, int rank, const char id[128]) {
   if (!h || !id || nranks < 1 || rank < 0 || rank >= nranks) return fail(MIK_EINVAL, "mik_comm_init: bad argument");
+  if (!h->kids.empty()) return fail(MIK_EINVAL, "mik_comm_init: this handle already spans several devices (mik_set_devices); use one or the other");
   MIKC(rccl_load());
   HIPC(hipSetDevice(h->device));
   ncclUniqueId uid;

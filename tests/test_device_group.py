@@ -1,0 +1,158 @@
+"""Single-process multi-GPU: a handle that spans several devices (include/mikrige.h: mik_set_devices,
+mik_handle_set_devices) must return, bit for bit, what one device returns -- the points are only cut into slabs, the
+inverted matrix only copied.  On a 1-GPU box the group ALIASES devices (several members on the one GPU, own streams, own
+buffers, own host threads), which exercises everything except the physical links."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import _fixtures as fx
+
+
+def _lib():
+    from pykrige_amd import _lib
+
+    return _lib
+
+
+def test_set_devices_argument_checks_need_no_gpu():
+    lib = _lib()
+    with pytest.raises(ValueError):
+        lib.set_devices(-1)
+    with pytest.raises(ValueError):
+        lib.set_devices(65)
+    lib.set_devices(2)  # only stored: it applies to handles created afterwards
+    lib.set_devices(1)
+
+
+def _problem(n=700, ndim=2, seed=11, model="exponential", params=(0.9, 0.3, 0.1)):
+    c, v = fx.synth(seed, n, ndim)
+    return c, v, model, list(params)
+
+
+def _run(h, c, v, model, params, pts, mask=None, window=None, rl=False):
+    lib = _lib()
+    ndim = len(c)
+    h.set_problem(ndim=ndim, xs=c[0], ys=c[1], zs=c[2] if ndim == 3 else None, values=v, model_id=lib.MODEL_IDS[model],
+                  params=params, regional_linear=rl)
+    h.set_points(pts[0], pts[1], pts[2] if ndim == 3 else None, mask=mask)
+    if window:
+        h.predict_moving_window(window)
+    else:
+        h.factor()
+        h.predict()
+    return h.get_results()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("members", [2, 3])
+@pytest.mark.parametrize("exchange", ["auto", "peer", "redundant"])
+def test_group_matches_one_device_bit_for_bit(members, exchange):
+    lib = _lib()
+    c, v, model, params = _problem()
+    rng = np.random.default_rng(3)
+    pts = [rng.random(5000), rng.random(5000)]
+    h1 = lib.Handle(0)
+    h1.set_option("chunk", 1024)  # several chunks per device: the overlapped result copies are part of the test
+    z1, s1 = _run(h1, c, v, model, params, pts)
+    hg = lib.Handle(0)
+    hg.set_devices(members, alias=True)
+    assert hg.n_devices == members
+    hg.set_option("chunk", 1024)
+    hg.set_option("exchange", {"auto": 0, "peer": 2, "redundant": 3}[exchange])
+    zg, sg = _run(hg, c, v, model, params, pts)
+    assert np.array_equal(z1, zg) and np.array_equal(s1, sg)
+    t = hg.timing()
+    assert t["n_devices"] == members
+    ndev = lib.load().mik_device_count()
+    want = {"peer": 2, "redundant": 3, "auto": 1 if ndev >= members else 2}[exchange]  # aliased devices: RCCL refuses, peer copies
+    assert t["exchange_path"] == want
+    for i in range(members):
+        assert hg.device_timing(i)["predict_ms"] > 0.0
+    # a second pass on the same handle (buffers, streams and events reused)
+    zg2, sg2 = _run(hg, c, v, model, params, pts)
+    assert np.array_equal(z1, zg2) and np.array_equal(s1, sg2)
+    h1.close()
+    hg.close()
+
+
+@pytest.mark.gpu
+def test_group_with_mask_drift_3d_and_moving_window():
+    lib = _lib()
+    rng = np.random.default_rng(4)
+    # masked points + regional-linear drift, 2-D
+    c, v, model, params = _problem(n=400, seed=12)
+    pts = [rng.random(3001), rng.random(3001)]
+    mask = rng.random(3001) < 0.4
+    h1, hg = lib.Handle(0), lib.Handle(0)
+    hg.set_devices(4, alias=True)
+    a = _run(h1, c, v, model, params, pts, mask=mask, rl=True)
+    b = _run(hg, c, v, model, params, pts, mask=mask, rl=True)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert np.all(b[0][mask] == 0.0) and np.all(b[1][mask] == 0.0) and np.all(b[1][~mask] != 0.0)
+    # 3-D, gaussian with nugget
+    c3, v3, _, _ = _problem(n=300, ndim=3, seed=13)
+    p3 = [rng.random(2000), rng.random(2000), rng.random(2000)]
+    a = _run(h1, c3, v3, "gaussian", [0.98, 0.4, 0.02], p3)
+    b = _run(hg, c3, v3, "gaussian", [0.98, 0.4, 0.02], p3)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    # moving window: no factor, no exchange at all
+    a = _run(h1, c, v, model, params, pts, window=12)
+    b = _run(hg, c, v, model, params, pts, window=12)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    # fewer points than members: empty slabs are fine
+    few = [np.array([0.25, 0.75]), np.array([0.5, 0.5])]
+    a = _run(h1, c, v, model, params, few)
+    b = _run(hg, c, v, model, params, few)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    h1.close()
+    hg.close()
+
+
+@pytest.mark.gpu
+def test_group_errors_are_reported_not_hung():
+    lib = _lib()
+    h = lib.Handle(0)
+    ndev = lib.load().mik_device_count()
+    with pytest.raises(ValueError, match="more devices requested"):
+        h.set_devices(ndev + 1)  # without the alias option
+    h.set_devices(2, alias=True)
+    # duplicated stations make the matrix singular: the leader's factorisation fails, nobody waits for an exchange
+    x = np.array([0.0, 0.0, 1.0, 0.3])
+    y = np.array([0.0, 0.0, 0.0, 0.8])
+    for exchange in (0, 3):
+        h.set_option("exchange", exchange)
+        h.set_problem(ndim=2, xs=x, ys=y, zs=None, values=np.array([1.0, 3.0, 6.0, 2.0]), model_id=lib.MODEL_IDS["linear"],
+                      params=[1.0, 0.0])
+        with pytest.raises(np.linalg.LinAlgError):
+            h.factor()
+    if ndev < 2:  # RCCL demanded on an aliased group: a clean error
+        h.set_option("exchange", 1)
+        c, v, model, params = _problem(n=200)
+        h.set_problem(ndim=2, xs=c[0], ys=c[1], zs=None, values=v, model_id=lib.MODEL_IDS[model], params=params)
+        with pytest.raises(RuntimeError, match="distinct GPU"):
+            h.factor()
+    h.close()
+
+
+@pytest.mark.gpu
+def test_execute_scales_without_a_script_change():
+    """The drop-in surface: pykrige_amd.set_devices(n) (or MIK_NGPU=n in the environment) and a plain
+    OrdinaryKriging.execute() (ok.py:760-768) runs on n devices."""
+    import pykrige_amd as pa
+
+    g = fx.load("ok2d_n2000")
+    ok1 = pa.OrdinaryKriging(g["x"], g["y"], g["v"], variogram_model="exponential", variogram_parameters=[1.0, 0.3, 0.0])
+    z1, s1 = ok1.execute("grid", g["gridx"], g["gridy"], backend="loop")
+    os.environ["MIK_ALIAS_DEVICES"] = "1"
+    try:
+        pa.set_devices(3)
+        ok3 = pa.OrdinaryKriging(g["x"], g["y"], g["v"], variogram_model="exponential", variogram_parameters=[1.0, 0.3, 0.0])
+        z3, s3 = ok3.execute("grid", g["gridx"], g["gridy"], backend="loop")
+        assert ok3._get_handle().n_devices == 3 and ok3.last_timing["n_devices"] == 3
+    finally:
+        pa.set_devices(1)
+        del os.environ["MIK_ALIAS_DEVICES"]
+    assert np.array_equal(z1, z3) and np.array_equal(s1, s3)
+    assert np.abs(z3 - g["z"]).max() <= 1e-8 and np.abs(s3 - g["ss"]).max() <= 1e-6  # and it is the reference's answer

@@ -92,7 +92,7 @@ def _worker(rank, world, port, q):
         x, y, v = rng.random(60), rng.random(60), rng.random(60)
         ok = pa.OrdinaryKriging(x, y, v, variogram_model="exponential", variogram_parameters=[1.0, 0.3, 0.01])
         hdl = OracleHandle()
-        ex = ShardedExecutor(ok, handle_factory=lambda: hdl)
+        ex = ShardedExecutor(ok, group=dist.group.WORLD, handle_factory=lambda: hdl)  # a torch group is accepted when passed
         assert ex.exchange.startswith("redundant_factor"), ex.exchange  # RCCL init failed on every rank -> fallback
         gx, gy = np.linspace(0, 1, 13), np.linspace(0, 1, 9)
         z, ss = ex.execute("grid", gx, gy, backend="loop")
@@ -220,3 +220,148 @@ def test_socket_group_with_eight_ranks():
         p.join(60)
         assert p.exitcode == 0
     assert [o[0] for o in out] == list(range(8)) and all(o[1] for o in out)
+
+
+class RcclStandInHandle(OracleHandle):
+    """A stand-in whose communicator comes up: drives ShardedExecutor's rccl_bcast control flow on CPU.  The 'broadcast' is
+    checked for its protocol: only rank 0 factors, every rank calls bcast_factor exactly once per execute, and nobody
+    enters it when rank 0's factorisation failed."""
+
+    def __init__(self, rank, fail_factor=False):
+        super().__init__()
+        self.rank, self.fail_factor = rank, fail_factor
+
+    def comm_init(self, world, rank, uid):
+        assert len(uid) == 128 and rank == self.rank
+        self.calls.append("comm_init")
+
+    def factor(self):
+        if self.fail_factor:
+            raise np.linalg.LinAlgError("singular matrix")
+        super().factor()
+
+    def bcast_factor(self, root):
+        assert root == 0
+        self.calls.append("bcast_factor")
+
+
+def _rccl_flow_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import pykrige_amd as pa
+    from oracle import kriging_oracle as ko
+    from pykrige_amd import _lib
+    from pykrige_amd.dist import ShardedExecutor, SocketGroup
+
+    _lib.Handle.comm_unique_id = staticmethod(lambda: bytes(range(128)))  # no RCCL on a CPU box: a fixed id
+    pg = SocketGroup(rank=rank, world=world, addr="127.0.0.1", port=port, token="job-1")
+    try:
+        rng = np.random.default_rng(7)
+        x, y, v = rng.random(40), rng.random(40), rng.random(40)
+        ok = pa.OrdinaryKriging(x, y, v, variogram_model="exponential", variogram_parameters=[1.0, 0.3, 0.01])
+        hdl = RcclStandInHandle(rank)
+        ex = ShardedExecutor(ok, group=pg, handle_factory=lambda: hdl)
+        assert ex.exchange == "rccl_bcast", ex.exchange
+        gx, gy = np.linspace(0, 1, 7), np.linspace(0, 1, 6)
+        z, ss = ex.execute("grid", gx, gy, backend="loop")
+        st = ko.KrigingState(ndim=2, coords_orig=np.stack([x, y], 1), values=v, model="exponential",
+                             params=ko.internal_parameters("exponential", [1.0, 0.3, 0.01]))
+        zr, sr = ko.execute(st, "grid", gx, gy)
+        good = bool(np.allclose(z, zr, atol=1e-12) and np.allclose(ss, sr, atol=1e-12))
+        flow = hdl.calls.count("factor") == (1 if rank == 0 else 0) and hdl.calls.count("bcast_factor") == 1
+        # local gather: only this rank's slab comes back
+        zl, sl, (lo, hi) = ShardedExecutor(ok, group=pg, handle_factory=lambda: hdl, gather="local").execute("grid", gx, gy, backend="loop")
+        local = bool(np.allclose(zl, zr.ravel()[lo:hi], atol=1e-12) and zl.size == hi - lo)
+        # rank 0's factorisation fails: every rank raises the same error, nobody waits inside the collective
+        bad = RcclStandInHandle(rank, fail_factor=True)
+        exb = ShardedExecutor(ok, group=pg, handle_factory=lambda: bad)
+        raised = False
+        try:
+            exb.execute("grid", gx, gy, backend="loop")
+        except np.linalg.LinAlgError as e:
+            raised = "singular" in str(e)
+        ex.close()
+        q.put((rank, good, flow, local, raised and bad.calls.count("bcast_factor") == 0))
+    finally:
+        pg.close()
+
+
+def test_rccl_broadcast_control_flow_world2():
+    import multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rccl_flow_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [o[0] for o in out] == [0, 1] and all(all(o[1:]) for o in out), out
+
+
+def test_socket_frames_carry_no_pickle_and_strangers_are_dropped():
+    import threading
+
+    from pykrige_amd import dist as d
+
+    bufs = []
+    tree = d._encode({"a": (1, 2.5, None, b"xy", np.arange(6, dtype=np.int32).reshape(2, 3)), "b": [True, "s"]}, bufs)
+    back = d._decode(json_roundtrip(tree), bufs)
+    assert back["a"][:3] == (1, 2.5, None) and back["a"][3] == b"xy" and back["b"] == [True, "s"]
+    assert back["a"][4].dtype == np.int32 and back["a"][4].tolist() == [[0, 1, 2], [3, 4, 5]]
+    with pytest.raises(TypeError):
+        d._encode(object(), [])
+    with pytest.raises(TypeError):
+        d._encode(np.array([object()]), [])
+    with pytest.raises(RuntimeError):
+        d._decode({"__a": ["|O", [1], 0]}, [b"12345678"])
+    # rendezvous: a stranger with the wrong token, then a peer claiming rank 5 of 2, are dropped; the real peer gets in
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    box = {}
+
+    def root():
+        box["pg"] = d.SocketGroup(rank=0, world=2, addr="127.0.0.1", port=port, token="secret", timeout=60)
+
+    th = threading.Thread(target=root)
+    th.start()
+    import struct
+    import time
+
+    def knock(rank, token):
+        for _ in range(100):
+            try:
+                c = socket.create_connection(("127.0.0.1", port), timeout=2.0)
+                c.sendall(struct.pack("<i", rank) + token.encode().ljust(64, b"\0"))
+                return c
+            except OSError:
+                time.sleep(0.05)
+        raise AssertionError("rank 0 never listened")
+
+    c1 = knock(1, "wrong")
+    c2 = knock(5, "secret")
+    peer = d.SocketGroup(rank=1, world=2, addr="127.0.0.1", port=port, token="secret", timeout=60)
+    th.join(60)
+    assert not th.is_alive()
+    t2 = threading.Thread(target=lambda: box.__setitem__("g0", box["pg"].all_gather_object("r0")))
+    t2.start()
+    assert peer.all_gather_object("r1") == ["r0", "r1"]
+    t2.join(30)
+    assert box["g0"] == ["r0", "r1"]
+    for c in (c1, c2):
+        c.close()
+    peer.close()
+    box["pg"].close()
+
+
+def json_roundtrip(tree):
+    import json
+
+    return json.loads(json.dumps(tree))
