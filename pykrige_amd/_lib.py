@@ -139,6 +139,7 @@ class Handle:
         check(lib.mik_create(int(device), C.byref(self._h)))
         self.device = int(device)
         self._keep = []
+        self.option_epoch = 0  # bumped by every option / device-group change (callers that cache a factor watch it)
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
@@ -152,6 +153,7 @@ class Handle:
             pass
 
     def set_option(self, key, value):
+        self.option_epoch += 1
         check(self._lib.mik_set_option(self._h, key.encode(), float(value)))
 
     # --- single-process multi-GPU: the handle spans n devices (mik_handle_set_devices) -----------------
@@ -160,6 +162,7 @@ class Handle:
         logical devices on one physical GPU -- only useful to exercise the multi-device path on a 1-GPU box)."""
         if alias:
             self.set_option("alias_devices", 1)
+        self.option_epoch += 1
         check(self._lib.mik_handle_set_devices(self._h, int(n)))
 
     @property

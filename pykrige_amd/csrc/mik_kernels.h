@@ -545,6 +545,26 @@ __device__ __forceinline__ int super_tile_at(int nIblk, int nTblk, int xcd, long
   return (iblk < nIblk && tblk < nTblk) ? 0 : 1;
 }
 
+// Symmetric form: the queue's unit of work is a PAIR of row blocks (p, nIblk-1-p) of one point block -- the long tile
+// (nIblk - p K blocks) followed by the short one (p + 1): nIblk + 1 K blocks whatever p is.  Tiles of the symmetric form
+// are 1..nIblk K blocks long; popped one by one, the 64 co-resident blocks of an XCD soon finish at different times, their
+// tiles no longer stream the shared operand panels together, and the XCD's L2 stops serving them (measured: 28 % hits,
+// against 71 % for the equal-length tiles of the full form).  Equal-length units are popped together and end together, gang
+// after gang.  A gang = MIK_SI pair-rows x MIK_ST point blocks = 64 units; position `seq` of XCD `xcd`'s sequence;
+// returns 0 = unit, 1 = padding slot, 2 = exhausted.  With an odd nIblk the middle row block stands alone (half a unit);
+// it belongs to the last pair-row group, i.e. to the end of the launch.
+__device__ __forceinline__ int pair_unit_at(int nIblk, int nTblk, int xcd, long seq, int& p, int& tblk) {
+  const int nP = (nIblk + 1) / 2;
+  const int nTg = (nTblk + MIK_ST - 1) / MIK_ST;
+  const long ngang = (long)((nP + MIK_SI - 1) / MIK_SI) * nTg;
+  const long s = (seq >> 6) * 8 + xcd;
+  if (s >= ngang) return 2;
+  const int r = (int)(seq & 63);
+  p = (int)(s / nTg) * MIK_SI + (r % MIK_SI);
+  tblk = (int)(s % nTg) * MIK_ST + (r / MIK_SI);
+  return (p < nP && tblk < nTblk) ? 0 : 1;
+}
+
 __device__ __forceinline__ bool super_tile(int nIblk, int nTblk, int& iblk, int& tblk) {
   const long nsuper = super_tiles_total(nIblk, nTblk) / 64;
   // block b runs on XCD b % 8; its position in that XCD's dispatch sequence is b / 8.  64 consecutive
@@ -574,7 +594,8 @@ __device__ __forceinline__ bool super_tile(int nIblk, int nTblk, int& iblk, int&
 // exhausted, then helps with the other XCDs' sequences.  With one block per tile the in-order workgroup dispatcher stalls behind whichever XCD is still
 // busy once tile lengths differ (symmetric form: 1..nIblk K blocks): measured 8 % of the MFMA rate.
 // PERSIST = false is the one-block-per-tile form (grid = super_grid(), queue unused), kept for A/B measurements.
-template <bool SYM, int NAI, bool PERSIST = true>
+// PAIR (symmetric + persistent only): the queue hands out pairs of row blocks of equal total length (pair_unit_at).
+template <bool SYM, int NAI, bool PERSIST = true, bool PAIR = false>
 __global__ void __launch_bounds__(64 * 2 * (8 / NAI), 2 * (4 / NAI))
 k_contract(const double* __restrict__ Ainv, long lda, const double* __restrict__ Bt, long ldb,
            double* __restrict__ part, int palloc, int nIblk, int kend, unsigned long long* __restrict__ queue) {
@@ -586,15 +607,17 @@ k_contract(const double* __restrict__ Ainv, long lda, const double* __restrict__
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 1, wn = wave & 1, lq = lane >> 4, lc = lane & 15;
   int steal = 0;  // 0 = own XCD's sequence; then the other seven in turn: every tile is done whatever the placement
+  static_assert(!PAIR || (SYM && PERSIST), "pair units exist for the symmetric persistent form");
   for (;;) {
-  int iblk, tblk;
+  int iblk, tblk, pair_p = 0;
   if (PERSIST) {
     const int xq = (xcd + steal) & 7;
     if (threadIdx.x == 0)
       sm.next = (long)__hip_atomic_fetch_add(&queue[xq], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     const long seq = sm.next;
-    const int kind = super_tile_at(nIblk, palloc / MIK_BN, xq, seq, iblk, tblk);
+    const int kind = PAIR ? pair_unit_at(nIblk, palloc / MIK_BN, xq, seq, pair_p, tblk)
+                          : super_tile_at(nIblk, palloc / MIK_BN, xq, seq, iblk, tblk);
     __syncthreads();  // everyone has read sm.next (and the previous tile's `red`) before anything is overwritten
     if (kind == 2) {  // this sequence is exhausted: help the next XCD's (correctness never depends on XCC_ID)
       if (++steal == 8) return;
@@ -603,6 +626,14 @@ k_contract(const double* __restrict__ Ainv, long lda, const double* __restrict__
     if (kind == 1) continue;
   } else if (!super_tile(nIblk, palloc / MIK_BN, iblk, tblk)) {
     return;
+  }
+  for (int half = 0; half < (PAIR ? 2 : 1); ++half) {  // PAIR: the long tile of the pair, then the short one
+  if (PAIR) {
+    iblk = half == 0 ? pair_p : nIblk - 1 - pair_p;
+    if (half == 1) {
+      if (iblk == pair_p) break;  // odd nIblk: the middle row block has no partner
+      __syncthreads();            // the first tile's `red` has been read before the staging LDS is filled again
+    }
   }
   const int i0 = iblk * MIK_BM, t0 = tblk * MIK_BN;
   const double* Ag = Ainv + (long)i0 * lda;
@@ -662,6 +693,7 @@ k_contract(const double* __restrict__ Ainv, long lda, const double* __restrict__
     for (int w = 0; w < NWM; ++w) v += red[w * 128 + threadIdx.x];
     part[(long)iblk * palloc + t0 + threadIdx.x] = v;
   }
+  }  // half
   if (!PERSIST) return;
   }  // for (;;): next tile of this XCD's sequence
 }

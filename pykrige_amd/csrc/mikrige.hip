@@ -186,6 +186,10 @@ struct mik_handle {
   int t_state = 0;  // what T holds: 0 nothing, 1 the kriging matrix A (shift 0), 2 its inverse
   // options
   int opt_waves = 8;  // waves per contraction block: 4 (wave tile 64x64) or 8 (32x64)
+  // symmetric contraction: the queue can hand out equal-length PAIRS of row blocks instead of single tiles.  Measured
+  // (profiles/r02_contract_pairs_vs_tiles.txt): L2 hit rate 28 % -> 47 %, fabric reads -19 %, and 2.7 % SLOWER -- co-resident
+  // blocks then reach their epilogues together and stop covering each other's bubbles; the kernel is not traffic-bound.  Off.
+  int opt_pairs = 0;
   int opt_factor = 0, opt_sym = 1, opt_engine = 0;  // engine: 0 = v_mfma_f64 contraction, 1 = v_fma_f64 (VALU) contraction
   long opt_chunk = 131072;
   int opt_mw_pivot = 0;       // 1 = always solve the moving-window systems with partial pivoting
@@ -473,6 +477,10 @@ static int create_one_body(mik_handle* h, int device) {
   if (env && (atoi(env) == 4 || atoi(env) == 8)) h->opt_waves = atoi(env);
   env = getenv("MIK_CHUNK");
   if (env && atol(env) >= 128) h->opt_chunk = (atol(env) / 128) * 128;
+  env = getenv("MIK_SYMSWEEP");
+  if (env) h->opt_symsweep = atoi(env) ? 1 : 0;
+  env = getenv("MIK_PAIRS");
+  if (env) h->opt_pairs = atoi(env) ? 1 : 0;
   env = getenv("MIK_EXCHANGE");
   if (env) h->opt_exchange = !strcmp(env, "rccl") ? 1 : !strcmp(env, "peer") ? 2 : !strcmp(env, "redundant") ? 3 : 0;
   env = getenv("MIK_ALIAS_DEVICES");
@@ -573,7 +581,7 @@ static int set_group(mik_handle* h, int n) {
     k->is_kid = true;
     k->opt_factor = h->opt_factor, k->opt_sym = h->opt_sym, k->opt_engine = h->opt_engine, k->opt_waves = h->opt_waves;
     k->opt_chunk = h->opt_chunk, k->opt_symsweep = h->opt_symsweep, k->opt_diag = h->opt_diag, k->opt_lookahead = h->opt_lookahead;
-    k->opt_mw_pivot = h->opt_mw_pivot, k->opt_mw_lds_cap = h->opt_mw_lds_cap;
+    k->opt_mw_pivot = h->opt_mw_pivot, k->opt_mw_lds_cap = h->opt_mw_lds_cap, k->opt_pairs = h->opt_pairs;
     k->custom_fn = h->custom_fn, k->custom_user = h->custom_user;
     h->kids.push_back(k);
   }
@@ -647,6 +655,8 @@ int mik_set_option(mik_handle* h, const char* key, double value) {
   } else if (!strcmp(key, "engine")) {
     if (value != 0.0 && value != 1.0) return fail(MIK_EINVAL, "engine must be 0 (mfma) or 1 (valu)");
     h->opt_engine = (int)value;
+  } else if (!strcmp(key, "pairs")) {
+    h->opt_pairs = value != 0.0;
   } else if (!strcmp(key, "waves")) {
     if (value != 4.0 && value != 8.0) return fail(MIK_EINVAL, "waves must be 4 or 8");
     h->opt_waves = (int)value;
@@ -1433,7 +1443,9 @@ static int one_predict(mik_handle* h) {
         HIPC(hipMemsetAsync(h->queue.p, 0, 8 * sizeof(unsigned long long), h->stream));
         unsigned long long* qp = h->queue.as<unsigned long long>();
         const unsigned pgrid = (unsigned)std::min<long>(2L * h->n_cu, (long)sgrid);
-        if (h->opt_waves == 8) {
+        if (h->opt_waves == 8 && h->opt_sym && h->opt_pairs) {
+          hipLaunchKernelGGL((k_contract<true, 2, true, true>), dim3(pgrid), dim3(512), 0, h->stream, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend, qp);
+        } else if (h->opt_waves == 8) {
           if (h->opt_sym) hipLaunchKernelGGL((k_contract<true, 2>), dim3(pgrid), dim3(512), 0, h->stream, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend, qp);
           else hipLaunchKernelGGL((k_contract<false, 2>), dim3(pgrid), dim3(512), 0, h->stream, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend, qp);
         } else {

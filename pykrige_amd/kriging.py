@@ -93,6 +93,7 @@ class _KrigingBase:
         except ImportError:
             return None
         h = self._get_handle()
+        self._factor_key = None
         ca = self._coords_adj
         h.set_problem(ndim=self._ndim, xs=ca[:, 0], ys=ca[:, 1], zs=ca[:, 2] if self._ndim == 3 else None,
                       values=self._values(), model_id=0, params=[1.0, 0.0],
@@ -165,6 +166,7 @@ class _KrigingBase:
 
     def _set_problem(self, h, with_drift=True, values=None, pseudo_inv=False):
         """H2D of the stations / drift description."""
+        self._factor_key = None  # whatever the handle held is replaced
         ca = self._coords_adj
         kw = dict(
             ndim=self._ndim, xs=ca[:, 0], ys=ca[:, 1], zs=ca[:, 2] if self._ndim == 3 else None,
@@ -184,11 +186,35 @@ class _KrigingBase:
             kw["pseudo_inv"] = {"pinv": 1, "pinvh": 2}[self.pseudo_inv_type]
         h.set_problem(**kw)
 
+    def _problem_key(self):
+        """Digest of everything mik_set_problem + mik_factor depend on; None = not cacheable (a user callable)."""
+        if self.variogram_model == "custom" or _os.environ.get("MIK_FACTOR_CACHE", "1") == "0":
+            return None
+        import hashlib
+
+        d = hashlib.blake2b(digest_size=16)
+        for a in (self._coords_adj, self._values(), self._wells(), self._station_extra_cols()):
+            d.update(b"-" if a is None else np.ascontiguousarray(a, dtype=np.float64).tobytes())
+        d.update(repr((self._ndim, self.variogram_model, [float(v) for v in self.variogram_model_parameters], float(self.eps),
+                       bool(self.exact_values), bool(self._regional_linear()), bool(self.pseudo_inv), self.pseudo_inv_type,
+                       getattr(self, "coordinates_type", "euclidean"))).encode())
+        return d.digest()
+
     def _upload_and_factor(self):
-        """K1 + K2 on the device (inverse, or pseudo-inverse when pseudo_inv=True)."""
+        """K1 + K2 on the device (inverse, or pseudo-inverse when pseudo_inv=True).  The reference re-assembles and re-inverts
+        the matrix on every execute() (ok.py:898, 663); here the factored matrix stays on the device and is reused while the
+        problem (stations, values, variogram, drift set-up) is unchanged -- a second execute() on new points only predicts."""
         h = self._get_handle()
+        key = self._problem_key()
+        if key is not None:
+            key = (key, h.option_epoch)  # a changed library option (factor path, device group, ...) invalidates the factor too
+        if key is not None and key == getattr(self, "_factor_key", None):
+            self.factor_reused = True
+            return h
         self._set_problem(h)
         h.factor()
+        self._factor_key = key
+        self.factor_reused = False
         return h
 
     def _solve(self, pts_adj, mask, extra_rows):

@@ -9,7 +9,7 @@ m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
 import pykrige_amd as pa
 from oracle import kriging_oracle as ko
 
-worst = collections.defaultdict(lambda: [0.0, 0.0, 0.0, 0.0, 0])
+worst = collections.defaultdict(lambda: [0.0, 0.0, 0.0, 0.0, 0, 0.0, 0.0])
 for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 400):
     c = m._case(seed)
     if c["window"] or c["drift"].get("specified") or c["drift"].get("functional"):
@@ -34,8 +34,9 @@ for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 400):
     zr, sr = ko.execute(st, c["style"], *c["axes"], mask=c["mask"])
     keep = np.ones(c["shape"], bool) if c["mask"] is None else ~c["mask"]
     key = (c["model"], "UK" if c["universal"] else "OK")
-    for fac, off in ((1, 0), (2, 2)):
+    for fac, off in ((1, 0), (2, 2), (1, 5)):  # sweep, pivoted, half sweep (upper block triangle only: option symsweep)
         mdl._get_handle().set_option("factor", fac)
+        mdl._get_handle().set_option("symsweep", 1 if off == 5 else 0)
         try:
             z, ss = mdl.execute(c["style"], *c["axes"], mask=c["mask"], backend="loop") if c["mask"] is not None else mdl.execute(c["style"], *c["axes"], backend="loop")
         except Exception:
@@ -45,4 +46,4 @@ for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 400):
         worst[key][off + 1] = max(worst[key][off + 1], float(np.abs(np.ma.getdata(ss) - np.ma.getdata(sr))[keep].max()))
 for key in sorted(worst):
     w = worst[key]
-    print("%-12s %s  sweep |dz| %.1e |dss| %.1e   pivoted |dz| %.1e |dss| %.1e   sweep refused %d" % (key[0], key[1], w[0], w[1], w[2], w[3], w[4]))
+    print("%-12s %s  sweep |dz| %.1e |dss| %.1e   pivoted |dz| %.1e |dss| %.1e   half sweep |dz| %.1e |dss| %.1e   sweep refused %d" % (key[0], key[1], w[0], w[1], w[2], w[3], w[5], w[6], w[4]))

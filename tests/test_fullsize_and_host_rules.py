@@ -126,19 +126,27 @@ def test_update_variogram_model_signatures_are_the_references():
 
 # ------------------------------------------------------------------------------------------- GPU
 @pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["default", "half_sweep", "pivoted", "pair_units"])
 @pytest.mark.parametrize("name", CASES)
-def test_hip_matches_the_reference_on_a_full_size_slab(name):
+def test_hip_matches_the_reference_on_a_full_size_slab(name, variant):
     g = _full(name)
     m = fx.amd_model_from(name, g)
+    h = m._get_handle()
+    if variant == "half_sweep":  # inverse from the upper block triangle only
+        h.set_option("symsweep", 1)
+    elif variant == "pivoted":
+        h.set_option("factor", 2)
+    elif variant == "pair_units":
+        h.set_option("pairs", 1)
     z, ss = m.execute("grid", *fx.grid_args(g), backend="vectorized")
     dz = float(np.abs(np.ma.getdata(z) - g["z"]).max())
     ds = float(np.abs(np.ma.getdata(ss) - g["ss"]).max())
-    print("%s: N=%d, %d points, cond_1(A)=%.3g, max|dz|=%.3e, max|dss|=%.3e" % (name, g["x"].size, g["z"].size,
-                                                                              float(g["cond1"]), dz, ds))
+    print("%s [%s]: N=%d, %d points, cond_1(A)=%.3g, max|dz|=%.3e, max|dss|=%.3e, invert %.2f ms" % (
+        name, variant, g["x"].size, g["z"].size, float(g["cond1"]), dz, ds, m.last_timing["invert_ms"]))
     assert dz <= Z_TOL and ds <= SS_TOL
     nodes = _node_points(g)
     np.testing.assert_allclose(np.ma.getdata(z).ravel()[nodes], g["v"][:8], rtol=0, atol=Z_TOL)
-    if "z_c" in g:
+    if "z_c" in g and variant == "default":
         zc, sc = m.execute("grid", *fx.grid_args(g), backend="C")
         assert type(zc) is np.ndarray
         assert np.abs(zc - g["z_c"]).max() <= Z_TOL and np.abs(sc - g["ss_c"]).max() <= SS_TOL
@@ -227,3 +235,26 @@ def test_hip_class_statistics_with_pseudo_inverse():
     ok = pa.OrdinaryKriging(g["pst_x"], g["pst_y"], g["pst_v"], variogram_model="linear", variogram_parameters=[1.5, 0.0],
                             pseudo_inv=True, enable_statistics=True)
     np.testing.assert_allclose([ok.Q1, ok.Q2, ok.cR], [g["pst_class_Q1"], g["pst_class_Q2"], g["pst_class_cR"]], rtol=1e-6)
+
+
+@pytest.mark.gpu
+def test_hip_factor_is_reused_while_the_problem_is_unchanged():
+    """ok.py:898 / 663 re-assemble and re-invert on every execute(); the drop-in keeps the factored matrix on the device."""
+    g = fx.load("ok2d_n2000")
+    m = fx.amd_model_from("ok2d_n2000", g)
+    z1, s1 = m.execute("grid", g["gridx"], g["gridy"], backend="loop")
+    assert m.factor_reused is False
+    z2, s2 = m.execute("points", g["x"][:50] + 0.001, g["y"][:50], backend="loop")  # new points, same problem
+    assert m.factor_reused is True and m.last_timing["invert_ms"] > 0.0
+    z3, s3 = m.execute("grid", g["gridx"], g["gridy"], backend="loop")
+    assert m.factor_reused is True and np.array_equal(z1, z3) and np.array_equal(s1, s3)
+    m.update_variogram_model("exponential", [1.0, 0.35, 0.0])  # a different variogram: new factor
+    z4, _ = m.execute("grid", g["gridx"], g["gridy"], backend="loop")
+    assert m.factor_reused is False and np.abs(z4 - z1).max() > 1e-6
+    m.update_variogram_model("exponential", [1.0, 0.3, 0.0])
+    m._get_handle().set_option("factor", 2)  # a library option changed: no reuse
+    z5, s5 = m.execute("grid", g["gridx"], g["gridy"], backend="loop")
+    assert m.factor_reused is False and np.abs(z5 - g["z"]).max() <= Z_TOL and np.abs(s5 - g["ss"]).max() <= SS_TOL
+    m.execute("grid", g["gridx"], g["gridy"], backend="loop", n_closest_points=8)  # the moving window replaces the handle's problem
+    z6, s6 = m.execute("grid", g["gridx"], g["gridy"], backend="loop")
+    assert m.factor_reused is False and np.abs(z6 - g["z"]).max() <= Z_TOL

@@ -657,7 +657,14 @@ def test_moving_window_cell_grid_against_kdtree(case):
     else:
         m = pa.OrdinaryKriging3D(c[:, 0], c[:, 1], c[:, 2], v, variogram_model=model, variogram_parameters=user)
         z, ss = m.execute("points", pts[:, 0], pts[:, 1], pts[:, 2], backend="loop", n_closest_points=k)
-    np.testing.assert_allclose(z, zr, rtol=0, atol=1e-7)   # far-outside points: the systems are ill-conditioned there
+    # BASELINE's 1e-8 on z holds for every point inside the stations' bounding box; the 1e-7 allowance exists for the points
+    # placed far outside it (clustered / collinear cases), whose local systems are ill-conditioned -- printed when it is used
+    dz = np.abs(z - zr)
+    inside = np.all((pts >= c.min(axis=0)) & (pts <= c.max(axis=0)), axis=1)
+    used = int((dz > 1e-8).sum())
+    print("moving-window %s: worst |dz| %.2e (inside the bounding box %.2e); %d of %d points above 1e-8" % (
+        case, dz.max(), dz[inside].max() if inside.any() else 0.0, used, dz.size))
+    np.testing.assert_allclose(z, zr, rtol=0, atol=1e-7)
     np.testing.assert_allclose(ss, sr, rtol=0, atol=1e-6)
 
 
