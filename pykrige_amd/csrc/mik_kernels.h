@@ -1979,6 +1979,139 @@ __global__ void __launch_bounds__(256) k_mw_solve(MwArgs a) {
   }
 }
 
+// Per-point solve WITHOUT pivot search, default of the moving window: LDL^T of the SPD-shifted station block in registers.
+// The shifted system (k_mw_solve above) reads  C lam + mu 1 = bt,  1.lam = 1  with C = s 11^T - Gamma (covariances, SPD) and
+// bt = b + s 1.  With C = L D L^T and the three forward-substituted vectors y_q = L^-1 {bt, 1, Z} everything the reference
+// returns is a D^-1-weighted inner product G_pq = y_p . D^-1 y_q  (= B_p^T C^-1 B_q):
+//     mu = (G_01 - 1) / G_11,   z = Z.lam = G_02 - mu G_12,   sigma^2 = -lam.b - mu = -(G_00 - mu G_01) + s - mu
+// -- no back substitution, no solution vector.  A point is worked on by a G x G thread grid; thread (ty, tx) keeps the
+// LOWER-triangle elements (ty + G i, tx + G j), j <= i < RI, in registers (cyclic: balanced while the trailing matrix
+// shrinks): RI (RI + 1) / 2 FMAs per thread and step on a matrix that loses a row and a column per step -- about a sixth of
+// the multiply-adds of the Gauss-Jordan form.  The three right-hand sides ride along as extra ROWS (threads ty = 0, 1, 2):
+// the elimination forward-substitutes them.  The step loop is unrolled over the local tile index, so every register index
+// is a compile-time constant (the Gauss-Jordan kernel selects its pivot row / column out of the tile with v_cndmask chains,
+// which cost more than its FMAs).  Per step the G owners of column c publish it through double-buffered LDS; with at most 64
+// threads per point the point lives inside one wavefront and no workgroup barrier is needed at all.
+// A non-positive pivot raises flag bit 1 (the host reruns the call with the pivoted kernel).
+template <int G, int RI>
+__global__ void __launch_bounds__((G * G < 256) ? 256 : G * G) k_mw_chol(MwArgs a) {
+  extern __shared__ double mw_lds[];
+  constexpr int T = G * G, NT = T < 256 ? 256 : T, NB = G * RI, ACOL = NB + 4;
+  const int K = a.K;
+  const int g = threadIdx.x / T, lt = threadIdx.x % T, ty = lt / G, tx = lt % G;
+  constexpr int PER = 2 * ACOL + 5 * NB;
+  double* acol = mw_lds + (long)g * PER;  // [2][ACOL]: column c of the trailing matrix by global row, right-hand-side rows at NB..NB+2
+  double* csx = acol + 2 * ACOL;
+  double* csy = csx + NB;
+  double* csz = csy + NB;
+  double* bvec = csz + NB;
+  double* zsel = bvec + NB;
+  const long pt = (long)blockIdx.x * (NT / T) + g;
+  const bool live = pt < a.npt;
+  auto sync = [&]() {
+    if (T <= 64) {  // the point's threads are lanes of one wavefront: LDS operations of a wave complete in order
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    } else {
+      __syncthreads();
+    }
+  };
+  for (int r = lt; r < NB; r += T) {
+    double x = 0.0, y = 0.0, z = 0.0, b = 0.0, zv = 0.0;
+    if (live && r < K) {
+      const int st = a.idx[pt * K + r];
+      x = a.sx[st];
+      y = a.sy[st];
+      z = (a.mode == 3) ? a.sz[st] : 0.0;
+      if (a.mode == 1) {
+        const double lat = y * MIK_PI / 180.0;
+        y = cos(lat);
+        z = sin(lat);
+      }
+      b = a.dist[pt * K + r];  // dist holds b = -gamma(d), 0 on an exact hit (k_mw_rhs)
+      zv = a.Z[st];
+    }
+    csx[r] = x, csy[r] = y, csz[r] = z, bvec[r] = b, zsel[r] = zv;
+  }
+  sync();
+  double shift;
+  if (a.v.model >= 2) {
+    shift = a.v.p0 + a.v.p2;
+  } else {
+    double gmax = 0.0;
+    for (int r = 0; r < K; ++r) gmax = fmax(gmax, -bvec[r]);
+    shift = 4.0 * gmax;
+  }
+  if (!(shift > 0.0)) shift = 1.0;
+  double m[RI][RI], rhs[RI];
+#pragma unroll
+  for (int i = 0; i < RI; ++i) {
+    const int row = ty + G * i;
+#pragma unroll
+    for (int j = 0; j <= i; ++j) {
+      const int col = tx + G * j;
+      double v = (row == col) ? 1.0 : 0.0;  // padding rows / columns: identity
+      if (row < K && col < K)
+        v = (row == col) ? shift : shift + mw_entry(a.v, a.mode, csx[row], csy[row], csz[row], csx[col], csy[col], csz[col]);
+      m[i][j] = v;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < RI; ++j) {
+    const int col = tx + G * j;
+    double v = 0.0;
+    if (col < K) v = (ty == 0) ? bvec[col] + shift : (ty == 1) ? 1.0 : (ty == 2) ? zsel[col] : 0.0;
+    rhs[j] = v;
+  }
+  double g00 = 0.0, g01 = 0.0, g11 = 0.0, g02 = 0.0, g12 = 0.0;
+  int bad = 0;
+#pragma unroll
+  for (int cc = 0; cc < RI; ++cc) {
+    for (int cx = 0; cx < G; ++cx) {
+      const int c = cc * G + cx;
+      if (c >= K) break;  // uniform over the block
+      double* ab = acol + (c & 1) * ACOL;
+      if (tx == cx) {
+#pragma unroll
+        for (int i = cc; i < RI; ++i) ab[ty + G * i] = m[i][cc];
+        if (ty < 3) ab[NB + ty] = rhs[cc];
+      }
+      sync();
+      const double d = ab[c];
+      if (!(d > 0.0)) bad = 2;
+      const double inv = 1.0 / d;
+      double u[RI], w[RI];
+#pragma unroll
+      for (int i = cc; i < RI; ++i) {
+        u[i] = ab[ty + G * i] * inv;
+        w[i] = ab[tx + G * i];
+      }
+      if (ty <= cx) u[cc] = 0.0;  // rows / columns <= c of the diagonal local tile are finished
+      if (tx <= cx) w[cc] = 0.0;
+      const double y0 = ab[NB], y1 = ab[NB + 1], y2 = ab[NB + 2];
+      const double ur = (ty < 3 ? ab[NB + ty] : 0.0) * inv;
+      g00 += y0 * y0 * inv;
+      g01 += y0 * y1 * inv;
+      g11 += y1 * y1 * inv;
+      g02 += y0 * y2 * inv;
+      g12 += y1 * y2 * inv;
+#pragma unroll
+      for (int i = cc; i < RI; ++i)
+#pragma unroll
+        for (int j = cc; j <= i; ++j) m[i][j] -= u[i] * w[j];
+#pragma unroll
+      for (int j = cc; j < RI; ++j) rhs[j] -= ur * w[j];
+    }
+  }
+  if (live && lt == 0) {
+    const double mu = (g01 - 1.0) / g11;
+    a.z[pt] = g02 - mu * g12;
+    a.ss[pt] = -(g00 - mu * g01) + shift - mu;
+    if (bad || !(g11 > 0.0)) atomicOr(a.flag, 2);
+  }
+}
+
 // ---- n_closest_points > MIK_MW_KMAX: the same two steps with their working sets in HBM instead of registers / LDS ----
 // k_mw_knn_big : one thread per point; its ascending candidate list lives in a [rank][point] work array (neighbouring
 //                threads touch neighbouring addresses while they are at the same rank) and is copied to the usual

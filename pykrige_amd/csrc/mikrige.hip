@@ -193,6 +193,7 @@ struct mik_handle {
   int opt_factor = 0, opt_sym = 1, opt_engine = 0;  // engine: 0 = v_mfma_f64 contraction, 1 = v_fma_f64 (VALU) contraction
   long opt_chunk = 131072;
   int opt_mw_pivot = 0;       // 1 = always solve the moving-window systems with partial pivoting
+  int opt_mw_solver = 0;      // 0 = LDL^T of the shifted system in registers (default), 1 = the Gauss-Jordan kernels
   bool mw_force_piv = false;
   int opt_mw_lds_cap = 8192;  // largest candidate buffer the moving-window neighbour search keeps in LDS
   mik_timing tm{};
@@ -440,6 +441,31 @@ static int dispatch_mw_solve(mik_handle* h, const MwArgs& a, long pc, bool piv) 
   return launch_mw_solve<16, 16, 8, 9>(h, a, pc, piv);               // 256, nb <= 128
 }
 
+template <int G, int RI>
+static int launch_mw_chol(mik_handle* h, const MwArgs& a, long pc) {
+  constexpr int T = G * G, NT = T < 256 ? 256 : T, PPB = NT / T, NB = G * RI;
+  if (a.K > NB) return fail(MIK_EINVAL, "moving-window LDL^T class too small for this window");
+  const size_t lds = sizeof(double) * (size_t)(2 * (NB + 4) + 5 * NB) * PPB;
+  const dim3 grid((unsigned)((pc + PPB - 1) / PPB));
+  HIPC(hipFuncSetAttribute((const void*)k_mw_chol<G, RI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL((k_mw_chol<G, RI>), grid, dim3(NT), lds, h->stream, a);
+  return MIK_OK;
+}
+
+// thread-grid / register-tile classes of k_mw_chol: {G, RI} covers K <= G * RI
+#define MIK_MW_CHOL_KMAX 256
+static int dispatch_mw_chol(mik_handle* h, const MwArgs& a, long pc) {
+  const int K = a.K;
+  if (K <= 16) return launch_mw_chol<4, 4>(h, a, pc);    // 16 threads per point, 4 points per wavefront
+  if (K <= 32) return launch_mw_chol<8, 4>(h, a, pc);    // one wavefront per point from here to K = 64: no workgroup barrier
+  if (K <= 48) return launch_mw_chol<8, 6>(h, a, pc);
+  if (K <= 64) return launch_mw_chol<8, 8>(h, a, pc);
+  if (K <= 96) return launch_mw_chol<16, 6>(h, a, pc);   // 256 threads per point
+  if (K <= 128) return launch_mw_chol<16, 8>(h, a, pc);
+  if (K <= 192) return launch_mw_chol<32, 6>(h, a, pc);  // 1024 threads per point
+  return launch_mw_chol<32, 8>(h, a, pc);                // K <= 256
+}
+
 extern "C" {
 
 const char* mik_last_error(void) { return g_err.c_str(); }
@@ -581,7 +607,7 @@ static int set_group(mik_handle* h, int n) {
     k->is_kid = true;
     k->opt_factor = h->opt_factor, k->opt_sym = h->opt_sym, k->opt_engine = h->opt_engine, k->opt_waves = h->opt_waves;
     k->opt_chunk = h->opt_chunk, k->opt_symsweep = h->opt_symsweep, k->opt_diag = h->opt_diag, k->opt_lookahead = h->opt_lookahead;
-    k->opt_mw_pivot = h->opt_mw_pivot, k->opt_mw_lds_cap = h->opt_mw_lds_cap, k->opt_pairs = h->opt_pairs;
+    k->opt_mw_pivot = h->opt_mw_pivot, k->opt_mw_lds_cap = h->opt_mw_lds_cap, k->opt_pairs = h->opt_pairs, k->opt_mw_solver = h->opt_mw_solver;
     k->custom_fn = h->custom_fn, k->custom_user = h->custom_user;
     h->kids.push_back(k);
   }
@@ -669,6 +695,9 @@ int mik_set_option(mik_handle* h, const char* key, double value) {
     h->opt_diag = (int)value;
   } else if (!strcmp(key, "lookahead")) {
     h->opt_lookahead = value < 0.0 ? -1 : (value != 0.0);
+  } else if (!strcmp(key, "mw_solver")) {
+    if (value != 0.0 && value != 1.0) return fail(MIK_EINVAL, "mw_solver must be 0 (LDL^T) or 1 (Gauss-Jordan)");
+    h->opt_mw_solver = (int)value;
   } else if (!strcmp(key, "mw_pivot")) {
     h->opt_mw_pivot = value != 0.0;
   } else if (!strcmp(key, "mw_lds_cap")) {
@@ -1518,19 +1547,23 @@ static int one_predict_mw(mik_handle* h, int n_closest) {
   // stays valid).
   // K <= MIK_MW_KMAX: candidate lists in registers, systems in LDS, all points in one pass.  Larger K: working sets in
   // HBM, points in chunks that bound those work arrays to ~2 GB.
-  const bool big = K > MIK_MW_KMAX;
   const int nb = K + 1;
-  long chunk = npt;
-  if (big) {
-    chunk = ((long)(2e9 / (24.0 * K)) / 256) * 256;
-    if (chunk < 256) chunk = 256;
-    if (chunk > npt) chunk = npt;
-  }
   const bool custom = h->model == MIK_MODEL_CUSTOM;
   // small windows are solved without a pivot search on the SPD-shifted local system unless the model cannot promise a
   // positive definite station block (hole-effect), has no device functor for the shift (custom), or a previous attempt
   // of this call hit a bad pivot
   const bool mw_piv = custom || h->model == MIK_MODEL_HOLE_EFFECT || h->mw_force_piv || h->opt_mw_pivot;
+  // three solvers: LDL^T of the shifted system in registers (no pivot search; windows up to 256), Gauss-Jordan in registers
+  // with or without implicit partial pivoting (opt_mw_solver = 1, or when the model cannot promise a positive definite
+  // station block; windows up to 127), LU with partial pivoting in HBM scratch (any window)
+  const bool chol = !mw_piv && h->opt_mw_solver == 0 && K <= MIK_MW_CHOL_KMAX;
+  const bool big = !chol && K > MIK_MW_KMAX;
+  long chunk = npt;
+  if (K > MIK_MW_KMAX) {  // neighbour lists of 12 K bytes per point: bound them to ~2 GB
+    chunk = ((long)(2e9 / (24.0 * K)) / 256) * 256;
+    if (chunk < 256) chunk = 256;
+    if (chunk > npt) chunk = npt;
+  }
   if (custom) {  // the K x K pair distances of every point visit the host: bound that table to ~1 GB
     long cc = ((long)(1e9 / (8.0 * K * (K + 1.0))) / 256) * 256;
     if (cc < 256) cc = 256;
@@ -1675,6 +1708,8 @@ static int one_predict_mw(mik_handle* h, int n_closest) {
       const int grid = (int)(pc < sgrid ? pc : sgrid);
       HIPC(hipFuncSetAttribute((const void*)k_mw_solve_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(k_mw_solve_big, dim3(grid), dim3(256), lds, h->stream, a, sysbuf.as<double>());
+    } else if (chol) {
+      MIKC(dispatch_mw_chol(h, a, pc));
     } else {
       MIKC(dispatch_mw_solve(h, a, pc, mw_piv));
     }

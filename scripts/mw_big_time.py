@@ -1,4 +1,5 @@
-"""Time the moving-window path for a few window sizes on config-2 stations (GPU box)."""
+"""Time the moving-window path for a range of window sizes on config-2 stations (GPU box): the LDL^T solver (default)
+beside the Gauss-Jordan / HBM-LU kernels it replaces (option mw_solver = 1), whole call and solve kernels alone."""
 import sys, time
 import numpy as np
 sys.path.insert(0, ".")
@@ -11,14 +12,22 @@ h = _lib.Handle(0)
 h.set_problem(ndim=2, xs=coords[0], ys=coords[1], zs=None, values=values, model_id=_lib.MODEL_IDS[cfg["model"]],
               params=internal_params(cfg["model"], cfg["params"]))
 rng = np.random.default_rng(0)
-for k, npt in ((10, 1000000), (100, 1000000), (127, 100000), (128, 100000), (200, 100000), (500, 20000), (1000, 4000)):
+print("%5s %9s | %12s %12s %14s | %12s %12s %14s | %9s" % ("k", "points", "LDLt ms", "solve ms", "points/s", "G-J/LU ms", "solve ms", "points/s", "max|dz|"))
+for k, npt in ((10, 1000000), (16, 1000000), (32, 1000000), (50, 1000000), (64, 1000000), (100, 1000000), (127, 100000), (128, 100000),
+               (192, 100000), (200, 100000), (256, 100000), (257, 20000), (500, 20000), (1000, 4000)):
     px, py = rng.random(npt), rng.random(npt)
     h.set_points(px, py, None)
-    h.predict_moving_window(k)
-    t0 = time.perf_counter()
-    h.predict_moving_window(k)
-    dt = time.perf_counter() - t0
-    print("k=%4d  npt=%8d  %9.2f ms  %10.0f points/s" % (k, npt, dt * 1e3, npt / dt), flush=True)
+    row, zs = [], []
+    for solver in (0, 1):
+        h.set_option("mw_solver", solver)
+        h.predict_moving_window(k)
+        t0 = time.perf_counter()
+        h.predict_moving_window(k)
+        dt = time.perf_counter() - t0
+        row += [dt * 1e3, h.timing()["contract_ms"], npt / dt]
+        zs.append(h.get_results()[0])
+    print("%5d %9d | %12.2f %12.2f %14.0f | %12.2f %12.2f %14.0f | %9.2e" % (k, npt, *row, np.abs(zs[0] - zs[1]).max()), flush=True)
+h.set_option("mw_solver", 0)
 
 # many stations: only coordinates live on the device (no N x N matrix on this path)
 for n, k in ((100000, 10), (1000000, 10), (1000000, 32)):

@@ -42,15 +42,15 @@ int main(int argc, char** argv) {
         hipMemsetAsync(queue, 0, 64, 0);
         hipEventRecord(e0);
         if (form == 0) hipLaunchKernelGGL((k_contract<true, 2, true>), dim3(512), dim3(512), 0, 0, (const double*)T, ld, (const double*)Bt, ld, part, P, nblk, kend, queue);
-        else if (form == 2) hipLaunchKernelGGL((k_contract<true, 2, true, true>), dim3(512), dim3(512), 0, 0, (const double*)T, ld, (const double*)Bt, ld, part, P, nblk, kend, queue);
+        else if (form >= 2) hipLaunchKernelGGL((k_contract<true, 2, true, true>), dim3(512), dim3(512), 0, 0, (const double*)T, ld, (const double*)Bt, ld, part, P, nblk, kend, queue);
         else hipLaunchKernelGGL((k_contract<false, 2, true>), dim3(512), dim3(512), 0, 0, (const double*)T, ld, (const double*)Bt, ld, part, P, nblk, kend, queue);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         if (rep > 0 && ms < best) best = ms;
       }
-      printf("ld = Mp + %3d  %s : %.3f ms  executed %.2f TF/s\n", pad, form == 0 ? "sym tiles" : form == 2 ? "sym pairs" : "full     ", best, (form != 1 ? fl_sym : fl_full) / best * 1e-9);
+      printf("ld = Mp + %3d  %s : %.3f ms  executed %.2f TF/s\n", pad, form == 0 ? "sym tiles" : form == 2 ? "sym pairs" : form == 3 ? "pairs +0.26ms" : form == 4 ? "pairs +0.52ms" : form == 5 ? "pairs +0.13ms" : "full     ", best, (form != 1 ? fl_sym : fl_full) / best * 1e-9);
       if (form == 0) CK(hipMemcpy(ref.data(), part, ref.size() * 8, hipMemcpyDeviceToHost));
-      if (form == 2) {
+      if (form >= 2) {
         CK(hipMemcpy(got.data(), part, got.size() * 8, hipMemcpyDeviceToHost));
         double md = 0; for (size_t i = 0; i < ref.size(); ++i) md = fmax(md, fabs(ref[i] - got[i]));
         printf("                 sym pairs vs sym tiles partials: max|diff| %.3e\n", md);
