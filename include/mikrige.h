@@ -126,7 +126,9 @@ int  mik_handle_devices(mik_handle *h);          /* members of the handle's devi
  * "chunk" = points per contraction launch (multiple of 128) ;
  * "lookahead" 0/1/-1 = overlap the next panel's serial chain with the current trailing update in the block sweep
  *   (default -1: from 24 block columns on) ; "diag" 0..3 = diagonal-block inverse kernel variant (default 1) ;
- * "symsweep" 0/1 = sweep only the upper block triangle (faster, less accurate on ill-conditioned systems; default 0) ;
+ * "symsweep" 0/1/-1 = sweep only the upper block triangle (faster; 10-100 x the rounding error of the full sweep, which stays far
+ *   inside the tolerance for the exponential and spherical models and does not for power + drift terms); default -1 = by
+ *   itself for exponential / spherical from 24 block columns on ;
  * "mw_pivot" 0/1 = always solve the moving-window systems with partial pivoting (default 0: SPD-shifted, no pivot search,
  *   falling back to pivoting when a local system is not positive definite) ;
  * "mw_lds_cap" = largest moving-window candidate buffer kept in LDS (entries, default 8192; 0 forces the HBM lists) ;

@@ -173,7 +173,7 @@ struct mik_handle {
   // OFF by default: the two triangles of the in-place inverse carry different rounding histories, and z / sigma^2 formed
   // from a mirrored triangle lose the small residual of the full sweep on ill-conditioned systems (power variogram with
   // drift terms, cond 3e5: |dz| 3e-9 -> 8e-7).  Fine for well-conditioned problems; opt in with the option.
-  int opt_symsweep = 0;
+  int opt_symsweep = -1;  // -1 = auto (see run_block_inverse), 0 = off, 1 = on
   int opt_diag = 1;        // diagonal-block inverse variant: 0 = 1024 threads (16 waves x 8 rows), 1 = 16x16 grid, 2 = 16x32, 3 = 32x32
   // points
   long npt_total = 0, npt = 0;
@@ -504,7 +504,7 @@ static int create_one_body(mik_handle* h, int device) {
   env = getenv("MIK_CHUNK");
   if (env && atol(env) >= 128) h->opt_chunk = (atol(env) / 128) * 128;
   env = getenv("MIK_SYMSWEEP");
-  if (env) h->opt_symsweep = atoi(env) ? 1 : 0;
+  if (env) h->opt_symsweep = atoi(env) < 0 ? -1 : atoi(env) ? 1 : 0;
   env = getenv("MIK_PAIRS");
   if (env) h->opt_pairs = atoi(env) ? 1 : 0;
   env = getenv("MIK_EXCHANGE");
@@ -690,7 +690,7 @@ int mik_set_option(mik_handle* h, const char* key, double value) {
     if (value < 128) return fail(MIK_EINVAL, "chunk must be >= 128");
     h->opt_chunk = ((long)value / 128) * 128;
   } else if (!strcmp(key, "symsweep")) {
-    h->opt_symsweep = value != 0.0;
+    h->opt_symsweep = value < 0.0 ? -1 : (value != 0.0);
   } else if (!strcmp(key, "diag")) {
     h->opt_diag = (int)value;
   } else if (!strcmp(key, "lookahead")) {
@@ -908,7 +908,10 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
   const unsigned pgrid = (unsigned)(((long)Mp * 128 + 255) / 256);
   // measured (scripts/inverse_lookahead_ab.py): +16 % at 16 block columns (the second stream's waits cost more than the
   // overlap returns), -12 % at 40, -17 % at 63
-  const bool symsweep = !pivoted && h->opt_symsweep;
+  // half sweep (upper block triangle only): on request, or by itself for the two variograms whose measured error stays three
+  // orders inside the 1e-8 / 1e-6 bar (exponential, spherical: profiles/r02_sweep_vs_pivoted_vs_half_sweep_accuracy.txt and the
+  // full-size fixtures) and from 24 block columns on, where it pays
+  const bool symsweep = !pivoted && (h->opt_symsweep > 0 || (h->opt_symsweep < 0 && (h->model == 3 || h->model == 4) && nblk >= 24));
   const long ltiles = symsweep ? (long)nblk * (nblk + 1) / 2 : tiles;
   const unsigned ug = (unsigned)(8 * ((ltiles + 7) / 8));
 #define UPD(GRID, STREAM, CO, CN, R, D, PART, COL)                                                                           \

@@ -126,7 +126,7 @@ def test_update_variogram_model_signatures_are_the_references():
 
 # ------------------------------------------------------------------------------------------- GPU
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", ["default", "half_sweep", "pivoted", "pair_units"])
+@pytest.mark.parametrize("variant", ["default", "full_sweep", "half_sweep", "pivoted", "pair_units"])
 @pytest.mark.parametrize("name", CASES)
 def test_hip_matches_the_reference_on_a_full_size_slab(name, variant):
     g = _full(name)
@@ -134,6 +134,8 @@ def test_hip_matches_the_reference_on_a_full_size_slab(name, variant):
     h = m._get_handle()
     if variant == "half_sweep":  # inverse from the upper block triangle only
         h.set_option("symsweep", 1)
+    elif variant == "full_sweep":  # (default = the library's choice: half sweep for exponential / spherical from 24 block columns on)
+        h.set_option("symsweep", 0)
     elif variant == "pivoted":
         h.set_option("factor", 2)
     elif variant == "pair_units":
