@@ -338,7 +338,7 @@ class ShardedExecutor:
         m, h = self.model, self._handle
         window = kw.pop("n_closest_points", None)
         m._check_backend(backend, window)
-        pts_adj, shape, fmask, extra = m._prepare_points(style, axes, mask, **kw) if kw else m._prepare_points(style, axes, mask)
+        pts_adj, shape, fmask, extra = m._prepare_points(style, axes, mask, kw.get("specified_drift_arrays"), backend)
         npt = pts_adj.shape[0]
         lo, hi = slab_bounds(npt, self.world, self.rank)
         m._set_problem(h)

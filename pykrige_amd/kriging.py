@@ -225,7 +225,7 @@ class _KrigingBase:
         self.last_timing = h.timing()
         return h.get_results()
 
-    def _prepare_points(self, style, axes, mask, specified_drift_arrays=None):
+    def _prepare_points(self, style, axes, mask, specified_drift_arrays=None, backend="vectorized"):
         """Everything execute() does on the host before the solve: returns (pts_adj, shape, mask, extra_rows)."""
         pts, shape, mask = self._points_from(style, axes, mask)
         if getattr(self, "coordinates_type", "euclidean") == "geographic":
@@ -625,15 +625,23 @@ class UniversalKriging(OrdinaryKriging):
         if style != "grid" and style != "masked" and style != "points":
             raise ValueError("style argument must be 'grid', 'points', or 'masked'")
         self._check_backend(backend, None)
-        pts_adj, shape, mask, extra = self._prepare_points(style, (xpoints, ypoints), mask, specified_drift_arrays)
+        pts_adj, shape, mask, extra = self._prepare_points(style, (xpoints, ypoints), mask, specified_drift_arrays, backend)
         z, ss = self._solve(pts_adj, mask, extra)
         return self._finish(z, ss, style, shape, mask, backend)
 
-    def _prepare_points(self, style, axes, mask, specified_drift_arrays=None):
+    def _prepare_points(self, style, axes, mask, specified_drift_arrays=None, backend="vectorized"):
         pts, shape, mask = self._points_from(style, axes, mask)
         rows = []
         if self.external_Z_drift:  # on ORIGINAL coordinates (uk.py:967-971)
-            rows.append(self._calculate_data_point_zscalars(pts[:, 0], pts[:, 1]))
+            if mask is not None and backend != "vectorized":
+                # the reference's loop looks the drift up point by point and skips masked points (uk.py:1034, 1061-1066), so a
+                # masked point outside the drift grid does not raise there; 'vectorized' looks every point up (uk.py:967-971)
+                zs = np.zeros(pts.shape[0])
+                keep = ~mask
+                zs[keep] = self._calculate_data_point_zscalars(pts[keep, 0], pts[keep, 1])
+                rows.append(zs)
+            else:
+                rows.append(self._calculate_data_point_zscalars(pts[:, 0], pts[:, 1]))
         rows.extend(self._spec_rows(style, shape, pts.shape[0], specified_drift_arrays))
         pts_adj = core.adjust_for_anisotropy(pts, self._center(), self._scaling(), self._angle())
         if self.functional_drift:
@@ -781,7 +789,7 @@ class UniversalKriging3D(OrdinaryKriging3D):
         z, ss = self._solve(pts_adj, mask, extra)
         return self._finish(z, ss, style, shape, mask, backend)
 
-    def _prepare_points(self, style, axes, mask, specified_drift_arrays=None):
+    def _prepare_points(self, style, axes, mask, specified_drift_arrays=None, backend="vectorized"):
         pts, shape, mask = self._points_from(style, axes, mask)
         rows = self._spec_rows(style, shape, pts.shape[0], specified_drift_arrays)
         pts_adj = core.adjust_for_anisotropy(pts, self._center(), self._scaling(), self._angle())

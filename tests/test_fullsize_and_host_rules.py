@@ -260,3 +260,24 @@ def test_hip_factor_is_reused_while_the_problem_is_unchanged():
     m.execute("grid", g["gridx"], g["gridy"], backend="loop", n_closest_points=8)  # the moving window replaces the handle's problem
     z6, s6 = m.execute("grid", g["gridx"], g["gridy"], backend="loop")
     assert m.factor_reused is False and np.abs(z6 - g["z"]).max() <= Z_TOL
+
+
+@pytest.mark.gpu
+def test_hip_masked_points_outside_the_external_drift_grid():
+    """uk.py:967-971 looks the external drift up at EVERY point in the vectorized backend (so a masked point outside the drift
+    grid raises there too) but only at the unmasked ones in the loop backend (uk.py:1034, 1061-1066)."""
+    import pykrige_amd as pa
+
+    g = _r2()
+    uk = pa.UniversalKriging(g["zs_x"], g["zs_y"], g["zs_v"], variogram_model="exponential",
+                             variogram_parameters=[1.0, 0.3, 0.02], drift_terms=["external_Z"], external_drift=g["zs_asc_dem"],
+                             external_drift_x=g["zs_asc_ax"], external_drift_y=g["zs_asc_ay"])
+    gx, gy = np.linspace(0.0, 1.4, 8), np.linspace(0.0, 1.0, 5)  # the last two columns lie outside the drift grid (x <= 1.1)
+    mask = np.zeros((5, 8), dtype=bool)
+    mask[:, 6:] = True
+    with pytest.raises(ValueError, match="does not cover"):
+        uk.execute("masked", gx, gy, mask=mask, backend="vectorized")
+    z, ss = uk.execute("masked", gx, gy, mask=mask, backend="loop")
+    zin, sin_ = uk.execute("grid", gx[:6], gy, backend="loop")
+    assert np.array_equal(np.ma.getdata(z)[:, :6], zin) and np.array_equal(np.ma.getdata(ss)[:, :6], sin_)
+    assert np.all(np.ma.getdata(z)[:, 6:] == 0.0) and z.mask[:, 6:].all()
