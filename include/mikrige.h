@@ -126,6 +126,8 @@ int  mik_handle_devices(mik_handle *h);          /* members of the handle's devi
  * "chunk" = points per contraction launch (multiple of 128) ;
  * "lookahead" 0/1/-1 = overlap the next panel's serial chain with the current trailing update in the block sweep
  *   (default -1: from 24 block columns on) ; "diag" 0..3 = diagonal-block inverse kernel variant (default 1) ;
+ * "gate" 0/1/-1 = look-ahead sweep: the trailing update of a step starts only once the next diagonal inverse sits on a CU of its
+ *   own (default -1: where the serial chain bounds the step) ;
  * "symsweep" 0/1/-1 = sweep only the upper block triangle (faster; 10-100 x the rounding error of the full sweep, which stays far
  *   inside the tolerance for the exponential and spherical models and does not for power + drift terms); default -1 = by
  *   itself for exponential / spherical from 24 block columns on ;

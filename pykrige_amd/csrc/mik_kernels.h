@@ -982,6 +982,21 @@ k_update(double* __restrict__ T, long ld, int nblk, int kb, const double* __rest
   }
 }
 
+// The diagonal inverse is the head of the sweep's serial chain: 128 barrier-separated pivot steps, 88 us on a CU of its own and
+// 120 - 200 us on a CU it shares with a trailing-update block (measured, profiles/r02_inverse_timeline.txt).  In the look-ahead
+// sweep it therefore gets a CU of its own: the big trailing update of a step is held back by k_gate until the diagonal inverse
+// of the next step HAS STARTED (flag[1 + block] is raised as its first action) -- it then sits on an empty CU --, and the
+// inverse is launched with ~100 KB of dynamic LDS it never touches, so that no 64-KB update block can join it there.
+__device__ __forceinline__ void diag_started(int* flag, int k0) {
+  if (threadIdx.x == 0) __hip_atomic_store(flag + 1 + k0 / 128, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void k_gate(const int* __restrict__ flag, int idx, int max_polls) {
+  for (int i = 0; i < max_polls; ++i) {  // bounded: a late chain only costs this kernel's time, never a hang
+    if (__hip_atomic_load(flag + 1 + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    __builtin_amdgcn_s_sleep(8);
+  }
+}
+
 // 128x128 in-register Gauss-Jordan inverse of the diagonal block, one 1024-thread workgroup.
 // Thread (w = wave 0..15, lane) owns rows 8w..8w+7, columns lane and lane+64.  Per elimination step
 // the owners publish the pivot row and pivot column through double-buffered LDS; one barrier per step.
@@ -991,6 +1006,7 @@ __global__ void __launch_bounds__(1024) k_diag_inv(const double* __restrict__ T,
                                                    double* __restrict__ Dinv, double* __restrict__ DinvT,
                                                    int* __restrict__ flag) {
   __shared__ double rowk[2][128], colk[2][128];
+  diag_started(flag, k0);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   double al[8], ah[8];  // columns lane / lane+64 of this thread's 8 rows (two arrays: never indexed dynamically)
 #pragma unroll
@@ -1054,6 +1070,7 @@ __global__ void __launch_bounds__(GY * GX) k_diag_inv_t(const double* __restrict
   constexpr int RI = 128 / GY, CJ = 128 / GX, KBN = GY;  // steps per unrolled group
   static_assert(GY <= GX && GX % GY == 0, "row groups nest in column groups");
   __shared__ double rowk[2][128], colk[2][128];
+  diag_started(flag, k0);
   const int ty = threadIdx.x / GX, tx = threadIdx.x % GX;
   double a[RI][CJ];
 #pragma unroll

@@ -174,6 +174,8 @@ struct mik_handle {
   // from a mirrored triangle lose the small residual of the full sweep on ill-conditioned systems (power variogram with
   // drift terms, cond 3e5: |dz| 3e-9 -> 8e-7).  Fine for well-conditioned problems; opt in with the option.
   int opt_symsweep = -1;  // -1 = auto (see run_block_inverse), 0 = off, 1 = on
+  int opt_gate = -1;       // look-ahead sweep: the trailing update waits until the next diagonal inverse has started and leaves
+                           // it a CU of its own (k_gate); -1 = where the serial chain, not the update, is the step period
   int opt_diag = 1;        // diagonal-block inverse variant: 0 = 1024 threads (16 waves x 8 rows), 1 = 16x16 grid, 2 = 16x32, 3 = 32x32
   // points
   long npt_total = 0, npt = 0;
@@ -606,7 +608,7 @@ static int set_group(mik_handle* h, int n) {
     }
     k->is_kid = true;
     k->opt_factor = h->opt_factor, k->opt_sym = h->opt_sym, k->opt_engine = h->opt_engine, k->opt_waves = h->opt_waves;
-    k->opt_chunk = h->opt_chunk, k->opt_symsweep = h->opt_symsweep, k->opt_diag = h->opt_diag, k->opt_lookahead = h->opt_lookahead;
+    k->opt_chunk = h->opt_chunk, k->opt_symsweep = h->opt_symsweep, k->opt_diag = h->opt_diag, k->opt_lookahead = h->opt_lookahead, k->opt_gate = h->opt_gate;
     k->opt_mw_pivot = h->opt_mw_pivot, k->opt_mw_lds_cap = h->opt_mw_lds_cap, k->opt_pairs = h->opt_pairs, k->opt_mw_solver = h->opt_mw_solver;
     k->custom_fn = h->custom_fn, k->custom_user = h->custom_user;
     h->kids.push_back(k);
@@ -691,6 +693,8 @@ int mik_set_option(mik_handle* h, const char* key, double value) {
     h->opt_chunk = ((long)value / 128) * 128;
   } else if (!strcmp(key, "symsweep")) {
     h->opt_symsweep = value < 0.0 ? -1 : (value != 0.0);
+  } else if (!strcmp(key, "gate")) {
+    h->opt_gate = value < 0.0 ? -1 : (value != 0.0);
   } else if (!strcmp(key, "diag")) {
     h->opt_diag = (int)value;
   } else if (!strcmp(key, "lookahead")) {
@@ -872,8 +876,19 @@ static int ensure_factor_buffers(mik_handle* h) {
   return MIK_OK;
 }
 
-static void launch_diag_inv(mik_handle* h, hipStream_t st, const double* T, long ld, int k0, int nspd, double* dinv, double* dinvT) {
+static void launch_diag_inv(mik_handle* h, hipStream_t st, const double* T, long ld, int k0, int nspd, double* dinv, double* dinvT,
+                            bool own_cu = false) {
   int* flag = h->flag.as<int>();
+  if (own_cu && h->opt_diag == 1) {  // keep trailing-update blocks (64 KB of LDS each) off this block's CU: see k_gate
+    constexpr int pad = 100 * 1024;
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)k_diag_inv_t<16, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, pad);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((k_diag_inv_t<16, 16>), dim3(1), dim3(256), pad, st, T, ld, k0, nspd, dinv, dinvT, flag);
+    return;
+  }
   switch (h->opt_diag) {
     case 1: hipLaunchKernelGGL((k_diag_inv_t<16, 16>), dim3(1), dim3(256), 0, st, T, ld, k0, nspd, dinv, dinvT, flag); break;
     case 2: hipLaunchKernelGGL((k_diag_inv_t<16, 32>), dim3(1), dim3(512), 0, st, T, ld, k0, nspd, dinv, dinvT, flag); break;
@@ -891,8 +906,8 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
   MIKC(h->Rt.ensure(panel));
   MIKC(h->Dinv.ensure(sizeof(double) * 128 * 128));
   MIKC(h->DinvT.ensure(sizeof(double) * 128 * 128));
-  MIKC(h->flag.ensure(sizeof(int)));
-  HIPC(hipMemsetAsync(h->flag.p, 0, sizeof(int), h->stream));
+  MIKC(h->flag.ensure(sizeof(int) * (size_t)(nblk + 2)));  // [0] = pivot flags, [1 + kb] = "diagonal inverse kb has started"
+  HIPC(hipMemsetAsync(h->flag.p, 0, sizeof(int) * (size_t)(nblk + 2), h->stream));
   const int ncand = Mp / 32;  // one candidate per 32-row block of the pivot-search panel (MIK_PIV_ROWS)
   if (pivoted) {
     MIKC(h->TKt.ensure(panel));
@@ -924,6 +939,10 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
                          (const double*)(R), (const double*)(D), PART, COL);                                                 \
   } while (0)
   const bool lookahead = h->opt_lookahead < 0 ? nblk >= 24 : h->opt_lookahead != 0;
+  // measured (profiles/r02_inverse_timeline.txt): with up to ~2400 update tiles per step (N=5000 full sweep: 1600, N=8000 half
+  // sweep: 2016) the serial chain is the step period and giving its head a CU of its own pays (-14 % / -10 %); with 3969 tiles
+  // (N=8000 full sweep) the update is, and holding it back costs 3 %
+  const bool gate = h->opt_gate < 0 ? ltiles <= 2400 : h->opt_gate != 0;
   if (!pivoted && nblk > 1 && lookahead) {
     // Look-ahead sweep.  Step kb's update is split: block column kb+1 first (nblk tiles), then -- on the second stream --
     // the whole panel chain of step kb+1 (diagonal inverse, panel copy, C_new, R^T; a serial ~160 us on few CUs) runs
@@ -945,7 +964,7 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
     double* dinvT[2] = {h->DinvT.as<double>(), h->DinvT2.as<double>()};
     auto panel_chain = [&](hipStream_t st, int kb, int set) {
       const int k0 = kb * 128;
-      launch_diag_inv(h, st, (const double*)T, ld, k0, nspd, dinv[set], dinvT[set]);
+      launch_diag_inv(h, st, (const double*)T, ld, k0, nspd, dinv[set], dinvT[set], gate && st == h->stream2);
       if (symsweep) hipLaunchKernelGGL(k_copy_panel_sym, dim3(Mp / 64), dim3(256), 0, st, (const double*)T, ld, k0, Mp, cold[set]);
       else hipLaunchKernelGGL(k_copy_panel, dim3(pgrid), dim3(256), 0, st, (const double*)T, ld, k0, Mp, cold[set]);
       hipLaunchKernelGGL(k_panel, dim3(nblk), dim3(256), 0, st, (const double*)cold[set], 128L, (const double*)dinvT[set], -1.0,
@@ -961,6 +980,8 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
         HIPC(hipStreamWaitEvent(h->stream2, h->la_events[2 * kb], 0));
         panel_chain(h->stream2, kb + 1, set ^ 1);
         HIPC(hipEventRecord(h->la_events[2 * kb + 1], h->stream2));
+        if (gate)  // hold the big update back until the next diagonal inverse sits on a CU (see k_gate)
+          hipLaunchKernelGGL(k_gate, dim3(1), dim3(1), 0, h->stream, (const int*)h->flag.as<int>(), kb + 1, 20000);
         UPD(dim3(ug), h->stream, cold[set], cnew[set], rt[set], dinv[set], 2, kb + 1);
         HIPC(hipStreamWaitEvent(h->stream, h->la_events[2 * kb + 1], 0));
       } else {

@@ -20,7 +20,7 @@ int main(int argc,char**argv){
   CK(hipMalloc(&T,sizeof(double)*(size_t)Mp*Mp)); CK(hipMalloc(&Bt,sizeof(double)*(size_t)P*Mp));
   CK(hipMalloc(&part,sizeof(double)*(size_t)P*nblk)); CK(hipMalloc(&Dinv,131072)); CK(hipMalloc(&DinvT,131072));
   CK(hipMalloc(&Cold,sizeof(double)*(size_t)Mp*128)); CK(hipMalloc(&Cnew,sizeof(double)*(size_t)Mp*128)); CK(hipMalloc(&Rt,sizeof(double)*(size_t)Mp*128));
-  CK(hipMalloc(&flag,4));
+  CK(hipMalloc(&flag,4096)); CK(hipMemset(flag,0,4096));
   { std::vector<double> h((size_t)Mp*Mp); srand(1);
     for(size_t i=0;i<h.size();++i) h[i]=(rand()/(double)RAND_MAX-0.5)*0.01;
     for(int i=0;i<Mp;++i) h[(size_t)i*Mp+i]=1.0+0.1*(i%7);
@@ -100,6 +100,9 @@ int main(int argc,char**argv){
   // inverse pieces
   ms=timeit([&]{hipLaunchKernelGGL(k_diag_inv,dim3(1),dim3(1024),0,0,(const double*)T,(long)Mp,0,0,Dinv,DinvT,flag);},10);
   printf("k_diag_inv (1024 thr) back-to-back: %.1f us\n",ms*1e3);
+  ms=timeit([&]{hipLaunchKernelGGL((k_diag_inv_t<16,16>),dim3(1),dim3(256),0,0,(const double*)T,(long)Mp,0,0,Dinv,DinvT,flag);},10);
+  printf("k_diag_inv_t<16,16> (scalar pivots) back-to-back: %.1f us\n",ms*1e3);
+
   const long ut=(long)nblk*nblk; const unsigned ug=(unsigned)(8*((ut+7)/8));
   ms=timeit([&]{hipLaunchKernelGGL(k_update<false>,dim3(ug),dim3(256),0,0,T,(long)Mp,nblk,1,(const double*)Cold,(const double*)Cnew,(const double*)Rt,(const double*)Dinv,0,0);},5);
   printf("k_update: %.1f us  %.2f TF/s\n",ms*1e3, 2.0*Mp*(double)Mp*128/ms*1e-9);
