@@ -881,11 +881,8 @@ static void launch_diag_inv(mik_handle* h, hipStream_t st, const double* T, long
   int* flag = h->flag.as<int>();
   if (own_cu && h->opt_diag == 1) {  // keep trailing-update blocks (64 KB of LDS each) off this block's CU: see k_gate
     constexpr int pad = 100 * 1024;
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)k_diag_inv_t<16, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, pad);
-      attr_set = true;
-    }
+    // per launch: the attribute belongs to the function object of the CURRENT device (device groups factor on several)
+    (void)hipFuncSetAttribute((const void*)k_diag_inv_t<16, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, pad);
     hipLaunchKernelGGL((k_diag_inv_t<16, 16>), dim3(1), dim3(256), pad, st, T, ld, k0, nspd, dinv, dinvT, flag);
     return;
   }
