@@ -118,6 +118,8 @@ void mik_destroy(mik_handle *h);
 int  mik_set_devices(int n);
 int  mik_handle_set_devices(mik_handle *h, int n);
 int  mik_handle_devices(mik_handle *h);          /* members of the handle's device group (1 = single device) */
+int  mik_slab_of(int64_t n, int members, int i, int64_t *lo, int64_t *count); /* the slab of n unmasked points member i gets
+                                                    (contiguous, cut at multiples of 128 points); needs no GPU */
 
 /* options: "factor" 0=auto 1=sweep 2=pivoted ; "symmetric" 0/1 (contraction uses A_inv symmetry) ;
  * "engine" 0 = MFMA f64 contraction, 1 = VALU (v_fma_f64) contraction ; "waves" 4 | 8 = wavefronts per contraction block ;

@@ -59,6 +59,7 @@ SIGNATURES = {
     "mik_set_devices": (C.c_int, [C.c_int]),
     "mik_handle_set_devices": (C.c_int, [C.c_void_p, C.c_int]),
     "mik_handle_devices": (C.c_int, [C.c_void_p]),
+    "mik_slab_of": (C.c_int, [C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "mik_get_device_timing": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(MikTiming)]),
     "mik_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double]),
     "mik_set_problem": (C.c_int, [C.c_void_p, C.POINTER(MikProblem)]),
@@ -299,6 +300,13 @@ class Handle:
 
     def bcast_factor(self, root=0):
         check(self._lib.mik_bcast_factor(self._h, int(root)))
+
+
+def slab_of(n, members, i):
+    """(lo, count) of the contiguous slab of n unmasked points that member i of a device group of `members` GPUs kriges."""
+    lo, cnt = C.c_int64(0), C.c_int64(0)
+    check(load().mik_slab_of(int(n), int(members), int(i), C.byref(lo), C.byref(cnt)))
+    return lo.value, cnt.value
 
 
 def set_devices(n):

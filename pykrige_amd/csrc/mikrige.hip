@@ -1381,6 +1381,15 @@ static void slab_of(long n, int members, int i, long* lo, long* cnt) {
   *cnt = cut(i + 1) - *lo;
 }
 
+int mik_slab_of(int64_t n, int members, int i, int64_t* lo, int64_t* count) {
+  if (n < 0 || members < 1 || i < 0 || i >= members || !lo || !count) return fail(MIK_EINVAL, "mik_slab_of: bad argument");
+  long l, c;
+  slab_of((long)n, members, i, &l, &c);
+  *lo = l;
+  *count = c;
+  return MIK_OK;
+}
+
 int mik_set_points(mik_handle* h, const mik_points* g) {
   if (!h || !g) return fail(MIK_EINVAL, "mik_set_points: NULL argument");
   if (!h->have_problem) return fail(MIK_ESTATE, "mik_set_points: set the problem first");

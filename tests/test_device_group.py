@@ -26,6 +26,23 @@ def test_set_devices_argument_checks_need_no_gpu():
     lib.set_devices(1)
 
 
+def test_device_group_slabs_partition_the_points():
+    """The library's slab rule (mik_set_points on a device group): contiguous, complete, cut at multiples of 128 points (the
+    contraction's tile), balanced to within one tile, empty slabs when there are fewer tiles than devices.  Host arithmetic."""
+    lib = _lib()
+    for n in (0, 1, 127, 128, 129, 5000, 1000000, 16777216, 16777217):
+        for members in (1, 2, 3, 4, 8):
+            spans = [lib.slab_of(n, members, i) for i in range(members)]
+            assert spans[0][0] == 0 and sum(c for _, c in spans) == n
+            for (lo, c), (lo2, _) in zip(spans, spans[1:]):
+                assert lo + c == lo2 and lo2 % 128 == 0
+            if n >= 128 * members * 8:
+                counts = [c for _, c in spans]
+                assert max(counts) - min(counts) <= 128 + n % 128
+    with pytest.raises(ValueError):
+        lib.slab_of(10, 2, 2)
+
+
 def _problem(n=700, ndim=2, seed=11, model="exponential", params=(0.9, 0.3, 0.1)):
     c, v = fx.synth(seed, n, ndim)
     return c, v, model, list(params)
