@@ -71,7 +71,9 @@ typedef struct mik_problem {
   int32_t geographic;       /* coordinates_type == 'geographic' (ordinary 2D only): xs/ys and px/py are lon/lat in
                                degrees, distances are great-circle degrees (core.py:36-97; ok.py:634-640, 990-996) */
   int32_t pseudo_inv;       /* self.pseudo_inv: 0 = inverse; 1 = 'pinv', 2 = 'pinvh' (core.py:33 P_INV): Moore-Penrose
-                               pseudo-inverse on the device (one-sided Jacobi; the two types coincide on a symmetric matrix) */
+                               pseudo-inverse on the device (the two types coincide on a symmetric matrix): the regular inverse of
+                               the matrix deflated by the null space of duplicated stations when that provably is it, else a
+                               one-sided Jacobi SVD */
 } mik_problem;
 
 /* The prediction points handed to _exec_vector: adjusted coordinates (SoA), mask, drift rows. */
@@ -91,7 +93,7 @@ typedef struct mik_timing {
   double predict_ms;      /* whole mik_predict on the stream */
   int64_t contract_launches;
   double contract_flops_executed; /* flops the contraction kernel really executed (symmetric form: ~M^2/pt) */
-  int32_t factor_path;    /* 1 = unpivoted symmetric block sweep on the SPD-shifted matrix, 2 = pivoted block Gauss-Jordan, 3 = caller-supplied inverse, 4 = device pseudo-inverse */
+  int32_t factor_path;    /* 1 = unpivoted symmetric block sweep on the SPD-shifted matrix, 2 = pivoted block Gauss-Jordan, 3 = caller-supplied inverse, 4 = device pseudo-inverse (one-sided Jacobi), 5 = pseudo-inverse as the regular inverse of the matrix deflated by the duplicated stations' null space (verified with probe vectors) */
   int32_t symmetric;      /* 1 = contraction used the symmetric half product */
   int32_t engine;         /* 0 = v_mfma_f64_4x4x4_4b_f64 contraction, 1 = v_fma_f64 register-tiled contraction */
   int32_t reserved;       /* mik_get_device_timing: the HIP device index of that group member */
@@ -128,6 +130,7 @@ int  mik_slab_of(int64_t n, int members, int i, int64_t *lo, int64_t *count); /*
  * "chunk" = points per contraction launch (multiple of 128) ;
  * "lookahead" 0/1/-1 = overlap the next panel's serial chain with the current trailing update in the block sweep
  *   (default -1: from 24 block columns on) ; "diag" 0..3 = diagonal-block inverse kernel variant (default 1) ;
+ * "pinv_fast" 0/1 = pseudo_inv: try the deflated regular inverse before the Jacobi pseudo-inverse (default 1) ;
  * "gate" 0/1/-1 = look-ahead sweep: the trailing update of a step starts only once the next diagonal inverse sits on a CU of its
  *   own (default -1: where the serial chain bounds the step) ;
  * "symsweep" 0/1/-1 = sweep only the upper block triangle (faster; 10-100 x the rounding error of the full sweep, which stays far

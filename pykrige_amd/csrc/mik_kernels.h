@@ -1386,6 +1386,24 @@ __global__ void k_selftest_mfma4(double* out /*4x16 row-major*/) {
 //   k_rownorm2  : sigma_i^2
 //   k_pinv_gemm : out = B^T diag(d) W, 64 x 64 tiles
 // ------------------------------------------------------------------------------------------------
+// pseudo-inverse, fast path: T[i][j] += sign * val for a short coordinate list (the projector onto the null space spanned
+// by duplicated stations), and a plain row-per-wavefront mat-vec for the probes that verify the result
+__global__ void __launch_bounds__(256) k_coo_add(double* __restrict__ T, long ld, const int* __restrict__ ij,
+                                                 const double* __restrict__ val, int n, double sign) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e < n) T[(long)ij[2 * e] * ld + ij[2 * e + 1]] += sign * val[e];
+}
+__global__ void __launch_bounds__(256) k_matvec(const double* __restrict__ A, long ld, int m, const double* __restrict__ x,
+                                                double* __restrict__ y) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= m) return;
+  const double* r = A + (long)row * ld;
+  double s = 0.0;
+  for (int b = lane; b < m; b += 64) s += r[b] * x[b];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) y[row] = s;
+}
+
 __global__ void __launch_bounds__(256) k_set_identity(double* __restrict__ W, long ld, int n) {
   const long e = (long)blockIdx.x * 256 + threadIdx.x;
   if (e >= (long)n * ld) return;

@@ -174,6 +174,7 @@ struct mik_handle {
   // from a mirrored triangle lose the small residual of the full sweep on ill-conditioned systems (power variogram with
   // drift terms, cond 3e5: |dz| 3e-9 -> 8e-7).  Fine for well-conditioned problems; opt in with the option.
   int opt_symsweep = -1;  // -1 = auto (see run_block_inverse), 0 = off, 1 = on
+  int opt_pinv_fast = 1;   // pseudo_inv: try the deflated regular inverse (duplicated stations) before the Jacobi pseudo-inverse
   int opt_gate = -1;       // look-ahead sweep: the trailing update waits until the next diagonal inverse has started and leaves
                            // it a CU of its own (k_gate); -1 = where the serial chain, not the update, is the step period
   int opt_diag = 1;        // diagonal-block inverse variant: 0 = 1024 threads (16 waves x 8 rows), 1 = 16x16 grid, 2 = 16x32, 3 = 32x32
@@ -608,7 +609,7 @@ static int set_group(mik_handle* h, int n) {
     }
     k->is_kid = true;
     k->opt_factor = h->opt_factor, k->opt_sym = h->opt_sym, k->opt_engine = h->opt_engine, k->opt_waves = h->opt_waves;
-    k->opt_chunk = h->opt_chunk, k->opt_symsweep = h->opt_symsweep, k->opt_diag = h->opt_diag, k->opt_lookahead = h->opt_lookahead, k->opt_gate = h->opt_gate;
+    k->opt_chunk = h->opt_chunk, k->opt_symsweep = h->opt_symsweep, k->opt_diag = h->opt_diag, k->opt_lookahead = h->opt_lookahead, k->opt_gate = h->opt_gate, k->opt_pinv_fast = h->opt_pinv_fast;
     k->opt_mw_pivot = h->opt_mw_pivot, k->opt_mw_lds_cap = h->opt_mw_lds_cap, k->opt_pairs = h->opt_pairs, k->opt_mw_solver = h->opt_mw_solver;
     k->custom_fn = h->custom_fn, k->custom_user = h->custom_user;
     h->kids.push_back(k);
@@ -693,6 +694,8 @@ int mik_set_option(mik_handle* h, const char* key, double value) {
     h->opt_chunk = ((long)value / 128) * 128;
   } else if (!strcmp(key, "symsweep")) {
     h->opt_symsweep = value < 0.0 ? -1 : (value != 0.0);
+  } else if (!strcmp(key, "pinv_fast")) {
+    h->opt_pinv_fast = value != 0.0;
   } else if (!strcmp(key, "gate")) {
     h->opt_gate = value < 0.0 ? -1 : (value != 0.0);
   } else if (!strcmp(key, "diag")) {
@@ -838,9 +841,9 @@ static int custom_roundtrip(mik_handle* h, double* dev, long rows, long cols, lo
   return MIK_OK;
 }
 
-static int launch_assemble(mik_handle* h, double shift) {
+static int launch_assemble(mik_handle* h, double shift, double* dst = nullptr) {
   AsmArgs a{};
-  a.T = h->T.as<double>();
+  a.T = dst ? dst : h->T.as<double>();
   a.ld = h->Mp;
   a.N = h->N;
   a.p = h->p;
@@ -1034,6 +1037,113 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
   return MIK_OK;
 }
 
+// Pseudo-inverse without an SVD for the case it exists for: DUPLICATED STATIONS (core.py:33, "redundant points are averaged").
+// With a zero nugget two stations at the same place give two identical rows, i.e. the null vector e_i - e_j; for a symmetric A
+// whose null space has the orthonormal basis N,  A + N N^T  is regular and  pinv(A) = (A + N N^T)^-1 - N N^T.  A group of m
+// coincident stations contributes the projector I_m - 11^T / m on its index set.  So: find the groups on the host (exact
+// coordinate equality -- what makes the reference's distances exactly zero), add the projectors, invert with the ordinary
+// shifted sweep (the station block C + N N^T is positive definite again), subtract them.  Nothing is assumed: the result is
+// VERIFIED with probe vectors -- A X A v = A v to 1e-8 and an estimated condition number far below SciPy's cut-off
+// 1 / (M eps), i.e. no singular value the pseudo-inverse would have dropped -- and on any doubt (other rank deficiencies,
+// near-singular matrices, a flagged pivot) *done stays false and the caller runs the Jacobi pseudo-inverse.
+static int run_deflated_inverse(mik_handle* h, bool* done) {
+  *done = false;
+  if (h->model == MIK_MODEL_CUSTOM || !h->opt_pinv_fast) return MIK_OK;
+  const int N = h->N, M = h->M;
+  const long ld = h->Mp;
+  const double nugget = (h->v.model == 0) ? h->v.p1 : h->v.p2;
+  std::vector<int> ij;
+  std::vector<double> val;
+  if (nugget == 0.0) {
+    std::vector<int> order(N);
+    for (int i = 0; i < N; ++i) order[i] = i;
+    const bool three = h->ndim == 3;
+    auto less = [&](int a, int b) {
+      if (h->hxs[a] != h->hxs[b]) return h->hxs[a] < h->hxs[b];
+      if (h->hys[a] != h->hys[b]) return h->hys[a] < h->hys[b];
+      if (three && h->hzs[a] != h->hzs[b]) return h->hzs[a] < h->hzs[b];
+      return a < b;
+    };
+    auto same = [&](int a, int b) { return h->hxs[a] == h->hxs[b] && h->hys[a] == h->hys[b] && (!three || h->hzs[a] == h->hzs[b]); };
+    std::sort(order.begin(), order.end(), less);
+    for (int s0 = 0; s0 < N;) {
+      int s1 = s0 + 1;
+      while (s1 < N && same(order[s0], order[s1])) ++s1;
+      const int m = s1 - s0;
+      if (m > 1) {
+        if ((long)val.size() + (long)m * m > 4000000L) return MIK_OK;  // absurdly many duplicates: leave it to the general path
+        for (int a = s0; a < s1; ++a)
+          for (int b = s0; b < s1; ++b) {
+            ij.push_back(order[a]);
+            ij.push_back(order[b]);
+            val.push_back((a == b ? 1.0 : 0.0) - 1.0 / m);
+          }
+      }
+      s0 = s1;
+    }
+  }
+  const int ne = (int)val.size();
+  DevBuf dij, dval, A2, vec;
+  if (ne) {
+    MIKC(dij.ensure(sizeof(int) * ij.size()));
+    MIKC(dval.ensure(sizeof(double) * val.size()));
+    HIPC(hipMemcpyAsync(dij.p, ij.data(), sizeof(int) * ij.size(), hipMemcpyHostToDevice, h->stream));
+    HIPC(hipMemcpyAsync(dval.p, val.data(), sizeof(double) * val.size(), hipMemcpyHostToDevice, h->stream));
+  }
+  const double shift = h->shift_guess;
+  MIKC(launch_assemble(h, shift));
+  if (ne) hipLaunchKernelGGL(k_coo_add, dim3((ne + 255) / 256), dim3(256), 0, h->stream, h->T.as<double>(), ld, (const int*)dij.as<int>(),
+                             (const double*)dval.as<double>(), ne, 1.0);
+  int flag = 0;
+  MIKC(run_block_inverse(h, false, N, &flag));
+  if (flag) return MIK_OK;
+  hipLaunchKernelGGL(k_add_diag, dim3(1), dim3(1), 0, h->stream, h->T.as<double>(), ld, M - 1, shift);
+  if (ne) hipLaunchKernelGGL(k_coo_add, dim3((ne + 255) / 256), dim3(256), 0, h->stream, h->T.as<double>(), ld, (const int*)dij.as<int>(),
+                             (const double*)dval.as<double>(), ne, -1.0);
+  // verification against the matrix itself (assembled again, unshifted, into a scratch buffer)
+  MIKC(A2.ensure(sizeof(double) * (size_t)h->Mp * h->Mp));
+  MIKC(launch_assemble(h, 0.0, A2.as<double>()));
+  constexpr int NPROBE = 3;
+  MIKC(vec.ensure(sizeof(double) * 4 * (size_t)h->Mp));
+  double *dv = vec.as<double>(), *dy = dv + h->Mp, *dw = dy + h->Mp, *dr = dw + h->Mp;
+  std::vector<double> hv(M), hy(M), hw(M), hr(M);
+  unsigned long long seed = 0x9E3779B97F4A7C15ull;
+  double worst_res = 0.0, est_a = 0.0, est_x = 0.0;
+  const unsigned mg = (unsigned)((M + 3) / 4);
+  auto norm = [&](const std::vector<double>& a) {
+    double s2 = 0.0;
+    for (double x : a) s2 += x * x;
+    return std::sqrt(s2);
+  };
+  for (int pr = 0; pr < NPROBE; ++pr) {
+    for (int i = 0; i < M; ++i) {
+      seed = seed * 6364136223846793005ull + 1442695040888963407ull;
+      hv[i] = (double)((seed >> 11) & 0xFFFFFFFFull) / 4294967296.0 - 0.5;
+    }
+    HIPC(hipMemcpyAsync(dv, hv.data(), sizeof(double) * M, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_matvec, dim3(mg), dim3(256), 0, h->stream, (const double*)A2.as<double>(), ld, M, (const double*)dv, dy);  // y = A v
+    hipLaunchKernelGGL(k_matvec, dim3(mg), dim3(256), 0, h->stream, (const double*)h->T.as<double>(), ld, M, (const double*)dy, dw);  // w = X y
+    hipLaunchKernelGGL(k_matvec, dim3(mg), dim3(256), 0, h->stream, (const double*)A2.as<double>(), ld, M, (const double*)dw, dr);  // r = A w
+    HIPC(hipMemcpyAsync(hy.data(), dy, sizeof(double) * M, hipMemcpyDeviceToHost, h->stream));
+    HIPC(hipMemcpyAsync(hr.data(), dr, sizeof(double) * M, hipMemcpyDeviceToHost, h->stream));
+    hipLaunchKernelGGL(k_matvec, dim3(mg), dim3(256), 0, h->stream, (const double*)h->T.as<double>(), ld, M, (const double*)dv, dw);  // X v
+    HIPC(hipMemcpyAsync(hw.data(), dw, sizeof(double) * M, hipMemcpyDeviceToHost, h->stream));
+    HIPC(hipStreamSynchronize(h->stream));
+    const double nv = norm(hv), ny = norm(hy);
+    double d2 = 0.0;
+    for (int i = 0; i < M; ++i) d2 += (hr[i] - hy[i]) * (hr[i] - hy[i]);
+    if (!(ny > 0.0) || !std::isfinite(ny)) return MIK_OK;
+    worst_res = std::max(worst_res, std::sqrt(d2) / ny);
+    est_a = std::max(est_a, ny / nv);
+    est_x = std::max(est_x, norm(hw) / nv);
+  }
+  HIPC(hipGetLastError());
+  const double eps = 2.220446049250313e-16;
+  if (!(worst_res <= 1e-8) || !(est_a * est_x <= 1e-3 / ((double)M * eps))) return MIK_OK;  // not provably the pseudo-inverse
+  *done = true;
+  return MIK_OK;
+}
+
 static int finish_factor(mik_handle* h) {
   hipLaunchKernelGGL(k_cvec, dim3((h->Mp + 3) / 4), dim3(256), 0, h->stream, (const double*)h->T.as<double>(),
                      (long)h->Mp, h->M, h->N, (const double*)h->vals.as<double>(), h->cvec.as<double>(), h->Mp);
@@ -1072,6 +1182,20 @@ static int one_factor(mik_handle* h) {
     return finish_factor(h);
   }
   if (h->pinv) {
+    {
+      HIPC(hipEventRecord(h->evpool[0], h->stream));
+      bool done = false;
+      MIKC(run_deflated_inverse(h, &done));
+      if (done) {
+        HIPC(hipEventRecord(h->evpool[2], h->stream));
+        HIPC(hipStreamSynchronize(h->stream));
+        float ms0 = 0.f;
+        HIPC(hipEventElapsedTime(&ms0, h->evpool[0], h->evpool[2]));
+        h->tm.invert_ms = ms0;
+        h->tm.factor_path = 5;
+        return finish_factor(h);
+      }
+    }
     HIPC(hipEventRecord(h->evpool[0], h->stream));
     MIKC(launch_assemble(h, 0.0));
     HIPC(hipEventRecord(h->evpool[1], h->stream));

@@ -139,17 +139,18 @@ def test_external_drift_known_answer_and_pseudo_inverse():
         ok = pa.OrdinaryKriging(d[:, 0], d[:, 1], d[:, 2], variogram_parameters=[1.0, 0.0], pseudo_inv=True,
                                 pseudo_inv_type=p_type)
         z, ss = ok.execute("grid", np.linspace(0, 1, 5), np.linspace(0, 1, 4), backend="loop")
-        assert ok.last_timing["factor_path"] == 4  # pseudo-inverse on the device (one-sided Jacobi), not a host SVD
+        assert ok.last_timing["factor_path"] in (4, 5)  # pseudo-inverse on the device (deflated inverse or Jacobi), not a host SVD
         np.testing.assert_allclose(z, g["z_" + p_type], rtol=0, atol=1e-8)
         np.testing.assert_allclose(ss, g["ss_" + p_type], rtol=0, atol=1e-6)
         z1, _ = ok.execute("points", 0.0, 0.0, backend="loop")
         assert np.isclose(z1.item(), 2.0)  # mean of the redundant data
 
 
+@pytest.mark.parametrize("fast", [1, 0])
 @pytest.mark.parametrize("n,drift", [(301, False), (257, True)])
-def test_device_pseudo_inverse_against_scipy(n, drift):
-    """mik_problem.pseudo_inv: the Moore-Penrose pseudo-inverse computed on the device (cyclic one-sided Jacobi, cut-off
-    M eps sigma_max) against scipy.linalg.pinv of the same kriging matrix -- odd matrix orders (tournament padding),
+def test_device_pseudo_inverse_against_scipy(n, drift, fast):
+    """mik_problem.pseudo_inv: the Moore-Penrose pseudo-inverse computed on the device (deflated regular inverse, or cyclic
+    one-sided Jacobi with cut-off M eps sigma_max) against scipy.linalg.pinv of the same kriging matrix -- odd matrix orders (tournament padding),
     several duplicated stations (rank deficiency > 1), with and without drift rows -- and the kriging through it
     against the oracle fed with SciPy's pseudo-inverse (ok.py:660-661, uk.py:932-933)."""
     import scipy.linalg
@@ -163,8 +164,11 @@ def test_device_pseudo_inverse_against_scipy(n, drift):
     user = [1.0, 0.5, 0.0]
     kw = dict(variogram_model="exponential", variogram_parameters=user, pseudo_inv=True, pseudo_inv_type="pinv")
     m = pa.UniversalKriging(x, y, v, drift_terms=["regional_linear"], **kw) if drift else pa.OrdinaryKriging(x, y, v, **kw)
+    # fast = 1: the regular inverse of the matrix deflated by the duplicated stations' null space, verified with probe
+    # vectors (factor_path 5); fast = 0: the general one-sided Jacobi pseudo-inverse (factor_path 4)
+    m._get_handle().set_option("pinv_fast", fast)
     z, ss = m.execute("points", pts[:, 0], pts[:, 1], backend="loop")
-    assert m.last_timing["factor_path"] == 4
+    assert m.last_timing["factor_path"] == (5 if fast else 4)
     st = ko.KrigingState(ndim=2, coords_orig=np.stack([x, y], 1), values=v, model="exponential",
                          params=ko.internal_parameters("exponential", user), regional_linear=drift)
     a = ko.kriging_matrix(st)
@@ -732,3 +736,39 @@ def test_integration_md_stub_runs_as_written():
     np.testing.assert_allclose(z[~mask], zr, rtol=0, atol=Z_TOL)
     np.testing.assert_allclose(ss[~mask], sr, rtol=0, atol=SS_TOL)
     assert np.all(z[mask] == 0.0) and np.all(ss[mask] == 0.0)
+
+
+def test_pseudo_inverse_fast_path_refuses_what_it_cannot_prove():
+    """The deflated-inverse shortcut of pseudo_inv covers duplicated stations (zero nugget).  Other rank deficiencies -- here
+    collinear stations under a regional-linear drift, which make two drift columns linearly dependent -- must end in the general
+    Jacobi pseudo-inverse (factor_path 4), and a regular matrix must come back as its plain inverse (factor_path 5)."""
+    import scipy.linalg
+
+    lib = _lib()
+    rng = np.random.default_rng(77)
+    n = 60
+    x = rng.random(n)
+    y = 2.0 * x + 0.25  # every station on one line: the x and y drift columns are dependent (rank M - 1), no duplicates
+    v = np.sin(4 * x) + 0.1 * rng.standard_normal(n)
+    st = ko.KrigingState(ndim=2, coords_orig=np.stack([x, y], 1), values=v, model="exponential",
+                         params=ko.internal_parameters("exponential", [1.0, 0.5, 0.05]), regional_linear=True)
+    a = ko.kriging_matrix(st)
+    assert np.linalg.matrix_rank(a) == a.shape[0] - 1
+    h = lib.Handle(0)
+    h.set_problem(ndim=2, xs=st.coords_adj[:, 0], ys=st.coords_adj[:, 1], zs=None, values=v, model_id=lib.MODEL_IDS["exponential"],
+                  params=st.params, regional_linear=True, pseudo_inv=1)
+    h.factor()
+    assert h.timing()["factor_path"] == 4
+    pinv = scipy.linalg.pinv(a)
+    assert np.abs(h.get_matrix(1) - pinv).max() <= 1e-8 * np.abs(pinv).max()
+    # regular matrix, pseudo_inv requested: the plain inverse, verified
+    y2 = rng.random(n)
+    st2 = ko.KrigingState(ndim=2, coords_orig=np.stack([x, y2], 1), values=v, model="exponential",
+                          params=ko.internal_parameters("exponential", [1.0, 0.5, 0.05]))
+    h.set_problem(ndim=2, xs=st2.coords_adj[:, 0], ys=st2.coords_adj[:, 1], zs=None, values=v, model_id=lib.MODEL_IDS["exponential"],
+                  params=st2.params, pseudo_inv=1)
+    h.factor()
+    assert h.timing()["factor_path"] == 5
+    inv = scipy.linalg.inv(ko.kriging_matrix(st2))
+    assert np.abs(h.get_matrix(1) - inv).max() <= 1e-9 * np.abs(inv).max()
+    h.close()
