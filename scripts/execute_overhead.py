@@ -1,6 +1,7 @@
 """End-to-end OrdinaryKriging.execute('grid') wall time at config 2 vs the library's own predict time: what the host-side
 Python (meshgrid, anisotropy adjustment, H2D / D2H, reshapes) adds."""
-import cProfile, pstats, sys, time
+import cProfile, os, pstats, sys, time
+os.environ["MIK_FACTOR_CACHE"] = "0"  # every execute() assembles and inverts, as the reference does
 import numpy as np
 sys.path.insert(0, ".")
 from bench import CONFIGS, synth
