@@ -987,6 +987,17 @@ k_update(double* __restrict__ T, long ld, int nblk, int kb, const double* __rest
 // sweep it therefore gets a CU of its own: the big trailing update of a step is held back by k_gate until the diagonal inverse
 // of the next step HAS STARTED (flag[1 + block] is raised as its first action) -- it then sits on an empty CU --, and the
 // inverse is launched with ~100 KB of dynamic LDS it never touches, so that no 64-KB update block can join it there.
+// 1 / p for the pivots of the diagonal-block inverse: hardware reciprocal estimate + two Newton steps (5 dependent operations)
+// instead of the ~35-instruction IEEE division sequence -- it sits on the serial path of every one of the 128 pivot steps.
+// Within 1 ulp of the correctly rounded quotient; zero / non-finite pivots are flagged by the callers before the result is used.
+__device__ __forceinline__ double pivot_recip(double p) {
+  double r = __builtin_amdgcn_rcp(p);
+  double e = __builtin_fma(-p, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-p, r, 1.0);
+  return __builtin_fma(r, e, r);
+}
+
 __device__ __forceinline__ void diag_started(int* flag, int k0) {
   if (threadIdx.x == 0) __hip_atomic_store(flag + 1 + k0 / 128, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -1035,7 +1046,7 @@ __global__ void __launch_bounds__(1024) k_diag_inv(const double* __restrict__ T,
       const double piv = rowk[pb][k];
       if (!(fabs(piv) > 1e-300) || !isfinite(piv)) bad |= 1;
       if ((k0 + k) < nspd && !(piv > 0.0)) bad |= 2;
-      const double pinv = 1.0 / piv;
+      const double pinv = pivot_recip(piv);
       const double rk0 = rowk[pb][lane] * pinv, rk1 = rowk[pb][lane + 64] * pinv;
       const bool c0 = (lane == k), c1 = (lane + 64 == k);
 #pragma unroll
@@ -1069,6 +1080,7 @@ __global__ void __launch_bounds__(GY * GX) k_diag_inv_t(const double* __restrict
                                                          int* __restrict__ flag) {
   constexpr int RI = 128 / GY, CJ = 128 / GX, KBN = GY;  // steps per unrolled group
   static_assert(GY <= GX && GX % GY == 0, "row groups nest in column groups");
+  // pivot row / column in OWNER-MAJOR order ([tx][j], [ty][i]): a thread's CJ + RI reads per step are contiguous (ds_read_b128)
   __shared__ double rowk[2][128], colk[2][128];
   diag_started(flag, k0);
   const int ty = threadIdx.x / GX, tx = threadIdx.x % GX;
@@ -1085,30 +1097,30 @@ __global__ void __launch_bounds__(GY * GX) k_diag_inv_t(const double* __restrict
     const int jb = (GY * kb) / GX, cbase = (GY * kb) % GX;  // compile-time after unrolling
 #pragma unroll 1
     for (int kr = 0; kr < KBN; ++kr) {
-      const int k = KBN * kb + kr, pb = kr & 1;
+      const int pb = kr & 1, pc = cbase + kr;  // pc = k % GX: the tx that owns pivot column k
       if (ty == kr) {
 #pragma unroll
-        for (int j = 0; j < CJ; ++j) rowk[pb][tx + GX * j] = a[kb][j];
+        for (int j = 0; j < CJ; ++j) rowk[pb][tx * CJ + j] = a[kb][j];
       }
-      if (tx == cbase + kr) {
+      if (tx == pc) {
 #pragma unroll
         for (int i = 0; i < RI; ++i) {
 #pragma unroll
           for (int j = 0; j < CJ; ++j)
-            if (j == jb) colk[pb][ty + GY * i] = a[i][j];
+            if (j == jb) colk[pb][ty * RI + i] = a[i][j];
         }
       }
       __syncthreads();
-      const double piv = rowk[pb][k];
+      const double piv = rowk[pb][pc * CJ + jb];  // element (k, k)
       if (!(fabs(piv) > 1e-300) || !isfinite(piv)) bad |= 1;
-      if ((k0 + k) < nspd && !(piv > 0.0)) bad |= 2;
-      const double pinv = 1.0 / piv;
+      if ((k0 + KBN * kb + kr) < nspd && !(piv > 0.0)) bad |= 2;
+      const double pinv = pivot_recip(piv);
       double rk[CJ], ck[RI];
 #pragma unroll
-      for (int j = 0; j < CJ; ++j) rk[j] = rowk[pb][tx + GX * j] * pinv;
+      for (int j = 0; j < CJ; ++j) rk[j] = rowk[pb][tx * CJ + j] * pinv;
 #pragma unroll
-      for (int i = 0; i < RI; ++i) ck[i] = colk[pb][ty + GY * i];
-      const bool prow = (ty == kr), pcol = (tx == cbase + kr);
+      for (int i = 0; i < RI; ++i) ck[i] = colk[pb][ty * RI + i];
+      const bool prow = (ty == kr), pcol = (tx == pc);
 #pragma unroll
       for (int i = 0; i < RI; ++i) {
 #pragma unroll

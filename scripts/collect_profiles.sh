@@ -5,7 +5,7 @@ for c in 2 3 4 5; do cp $S/bench_c$c.json $P/${R}_bench_c$c.json; cp $S/ks_c$c/k
 for k in 10 50 100; do cp $S/bench_mw$k.json $P/${R}_bench_moving_window_k$k.json; done
 cp $S/ks_mw50/ks_kernel_stats.csv $P/${R}_bench_moving_window_k50_rocprofv3_kernel_stats.csv
 cp $S/bench_g2.json $P/${R}_bench_c2_group2_aliased_on_1gpu.json; cp $S/bench_g4.json $P/${R}_bench_c2_group4_aliased_on_1gpu.json
-cp $S/bench_g2_c5.json $P/${R}_bench_c5_group2_aliased_on_1gpu.json; cp $S/bench_2rank.json $P/${R}_bench_torchrun_2ranks_on_1gpu.json
+cp $S/bench_g2_c5.json $P/${R}_bench_c5_group2_aliased_on_1gpu.json; cp $S/bench_g8.json $P/${R}_bench_c2_group8_aliased_on_1gpu.json; cp $S/bench_2rank.json $P/${R}_bench_torchrun_2ranks_on_1gpu.json
 cp $S/pytest_gpu.txt $P/${R}_pytest_gpu.txt; cp $S/kernel_bench.txt $P/${R}_kernel_bench.txt; cp $S/ubench_f64.txt $P/${R}_ubench_f64.txt
 cp $S/env.txt $P/${R}_env.txt; cp $S/stat_time.txt $P/${R}_statistics_timing.txt; cp $S/mw_big_time.txt $P/${R}_moving_window_timing.txt
 cp $S/pinv_time.txt $P/${R}_pseudo_inverse_timing.txt; cp $S/small_problem_latency.txt $P/${R}_small_problem_latency.txt

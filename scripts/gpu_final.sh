@@ -12,6 +12,7 @@ for k in 10 50 100; do timeout 600 python bench.py --steps 3 --warmup 1 --moving
 timeout 600 python bench.py --gpus 2 --steps 3 --warmup 1 > $OUT/bench_g2.json 2>> $OUT/bench.err
 timeout 600 python bench.py --gpus 4 --steps 2 --warmup 1 > $OUT/bench_g4.json 2>> $OUT/bench.err
 timeout 600 python bench.py --gpus 2 --config 5 --steps 2 --warmup 1 > $OUT/bench_g2_c5.json 2>> $OUT/bench.err
+timeout 600 python bench.py --gpus 8 --steps 1 --warmup 1 > $OUT/bench_g8.json 2>> $OUT/bench.err
 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 2 --steps 2 --warmup 1 > $OUT/bench_2rank.json 2> $OUT/bench_2rank.err
 timeout 900 python scripts/mw_big_time.py > $OUT/mw_big_time.txt 2>&1
 timeout 300 python scripts/pinv_time.py > $OUT/pinv_time.txt 2>&1

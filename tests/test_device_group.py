@@ -63,7 +63,7 @@ def _run(h, c, v, model, params, pts, mask=None, window=None, rl=False):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("members", [2, 3])
+@pytest.mark.parametrize("members", [2, 3, 8])
 @pytest.mark.parametrize("exchange", ["auto", "peer", "redundant"])
 def test_group_matches_one_device_bit_for_bit(members, exchange):
     lib = _lib()
