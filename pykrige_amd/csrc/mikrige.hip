@@ -237,7 +237,6 @@ struct mik_handle {
   int exchange_used = 0;       // what the last mik_factor did (same codes; 0 = single device)
   double exchange_ms = 0.0;
   std::string exchange_note;
-  std::vector<ncclComm_t> gcomms;                 // one communicator per device of the group (ncclCommInitAll)
   std::vector<std::vector<hipStream_t>> xstreams; // xstreams[i][k]: stream on device i for the copy to device k (peer exchange)
   std::vector<hipEvent_t> xevents;
 };
@@ -559,8 +558,6 @@ static void destroy_one(mik_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->stream_d2h) (void)hipStreamSynchronize(h->stream_d2h);
   if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
-  for (ncclComm_t c : h->gcomms)
-    if (c && g_rccl.CommDestroy) g_rccl.CommDestroy(c);
   DevBuf* bufs[] = {&h->xs, &h->ys, &h->zs, &h->vals, &h->wells, &h->extra_cols, &h->T, &h->cvec, &h->Cold, &h->Cnew,
                     &h->Rt, &h->TKt, &h->Dinv, &h->DinvT, &h->P0, &h->P1, &h->cand0, &h->cand1, &h->pivall, &h->flag,
                     &h->Cold2, &h->Cnew2, &h->Rt2, &h->Dinv2, &h->DinvT2, &h->grid.gx, &h->grid.gy, &h->grid.gz, &h->grid.orig,
@@ -598,9 +595,6 @@ static void release_group(mik_handle* h) {
       if (st) (void)hipStreamDestroy(st);
   }
   h->xstreams.clear();
-  for (ncclComm_t c : h->gcomms)
-    if (c && g_rccl.CommDestroy) g_rccl.CommDestroy(c);
-  h->gcomms.clear();
   for (mik_handle* k : h->kids) destroy_one(k);
   h->kids.clear();
   (void)hipSetDevice(h->device);
