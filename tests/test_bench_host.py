@@ -68,3 +68,32 @@ def test_bench_refuses_to_run_without_a_gpu():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu"],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "no HIP device" in r.stderr and r.stdout.strip() == ""
+
+
+def test_cpu_protocol_slabs_are_rows_of_the_configs_own_grid():
+    """the reference is timed on ROW SLABS of the grid (style='grid' with a y-subrange), not on random points."""
+    for c, full_rows in ((2, 1000), (4, 1024), (5, 4096)):
+        cfg = bench.CONFIGS[c]
+        pts = bench.row_slab(cfg, 16384)
+        nx = cfg["grid"][0]
+        assert pts.shape[1] == 2 and pts.shape[0] >= 16384 and pts.shape[0] % nx == 0
+        gx, gy = np.linspace(0, 1, nx), np.linspace(0, 1, full_rows)
+        assert np.array_equal(pts[:nx, 0], gx)                      # whole rows, x fastest (the reference's meshgrid order)
+        assert np.all(np.isin(np.unique(pts[:, 1]), gy))            # y values are rows of the full grid
+    p3 = bench.row_slab(bench.CONFIGS[3], 4096)
+    assert p3.shape[1] == 3 and p3.shape[0] >= 4096 and np.unique(p3[:, 2]).size == 1
+    d = bench.host_description()
+    assert d["host_cpus"] >= 1 and "numpy" in d
+
+
+def test_exchange_names_match_the_header():
+    hdr = open(os.path.join(ROOT, "include", "mikrige.h")).read()
+    assert "0 = none (one device), 1 = RCCL broadcast, 2 = peer copies (scatter + all-gather), 3 = every device factored" in hdr
+    assert bench.EXCHANGE_CODES == {"auto": 0, "rccl": 1, "peer": 2, "redundant": 3}
+    assert bench.EXCHANGE_NAMES[1] == "rccl_bcast" and bench.EXCHANGE_NAMES[2].startswith("peer")
+
+
+def test_live_traffic_collection_degrades_to_a_reason(monkeypatch):
+    monkeypatch.setattr(bench.shutil, "which", lambda name: None)
+    res, why = bench.collect_traffic_live(["--steps", "1"], "void mik::k_contract")
+    assert res is None and "rocprofv3" in why
