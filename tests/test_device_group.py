@@ -173,3 +173,28 @@ def test_execute_scales_without_a_script_change():
         del os.environ["MIK_ALIAS_DEVICES"]
     assert np.array_equal(z1, z3) and np.array_equal(s1, s3)
     assert np.abs(z3 - g["z"]).max() <= 1e-8 and np.abs(s3 - g["ss"]).max() <= 1e-6  # and it is the reference's answer
+
+
+@pytest.mark.gpu
+def test_environment_variable_alone_makes_execute_multi_device():
+    """MIK_NGPU in the environment of an UNCHANGED script: the same values as with one device."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "import pykrige_amd as pa\n"
+        "rng = np.random.default_rng(5); x, y, v = rng.random(300), rng.random(300), rng.random(300)\n"
+        "ok = pa.OrdinaryKriging(x, y, v, variogram_model='spherical', variogram_parameters=[1.0, 0.5, 0.05])\n"
+        "z, ss = ok.execute('grid', np.linspace(0, 1, 40), np.linspace(0, 1, 30), backend='loop')\n"
+        "print(ok.last_timing['n_devices'], repr(float(z.sum())), repr(float(ss.sum())))\n" % root)
+    outs = []
+    for env_extra in ({}, {"MIK_NGPU": "3", "MIK_ALIAS_DEVICES": "1"}):
+        env = dict(os.environ, **env_extra)
+        env.pop("MIK_NGPU", None) if not env_extra else None
+        r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stderr[-500:]
+        outs.append(r.stdout.strip().splitlines()[-1].split())
+    assert outs[0][0] == "1" and outs[1][0] == "3"
+    assert outs[0][1:] == outs[1][1:]  # bit-identical sums
