@@ -15,11 +15,13 @@ for n, g in ((100, 50), (500, 100), (1000, 200), (2000, 300), (5000, 256)):
     ok.execute("grid", ax, ax, backend="loop")
     ts, tc_ = [], []
     os.environ["MIK_FACTOR_CACHE"] = "0"  # every call assembles and inverts, as the reference does
+    t = None
     for _ in range(5):
         t0 = time.perf_counter()
         ok.execute("grid", ax, ax, backend="loop")
         ts.append(time.perf_counter() - t0)
-    t = ok.last_timing
+        if ts[-1] == min(ts):
+            t = ok.last_timing  # device phases of the fastest call
     os.environ["MIK_FACTOR_CACHE"] = "1"  # the factored matrix stays on the device while the problem is unchanged
     ok.execute("grid", ax, ax, backend="loop")
     for _ in range(5):
