@@ -877,7 +877,8 @@ __global__ void __launch_bounds__(256) k_ss_reduce(const double* __restrict__ pa
 // Out[i][n] = alpha * sum_m A[i][m] * Bt[n][m],  i over Mp rows, n < 128, m < 128 (one tile column)
 __global__ void __launch_bounds__(256, 2)
 k_panel(const double* __restrict__ A, long lda, const double* __restrict__ Bt, double alpha,
-        double* __restrict__ Out) {
+        double* __restrict__ Out, double* __restrict__ RtOut = nullptr, int k0 = 0) {
+  // RtOut (symmetric sweep): also Rt[i][:] = -sigma_i Out[i][:], sigma_i = -1 for row blocks already swept (k_rt_from_cnew)
   __shared__ GemmSmem sm;
   const int i0 = blockIdx.x * MIK_BM;
   d4 acc[4][4];
@@ -896,7 +897,9 @@ k_panel(const double* __restrict__ A, long lda, const double* __restrict__ Bt, d
       for (int r = 0; r < 4; ++r) {
         const int i = i0 + wm * 64 + ai * 16 + lq + 4 * r;
         const int n = wn * 64 + bi * 16 + lc;
-        Out[(long)i * 128 + n] = alpha * acc[ai][bi][r];
+        const double v = alpha * acc[ai][bi][r];
+        Out[(long)i * 128 + n] = v;
+        if (RtOut) RtOut[(long)i * 128 + n] = (i < k0) ? v : -v;
       }
 }
 
@@ -918,7 +921,11 @@ __global__ void __launch_bounds__(256) k_rt_from_cnew(const double* __restrict__
 template <bool SYM>
 __global__ void __launch_bounds__(256, 2)
 k_update(double* __restrict__ T, long ld, int nblk, int kb, const double* __restrict__ Cold,
-         const double* __restrict__ Cnew, const double* __restrict__ Rt, const double* __restrict__ Dinv, int part, int col) {
+         const double* __restrict__ Cnew, const double* __restrict__ Rt, const double* __restrict__ Dinv, int part, int col,
+         double* __restrict__ Pout) {
+  // Pout (part 1 only; nullable): the updated block column `col` is ALSO written as the next step's column panel
+  // P[row][0..127] (what k_copy_panel / k_copy_panel_sym would read back out of T: tiles of the block row `col` go in transposed),
+  // so that the next panel chain starts with the diagonal inverse instead of a copy kernel
   __shared__ GemmSmem sm;
   int iblk, jblk;
   if (part == 1) {
@@ -946,6 +953,8 @@ k_update(double* __restrict__ T, long ld, int nblk, int kb, const double* __rest
     if (part == 2 && jblk == col) return;
   }
   const int i0 = iblk * MIK_BM, j0 = jblk * MIK_BN, k0 = kb * 128;
+  const bool ptrans = SYM && part == 1 && iblk == col && jblk != col;  // a tile of the block ROW col: panel rows = its columns
+  double* P = (part == 1) ? Pout : nullptr;
   if (iblk == kb || jblk == kb) {
     for (int e = threadIdx.x; e < 128 * 128; e += 256) {
       const int r = e >> 7, c = e & 127;
@@ -954,6 +963,10 @@ k_update(double* __restrict__ T, long ld, int nblk, int kb, const double* __rest
       else if (jblk == kb) v = Cnew[(long)(i0 + r) * 128 + c];
       else v = Rt[(long)(j0 + c) * 128 + r];
       T[(long)(i0 + r) * ld + j0 + c] = v;
+      if (P) {
+        if (ptrans) P[(long)(j0 + c) * 128 + r] = v;
+        else P[(long)(i0 + r) * 128 + c] = v;
+      }
     }
     return;
   }
@@ -977,7 +990,15 @@ k_update(double* __restrict__ T, long ld, int nblk, int kb, const double* __rest
 #pragma unroll
     for (int bi = 0; bi < 4; ++bi)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) tp[(long)(4 * r) * ld + bi * 16] = tv[bi][r] - acc[ai][bi][r];
+      for (int r = 0; r < 4; ++r) {
+        const double v = tv[bi][r] - acc[ai][bi][r];
+        tp[(long)(4 * r) * ld + bi * 16] = v;
+        if (P) {
+          const int row = wm * 64 + ai * 16 + lq + 4 * r, cc = wn * 64 + bi * 16 + lc;  // position inside the tile
+          if (ptrans) P[(long)(j0 + cc) * 128 + row] = v;
+          else P[(long)(i0 + row) * 128 + cc] = v;
+        }
+      }
     __builtin_amdgcn_sched_barrier(0);
   }
 }

@@ -194,6 +194,7 @@ struct mik_handle {
   // drift terms, cond 3e5: |dz| 3e-9 -> 8e-7).  Fine for well-conditioned problems; opt in with the option.
   int opt_symsweep = -1;  // -1 = auto (see run_block_inverse), 0 = off, 1 = on
   int opt_pinv_fast = 1;   // pseudo_inv: try the deflated regular inverse (duplicated stations) before the Jacobi pseudo-inverse
+  int opt_fuse_chain = 1;  // look-ahead sweep: the column update writes the next panel copy too (no copy kernel on the chain)
   int opt_gate = -1;       // look-ahead sweep: the trailing update waits until the next diagonal inverse has started and leaves
                            // it a CU of its own (k_gate); -1 = where the serial chain, not the update, is the step period
   int opt_diag = 1;        // diagonal-block inverse variant: 0 = 1024 threads (16 waves x 8 rows), 1 = 16x16 grid, 2 = 16x32, 3 = 32x32
@@ -622,7 +623,7 @@ static int set_group(mik_handle* h, int n) {
     }
     k->is_kid = true;
     k->opt_factor = h->opt_factor, k->opt_sym = h->opt_sym, k->opt_engine = h->opt_engine, k->opt_waves = h->opt_waves;
-    k->opt_chunk = h->opt_chunk, k->opt_symsweep = h->opt_symsweep, k->opt_diag = h->opt_diag, k->opt_lookahead = h->opt_lookahead, k->opt_gate = h->opt_gate, k->opt_pinv_fast = h->opt_pinv_fast;
+    k->opt_chunk = h->opt_chunk, k->opt_symsweep = h->opt_symsweep, k->opt_diag = h->opt_diag, k->opt_lookahead = h->opt_lookahead, k->opt_gate = h->opt_gate, k->opt_fuse_chain = h->opt_fuse_chain, k->opt_pinv_fast = h->opt_pinv_fast;
     k->opt_mw_pivot = h->opt_mw_pivot, k->opt_mw_lds_cap = h->opt_mw_lds_cap, k->opt_pairs = h->opt_pairs, k->opt_mw_solver = h->opt_mw_solver;
     k->custom_fn = h->custom_fn, k->custom_user = h->custom_user;
     h->kids.push_back(k);
@@ -709,6 +710,8 @@ int mik_set_option(mik_handle* h, const char* key, double value) {
     h->opt_symsweep = value < 0.0 ? -1 : (value != 0.0);
   } else if (!strcmp(key, "pinv_fast")) {
     h->opt_pinv_fast = value != 0.0;
+  } else if (!strcmp(key, "fuse_chain")) {
+    h->opt_fuse_chain = value != 0.0;
   } else if (!strcmp(key, "gate")) {
     h->opt_gate = value < 0.0 ? -1 : (value != 0.0);
   } else if (!strcmp(key, "diag")) {
@@ -942,14 +945,14 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
   const bool symsweep = !pivoted && (h->opt_symsweep > 0 || (h->opt_symsweep < 0 && (h->model == 3 || h->model == 4) && nblk >= 24));
   const long ltiles = symsweep ? (long)nblk * (nblk + 1) / 2 : tiles;
   const unsigned ug = (unsigned)(8 * ((ltiles + 7) / 8));
-#define UPD(GRID, STREAM, CO, CN, R, D, PART, COL)                                                                           \
+#define UPD(GRID, STREAM, CO, CN, R, D, PART, COL, POUT)                                                                           \
   do {                                                                                                                       \
     if (symsweep)                                                                                                            \
       hipLaunchKernelGGL(k_update<true>, GRID, dim3(256), 0, STREAM, T, ld, nblk, kb, (const double*)(CO), (const double*)(CN), \
-                         (const double*)(R), (const double*)(D), PART, COL);                                                 \
+                         (const double*)(R), (const double*)(D), PART, COL, POUT);                                           \
     else                                                                                                                     \
       hipLaunchKernelGGL(k_update<false>, GRID, dim3(256), 0, STREAM, T, ld, nblk, kb, (const double*)(CO), (const double*)(CN), \
-                         (const double*)(R), (const double*)(D), PART, COL);                                                 \
+                         (const double*)(R), (const double*)(D), PART, COL, POUT);                                           \
   } while (0)
   const bool lookahead = h->opt_lookahead < 0 ? nblk >= 24 : h->opt_lookahead != 0;
   // measured (profiles/r02_inverse_timeline.txt): with up to ~2400 update tiles per step (N=5000 full sweep: 1600, N=8000 half
@@ -975,30 +978,35 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
     double* rt[2] = {h->Rt.as<double>(), h->Rt2.as<double>()};
     double* dinv[2] = {h->Dinv.as<double>(), h->Dinv2.as<double>()};
     double* dinvT[2] = {h->DinvT.as<double>(), h->DinvT2.as<double>()};
-    auto panel_chain = [&](hipStream_t st, int kb, int set) {
+    // the serial chain of a step: diagonal inverse -> [panel copy, unless the column update already left it in Cold] -> panel
+    // kernel (C_new and R^T in one launch)
+    auto panel_chain = [&](hipStream_t st, int kb, int set, bool have_cold) {
       const int k0 = kb * 128;
       launch_diag_inv(h, st, (const double*)T, ld, k0, nspd, dinv[set], dinvT[set], gate && st == h->stream2);
-      if (symsweep) hipLaunchKernelGGL(k_copy_panel_sym, dim3(Mp / 64), dim3(256), 0, st, (const double*)T, ld, k0, Mp, cold[set]);
-      else hipLaunchKernelGGL(k_copy_panel, dim3(pgrid), dim3(256), 0, st, (const double*)T, ld, k0, Mp, cold[set]);
+      if (!have_cold) {
+        if (symsweep) hipLaunchKernelGGL(k_copy_panel_sym, dim3(Mp / 64), dim3(256), 0, st, (const double*)T, ld, k0, Mp, cold[set]);
+        else hipLaunchKernelGGL(k_copy_panel, dim3(pgrid), dim3(256), 0, st, (const double*)T, ld, k0, Mp, cold[set]);
+      }
       hipLaunchKernelGGL(k_panel, dim3(nblk), dim3(256), 0, st, (const double*)cold[set], 128L, (const double*)dinvT[set], -1.0,
-                         cnew[set]);
-      hipLaunchKernelGGL(k_rt_from_cnew, dim3(pgrid), dim3(256), 0, st, (const double*)cnew[set], rt[set], Mp, k0);
+                         cnew[set], rt[set], k0);
     };
-    panel_chain(h->stream, 0, 0);
+    panel_chain(h->stream, 0, 0, false);
     for (int kb = 0; kb < nblk; ++kb) {
       const int set = kb & 1;
       if (kb + 1 < nblk) {
-        UPD(dim3(nblk), h->stream, cold[set], cnew[set], rt[set], dinv[set], 1, kb + 1);
+        // the column update leaves the updated block column in the other panel set as well (its last reader, the rest of step
+        // kb-1, is earlier on this very stream): the chain below starts with the diagonal inverse
+        UPD(dim3(nblk), h->stream, cold[set], cnew[set], rt[set], dinv[set], 1, kb + 1, h->opt_fuse_chain ? cold[set ^ 1] : (double*)nullptr);
         HIPC(hipEventRecord(h->la_events[2 * kb], h->stream));
         HIPC(hipStreamWaitEvent(h->stream2, h->la_events[2 * kb], 0));
-        panel_chain(h->stream2, kb + 1, set ^ 1);
+        panel_chain(h->stream2, kb + 1, set ^ 1, h->opt_fuse_chain != 0);
         HIPC(hipEventRecord(h->la_events[2 * kb + 1], h->stream2));
         if (gate)  // hold the big update back until the next diagonal inverse sits on a CU (see k_gate)
           hipLaunchKernelGGL(k_gate, dim3(1), dim3(1), 0, h->stream, (const int*)h->flag.as<int>(), kb + 1, 20000);
-        UPD(dim3(ug), h->stream, cold[set], cnew[set], rt[set], dinv[set], 2, kb + 1);
+        UPD(dim3(ug), h->stream, cold[set], cnew[set], rt[set], dinv[set], 2, kb + 1, (double*)nullptr);
         HIPC(hipStreamWaitEvent(h->stream, h->la_events[2 * kb + 1], 0));
       } else {
-        UPD(dim3(ug), h->stream, cold[set], cnew[set], rt[set], dinv[set], 0, 0);
+        UPD(dim3(ug), h->stream, cold[set], cnew[set], rt[set], dinv[set], 0, 0, (double*)nullptr);
       }
     }
   } else
@@ -1035,7 +1043,7 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
       hipLaunchKernelGGL(k_rt_from_cnew, dim3(pgrid), dim3(256), 0, h->stream, (const double*)h->Cnew.as<double>(),
                          h->Rt.as<double>(), Mp, k0);
     }
-    UPD(dim3(ug), h->stream, h->Cold.as<double>(), h->Cnew.as<double>(), h->Rt.as<double>(), h->Dinv.as<double>(), 0, 0);
+    UPD(dim3(ug), h->stream, h->Cold.as<double>(), h->Cnew.as<double>(), h->Rt.as<double>(), h->Dinv.as<double>(), 0, 0, (double*)nullptr);
   }
 #undef UPD
   if (symsweep) hipLaunchKernelGGL(k_mirror_upper, dim3(Mp / 64, Mp / 64), dim3(256), 0, h->stream, T, ld, Mp / 64);

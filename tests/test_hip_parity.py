@@ -189,9 +189,10 @@ def test_block_sweep_variants_agree():
     h = _handle_for(st)
     h.set_option("factor", 1)
     ref = None
-    for la, diag, sym, gate in ((0, 0, 0, 1), (1, 0, 0, 1), (0, 1, 0, 1), (1, 1, 0, 1), (1, 1, 0, 0), (1, 2, 0, 1), (0, 3, 0, 1), (0, 1, 1, 1),
-                                (1, 1, 1, 1), (1, 1, 1, 0)):
+    for la, diag, sym, gate, fuse in ((0, 0, 0, 1, 1), (1, 0, 0, 1, 1), (0, 1, 0, 1, 1), (1, 1, 0, 1, 1), (1, 1, 0, 0, 1), (1, 1, 0, 1, 0), (1, 2, 0, 1, 1),
+                                      (0, 3, 0, 1, 1), (0, 1, 1, 1, 1), (1, 1, 1, 1, 1), (1, 1, 1, 0, 1), (1, 1, 1, 1, 0)):
         h.set_option("lookahead", la)
+        h.set_option("fuse_chain", fuse)  # the column update also leaves the next panel copy, the panel kernel also writes R^T
         h.set_option("diag", diag)
         h.set_option("symsweep", sym)
         h.set_option("gate", gate)  # schedule only (the update waits for the next diagonal inverse to start): same numbers
