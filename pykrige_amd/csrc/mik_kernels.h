@@ -878,7 +878,7 @@ __global__ void __launch_bounds__(256) k_ss_reduce(const double* __restrict__ pa
 __global__ void __launch_bounds__(256, 2)
 k_panel(const double* __restrict__ A, long lda, const double* __restrict__ Bt, double alpha,
         double* __restrict__ Out, double* __restrict__ RtOut = nullptr, int k0 = 0) {
-  // RtOut (symmetric sweep): also Rt[i][:] = -sigma_i Out[i][:], sigma_i = -1 for row blocks already swept (k_rt_from_cnew)
+  // RtOut (symmetric sweep): also Rt[i][:] = -sigma_i Out[i][:], sigma_i = -1 for row blocks already swept
   __shared__ GemmSmem sm;
   const int i0 = blockIdx.x * MIK_BM;
   d4 acc[4][4];
@@ -901,15 +901,6 @@ k_panel(const double* __restrict__ A, long lda, const double* __restrict__ Bt, d
         Out[(long)i * 128 + n] = v;
         if (RtOut) RtOut[(long)i * 128 + n] = (i < k0) ? v : -v;
       }
-}
-
-// Rt[j][:] = -sigma_j * Cnew[j][:]   (symmetric path)
-__global__ void __launch_bounds__(256) k_rt_from_cnew(const double* __restrict__ Cnew, double* __restrict__ Rt, int Mp,
-                                                      int k0) {
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (long)Mp * 128) return;
-  const int j = (int)(idx >> 7);
-  Rt[idx] = (j < k0) ? Cnew[idx] : -Cnew[idx];
 }
 
 // trailing update + panel write-back, one 128x128 tile per block.  part = 0: every tile; part = 1: only block column

@@ -1032,16 +1032,14 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
                                      h->Cold.as<double>());
     else hipLaunchKernelGGL(k_copy_panel, dim3(pgrid), dim3(256), 0, h->stream, (const double*)T, ld, k0, Mp,
                             h->Cold.as<double>());
+    // unpivoted sweep: the panel kernel writes R^T = -sigma C_new as well (one launch less per step)
     hipLaunchKernelGGL(k_panel, dim3(nblk), dim3(256), 0, h->stream, (const double*)h->Cold.as<double>(), 128L,
-                       (const double*)h->DinvT.as<double>(), -1.0, h->Cnew.as<double>());
+                       (const double*)h->DinvT.as<double>(), -1.0, h->Cnew.as<double>(), pivoted ? (double*)nullptr : h->Rt.as<double>(), k0);
     if (pivoted) {
       hipLaunchKernelGGL(k_transpose_rows, dim3(Mp / 64, 2), dim3(256), 0, h->stream, (const double*)T, ld, k0, Mp,
                          h->TKt.as<double>());
       hipLaunchKernelGGL(k_panel, dim3(nblk), dim3(256), 0, h->stream, (const double*)h->TKt.as<double>(), 128L,
                          (const double*)h->Dinv.as<double>(), 1.0, h->Rt.as<double>());
-    } else {
-      hipLaunchKernelGGL(k_rt_from_cnew, dim3(pgrid), dim3(256), 0, h->stream, (const double*)h->Cnew.as<double>(),
-                         h->Rt.as<double>(), Mp, k0);
     }
     UPD(dim3(ug), h->stream, h->Cold.as<double>(), h->Cnew.as<double>(), h->Rt.as<double>(), h->Dinv.as<double>(), 0, 0, (double*)nullptr);
   }

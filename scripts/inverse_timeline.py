@@ -44,8 +44,8 @@ def parse(d):
         print("  %-34s x %4d   total %9.1f us   mean %7.1f us" % (k, n, us, us / n))
     # chain: from the start of each diagonal inverse to the end of the last panel kernel before the next trailing update finishes
     diag = [r for r in rows if r[2].startswith("k_diag_inv")]
-    chain_k = ("k_diag_inv", "k_copy_panel", "k_panel", "k_rt_from_cnew")
-    chain = [r for r in rows if r[2].startswith(chain_k)]
+    chain_k = ("k_diag_inv", "k_copy_panel", "k_panel")
+    chain = [r for r in rows if r[2].replace("mik::", "").startswith(chain_k)]
     spans, gaps = [], []
     for i, d0 in enumerate(diag):
         nxt = diag[i + 1][0] if i + 1 < len(diag) else t1
