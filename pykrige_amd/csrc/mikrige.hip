@@ -1329,13 +1329,19 @@ static int exchange_rccl(mik_handle* h) {
     MIKC(ensure_factor_buffers(member(h, i)));
   }
   NCCLC(g_rccl.GroupStart());
-  for (int i = 0; i < n; ++i) {
+  ncclResult_t first_bad = ncclSuccess;  // a failing call must not leave RCCL inside an open group
+  for (int i = 0; i < n && first_bad == ncclSuccess; ++i) {
     mik_handle* d = member(h, i);
-    HIPC(hipSetDevice(d->device));
-    NCCLC(g_rccl.Broadcast(d->T.p, d->T.p, Mp * Mp, ncclDouble, 0, (*comms)[i], d->stream));
-    NCCLC(g_rccl.Broadcast(d->cvec.p, d->cvec.p, Mp, ncclDouble, 0, (*comms)[i], d->stream));
+    if (hipSetDevice(d->device) != hipSuccess) {
+      first_bad = ncclUnhandledCudaError;
+      break;
+    }
+    first_bad = g_rccl.Broadcast(d->T.p, d->T.p, Mp * Mp, ncclDouble, 0, (*comms)[i], d->stream);
+    if (first_bad == ncclSuccess) first_bad = g_rccl.Broadcast(d->cvec.p, d->cvec.p, Mp, ncclDouble, 0, (*comms)[i], d->stream);
   }
-  NCCLC(g_rccl.GroupEnd());
+  const ncclResult_t end_rc = g_rccl.GroupEnd();
+  NCCLC(first_bad);
+  NCCLC(end_rc);
   for (int i = 0; i < n; ++i) {
     HIPC(hipSetDevice(member(h, i)->device));
     HIPC(hipStreamSynchronize(member(h, i)->stream));
