@@ -1379,6 +1379,7 @@ static int exchange_peer(mik_handle* h) {
         }
       }
     }
+    HIPC(hipSetDevice(h->device));  // the arrival events are recorded on the LEADER's streams: they belong to its device
     while (h->xevents.size() < (size_t)n) {
       hipEvent_t e;
       HIPC(hipEventCreateWithFlags(&e, hipEventDisableTiming));
