@@ -877,10 +877,12 @@ __global__ void __launch_bounds__(256) k_ss_reduce(const double* __restrict__ pa
 // Out[i][n] = alpha * sum_m A[i][m] * Bt[n][m],  i over Mp rows, n < 128, m < 128 (one tile column)
 __global__ void __launch_bounds__(256, 2)
 k_panel(const double* __restrict__ A, long lda, const double* __restrict__ Bt, double alpha,
-        double* __restrict__ Out, double* __restrict__ RtOut = nullptr, int k0 = 0) {
+        double* __restrict__ Out, double* __restrict__ RtOut = nullptr, int k0 = 0, int blk0 = 0, int orow = 0) {
   // RtOut (symmetric sweep): also Rt[i][:] = -sigma_i Out[i][:], sigma_i = -1 for row blocks already swept
+  // blk0 / orow (early-diagonal chain): start at row block blk0 and store row i at Out / RtOut row i - orow (a one-block launch
+  // that leaves the 128 panel rows of one block in a 128 x 128 scratch)
   __shared__ GemmSmem sm;
-  const int i0 = blockIdx.x * MIK_BM;
+  const int i0 = (blockIdx.x + blk0) * MIK_BM;
   d4 acc[4][4];
 #pragma unroll
   for (int x = 0; x < 4; ++x)
@@ -898,8 +900,8 @@ k_panel(const double* __restrict__ A, long lda, const double* __restrict__ Bt, d
         const int i = i0 + wm * 64 + ai * 16 + lq + 4 * r;
         const int n = wn * 64 + bi * 16 + lc;
         const double v = alpha * acc[ai][bi][r];
-        Out[(long)i * 128 + n] = v;
-        if (RtOut) RtOut[(long)i * 128 + n] = (i < k0) ? v : -v;
+        Out[(long)(i - orow) * 128 + n] = v;
+        if (RtOut) RtOut[(long)(i - orow) * 128 + n] = (i < k0) ? v : -v;
       }
 }
 
@@ -913,10 +915,12 @@ template <bool SYM>
 __global__ void __launch_bounds__(256, 2)
 k_update(double* __restrict__ T, long ld, int nblk, int kb, const double* __restrict__ Cold,
          const double* __restrict__ Cnew, const double* __restrict__ Rt, const double* __restrict__ Dinv, int part, int col,
-         double* __restrict__ Pout) {
-  // Pout (part 1 only; nullable): the updated block column `col` is ALSO written as the next step's column panel
+         double* __restrict__ Pout, double* __restrict__ Dcopy = nullptr) {
+  // Pout (nullable): the updated block column `col` is ALSO written as the next step's column panel
   // P[row][0..127] (what k_copy_panel / k_copy_panel_sym would read back out of T: tiles of the block row `col` go in transposed),
-  // so that the next panel chain starts with the diagonal inverse instead of a copy kernel
+  // so that the next panel chain starts with the diagonal inverse instead of a copy kernel.
+  // Dcopy (nullable): the updated diagonal tile (col + 1, col + 1) is also left there (128 x 128): the early-diagonal chain
+  // builds the diagonal block after next from it without touching T
   __shared__ GemmSmem sm;
   int iblk, jblk;
   if (part == 1) {
@@ -944,8 +948,9 @@ k_update(double* __restrict__ T, long ld, int nblk, int kb, const double* __rest
     if (part == 2 && jblk == col) return;
   }
   const int i0 = iblk * MIK_BM, j0 = jblk * MIK_BN, k0 = kb * 128;
-  const bool ptrans = SYM && part == 1 && iblk == col && jblk != col;  // a tile of the block ROW col: panel rows = its columns
-  double* P = (part == 1) ? Pout : nullptr;
+  const bool ptrans = SYM && iblk == col && jblk != col;  // a tile of the block ROW col: panel rows = its columns
+  double* P = (jblk == col || (SYM && iblk == col)) ? Pout : nullptr;
+  double* DC = (iblk == col + 1 && jblk == col + 1) ? Dcopy : nullptr;
   if (iblk == kb || jblk == kb) {
     for (int e = threadIdx.x; e < 128 * 128; e += 256) {
       const int r = e >> 7, c = e & 127;
@@ -989,8 +994,73 @@ k_update(double* __restrict__ T, long ld, int nblk, int kb, const double* __rest
           if (ptrans) P[(long)(j0 + cc) * 128 + row] = v;
           else P[(long)(i0 + row) * 128 + cc] = v;
         }
+        if (DC) DC[(wm * 64 + ai * 16 + lq + 4 * r) * 128 + wn * 64 + bi * 16 + lc] = v;
       }
     __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// Early-diagonal chain: the diagonal block kb + 1 as step kb's update will leave it, Dnext = Dsrc - Cb . Rb^T, from the 128 panel
+// rows of that block alone (Cb = rows of the column panel, Rb = the matching rows of R^T, see k_panel's blk0) -- the same tile
+// loop, operands and subtraction as k_update uses for this tile, hence the same bits.  One block.
+__global__ void __launch_bounds__(256, 2)
+k_next_diag(const double* __restrict__ Dsrc, long ldsrc, const double* __restrict__ Cb, const double* __restrict__ Rb,
+            double* __restrict__ Dnext) {
+  __shared__ GemmSmem sm;
+  d4 acc[4][4];
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int y = 0; y < 4; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
+  gemm_core<4>(Cb, 128, Rb, 128, 0, 128, acc, sm);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1, lq = lane >> 4, lc = lane & 15;
+#pragma unroll
+  for (int ai = 0; ai < 4; ++ai)
+#pragma unroll
+    for (int bi = 0; bi < 4; ++bi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = wm * 64 + ai * 16 + lq + 4 * r, cc = wn * 64 + bi * 16 + lc;
+        Dnext[row * 128 + cc] = Dsrc[(long)row * ldsrc + cc] - acc[ai][bi][r];
+      }
+}
+
+// One 128 x 128 x 128 product C = A . Bt^T spread over the chip: 256 wavefronts (64 blocks), each ONE accumulator stream of
+// gemm_core's tile loop -- 4 rows x 16 columns, v_mfma_f64_4x4x4_4b, K tiles of 16 from the top down, within a tile the k
+// quadruples {8m + 2kq + h} in the order (m, h) = (0,0) (0,1) (1,0) (1,1) -- so every entry is accumulated in exactly the order
+// k_panel / k_update use and comes out with the same bits, but in ~4 us instead of the 22 us one 256-thread block needs for
+// the tile (a CU's MFMA rate).  All 32 operand fragments of a lane are loaded up front (one memory latency).
+//   MODE 0: Out = -(alpha * acc)  (R^T rows of a block below the pivot block, what k_panel's RtOut holds for them)
+//   MODE 1: Out = Dsrc - acc      (k_update's tile)
+// A, Bt, Out: 128 x 128, row stride 128; Dsrc: row stride ldsrc.
+template <int MODE>
+__global__ void __launch_bounds__(256) k_gemm128(const double* __restrict__ A, const double* __restrict__ Bt, double alpha,
+                                                 const double* __restrict__ Dsrc, long ldsrc, double* __restrict__ Out) {
+  const int lane = threadIdx.x & 63, w = blockIdx.x * 4 + (threadIdx.x >> 6);  // 0 .. 255
+  const int R = w >> 3, Cg = w & 7, kq = lane >> 4;
+  const double* ap = A + (long)(4 * R + (lane & 3)) * 128 + 2 * kq;
+  const double* bp = Bt + (long)(16 * Cg + (lane & 15)) * 128 + 2 * kq;
+  double2 fa[16], fb[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {  // t = 2 * tile + m: k = 8 t + 2 kq + h
+    fa[t] = *reinterpret_cast<const double2*>(ap + 8 * t);
+    fb[t] = *reinterpret_cast<const double2*>(bp + 8 * t);
+  }
+  double acc = 0.0;
+#pragma unroll
+  for (int tile = 7; tile >= 0; --tile)
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      acc = __builtin_amdgcn_mfma_f64_4x4x4f64(fa[2 * tile + m].x, fb[2 * tile + m].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_4x4x4f64(fa[2 * tile + m].y, fb[2 * tile + m].y, acc, 0, 0, 0);
+    }
+  const int row = 4 * R + (lane >> 4), col = 16 * Cg + (lane & 15);
+  if (MODE == 0) {
+    const double v = alpha * acc;
+    Out[row * 128 + col] = -v;
+  } else {
+    Out[row * 128 + col] = Dsrc[(long)row * ldsrc + col] - acc;
   }
 }
 

@@ -185,6 +185,7 @@ struct mik_handle {
   // factor
   DevBuf T, cvec, Cold, Cnew, Rt, TKt, Dinv, DinvT, P0, P1, cand0, cand1, pivall, flag;
   DevBuf Cold2, Cnew2, Rt2, Dinv2, DinvT2;  // second panel set of the look-ahead sweep
+  DevBuf Dnext, Dcopy, Cb, Rb;              // early-diagonal chain: 128 x 128 scratch (next diagonal block, its source tile, one block of panel rows)
   hipStream_t stream2 = nullptr;            // the look-ahead branch (next panel) runs here
   std::vector<hipEvent_t> la_events;
   int opt_lookahead = -1;  // -1 = where it pays (>= 24 block columns), 0 = off, 1 = on
@@ -195,6 +196,7 @@ struct mik_handle {
   int opt_symsweep = -1;  // -1 = auto (see run_block_inverse), 0 = off, 1 = on
   int opt_pinv_fast = 1;   // pseudo_inv: try the deflated regular inverse (duplicated stations) before the Jacobi pseudo-inverse
   int opt_fuse_chain = 1;  // look-ahead sweep: the column update writes the next panel copy too (no copy kernel on the chain)
+  int opt_early_diag = -1; // look-ahead sweep: the next diagonal block is built and inverted ahead of the panel / update stream (-1 = with the look-ahead)
   int opt_gate = -1;       // look-ahead sweep: the trailing update waits until the next diagonal inverse has started and leaves
                            // it a CU of its own (k_gate); -1 = where the serial chain, not the update, is the step period
   int opt_diag = 1;        // diagonal-block inverse variant: 0 = 1024 threads (16 waves x 8 rows), 1 = 16x16 grid, 2 = 16x32, 3 = 32x32
@@ -561,7 +563,7 @@ static void destroy_one(mik_handle* h) {
   if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
   DevBuf* bufs[] = {&h->xs, &h->ys, &h->zs, &h->vals, &h->wells, &h->extra_cols, &h->T, &h->cvec, &h->Cold, &h->Cnew,
                     &h->Rt, &h->TKt, &h->Dinv, &h->DinvT, &h->P0, &h->P1, &h->cand0, &h->cand1, &h->pivall, &h->flag,
-                    &h->Cold2, &h->Cnew2, &h->Rt2, &h->Dinv2, &h->DinvT2, &h->grid.gx, &h->grid.gy, &h->grid.gz, &h->grid.orig,
+                    &h->Cold2, &h->Cnew2, &h->Rt2, &h->Dinv2, &h->DinvT2, &h->Dnext, &h->Dcopy, &h->Cb, &h->Rb, &h->grid.gx, &h->grid.gy, &h->grid.gz, &h->grid.orig,
                     &h->grid.cstart,
                     &h->px, &h->py, &h->pz, &h->extra_rows, &h->z, &h->ss, &h->Bt, &h->part, &h->mw_idx, &h->mw_dist, &h->stat_S, &h->stat_x, &h->stat_out, &h->queue};
   for (DevBuf* b : bufs) b->release();
@@ -623,7 +625,7 @@ static int set_group(mik_handle* h, int n) {
     }
     k->is_kid = true;
     k->opt_factor = h->opt_factor, k->opt_sym = h->opt_sym, k->opt_engine = h->opt_engine, k->opt_waves = h->opt_waves;
-    k->opt_chunk = h->opt_chunk, k->opt_symsweep = h->opt_symsweep, k->opt_diag = h->opt_diag, k->opt_lookahead = h->opt_lookahead, k->opt_gate = h->opt_gate, k->opt_fuse_chain = h->opt_fuse_chain, k->opt_pinv_fast = h->opt_pinv_fast;
+    k->opt_chunk = h->opt_chunk, k->opt_symsweep = h->opt_symsweep, k->opt_diag = h->opt_diag, k->opt_lookahead = h->opt_lookahead, k->opt_gate = h->opt_gate, k->opt_fuse_chain = h->opt_fuse_chain, k->opt_early_diag = h->opt_early_diag, k->opt_pinv_fast = h->opt_pinv_fast;
     k->opt_mw_pivot = h->opt_mw_pivot, k->opt_mw_lds_cap = h->opt_mw_lds_cap, k->opt_pairs = h->opt_pairs, k->opt_mw_solver = h->opt_mw_solver;
     k->custom_fn = h->custom_fn, k->custom_user = h->custom_user;
     h->kids.push_back(k);
@@ -712,6 +714,8 @@ int mik_set_option(mik_handle* h, const char* key, double value) {
     h->opt_pinv_fast = value != 0.0;
   } else if (!strcmp(key, "fuse_chain")) {
     h->opt_fuse_chain = value != 0.0;
+  } else if (!strcmp(key, "early_diag")) {
+    h->opt_early_diag = value < 0.0 ? -1 : (int)value;  // 2 = with the one-block tile kernels
   } else if (!strcmp(key, "gate")) {
     h->opt_gate = value < 0.0 ? -1 : (value != 0.0);
   } else if (!strcmp(key, "diag")) {
@@ -945,16 +949,18 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
   const bool symsweep = !pivoted && (h->opt_symsweep > 0 || (h->opt_symsweep < 0 && (h->model == 3 || h->model == 4) && nblk >= 24));
   const long ltiles = symsweep ? (long)nblk * (nblk + 1) / 2 : tiles;
   const unsigned ug = (unsigned)(8 * ((ltiles + 7) / 8));
-#define UPD(GRID, STREAM, CO, CN, R, D, PART, COL, POUT)                                                                           \
+#define UPDX(GRID, STREAM, CO, CN, R, D, PART, COL, POUT, DCOPY)                                                             \
   do {                                                                                                                       \
     if (symsweep)                                                                                                            \
       hipLaunchKernelGGL(k_update<true>, GRID, dim3(256), 0, STREAM, T, ld, nblk, kb, (const double*)(CO), (const double*)(CN), \
-                         (const double*)(R), (const double*)(D), PART, COL, POUT);                                           \
+                         (const double*)(R), (const double*)(D), PART, COL, POUT, DCOPY);                                    \
     else                                                                                                                     \
       hipLaunchKernelGGL(k_update<false>, GRID, dim3(256), 0, STREAM, T, ld, nblk, kb, (const double*)(CO), (const double*)(CN), \
-                         (const double*)(R), (const double*)(D), PART, COL, POUT);                                           \
+                         (const double*)(R), (const double*)(D), PART, COL, POUT, DCOPY);                                    \
   } while (0)
-  const bool lookahead = h->opt_lookahead < 0 ? nblk >= 24 : h->opt_lookahead != 0;
+#define UPD(GRID, STREAM, CO, CN, R, D, PART, COL, POUT) UPDX(GRID, STREAM, CO, CN, R, D, PART, COL, POUT, (double*)nullptr)
+  const bool early_ok = h->opt_early_diag != 0;
+  const bool lookahead = h->opt_lookahead < 0 ? nblk >= (early_ok ? 3 : 24) : h->opt_lookahead != 0;
   // measured (profiles/r02_inverse_timeline.txt): with up to ~2400 update tiles per step (N=5000 full sweep: 1600, N=8000 half
   // sweep: 2016) the serial chain is the step period and giving its head a CU of its own pays (-14 % / -10 %); with 3969 tiles
   // (N=8000 full sweep) the update is, and holding it back costs 3 %
@@ -968,7 +974,7 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
     MIKC(h->Rt2.ensure(panel));
     MIKC(h->Dinv2.ensure(sizeof(double) * 128 * 128));
     MIKC(h->DinvT2.ensure(sizeof(double) * 128 * 128));
-    while (h->la_events.size() < 2 * (size_t)nblk) {
+    while (h->la_events.size() < 2 * (size_t)nblk + 2) {
       hipEvent_t e;
       HIPC(hipEventCreateWithFlags(&e, hipEventDisableTiming));
       h->la_events.push_back(e);
@@ -990,7 +996,64 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
       hipLaunchKernelGGL(k_panel, dim3(nblk), dim3(256), 0, st, (const double*)cold[set], 128L, (const double*)dinvT[set], -1.0,
                          cnew[set], rt[set], k0);
     };
+    const bool early = h->opt_early_diag < 0 ? true : h->opt_early_diag != 0;
     panel_chain(h->stream, 0, 0, false);
+    if (early) {
+      // Early-diagonal schedule.  What the next diagonal inverse needs of step kb is ONE tile, D(kb+1) - C_b R_b^T, and that takes
+      // only the 128 panel rows of block kb + 1.  The second stream therefore runs, per step,
+      //     [wait: update kb-1 done]  k_panel (one block) -> k_next_diag -> diagonal inverse kb+1
+      // from the column panel and the diagonal-tile copy (two alternate) that update kb-1 left behind (it never reads T), while the first stream
+      // runs  [wait: diagonal inverse kb done]  k_panel (all rows) -> the WHOLE update of step kb  -- one launch, no split, and
+      // the serial chain (diagonal inverse + two one-block kernels) no longer contains the full panel kernel, the block-column
+      // update or a second cross-stream wait.  Same kernels, same operands per tile: the inverse is bit-identical.
+      MIKC(h->Dnext.ensure(sizeof(double) * 128 * 128));
+      MIKC(h->Dcopy.ensure(sizeof(double) * 2 * 128 * 128));
+      MIKC(h->Cb.ensure(sizeof(double) * 128 * 128));
+      MIKC(h->Rb.ensure(sizeof(double) * 128 * 128));
+      double* dnext = h->Dnext.as<double>();
+      double* dcopy[2] = {h->Dcopy.as<double>(), h->Dcopy.as<double>() + 128 * 128};  // [kb & 1] is read by step kb's chain
+      double* cb = h->Cb.as<double>();
+      double* rb = h->Rb.as<double>();
+      HIPC(hipMemcpy2DAsync(dcopy[0], sizeof(double) * 128, T + 128L * ld + 128, sizeof(double) * ld, sizeof(double) * 128, 128,
+                            hipMemcpyDeviceToDevice, h->stream));  // tile (1, 1) as assembled: the second stream never reads T
+      HIPC(hipEventRecord(h->la_events[0], h->stream));  // "update -1": the first panel set and diagonal inverse are there
+      for (int kb = 0; kb < nblk; ++kb) {
+        const int set = kb & 1, k0 = kb * 128, k1 = k0 + 128;
+        if (kb + 1 < nblk) {
+          hipStream_t s2 = h->stream2;
+          HIPC(hipStreamWaitEvent(s2, h->la_events[2 * kb], 0));  // update kb-1 (event 2 kb) has left cold[set], dcopy
+          if (h->opt_early_diag == 2) {  // the library's one-block tile kernels (22 us each: a CU's MFMA rate), kept for comparison
+            hipLaunchKernelGGL(k_panel, dim3(1), dim3(256), 0, s2, (const double*)cold[set], 128L, (const double*)dinvT[set], -1.0, cb, rb,
+                               k0, kb + 1, k1);
+            hipLaunchKernelGGL(k_next_diag, dim3(1), dim3(256), 0, s2, (const double*)dcopy[set], 128L,
+                               (const double*)(cold[set] + (long)k1 * 128), (const double*)rb, dnext);
+          } else {  // the same accumulation streams, one per wavefront, over 64 blocks
+            hipLaunchKernelGGL(k_gemm128<0>, dim3(64), dim3(256), 0, s2, (const double*)(cold[set] + (long)k1 * 128), (const double*)dinvT[set],
+                               -1.0, (const double*)nullptr, 0L, rb);
+            hipLaunchKernelGGL(k_gemm128<1>, dim3(64), dim3(256), 0, s2, (const double*)(cold[set] + (long)k1 * 128), (const double*)rb, 0.0,
+                               (const double*)dcopy[set], 128L, dnext);
+          }
+          // the diagonal-inverse kernels address T[(k0 + r) * ld + k0 + c]: hand them the 128 x 128 copy under that indexing
+          const double* dview = (const double*)((uintptr_t)dnext - sizeof(double) * ((size_t)k1 * 128 + (size_t)k1));
+          launch_diag_inv(h, s2, dview, 128L, k1, nspd, dinv[set ^ 1], dinvT[set ^ 1], gate);
+          HIPC(hipEventRecord(h->la_events[2 * kb + 1], s2));
+        }
+        if (kb > 0) {
+          HIPC(hipStreamWaitEvent(h->stream, h->la_events[2 * kb - 1], 0));  // diagonal inverse kb
+          // (the per-wavefront form of k_gemm128 for ALL panel rows was tried here: 30 us against 26 us -- its strided fragment
+          // loads do not coalesce -- and its 640 blocks delay the chain's 64)
+          hipLaunchKernelGGL(k_panel, dim3(nblk), dim3(256), 0, h->stream, (const double*)cold[set], 128L, (const double*)dinvT[set], -1.0,
+                             cnew[set], rt[set], k0);
+        }
+        if (kb + 1 < nblk) {
+          if (gate) hipLaunchKernelGGL(k_gate, dim3(1), dim3(1), 0, h->stream, (const int*)h->flag.as<int>(), kb + 1, 20000);
+          UPDX(dim3(ug), h->stream, cold[set], cnew[set], rt[set], dinv[set], 0, kb + 1, cold[set ^ 1], dcopy[set ^ 1]);
+          HIPC(hipEventRecord(h->la_events[2 * kb + 2], h->stream));
+        } else {
+          UPD(dim3(ug), h->stream, cold[set], cnew[set], rt[set], dinv[set], 0, -2, (double*)nullptr);
+        }
+      }
+    } else
     for (int kb = 0; kb < nblk; ++kb) {
       const int set = kb & 1;
       if (kb + 1 < nblk) {
@@ -1044,6 +1107,7 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
     UPD(dim3(ug), h->stream, h->Cold.as<double>(), h->Cnew.as<double>(), h->Rt.as<double>(), h->Dinv.as<double>(), 0, 0, (double*)nullptr);
   }
 #undef UPD
+#undef UPDX
   if (symsweep) hipLaunchKernelGGL(k_mirror_upper, dim3(Mp / 64, Mp / 64), dim3(256), 0, h->stream, T, ld, Mp / 64);
   if (pivoted)
     hipLaunchKernelGGL(k_swap_cols, dim3((Mp + 255) / 256), dim3(256), 0, h->stream, T, ld,

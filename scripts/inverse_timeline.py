@@ -55,6 +55,12 @@ def parse(d):
     print("  panel chain per step: mean %.1f us (min %.1f, max %.1f), of which idle gaps between its kernels %.1f us" % (np.mean(spans), min(spans), max(spans), np.mean(gaps)))
     step = np.diff([d[0] for d in diag]) * 1e-3
     print("  step period (diag inverse start to start): mean %.1f us; chain covers %.0f %% of it" % (step.mean(), 100 * np.mean(spans[:-1]) / step.mean()))
+    if len(diag) > 22:  # three steps from the middle, kernel by kernel (start relative to the first, duration; microseconds)
+        w0, w1 = diag[20][0], diag[23][0] if len(diag) > 23 else t1
+        print("  steps 20-22, kernel by kernel:")
+        for s_, e_, k_ in rows:
+            if w0 <= s_ < w1:
+                print("    %8.1f  +%7.1f  %s" % ((s_ - w0) * 1e-3, (e_ - s_) * 1e-3, k_))
     upd = [r for r in rows if r[2].startswith("k_update")]
     big = [(e - s) * 1e-3 for s, e, k in upd if (e - s) > 30000]
     if big:
