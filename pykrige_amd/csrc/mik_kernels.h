@@ -874,14 +874,64 @@ __global__ void __launch_bounds__(256) k_ss_reduce(const double* __restrict__ pa
 // with sigma_j = -1 for already-swept column blocks and +1 otherwise, so no transposes are needed.
 // ------------------------------------------------------------------------------------------------
 
+// The sweep's flag buffer (ints, zeroed before every inverse):
+//   [0]                      pivot status bits (1 = zero / non-finite pivot, 2 = non-positive pivot inside the station block)
+//   [MIK_F_START + kb]       diagonal inverse kb has STARTED        (relaxed: a scheduling hint, see k_gate)
+//   [MIK_F_DDONE + kb]       diagonal inverse kb has FINISHED       (release; its Dinv / DinvT are visible to an acquire)
+//   [MIK_F_UCNT + kb]        finished blocks of the update of step kb (release each)
+//   [MIK_F_ERR]              a bounded wait below ran out (never in a healthy run; the host turns it into an error)
+// The early-diagonal schedule orders its two streams through these instead of cross-stream events: a satisfied
+// hipStreamWaitEvent still costs ~12 us of barrier-packet latency per step and stream (profiles/r02_inverse_timeline.txt).
+#define MIK_F_STRIDE 4096  // block columns a sweep can have (N x N matrices end long before 524 288 stations)
+#define MIK_F_START 1
+#define MIK_F_DDONE (1 + MIK_F_STRIDE)
+#define MIK_F_UCNT (1 + 2 * MIK_F_STRIDE)
+#define MIK_F_ERR (1 + 3 * MIK_F_STRIDE)
+#define MIK_F_INTS (2 + 3 * MIK_F_STRIDE)
+#define MIK_WAIT_POLLS 4000000  // x (s_sleep 8 + one L2 round trip) > 1 s: only a lost kernel gets there
+
+__device__ __forceinline__ void diag_started(int* flag, int k0) {
+  if (threadIdx.x == 0) __hip_atomic_store(flag + MIK_F_START + k0 / 128, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// last action of a diagonal inverse: publish Dinv / DinvT (every thread's stores, through the barrier) and raise the flag
+__device__ __forceinline__ void diag_done(int* flag, int k0) {
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(flag + MIK_F_DDONE + k0 / 128, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+// one thread waits until flag[idx] >= expect (acquire); false after MIK_WAIT_POLLS polls (and MIK_F_ERR is raised)
+__device__ __forceinline__ bool flag_wait_ge(int* flag, int idx, int expect) {
+  for (int i = 0; i < MIK_WAIT_POLLS; ++i) {
+    if (__hip_atomic_load(flag + idx, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= expect) return true;
+    __builtin_amdgcn_s_sleep(8);
+  }
+  __hip_atomic_store(flag + MIK_F_ERR, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return false;
+}
+__global__ void k_gate(const int* __restrict__ flag, int idx, int max_polls) {
+  for (int i = 0; i < max_polls; ++i) {  // bounded: a late chain only costs this kernel's time, never a hang
+    if (__hip_atomic_load(flag + MIK_F_START + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    __builtin_amdgcn_s_sleep(8);
+  }
+}
+// a dependency, not a hint: the kernels behind this one on its stream read what the counted / flagged producers wrote
+__global__ void k_wait_ge(int* __restrict__ flag, int idx, int expect) { (void)flag_wait_ge(flag, idx, expect); }
+
 // Out[i][n] = alpha * sum_m A[i][m] * Bt[n][m],  i over Mp rows, n < 128, m < 128 (one tile column)
 __global__ void __launch_bounds__(256, 2)
 k_panel(const double* __restrict__ A, long lda, const double* __restrict__ Bt, double alpha,
-        double* __restrict__ Out, double* __restrict__ RtOut = nullptr, int k0 = 0, int blk0 = 0, int orow = 0) {
+        double* __restrict__ Out, double* __restrict__ RtOut = nullptr, int k0 = 0, int blk0 = 0, int orow = 0,
+        int* __restrict__ flag = nullptr, int wait_diag = -1, int gate_diag = -1) {
   // RtOut (symmetric sweep): also Rt[i][:] = -sigma_i Out[i][:], sigma_i = -1 for row blocks already swept
   // blk0 / orow (early-diagonal chain): start at row block blk0 and store row i at Out / RtOut row i - orow (a one-block launch
   // that leaves the 128 panel rows of one block in a 128 x 128 scratch)
+  // flag (early-diagonal schedule): wait_diag >= 0 -- Bt is the DinvT of diagonal inverse wait_diag, running on the other
+  // stream: wait for its flag before touching it; gate_diag >= 0 -- block 0 leaves only when diagonal inverse gate_diag has
+  // started (k_gate's hint without its launch: the update behind this kernel then finds that inverse already on its CU)
   __shared__ GemmSmem sm;
+  if (flag && wait_diag >= 0) {
+    if (threadIdx.x == 0) (void)flag_wait_ge(flag, MIK_F_DDONE + wait_diag, 1);
+    __syncthreads();
+  }
   const int i0 = (blockIdx.x + blk0) * MIK_BM;
   d4 acc[4][4];
 #pragma unroll
@@ -903,6 +953,12 @@ k_panel(const double* __restrict__ A, long lda, const double* __restrict__ Bt, d
         Out[(long)(i - orow) * 128 + n] = v;
         if (RtOut) RtOut[(long)(i - orow) * 128 + n] = (i < k0) ? v : -v;
       }
+  if (flag && gate_diag >= 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+    for (int i = 0; i < 20000; ++i) {
+      if (__hip_atomic_load(flag + MIK_F_START + gate_diag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+      __builtin_amdgcn_s_sleep(8);
+    }
+  }
 }
 
 // trailing update + panel write-back, one 128x128 tile per block.  part = 0: every tile; part = 1: only block column
@@ -915,16 +971,24 @@ template <bool SYM>
 __global__ void __launch_bounds__(256, 2)
 k_update(double* __restrict__ T, long ld, int nblk, int kb, const double* __restrict__ Cold,
          const double* __restrict__ Cnew, const double* __restrict__ Rt, const double* __restrict__ Dinv, int part, int col,
-         double* __restrict__ Pout, double* __restrict__ Dcopy = nullptr) {
+         double* __restrict__ Pout, double* __restrict__ Dcopy = nullptr, int* __restrict__ done_cnt = nullptr) {
   // Pout (nullable): the updated block column `col` is ALSO written as the next step's column panel
   // P[row][0..127] (what k_copy_panel / k_copy_panel_sym would read back out of T: tiles of the block row `col` go in transposed),
   // so that the next panel chain starts with the diagonal inverse instead of a copy kernel.
   // Dcopy (nullable): the updated diagonal tile (col + 1, col + 1) is also left there (128 x 128): the early-diagonal chain
-  // builds the diagonal block after next from it without touching T
+  // builds the diagonal block after next from it without touching T.
+  // done_cnt (nullable): every block of the launch adds one when its stores are out (release): the other stream waits for
+  // gridDim.x of them instead of for an event
   __shared__ GemmSmem sm;
+  auto finish = [&]() {
+    if (done_cnt) {
+      __syncthreads();
+      if (threadIdx.x == 0) __hip_atomic_fetch_add(done_cnt, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
   int iblk, jblk;
   if (part == 1) {
-    if ((int)blockIdx.x >= nblk) return;
+    if ((int)blockIdx.x >= nblk) return finish();
     if (SYM && (int)blockIdx.x > col) {
       iblk = col;
       jblk = blockIdx.x;
@@ -934,18 +998,18 @@ k_update(double* __restrict__ T, long ld, int nblk, int kb, const double* __rest
     }
   } else if (SYM) {
     const long L = xcd_tile((long)nblk * (nblk + 1) / 2);
-    if (L < 0) return;
+    if (L < 0) return finish();
     jblk = (int)((sqrt(8.0 * (double)L + 1.0) - 1.0) * 0.5);
     while ((long)jblk * (jblk + 1) / 2 > L) --jblk;            // guard the float estimate
     while ((long)(jblk + 1) * (jblk + 2) / 2 <= L) ++jblk;
     iblk = (int)(L - (long)jblk * (jblk + 1) / 2);             // i <= j: the upper block triangle
-    if (part == 2 && (iblk == col || jblk == col)) return;
+    if (part == 2 && (iblk == col || jblk == col)) return finish();
   } else {
     const long L = xcd_tile((long)nblk * nblk);
-    if (L < 0) return;
+    if (L < 0) return finish();
     iblk = (int)(L / nblk);
     jblk = (int)(L % nblk);
-    if (part == 2 && jblk == col) return;
+    if (part == 2 && jblk == col) return finish();
   }
   const int i0 = iblk * MIK_BM, j0 = jblk * MIK_BN, k0 = kb * 128;
   const bool ptrans = SYM && iblk == col && jblk != col;  // a tile of the block ROW col: panel rows = its columns
@@ -964,7 +1028,7 @@ k_update(double* __restrict__ T, long ld, int nblk, int kb, const double* __rest
         else P[(long)(i0 + r) * 128 + c] = v;
       }
     }
-    return;
+    return finish();
   }
   d4 acc[4][4];
 #pragma unroll
@@ -998,6 +1062,7 @@ k_update(double* __restrict__ T, long ld, int nblk, int kb, const double* __rest
       }
     __builtin_amdgcn_sched_barrier(0);
   }
+  finish();
 }
 
 // Early-diagonal chain: the diagonal block kb + 1 as step kb's update will leave it, Dnext = Dsrc - Cb . Rb^T, from the 128 panel
@@ -1080,16 +1145,6 @@ __device__ __forceinline__ double pivot_recip(double p) {
   return __builtin_fma(r, e, r);
 }
 
-__device__ __forceinline__ void diag_started(int* flag, int k0) {
-  if (threadIdx.x == 0) __hip_atomic_store(flag + 1 + k0 / 128, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__global__ void k_gate(const int* __restrict__ flag, int idx, int max_polls) {
-  for (int i = 0; i < max_polls; ++i) {  // bounded: a late chain only costs this kernel's time, never a hang
-    if (__hip_atomic_load(flag + 1 + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
-    __builtin_amdgcn_s_sleep(8);
-  }
-}
-
 // 128x128 in-register Gauss-Jordan inverse of the diagonal block, one 1024-thread workgroup.
 // Thread (w = wave 0..15, lane) owns rows 8w..8w+7, columns lane and lane+64.  Per elimination step
 // the owners publish the pivot row and pivot column through double-buffered LDS; one barrier per step.
@@ -1151,6 +1206,7 @@ __global__ void __launch_bounds__(1024) k_diag_inv(const double* __restrict__ T,
     DinvT[(lane + 64) * 128 + i] = ah[r];
   }
   if (bad && threadIdx.x == 0) atomicOr(flag, bad);
+  diag_done(flag, k0);
 }
 
 // The same 128x128 in-place Gauss-Jordan inverse on a NT-thread workgroup laid out as a GY x GX grid with a cyclic
@@ -1224,6 +1280,7 @@ __global__ void __launch_bounds__(GY * GX) k_diag_inv_t(const double* __restrict
       DinvT[c * 128 + r] = a[i][j];
     }
   if (bad && threadIdx.x == 0) atomicOr(flag, bad);
+  diag_done(flag, k0);
 }
 
 // Out[j][m] = T[k0+m][j]   (transpose of a 128-row panel; general path)

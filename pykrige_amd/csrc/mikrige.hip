@@ -715,7 +715,7 @@ int mik_set_option(mik_handle* h, const char* key, double value) {
   } else if (!strcmp(key, "fuse_chain")) {
     h->opt_fuse_chain = value != 0.0;
   } else if (!strcmp(key, "early_diag")) {
-    h->opt_early_diag = value < 0.0 ? -1 : (int)value;  // 2 = with the one-block tile kernels
+    h->opt_early_diag = value < 0.0 ? -1 : (int)value;  // 2 = with the one-block tile kernels, 3 = ordered by events only, 4 = by flags only
   } else if (!strcmp(key, "gate")) {
     h->opt_gate = value < 0.0 ? -1 : (value != 0.0);
   } else if (!strcmp(key, "diag")) {
@@ -926,8 +926,9 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
   MIKC(h->Rt.ensure(panel));
   MIKC(h->Dinv.ensure(sizeof(double) * 128 * 128));
   MIKC(h->DinvT.ensure(sizeof(double) * 128 * 128));
-  MIKC(h->flag.ensure(sizeof(int) * (size_t)(nblk + 2)));  // [0] = pivot flags, [1 + kb] = "diagonal inverse kb has started"
-  HIPC(hipMemsetAsync(h->flag.p, 0, sizeof(int) * (size_t)(nblk + 2), h->stream));
+  if (nblk > MIK_F_STRIDE) return fail(MIK_EINVAL, "more block columns than the sweep's flag layout holds");
+  MIKC(h->flag.ensure(sizeof(int) * (size_t)MIK_F_INTS));  // layout: MIK_F_* in mik_kernels.h
+  HIPC(hipMemsetAsync(h->flag.p, 0, sizeof(int) * (size_t)MIK_F_INTS, h->stream));
   const int ncand = Mp / 32;  // one candidate per 32-row block of the pivot-search panel (MIK_PIV_ROWS)
   if (pivoted) {
     MIKC(h->TKt.ensure(panel));
@@ -1017,11 +1018,26 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
       HIPC(hipMemcpy2DAsync(dcopy[0], sizeof(double) * 128, T + 128L * ld + 128, sizeof(double) * ld, sizeof(double) * 128, 128,
                             hipMemcpyDeviceToDevice, h->stream));  // tile (1, 1) as assembled: the second stream never reads T
       HIPC(hipEventRecord(h->la_events[0], h->stream));  // "update -1": the first panel set and diagonal inverse are there
+      HIPC(hipStreamWaitEvent(h->stream2, h->la_events[0], 0));
+      // The two streams order themselves through the flag buffer (MIK_F_*) where that is cheaper than an event wait (12 us of
+      // barrier-packet latency even when long satisfied):
+      //  * update stream <- "diagonal inverse kb finished": always a flag, polled by k_panel itself (one releasing block);
+      //  * chain stream <- "update kb-1 finished": a count of finished blocks behind k_wait_ge only for small sweeps (<= 300
+      //    tiles per step: N=2000 1.86 -> 1.77 ms) -- every block's release writes its XCD's L2 back, which costs a large
+      //    update more than the event does (N=5000: 5.4 -> 5.8 ms, N=8000: 15.1 -> 20.8 ms) -- otherwise an event.
+      // early_diag = 3 keeps events on both sides.  (Flags not beyond 128 block columns: k_panel's waiting blocks hold LDS, and
+      // with two of them on every CU a diagonal inverse that has not been placed yet could never start.)
+      const bool flags_s1 = h->opt_early_diag != 2 && h->opt_early_diag != 3 && nblk <= 128;
+      const bool flags_s2 = flags_s1 && (h->opt_early_diag == 4 || ltiles <= 300);
+      int* fl = h->flag.as<int>();
       for (int kb = 0; kb < nblk; ++kb) {
         const int set = kb & 1, k0 = kb * 128, k1 = k0 + 128;
         if (kb + 1 < nblk) {
           hipStream_t s2 = h->stream2;
-          HIPC(hipStreamWaitEvent(s2, h->la_events[2 * kb], 0));  // update kb-1 (event 2 kb) has left cold[set], dcopy
+          if (kb > 0) {  // update kb-1 has left cold[set], dcopy[set]
+            if (flags_s2) hipLaunchKernelGGL(k_wait_ge, dim3(1), dim3(1), 0, s2, fl, MIK_F_UCNT + kb - 1, (int)ug);
+            else HIPC(hipStreamWaitEvent(s2, h->la_events[2 * kb], 0));
+          }
           if (h->opt_early_diag == 2) {  // the library's one-block tile kernels (22 us each: a CU's MFMA rate), kept for comparison
             hipLaunchKernelGGL(k_panel, dim3(1), dim3(256), 0, s2, (const double*)cold[set], 128L, (const double*)dinvT[set], -1.0, cb, rb,
                                k0, kb + 1, k1);
@@ -1036,22 +1052,36 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
           // the diagonal-inverse kernels address T[(k0 + r) * ld + k0 + c]: hand them the 128 x 128 copy under that indexing
           const double* dview = (const double*)((uintptr_t)dnext - sizeof(double) * ((size_t)k1 * 128 + (size_t)k1));
           launch_diag_inv(h, s2, dview, 128L, k1, nspd, dinv[set ^ 1], dinvT[set ^ 1], gate);
-          HIPC(hipEventRecord(h->la_events[2 * kb + 1], s2));
+          if (!flags_s1) HIPC(hipEventRecord(h->la_events[2 * kb + 1], s2));
         }
+        const bool gate_here = gate && kb + 1 < nblk;
         if (kb > 0) {
-          HIPC(hipStreamWaitEvent(h->stream, h->la_events[2 * kb - 1], 0));  // diagonal inverse kb
+          if (!flags_s1) HIPC(hipStreamWaitEvent(h->stream, h->la_events[2 * kb - 1], 0));  // diagonal inverse kb
           // (the per-wavefront form of k_gemm128 for ALL panel rows was tried here: 30 us against 26 us -- its strided fragment
           // loads do not coalesce -- and its 640 blocks delay the chain's 64)
-          hipLaunchKernelGGL(k_panel, dim3(nblk), dim3(256), 0, h->stream, (const double*)cold[set], 128L, (const double*)dinvT[set], -1.0,
-                             cnew[set], rt[set], k0);
+          if (flags_s1)  // waits for diagonal inverse kb itself and, leaving, for diagonal inverse kb+1 to have started (the gate)
+            hipLaunchKernelGGL(k_panel, dim3(nblk), dim3(256), 0, h->stream, (const double*)cold[set], 128L, (const double*)dinvT[set], -1.0,
+                               cnew[set], rt[set], k0, 0, 0, fl, kb, gate_here ? kb + 1 : -1);
+          else
+            hipLaunchKernelGGL(k_panel, dim3(nblk), dim3(256), 0, h->stream, (const double*)cold[set], 128L, (const double*)dinvT[set], -1.0,
+                               cnew[set], rt[set], k0);
         }
         if (kb + 1 < nblk) {
-          if (gate) hipLaunchKernelGGL(k_gate, dim3(1), dim3(1), 0, h->stream, (const int*)h->flag.as<int>(), kb + 1, 20000);
-          UPDX(dim3(ug), h->stream, cold[set], cnew[set], rt[set], dinv[set], 0, kb + 1, cold[set ^ 1], dcopy[set ^ 1]);
-          HIPC(hipEventRecord(h->la_events[2 * kb + 2], h->stream));
+          if (gate_here && (!flags_s1 || kb == 0)) hipLaunchKernelGGL(k_gate, dim3(1), dim3(1), 0, h->stream, (const int*)fl, kb + 1, 20000);
+          if (symsweep)
+            hipLaunchKernelGGL(k_update<true>, dim3(ug), dim3(256), 0, h->stream, T, ld, nblk, kb, (const double*)cold[set], (const double*)cnew[set],
+                               (const double*)rt[set], (const double*)dinv[set], 0, kb + 1, cold[set ^ 1], dcopy[set ^ 1], flags_s2 ? fl + MIK_F_UCNT + kb : (int*)nullptr);
+          else
+            hipLaunchKernelGGL(k_update<false>, dim3(ug), dim3(256), 0, h->stream, T, ld, nblk, kb, (const double*)cold[set], (const double*)cnew[set],
+                               (const double*)rt[set], (const double*)dinv[set], 0, kb + 1, cold[set ^ 1], dcopy[set ^ 1], flags_s2 ? fl + MIK_F_UCNT + kb : (int*)nullptr);
+          if (!flags_s2) HIPC(hipEventRecord(h->la_events[2 * kb + 2], h->stream));
         } else {
           UPD(dim3(ug), h->stream, cold[set], cnew[set], rt[set], dinv[set], 0, -2, (double*)nullptr);
         }
+      }
+      if (flags_s1) {  // once per inverse: the second stream has drained before this one goes on (and before the next call's memset)
+        HIPC(hipEventRecord(h->la_events[1], h->stream2));
+        HIPC(hipStreamWaitEvent(h->stream, h->la_events[1], 0));
       }
     } else
     for (int kb = 0; kb < nblk; ++kb) {
@@ -1113,9 +1143,11 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
     hipLaunchKernelGGL(k_swap_cols, dim3((Mp + 255) / 256), dim3(256), 0, h->stream, T, ld,
                        (const int*)h->pivall.as<int>(), Mp, Mp);
   HIPC(hipGetLastError());
-  int flag = 0;
+  int flag = 0, lost = 0;
   HIPC(hipMemcpyAsync(&flag, h->flag.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPC(hipMemcpyAsync(&lost, h->flag.as<int>() + MIK_F_ERR, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIPC(hipStreamSynchronize(h->stream));
+  if (lost) return fail(MIK_EHIP, "block sweep: a cross-stream wait ran out (a producer kernel never finished)");
   *flag_out = flag;
   return MIK_OK;
 }

@@ -20,7 +20,7 @@ int main(int argc,char**argv){
   CK(hipMalloc(&T,sizeof(double)*(size_t)Mp*Mp)); CK(hipMalloc(&Bt,sizeof(double)*(size_t)P*Mp));
   CK(hipMalloc(&part,sizeof(double)*(size_t)P*nblk)); CK(hipMalloc(&Dinv,131072)); CK(hipMalloc(&DinvT,131072));
   CK(hipMalloc(&Cold,sizeof(double)*(size_t)Mp*128)); CK(hipMalloc(&Cnew,sizeof(double)*(size_t)Mp*128)); CK(hipMalloc(&Rt,sizeof(double)*(size_t)Mp*128));
-  CK(hipMalloc(&flag,4096)); CK(hipMemset(flag,0,4096));
+  CK(hipMalloc(&flag,sizeof(int)*MIK_F_INTS)); CK(hipMemset(flag,0,sizeof(int)*MIK_F_INTS));
   { std::vector<double> h((size_t)Mp*Mp); srand(1);
     for(size_t i=0;i<h.size();++i) h[i]=(rand()/(double)RAND_MAX-0.5)*0.01;
     for(int i=0;i<Mp;++i) h[(size_t)i*Mp+i]=1.0+0.1*(i%7);
