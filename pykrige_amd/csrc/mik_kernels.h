@@ -1038,20 +1038,28 @@ k_update(double* __restrict__ T, long ld, int nblk, int kb, const double* __rest
   gemm_core<4>(Cold + (long)i0 * 128, 128, Rt + (long)j0 * 128, 128, 0, 128, acc, sm);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 1, wn = wave & 1, lq = lane >> 4, lc = lane & 15;
-#pragma unroll
-  for (int ai = 0; ai < 4; ++ai) {  // read-modify-write in batches of 16 independent loads (see k_contract's epilogue)
-    double tv[4][4];
-    double* tp = T + (long)(i0 + wm * 64 + ai * 16 + lq) * ld + j0 + wn * 64 + lc;
+  // read-modify-write in batches of 16 independent loads, the NEXT batch's loads in flight while this one is subtracted and
+  // stored (two register sets): the epilogue pays the memory latency once, not four times
+  double tv[2][4][4];
+  auto tile_ptr = [&](int ai) { return T + (long)(i0 + wm * 64 + ai * 16 + lq) * ld + j0 + wn * 64 + lc; };
+  auto load_batch = [&](int ai, double (&dst)[4][4]) {
+    const double* tp = tile_ptr(ai);
 #pragma unroll
     for (int bi = 0; bi < 4; ++bi)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) tv[bi][r] = tp[(long)(4 * r) * ld + bi * 16];
+      for (int r = 0; r < 4; ++r) dst[bi][r] = tp[(long)(4 * r) * ld + bi * 16];
+  };
+  load_batch(0, tv[0]);
+#pragma unroll
+  for (int ai = 0; ai < 4; ++ai) {
+    if (ai + 1 < 4) load_batch(ai + 1, tv[(ai + 1) & 1]);
     __builtin_amdgcn_sched_barrier(0);
+    double* tp = tile_ptr(ai);
 #pragma unroll
     for (int bi = 0; bi < 4; ++bi)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const double v = tv[bi][r] - acc[ai][bi][r];
+        const double v = tv[ai & 1][bi][r] - acc[ai][bi][r];
         tp[(long)(4 * r) * ld + bi * 16] = v;
         if (P) {
           const int row = wm * 64 + ai * 16 + lq + 4 * r, cc = wn * 64 + bi * 16 + lc;  // position inside the tile
