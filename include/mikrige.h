@@ -129,7 +129,12 @@ int  mik_slab_of(int64_t n, int members, int i, int64_t *lo, int64_t *count); /*
  *   blocks (higher L2 hit rate, measured 2.7 % slower: the kernel is not traffic-bound) ;
  * "chunk" = points per contraction launch (multiple of 128) ;
  * "lookahead" 0/1/-1 = overlap the next panel's serial chain with the current trailing update in the block sweep
- *   (default -1: from 24 block columns on) ; "fuse_chain" 0/1 = the block-column update leaves the next panel copy in place and the
+ *   (default -1: from 3 block columns on with the early-diagonal schedule, else from 24) ;
+ * "early_diag" -1/0/1/2/3/4 = look-ahead sweep: the next diagonal block is built from 128 panel rows (two distributed 128^3
+ *   products) and inverted on the second stream AHEAD of the panel kernel and update of its step (default -1 = 1 = on, the two
+ *   streams ordered by flags where that is cheaper than events; 0 = the round-1 look-ahead; 2 = with one-block tile kernels;
+ *   3 / 4 = ordered by events / by flags only).  Every setting returns the bit-identical inverse ;
+ * "fuse_chain" 0/1 = the block-column update leaves the next panel copy in place and the
  *   panel kernel writes R^T itself: two kernels on the serial chain instead of four (default 1) ; "diag" 0..3 = diagonal-block inverse kernel variant (default 1) ;
  * "pinv_fast" 0/1 = pseudo_inv: try the deflated regular inverse before the Jacobi pseudo-inverse (default 1) ;
  * "gate" 0/1/-1 = look-ahead sweep: the trailing update of a step starts only once the next diagonal inverse sits on a CU of its

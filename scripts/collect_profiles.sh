@@ -1,6 +1,7 @@
 #!/bin/bash
 # Copy the summaries of an evidence run (gpurun_out/TAG, written by scripts/gpu_final.sh) into profiles/ (tracked).
 TAG=${1:?tag}; R=${2:-r02}; S=gpurun_out/$TAG; P=profiles
+cp() { [ -e "$1" ] && command cp "$1" "$2"; }   # a "k2" run of gpu_final.sh leaves some files out: keep the older summaries
 for c in 2 3 4 5; do cp $S/bench_c$c.json $P/${R}_bench_c$c.json; cp $S/ks_c$c/ks_kernel_stats.csv $P/${R}_bench_c${c}_rocprofv3_kernel_stats.csv; done
 for k in 10 50 100; do cp $S/bench_mw$k.json $P/${R}_bench_moving_window_k$k.json; done
 cp $S/ks_mw50/ks_kernel_stats.csv $P/${R}_bench_moving_window_k50_rocprofv3_kernel_stats.csv
