@@ -130,10 +130,12 @@ int  mik_slab_of(int64_t n, int members, int i, int64_t *lo, int64_t *count); /*
  * "chunk" = points per contraction launch (multiple of 128) ;
  * "lookahead" 0/1/-1 = overlap the next panel's serial chain with the current trailing update in the block sweep
  *   (default -1: from 3 block columns on with the early-diagonal schedule, else from 24) ;
- * "early_diag" -1/0/1/2/3/4 = look-ahead sweep: the next diagonal block is built from 128 panel rows (two distributed 128^3
+ * "early_diag" -1/0/1/2/4/5 = look-ahead sweep: the next diagonal block is built from 128 panel rows (two distributed 128^3
  *   products) and inverted on the second stream AHEAD of the panel kernel and update of its step (default -1 = 1 = on, the two
- *   streams ordered by flags where that is cheaper than events; 0 = the round-1 look-ahead; 2 = with one-block tile kernels;
- *   3 / 4 = ordered by events / by flags only).  Every setting returns the bit-identical inverse ;
+ *   streams ordered by events; 0 = the round-1 look-ahead; 2 = with one-block tile kernels; 5 / 4 = the update stream / both
+ *   streams ordered by in-kernel flag waits instead -- 6 % faster at N=5000, but not for runs under tools that serialise
+ *   kernel dispatches such as rocprofv3 --pmc: there the wait runs out and mik_factor returns MIK_EHIP).  Environment:
+ *   MIK_EARLY_DIAG.  Every setting returns the bit-identical inverse ;
  * "fuse_chain" 0/1 = the block-column update leaves the next panel copy in place and the
  *   panel kernel writes R^T itself: two kernels on the serial chain instead of four (default 1) ; "diag" 0..3 = diagonal-block inverse kernel variant (default 1) ;
  * "pinv_fast" 0/1 = pseudo_inv: try the deflated regular inverse before the Jacobi pseudo-inverse (default 1) ;

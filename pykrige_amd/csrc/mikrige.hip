@@ -535,6 +535,8 @@ static int create_one_body(mik_handle* h, int device) {
   if (env) h->opt_exchange = !strcmp(env, "rccl") ? 1 : !strcmp(env, "peer") ? 2 : !strcmp(env, "redundant") ? 3 : 0;
   env = getenv("MIK_ALIAS_DEVICES");
   if (env) h->alias_ok = atoi(env) != 0;
+  env = getenv("MIK_EARLY_DIAG");
+  if (env) h->opt_early_diag = atoi(env) < 0 ? -1 : atoi(env);
   return MIK_OK;
 }
 
@@ -715,7 +717,7 @@ int mik_set_option(mik_handle* h, const char* key, double value) {
   } else if (!strcmp(key, "fuse_chain")) {
     h->opt_fuse_chain = value != 0.0;
   } else if (!strcmp(key, "early_diag")) {
-    h->opt_early_diag = value < 0.0 ? -1 : (int)value;  // 2 = with the one-block tile kernels, 3 = ordered by events only, 4 = by flags only
+    h->opt_early_diag = value < 0.0 ? -1 : (int)value;  // 1 / 3 = on (streams ordered by events), 2 = with the one-block tile kernels, 4 / 5 = ordered by flags (both sides / update stream only)
   } else if (!strcmp(key, "gate")) {
     h->opt_gate = value < 0.0 ? -1 : (value != 0.0);
   } else if (!strcmp(key, "diag")) {
@@ -1019,16 +1021,20 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
                             hipMemcpyDeviceToDevice, h->stream));  // tile (1, 1) as assembled: the second stream never reads T
       HIPC(hipEventRecord(h->la_events[0], h->stream));  // "update -1": the first panel set and diagonal inverse are there
       HIPC(hipStreamWaitEvent(h->stream2, h->la_events[0], 0));
-      // The two streams order themselves through the flag buffer (MIK_F_*) where that is cheaper than an event wait (12 us of
-      // barrier-packet latency even when long satisfied):
-      //  * update stream <- "diagonal inverse kb finished": always a flag, polled by k_panel itself (one releasing block);
-      //  * chain stream <- "update kb-1 finished": a count of finished blocks behind k_wait_ge only for small sweeps (<= 300
-      //    tiles per step: N=2000 1.86 -> 1.77 ms) -- every block's release writes its XCD's L2 back, which costs a large
-      //    update more than the event does (N=5000: 5.4 -> 5.8 ms, N=8000: 15.1 -> 20.8 ms) -- otherwise an event.
-      // early_diag = 3 keeps events on both sides.  (Flags not beyond 128 block columns: k_panel's waiting blocks hold LDS, and
-      // with two of them on every CU a diagonal inverse that has not been placed yet could never start.)
-      const bool flags_s1 = h->opt_early_diag != 2 && h->opt_early_diag != 3 && nblk <= 128;
-      const bool flags_s2 = flags_s1 && (h->opt_early_diag == 4 || ltiles <= 300);
+      // The two streams are ordered by events (default).  A satisfied hipStreamWaitEvent still costs ~12 us of barrier-packet
+      // latency per step and stream, so two opt-in modes order them through the flag buffer (MIK_F_*) instead:
+      //   early_diag = 5: update stream <- "diagonal inverse kb finished" by a flag the inverse releases, polled inside k_panel
+      //                   (N=5000: 5.35 -> 5.0 ms, N=8000: 15.1 -> 14.6 ms);
+      //   early_diag = 4: also chain stream <- "update kb-1 finished" by a count of finished blocks behind k_wait_ge -- every
+      //                   block's release writes its XCD's L2 back: good for small sweeps only (N=2000: 1.86 -> 1.76 ms; N=8000:
+      //                   15.1 -> 20.8 ms).
+      // They are NOT the default because a kernel that waits for a kernel of another stream needs both to be able to run
+      // concurrently: under tools that serialise dispatches (rocprofv3 --pmc, debuggers) the wait runs out (bounded: an error,
+      // not a hang).  (Also not beyond 128 block columns: k_panel's waiting blocks hold LDS, and with two of them on every CU
+      // a diagonal inverse that has not been placed yet could never start.)  What IS folded into k_panel in every mode is
+      // k_gate's poll: a hint with a bounded wait, harmless when serialised.
+      const bool flags_s1 = (h->opt_early_diag == 4 || h->opt_early_diag == 5) && nblk <= 128;
+      const bool flags_s2 = flags_s1 && h->opt_early_diag == 4;
       int* fl = h->flag.as<int>();
       for (int kb = 0; kb < nblk; ++kb) {
         const int set = kb & 1, k0 = kb * 128, k1 = k0 + 128;
@@ -1059,15 +1065,13 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
           if (!flags_s1) HIPC(hipStreamWaitEvent(h->stream, h->la_events[2 * kb - 1], 0));  // diagonal inverse kb
           // (the per-wavefront form of k_gemm128 for ALL panel rows was tried here: 30 us against 26 us -- its strided fragment
           // loads do not coalesce -- and its 640 blocks delay the chain's 64)
-          if (flags_s1)  // waits for diagonal inverse kb itself and, leaving, for diagonal inverse kb+1 to have started (the gate)
-            hipLaunchKernelGGL(k_panel, dim3(nblk), dim3(256), 0, h->stream, (const double*)cold[set], 128L, (const double*)dinvT[set], -1.0,
-                               cnew[set], rt[set], k0, 0, 0, fl, kb, gate_here ? kb + 1 : -1);
-          else
-            hipLaunchKernelGGL(k_panel, dim3(nblk), dim3(256), 0, h->stream, (const double*)cold[set], 128L, (const double*)dinvT[set], -1.0,
-                               cnew[set], rt[set], k0);
+          // k_panel, leaving, polls for diagonal inverse kb+1 to have started (the gate); with flags_s1 it first waits for
+          // diagonal inverse kb itself
+          hipLaunchKernelGGL(k_panel, dim3(nblk), dim3(256), 0, h->stream, (const double*)cold[set], 128L, (const double*)dinvT[set], -1.0,
+                             cnew[set], rt[set], k0, 0, 0, fl, flags_s1 ? kb : -1, gate_here ? kb + 1 : -1);
         }
         if (kb + 1 < nblk) {
-          if (gate_here && (!flags_s1 || kb == 0)) hipLaunchKernelGGL(k_gate, dim3(1), dim3(1), 0, h->stream, (const int*)fl, kb + 1, 20000);
+          if (gate_here && kb == 0) hipLaunchKernelGGL(k_gate, dim3(1), dim3(1), 0, h->stream, (const int*)fl, kb + 1, 20000);
           if (symsweep)
             hipLaunchKernelGGL(k_update<true>, dim3(ug), dim3(256), 0, h->stream, T, ld, nblk, kb, (const double*)cold[set], (const double*)cnew[set],
                                (const double*)rt[set], (const double*)dinv[set], 0, kb + 1, cold[set ^ 1], dcopy[set ^ 1], flags_s2 ? fl + MIK_F_UCNT + kb : (int*)nullptr);

@@ -12,7 +12,7 @@ for cfgid in (2, 3, 5):
     coords, values = synth(cfg["seed"], cfg["n"], nd)
     ref = None
     line = "config %d N=%d:" % (cfgid, cfg["n"])
-    for la, early, gate in ((0, 0, -1), (1, 0, -1), (1, 3, -1), (1, 4, -1), (1, 1, -1)):
+    for la, early, gate in ((0, 0, -1), (1, 0, -1), (1, 1, -1), (1, 5, -1), (1, 4, -1)):
         for diag, sym in ((1, 0), (1, 1)):
             h = _lib.Handle(0)
             h.set_option("lookahead", la)
@@ -30,7 +30,7 @@ for cfgid in (2, 3, 5):
             a = h.get_matrix(1)
             if ref is None:
                 ref = a
-            line += "  la%d%s/d%d/sym%d %.2f ms (%.0e)" % (la, ("", "e", "e2", "e3", "e4")[early] + ("" if gate < 0 else "g%d" % gate), diag, sym, min(ts), np.abs(a - ref).max() / np.abs(ref).max())
+            line += "  la%d%s/d%d/sym%d %.2f ms (%.0e)" % (la, ("", "e", "e2", "e3", "e4", "e5")[early] + ("" if gate < 0 else "g%d" % gate), diag, sym, min(ts), np.abs(a - ref).max() / np.abs(ref).max())
             h.close()
     print(line, flush=True)
 

@@ -192,8 +192,8 @@ def test_block_sweep_variants_agree():
     # (look-ahead, diagonal kernel, half sweep, gate, fused chain, early-diagonal schedule)
     for la, diag, sym, gate, fuse, early in ((0, 0, 0, 1, 1, 1), (1, 0, 0, 1, 1, 1), (0, 1, 0, 1, 1, 1), (1, 1, 0, 1, 1, 1), (1, 1, 0, 0, 1, 1), (1, 1, 0, 1, 1, 0),
                                              (1, 1, 0, 0, 1, 0), (1, 1, 0, 1, 0, 0), (1, 2, 0, 1, 1, 1), (0, 3, 0, 1, 1, 1), (0, 1, 1, 1, 1, 1), (1, 1, 1, 1, 1, 1),
-                                             (1, 1, 1, 0, 1, 1), (1, 1, 1, 1, 1, 0), (1, 1, 1, 0, 1, 0), (1, 1, 1, 1, 0, 0), (1, 1, 0, 1, 1, 2), (1, 1, 1, 1, 1, 2), (1, 1, 0, 1, 1, 3), (1, 1, 1, 0, 1, 3), (1, 1, 0, 1, 1, 4), (1, 1, 1, 1, 1, 4)):
-        h.set_option("early_diag", early)  # the next diagonal block is built and inverted ahead of the panel / update stream (2: one-block kernels, 3 / 4: streams ordered by events / by flags only)
+                                             (1, 1, 1, 0, 1, 1), (1, 1, 1, 1, 1, 0), (1, 1, 1, 0, 1, 0), (1, 1, 1, 1, 0, 0), (1, 1, 0, 1, 1, 2), (1, 1, 1, 1, 1, 2), (1, 1, 0, 1, 1, 5), (1, 1, 1, 0, 1, 5), (1, 1, 0, 1, 1, 4), (1, 1, 1, 1, 1, 4)):
+        h.set_option("early_diag", early)  # the next diagonal block is built and inverted ahead of the panel / update stream (2: one-block kernels, 5 / 4: update stream / both streams ordered by flags instead of events)
         h.set_option("lookahead", la)
         h.set_option("fuse_chain", fuse)  # the column update also leaves the next panel copy, the panel kernel also writes R^T
         h.set_option("diag", diag)
