@@ -146,6 +146,8 @@ int  mik_slab_of(int64_t n, int members, int i, int64_t *lo, int64_t *count); /*
  *   itself for exponential / spherical from 24 block columns on ;
  * "mw_pivot" 0/1 = always solve the moving-window systems with partial pivoting (default 0: SPD-shifted, no pivot search,
  *   falling back to pivoting when a local system is not positive definite) ;
+ * "mw_solver" 0/1 = moving-window systems by the register-tile LDL^T kernel (default 0, K <= 256) or by the Gauss-Jordan / HBM-LU
+ *   kernels of round 1 (1; also what larger windows use) ;
  * "mw_lds_cap" = largest moving-window candidate buffer kept in LDS (entries, default 8192; 0 forces the HBM lists) ;
  * "exchange" 0..3 = how a device group distributes the inverted matrix: 0 auto (RCCL broadcast, peer copies if RCCL is
  *   unavailable), 1 RCCL broadcast, 2 peer copies (scatter + all-gather over xGMI), 3 none (every device factors) [MIK_EXCHANGE] ;

@@ -32,6 +32,22 @@ def test_library_exports_every_declared_symbol():
     assert set(_lib.SIGNATURES) == set(names)
 
 
+def test_every_option_and_environment_variable_of_the_library_is_documented():
+    """mik_set_option keys and MIK_* environment variables the library reads (csrc/mikrige.hip) appear in the header's option
+    list (include/mikrige.h) / INTEGRATION.md's environment table: the boundary's documentation cannot fall behind the code."""
+    src = open(os.path.join(ROOT, "pykrige_amd", "csrc", "mikrige.hip")).read()
+    header = open(os.path.join(ROOT, "include", "mikrige.h")).read()
+    integration = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    keys = sorted(set(re.findall(r'strcmp\(key, "([a-z_0-9]+)"\)', src)))
+    assert len(keys) >= 18
+    for k in keys:
+        assert '"%s"' % k in header, "option %r is not documented in include/mikrige.h" % k
+    envs = sorted(set(re.findall(r'getenv\("(MIK_[A-Z_0-9]+)"\)', src)))
+    assert "MIK_NGPU" in envs and "MIK_EARLY_DIAG" in envs
+    for e in envs:
+        assert "`%s`" % e in integration or "`%s`" % e in header or e in integration, "%s is not in INTEGRATION.md's environment table" % e
+
+
 def test_ctypes_structs_match_header_layout():
     from pykrige_amd import _lib
 
