@@ -1004,11 +1004,12 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
     if (early) {
       // Early-diagonal schedule.  What the next diagonal inverse needs of step kb is ONE tile, D(kb+1) - C_b R_b^T, and that takes
       // only the 128 panel rows of block kb + 1.  The second stream therefore runs, per step,
-      //     [wait: update kb-1 done]  k_panel (one block) -> k_next_diag -> diagonal inverse kb+1
-      // from the column panel and the diagonal-tile copy (two alternate) that update kb-1 left behind (it never reads T), while the first stream
-      // runs  [wait: diagonal inverse kb done]  k_panel (all rows) -> the WHOLE update of step kb  -- one launch, no split, and
-      // the serial chain (diagonal inverse + two one-block kernels) no longer contains the full panel kernel, the block-column
-      // update or a second cross-stream wait.  Same kernels, same operands per tile: the inverse is bit-identical.
+      //     [wait: update kb-1 done]  k_gemm128<0> (R_b = C_b Dinv) -> k_gemm128<1> (the tile) -> diagonal inverse kb+1
+      // from the column panel and the diagonal-tile copy (two alternate) that update kb-1 left behind (it never reads T), while
+      // the first stream runs  [wait: diagonal inverse kb done]  k_panel (all rows) -> the WHOLE update of step kb  -- one
+      // launch, no split.  The serial chain (diagonal inverse + two 6-us products spread over 64 blocks) no longer contains the
+      // full panel kernel, the block-column update or a second cross-stream wait, and the diagonal inverse overlaps the update.
+      // Same accumulation order per entry as k_panel / k_update: the inverse is bit-identical.
       MIKC(h->Dnext.ensure(sizeof(double) * 128 * 128));
       MIKC(h->Dcopy.ensure(sizeof(double) * 2 * 128 * 128));
       MIKC(h->Cb.ensure(sizeof(double) * 128 * 128));
