@@ -84,6 +84,27 @@ typedef struct mik_points {
   const double *extra_rows;   /* n_extra x npt row-major: host-evaluated drift terms at the points; nullable if n_extra==0 */
 } mik_points;
 
+/* The prediction points of style='grid' / 'masked' given by their AXES: what execute() builds with np.meshgrid and
+ * adjusts point by point on the host (ok.py:863-885, uk.py:1263-1284, ok3d.py:866-883, uk3d.py:1089-1106;
+ * core.py:120-193 _adjust_for_anisotropy) is generated on the device, so the H2D traffic of a grid is O(nx + ny + nz)
+ * instead of npt x d doubles.  Point order = the reference's flattened meshgrid: 2-D cell iy*nx + ix, 3-D cell
+ * (iz*ny + iy)*nx + ix.  Arithmetic in the reference's order (X -= c ; rot . X ; stretch . (..) ; += c). */
+typedef struct mik_grid {
+  int32_t ndim;                /* 2 or 3 (must equal the problem's) */
+  int32_t adjust;              /* 1 = apply the anisotropy transform below; 0 = take the axes' values as they are
+                                  (geographic coordinates: ok.py:892-896) */
+  int64_t nx, ny, nz;          /* axis lengths; nz ignored when ndim == 2 */
+  const double *gx, *gy, *gz;  /* xpoints, ypoints[, zpoints] as handed to execute(), fp64 */
+  double center[3];            /* XCENTER, YCENTER[, ZCENTER] */
+  double rot[9];               /* rotation matrix of core.py:150-154 / 166-187, row-major ndim x ndim (leading entries) */
+  double stretch[3];           /* diagonal of the stretch matrix: 1, scaling  /  1, scaling_y, scaling_z */
+  int64_t cell_first, cell_count; /* krige only cells cell_first .. cell_first + cell_count - 1 of the flattened grid (one
+                                  rank's slab when the caller shards: pykrige_amd.dist); cell_count = 0: the whole grid.
+                                  mask, extra_rows and the outputs of mik_get_results are relative to this range */
+  const int8_t *mask;          /* nullable; one byte per cell of the range, flattened like the cells; nonzero = skip */
+  const double *extra_rows;    /* n_extra x (cells of the range) row-major host-evaluated drift terms; nullable if n_extra == 0 */
+} mik_grid;
+
 /* Per-phase device times of the last mik_factor / mik_predict (HIP events on the handle's stream). */
 typedef struct mik_timing {
   double assemble_ms;     /* K1: kriging-matrix assembly */
@@ -100,6 +121,9 @@ typedef struct mik_timing {
   double exchange_ms;     /* device groups: host wall time of the factor exchange of the last mik_factor (0 for one device) */
   int32_t exchange_path;  /* 0 = none (one device), 1 = RCCL broadcast, 2 = peer copies (scatter + all-gather), 3 = every device factored */
   int32_t n_devices;      /* members of the handle's device group */
+  double exchange_wait_ms;     /* of exchange_ms, the part a caller was blocked for (the rest overlapped the leader's prediction) */
+  int32_t exchange_fallbacks;  /* exchange paths that failed or timed out before exchange_path succeeded (mik_exchange_note says why) */
+  int32_t rccl_ranks;          /* communicators (= ranks = devices) the RCCL broadcast ran over; 0 if RCCL was not used */
 } mik_timing;
 
 int  mik_device_count(void);
@@ -151,7 +175,11 @@ int  mik_slab_of(int64_t n, int members, int i, int64_t *lo, int64_t *count); /*
  * "mw_lds_cap" = largest moving-window candidate buffer kept in LDS (entries, default 8192; 0 forces the HBM lists) ;
  * "exchange" 0..3 = how a device group distributes the inverted matrix: 0 auto (RCCL broadcast, peer copies if RCCL is
  *   unavailable), 1 RCCL broadcast, 2 peer copies (scatter + all-gather over xGMI), 3 none (every device factors) [MIK_EXCHANGE] ;
- * "alias_devices" 0/1 = a device group may place several members on one physical GPU (1-GPU test boxes) [MIK_ALIAS_DEVICES] */
+ * "alias_devices" 0/1 = a device group may place several members on one physical GPU (1-GPU test boxes) [MIK_ALIAS_DEVICES] ;
+ * "async_exchange" 0/1 = device groups: mik_factor returns once the leader has factored, the exchange is joined by the next
+ *   call and overlaps the leader's prediction (default 1) [MIK_ASYNC_EXCHANGE] ;
+ * "rccl_init_timeout", "rccl_bcast_timeout", "peer_timeout" = the bounded waits of the factor exchange, seconds (see
+ *   "Bounded waits" below) [MIK_RCCL_INIT_TIMEOUT, MIK_RCCL_BCAST_TIMEOUT, MIK_PEER_TIMEOUT] */
 int  mik_set_option(mik_handle *h, const char *key, double value);
 
 /* variogram_model='custom' (a Python callable in the reference: ok.py:305-318, core.py:584-586).  Geometry stays on the
@@ -164,6 +192,9 @@ int  mik_set_custom_variogram(mik_handle *h, mik_variogram_fn fn, void *user);
 int  mik_set_problem(mik_handle *h, const mik_problem *p); /* H2D of stations/values/drifts            */
 int  mik_factor(mik_handle *h);                            /* K1 + K2 (+ c = A_inv[:, :n].Z) on device   */
 int  mik_set_points(mik_handle *h, const mik_points *g);   /* H2D of the (unmasked) points              */
+int  mik_set_grid(mik_handle *h, const mik_grid *g);       /* the same for a grid given by its axes: H2D of the axes (and
+                                                              the compacted cell indices of a mask), points generated and
+                                                              anisotropy-adjusted on the device */
 int  mik_predict(mik_handle *h);                           /* K3 over the resident points; results stay in HBM */
 int  mik_get_results(mik_handle *h, double *z_out, double *ss_out); /* D2H, scattered through the mask  */
 int  mik_synchronize(mik_handle *h);                       /* wait until the handle's stream is idle (every call above
@@ -191,6 +222,9 @@ int  mik_krige_execute(int device, const mik_problem *p, const mik_points *g, do
 int  mik_assemble_only(mik_handle *h);
 int  mik_get_matrix(mik_handle *h, int which, double *out);
 int64_t mik_matrix_order(mik_handle *h); /* M = n + ndrift + 1 */
+int64_t mik_points_resident(mik_handle *h);  /* unmasked points on the device(s) after mik_set_points / mik_set_grid */
+int  mik_get_points(mik_handle *h, double *px_out, double *py_out, double *pz_out); /* those points' adjusted coordinates
+                                            (diagnostic: what mik_set_grid generated), mik_points_resident() doubles each */
 int  mik_get_timing(mik_handle *h, mik_timing *out);   /* device group: the leader's phases, predict_ms = slowest member */
 int  mik_get_device_timing(mik_handle *h, int member, mik_timing *out); /* one member of a device group (0 = the handle's own device) */
 int  mik_selftest_mfma(int device); /* 0 if the v_mfma_f64_4x4x4_4b_f64 (and 16x16x4) fragment layouts are what the kernels assume */
@@ -201,6 +235,27 @@ int  mik_selftest_mfma(int device); /* 0 if the v_mfma_f64_4x4x4_4b_f64 (and 16x
 int  mik_comm_unique_id(char id_out[128]);
 int  mik_comm_init(mik_handle *h, int nranks, int rank, const char id[128]);
 int  mik_bcast_factor(mik_handle *h, int root); /* ranks != root need mik_set_problem first, not mik_factor */
+int  mik_factor_checksum(mik_handle *h, uint64_t out[4]); /* order-independent checksums of the inverted matrix (2 words) and
+                                                  of c (2 words) as this handle's device holds them: equal on every rank
+                                                  after a sound broadcast */
+
+/* Bounded waits.  Nothing in the multi-GPU paths can block for ever: communicator set-up (ncclCommInitAll /
+ * ncclCommInitRank) is given MIK_RCCL_INIT_TIMEOUT seconds (default 120; option "rccl_init_timeout"), a broadcast of the
+ * factor MIK_RCCL_BCAST_TIMEOUT (default 30; "rccl_bcast_timeout"), the peer scatter + all-gather MIK_PEER_TIMEOUT (default
+ * 30; "peer_timeout").  When a limit expires the stuck call is abandoned on its worker thread together with the streams
+ * and buffers it may still touch (leaked on purpose), RCCL is marked unusable for the rest of the process, and
+ *   - a device group with exchange = auto goes on to peer copies, then to every member factoring the matrix itself;
+ *     mik_timing.exchange_path / exchange_fallbacks and mik_exchange_note() say what happened;
+ *   - a forced path ("exchange" 1 / 2), mik_comm_init and mik_bcast_factor return MIK_ERCCL / MIK_EHIP.
+ * Every exchange of a device group is verified: each member checksums its copy of the inverse on its device against the
+ * leader's; a mismatch counts as a failed exchange.  With "async_exchange" 1 (default; MIK_ASYNC_EXCHANGE) mik_factor
+ * returns when the leader has factored; the exchange is joined by the next call on the handle, and mik_predict lets the
+ * leader krige its slab while the transfer is in flight. */
+const char *mik_exchange_note(mik_handle *h);   /* why exchange paths of the last mik_factor were given up ("" if none were) */
+int  mik_selftest_exchange(int members, double init_limit_s, double bcast_limit_s, char *report, int report_len);
+                                                /* the RCCL path of the group exchange with stand-in members and NO HIP
+                                                   call (runs without a GPU): drives the bounded waits against whatever
+                                                   MIK_RCCL_LIB names */
 
 const char *mik_last_error(void);
 

@@ -36,6 +36,16 @@ class MikPoints(C.Structure):
     ]
 
 
+class MikGrid(C.Structure):
+    _fields_ = [
+        ("ndim", C.c_int32), ("adjust", C.c_int32), ("nx", C.c_int64), ("ny", C.c_int64), ("nz", C.c_int64),
+        ("gx", _dp), ("gy", _dp), ("gz", _dp),
+        ("center", C.c_double * 3), ("rot", C.c_double * 9), ("stretch", C.c_double * 3),
+        ("cell_first", C.c_int64), ("cell_count", C.c_int64),
+        ("mask", C.POINTER(C.c_int8)), ("extra_rows", _dp),
+    ]
+
+
 class MikTiming(C.Structure):
     _fields_ = [
         ("assemble_ms", C.c_double), ("invert_ms", C.c_double), ("rhs_ms", C.c_double),
@@ -43,6 +53,7 @@ class MikTiming(C.Structure):
         ("contract_flops_executed", C.c_double), ("factor_path", C.c_int32), ("symmetric", C.c_int32),
         ("engine", C.c_int32), ("reserved", C.c_int32),
         ("exchange_ms", C.c_double), ("exchange_path", C.c_int32), ("n_devices", C.c_int32),
+        ("exchange_wait_ms", C.c_double), ("exchange_fallbacks", C.c_int32), ("rccl_ranks", C.c_int32),
     ]
 
     def as_dict(self):
@@ -65,6 +76,7 @@ SIGNATURES = {
     "mik_set_problem": (C.c_int, [C.c_void_p, C.POINTER(MikProblem)]),
     "mik_factor": (C.c_int, [C.c_void_p]),
     "mik_set_points": (C.c_int, [C.c_void_p, C.POINTER(MikPoints)]),
+    "mik_set_grid": (C.c_int, [C.c_void_p, C.POINTER(MikGrid)]),
     "mik_predict": (C.c_int, [C.c_void_p]),
     "mik_get_results": (C.c_int, [C.c_void_p, _dp, _dp]),
     "mik_synchronize": (C.c_int, [C.c_void_p]),
@@ -76,11 +88,16 @@ SIGNATURES = {
     "mik_assemble_only": (C.c_int, [C.c_void_p]),
     "mik_get_matrix": (C.c_int, [C.c_void_p, C.c_int, _dp]),
     "mik_matrix_order": (C.c_int64, [C.c_void_p]),
+    "mik_points_resident": (C.c_int64, [C.c_void_p]),
+    "mik_get_points": (C.c_int, [C.c_void_p, _dp, _dp, _dp]),
     "mik_get_timing": (C.c_int, [C.c_void_p, C.POINTER(MikTiming)]),
     "mik_selftest_mfma": (C.c_int, [C.c_int]),
     "mik_comm_unique_id": (C.c_int, [C.c_char_p]),
     "mik_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_char_p]),
     "mik_bcast_factor": (C.c_int, [C.c_void_p, C.c_int]),
+    "mik_factor_checksum": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "mik_exchange_note": (C.c_char_p, [C.c_void_p]),
+    "mik_selftest_exchange": (C.c_int, [C.c_int, C.c_double, C.c_double, C.c_char_p, C.c_int]),
     "mik_last_error": (C.c_char_p, []),
 }
 
@@ -238,6 +255,45 @@ class Handle:
         self._npt = px.size
         check(self._lib.mik_set_points(self._h, C.byref(g)))
 
+    def set_grid(self, axes, center=None, rot=None, stretch=None, mask=None, extra_rows=None, cell_range=None):
+        """The prediction points of style='grid' / 'masked' from their axes (mik_set_grid): meshgrid order and anisotropy
+        adjustment on the device, H2D = the axes.  axes = (gx, gy[, gz]); center / rot (d x d) / stretch (d,) as
+        core.anisotropy_matrices returns them, or all None for coordinates taken as they are (geographic).  cell_range =
+        (first, count) kriges only that part of the flattened grid (mask / extra_rows / results are relative to it)."""
+        g = MikGrid()
+        ax = [_f64(np.asarray(a).ravel()) for a in axes]
+        nd = len(ax)
+        g.ndim, g.adjust = nd, int(rot is not None)
+        g.nx, g.ny, g.nz = ax[0].size, ax[1].size, ax[2].size if nd == 3 else 1
+        g.gx, g.gy, g.gz = _ptr(ax[0]), _ptr(ax[1]), _ptr(ax[2]) if nd == 3 else None
+        if rot is not None:
+            g.center = (C.c_double * 3)(*([float(v) for v in center] + [0.0] * (3 - nd)))
+            g.rot = (C.c_double * 9)(*([float(v) for v in np.asarray(rot, dtype=np.float64).ravel()] + [0.0] * (9 - nd * nd)))
+            g.stretch = (C.c_double * 3)(*([float(v) for v in stretch] + [1.0] * (3 - nd)))
+        ncell = int(g.nx) * int(g.ny) * int(g.nz)
+        first, count = (0, ncell) if cell_range is None else (int(cell_range[0]), int(cell_range[1]))
+        g.cell_first, g.cell_count = (first, count) if cell_range is not None else (0, 0)
+        m8 = None
+        if mask is not None:
+            m8 = np.ascontiguousarray(np.asarray(mask).ravel()).view(np.int8) if np.asarray(mask).dtype == np.bool_ else \
+                np.ascontiguousarray(np.asarray(mask).astype(np.int8).ravel())
+            if m8.size != count:
+                raise ValueError("mask length must equal the number of cells")
+        er = None
+        if extra_rows is not None and np.size(extra_rows):
+            er = _f64(extra_rows).reshape(-1, count)
+        g.mask = m8.ctypes.data_as(C.POINTER(C.c_int8)) if m8 is not None else None
+        g.extra_rows = _ptr(er)
+        self._npt = count
+        check(self._lib.mik_set_grid(self._h, C.byref(g)))
+
+    def get_points(self, ndim):
+        """Adjusted coordinates of the unmasked points resident on the device(s), (n, ndim) -- diagnostic."""
+        n = int(self._lib.mik_points_resident(self._h))
+        cols = [np.empty(n, dtype=np.float64) for _ in range(ndim)]
+        check(self._lib.mik_get_points(self._h, _ptr(cols[0]), _ptr(cols[1]), _ptr(cols[2]) if ndim == 3 else None))
+        return np.stack(cols, axis=1)
+
     def predict(self):
         check(self._lib.mik_predict(self._h))
 
@@ -301,6 +357,16 @@ class Handle:
     def bcast_factor(self, root=0):
         check(self._lib.mik_bcast_factor(self._h, int(root)))
 
+    def factor_checksum(self):
+        """4 integers: order-independent checksums of the inverted matrix and of c as this handle's device holds them."""
+        out = (C.c_uint64 * 4)()
+        check(self._lib.mik_factor_checksum(self._h, out))
+        return tuple(int(v) for v in out)
+
+    def exchange_note(self):
+        """Why exchange paths of the last factor() were given up ('' if none were)."""
+        return (self._lib.mik_exchange_note(self._h) or b"").decode("utf-8", "replace")
+
 
 def slab_of(n, members, i):
     """(lo, count) of the contiguous slab of n unmasked points that member i of a device group of `members` GPUs kriges."""
@@ -313,6 +379,14 @@ def set_devices(n):
     """Process-wide default: every handle created from now on spans `n` GPUs of the node (0 = all visible, 1 = one).  The
     environment variable MIK_NGPU does the same without touching the script."""
     check(load().mik_set_devices(int(n)))
+
+
+def selftest_exchange(members, init_limit_s, bcast_limit_s):
+    """The RCCL path of the device-group exchange against whatever MIK_RCCL_LIB names, with stand-in members and no HIP call
+    (runs without a GPU).  Returns (rc, report)."""
+    buf = C.create_string_buffer(512)
+    rc = load().mik_selftest_exchange(int(members), float(init_limit_s), float(bcast_limit_s), buf, 512)
+    return rc, buf.value.decode("utf-8", "replace")
 
 
 def selftest_mfma(device=0):

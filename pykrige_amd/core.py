@@ -39,6 +39,22 @@ def adjust_for_anisotropy(X, center, scaling, angle):
     return out
 
 
+def anisotropy_matrices(ndim, scaling, angle):
+    """(rot, stretch_diagonal) of adjust_for_anisotropy -- the same NumPy calls, so that the device-side generation of grid
+    points (mik_set_grid) multiplies by bit-identical matrix entries."""
+    ang = np.asarray(angle, dtype=np.float64) * np.pi / 180
+    if ndim == 2:
+        c, s = np.cos(-ang[0]), np.sin(-ang[0])
+        return np.array([[c, -s], [s, c]]), np.array([1.0, scaling[0]], dtype=np.float64)
+    cx, sx = np.cos(-ang[0]), np.sin(-ang[0])
+    cy, sy = np.cos(-ang[1]), np.sin(-ang[1])
+    cz, sz = np.cos(-ang[2]), np.sin(-ang[2])
+    rot_x = np.array([[1.0, 0.0, 0.0], [0.0, cx, -sx], [0.0, sx, cx]])
+    rot_y = np.array([[cy, 0.0, sy], [0.0, 1.0, 0.0], [-sy, 0.0, cy]])
+    rot_z = np.array([[cz, -sz, 0.0], [sz, cz, 0.0], [0.0, 0.0, 1.0]])
+    return np.dot(rot_z, np.dot(rot_y, rot_x)), np.array([1.0, scaling[0], scaling[1]], dtype=np.float64)
+
+
 def great_circle_distance(lon1, lat1, lon2, lat2):
     """Great-circle distance in degrees, arctan form (core.py:36-97) -- host twin of the device functor
     gc_dist; used by the constructor-time variogram fit only."""

@@ -198,6 +198,87 @@ __global__ void __launch_bounds__(256) k_cvec(const double* __restrict__ Ainv, l
   if (lane == 0) c[row] = s;
 }
 
+// Order-independent checksum of a device array seen as 64-bit words: sum of the words and sum of word x (2 i + 1), both
+// modulo 2^64 (integer adds commute, so any grid / any atomic order gives the same two numbers).  Used after the factor
+// exchange of a device group: every member's copy of the inverse must carry the leader's checksum -- a broken exchange is
+// detected instead of kriging with a wrong inverse.  out[0], out[1] are zeroed by the caller.
+__global__ void __launch_bounds__(256) k_checksum(const unsigned long long* __restrict__ w, size_t n, unsigned long long* __restrict__ out) {
+  __shared__ unsigned long long sa[4], sb[4];
+  unsigned long long a = 0ull, b = 0ull;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const unsigned long long v = w[i];
+    a += v;
+    b += v * (2ull * (unsigned long long)i + 1ull);
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    a += __shfl_xor(a, o);
+    b += __shfl_xor(b, o);
+  }
+  if ((threadIdx.x & 63) == 0) sa[threadIdx.x >> 6] = a, sb[threadIdx.x >> 6] = b;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(out, sa[0] + sa[1] + sa[2] + sa[3]);
+    atomicAdd(out + 1, sb[0] + sb[1] + sb[2] + sb[3]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Prediction points of style='grid' / 'masked' generated from the AXES (mik_set_grid): replaces np.meshgrid + the
+// anisotropy adjustment of every grid point on the host (ok.py:863-885, ok3d.py:866-883; core.py:120-193) and the H2D
+// copy of npt x d doubles -- what crosses PCIe is O(nx + ny [+ nz]).  Point t of the slab is cell cell0 + t of the
+// reference's flattened meshgrid (2-D: iy nx + ix; 3-D: (iz ny + iy) nx + ix), or cell cell0 + idx[t] when a mask compacted
+// the sequence.  Arithmetic in the reference's order: X -= c ; rot . X ; stretch . (..) ; += c, each dot product
+// accumulated k-ascending with fused multiply-adds (what the BLAS kernels behind np.dot do); the result is within an
+// ulp of NumPy's, far inside the |d| <= eps = 1e-10 coincidence rule (ok.py:665).  adjust == 0 (geographic
+// coordinates, ok.py:892-896): the axes' values as they are.
+// ------------------------------------------------------------------------------------------------
+struct GridArgs {
+  const double *gx, *gy, *gz;  // the axes on the device
+  long nx, ny, nz;
+  long cell0, n;               // this slab: n points; point t is cell cell0 + t, or cell0 + idx[t] under a mask
+  const unsigned* idx;         // nullable: idx[t] = cell (relative to cell0) of the t-th unmasked point of the slab
+  int ndim, adjust;
+  double c[3], rot[9], st[3];  // centre, rotation (row-major d x d), diagonal of the stretch matrix
+  double *px, *py, *pz;
+};
+
+__global__ void __launch_bounds__(256) k_grid_points(GridArgs a) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= a.n) return;
+  const long cell = a.cell0 + (a.idx ? (long)a.idx[t] : t);
+  const long ix = cell % a.nx, r = cell / a.nx;
+  double x = a.gx[ix], y, z = 0.0;
+  if (a.ndim == 3) {
+    y = a.gy[r % a.ny];
+    z = a.gz[r / a.ny];
+  } else {
+    y = a.gy[r];
+  }
+  if (a.adjust) {
+    // __dmul_rn / __dadd_rn: never contracted into FMAs (hipcc contracts a * b + c by default); only the accumulation of
+    // a dot product is fused, like in the BLAS kernel -- measured bit-identical to np.dot on the hosts tried
+    const double dx = x - a.c[0], dy = y - a.c[1];
+    if (a.ndim == 3) {
+      const double dz = z - a.c[2];
+      const double r0 = __fma_rn(a.rot[2], dz, __fma_rn(a.rot[1], dy, __dmul_rn(a.rot[0], dx)));
+      const double r1 = __fma_rn(a.rot[5], dz, __fma_rn(a.rot[4], dy, __dmul_rn(a.rot[3], dx)));
+      const double r2 = __fma_rn(a.rot[8], dz, __fma_rn(a.rot[7], dy, __dmul_rn(a.rot[6], dx)));
+      // stretch = diag(1, s_y, s_z): row i of the product is st[i] * r_i plus exact zeros
+      x = __dadd_rn(__dmul_rn(a.st[0], r0), a.c[0]);
+      y = __dadd_rn(__dmul_rn(a.st[1], r1), a.c[1]);
+      z = __dadd_rn(__dmul_rn(a.st[2], r2), a.c[2]);
+    } else {
+      const double r0 = __fma_rn(a.rot[1], dy, __dmul_rn(a.rot[0], dx));
+      const double r1 = __fma_rn(a.rot[3], dy, __dmul_rn(a.rot[2], dx));
+      x = __dadd_rn(__dmul_rn(a.st[0], r0), a.c[0]);
+      y = __dadd_rn(__dmul_rn(a.st[1], r1), a.c[1]);
+    }
+  }
+  a.px[t] = x;
+  a.py[t] = y;
+  if (a.ndim == 3) a.pz[t] = z;
+}
+
 // ------------------------------------------------------------------------------------------------
 // K3a: right-hand sides for a chunk of points, written POINT-MAJOR: Bt[t][j], j contiguous, ld = Mp
 // (this is the reference's `b` array layout, ok.py:669, and the "NT" operand layout of k_gemm_nt).

@@ -12,7 +12,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <memory>
 #include <map>
 #include <mutex>
 #include <string>
@@ -60,6 +63,10 @@ struct DevBuf {
   }
   void release() {
     if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  void leak() {  // give the memory up without freeing it (an abandoned transfer may still write it)
     p = nullptr;
     bytes = 0;
   }
@@ -127,7 +134,8 @@ struct RcclApi {
 static RcclApi g_rccl;
 static int rccl_load() {
   if (g_rccl.lib) return MIK_OK;
-  const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+  // MIK_RCCL_LIB: load this library instead (the tests' stand-ins whose calls hang, fail or copy)
+  const char* names[] = {getenv("MIK_RCCL_LIB") ? getenv("MIK_RCCL_LIB") : "librccl.so", "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
   void* lib = nullptr;
   for (const char* n : names) {
     lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
@@ -205,6 +213,7 @@ struct mik_handle {
   bool masked = false;  // the caller's mask skipped at least one point: outputs are zero-filled before the scatter
   std::vector<long> scatter;  // empty = identity
   DevBuf px, py, pz, extra_rows, z, ss;
+  DevBuf grid_axes, grid_idx;  // mik_set_grid: the axes and (masked style) the slab's compacted cell numbers
   // work
   DevBuf Bt, part, mw_idx, mw_dist, stat_S, stat_x, stat_out, queue;
   int n_cu = 256;
@@ -242,6 +251,15 @@ struct mik_handle {
   std::string exchange_note;
   std::vector<std::vector<hipStream_t>> xstreams; // xstreams[i][k]: stream on device i for the copy to device k (peer exchange)
   std::vector<hipEvent_t> xevents;
+  // the exchange in flight (see "the factor exchange of a device group" below)
+  std::shared_ptr<struct XchgJob> xjob;
+  hipStream_t xstream = nullptr;  // this member's exchange stream (RCCL broadcast, checksums)
+  DevBuf xsum;                 // 4 x u64: checksums of T and c after an exchange
+  std::chrono::steady_clock::time_point xchg_t0;
+  double exchange_wait_ms = 0.0;  // of exchange_ms, what a caller really waited for (the rest overlapped the leader's prediction)
+  int exchange_fallbacks = 0, rccl_ranks = 0;
+  int opt_async_exchange = 1;  // "async_exchange": mik_factor returns after the leader's K1 + K2; the exchange is joined by the next call
+  double rccl_init_limit = 120.0, rccl_bcast_limit = 30.0, peer_limit = 30.0;  // seconds; MIK_RCCL_INIT_TIMEOUT, MIK_RCCL_BCAST_TIMEOUT, MIK_PEER_TIMEOUT
 };
 
 static int get_events(mik_handle* h, size_t n) {
@@ -502,6 +520,13 @@ int mik_device_count(void) {
 
 static void destroy_one(mik_handle* h);
 
+static double env_seconds(const char* name, double dflt) {
+  const char* e = getenv(name);
+  if (!e || !*e) return dflt;
+  const double v = atof(e);
+  return v > 0.0 ? v : dflt;
+}
+
 static int create_one_body(mik_handle* h, int device) {
   h->device = device;
   HIPC(hipSetDevice(device));
@@ -537,6 +562,11 @@ static int create_one_body(mik_handle* h, int device) {
   if (env) h->alias_ok = atoi(env) != 0;
   env = getenv("MIK_EARLY_DIAG");
   if (env) h->opt_early_diag = atoi(env) < 0 ? -1 : atoi(env);
+  env = getenv("MIK_ASYNC_EXCHANGE");
+  if (env) h->opt_async_exchange = atoi(env) ? 1 : 0;
+  h->rccl_init_limit = env_seconds("MIK_RCCL_INIT_TIMEOUT", 120.0);
+  h->rccl_bcast_limit = env_seconds("MIK_RCCL_BCAST_TIMEOUT", 30.0);
+  h->peer_limit = env_seconds("MIK_PEER_TIMEOUT", 30.0);
   return MIK_OK;
 }
 
@@ -563,11 +593,16 @@ static void destroy_one(mik_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->stream_d2h) (void)hipStreamSynchronize(h->stream_d2h);
   if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
+  if (h->xstream) {
+    (void)hipStreamSynchronize(h->xstream);
+    (void)hipStreamDestroy(h->xstream);
+  }
+  h->xsum.release();
   DevBuf* bufs[] = {&h->xs, &h->ys, &h->zs, &h->vals, &h->wells, &h->extra_cols, &h->T, &h->cvec, &h->Cold, &h->Cnew,
                     &h->Rt, &h->TKt, &h->Dinv, &h->DinvT, &h->P0, &h->P1, &h->cand0, &h->cand1, &h->pivall, &h->flag,
                     &h->Cold2, &h->Cnew2, &h->Rt2, &h->Dinv2, &h->DinvT2, &h->Dnext, &h->Dcopy, &h->Cb, &h->Rb, &h->grid.gx, &h->grid.gy, &h->grid.gz, &h->grid.orig,
                     &h->grid.cstart,
-                    &h->px, &h->py, &h->pz, &h->extra_rows, &h->z, &h->ss, &h->Bt, &h->part, &h->mw_idx, &h->mw_dist, &h->stat_S, &h->stat_x, &h->stat_out, &h->queue};
+                    &h->px, &h->py, &h->pz, &h->grid_axes, &h->grid_idx, &h->extra_rows, &h->z, &h->ss, &h->Bt, &h->part, &h->mw_idx, &h->mw_dist, &h->stat_S, &h->stat_x, &h->stat_out, &h->queue};
   for (DevBuf* b : bufs) b->release();
   h->pin_in.release();
   h->pin_out.release();
@@ -592,7 +627,10 @@ static int default_devices() {
   return std::max(0, atoi(env));
 }
 
+static int join_exchange(mik_handle* h);
+
 static void release_group(mik_handle* h) {
+  (void)join_exchange(h);  // bounded; an exchange that cannot finish has given up its buffers and streams already
   for (size_t i = 0; i < h->xstreams.size(); ++i) {
     const int dev = i == 0 ? h->device : h->kids[i - 1]->device;
     (void)hipSetDevice(dev);
@@ -688,8 +726,14 @@ int mik_set_custom_variogram(mik_handle* h, mik_variogram_fn fn, void* user) {
 
 int mik_set_option(mik_handle* h, const char* key, double value) {
   if (!h || !key) return fail(MIK_EINVAL, "mik_set_option: NULL argument");
+  MIKC(join_exchange(h));
   for (mik_handle* k : h->kids) MIKC(mik_set_option(k, key, value));
-  if (!strcmp(key, "exchange")) {
+  if (!strcmp(key, "async_exchange")) {
+    h->opt_async_exchange = value != 0.0;
+  } else if (!strcmp(key, "rccl_init_timeout") || !strcmp(key, "rccl_bcast_timeout") || !strcmp(key, "peer_timeout")) {
+    if (!(value > 0.0)) return fail(MIK_EINVAL, "a timeout must be a positive number of seconds");
+    (key[0] == 'p' ? h->peer_limit : key[5] == 'i' ? h->rccl_init_limit : h->rccl_bcast_limit) = value;
+  } else if (!strcmp(key, "exchange")) {
     if (value < 0 || value > 3) return fail(MIK_EINVAL, "exchange must be 0 (auto), 1 (rccl), 2 (peer copies) or 3 (redundant factorisation)");
     h->opt_exchange = (int)value;
   } else if (!strcmp(key, "alias_devices")) {
@@ -837,6 +881,7 @@ static int one_set_problem(mik_handle* h, const mik_problem* p) {
 }
 
 int mik_set_problem(mik_handle* h, const mik_problem* p) {
+  MIKC(join_exchange(h));
   MIKC(one_set_problem(h, p));
   for (mik_handle* k : h->kids) MIKC(one_set_problem(k, p));  // a few hundred KB of station data per device
   return MIK_OK;
@@ -1277,6 +1322,7 @@ static int finish_factor(mik_handle* h) {
 
 int mik_assemble_only(mik_handle* h) {
   if (!h || !h->have_problem) return fail(MIK_ESTATE, "mik_assemble_only: no problem set");
+  MIKC(join_exchange(h));
   HIPC(hipSetDevice(h->device));
   MIKC(ensure_factor_buffers(h));
   MIKC(launch_assemble(h, 0.0));
@@ -1390,65 +1436,139 @@ static int for_each_device(mik_handle* h, F fn) {
 }
 }  // extern "C++"
 
-// RCCL communicators of a single-process device group are cached per device list for the life of the process: creating
-// them (ncclCommInitAll) costs seconds on an 8-GPU node, and every kriging object has its own handle.
-static std::mutex g_group_mutex;
-static std::map<std::vector<int>, std::vector<ncclComm_t>> g_group_comms;
+// ---- the factor exchange of a device group: bounded, checked, asynchronous ---------------------------------------------
+//
+// mik_factor on a group = the leader's K1 + K2 (blocking), then the EXCHANGE of the inverse and of c.  The exchange runs on
+// a worker thread over dedicated streams and is joined by the next call that needs the members (mik_predict starts the
+// leader's slab first: its prediction overlaps the transfer).  Every wait is BOUNDED:
+//   MIK_RCCL_INIT_TIMEOUT  (s, default 120; option "rccl_init_timeout")   ncclCommInitAll of the group's communicators
+//   MIK_RCCL_BCAST_TIMEOUT (s, default 30;  option "rccl_bcast_timeout")  the grouped ncclBroadcast until every stream drained
+//   MIK_PEER_TIMEOUT       (s, default 30;  option "peer_timeout")        the peer scatter + all-gather
+// When a limit expires the worker is abandoned (detached; it owns everything it touches through a shared job record, never
+// the handle), the members' matrix buffers and exchange streams are LEAKED on purpose (a late transfer may still write
+// them) and replaced, RCCL is marked unusable for the rest of the process, and the exchange continues on the next path of
+// exchange = auto:  RCCL broadcast -> peer copies -> every member factors the matrix itself.  A forced path ("exchange"
+// 1 / 2) returns the error instead.  After every transfer each member's copy is CHECKSUMMED on its device against the
+// leader's (k_checksum: order-independent 2 x 64-bit sums of T and c); a mismatch counts as a failed exchange.
+struct XchgMember {
+  int device = 0;
+  double* T = nullptr;
+  double* cvec = nullptr;
+  hipStream_t xs = nullptr;              // the member's exchange stream
+  unsigned long long* sum_dev = nullptr; // 4 words on the member's device: checksums of T and of c
+  ncclComm_t comm = nullptr;
+};
+struct XchgJob {
+  std::mutex m;
+  std::condition_variable cv;
+  bool done = false;
+  int rc = MIK_OK;
+  std::string err;
+  std::atomic<int> phase{0};  // 0 = communicator set-up (RCCL only), 1 = transfer
+  std::chrono::steady_clock::time_point t_start, t_phase1, t_done;
+  int path = 0;               // 1 = RCCL broadcast, 2 = peer copies
+  bool dry = false;           // mik_selftest_exchange: no HIP calls (drives the control flow against a stand-in RCCL on CPU)
+  size_t Mp = 0;
+  std::vector<XchgMember> mem;
+  std::vector<std::vector<hipStream_t>> xstreams;  // peer path: xstreams[i][k] = stream on device i for the copy to device k
+  std::vector<hipEvent_t> xevents;
+  std::vector<unsigned long long> sums;            // 4 words per member, host side
+  int rccl_ranks = 0;
+};
 
-static int group_comms(mik_handle* h, std::vector<ncclComm_t>** out) {
-  const int n = (int)h->kids.size() + 1;
-  std::vector<int> devs(n);
-  for (int i = 0; i < n; ++i) devs[i] = member(h, i)->device;
+static std::timed_mutex g_group_mutex;
+static std::map<std::vector<int>, std::vector<ncclComm_t>> g_group_comms;
+static std::atomic<bool> g_rccl_dead{false};  // a bounded wait on RCCL ran out: not used again in this process
+static std::string g_rccl_dead_why;           // (written before the flag is raised)
+
+// communicators of a single-process device group, cached per device list for the life of the process: creating them
+// (ncclCommInitAll) costs seconds on an 8-GPU node, and every kriging object has its own handle.  g_group_mutex held.
+static int group_comms(const std::vector<int>& devs, std::vector<ncclComm_t>** out) {
   {
     std::vector<int> sorted = devs;
     std::sort(sorted.begin(), sorted.end());
-    if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end())
+    const char* allow = getenv("MIK_RCCL_ALLOW_ALIAS");  // stand-in libraries of the tests accept duplicate devices
+    if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end() && !(allow && atoi(allow)))
       return fail(MIK_ERCCL, "RCCL needs one distinct GPU per group member (this group aliases a device)");
   }
   auto it = g_group_comms.find(devs);
   if (it == g_group_comms.end()) {
     MIKC(rccl_load());
     if (!g_rccl.CommInitAll || !g_rccl.GroupStart || !g_rccl.GroupEnd) return fail(MIK_ERCCL, "librccl.so lacks ncclCommInitAll / ncclGroupStart / ncclGroupEnd");
-    std::vector<ncclComm_t> comms(n, nullptr);
-    NCCLC(g_rccl.CommInitAll(comms.data(), n, devs.data()));
+    std::vector<ncclComm_t> comms(devs.size(), nullptr);
+    NCCLC(g_rccl.CommInitAll(comms.data(), (int)devs.size(), devs.data()));
     it = g_group_comms.emplace(devs, std::move(comms)).first;
   }
   *out = &it->second;
   return MIK_OK;
 }
 
+// checksums of every member's T and c on its exchange stream, then the streams are drained and the sums compared
+static int xchg_verify(XchgJob* j) {
+  const size_t Mp = j->Mp, n = j->mem.size();
+  j->sums.assign(4 * n, 0ull);
+  for (size_t i = 0; i < n; ++i) {
+    const XchgMember& d = j->mem[i];
+    HIPC(hipSetDevice(d.device));
+    HIPC(hipMemsetAsync(d.sum_dev, 0, 4 * sizeof(unsigned long long), d.xs));
+    hipLaunchKernelGGL(k_checksum, dim3(1024), dim3(256), 0, d.xs, (const unsigned long long*)d.T, Mp * Mp, d.sum_dev);
+    hipLaunchKernelGGL(k_checksum, dim3(4), dim3(256), 0, d.xs, (const unsigned long long*)d.cvec, Mp, d.sum_dev + 2);
+    HIPC(hipGetLastError());
+    HIPC(hipMemcpyAsync(j->sums.data() + 4 * i, d.sum_dev, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, d.xs));
+  }
+  for (size_t i = 0; i < n; ++i) {
+    HIPC(hipSetDevice(j->mem[i].device));
+    HIPC(hipStreamSynchronize(j->mem[i].xs));
+  }
+  for (size_t i = 1; i < n; ++i)
+    for (int w = 0; w < 4; ++w)
+      if (j->sums[4 * i + w] != j->sums[w]) {
+        char b[200];
+        snprintf(b, sizeof b, "exchange checksum mismatch on group member %zu (device %d): the copy of the inverse differs from the leader's",
+                 i, j->mem[i].device);
+        return fail(MIK_ERCCL, b);
+      }
+  return MIK_OK;
+}
+
 // the north_star's exchange: ONE ncclBroadcast of the inverted matrix (and one of c) from the leader to every member, all
-// members' calls fused in a group, each on its own device's stream
-static int exchange_rccl(mik_handle* h) {
-  std::lock_guard<std::mutex> lock(g_group_mutex);
+// members' calls fused in a group, each on its own device's exchange stream
+static int xchg_rccl(XchgJob* j) {
+  // one RCCL exchange at a time; a worker stuck inside RCCL keeps the lock for ever, so waiting for it watches the flag
+  std::unique_lock<std::timed_mutex> lock(g_group_mutex, std::defer_lock);
+  for (;;) {
+    if (g_rccl_dead.load()) return fail(MIK_ERCCL, "RCCL disabled for this process: " + g_rccl_dead_why);
+    if (lock.try_lock_for(std::chrono::milliseconds(50))) break;
+  }
+  if (g_rccl_dead.load()) return fail(MIK_ERCCL, "RCCL disabled for this process: " + g_rccl_dead_why);
+  const int n = (int)j->mem.size();
+  std::vector<int> devs(n);
+  for (int i = 0; i < n; ++i) devs[i] = j->mem[i].device;
   std::vector<ncclComm_t>* comms = nullptr;
-  MIKC(group_comms(h, &comms));
-  const int n = (int)h->kids.size() + 1;
-  const size_t Mp = h->Mp;
-  for (int i = 1; i < n; ++i) {
-    HIPC(hipSetDevice(member(h, i)->device));
-    MIKC(ensure_factor_buffers(member(h, i)));
+  MIKC(group_comms(devs, &comms));
+  j->rccl_ranks = (int)comms->size();
+  {
+    std::lock_guard<std::mutex> lk(j->m);
+    j->t_phase1 = std::chrono::steady_clock::now();
+    j->phase.store(1);
+    j->cv.notify_all();  // the waiter switches from the set-up limit to the transfer limit
   }
   NCCLC(g_rccl.GroupStart());
   ncclResult_t first_bad = ncclSuccess;  // a failing call must not leave RCCL inside an open group
   for (int i = 0; i < n && first_bad == ncclSuccess; ++i) {
-    mik_handle* d = member(h, i);
-    if (hipSetDevice(d->device) != hipSuccess) {
+    const XchgMember& d = j->mem[i];
+    if (!j->dry && hipSetDevice(d.device) != hipSuccess) {
       first_bad = ncclUnhandledCudaError;
       break;
     }
-    first_bad = g_rccl.Broadcast(d->T.p, d->T.p, Mp * Mp, ncclDouble, 0, (*comms)[i], d->stream);
-    if (first_bad == ncclSuccess) first_bad = g_rccl.Broadcast(d->cvec.p, d->cvec.p, Mp, ncclDouble, 0, (*comms)[i], d->stream);
+    first_bad = g_rccl.Broadcast(d.T, d.T, j->Mp * j->Mp, ncclDouble, 0, (*comms)[i], d.xs);
+    if (first_bad == ncclSuccess) first_bad = g_rccl.Broadcast(d.cvec, d.cvec, j->Mp, ncclDouble, 0, (*comms)[i], d.xs);
   }
   const ncclResult_t end_rc = g_rccl.GroupEnd();
   NCCLC(first_bad);
   NCCLC(end_rc);
-  for (int i = 0; i < n; ++i) {
-    HIPC(hipSetDevice(member(h, i)->device));
-    HIPC(hipStreamSynchronize(member(h, i)->stream));
-  }
-  HIPC(hipSetDevice(h->device));
-  return MIK_OK;
+  if (j->dry) return MIK_OK;
+  return xchg_verify(j);
 }
 
 static int copy_between(void* dst, int ddev, const void* src, int sdev, size_t bytes, hipStream_t st) {
@@ -1462,10 +1582,83 @@ static int copy_between(void* dst, int ddev, const void* src, int sdev, size_t b
 // SCATTERS the matrix in n-1 pieces, one per member, and every member forwards its piece to the other members
 // (ALL-GATHER) as soon as it has arrived.  Every link carries 1/(n-1) of the matrix in each of the two steps, against the
 // whole matrix on each of the leader's links for a direct fan-out: 3.5x less time on 8 GPUs.
-static int exchange_peer(mik_handle* h) {
+static int xchg_peer(XchgJob* j) {
+  const int n = (int)j->mem.size();
+  const size_t Mp = j->Mp, S = Mp * Mp;
+  const size_t pieces = (size_t)(n - 1);
+  const size_t per = ((S + pieces - 1) / pieces + 511) / 512 * 512;
+  auto piece = [&](int k, size_t* off, size_t* len) {
+    *off = std::min(S, (size_t)(k - 1) * per);
+    *len = std::min(per, S - *off);
+  };
+  const XchgMember& d0 = j->mem[0];
+  HIPC(hipSetDevice(d0.device));
+  for (int k = 1; k < n; ++k) {  // scatter (and c, which is small, to everybody directly)
+    const XchgMember& dk = j->mem[k];
+    size_t off, len;
+    piece(k, &off, &len);
+    hipStream_t st = j->xstreams[0][k];
+    MIKC(copy_between(dk.T + off, dk.device, d0.T + off, d0.device, sizeof(double) * len, st));
+    MIKC(copy_between(dk.cvec, dk.device, d0.cvec, d0.device, sizeof(double) * Mp, st));
+    HIPC(hipEventRecord(j->xevents[k], st));
+  }
+  for (int q = 1; q < n; ++q) {  // all-gather among the members
+    const XchgMember& dq = j->mem[q];
+    size_t off, len;
+    piece(q, &off, &len);
+    HIPC(hipSetDevice(dq.device));
+    for (int k = 1; k < n; ++k) {
+      if (k == q) continue;
+      const XchgMember& dk = j->mem[k];
+      hipStream_t st = j->xstreams[q][k];
+      HIPC(hipStreamWaitEvent(st, j->xevents[q], 0));
+      MIKC(copy_between(dk.T + off, dk.device, dq.T + off, dq.device, sizeof(double) * len, st));
+    }
+  }
+  for (int i = 0; i < n; ++i) {
+    HIPC(hipSetDevice(j->mem[i].device));
+    for (int k = 0; k < n; ++k)
+      if (j->xstreams[i][k]) HIPC(hipStreamSynchronize(j->xstreams[i][k]));
+  }
+  return xchg_verify(j);
+}
+
+static void xchg_worker(std::shared_ptr<XchgJob> j) {
+  g_err.clear();
+  const int rc = j->path == 1 ? xchg_rccl(j.get()) : xchg_peer(j.get());
+  std::lock_guard<std::mutex> lk(j->m);
+  j->rc = rc;
+  j->err = g_err;
+  j->t_done = std::chrono::steady_clock::now();
+  j->done = true;
+  j->cv.notify_all();
+}
+
+// wait for the worker within the limits; returns true if it finished (its status is then in j->rc / j->err)
+static bool xchg_wait(XchgJob* j, double init_limit, double xfer_limit) {
+  using clock = std::chrono::steady_clock;
+  std::unique_lock<std::mutex> lk(j->m);
+  while (!j->done) {
+    const bool in_xfer = j->phase.load() >= 1;
+    const auto deadline = in_xfer ? j->t_phase1 + std::chrono::duration_cast<clock::duration>(std::chrono::duration<double>(xfer_limit))
+                                  : j->t_start + std::chrono::duration_cast<clock::duration>(std::chrono::duration<double>(init_limit));
+    if (j->cv.wait_until(lk, deadline) == std::cv_status::timeout && !j->done) {
+      const bool now_xfer = j->phase.load() >= 1;
+      if (now_xfer == in_xfer) return false;  // same phase, limit expired
+    }
+  }
+  return true;
+}
+
+static int ensure_exchange_streams(mik_handle* h, bool peer) {
   const int n = (int)h->kids.size() + 1;
-  const size_t Mp = h->Mp, S = Mp * Mp;
-  if (h->xstreams.size() != (size_t)n) {
+  for (int i = 0; i < n; ++i) {
+    mik_handle* d = member(h, i);
+    HIPC(hipSetDevice(d->device));
+    if (!d->xstream) HIPC(hipStreamCreateWithFlags(&d->xstream, hipStreamNonBlocking));
+    MIKC(d->xsum.ensure(4 * sizeof(unsigned long long)));
+  }
+  if (peer && h->xstreams.size() != (size_t)n) {
     h->xstreams.assign(n, std::vector<hipStream_t>(n, nullptr));
     for (int i = 0; i < n; ++i) {
       HIPC(hipSetDevice(member(h, i)->device));
@@ -1487,53 +1680,160 @@ static int exchange_peer(mik_handle* h) {
       h->xevents.push_back(e);
     }
   }
+  HIPC(hipSetDevice(h->device));
+  return MIK_OK;
+}
+
+// launch the exchange on `path` (1 = RCCL, 2 = peer copies) on a worker thread; the job is joined by join_exchange
+static int start_exchange(mik_handle* h, int path) {
+  const int n = (int)h->kids.size() + 1;
   for (int i = 1; i < n; ++i) {
     HIPC(hipSetDevice(member(h, i)->device));
     MIKC(ensure_factor_buffers(member(h, i)));
   }
-  const size_t pieces = (size_t)(n - 1);
-  const size_t per = ((S + pieces - 1) / pieces + 511) / 512 * 512;
-  auto piece = [&](int j, size_t* off, size_t* len) {
-    *off = std::min(S, (size_t)(j - 1) * per);
-    *len = std::min(per, S - *off);
-  };
-  const int d0 = h->device;
-  HIPC(hipSetDevice(d0));
-  for (int j = 1; j < n; ++j) {  // scatter (and c, which is small, to everybody directly)
-    mik_handle* dj = member(h, j);
-    size_t off, len;
-    piece(j, &off, &len);
-    hipStream_t st = h->xstreams[0][j];
-    MIKC(copy_between(dj->T.as<double>() + off, dj->device, h->T.as<double>() + off, d0, sizeof(double) * len, st));
-    MIKC(copy_between(dj->cvec.p, dj->device, h->cvec.p, d0, sizeof(double) * Mp, st));
-    HIPC(hipEventRecord(h->xevents[j], st));
+  MIKC(ensure_exchange_streams(h, path == 2));
+  auto j = std::make_shared<XchgJob>();
+  j->path = path;
+  j->Mp = (size_t)h->Mp;
+  j->mem.resize(n);
+  for (int i = 0; i < n; ++i) {
+    mik_handle* d = member(h, i);
+    j->mem[i].device = d->device;
+    j->mem[i].T = d->T.as<double>();
+    j->mem[i].cvec = d->cvec.as<double>();
+    j->mem[i].xs = d->xstream;
+    j->mem[i].sum_dev = d->xsum.as<unsigned long long>();
   }
-  for (int j = 1; j < n; ++j) {  // all-gather among the members
-    mik_handle* dj = member(h, j);
-    size_t off, len;
-    piece(j, &off, &len);
-    HIPC(hipSetDevice(dj->device));
-    for (int k = 1; k < n; ++k) {
-      if (k == j) continue;
-      mik_handle* dk = member(h, k);
-      hipStream_t st = h->xstreams[j][k];
-      HIPC(hipStreamWaitEvent(st, h->xevents[j], 0));
-      MIKC(copy_between(dk->T.as<double>() + off, dk->device, dj->T.as<double>() + off, dj->device, sizeof(double) * len, st));
+  if (path == 2) {
+    j->xstreams = h->xstreams;
+    j->xevents = h->xevents;
+    j->phase.store(1);
+  }
+  j->t_start = j->t_phase1 = std::chrono::steady_clock::now();
+  h->xjob = j;
+  std::thread(xchg_worker, j).detach();
+  return MIK_OK;
+}
+
+// a bounded wait ran out: nothing the abandoned worker may still touch is reused or freed
+static void abandon_exchange(mik_handle* h, XchgJob* j) {
+  for (size_t i = 0; i < h->kids.size() + 1; ++i) {
+    mik_handle* d = member(h, (int)i);
+    d->xstream = nullptr;  // leaked with whatever is stuck on it
+    if (i > 0) {      // the leader's matrix is only read by a transfer
+      d->T.leak();
+      d->cvec.leak();
+    }
+    d->xsum.leak();
+  }
+  if (j->path == 2) {
+    h->xstreams.clear();  // leaked
+    h->xevents.clear();
+  } else {
+    g_rccl_dead_why = "a bounded wait on " + std::string(j->phase.load() >= 1 ? "the grouped ncclBroadcast" : "ncclCommInitAll") + " ran out";
+    g_rccl_dead.store(true);
+    // the communicator cache may be locked by the stuck worker: try, do not wait (a dead RCCL is never looked up again)
+    if (g_group_mutex.try_lock()) {
+      std::vector<int> devs;
+      for (const XchgMember& m : j->mem) devs.push_back(m.device);
+      g_group_comms.erase(devs);  // the communicators themselves are leaked
+      g_group_mutex.unlock();
     }
   }
-  for (int i = 0; i < n; ++i) {
-    HIPC(hipSetDevice(member(h, i)->device));
-    for (int k = 0; k < n; ++k)
-      if (h->xstreams[i][k]) HIPC(hipStreamSynchronize(h->xstreams[i][k]));
+}
+
+static void mark_kids_factored(mik_handle* h) {
+  for (mik_handle* k : h->kids) {
+    k->have_factor = true;
+    k->t_state = 2;
+    k->have_results = false;
+    k->tm.factor_path = h->tm.factor_path;
+    k->tm.assemble_ms = k->tm.invert_ms = 0.0;
   }
-  HIPC(hipSetDevice(h->device));
+}
+
+// Finish the exchange mik_factor started (no-op when none is in flight): wait within the limits, fall through the paths
+// of exchange = auto on failure, leave every member with a verified copy of the inverse or return the error.
+static int join_exchange(mik_handle* h) {
+  if (!h || !h->xjob) return MIK_OK;
+  using clock = std::chrono::steady_clock;
+  const auto t_join = clock::now();
+  int path = h->xjob->path;
+  for (;;) {
+    std::shared_ptr<XchgJob> j = h->xjob;
+    h->xjob.reset();
+    const bool finished = xchg_wait(j.get(), h->rccl_init_limit, path == 1 ? h->rccl_bcast_limit : h->peer_limit);
+    int rc;
+    std::string why;
+    if (finished) {
+      rc = j->rc;
+      why = j->err;
+    } else {
+      char b[160];
+      snprintf(b, sizeof b, "%s did not finish within %.1f s", path == 1 ? (j->phase.load() >= 1 ? "the grouped ncclBroadcast" : "ncclCommInitAll") : "the peer scatter + all-gather",
+               path == 2 ? h->peer_limit : (j->phase.load() >= 1 ? h->rccl_bcast_limit : h->rccl_init_limit));
+      why = b;
+      rc = path == 1 ? MIK_ERCCL : MIK_EHIP;
+      abandon_exchange(h, j.get());
+    }
+    if (rc == MIK_OK) {
+      h->exchange_used = path;
+      h->rccl_ranks = j->rccl_ranks;
+      h->exchange_ms = std::chrono::duration<double, std::milli>(j->t_done - h->xchg_t0).count();
+      mark_kids_factored(h);
+      break;
+    }
+    ++h->exchange_fallbacks;
+    const char* names[] = {"", "rccl broadcast", "peer copies"};
+    h->exchange_note += std::string(h->exchange_note.empty() ? "" : "; ") + names[path] + " failed (" + why + ")";
+    if (h->opt_exchange == path) {  // the caller forced this path
+      (void)hipSetDevice(h->device);
+      return fail(path == 1 ? MIK_ERCCL : MIK_EHIP, "factor exchange: " + h->exchange_note);
+    }
+    if (path == 1) {
+      const int src = start_exchange(h, 2);
+      if (src == MIK_OK) {
+        path = 2;
+        continue;
+      }
+      h->exchange_note += "; peer copies could not be started (" + g_err + ")";
+    }
+    // last resort of exchange = auto: every member assembles and inverts the (identical) matrix itself
+    h->exchange_note += "; every member factors the matrix itself";
+    int frc = MIK_OK;
+    std::string ferr;
+    {
+      std::vector<std::thread> th;
+      std::vector<int> rcs(h->kids.size(), MIK_OK);
+      std::vector<std::string> errs(h->kids.size());
+      for (size_t i = 0; i < h->kids.size(); ++i)
+        th.emplace_back([&, i] {
+          g_err.clear();
+          rcs[i] = one_factor(h->kids[i]);
+          errs[i] = g_err;
+        });
+      for (auto& t : th) t.join();
+      for (size_t i = 0; i < rcs.size(); ++i)
+        if (rcs[i] != MIK_OK && frc == MIK_OK) frc = rcs[i], ferr = errs[i];
+    }
+    (void)hipSetDevice(h->device);
+    if (frc != MIK_OK) return fail(frc, "factor exchange: " + h->exchange_note + "; redundant factorisation failed: " + ferr);
+    h->exchange_used = 3;
+    h->exchange_ms = std::chrono::duration<double, std::milli>(clock::now() - h->xchg_t0).count();
+    break;
+  }
+  h->exchange_wait_ms = std::chrono::duration<double, std::milli>(clock::now() - t_join).count();
+  (void)hipSetDevice(h->device);
   return MIK_OK;
 }
 
 int mik_factor(mik_handle* h) {
   if (!h) return fail(MIK_ESTATE, "mik_factor: NULL handle");
+  MIKC(join_exchange(h));  // an exchange nobody waited for yet still reads the leader's matrix
   h->exchange_used = 0;
-  h->exchange_ms = 0.0;
+  h->exchange_ms = h->exchange_wait_ms = 0.0;
+  h->exchange_fallbacks = 0;
+  h->rccl_ranks = 0;
   h->exchange_note.clear();
   if (h->kids.empty()) return one_factor(h);
   for (mik_handle* k : h->kids) k->have_factor = false;
@@ -1542,34 +1842,60 @@ int mik_factor(mik_handle* h) {
     return for_each_device(h, [](int, mik_handle* d) { return one_factor(d); });
   }
   MIKC(one_factor(h));
-  const auto t0 = std::chrono::steady_clock::now();
-  int used = 0;
-  if (h->opt_exchange == 0 || h->opt_exchange == 1) {
-    const int rc = exchange_rccl(h);
-    if (rc == MIK_OK) used = 1;
-    else if (h->opt_exchange == 1) return rc;
-    else h->exchange_note = "rccl unavailable (" + g_err + "); peer copies used";
+  h->xchg_t0 = std::chrono::steady_clock::now();
+  int path = h->opt_exchange == 2 ? 2 : 1;
+  if (path == 1 && h->opt_exchange == 0 && g_rccl_dead.load()) {
+    h->exchange_note = "rccl disabled for this process (" + g_rccl_dead_why + ")";
+    ++h->exchange_fallbacks;
+    path = 2;
   }
-  if (!used) {
-    MIKC(exchange_peer(h));
-    used = 2;
-  }
-  h->exchange_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-  h->exchange_used = used;
-  for (mik_handle* k : h->kids) {
-    k->have_factor = true;
-    k->t_state = 2;
-    k->have_results = false;
-    k->tm.factor_path = h->tm.factor_path;
-    k->tm.assemble_ms = k->tm.invert_ms = 0.0;
-  }
+  MIKC(start_exchange(h, path));
+  if (!h->opt_async_exchange) return join_exchange(h);
   return MIK_OK;
+}
+
+// CPU-runnable check of the bounded exchange (no HIP call is made): `members` stand-in members run the RCCL path of the
+// exchange against whatever librccl the process loads (MIK_RCCL_LIB: a stand-in whose calls hang / fail / succeed) under
+// the given limits.  Returns MIK_OK when the exchange finished, MIK_ERCCL when it failed or a limit expired; report gets
+// one line: "ok ranks=N" | "failed: ..." | "timeout phase=init|bcast after S s; rccl_dead=1".
+int mik_selftest_exchange(int members, double init_limit_s, double bcast_limit_s, char* report, int report_len) {
+  if (members < 2 || members > 64 || !report || report_len < 8) return fail(MIK_EINVAL, "mik_selftest_exchange: bad argument");
+  auto j = std::make_shared<XchgJob>();
+  j->path = 1;
+  j->dry = true;
+  j->Mp = 128;
+  j->mem.resize(members);
+  for (int i = 0; i < members; ++i) j->mem[i].device = i;
+  j->t_start = j->t_phase1 = std::chrono::steady_clock::now();
+  std::thread(xchg_worker, j).detach();
+  const bool finished = xchg_wait(j.get(), init_limit_s, bcast_limit_s);
+  const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - j->t_start).count();
+  if (!finished) {
+    const bool bc = j->phase.load() >= 1;
+    g_rccl_dead_why = std::string("a bounded wait on ") + (bc ? "the grouped ncclBroadcast" : "ncclCommInitAll") + " ran out";
+    g_rccl_dead.store(true);
+    snprintf(report, report_len, "timeout phase=%s after %.2f s; rccl_dead=1", bc ? "bcast" : "init", waited);
+    return fail(MIK_ERCCL, report);
+  }
+  if (j->rc != MIK_OK) {
+    snprintf(report, report_len, "failed: %s", j->err.c_str());
+    return fail(MIK_ERCCL, report);
+  }
+  snprintf(report, report_len, "ok ranks=%d", j->rccl_ranks);
+  return MIK_OK;
+}
+
+const char* mik_exchange_note(mik_handle* h) {
+  static thread_local std::string note;
+  note = h ? h->exchange_note : std::string();
+  return note.c_str();
 }
 
 int mik_get_matrix(mik_handle* h, int which, double* out) {
   if (!h || !out) return fail(MIK_EINVAL, "mik_get_matrix: NULL argument");
   if (!h->T.p) return fail(MIK_ESTATE, "mik_get_matrix: nothing assembled");
   if (which == 1 && !h->have_factor) return fail(MIK_ESTATE, "mik_get_matrix: not factored");
+  MIKC(join_exchange(h));
   HIPC(hipSetDevice(h->device));
   HIPC(hipMemcpy2D(out, sizeof(double) * h->M, h->T.p, sizeof(double) * h->Mp, sizeof(double) * h->M, h->M,
                    hipMemcpyDeviceToHost));
@@ -1647,7 +1973,7 @@ int mik_set_points(mik_handle* h, const mik_points* g) {
   if (g->npt < 0) return fail(MIK_EINVAL, "npt < 0");
   if (g->npt > 0 && (!g->px || !g->py || (h->ndim == 3 && !g->pz))) return fail(MIK_EINVAL, "point arrays missing");
   if (h->nextra > 0 && g->npt > 0 && !g->extra_rows) return fail(MIK_EINVAL, "extra_rows missing for host-evaluated drifts");
-  h->npt_total = g->npt;
+  h->npt_total = g->npt;  // (an exchange in flight touches neither the points nor their buffers: not joined here)
   std::vector<long> idx;
   long n = g->npt;
   h->masked = false;
@@ -1665,6 +1991,134 @@ int mik_set_points(mik_handle* h, const mik_points* g) {
     slab_of(n, members, i, &lo, &cnt);
     return one_set_points(d, g, ip, lo, cnt);
   });
+}
+
+// The slab [lo, lo + n) of the unmasked cells of a grid given by its axes, generated on ONE device (k_grid_points).  idx as
+// in one_set_points.  H2D: the axes, the slab's compacted cell numbers (4 bytes per point, masked style only) and the
+// host-evaluated drift rows if the problem has any.
+static int one_set_grid(mik_handle* h, const mik_grid* g, const long* idx, long lo, long n, long first, long ncells) {
+  HIPC(hipSetDevice(h->device));
+  HIPC(hipStreamSynchronize(h->stream_d2h));  // result copies of an earlier predict still read z / ss
+  h->npt = n;
+  h->out_off = lo;
+  if (idx) h->scatter.assign(idx + lo, idx + lo + n);
+  else h->scatter.clear();
+  const long cap = std::max<long>(n, 1);
+  const int three = g->ndim == 3;
+  const long nax = g->nx + g->ny + (three ? g->nz : 0);
+  MIKC(h->grid_axes.ensure(sizeof(double) * (size_t)nax));
+  double* ax = h->grid_axes.as<double>();
+  HIPC(hipMemcpyAsync(ax, g->gx, sizeof(double) * g->nx, hipMemcpyHostToDevice, h->stream));
+  HIPC(hipMemcpyAsync(ax + g->nx, g->gy, sizeof(double) * g->ny, hipMemcpyHostToDevice, h->stream));
+  if (three) HIPC(hipMemcpyAsync(ax + g->nx + g->ny, g->gz, sizeof(double) * g->nz, hipMemcpyHostToDevice, h->stream));
+  MIKC(h->px.ensure(sizeof(double) * cap));
+  MIKC(h->py.ensure(sizeof(double) * cap));
+  if (three) MIKC(h->pz.ensure(sizeof(double) * cap));
+  const size_t stage_bytes = std::max(sizeof(double) * (size_t)cap * (size_t)std::max(h->nextra, 1), sizeof(unsigned) * (size_t)cap);
+  if (idx || h->nextra) MIKC(h->pin_in.ensure(stage_bytes));
+  if (idx && n > 0) {
+    MIKC(h->grid_idx.ensure(sizeof(unsigned) * (size_t)cap));
+    unsigned* st = h->pin_in.as<unsigned>();
+    const long* ix = idx + lo;
+    for (long i = 0; i < n; ++i) st[i] = (unsigned)ix[i];
+    HIPC(hipMemcpyAsync(h->grid_idx.p, st, sizeof(unsigned) * (size_t)n, hipMemcpyHostToDevice, h->stream));
+    HIPC(hipStreamSynchronize(h->stream));  // the staging buffer is reused for the drift rows below
+  }
+  if (h->nextra) {
+    MIKC(h->extra_rows.ensure(sizeof(double) * (size_t)cap * h->nextra));
+    for (int r = 0; r < h->nextra && n > 0; ++r) {
+      const double* from = g->extra_rows + (size_t)r * ncells;
+      double* stage = h->pin_in.as<double>() + (size_t)r * cap;
+      if (idx) {
+        const long* ix = idx + lo;
+        for (long i = 0; i < n; ++i) stage[i] = from[ix[i]];
+      } else {
+        host_copy(stage, from + lo, sizeof(double) * n);
+      }
+      HIPC(hipMemcpyAsync(h->extra_rows.as<double>() + (size_t)r * n, stage, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+    }
+  }
+  if (n > 0) {
+    GridArgs a{};
+    a.gx = ax;
+    a.gy = ax + g->nx;
+    a.gz = three ? ax + g->nx + g->ny : nullptr;
+    a.nx = g->nx, a.ny = g->ny, a.nz = three ? g->nz : 1;
+    a.cell0 = idx ? first : first + lo, a.n = n;
+    a.idx = idx ? h->grid_idx.as<unsigned>() : nullptr;
+    a.ndim = g->ndim, a.adjust = g->adjust ? 1 : 0;
+    for (int i = 0; i < 3; ++i) a.c[i] = g->center[i], a.st[i] = g->stretch[i];
+    for (int i = 0; i < 9; ++i) a.rot[i] = g->rot[i];
+    a.px = h->px.as<double>(), a.py = h->py.as<double>(), a.pz = three ? h->pz.as<double>() : nullptr;
+    hipLaunchKernelGGL(k_grid_points, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, a);
+    HIPC(hipGetLastError());
+  }
+  MIKC(h->z.ensure(sizeof(double) * cap));
+  MIKC(h->ss.ensure(sizeof(double) * cap));
+  MIKC(h->pin_out.ensure(sizeof(double) * 2 * (size_t)cap));
+  HIPC(hipStreamSynchronize(h->stream));
+  h->have_points = true;
+  h->have_results = false;
+  return MIK_OK;
+}
+
+int mik_set_grid(mik_handle* h, const mik_grid* g) {
+  if (!h || !g) return fail(MIK_EINVAL, "mik_set_grid: NULL argument");
+  if (!h->have_problem) return fail(MIK_ESTATE, "mik_set_grid: set the problem first");
+  if (g->ndim != h->ndim) return fail(MIK_EINVAL, "mik_set_grid: ndim differs from the problem's");
+  if (g->nx < 1 || g->ny < 1 || (g->ndim == 3 && g->nz < 1)) return fail(MIK_EINVAL, "mik_set_grid: empty axis");
+  if (!g->gx || !g->gy || (g->ndim == 3 && !g->gz)) return fail(MIK_EINVAL, "mik_set_grid: axis arrays missing");
+  const double cells = (double)g->nx * (double)g->ny * (g->ndim == 3 ? (double)g->nz : 1.0);
+  if (cells >= 9.0e15) return fail(MIK_EINVAL, "mik_set_grid: grid too large");
+  const long first = g->cell_count > 0 ? g->cell_first : 0;
+  const long ncells = g->cell_count > 0 ? g->cell_count : (long)cells;
+  if (first < 0 || g->cell_count < 0 || (double)first + (double)ncells > cells) return fail(MIK_EINVAL, "mik_set_grid: cell range outside the grid");
+  if (ncells >= 4294967296L) return fail(MIK_EINVAL, "mik_set_grid: more than 2^32 - 1 cells in one call (use cell_first / cell_count)");
+  if (h->nextra > 0 && !g->extra_rows) return fail(MIK_EINVAL, "extra_rows missing for host-evaluated drifts");
+  h->npt_total = ncells;
+  std::vector<long> idx;
+  long n = ncells;
+  h->masked = false;
+  if (g->mask) {  // np.nonzero(~mask) (ok.py:700) / `if mask[i]: continue` (cok.pyx:57-58)
+    idx.reserve(ncells);
+    for (long i = 0; i < ncells; ++i)
+      if (!g->mask[i]) idx.push_back(i);
+    n = (long)idx.size();
+    h->masked = n != ncells;
+  }
+  const long* ip = h->masked ? idx.data() : nullptr;
+  const int members = (int)h->kids.size() + 1;
+  return for_each_device(h, [&](int i, mik_handle* d) {
+    long lo, cnt;
+    slab_of(n, members, i, &lo, &cnt);
+    return one_set_grid(d, g, ip, lo, cnt, first, ncells);
+  });
+}
+
+int mik_get_points(mik_handle* h, double* px_out, double* py_out, double* pz_out) {
+  if (!h || !px_out || !py_out) return fail(MIK_EINVAL, "mik_get_points: NULL argument");
+  if (!h->have_points) return fail(MIK_ESTATE, "mik_get_points: set points first");
+  if (h->ndim == 3 && !pz_out) return fail(MIK_EINVAL, "mik_get_points: pz_out missing");
+  long off = 0;  // the members' slabs follow each other in the unmasked sequence
+  for (int i = 0; i <= (int)h->kids.size(); ++i) {
+    mik_handle* d = member(h, i);
+    HIPC(hipSetDevice(d->device));
+    if (d->npt > 0) {
+      HIPC(hipMemcpy(px_out + off, d->px.p, sizeof(double) * d->npt, hipMemcpyDeviceToHost));
+      HIPC(hipMemcpy(py_out + off, d->py.p, sizeof(double) * d->npt, hipMemcpyDeviceToHost));
+      if (h->ndim == 3) HIPC(hipMemcpy(pz_out + off, d->pz.p, sizeof(double) * d->npt, hipMemcpyDeviceToHost));
+    }
+    off += d->npt;
+  }
+  HIPC(hipSetDevice(h->device));
+  return MIK_OK;
+}
+
+int64_t mik_points_resident(mik_handle* h) {
+  if (!h || !h->have_points) return 0;
+  long n = 0;
+  for (int i = 0; i <= (int)h->kids.size(); ++i) n += member(h, i)->npt;
+  return n;
 }
 
 static int one_predict(mik_handle* h) {
@@ -1799,7 +2253,27 @@ static int one_predict(mik_handle* h) {
 
 int mik_predict(mik_handle* h) {
   if (!h) return fail(MIK_ESTATE, "mik_predict: NULL handle");
-  return for_each_device(h, [](int, mik_handle* d) { return one_predict(d); });
+  if (h->kids.empty() || !h->xjob) return for_each_device(h, [](int, mik_handle* d) { return one_predict(d); });
+  // The exchange mik_factor started is still in flight: the leader kriges its slab NOW (a transfer only reads its matrix),
+  // the members start as soon as their copies have arrived and been verified.
+  int lrc = MIK_OK;
+  std::string lerr;
+  std::thread leader([&] {
+    g_err.clear();
+    lrc = one_predict(h);
+    lerr = g_err;
+  });
+  int rc = join_exchange(h);
+  std::string err = g_err;
+  if (rc == MIK_OK) {
+    rc = for_each_device(h, [](int i, mik_handle* d) { return i == 0 ? MIK_OK : one_predict(d); });
+    err = g_err;
+  }
+  leader.join();
+  (void)hipSetDevice(h->device);
+  if (lrc != MIK_OK) return fail(lrc, "device " + std::to_string(h->device) + " (group member 0): " + lerr);
+  if (rc != MIK_OK) return fail(rc, err);
+  return MIK_OK;
 }
 
 
@@ -2027,6 +2501,7 @@ static int one_predict_mw(mik_handle* h, int n_closest) {
 
 int mik_predict_moving_window(mik_handle* h, int n_closest) {
   if (!h) return fail(MIK_ESTATE, "mik_predict_moving_window: NULL handle");
+  MIKC(join_exchange(h));
   return for_each_device(h, [n_closest](int, mik_handle* d) { return one_predict_mw(d, n_closest); });
 }
 
@@ -2034,6 +2509,7 @@ int mik_statistics(mik_handle* h, double* k_out, double* ss_out) {
   if (!h || !k_out || !ss_out) return fail(MIK_EINVAL, "mik_statistics: NULL argument");
   if (!h->have_problem) return fail(MIK_ESTATE, "mik_statistics: set the problem first");
   if (h->p != 0) return fail(MIK_EINVAL, "statistics use the ordinary-kriging system (core.py:654-756): no drift terms");
+  MIKC(join_exchange(h));
   HIPC(hipSetDevice(h->device));
   const int N = h->N, Ns = N + 1;
   const long ld = ((Ns + 63) / 64) * 64;
@@ -2149,6 +2625,7 @@ int mik_experimental_variogram(mik_handle* h, int nlags, double* lags_out, doubl
 
 int mik_synchronize(mik_handle* h) {
   if (!h) return fail(MIK_EINVAL, "mik_synchronize: NULL handle");
+  MIKC(join_exchange(h));
   for (int i = 0; i <= (int)h->kids.size(); ++i) {
     mik_handle* d = member(h, i);
     HIPC(hipSetDevice(d->device));
@@ -2194,10 +2671,14 @@ int mik_get_results(mik_handle* h, double* z_out, double* ss_out) {
 
 int mik_get_timing(mik_handle* h, mik_timing* out) {
   if (!h || !out) return fail(MIK_EINVAL, "mik_get_timing: NULL argument");
+  MIKC(join_exchange(h));  // the exchange figures are final only then
   *out = h->tm;
   out->n_devices = (int)h->kids.size() + 1;
   out->exchange_path = h->exchange_used;
   out->exchange_ms = h->exchange_ms;
+  out->exchange_wait_ms = h->exchange_wait_ms;
+  out->exchange_fallbacks = h->exchange_fallbacks;
+  out->rccl_ranks = h->rccl_ranks;
   for (mik_handle* k : h->kids) out->predict_ms = std::max(out->predict_ms, k->tm.predict_ms);  // the group's predict = its slowest member
   return MIK_OK;
 }
@@ -2205,10 +2686,14 @@ int mik_get_timing(mik_handle* h, mik_timing* out) {
 int mik_get_device_timing(mik_handle* h, int member_index, mik_timing* out) {
   if (!h || !out) return fail(MIK_EINVAL, "mik_get_device_timing: NULL argument");
   if (member_index < 0 || member_index > (int)h->kids.size()) return fail(MIK_EINVAL, "mik_get_device_timing: no such group member");
+  MIKC(join_exchange(h));
   *out = member(h, member_index)->tm;
   out->n_devices = (int)h->kids.size() + 1;
   out->exchange_path = h->exchange_used;
   out->exchange_ms = h->exchange_ms;
+  out->exchange_wait_ms = h->exchange_wait_ms;
+  out->exchange_fallbacks = h->exchange_fallbacks;
+  out->rccl_ranks = h->rccl_ranks;
   out->reserved = member(h, member_index)->device;
   return MIK_OK;
 }
@@ -2272,14 +2757,62 @@ int mik_comm_unique_id(char id_out[128]) {
   return MIK_OK;
 }
 
+// a call that may never return (RCCL set-up, a collective), run on a worker thread under a limit; the worker owns what it
+// touches through the captures of fn (by value / shared_ptr), so it can be abandoned
+struct BoundedCall {
+  std::mutex m;
+  std::condition_variable cv;
+  bool done = false;
+  int rc = MIK_OK;
+  std::string err;
+};
+extern "C++" {
+template <class F>
+static int run_bounded(F fn, double limit_s, const char* what, bool* timed_out) {
+  auto st = std::make_shared<BoundedCall>();
+  std::thread([st, fn]() mutable {
+    g_err.clear();
+    const int rc = fn();
+    std::lock_guard<std::mutex> lk(st->m);
+    st->rc = rc;
+    st->err = g_err;
+    st->done = true;
+    st->cv.notify_all();
+  }).detach();
+  std::unique_lock<std::mutex> lk(st->m);
+  *timed_out = !st->cv.wait_for(lk, std::chrono::duration<double>(limit_s), [&] { return st->done; });
+  if (*timed_out) {
+    char b[200];
+    snprintf(b, sizeof b, "%s did not finish within %.1f s", what, limit_s);
+    return fail(MIK_ERCCL, b);
+  }
+  g_err = st->err;
+  return st->rc;
+}
+}  // extern "C++"
+
 int mik_comm_init(mik_handle* h, int nranks, int rank, const char id[128]) {
   if (!h || !id || nranks < 1 || rank < 0 || rank >= nranks) return fail(MIK_EINVAL, "mik_comm_init: bad argument");
   if (!h->kids.empty()) return fail(MIK_EINVAL, "mik_comm_init: this handle already spans several devices (mik_set_devices); use one or the other");
+  if (g_rccl_dead.load()) return fail(MIK_ERCCL, "RCCL disabled for this process: " + g_rccl_dead_why);
   MIKC(rccl_load());
   HIPC(hipSetDevice(h->device));
   ncclUniqueId uid;
   memcpy(&uid, id, 128);
-  NCCLC(g_rccl.CommInitRank(&h->comm, nranks, uid, rank));
+  auto out = std::make_shared<ncclComm_t>(nullptr);
+  const int dev = h->device;
+  bool timed_out = false;
+  const int rc = run_bounded([=] {
+    HIPC(hipSetDevice(dev));
+    NCCLC(g_rccl.CommInitRank(out.get(), nranks, uid, rank));
+    return MIK_OK;
+  }, h->rccl_init_limit, "ncclCommInitRank", &timed_out);
+  if (timed_out) {
+    g_rccl_dead_why = "a bounded wait on ncclCommInitRank ran out";
+    g_rccl_dead.store(true);
+  }
+  MIKC(rc);
+  h->comm = *out;
   h->nranks = nranks;
   h->rank = rank;
   return MIK_OK;
@@ -2291,13 +2824,57 @@ int mik_bcast_factor(mik_handle* h, int root) {
   if (h->rank == root && !h->have_factor) return fail(MIK_ESTATE, "mik_bcast_factor: root has not factored");
   HIPC(hipSetDevice(h->device));
   MIKC(ensure_factor_buffers(h));
+  if (!h->xstream) HIPC(hipStreamCreateWithFlags(&h->xstream, hipStreamNonBlocking));
+  HIPC(hipStreamSynchronize(h->stream));  // the broadcast runs on the exchange stream: the factor (root) / earlier reads are done
   const size_t Mp = h->Mp;
-  NCCLC(g_rccl.Broadcast(h->T.p, h->T.p, Mp * Mp, ncclDouble, root, h->comm, h->stream));
-  NCCLC(g_rccl.Broadcast(h->cvec.p, h->cvec.p, Mp, ncclDouble, root, h->comm, h->stream));
-  HIPC(hipStreamSynchronize(h->stream));
+  const int dev = h->device;
+  double* T = h->T.as<double>();
+  double* cv = h->cvec.as<double>();
+  ncclComm_t comm = h->comm;
+  hipStream_t xs = h->xstream;
+  bool timed_out = false;
+  const int rc = run_bounded([=] {
+    HIPC(hipSetDevice(dev));
+    NCCLC(g_rccl.Broadcast(T, T, Mp * Mp, ncclDouble, root, comm, xs));
+    NCCLC(g_rccl.Broadcast(cv, cv, Mp, ncclDouble, root, comm, xs));
+    HIPC(hipStreamSynchronize(xs));
+    return MIK_OK;
+  }, h->rccl_bcast_limit, "ncclBroadcast of the factor", &timed_out);
+  if (timed_out) {  // nothing the abandoned collective may still touch is reused: stream, buffers and communicator are leaked
+    h->xstream = nullptr;
+    if (h->rank != root) {
+      h->T.leak();
+      h->cvec.leak();
+    }
+    h->comm = nullptr;
+    g_rccl_dead_why = "a bounded wait on ncclBroadcast ran out";
+    g_rccl_dead.store(true);
+  }
+  MIKC(rc);
   h->have_factor = true;
   h->t_state = 2;
   h->have_results = false;
+  return MIK_OK;
+}
+
+// 4 words: order-independent checksums of the handle's inverted matrix and of c (k_checksum).  One process per GPU: the
+// ranks compare theirs with the root's after mik_bcast_factor (pykrige_amd.dist) -- a broken broadcast is detected, not kriged with.
+int mik_factor_checksum(mik_handle* h, uint64_t out[4]) {
+  if (!h || !out) return fail(MIK_EINVAL, "mik_factor_checksum: NULL argument");
+  if (!h->have_factor) return fail(MIK_ESTATE, "mik_factor_checksum: no factor");
+  MIKC(join_exchange(h));
+  HIPC(hipSetDevice(h->device));
+  MIKC(h->xsum.ensure(4 * sizeof(unsigned long long)));
+  unsigned long long* sd = h->xsum.as<unsigned long long>();
+  const size_t Mp = h->Mp;
+  HIPC(hipMemsetAsync(sd, 0, 4 * sizeof(unsigned long long), h->stream));
+  hipLaunchKernelGGL(k_checksum, dim3(1024), dim3(256), 0, h->stream, (const unsigned long long*)h->T.p, Mp * Mp, sd);
+  hipLaunchKernelGGL(k_checksum, dim3(4), dim3(256), 0, h->stream, (const unsigned long long*)h->cvec.p, Mp, sd + 2);
+  HIPC(hipGetLastError());
+  unsigned long long host[4];
+  HIPC(hipMemcpyAsync(host, sd, sizeof host, hipMemcpyDeviceToHost, h->stream));
+  HIPC(hipStreamSynchronize(h->stream));
+  for (int i = 0; i < 4; ++i) out[i] = host[i];
   return MIK_OK;
 }
 

@@ -11,6 +11,7 @@ MASTER_PORT, so the process never imports torch and holds one HIP runtime and on
 accepted too).  The per-rank slabs of z / sigma^2 meet in a shared-memory segment (ranks of one node), not in a socket.
 If RCCL cannot be initialised every rank factors the (identical) matrix itself.
 """
+import hmac
 import json
 import os
 import socket
@@ -76,10 +77,13 @@ class SocketGroup:
     torch, so that the process holds one HIP runtime and one RCCL (the ROCm install's).  Device data never goes through it.
 
     Frames are length-prefixed JSON headers followed by raw buffers (no pickle).  A joining peer must present the job's
-    token (MIK_SOCKET_TOKEN, else the launcher's TORCHELASTIC_RUN_ID, else empty) and a rank in 1..world-1 that nobody
-    else has claimed; anything else is dropped."""
+    token (MIK_SOCKET_TOKEN, else the launcher's TORCHELASTIC_RUN_ID) and a rank in 1..world-1 that nobody else has claimed;
+    anything else is dropped (constant-time comparison).  Without a token the group only forms on the loopback interface:
+    a port any host can reach must not hand out ranks to whoever connects first.  A frame is capped at `max_frame` bytes
+    (default 256 MiB: the group carries ids, statuses and -- multi-node gathers only -- result slabs; callers that expect
+    more raise it for that call), so an accepted peer cannot make rank 0 allocate without bound."""
 
-    MAX_FRAME = 1 << 34
+    MAX_FRAME = 1 << 28
 
     def __init__(self, rank=None, world=None, addr=None, port=None, timeout=120.0, token=None):
         self.rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
@@ -90,6 +94,10 @@ class SocketGroup:
             base -= 2 * 1017 + 16
         if token is None:
             token = os.environ.get("MIK_SOCKET_TOKEN", os.environ.get("TORCHELASTIC_RUN_ID", ""))
+        self.max_frame = self.MAX_FRAME
+        if not str(token) and self.world > 1 and addr not in ("127.0.0.1", "localhost", "::1"):
+            raise RuntimeError("SocketGroup: refusing to form a group on %s without a job token (set MIK_SOCKET_TOKEN, or launch "
+                               "through torch.distributed.run which provides TORCHELASTIC_RUN_ID)" % addr)
         self._token = str(token).encode("utf-8")[:64].ljust(64, b"\0")
         self._peers = []
         self._sock = None
@@ -120,7 +128,7 @@ class SocketGroup:
                     c.settimeout(10.0)
                     hello = self._recvn(c, 68)
                     r = struct.unpack("<i", hello[:4])[0]
-                    if hello[4:] != self._token or not (1 <= r < self.world) or r in peers:
+                    if not hmac.compare_digest(hello[4:], self._token) or not (1 <= r < self.world) or r in peers:
                         raise RuntimeError("bad hello")
                     c.settimeout(None)
                     c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
@@ -164,11 +172,11 @@ class SocketGroup:
 
     def _recv(self, c):
         n = struct.unpack("<q", self._recvn(c, 8))[0]
-        if not (0 < n <= self.MAX_FRAME):
+        if not (0 < n <= self.max_frame):
             raise RuntimeError("SocketGroup: malformed frame length")
         head = json.loads(self._recvn(c, n).decode("utf-8"))
         sizes = [int(s) for s in head["bufs"]]
-        if any(s < 0 for s in sizes) or sum(sizes) > self.MAX_FRAME:
+        if any(s < 0 for s in sizes) or sum(sizes) > self.max_frame:
             raise RuntimeError("SocketGroup: malformed buffer table")
         bufs = [self._recvn(c, s) for s in sizes]
         return _decode(head["v"], bufs)
@@ -304,6 +312,9 @@ class ShardedExecutor:
         self._handle = handle_factory() if handle_factory is not None else model._get_handle()
         if self.exchange == "rccl_bcast":
             self.exchange = init_rccl(self._handle, self.pg)
+        # a shared-memory segment only exists on ONE node: ranks on different hosts gather through the group instead
+        hosts = self.pg.all_gather_object(socket.gethostname()) if self.world > 1 else [socket.gethostname()]
+        self.single_node = len(set(hosts)) == 1
         self._shared = _SharedResults(self.pg)
 
     def close(self):
@@ -324,12 +335,17 @@ class ShardedExecutor:
             kind, msg = status
             exc = {"LinAlgError": np.linalg.LinAlgError, "ValueError": ValueError}.get(kind, RuntimeError)
             raise exc(msg if self.rank == 0 else "rank 0: " + msg)
-        err = None
+        err, sums = None, None
         try:
-            h.bcast_factor(0)
+            h.bcast_factor(0)  # bounded inside the library (MIK_RCCL_BCAST_TIMEOUT): returns an error instead of hanging
+            sums = h.factor_checksum() if hasattr(h, "factor_checksum") else None
         except Exception as e:  # noqa: BLE001
             err = repr(e)[:200]
-        errs = [e for e in self.pg.all_gather_object(err) if e]
+        res = self.pg.all_gather_object((err, sums))
+        errs = [e for e, _ in res if e]
+        if not errs and any(sm != res[0][1] for _, sm in res):  # a copy of the inverse that differs from the root's
+            errs = ["checksum of the broadcast inverse differs from rank 0's on rank(s) %s"
+                    % [r for r, (_, sm) in enumerate(res) if sm != res[0][1]]]
         if errs:  # the collective itself failed somewhere: from now on (and for this call) every rank factors itself
             self.exchange = "redundant_factor (rccl broadcast failed: %s)" % errs[0]
             h.factor()
@@ -338,8 +354,8 @@ class ShardedExecutor:
         m, h = self.model, self._handle
         window = kw.pop("n_closest_points", None)
         m._check_backend(backend, window)
-        pts_adj, shape, fmask, extra = m._prepare_points(style, axes, mask, kw.get("specified_drift_arrays"), backend)
-        npt = pts_adj.shape[0]
+        P = m._prepare(style, axes, mask, kw.get("specified_drift_arrays"), backend)  # a grid stays axes: no host meshgrid
+        npt, shape, fmask = P.npt, P.shape, P.mask
         lo, hi = slab_bounds(npt, self.world, self.rank)
         m._set_problem(h)
         if window is None:
@@ -347,9 +363,7 @@ class ShardedExecutor:
                 self._factor_everywhere(h)
             else:
                 h.factor()
-        sl = slice(lo, hi)
-        h.set_points(pts_adj[sl, 0], pts_adj[sl, 1], pts_adj[sl, 2] if m._ndim == 3 else None,
-                     mask=None if fmask is None else fmask[sl], extra_rows=None if extra is None else extra[:, sl])
+        P.load(h, m._ndim, cell_range=(lo, hi - lo), with_extra=window is None)
         if window is None:
             h.predict()
         else:  # moving window: every point needs only its own neighbours -- no factor, no exchange of any kind
@@ -359,6 +373,11 @@ class ShardedExecutor:
             return z, ss, (lo, hi)
         if self.world == 1:
             zf, sf = z, ss
+        elif not self.single_node:  # ranks on several hosts: the slabs travel through the group (raw buffers, no pickle)
+            if hasattr(self.pg, "max_frame"):
+                self.pg.max_frame = max(self.pg.max_frame, 32 * npt + (1 << 20))
+            parts = self.pg.all_gather_object((z, ss))
+            zf, sf = np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
         else:
             zs, sshared = self._shared.arrays(npt)
             zs[lo:hi], sshared[lo:hi] = z, ss

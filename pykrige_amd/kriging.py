@@ -22,6 +22,34 @@ from . import _lib
 from . import core
 
 
+class _Pts:
+    """The prediction points of one execute(): adjusted coordinate arrays (style='points', or a grid whose drift callables
+    need the adjusted coordinates on the host), or a grid described by its axes and generated on the device (mik_set_grid:
+    the meshgrid and the anisotropy adjustment of ok.py:863-885 never exist on the host)."""
+
+    __slots__ = ("arrays", "axes", "center", "rot", "stretch", "mask", "extra", "shape", "npt")
+
+    def __init__(self, shape, mask, extra, arrays=None, axes=None, center=None, rot=None, stretch=None):
+        self.shape, self.mask, self.extra = shape, mask, extra
+        self.arrays, self.axes, self.center, self.rot, self.stretch = arrays, axes, center, rot, stretch
+        self.npt = int(np.prod(shape))
+
+    def load(self, h, ndim, cell_range=None, with_extra=True):
+        """H2D (arrays) or device-side generation (grid) of the points, optionally only cells [first, first + count)."""
+        extra = self.extra if with_extra else None
+        if cell_range is None:
+            mask = self.mask
+        else:
+            sl = slice(cell_range[0], cell_range[0] + cell_range[1])
+            mask = None if self.mask is None else self.mask[sl]
+            extra = None if extra is None else np.ascontiguousarray(extra[:, sl])
+        if self.axes is not None:
+            h.set_grid(self.axes, self.center, self.rot, self.stretch, mask=mask, extra_rows=extra, cell_range=cell_range)
+            return
+        a = self.arrays if cell_range is None else self.arrays[sl]
+        h.set_points(a[:, 0], a[:, 1], a[:, 2] if ndim == 3 else None, mask=mask, extra_rows=extra)
+
+
 class _KrigingBase:
     eps = 1.0e-10  # ok.py:177, uk.py:210
     UNBIAS = True  # uk.py:208
@@ -217,13 +245,30 @@ class _KrigingBase:
         self.factor_reused = False
         return h
 
-    def _solve(self, pts_adj, mask, extra_rows):
+    def _solve(self, P):
         h = self._upload_and_factor()
-        h.set_points(pts_adj[:, 0], pts_adj[:, 1], pts_adj[:, 2] if self._ndim == 3 else None,
-                     mask=mask, extra_rows=extra_rows)
+        P.load(h, self._ndim)
         h.predict()
         self.last_timing = h.timing()
         return h.get_results()
+
+    def _prepare(self, style, axes, mask, specified_drift_arrays=None, backend="vectorized"):
+        """Everything execute() does on the host before the solve -> _Pts.  Grids ('grid' / 'masked') are handed to the
+        device as axes + the anisotropy matrices unless a drift callable needs the adjusted coordinates on the host
+        (functional drifts) or MIK_DEVICE_GRID=0 asks for the host meshgrid."""
+        if (style not in ("grid", "masked") or _os.environ.get("MIK_DEVICE_GRID", "1") == "0"
+                or getattr(self, "functional_drift", False)):
+            pts_adj, shape, mask, extra = self._prepare_points(style, axes, mask, specified_drift_arrays, backend)
+            return _Pts(shape, mask, extra, arrays=pts_adj)
+        axes, shape, mask = self._grid_from(style, axes, mask)
+        extra = self._grid_rows(style, axes, shape, mask, specified_drift_arrays, backend)
+        if getattr(self, "coordinates_type", "euclidean") == "geographic":
+            return _Pts(shape, mask, extra, axes=axes)  # no anisotropy correction in spherical coordinates (ok.py:892-896)
+        rot, stretch = core.anisotropy_matrices(self._ndim, self._scaling(), self._angle())
+        return _Pts(shape, mask, extra, axes=axes, center=self._center(), rot=rot, stretch=stretch)
+
+    def _grid_rows(self, style, axes, shape, mask, specified_drift_arrays, backend):
+        return None  # host-evaluated drift rows of a grid: universal kriging only
 
     def _prepare_points(self, style, axes, mask, specified_drift_arrays=None, backend="vectorized"):
         """Everything execute() does on the host before the solve: returns (pts_adj, shape, mask, extra_rows)."""
@@ -346,11 +391,11 @@ class _KrigingBase:
         if n_closest_points is not None and backend not in self._mw_backends:
             raise ValueError("Specified backend {} for a moving window is not supported.".format(backend))  # ok.py:982-986
 
-    def _solve_moving_window(self, pts_adj, mask, n_closest_points, backend):
+    def _solve_moving_window(self, P, n_closest_points, backend):
         """cKDTree.query + _exec_loop_moving_window / _c_exec_loop_moving_window on the device."""
         h = self._get_handle()
         self._set_problem(h)
-        h.set_points(pts_adj[:, 0], pts_adj[:, 1], pts_adj[:, 2] if self._ndim == 3 else None, mask=mask)
+        P.load(h, self._ndim, with_extra=False)
         try:
             h.predict_moving_window(int(n_closest_points))
         except np.linalg.LinAlgError as e:
@@ -360,39 +405,50 @@ class _KrigingBase:
         self.last_timing = h.timing()
         return h.get_results()
 
+    def _grid_from(self, style, axes, mask):
+        """Axes cast to fp64, output shape and the flattened mask of style='grid' / 'masked' (ok.py:849-862, 896;
+        ok3d.py:841-861, 893) -- the checks of the reference without its meshgrid."""
+        # the reference does not cast (integer grids crash in its in-place subtract); cast to fp64 here
+        axes = [np.atleast_1d(np.squeeze(np.array(a, copy=True, dtype=np.float64))) for a in axes]
+        sizes = [a.size for a in axes]
+        shape = tuple(reversed(sizes))  # (ny, nx) / (nz, ny, nx)
+        if style == "masked":
+            if mask is None:
+                raise IOError("Must specify boolean masking array when style is 'masked'.")
+            mask = np.asarray(mask)
+            if self._ndim == 3 and mask.ndim != 3:
+                raise ValueError("Mask is not three-dimensional.")
+            if mask.ndim != self._ndim:
+                raise ValueError("Mask dimensions do not match specified grid dimensions.")
+            if mask.shape != shape:
+                if mask.shape == tuple(sizes):
+                    mask = mask.T if self._ndim == 2 else mask.swapaxes(0, 2)
+                else:
+                    raise ValueError("Mask dimensions do not match specified grid dimensions.")
+            mask = mask.flatten().astype(bool)
+        else:
+            mask = None  # ok.py:896 / ok3d.py:893: `if style != "masked": mask = np.zeros(npt, dtype="bool")` -- a mask handed
+            # to style="grid" is ignored, every cell is kriged
+        return axes, shape, mask
+
+    def _meshgrid(self, axes):
+        """The reference's flattened meshgrid (ok.py:863-867, ok3d.py:866-870) as an (npt, d) array."""
+        if self._ndim == 2:
+            gx, gy = np.meshgrid(axes[0], axes[1])
+            return np.stack((gx.ravel(), gy.ravel()), axis=1)
+        gz, gy, gx = np.meshgrid(axes[2], axes[1], axes[0], indexing="ij")
+        return np.stack((gx.ravel(), gy.ravel(), gz.ravel()), axis=1)
+
     def _points_from(self, style, axes, mask):
         """Reference meshgrid order and mask handling (ok.py:849-878; ok3d.py:841-876)."""
         if style != "grid" and style != "masked" and style != "points":
             raise ValueError("style argument must be 'grid', 'points', or 'masked'")
-        # the reference does not cast (integer grids crash in its in-place subtract); cast to fp64 here
-        axes = [np.atleast_1d(np.squeeze(np.array(a, copy=True, dtype=np.float64))) for a in axes]
-        sizes = [a.size for a in axes]
         if style in ("grid", "masked"):
-            shape = tuple(reversed(sizes))  # (ny, nx) / (nz, ny, nx)
-            if style == "masked":
-                if mask is None:
-                    raise IOError("Must specify boolean masking array when style is 'masked'.")
-                mask = np.asarray(mask)
-                if self._ndim == 3 and mask.ndim != 3:
-                    raise ValueError("Mask is not three-dimensional.")
-                if mask.ndim != self._ndim:
-                    raise ValueError("Mask dimensions do not match specified grid dimensions.")
-                if mask.shape != shape:
-                    if mask.shape == tuple(sizes):
-                        mask = mask.T if self._ndim == 2 else mask.swapaxes(0, 2)
-                    else:
-                        raise ValueError("Mask dimensions do not match specified grid dimensions.")
-                mask = mask.flatten().astype(bool)
-            else:
-                mask = None  # ok.py:896 / ok3d.py:893: `if style != "masked": mask = np.zeros(npt, dtype="bool")` -- a mask handed
-                # to style="grid" is ignored, every cell is kriged
-            if self._ndim == 2:
-                gx, gy = np.meshgrid(axes[0], axes[1])
-                pts = np.stack((gx.ravel(), gy.ravel()), axis=1)
-            else:
-                gz, gy, gx = np.meshgrid(axes[2], axes[1], axes[0], indexing="ij")
-                pts = np.stack((gx.ravel(), gy.ravel(), gz.ravel()), axis=1)
+            axes, shape, mask = self._grid_from(style, axes, mask)
+            pts = self._meshgrid(axes)
         else:
+            axes = [np.atleast_1d(np.squeeze(np.array(a, copy=True, dtype=np.float64))) for a in axes]
+            sizes = [a.size for a in axes]
             if len(set(sizes)) != 1:
                 raise ValueError("xpoints and ypoints%s must have same dimensions when treated as listing "
                                  "discrete points." % (", zpoints" if self._ndim == 3 else ""))
@@ -514,12 +570,12 @@ class OrdinaryKriging(_KrigingBase):
         if style != "grid" and style != "masked" and style != "points":
             raise ValueError("style argument must be 'grid', 'points', or 'masked'")
         self._check_backend(backend, n_closest_points)
-        pts_adj, shape, mask, extra = self._prepare_points(style, (xpoints, ypoints), mask)
+        P = self._prepare(style, (xpoints, ypoints), mask)
         if n_closest_points is not None:
-            z, ss = self._solve_moving_window(pts_adj, mask, n_closest_points, backend)
+            z, ss = self._solve_moving_window(P, n_closest_points, backend)
         else:
-            z, ss = self._solve(pts_adj, mask, extra)
-        return self._finish(z, ss, style, shape, mask, backend)
+            z, ss = self._solve(P)
+        return self._finish(z, ss, style, P.shape, P.mask, backend)
 
 
 # =====================================================================================================
@@ -625,9 +681,23 @@ class UniversalKriging(OrdinaryKriging):
         if style != "grid" and style != "masked" and style != "points":
             raise ValueError("style argument must be 'grid', 'points', or 'masked'")
         self._check_backend(backend, None)
-        pts_adj, shape, mask, extra = self._prepare_points(style, (xpoints, ypoints), mask, specified_drift_arrays, backend)
-        z, ss = self._solve(pts_adj, mask, extra)
-        return self._finish(z, ss, style, shape, mask, backend)
+        P = self._prepare(style, (xpoints, ypoints), mask, specified_drift_arrays, backend)
+        z, ss = self._solve(P)
+        return self._finish(z, ss, style, P.shape, P.mask, backend)
+
+    def _grid_rows(self, style, axes, shape, mask, specified_drift_arrays, backend):
+        rows = []
+        if self.external_Z_drift:  # looked up at the ORIGINAL coordinates (uk.py:967-971): the host meshgrid, for this term only
+            pts = self._meshgrid(axes)
+            if mask is not None and backend != "vectorized":  # see _prepare_points
+                zs = np.zeros(pts.shape[0])
+                keep = ~mask
+                zs[keep] = self._calculate_data_point_zscalars(pts[keep, 0], pts[keep, 1])
+                rows.append(zs)
+            else:
+                rows.append(self._calculate_data_point_zscalars(pts[:, 0], pts[:, 1]))
+        rows.extend(self._spec_rows(style, shape, int(np.prod(shape)), specified_drift_arrays))
+        return np.array(rows, dtype=np.float64) if rows else None
 
     def _prepare_points(self, style, axes, mask, specified_drift_arrays=None, backend="vectorized"):
         pts, shape, mask = self._points_from(style, axes, mask)
@@ -714,12 +784,12 @@ class OrdinaryKriging3D(_KrigingBase):
         if style != "grid" and style != "masked" and style != "points":
             raise ValueError("style argument must be 'grid', 'points', or 'masked'")
         self._check_backend(backend, n_closest_points)
-        pts_adj, shape, mask, extra = self._prepare_points(style, (xpoints, ypoints, zpoints), mask)
+        P = self._prepare(style, (xpoints, ypoints, zpoints), mask)
         if n_closest_points is not None:
-            z, ss = self._solve_moving_window(pts_adj, mask, n_closest_points, backend)
+            z, ss = self._solve_moving_window(P, n_closest_points, backend)
         else:
-            z, ss = self._solve(pts_adj, mask, extra)
-        return self._finish(z, ss, style, shape, mask, backend)
+            z, ss = self._solve(P)
+        return self._finish(z, ss, style, P.shape, P.mask, backend)
 
 
 # =====================================================================================================
@@ -785,9 +855,13 @@ class UniversalKriging3D(OrdinaryKriging3D):
         if style != "grid" and style != "masked" and style != "points":
             raise ValueError("style argument must be 'grid', 'points', or 'masked'")
         self._check_backend(backend, None)
-        pts_adj, shape, mask, extra = self._prepare_points(style, (xpoints, ypoints, zpoints), mask, specified_drift_arrays)
-        z, ss = self._solve(pts_adj, mask, extra)
-        return self._finish(z, ss, style, shape, mask, backend)
+        P = self._prepare(style, (xpoints, ypoints, zpoints), mask, specified_drift_arrays)
+        z, ss = self._solve(P)
+        return self._finish(z, ss, style, P.shape, P.mask, backend)
+
+    def _grid_rows(self, style, axes, shape, mask, specified_drift_arrays, backend):
+        rows = self._spec_rows(style, shape, int(np.prod(shape)), specified_drift_arrays)
+        return np.array(rows, dtype=np.float64) if rows else None
 
     def _prepare_points(self, style, axes, mask, specified_drift_arrays=None, backend="vectorized"):
         pts, shape, mask = self._points_from(style, axes, mask)

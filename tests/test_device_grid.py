@@ -1,0 +1,127 @@
+"""mik_set_grid: the points of style='grid' / 'masked' are generated on the device from the axes (meshgrid order +
+anisotropy adjustment of ok.py:863-885, ok3d.py:866-883, core.py:120-193).  They must be the coordinates the reference
+builds on the host -- the |d| <= eps coincidence rule (ok.py:665) and everything downstream depend on them."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import _fixtures as fx
+
+
+def _host_points(axes, center, scaling, angle):
+    from pykrige_amd import core
+
+    if len(axes) == 2:
+        gx, gy = np.meshgrid(axes[0], axes[1])
+        p = np.stack((gx.ravel(), gy.ravel()), 1)
+    else:
+        gz, gy, gx = np.meshgrid(axes[2], axes[1], axes[0], indexing="ij")
+        p = np.stack((gx.ravel(), gy.ravel(), gz.ravel()), 1)
+    return core.adjust_for_anisotropy(p, center, scaling, angle)
+
+
+def test_anisotropy_matrices_are_the_ones_adjust_for_anisotropy_multiplies_by():
+    """Host arithmetic (no GPU): rot / stretch handed to the device reproduce core.adjust_for_anisotropy when applied with
+    NumPy's own dot -- i.e. they are the reference's matrices (core.py:150-154, 166-187), entry for entry."""
+    from pykrige_amd import core
+
+    rng = np.random.default_rng(0)
+    for nd, sc, an in ((2, [3.0], [45.0]), (2, [0.37], [-123.4]), (3, [1.5, 2.0], [10.0, 20.0, 30.0]), (3, [1.0, 1.0], [0.0, 0.0, 0.0])):
+        X = rng.random((500, nd)) * 7 - 2
+        c = rng.random(nd)
+        rot, st = core.anisotropy_matrices(nd, sc, an)
+        Y = np.dot(np.diag(st), np.dot(rot, (X - c[None, :]).T)).T + c[None, :]
+        assert np.array_equal(Y, core.adjust_for_anisotropy(X, c, sc, an))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["2d_iso", "2d_aniso", "2d_aniso_b", "3d_iso", "3d_aniso", "geographic"])
+def test_device_grid_points_equal_the_host_meshgrid(case):
+    from pykrige_amd import _lib, core
+
+    rng = np.random.default_rng(7)
+    nd = 3 if case.startswith("3d") else 2
+    axes = [np.sort(rng.random(n)) * 10 - 3 for n in ((37, 29, 11) if nd == 3 else (213, 157))]
+    center = list(rng.random(nd) * 4)
+    sc, an = {"2d_iso": ([1.0], [0.0]), "2d_aniso": ([3.0], [45.0]), "2d_aniso_b": ([0.37], [-123.4]), "3d_iso": ([1.0, 1.0], [0.0] * 3),
+              "3d_aniso": ([1.5, 2.0], [10.0, 20.0, 30.0]), "geographic": ([1.0], [0.0])}[case]
+    c, v = fx.synth(1, 50, nd)
+    h = _lib.Handle(0)
+    h.set_problem(ndim=nd, xs=c[0], ys=c[1], zs=c[2] if nd == 3 else None, values=v, model_id=4, params=[1.0, 0.3, 0.0])
+    if case == "geographic":
+        h.set_grid(axes)
+        want = _host_points(axes, [0.0] * nd, [1.0], [0.0])
+        want = np.stack(np.meshgrid(axes[0], axes[1]), -1).reshape(-1, 2)
+    else:
+        rot, st = core.anisotropy_matrices(nd, sc, an)
+        h.set_grid(axes, center, rot, st)
+        want = _host_points(axes, center, sc, an)
+    got = h.get_points(nd)
+    assert got.shape == want.shape
+    ulp = np.abs(got - want) / np.spacing(np.maximum(np.abs(want), 1e-300))
+    print("device grid vs host meshgrid (%s): %d of %d coordinates differ, worst %.1f ulp" % (case, int((got != want).sum()), got.size, float(ulp.max())))
+    assert ulp.max() <= 2.0  # measured: 0 (the dot products are accumulated like NumPy's BLAS kernel does)
+    # a mask compacts the sequence; a cell range takes a slab of it
+    mask = rng.random(want.shape[0]) < 0.35
+    if case != "geographic":
+        h.set_grid(axes, center, rot, st, mask=mask)
+        assert np.array_equal(h.get_points(nd), got[~mask])
+        lo, cnt = 1234, 4321
+        h.set_grid(axes, center, rot, st, mask=mask[lo:lo + cnt], cell_range=(lo, cnt))
+        assert np.array_equal(h.get_points(nd), got[lo:lo + cnt][~mask[lo:lo + cnt]])
+        h.set_devices(3, alias=True)  # device group: the slabs follow each other
+        h.set_problem(ndim=nd, xs=c[0], ys=c[1], zs=c[2] if nd == 3 else None, values=v, model_id=4, params=[1.0, 0.3, 0.0])
+        h.set_grid(axes, center, rot, st, mask=mask)
+        assert np.array_equal(h.get_points(nd), got[~mask])
+    h.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["ok2d_exponential_exact", "ok2d_spherical_noexact", "ok3d_gaussian_aniso", "uk2d_rl_pl_node",
+                                  "uk2d_external_z", "ok2d_masked_points", "ok2d_n2000", "uk3d_rl_func"])
+def test_execute_from_axes_equals_execute_from_host_points(name):
+    """execute('grid' / 'masked') through mik_set_grid against the same call through the host meshgrid (MIK_DEVICE_GRID=0) and
+    against the reference's stored answer."""
+    g = fx.load(name)
+    style = "masked" if "mask" in g else "grid"
+    kw = dict(mask=g["mask"].astype(bool)) if "mask" in g else {}
+    if "spec_grid" in g:
+        kw["specified_drift_arrays"] = [g["spec_grid"]]
+    outs = []
+    for dev_grid in ("1", "0"):
+        os.environ["MIK_DEVICE_GRID"] = dev_grid
+        try:
+            m = fx.amd_model_from(name, g)
+            outs.append(m.execute(style, *fx.grid_args(g), backend="vectorized", **kw))
+        finally:
+            del os.environ["MIK_DEVICE_GRID"]
+    (za, sa), (zb, sb) = outs
+    za, sa, zb, sb = (np.ma.getdata(a) for a in (za, sa, zb, sb))
+    print("%s: device grid vs host points max|dz| %.2e max|dss| %.2e" % (name, np.abs(za - zb).max(), np.abs(sa - sb).max()))
+    assert np.abs(za - zb).max() <= 1e-12 and np.abs(sa - sb).max() <= 1e-12
+    if "z" in g and style == "grid":
+        assert np.abs(za - g["z"]).max() <= 1e-8 and np.abs(sa - g["ss"]).max() <= 1e-6
+
+
+@pytest.mark.gpu
+def test_grid_cell_ranges_tile_the_whole_grid():
+    """One rank's slab of a sharded grid (pykrige_amd.dist): cell ranges of mik_set_grid put together = the whole grid."""
+    from pykrige_amd import _lib, core
+
+    g = fx.load("ok2d_n2000")
+    import pykrige_amd as pa
+
+    ok = pa.OrdinaryKriging(g["x"], g["y"], g["v"], variogram_model="exponential", variogram_parameters=[1.0, 0.3, 0.0],
+                            anisotropy_scaling=2.0, anisotropy_angle=30.0)
+    z, ss = ok.execute("grid", g["gridx"], g["gridy"], backend="loop")
+    h = ok._get_handle()
+    P = ok._prepare("grid", (g["gridx"], g["gridy"]), None)
+    parts = []
+    n = P.npt
+    for lo, hi in ((0, n // 3), (n // 3, n // 3 + 1), (n // 3 + 1, n)):
+        P.load(h, 2, cell_range=(lo, hi - lo))
+        h.predict()
+        parts.append(h.get_results())
+    assert np.array_equal(np.concatenate([p[0] for p in parts]), z.ravel())
+    assert np.array_equal(np.concatenate([p[1] for p in parts]), ss.ravel())

@@ -56,6 +56,22 @@ class OracleHandle:
         self.pts = np.stack([px, py] + ([pz] if pz is not None else []), 1)
         self.mask = mask
 
+    def set_grid(self, axes, center=None, rot=None, stretch=None, mask=None, extra_rows=None, cell_range=None):
+        """mik_set_grid restated with NumPy: the reference's flattened meshgrid, the anisotropy transform, a cell range."""
+        if len(axes) == 2:
+            gx, gy = np.meshgrid(axes[0], axes[1])
+            p = np.stack((gx.ravel(), gy.ravel()), 1)
+        else:
+            gz, gy, gx = np.meshgrid(axes[2], axes[1], axes[0], indexing="ij")
+            p = np.stack((gx.ravel(), gy.ravel(), gz.ravel()), 1)
+        if rot is not None:
+            c = np.asarray(center, float)[None, :]
+            p = (np.diag(stretch) @ (np.asarray(rot) @ (p - c).T)).T + c
+        if cell_range is not None:
+            p = p[cell_range[0]:cell_range[0] + cell_range[1]]
+        self.pts, self.mask = p, mask
+        self.calls.append("set_grid")
+
     def predict(self):
         self.calls.append("predict")
         self.window = None
@@ -244,6 +260,11 @@ class RcclStandInHandle(OracleHandle):
         assert root == 0
         self.calls.append("bcast_factor")
 
+    def factor_checksum(self):
+        # what every rank's device would report for its copy of the inverse: equal everywhere unless `corrupt_rank` says
+        # this rank's copy arrived damaged
+        return (1, 2, 3, 4) if getattr(self, "corrupt_rank", None) != self.rank else (1, 2, 3, 5)
+
 
 def _rccl_flow_worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
@@ -279,8 +300,15 @@ def _rccl_flow_worker(rank, world, port, q):
             exb.execute("grid", gx, gy, backend="loop")
         except np.linalg.LinAlgError as e:
             raised = "singular" in str(e)
+        # a broadcast that delivers a damaged copy to rank 1: the checksums disagree, EVERY rank factors for itself
+        dmg = RcclStandInHandle(rank)
+        dmg.corrupt_rank = 1
+        exd = ShardedExecutor(ok, group=pg, handle_factory=lambda: dmg)
+        zd, ssd = exd.execute("grid", gx, gy, backend="loop")
+        damaged = bool(exd.exchange.startswith("redundant_factor (rccl broadcast failed: checksum") and dmg.calls.count("factor") >= 1
+                       and np.allclose(zd, zr, atol=1e-12) and "set_grid" in dmg.calls)
         ex.close()
-        q.put((rank, good, flow, local, raised and bad.calls.count("bcast_factor") == 0))
+        q.put((rank, good, flow, local, raised and bad.calls.count("bcast_factor") == 0, damaged))
     finally:
         pg.close()
 

@@ -1,0 +1,150 @@
+"""The factor exchange of a device group cannot hang (include/mikrige.h, "Bounded waits"): every RCCL call of it runs on a
+worker thread under a limit, a stuck call is abandoned and the exchange goes on over peer copies.
+
+CPU part: mik_selftest_exchange drives the RCCL path of the exchange -- communicator set-up, the grouped broadcast, the
+wait with its two limits -- with stand-in members and without a single HIP call, against a stand-in librccl
+(tests/standin/standin_rccl.cpp via MIK_RCCL_LIB) whose calls succeed, fail or NEVER RETURN.
+GPU part: the same stand-ins under a real mik_factor on a device group (aliased onto the one GPU): the call returns within
+the limit through the peer path, says so, and the results are bit-identical to one device's."""
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _standins():
+    from tests.standin import build
+
+    return build.build()
+
+
+def _selftest(mode, members=4, init=0.6, bcast=0.6):
+    cpu, _ = _standins()
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from pykrige_amd import _lib\n"
+            "import time; t0 = time.time()\n"
+            "rc, rep = _lib.selftest_exchange(%d, %r, %r)\n"
+            "rc2, rep2 = _lib.selftest_exchange(%d, %r, %r)\n"  # a second exchange in the same process
+            "print('%%d|%%s|%%d|%%s|%%.2f' %% (rc, rep, rc2, rep2, time.time() - t0))\n" % (ROOT, members, init, bcast, members, init, bcast))
+    env = dict(os.environ, MIK_RCCL_LIB=cpu, STANDIN_RCCL_MODE=mode)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 0, r.stderr[-800:]
+    rc, rep, rc2, rep2, dt = r.stdout.strip().splitlines()[-1].split("|")
+    return int(rc), rep, int(rc2), rep2, float(dt), time.time() - t0
+
+
+def test_exchange_with_a_working_rccl_reports_its_ranks():
+    rc, rep, rc2, rep2, dt, _ = _selftest("ok", members=8)
+    assert rc == 0 and rep == "ok ranks=8" and rc2 == 0 and rep2 == "ok ranks=8"  # communicators are cached: the second one too
+    assert dt < 5.0
+
+
+def test_comm_init_that_never_returns_is_abandoned_within_the_limit():
+    rc, rep, rc2, rep2, dt, wall = _selftest("hang_init")
+    assert rc == -4 and rep.startswith("timeout phase=init after 0.6") and "rccl_dead=1" in rep, rep
+    # RCCL is not tried again in this process: the second exchange fails at once instead of waiting out another limit
+    assert rc2 == -4 and "RCCL disabled for this process" in rep2 and "ncclCommInitAll" in rep2, rep2
+    assert dt < 3.0 and wall < 60.0  # and the process exits although a worker thread is still stuck inside the stand-in
+
+
+def test_broadcast_that_never_returns_is_abandoned_within_the_limit():
+    rc, rep, rc2, rep2, dt, _ = _selftest("hang_bcast", init=5.0, bcast=0.5)
+    assert rc == -4 and rep.startswith("timeout phase=bcast after 0.5"), rep  # the init limit (5 s) was NOT what expired
+    assert rc2 == -4 and "RCCL disabled" in rep2 and "ncclBroadcast" in rep2
+    assert dt < 3.0
+
+
+def test_comm_init_that_fails_is_an_error_not_a_wait():
+    rc, rep, rc2, rep2, dt, _ = _selftest("fail_init", init=30.0, bcast=30.0)
+    assert rc == -4 and rep.startswith("failed:") and "CommInitAll" in rep
+    assert rc2 == -4 and rep2.startswith("failed:")  # a failure (not a stall) does not disable RCCL: it is simply tried again
+    assert dt < 3.0
+
+
+# ------------------------------------------------------------------------------------------------ on the GPU
+_GPU_SCRIPT = r"""
+import sys, time, json
+sys.path.insert(0, %(root)r)
+import numpy as np
+from pykrige_amd import _lib
+from tests import _fixtures as fx
+c, v = fx.synth(11, 700, 2)
+rng = np.random.default_rng(3)
+pts = [rng.random(5000), rng.random(5000)]
+def run(h):
+    h.set_problem(ndim=2, xs=c[0], ys=c[1], zs=None, values=v, model_id=_lib.MODEL_IDS["exponential"], params=[0.9, 0.3, 0.1])
+    h.set_points(pts[0], pts[1])
+    t0 = time.time(); h.factor(); tf = time.time() - t0
+    h.predict()
+    return h.get_results(), tf
+h1 = _lib.Handle(0)
+(z1, s1), _ = run(h1)
+hg = _lib.Handle(0)
+hg.set_devices(3, alias=True)
+hg.set_option("exchange", %(exchange)d)
+out = {}
+try:
+    (zg, sg), tf = run(hg)
+    t = hg.timing()
+    out = dict(ok=True, same=bool(np.array_equal(z1, zg) and np.array_equal(s1, sg)), path=t["exchange_path"], fallbacks=t["exchange_fallbacks"],
+               ranks=t["rccl_ranks"], note=hg.exchange_note(), factor_s=tf, wait_ms=t["exchange_wait_ms"], ms=t["exchange_ms"])
+    t0 = time.time()
+    (zg2, sg2), tf2 = run(hg)   # the next factor on the same handle (and, after a stall, with RCCL disabled)
+    t2 = hg.timing()
+    out.update(same2=bool(np.array_equal(z1, zg2)), path2=t2["exchange_path"], second_s=time.time() - t0, note2=hg.exchange_note())
+except Exception as e:
+    out = dict(ok=False, err=repr(e))
+print("RESULT " + json.dumps(out))
+"""
+
+
+def _gpu_case(mode, exchange=0, init="1.0", bcast="1.0"):
+    import json
+
+    _, hip = _standins()
+    assert os.path.exists(hip), "the HIP stand-in needs hipcc"
+    env = dict(os.environ, MIK_RCCL_LIB=hip, STANDIN_RCCL_MODE=mode, MIK_RCCL_ALLOW_ALIAS="1", MIK_RCCL_INIT_TIMEOUT=init,
+               MIK_RCCL_BCAST_TIMEOUT=bcast)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-c", _GPU_SCRIPT % dict(root=ROOT, exchange=exchange)], capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-800:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1]
+    return json.loads(line[7:]), time.time() - t0
+
+
+@pytest.mark.gpu
+def test_group_exchange_over_a_working_rccl_standin():
+    o, _ = _gpu_case("ok")
+    assert o["ok"] and o["same"] and o["path"] == 1 and o["ranks"] == 3 and o["fallbacks"] == 0 and o["note"] == "", o
+    assert o["same2"] and o["path2"] == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,what", [("hang_init", "ncclCommInitAll did not finish within 1.0 s"),
+                                       ("hang_bcast", "the grouped ncclBroadcast did not finish within 1.0 s"),
+                                       ("corrupt", "checksum mismatch on group member 1"),
+                                       ("fail_init", "stand-in RCCL error")])
+def test_group_exchange_survives_a_stuck_or_broken_rccl(mode, what):
+    """exchange = auto: mik_factor + mik_predict return through the peer path within the limit, bit-identical results."""
+    o, wall = _gpu_case(mode)
+    assert o["ok"], o
+    assert o["same"] and o["path"] == 2 and o["fallbacks"] == 1 and what in o["note"] and "rccl broadcast failed" in o["note"], o
+    assert o["factor_s"] < 1.0  # asynchronous exchange: mik_factor itself returned at once
+    assert o["same2"] and o["path2"] == 2, o
+    if mode.startswith("hang"):
+        assert "rccl disabled for this process" in o["note2"] and o["second_s"] < 0.9, o  # no second wait on a dead RCCL
+    assert wall < 120.0
+
+
+@pytest.mark.gpu
+def test_forced_rccl_that_hangs_is_an_error_not_a_hang():
+    o, wall = _gpu_case("hang_bcast", exchange=1)
+    assert not o["ok"] and "RuntimeError" in o["err"] and "did not finish within" in o["err"], o
+    assert wall < 120.0
