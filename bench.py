@@ -3,10 +3,12 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4|5] [--no-cpu] [--moving-window K]
 
-One "step" = one pass of the hot path over the workload with inputs already resident in HBM:
-kriging-matrix assembly + inverse (K1, K2) [+ the exchange of the inverse when N > 1] + RHS assembly
-and contraction (K3) for every grid point; z and sigma^2 land in page-locked host memory chunk by chunk while the next chunk
-is computed (the timed region ends when every device AND its result copies are idle).
+One "step" = ONE call of the drop-in class's execute('grid', axes) end to end ("wall-clock of execute()"):
+host front matter, the grid generated on the device from its axes (mik_set_grid: what crosses PCIe on the way in is
+O(nx + ny)), kriging-matrix assembly + inverse (K1, K2) [+ the exchange of the inverse when N > 1, overlapped with the
+leader's prediction] + RHS assembly and contraction (K3) for every grid point; z and sigma^2 land in page-locked host
+memory chunk by chunk while the next chunk is computed and are copied into the returned arrays.  The rate with the points
+already resident in HBM (mik_factor + mik_predict per step) stands beside it as `resident`.
 Default workload = BASELINE.json configs[1]: OrdinaryKriging 2D, N=5000 stations, 1000x1000 grid,
 exponential variogram [1.0, 0.3, 0.0], fp64, synthetic stations (seed 2).
 
@@ -297,6 +299,32 @@ def collect_traffic_live(argv_tail, kernel_prefix, timeout=240):
             "WRITE_SIZE_KB_per_launch": write_kb, "launches_seen": res["FETCH_SIZE"][1]}, None
 
 
+def grid_axes(cfg, n_gpus):
+    """Axes of the weak-scaled grid: config's grid with its slowest axis n_gpus times as long (shard_points r = slab r of it)."""
+    g = cfg["grid"]
+    if cfg["ndim"] == 2:
+        return [np.linspace(0.0, 1.0, g[0]), np.linspace(0.0, 1.0, g[1] * n_gpus)]
+    return [np.linspace(0.0, 1.0, g[0]), np.linspace(0.0, 1.0, g[1]), np.linspace(0.0, 1.0, g[2] * n_gpus)]
+
+
+def make_model(cfg, coords, values):
+    """The drop-in class of the config (ok.py:187-206, uk.py:220-244, ok3d.py:198-219 constructor keywords)."""
+    import pykrige_amd as pa
+
+    kw = dict(variogram_model=cfg["model"], variogram_parameters=list(cfg["params"]))
+    if cfg["ndim"] == 3:
+        return pa.OrdinaryKriging3D(coords[0], coords[1], coords[2], values, **kw)
+    if cfg.get("rl") or cfg.get("wells"):
+        terms = (["regional_linear"] if cfg.get("rl") else []) + (["point_log"] if cfg.get("wells") else [])
+        return pa.UniversalKriging(coords[0], coords[1], values, drift_terms=terms, point_drift=cfg.get("wells"), **kw)
+    return pa.OrdinaryKriging(coords[0], coords[1], values, **kw)
+
+
+MW_KERNELS = {1: "k_mw_chol", 2: "k_mw_solve", 3: "k_mw_solve_big"}
+FACTOR_PATHS = {1: "spd-shift block sweep", 2: "pivoted block gauss-jordan", 3: "caller-supplied inverse", 4: "device pseudo-inverse (jacobi)",
+                5: "deflated inverse (pseudo-inverse of duplicated stations)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -305,8 +333,9 @@ def main():
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-sample", type=int, default=4096, help="points of the bounded CPU slab")
-    ap.add_argument("--cpu-protocol", choices=["bounded", "full"], default="bounded",
-                    help="full = BASELINE.md section 3 to the letter (>= 16 384-point slab, 3 repeats): minutes of CPU time")
+    ap.add_argument("--cpu-protocol", choices=["bounded", "full"], default="full",
+                    help="full (default) = BASELINE.md section 3 to the letter (>= 16 384-point slab, best of 3, thread sweep): about a "
+                         "minute of CPU time; bounded = the same protocol on --cpu-sample points")
     ap.add_argument("--pmc", choices=["auto", "on", "off"], default="auto",
                     help="collect roofline.traffic live with two rocprofv3 --pmc passes of one step (auto: when N = 1)")
     ap.add_argument("--exchange", choices=sorted(EXCHANGE_CODES), default=os.environ.get("MIK_BENCH_EXCHANGE", "auto"),
@@ -340,6 +369,30 @@ def main():
         args.gpus = world
     elif args.gpus > 1:
         group = args.gpus  # plain `python bench.py --gpus N`: single process, the library's device group
+    n_gpus = world * group
+
+    # A line ALWAYS comes out.  Every wait of the multi-GPU paths is bounded inside the library (include/mikrige.h, "Bounded
+    # waits"); this is the last line of defence for anything else that stalls: after MIK_BENCH_DEADLINE seconds rank 0 prints
+    # an error line (value null) and the process exits.
+    import threading
+
+    progress = {"stage": "start", "done": False}
+
+    def deadline_watch(limit):
+        t_end = time.time() + limit
+        while time.time() < t_end:
+            if progress["done"]:
+                return
+            time.sleep(0.5)
+        if rank == 0:
+            emit(json.dumps({"metric": "kriged grid-points/sec (z + sigma^2)", "value": None, "unit": "grid-points/s", "n_gpus": n_gpus,
+                             "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak",
+                             "error": "bench.py did not finish within %.0f s; last stage: %s" % (limit, progress["stage"])}))
+        os._exit(3)
+
+    if not inner:
+        threading.Thread(target=deadline_watch, args=(float(os.environ.get("MIK_BENCH_DEADLINE", "1500")),), daemon=True).start()
+
     pg = None
     if world > 1:
         # Host-side rendezvous / barrier / max-over-ranks only.  The launcher's env (RANK, WORLD_SIZE, MASTER_*) is used
@@ -364,23 +417,24 @@ def main():
     cfg = CONFIGS[args.config]
     ndim = cfg["ndim"]
     coords, values = synth(cfg["seed"], cfg["n"], ndim)
-    n_gpus = world * group
-    if group > 1:  # the whole weak-scaled grid; the library cuts it into one contiguous slab per device
-        parts = [shard_points(cfg, r, group) for r in range(group)]
-        pts = [np.concatenate([p[d] for p in parts]) for d in range(ndim)]
-        del parts
-    else:
-        pts = shard_points(cfg, rank, world)
-    npt = pts[0].size
+    axes = grid_axes(cfg, n_gpus)  # the whole weak-scaled grid; the library (device group) / the executor (ranks) cuts the slabs
+    npt_total = int(np.prod([a.size for a in axes]))
+    npt_rank = npt_total // world
 
     ndev = _lib.load().mik_device_count()
-    wells = np.array(cfg["wells"]) if cfg.get("wells") else None
     aliased = group > max(ndev, 1)
+    os.environ["MIK_FACTOR_CACHE"] = "0"  # every execute() assembles and inverts the matrix, as the reference does (ok.py:898, 663)
+    os.environ["MIK_DEVICE"] = str(local_rank % max(ndev, 1))  # one GPU per rank on a real node; wraps only on a 1-GPU test box
+    if aliased:
+        os.environ["MIK_ALIAS_DEVICES"] = "1"
+    if group > 1:
+        _lib.set_devices(group)
+    kw = args.moving_window
 
-    def make_handle():
-        hh = _lib.Handle(local_rank % max(ndev, 1))  # one GPU per rank on a real node; wraps only on a 1-GPU test box
+    def make():
+        m = make_model(cfg, coords, values)
+        hh = m._get_handle()
         if group > 1:
-            hh.set_devices(group, alias=aliased)
             hh.set_option("exchange", EXCHANGE_CODES[args.exchange])
         if args.symmetric is not None:
             hh.set_option("symmetric", args.symmetric)
@@ -390,25 +444,29 @@ def main():
             hh.set_option("engine", 1 if args.engine == "valu" else 0)
         if args.factor is not None:
             hh.set_option("factor", {"auto": 0, "sweep": 1, "lu": 2}[args.factor])
-        hh.set_problem(ndim=ndim, xs=coords[0], ys=coords[1], zs=coords[2] if ndim == 3 else None, values=values,
-                       model_id=_lib.MODEL_IDS[cfg["model"]], params=internal_params(cfg["model"], cfg["params"]),
-                       regional_linear=bool(cfg.get("rl")), wells=wells)
-        hh.set_points(pts[0], pts[1], pts[2] if ndim == 3 else None)
-        return hh
+        return m, hh
 
-    h = make_handle()
+    progress["stage"] = "create the kriging object and its device handle"
+    model, h = make()
+    exe_kw = dict(backend="loop")
+    if kw:
+        exe_kw["n_closest_points"] = kw
 
     # How the inverted matrix reaches every GPU.  The north_star's design is the default and the one timed: the leader
     # factors, ONE broadcast over RCCL/xGMI.  The alternatives are measured beside it, outside the timed region, and
     # printed (factor_exchange_trial): peer copies shaped as scatter + all-gather, and no exchange at all (every GPU
     # factors the identical matrix; the others wait for the leader's factorisation anyway, so this is a wall-clock tie at
-    # best for the broadcast and costs N-1 redundant O(M^3) factorisations of energy).
-    exchange, trial, leaked = "none", None, False
-    if group > 1 and not args.moving_window:
+    # best for the broadcast and costs N-1 redundant O(M^3) factorisations of energy).  Every trial is bounded by the
+    # library's own limits (a stalled RCCL call is abandoned, reported, and the next path runs).
+    exchange, trial, executor = "none", None, None
+    if group > 1 and not kw:
+        progress["stage"] = "exchange trials of the device group"
         trial = {}
+        model._set_problem(h)
         for name in ("rccl", "peer", "redundant"):
             try:
                 h.set_option("exchange", EXCHANGE_CODES[name])
+                h.set_option("async_exchange", 0)  # the trial times factor + exchange as one blocking call
                 best = None
                 for _ in range(2):  # the first round pays RCCL's communicator / stream set-up and the buffer allocations
                     t0 = time.perf_counter()
@@ -418,63 +476,17 @@ def main():
                 trial[name + "_factor_plus_exchange_ms"] = best * 1e3
                 trial[name + "_exchange_ms"] = h.timing()["exchange_ms"]
             except Exception as e:  # noqa: BLE001
-                trial[name + "_error"] = repr(e)[:200]
+                trial[name + "_error"] = repr(e)[:300]
         h.set_option("exchange", EXCHANGE_CODES[args.exchange])
-        h.factor()
-        exchange = EXCHANGE_NAMES[h.timing()["exchange_path"]]
-        if args.exchange == "auto" and exchange != "rccl_bcast":
-            exchange += " (rccl unavailable: %s)" % trial.get("rccl_error", "?")
-    elif world > 1 and not args.moving_window:
-        if args.exchange == "redundant":
-            exchange = "redundant_factor"
-        else:
-            import threading
+        h.set_option("async_exchange", 1)
+    elif world > 1:
+        progress["stage"] = "process group / RCCL set-up of the ranks"
+        from pykrige_amd.dist import ShardedExecutor
 
-            from pykrige_amd.dist import init_rccl
-
-            exchange = init_rccl(h, pg)  # "rccl_bcast", or "redundant_factor (...)"
-            if exchange == "rccl_bcast":
-                def watchdog(fn, limit):
-                    box = {}
-
-                    def run():
-                        try:
-                            fn()
-                            box["ok"] = True
-                        except Exception as e:  # noqa: BLE001
-                            box["err"] = repr(e)[:120]
-
-                    th = threading.Thread(target=run, daemon=True)
-                    t0 = time.perf_counter()
-                    th.start()
-                    th.join(limit)
-                    return box.get("ok", False), time.perf_counter() - t0, box.get("err"), th.is_alive()
-
-                def via_bcast():
-                    if rank == 0:
-                        h.factor()
-                    h.bcast_factor(0)
-
-                limit = float(os.environ.get("MIK_RCCL_BCAST_TIMEOUT", "60"))
-                ta = tb = None
-                for _ in range(2):  # first round pays RCCL's lazy channel set-up and the buffer allocations
-                    pg.barrier()
-                    ok, ta, err, hung = watchdog(via_bcast, limit)
-                    res = pg.all_gather_object((ok, ta, err))
-                    if not all(r[0] for r in res):
-                        why = next((r[2] for r in res if r[2]), "broadcast did not finish within %.0f s" % limit)
-                        exchange = "redundant_factor (rccl broadcast failed: %s)" % why
-                        if hung:  # this rank's stream is stuck behind the collective: abandon the handle
-                            leaked = True
-                            h = make_handle()
-                        break
-                    ta = max(r[1] for r in res)
-                    pg.barrier()
-                    t0 = time.perf_counter()
-                    h.factor()
-                    tb = pg.all_reduce_max(time.perf_counter() - t0)
-                if exchange == "rccl_bcast":
-                    trial = {"rccl_factor_plus_exchange_ms": ta * 1e3, "redundant_factor_plus_exchange_ms": tb * 1e3}
+        # rank r kriges slab r and keeps it (gather='local': "each GPU writes its slab"); rank 0 factors, the library
+        # broadcasts over RCCL (bounded: MIK_RCCL_INIT_TIMEOUT / MIK_RCCL_BCAST_TIMEOUT), checksums are compared, and any
+        # failure degrades to every rank factoring for itself
+        executor = ShardedExecutor(model, group=pg, use_rccl=(args.exchange != "redundant") and not kw, gather="local")
 
     def sync():
         h.synchronize()  # every device of the handle and its result copies idle (the calls already block; explicit bracket)
@@ -482,75 +494,76 @@ def main():
             pg.barrier()
 
     tsum = dict(assemble_ms=0.0, invert_ms=0.0, rhs_ms=0.0, contract_ms=0.0, predict_ms=0.0, contract_launches=0,
-                contract_flops_executed=0.0, exchange_ms=0.0)
+                contract_flops_executed=0.0, exchange_ms=0.0, exchange_wait_ms=0.0)
+    last = {}
 
     def step(record):
-        if args.moving_window:
-            h.predict_moving_window(args.moving_window)
-            if record:
-                t = h.timing()
-                for k in ("rhs_ms", "contract_ms", "predict_ms", "contract_launches"):
-                    tsum[k] += t[k]
-            return
-        if world > 1 and exchange == "rccl_bcast":
-            if rank == 0:
-                h.factor()
-            h.bcast_factor(0)
+        # ONE execute() of the drop-in class, host arrays in -> host arrays out (SURVEY 8d "wall-clock of execute() end-to-end"):
+        # front matter, mik_set_problem, K1 + K2 [+ exchange], the grid generated on the device from its axes, K3 for every
+        # point, z and sigma^2 into page-locked memory chunk by chunk, copy into the returned arrays, back matter
+        if executor is not None:
+            out = executor.execute("grid", *axes, **exe_kw)
+            t = h.timing() if record else None
         else:
-            h.factor()
-        if record and (rank == 0 or exchange != "rccl_bcast"):
-            t = h.timing()
-            tsum["assemble_ms"] += t["assemble_ms"]
-            tsum["invert_ms"] += t["invert_ms"]
-            tsum["exchange_ms"] += t["exchange_ms"]
-        h.predict()  # blocking: returns after every device's compute stream has drained
+            out = model.execute("grid", *axes, **exe_kw)
+            t = model.last_timing
         if record:
-            t = h.timing()
-            for k in ("rhs_ms", "contract_ms", "predict_ms", "contract_launches", "contract_flops_executed"):
+            for k in ("assemble_ms", "invert_ms", "exchange_ms", "exchange_wait_ms", "rhs_ms", "contract_ms", "predict_ms", "contract_launches",
+                      "contract_flops_executed"):
                 tsum[k] += t[k]
-            tsum["factor_path"], tsum["symmetric"], tsum["engine"] = t["factor_path"], t["symmetric"], t["engine"]
+            last.update(t)
+        return out
 
+    progress["stage"] = "warm-up steps"
     for _ in range(args.warmup):
         step(False)
     sync()
+    progress["stage"] = "timed steps"
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(True)
+        res = step(True)
     sync()
     dt = time.perf_counter() - t0
     if pg is not None:
         dt = pg.all_reduce_max(dt)
+    if executor is not None:
+        exchange = executor.exchange
+    elif group > 1 and not kw:
+        exchange = EXCHANGE_NAMES[last["exchange_path"]]
+        note = h.exchange_note()
+        if note:
+            exchange += " (" + note + ")"
 
     if rank == 0:
+        progress["stage"] = "report"
         K = args.steps
         M = cfg["n"] + (ndim if cfg.get("rl") else 0) + (len(cfg["wells"]) if cfg.get("wells") else 0) + 1
-        total_pts = npt * world
-        value = total_pts * K / dt
+        value = npt_total * K / dt
         launches = max(1, int(tsum["contract_launches"]))  # of the leader device (its slab = total / n_gpus points)
         avg_launch_s = tsum["contract_ms"] * 1e-3 / launches
-        pts_per_launch = (npt / group) * K / launches
-        kw = args.moving_window
+        pts_per_launch = (npt_total / n_gpus) * K / launches
         if kw:
             # dominant kernel: the per-point (k+1) x (k+1) solves.  Algorithmic work per point = what the reference's dgesv
             # does (cok.pyx:165): 2/3 n^3 + 2 n^2 flops, n = k + 1; bytes: k x 12 (neighbour index + distance) in, 16 out.
             nn = kw + 1.0
             algo_flops_pt = 2.0 / 3.0 * nn ** 3 + 2.0 * nn ** 2
             achieved = algo_flops_pt * pts_per_launch / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0
-            roof = {"bound": "mfma", "kernel": "k_mw_solve", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            kname = MW_KERNELS.get(last.get("mw_kernel"), "k_mw_chol")  # the solver that ran (mik_timing.mw_kernel)
+            roof = {"bound": "mfma", "kernel": kname, "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
                     "note": "fp64 compute roof (vector = matrix rate on this part): %.0f flop per point against %d bytes; the kernel "
-                            "is a register-tiled elimination with one barrier per step -- issue / latency bound, not MFMA work"
+                            "is a register-tiled elimination with one LDS exchange per step -- issue / latency bound, not MFMA work"
                             % (algo_flops_pt, 12 * kw + 16),
                     "avg_launch_ms": avg_launch_s * 1e3, "algorithmic_flops_per_point": algo_flops_pt,
                     "algorithmic_bytes_per_point": 12 * kw + 16}
             metric = "kriged grid-points/sec (z + sigma^2), moving window n_closest_points=%d, %s" % (kw, cfg["name"])
-            config = {"workload": cfg["name"], "n_closest_points": kw, "stations": cfg["n"], "grid_points_total": total_pts}
-            kernel_prefix = "void mik::k_mw_solve"
+            config = {"workload": cfg["name"], "n_closest_points": kw, "stations": cfg["n"], "grid_points_total": npt_total}
+            kernel_prefix = "void mik::" + kname + "<"
         else:
             algo_flops_per_launch = 2.0 * M * M * pts_per_launch  # 2 M^2 per point for w = A_inv . b
             effective = algo_flops_per_launch / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0
             executed = tsum["contract_flops_executed"] / (tsum["contract_ms"] * 1e-3) / 1e12 if tsum["contract_ms"] > 0 else 0.0
-            roof = {"bound": "mfma", "kernel": "k_contract_valu" if tsum.get("engine") else "k_contract",
+            roof = {"bound": "mfma", "kernel": "k_contract_valu" if last.get("engine") else "k_contract",
                     "achieved": executed, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": executed / FP64_MFMA_PEAK_TFLOPS,
                     "peak_measured": FP64_MFMA_MEASURED_TFLOPS, "frac_of_measured_peak": executed / FP64_MFMA_MEASURED_TFLOPS,
                     "effective_tflops": effective, "effective_frac": effective / FP64_MFMA_PEAK_TFLOPS,
@@ -559,29 +572,51 @@ def main():
                             "peak: a true fraction.  effective_* = the reference's 2 M^2 flops per point (SURVEY 8d) over the same "
                             "time: the rate a full product would need to match this kernel; it can exceed the peak.",
                     "avg_launch_ms": avg_launch_s * 1e3, "launches_per_step": launches / K,
-                    "algorithmic_flops_per_point": 2.0 * M * M, "executed_flops_per_point": tsum["contract_flops_executed"] / max(1.0, pts_per_launch * launches)}
+                    "algorithmic_flops_per_point": 2.0 * M * M, "useful_flops_per_point": float(M) * M,
+                    "executed_flops_per_point": tsum["contract_flops_executed"] / max(1.0, pts_per_launch * launches),
+                    "flops_note": "algorithmic = the reference's w = A_inv.b (2 M^2, ok.py:679); useful = the quadratic form b^T A_inv b "
+                                  "over one triangle (M^2); executed = useful + the mirrored halves of the 128 x 128 diagonal blocks"}
             metric = ("kriged grid-points/sec (z + sigma^2), OK2D N=5000 on 1000x1000 grid" if args.config == 2
                       else "kriged grid-points/sec (z + sigma^2), " + cfg["name"])
             config = {"workload": cfg["name"], "stations": cfg["n"], "matrix_order": M,
-                      "grid_points_per_gpu": npt // group, "grid_points_total": total_pts, "variogram": cfg["model"],
+                      "grid_points_per_gpu": npt_total // n_gpus, "grid_points_total": npt_total, "variogram": cfg["model"],
                       "variogram_parameters": cfg["params"], "factor_exchange": exchange, "factor_exchange_trial": trial,
-                      "factor_path": {1: "spd-shift block sweep", 2: "pivoted block gauss-jordan", 3: "caller-supplied inverse",
-                                      4: "device pseudo-inverse"}.get(tsum.get("factor_path"), "?"),
-                      "symmetric_contraction": bool(tsum.get("symmetric"))}
+                      "factor_path": FACTOR_PATHS.get(last.get("factor_path"), "?"),
+                      "symmetric_contraction": bool(last.get("symmetric"))}
             kernel_prefix = "void mik::k_contract"
-        config["launch"] = ("one process per GPU (torch.distributed.run)" if world > 1 else
+        config["timed_call"] = ("%s.execute('grid', axes, backend='loop'%s): host arrays in, host arrays out; the grid is generated on the "
+                                "device from its axes (mik_set_grid), every call assembles and inverts the matrix (MIK_FACTOR_CACHE=0, as "
+                                "the reference does)" % (type(model).__name__, ", n_closest_points=%d" % kw if kw else ""))
+        config["launch"] = ("one process per GPU (torch.distributed.run), pykrige_amd.dist.ShardedExecutor, gather='local'" if world > 1 else
                             "one process, device group of %d%s" % (group, " ALIASED onto %d physical GPU(s)" % ndev if aliased else "")
                             if group > 1 else "one process, one GPU")
         out = {"metric": metric, "value": value, "unit": "grid-points/s", "n_gpus": n_gpus, "steps": K, "warmup": args.warmup,
                "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f64", "data": "synthetic", "config": config, "roofline": roof,
                "phases_ms_per_step": {"assemble": tsum["assemble_ms"] / K, "invert": tsum["invert_ms"] / K,
-                                      "exchange": tsum["exchange_ms"] / K, "rhs": tsum["rhs_ms"] / K,
-                                      "contract": tsum["contract_ms"] / K, "predict_total": tsum["predict_ms"] / K}}
+                                      "exchange": tsum["exchange_ms"] / K, "exchange_not_overlapped": tsum["exchange_wait_ms"] / K,
+                                      "rhs": tsum["rhs_ms"] / K, "contract": tsum["contract_ms"] / K, "predict_total": tsum["predict_ms"] / K}}
+        dev_ms = (tsum["assemble_ms"] + tsum["invert_ms"] + tsum["exchange_wait_ms"] + tsum["predict_ms"]) / K
+        out["host_overhead"] = {"ms_per_step": dt / K * 1e3 - dev_ms, "frac": 1.0 - dev_ms / (dt / K * 1e3),
+                                "what": "execute() wall-clock minus the device phases (assemble + invert + the exchange time a caller "
+                                        "waited for + the slowest device's predict)"}
+        # ---- the multi-GPU path describes itself (every --gpus N)
         if group > 1:
-            out["per_device_predict_ms"] = [h.device_timing(i)["predict_ms"] for i in range(group)]
+            per_dev = [h.device_timing(i) for i in range(group)]
+            out["multi_gpu"] = {"devices": [t["reserved"] for t in per_dev], "per_device_predict_ms": [t["predict_ms"] for t in per_dev],
+                                "exchange_path": EXCHANGE_NAMES.get(last.get("exchange_path"), "?"), "rccl_ranks": last.get("rccl_ranks"),
+                                "exchange_fallbacks": last.get("exchange_fallbacks"), "exchange_note": h.exchange_note(),
+                                "exchange_ms": last.get("exchange_ms"), "exchange_wait_ms": last.get("exchange_wait_ms"),
+                                "timeouts_s": {"rccl_init": float(os.environ.get("MIK_RCCL_INIT_TIMEOUT", "120")),
+                                               "rccl_bcast": float(os.environ.get("MIK_RCCL_BCAST_TIMEOUT", "30")),
+                                               "peer": float(os.environ.get("MIK_PEER_TIMEOUT", "30"))}}
+            out["per_device_predict_ms"] = out["multi_gpu"]["per_device_predict_ms"]
+        elif world > 1:
+            allp = pg.all_gather_object({"rank": rank, "device": int(os.environ["MIK_DEVICE"]), "predict_ms": last.get("predict_ms")})
+            out["multi_gpu"] = {"ranks": allp, "exchange_path": exchange, "rccl_ranks": world if exchange == "rccl_bcast" else 0}
         # ---- roofline.traffic: live PMC passes over one step of this benchmark, else the committed profile (labelled)
         if n_gpus == 1 and not inner and args.pmc != "off":
+            progress["stage"] = "live PMC passes (rocprofv3)"
             tail = ["--steps", "1", "--warmup", "0", "--no-cpu", "--pmc", "off", "--config", str(args.config)]
             if kw:
                 tail += ["--moving-window", str(kw)]
@@ -598,7 +633,7 @@ def main():
         if roof.get("traffic") is None and not kw:
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", "k_contract_traffic.json")))
-                if tj["workload"] == cfg["name"] and not tsum.get("engine") and tsum.get("symmetric"):
+                if tj["workload"] == cfg["name"] and not last.get("engine") and last.get("symmetric"):
                     roof["traffic"] = tj["hbm_bytes_per_launch"] * (pts_per_launch / tj["points_per_launch"])
                     roof["traffic_source"] = ("from_profile (NOT collected in this run): " + tj["source"]
                                               + ("; " + roof["traffic_source"] if roof.get("traffic_source") else ""))
@@ -607,31 +642,51 @@ def main():
         if not kw:
             # compulsory bytes of one launch: the inverse once, the RHS panel (8 M per point) in, 8 M/128 partial sums per point out
             roof["algorithmic_bytes_per_launch"] = 8.0 * (M * M + pts_per_launch * (M + M / 128.0))
-        if n_gpus == 1 and not inner:  # the same step with host buffers handed over and results copied back (never `value`)
-            best = None
-            for _ in range(2):
-                t1 = time.perf_counter()
-                h.set_points(pts[0], pts[1], pts[2] if ndim == 3 else None)
+        if world == 1 and not inner:
+            progress["stage"] = "resident-points rate and points-style rate"
+            # the same work through the C ABI with the points already resident in HBM: mik_factor + mik_predict per step
+            # (round 1-2 headline; what execute() costs on top of it is host_overhead above)
+            model._set_problem(h)
+            P = model._prepare("grid", axes, None)
+            P.load(h, ndim)
+            h.factor(); h.predict(); h.synchronize()  # noqa: E702
+            t1 = time.perf_counter()
+            for _ in range(K):
                 if kw:
                     h.predict_moving_window(kw)
                 else:
                     h.factor()
                     h.predict()
-                zz, sss = h.get_results()
-                d1 = time.perf_counter() - t1
-                best = d1 if best is None else min(best, d1)
-            out["pcie_inclusive"] = {"value": npt / best, "unit": "grid-points/s",
-                                     "includes": "H2D of the point coordinates (page-locked staging), assemble+invert, predict with "
-                                                 "overlapped D2H of z and sigma^2, copy into the caller's arrays"}
-            out["checksum"] = {"z_sum": float(zz.sum()), "ss_sum": float(sss.sum())}
+            h.synchronize()
+            d1 = time.perf_counter() - t1
+            out["resident"] = {"value": npt_total * K / d1, "unit": "grid-points/s", "ms_per_step": d1 / K * 1e3,
+                               "what": "mik_factor + mik_predict per step on points resident in HBM, results left in page-locked memory"}
+            if n_gpus == 1:
+                # style='points': the same points handed over as host arrays (npt x d doubles over PCIe)
+                parts = shard_points(cfg, 0, 1)
+                best = None
+                for _ in range(2):
+                    t1 = time.perf_counter()
+                    zz, sss = model.execute("points", *parts, **exe_kw)
+                    d1 = time.perf_counter() - t1
+                    best = d1 if best is None else min(best, d1)
+                out["execute_points_style"] = {"value": npt_total / best, "unit": "grid-points/s",
+                                               "includes": "H2D of npt x d point coordinates (page-locked staging) on top of everything the "
+                                                           "grid call does"}
+                zg, ssg = (np.asarray(a).ravel() for a in res)
+                out["checksum"] = {"z_sum": float(zg.sum()), "ss_sum": float(ssg.sum()),
+                                   "grid_vs_points_max_abs_dz": float(np.abs(zg - zz).max()), "grid_vs_points_max_abs_dss": float(np.abs(ssg - sss).max())}
         if n_gpus == 1 and not args.no_cpu and not inner:
+            progress["stage"] = "cpu_baseline leg"
             try:
                 cb, (cp, cz, css) = cpu_baseline(cfg, coords, values, args.cpu_sample, window=kw, full=args.cpu_protocol == "full")
                 # parity of the GPU path on the very points the CPU baseline kriged
+                model._set_problem(h)
                 h.set_points(*[np.ascontiguousarray(cp[:, d]) for d in range(ndim)])
                 if kw:
                     h.predict_moving_window(kw)
                 else:
+                    h.factor()
                     h.predict()
                 gz, gss = h.get_results()
                 cb["gpu_vs_cpu_max_abs_dz"] = float(np.abs(gz - cz).max())
@@ -641,12 +696,13 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "grid-points/s", "cores": None, "kind": "port",
                                        "sample": "failed: %r" % (e,)}
         emit(json.dumps(out))
+    elif world > 1:
+        pg.all_gather_object({"rank": rank, "device": int(os.environ["MIK_DEVICE"]), "predict_ms": last.get("predict_ms")})
+    progress["done"] = True
     if pg is not None:
         pg.barrier()  # nobody tears its communicator down while another rank is still inside a collective
-    if leaked:  # a handle was abandoned behind a stuck collective: skip every destructor
-        sys.stdout.flush()
-        sys.stderr.flush()
-        os._exit(0)
+    if executor is not None:
+        executor.close()
     h.close()
 
 

@@ -124,6 +124,10 @@ typedef struct mik_timing {
   double exchange_wait_ms;     /* of exchange_ms, the part a caller was blocked for (the rest overlapped the leader's prediction) */
   int32_t exchange_fallbacks;  /* exchange paths that failed or timed out before exchange_path succeeded (mik_exchange_note says why) */
   int32_t rccl_ranks;          /* communicators (= ranks = devices) the RCCL broadcast ran over; 0 if RCCL was not used */
+  int32_t mw_kernel;           /* mik_predict_moving_window: the per-point solver that ran (contract_ms is its time): 1 = k_mw_chol
+                                  (LDL^T in registers), 2 = k_mw_solve (Gauss-Jordan in registers), 3 = k_mw_solve_big (LU in HBM
+                                  scratch); 0 after mik_predict */
+  int32_t reserved2;
 } mik_timing;
 
 int  mik_device_count(void);

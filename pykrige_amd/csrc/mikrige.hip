@@ -2132,6 +2132,7 @@ static int one_predict(mik_handle* h) {
   h->tm.contract_flops_executed = 0.0;
   h->tm.symmetric = h->opt_sym;
   h->tm.engine = h->opt_engine;
+  h->tm.mw_kernel = 0;
   if (npt == 0) {
     h->have_results = true;
     return MIK_OK;
@@ -2484,6 +2485,7 @@ static int one_predict_mw(mik_handle* h, int n_closest) {
     h->tm.contract_ms += ms;
   }
   h->tm.contract_launches = solve_chunks;
+  h->tm.mw_kernel = chol ? 1 : (big ? 3 : 2);
   h->tm.rhs_ms = h->tm.predict_ms - h->tm.contract_ms;  // neighbour search + right-hand sides
   if ((flag & 2) && !mw_piv) {  // a local system was not positive definite after the shift: redo with partial pivoting
     h->mw_force_piv = true;

@@ -59,9 +59,18 @@ def test_device_grid_points_equal_the_host_meshgrid(case):
         want = _host_points(axes, center, sc, an)
     got = h.get_points(nd)
     assert got.shape == want.shape
-    ulp = np.abs(got - want) / np.spacing(np.maximum(np.abs(want), 1e-300))
-    print("device grid vs host meshgrid (%s): %d of %d coordinates differ, worst %.1f ulp" % (case, int((got != want).sum()), got.size, float(ulp.max())))
-    assert ulp.max() <= 2.0  # measured: 0 (the dot products are accumulated like NumPy's BLAS kernel does)
+    # differences in units of the last place of the coordinate SCALE (entries near zero come out of a cancellation: their own
+    # ulp is meaningless).  The device accumulates each dot product k-ascending with FMAs; whether that reproduces np.dot bit
+    # for bit depends on the host's BLAS kernel (it does in the build container, it does not on the GPU box's EPYC host: 14 % of
+    # the rotated coordinates differ by one rounding) -- either way the difference is ~1e-15 of the extent, against the 1e-10
+    # of the coincidence rule (ok.py:665).
+    scale = np.spacing(np.abs(want).max(axis=0))[None, :]
+    ulp = np.abs(got - want) / scale
+    print("device grid vs host meshgrid (%s): %d of %d coordinates differ, worst %.2f ulp of the coordinate scale (%.1e absolute)"
+          % (case, int((got != want).sum()), got.size, float(ulp.max()), float(np.abs(got - want).max())))
+    assert ulp.max() <= 2.0
+    if case in ("2d_iso", "3d_iso", "geographic"):
+        assert np.array_equal(got, want)  # no rotation: (x - c) + c has one way to round
     # a mask compacts the sequence; a cell range takes a slab of it
     mask = rng.random(want.shape[0]) < 0.35
     if case != "geographic":
