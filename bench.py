@@ -479,6 +479,26 @@ def main():
                 trial[name + "_error"] = repr(e)[:300]
         h.set_option("exchange", EXCHANGE_CODES[args.exchange])
         h.set_option("async_exchange", 1)
+        # Should the leader krige its slab WHILE an RCCL broadcast is in flight?  The broadcast's root needs compute units that the
+        # leader's persistent contraction launch holds, so the library's default (1) joins an RCCL exchange first and overlaps only
+        # copy-engine transfers; 2 overlaps any.  Measured here on the hardware at hand, outside the timed region; the faster one runs.
+        progress["stage"] = "overlap trial of the device group"
+        try:
+            model.execute("grid", *axes, **exe_kw)
+            if model.last_timing["exchange_path"] == 1:
+                ov = {}
+                for mode in (1, 2):
+                    h.set_option("async_exchange", mode)
+                    model.execute("grid", *axes, **exe_kw)
+                    t0 = time.perf_counter()
+                    model.execute("grid", *axes, **exe_kw)
+                    ov[mode] = (time.perf_counter() - t0) * 1e3
+                pick = min(ov, key=ov.get)
+                h.set_option("async_exchange", pick)
+                trial["execute_ms_leader_waits_for_rccl"], trial["execute_ms_leader_overlaps_rccl"] = ov[1], ov[2]
+                trial["async_exchange_used"] = pick
+        except Exception as e:  # noqa: BLE001
+            trial["overlap_trial_error"] = repr(e)[:300]
     elif world > 1:
         progress["stage"] = "process group / RCCL set-up of the ranks"
         from pykrige_amd.dist import ShardedExecutor

@@ -180,8 +180,11 @@ int  mik_slab_of(int64_t n, int members, int i, int64_t *lo, int64_t *count); /*
  * "exchange" 0..3 = how a device group distributes the inverted matrix: 0 auto (RCCL broadcast, peer copies if RCCL is
  *   unavailable), 1 RCCL broadcast, 2 peer copies (scatter + all-gather over xGMI), 3 none (every device factors) [MIK_EXCHANGE] ;
  * "alias_devices" 0/1 = a device group may place several members on one physical GPU (1-GPU test boxes) [MIK_ALIAS_DEVICES] ;
- * "async_exchange" 0/1 = device groups: mik_factor returns once the leader has factored, the exchange is joined by the next
- *   call and overlaps the leader's prediction (default 1) [MIK_ASYNC_EXCHANGE] ;
+ * "async_exchange" 0/1/2 = device groups with exchange = auto: 0 = mik_factor blocks until every member holds the inverse; 1
+ *   (default) = it returns once the leader has factored, the exchange is joined by the next call, and mik_predict lets the leader
+ *   krige its slab during a copy-engine transfer (peer copies) but joins an RCCL broadcast first (its root needs compute units
+ *   the leader's persistent contraction launch would hold for 47 - 480 ms); 2 = the leader's prediction overlaps any exchange
+ *   [MIK_ASYNC_EXCHANGE].  A forced exchange path always completes (or fails) inside mik_factor ;
  * "rccl_init_timeout", "rccl_bcast_timeout", "peer_timeout" = the bounded waits of the factor exchange, seconds (see
  *   "Bounded waits" below) [MIK_RCCL_INIT_TIMEOUT, MIK_RCCL_BCAST_TIMEOUT, MIK_PEER_TIMEOUT] */
 int  mik_set_option(mik_handle *h, const char *key, double value);
@@ -253,8 +256,7 @@ int  mik_factor_checksum(mik_handle *h, uint64_t out[4]); /* order-independent c
  *   - a forced path ("exchange" 1 / 2), mik_comm_init and mik_bcast_factor return MIK_ERCCL / MIK_EHIP.
  * Every exchange of a device group is verified: each member checksums its copy of the inverse on its device against the
  * leader's; a mismatch counts as a failed exchange.  With "async_exchange" 1 (default; MIK_ASYNC_EXCHANGE) mik_factor
- * returns when the leader has factored; the exchange is joined by the next call on the handle, and mik_predict lets the
- * leader krige its slab while the transfer is in flight. */
+ * returns when the leader has factored; the exchange is joined by the next call on the handle (see the option). */
 const char *mik_exchange_note(mik_handle *h);   /* why exchange paths of the last mik_factor were given up ("" if none were) */
 int  mik_selftest_exchange(int members, double init_limit_s, double bcast_limit_s, char *report, int report_len);
                                                 /* the RCCL path of the group exchange with stand-in members and NO HIP

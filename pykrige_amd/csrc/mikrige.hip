@@ -563,7 +563,7 @@ static int create_one_body(mik_handle* h, int device) {
   env = getenv("MIK_EARLY_DIAG");
   if (env) h->opt_early_diag = atoi(env) < 0 ? -1 : atoi(env);
   env = getenv("MIK_ASYNC_EXCHANGE");
-  if (env) h->opt_async_exchange = atoi(env) ? 1 : 0;
+  if (env && atoi(env) >= 0 && atoi(env) <= 2) h->opt_async_exchange = atoi(env);
   h->rccl_init_limit = env_seconds("MIK_RCCL_INIT_TIMEOUT", 120.0);
   h->rccl_bcast_limit = env_seconds("MIK_RCCL_BCAST_TIMEOUT", 30.0);
   h->peer_limit = env_seconds("MIK_PEER_TIMEOUT", 30.0);
@@ -729,7 +729,8 @@ int mik_set_option(mik_handle* h, const char* key, double value) {
   MIKC(join_exchange(h));
   for (mik_handle* k : h->kids) MIKC(mik_set_option(k, key, value));
   if (!strcmp(key, "async_exchange")) {
-    h->opt_async_exchange = value != 0.0;
+    if (value != 0.0 && value != 1.0 && value != 2.0) return fail(MIK_EINVAL, "async_exchange must be 0, 1 or 2");
+    h->opt_async_exchange = (int)value;
   } else if (!strcmp(key, "rccl_init_timeout") || !strcmp(key, "rccl_bcast_timeout") || !strcmp(key, "peer_timeout")) {
     if (!(value > 0.0)) return fail(MIK_EINVAL, "a timeout must be a positive number of seconds");
     (key[0] == 'p' ? h->peer_limit : key[5] == 'i' ? h->rccl_init_limit : h->rccl_bcast_limit) = value;
@@ -1473,6 +1474,7 @@ struct XchgJob {
   std::vector<std::vector<hipStream_t>> xstreams;  // peer path: xstreams[i][k] = stream on device i for the copy to device k
   std::vector<hipEvent_t> xevents;
   std::vector<unsigned long long> sums;            // 4 words per member, host side
+  unsigned long long leader_sums[4] = {0, 0, 0, 0};  // computed by mik_factor before the exchange starts
   int rccl_ranks = 0;
 };
 
@@ -1507,7 +1509,8 @@ static int group_comms(const std::vector<int>& devs, std::vector<ncclComm_t>** o
 static int xchg_verify(XchgJob* j) {
   const size_t Mp = j->Mp, n = j->mem.size();
   j->sums.assign(4 * n, 0ull);
-  for (size_t i = 0; i < n; ++i) {
+  for (int w = 0; w < 4; ++w) j->sums[w] = j->leader_sums[w];
+  for (size_t i = 1; i < n; ++i) {
     const XchgMember& d = j->mem[i];
     HIPC(hipSetDevice(d.device));
     HIPC(hipMemsetAsync(d.sum_dev, 0, 4 * sizeof(unsigned long long), d.xs));
@@ -1516,9 +1519,13 @@ static int xchg_verify(XchgJob* j) {
     HIPC(hipGetLastError());
     HIPC(hipMemcpyAsync(j->sums.data() + 4 * i, d.sum_dev, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, d.xs));
   }
-  for (size_t i = 0; i < n; ++i) {
+  for (size_t i = 1; i < n; ++i) {
     HIPC(hipSetDevice(j->mem[i].device));
     HIPC(hipStreamSynchronize(j->mem[i].xs));
+  }
+  if (j->path == 1) {  // the root's part of the broadcast runs on the leader's exchange stream
+    HIPC(hipSetDevice(j->mem[0].device));
+    HIPC(hipStreamSynchronize(j->mem[0].xs));
   }
   for (size_t i = 1; i < n; ++i)
     for (int w = 0; w < 4; ++w)
@@ -1709,6 +1716,18 @@ static int start_exchange(mik_handle* h, int path) {
     j->xevents = h->xevents;
     j->phase.store(1);
   }
+  {
+    // the leader's checksums NOW, on its compute stream (0.1 ms): once its prediction runs, a small kernel on another stream
+    // of that device would queue behind a persistent contraction launch (47 - 480 ms) and hold the whole exchange up
+    unsigned long long* sd = h->xsum.as<unsigned long long>();
+    HIPC(hipSetDevice(h->device));
+    HIPC(hipMemsetAsync(sd, 0, 4 * sizeof(unsigned long long), h->stream));
+    hipLaunchKernelGGL(k_checksum, dim3(1024), dim3(256), 0, h->stream, (const unsigned long long*)h->T.p, j->Mp * j->Mp, sd);
+    hipLaunchKernelGGL(k_checksum, dim3(4), dim3(256), 0, h->stream, (const unsigned long long*)h->cvec.p, j->Mp, sd + 2);
+    HIPC(hipGetLastError());
+    HIPC(hipMemcpyAsync(j->leader_sums, sd, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+    HIPC(hipStreamSynchronize(h->stream));
+  }
   j->t_start = j->t_phase1 = std::chrono::steady_clock::now();
   h->xjob = j;
   std::thread(xchg_worker, j).detach();
@@ -1850,7 +1869,8 @@ int mik_factor(mik_handle* h) {
     path = 2;
   }
   MIKC(start_exchange(h, path));
-  if (!h->opt_async_exchange) return join_exchange(h);
+  // a forced path reports its failure HERE; auto cannot fail short of every path failing and may finish behind the caller's back
+  if (!h->opt_async_exchange || h->opt_exchange != 0) return join_exchange(h);
   return MIK_OK;
 }
 
@@ -2254,9 +2274,14 @@ static int one_predict(mik_handle* h) {
 
 int mik_predict(mik_handle* h) {
   if (!h) return fail(MIK_ESTATE, "mik_predict: NULL handle");
+  // The exchange mik_factor started may still be in flight.  A transfer only reads the leader's matrix, so the leader can
+  // krige its slab while it runs -- but only a COPY-ENGINE transfer (peer copies) is overlapped by default: an RCCL
+  // broadcast needs compute units on the root, and once the leader's persistent contraction launch (all VGPRs of every
+  // SIMD for 47 - 480 ms) is resident the root's part would queue behind it and every member would wait for that.
+  // "async_exchange" 2 overlaps any path (for A/B runs on a real node: bench.py's overlap trial).
+  if (h->xjob && !(h->xjob->path == 2 || h->opt_async_exchange == 2)) MIKC(join_exchange(h));
   if (h->kids.empty() || !h->xjob) return for_each_device(h, [](int, mik_handle* d) { return one_predict(d); });
-  // The exchange mik_factor started is still in flight: the leader kriges its slab NOW (a transfer only reads its matrix),
-  // the members start as soon as their copies have arrived and been verified.
+  // the leader kriges its slab NOW, the members start as soon as their copies have arrived and been verified
   int lrc = MIK_OK;
   std::string lerr;
   std::thread leader([&] {
