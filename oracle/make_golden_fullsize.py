@@ -34,6 +34,10 @@ CASES = {
     "c4": dict(ndim=2, seed=4, n=4000, grid=(1024, 1024), model="exponential", params=[1.0, 0.3, 0.01], rows=(300, 316),
                rl=True, wells=WELLS),
     "c5": dict(ndim=2, seed=5, n=8000, grid=(4096, 4096), model="spherical", params=[1.0, 0.2, 0.01], rows=(2048, 2052)),
+    # round 3: the fourth class at full size -- UniversalKriging3D (uk3d.py:739-811), regional_linear + one functional drift
+    # (f(x, y, z) = x z on ADJUSTED coordinates, tests/_fixtures.py FUNCS["uk3d"]), anisotropic, N = 2000
+    "uk3d": dict(ndim=3, seed=7, n=2000, grid=(200, 200, 50), model="exponential", params=[1.0, 0.5, 0.02], rows=(40, 122),
+                 zrows=(30, 31), uk3d=True, scaling=(1.5, 0.7), angle=(10.0, 20.0, 30.0)),
 }
 
 
@@ -46,6 +50,7 @@ def main():
     from pykrige.ok import OrdinaryKriging
     from pykrige.ok3d import OrdinaryKriging3D
     from pykrige.uk import UniversalKriging
+    from pykrige.uk3d import UniversalKriging3D
 
     os.makedirs(OUT, exist_ok=True)
     for name, c in CASES.items():
@@ -66,7 +71,16 @@ def main():
         for cc, ax, ii in zip(coords, slab, idx):
             cc[:8] = ax[ii]
         extra = {}
-        if ndim == 3:
+        if c.get("uk3d"):
+            sc, an = c["scaling"], c["angle"]
+            k = UniversalKriging3D(coords[0], coords[1], coords[2], v, variogram_model=c["model"],
+                                   variogram_parameters=list(c["params"]), drift_terms=["regional_linear", "functional"],
+                                   functional_drift=[lambda a, b, cc: a * cc], anisotropy_scaling_y=sc[0], anisotropy_scaling_z=sc[1],
+                                   anisotropy_angle_x=an[0], anisotropy_angle_y=an[1], anisotropy_angle_z=an[2])
+            A = k._get_kriging_matrix(c["n"], c["n"] + 4)
+            z, ss = k.execute("grid", slab[0], slab[1], slab[2], backend="vectorized")
+            extra = dict(regional_linear=True, scaling=np.array(sc), angle=np.array(an))
+        elif ndim == 3:
             k = OrdinaryKriging3D(coords[0], coords[1], coords[2], v, variogram_model=c["model"],
                                   variogram_parameters=list(c["params"]))
             A = k._get_kriging_matrix(c["n"])

@@ -1644,6 +1644,28 @@ __global__ void __launch_bounds__(256) k_matvec(const double* __restrict__ A, lo
   if (lane == 0) y[row] = s;
 }
 
+// three matrix-vector products in one pass over the matrix (the probe columns of verify_inverse)
+__global__ void __launch_bounds__(256) k_matvec3(const double* __restrict__ A, long ld, int m, const double* __restrict__ x0,
+                                                 const double* __restrict__ x1, const double* __restrict__ x2, double* __restrict__ y0,
+                                                 double* __restrict__ y1, double* __restrict__ y2) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= m) return;
+  const double* r = A + (long)row * ld;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  for (int b = lane; b < m; b += 64) {
+    const double a = r[b];
+    s0 += a * x0[b];
+    s1 += a * x1[b];
+    s2 += a * x2[b];
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    s0 += __shfl_xor(s0, o);
+    s1 += __shfl_xor(s1, o);
+    s2 += __shfl_xor(s2, o);
+  }
+  if (lane == 0) y0[row] = s0, y1[row] = s1, y2[row] = s2;
+}
+
 __global__ void __launch_bounds__(256) k_set_identity(double* __restrict__ W, long ld, int n) {
   const long e = (long)blockIdx.x * 256 + threadIdx.x;
   if (e >= (long)n * ld) return;

@@ -197,12 +197,23 @@ struct mik_handle {
   hipStream_t stream2 = nullptr;            // the look-ahead branch (next panel) runs here
   std::vector<hipEvent_t> la_events;
   int opt_lookahead = -1;  // -1 = where it pays (>= 24 block columns), 0 = off, 1 = on
-  // unpivoted sweep maintaining only the upper block triangle (half the update tiles: -9 % at N=5000, -30 % at N=8000).
-  // OFF by default: the two triangles of the in-place inverse carry different rounding histories, and z / sigma^2 formed
-  // from a mirrored triangle lose the small residual of the full sweep on ill-conditioned systems (power variogram with
-  // drift terms, cond 3e5: |dz| 3e-9 -> 8e-7).  Fine for well-conditioned problems; opt in with the option.
-  int opt_symsweep = -1;  // -1 = auto (see run_block_inverse), 0 = off, 1 = on
+  // unpivoted sweep maintaining only the upper block triangle (half the update tiles: -9 % at N=5000, -30 % at N=8000).  The two
+  // triangles of the in-place inverse carry different rounding histories, and z / sigma^2 formed from a mirrored triangle
+  // lose the small residual of the full sweep on ill-conditioned systems (power variogram with drift terms, cond 3e5: |dz|
+  // 3e-9 -> 8e-7).  AUTO (default): on for exponential / spherical models from 24 block columns on (where it pays and where
+  // its measured error stays three orders inside the bar) AND only as long as the probe of the result passes
+  // (verify_inverse) -- an ill-conditioned set-up of those models falls back to the full sweep by itself.
+  int opt_symsweep = -1;  // -1 = auto, 0 = off, 1 = on
   int opt_pinv_fast = 1;   // pseudo_inv: try the deflated regular inverse (duplicated stations) before the Jacobi pseudo-inverse
+  // every inverse the device computes is PROBED before it is used (verify_inverse): A c against the data vector (bounds the
+  // error of z) and X A e_j against e_j for three station columns (the sigma^2 side).  A failed probe sends the factorisation
+  // to the next more careful path: half sweep -> full sweep -> partial pivoting.
+  int opt_verify = 1;
+  double verify_tol_z = 2e-10, verify_tol_inv = 2e-9;
+  bool no_half_sweep = false;  // transient: this attempt must not use the half sweep
+  bool last_half_sweep = false;
+  DevBuf Averify, vbuf;
+  std::vector<double> hvals;   // host copy of the station values (the probe compares A c with them)
   int opt_fuse_chain = 1;  // look-ahead sweep: the column update writes the next panel copy too (no copy kernel on the chain)
   int opt_early_diag = -1; // look-ahead sweep: the next diagonal block is built and inverted ahead of the panel / update stream (-1 = with the look-ahead)
   int opt_gate = -1;       // look-ahead sweep: the trailing update waits until the next diagonal inverse has started and leaves
@@ -602,7 +613,7 @@ static void destroy_one(mik_handle* h) {
                     &h->Rt, &h->TKt, &h->Dinv, &h->DinvT, &h->P0, &h->P1, &h->cand0, &h->cand1, &h->pivall, &h->flag,
                     &h->Cold2, &h->Cnew2, &h->Rt2, &h->Dinv2, &h->DinvT2, &h->Dnext, &h->Dcopy, &h->Cb, &h->Rb, &h->grid.gx, &h->grid.gy, &h->grid.gz, &h->grid.orig,
                     &h->grid.cstart,
-                    &h->px, &h->py, &h->pz, &h->grid_axes, &h->grid_idx, &h->extra_rows, &h->z, &h->ss, &h->Bt, &h->part, &h->mw_idx, &h->mw_dist, &h->stat_S, &h->stat_x, &h->stat_out, &h->queue};
+                    &h->px, &h->py, &h->pz, &h->grid_axes, &h->grid_idx, &h->Averify, &h->vbuf, &h->extra_rows, &h->z, &h->ss, &h->Bt, &h->part, &h->mw_idx, &h->mw_dist, &h->stat_S, &h->stat_x, &h->stat_out, &h->queue};
   for (DevBuf* b : bufs) b->release();
   h->pin_in.release();
   h->pin_out.release();
@@ -665,7 +676,7 @@ static int set_group(mik_handle* h, int n) {
     }
     k->is_kid = true;
     k->opt_factor = h->opt_factor, k->opt_sym = h->opt_sym, k->opt_engine = h->opt_engine, k->opt_waves = h->opt_waves;
-    k->opt_chunk = h->opt_chunk, k->opt_symsweep = h->opt_symsweep, k->opt_diag = h->opt_diag, k->opt_lookahead = h->opt_lookahead, k->opt_gate = h->opt_gate, k->opt_fuse_chain = h->opt_fuse_chain, k->opt_early_diag = h->opt_early_diag, k->opt_pinv_fast = h->opt_pinv_fast;
+    k->opt_chunk = h->opt_chunk, k->opt_symsweep = h->opt_symsweep, k->opt_diag = h->opt_diag, k->opt_lookahead = h->opt_lookahead, k->opt_gate = h->opt_gate, k->opt_fuse_chain = h->opt_fuse_chain, k->opt_early_diag = h->opt_early_diag, k->opt_pinv_fast = h->opt_pinv_fast, k->opt_verify = h->opt_verify, k->verify_tol_z = h->verify_tol_z, k->verify_tol_inv = h->verify_tol_inv;
     k->opt_mw_pivot = h->opt_mw_pivot, k->opt_mw_lds_cap = h->opt_mw_lds_cap, k->opt_pairs = h->opt_pairs, k->opt_mw_solver = h->opt_mw_solver;
     k->custom_fn = h->custom_fn, k->custom_user = h->custom_user;
     h->kids.push_back(k);
@@ -757,6 +768,11 @@ int mik_set_option(mik_handle* h, const char* key, double value) {
     h->opt_chunk = ((long)value / 128) * 128;
   } else if (!strcmp(key, "symsweep")) {
     h->opt_symsweep = value < 0.0 ? -1 : (value != 0.0);
+  } else if (!strcmp(key, "verify")) {
+    h->opt_verify = value != 0.0;
+  } else if (!strcmp(key, "verify_tol_z") || !strcmp(key, "verify_tol_inv")) {
+    if (!(value > 0.0)) return fail(MIK_EINVAL, "a tolerance must be positive");
+    (key[11] == 'z' ? h->verify_tol_z : h->verify_tol_inv) = value;
   } else if (!strcmp(key, "pinv_fast")) {
     h->opt_pinv_fast = value != 0.0;
   } else if (!strcmp(key, "fuse_chain")) {
@@ -832,6 +848,7 @@ static int one_set_problem(mik_handle* h, const mik_problem* p) {
   MIKC(h->xs.ensure(nb));
   MIKC(h->ys.ensure(nb));
   MIKC(h->vals.ensure(nb));
+  h->hvals.assign(p->values, p->values + h->N);
   h->hxs.assign(p->xs, p->xs + h->N);
   h->hys.assign(p->ys, p->ys + h->N);
   if (p->ndim == 3) h->hzs.assign(p->zs, p->zs + h->N);
@@ -995,7 +1012,8 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
   // half sweep (upper block triangle only): on request, or by itself for the two variograms whose measured error stays three
   // orders inside the 1e-8 / 1e-6 bar (exponential, spherical: profiles/r02_sweep_vs_pivoted_vs_half_sweep_accuracy.txt and the
   // full-size fixtures) and from 24 block columns on, where it pays
-  const bool symsweep = !pivoted && (h->opt_symsweep > 0 || (h->opt_symsweep < 0 && (h->model == 3 || h->model == 4) && nblk >= 24));
+  const bool symsweep = !pivoted && (h->opt_symsweep > 0 || (h->opt_symsweep < 0 && !h->no_half_sweep && (h->model == 3 || h->model == 4) && nblk >= 24));
+  h->last_half_sweep = symsweep;
   const long ltiles = symsweep ? (long)nblk * (nblk + 1) / 2 : tiles;
   const unsigned ug = (unsigned)(8 * ((ltiles + 7) / 8));
 #define UPDX(GRID, STREAM, CO, CN, R, D, PART, COL, POUT, DCOPY)                                                             \
@@ -1272,9 +1290,9 @@ static int run_deflated_inverse(mik_handle* h, bool* done) {
   constexpr int NPROBE = 3;
   MIKC(vec.ensure(sizeof(double) * 4 * (size_t)h->Mp));
   double *dv = vec.as<double>(), *dy = dv + h->Mp, *dw = dy + h->Mp, *dr = dw + h->Mp;
-  std::vector<double> hv(M), hy(M), hw(M), hr(M);
+  std::vector<double> hv(M), hy(M), hw(M), hr(M), hx(M);
   unsigned long long seed = 0x9E3779B97F4A7C15ull;
-  double worst_res = 0.0, est_a = 0.0, est_x = 0.0;
+  double worst_res = 0.0, worst_res2 = 0.0, est_a = 0.0, est_x = 0.0;
   const unsigned mg = (unsigned)((M + 3) / 4);
   auto norm = [&](const std::vector<double>& a) {
     double s2 = 0.0;
@@ -1292,9 +1310,21 @@ static int run_deflated_inverse(mik_handle* h, bool* done) {
     hipLaunchKernelGGL(k_matvec, dim3(mg), dim3(256), 0, h->stream, (const double*)A2.as<double>(), ld, M, (const double*)dw, dr);  // r = A w
     HIPC(hipMemcpyAsync(hy.data(), dy, sizeof(double) * M, hipMemcpyDeviceToHost, h->stream));
     HIPC(hipMemcpyAsync(hr.data(), dr, sizeof(double) * M, hipMemcpyDeviceToHost, h->stream));
-    hipLaunchKernelGGL(k_matvec, dim3(mg), dim3(256), 0, h->stream, (const double*)h->T.as<double>(), ld, M, (const double*)dv, dw);  // X v
+    hipLaunchKernelGGL(k_matvec, dim3(mg), dim3(256), 0, h->stream, (const double*)h->T.as<double>(), ld, M, (const double*)dv, dw);  // u = X v
     HIPC(hipMemcpyAsync(hw.data(), dw, sizeof(double) * M, hipMemcpyDeviceToHost, h->stream));
+    // the second Penrose condition, X A X v = X v: it is what tells the Moore-Penrose inverse from the other generalised
+    // inverses pinv(A) + c P (P = the duplicated stations' projector, A P = 0), which all pass A X A v = A v
+    hipLaunchKernelGGL(k_matvec, dim3(mg), dim3(256), 0, h->stream, (const double*)A2.as<double>(), ld, M, (const double*)dw, dy);   // A u
+    hipLaunchKernelGGL(k_matvec, dim3(mg), dim3(256), 0, h->stream, (const double*)h->T.as<double>(), ld, M, (const double*)dy, dr);  // X A u
+    HIPC(hipMemcpyAsync(hx.data(), dr, sizeof(double) * M, hipMemcpyDeviceToHost, h->stream));
     HIPC(hipStreamSynchronize(h->stream));
+    {
+      double e2 = 0.0;
+      for (int i = 0; i < M; ++i) e2 += (hx[i] - hw[i]) * (hx[i] - hw[i]);
+      const double nu = norm(hw);
+      if (!(nu > 0.0) || !std::isfinite(nu)) return MIK_OK;
+      worst_res2 = std::max(worst_res2, std::sqrt(e2) / nu);
+    }
     const double nv = norm(hv), ny = norm(hy);
     double d2 = 0.0;
     for (int i = 0; i < M; ++i) d2 += (hr[i] - hy[i]) * (hr[i] - hy[i]);
@@ -1305,15 +1335,58 @@ static int run_deflated_inverse(mik_handle* h, bool* done) {
   }
   HIPC(hipGetLastError());
   const double eps = 2.220446049250313e-16;
-  if (!(worst_res <= 1e-8) || !(est_a * est_x <= 1e-3 / ((double)M * eps))) return MIK_OK;  // not provably the pseudo-inverse
+  if (!(worst_res <= 1e-8) || !(worst_res2 <= 1e-8) || !(est_a * est_x <= 1e-3 / ((double)M * eps))) return MIK_OK;  // not provably the pseudo-inverse
   *done = true;
   return MIK_OK;
 }
 
-static int finish_factor(mik_handle* h) {
+// Probe of the inverse X in T against the matrix itself (assembled again, unshifted, into a scratch buffer):
+//   res_z   = max |A c - [Z; 0]| / max(1, max|Z|)   with c = X[:, :N] Z: every z_g = c.b_g is w_g.(A c) with the kriging weights
+//             w_g of the point (sum 1, |w|_1 of order 1..10), so the error of z is bounded by |w_g|_1 res_z max|Z|;
+//   res_inv = max_j max |X A e_j - e_j|  for three station columns j (first, middle, last): A e_j is the right-hand side of a
+//             point ON station j, X A e_j its weight vector -- what sigma^2 is formed from.
+// Cost: one assembly, one product with A, one pass over X (0.25 ms at N = 5000).  cvec must be current.
+static int verify_inverse(mik_handle* h, double* res_z, double* res_inv) {
+  const int M = h->M, N = h->N, Mp = h->Mp;
+  const long ld = Mp;
+  MIKC(h->Averify.ensure(sizeof(double) * (size_t)Mp * Mp));
+  MIKC(h->vbuf.ensure(sizeof(double) * 4 * (size_t)Mp));
+  MIKC(launch_assemble(h, 0.0, h->Averify.as<double>()));
+  const double* A2 = h->Averify.as<double>();
+  double* y = h->vbuf.as<double>();
+  const unsigned mg = (unsigned)((M + 3) / 4);
+  const int cols[3] = {0, N / 2, N - 1};
+  hipLaunchKernelGGL(k_matvec, dim3(mg), dim3(256), 0, h->stream, A2, ld, M, (const double*)h->cvec.as<double>(), y);
+  hipLaunchKernelGGL(k_matvec3, dim3(mg), dim3(256), 0, h->stream, (const double*)h->T.as<double>(), ld, M, A2 + (long)cols[0] * ld,
+                     A2 + (long)cols[1] * ld, A2 + (long)cols[2] * ld, y + Mp, y + 2 * Mp, y + 3 * Mp);
+  HIPC(hipGetLastError());
+  std::vector<double> host(4 * (size_t)Mp);
+  HIPC(hipMemcpyAsync(host.data(), y, sizeof(double) * host.size(), hipMemcpyDeviceToHost, h->stream));
+  HIPC(hipStreamSynchronize(h->stream));
+  double zmax = 1.0, rz = 0.0, ri = 0.0;
+  for (int i = 0; i < N; ++i) zmax = std::max(zmax, std::fabs(h->hvals[i]));
+  for (int i = 0; i < M; ++i) {
+    const double d = std::fabs(host[i] - (i < N ? h->hvals[i] : 0.0));
+    rz = std::max(rz, std::isfinite(d) ? d : 1e300);
+    for (int k = 0; k < 3; ++k) {
+      const double e = std::fabs(host[(size_t)(k + 1) * Mp + i] - (i == cols[k] ? 1.0 : 0.0));
+      ri = std::max(ri, std::isfinite(e) ? e : 1e300);
+    }
+  }
+  *res_z = rz / zmax;
+  *res_inv = ri;
+  return MIK_OK;
+}
+
+static int launch_cvec(mik_handle* h) {
   hipLaunchKernelGGL(k_cvec, dim3((h->Mp + 3) / 4), dim3(256), 0, h->stream, (const double*)h->T.as<double>(),
                      (long)h->Mp, h->M, h->N, (const double*)h->vals.as<double>(), h->cvec.as<double>(), h->Mp);
   HIPC(hipGetLastError());
+  return MIK_OK;
+}
+
+static int finish_factor(mik_handle* h) {
+  MIKC(launch_cvec(h));
   HIPC(hipStreamSynchronize(h->stream));
   h->have_factor = true;
   h->t_state = 2;
@@ -1382,9 +1455,14 @@ static int one_factor(mik_handle* h) {
   // positive definite, e.g. hole-effect in 2-D) sends the attempt to the pivoted path below.
   bool try_sweep = h->opt_factor == 1 || h->opt_factor == 0;
   if (h->model == MIK_MODEL_CUSTOM) try_sweep = false;  // no sill to shift by: pivoted elimination
-  for (int attempt = 0; attempt < 2; ++attempt) {
+  h->no_half_sweep = false;
+  h->tm.factor_attempts = 0;
+  h->tm.verify_ms = h->tm.verify_res_z = h->tm.verify_res_inv = 0.0;
+  MIKC(get_events(h, 6));
+  for (int attempt = 0; attempt < 3; ++attempt) {
     const bool pivoted = !try_sweep;
     const double shift = pivoted ? 0.0 : h->shift_guess;
+    ++h->tm.factor_attempts;
     HIPC(hipEventRecord(h->evpool[0], h->stream));
     MIKC(launch_assemble(h, shift));
     HIPC(hipEventRecord(h->evpool[1], h->stream));
@@ -1399,12 +1477,38 @@ static int one_factor(mik_handle* h) {
     HIPC(hipEventElapsedTime(&ms, h->evpool[1], h->evpool[2]));
     h->tm.invert_ms += ms;
     h->tm.factor_path = pivoted ? 2 : 1;
-    if (flag == 0) return finish_factor(h);
-    if (!pivoted && h->opt_factor == 0) {  // shifted matrix not positive definite: redo with pivoting
+    h->tm.half_sweep = h->last_half_sweep ? 1 : 0;
+    if (flag != 0) {
+      if (!pivoted && h->opt_factor == 0) {  // shifted matrix not positive definite: redo with pivoting
+        try_sweep = false;
+        continue;
+      }
+      return fail(MIK_ESINGULAR, pivoted ? "singular matrix" : "singular matrix (unpivoted sweep hit a bad pivot; use factor=auto or pivoted)");
+    }
+    if (!h->opt_verify || h->model == MIK_MODEL_CUSTOM) return finish_factor(h);
+    // the probe (verify_inverse): a half sweep the library chose by itself that fails it is redone as a full sweep, a full
+    // sweep of factor = auto that fails it by partial pivoting; what the caller forced is only reported
+    HIPC(hipEventRecord(h->evpool[4], h->stream));
+    MIKC(launch_cvec(h));
+    double rz = 0.0, ri = 0.0;
+    MIKC(verify_inverse(h, &rz, &ri));
+    HIPC(hipEventRecord(h->evpool[5], h->stream));
+    HIPC(hipStreamSynchronize(h->stream));
+    HIPC(hipEventElapsedTime(&ms, h->evpool[4], h->evpool[5]));
+    h->tm.verify_ms += ms;
+    h->tm.verify_res_z = rz;
+    h->tm.verify_res_inv = ri;
+    const bool good = rz <= h->verify_tol_z && ri <= h->verify_tol_inv;
+    if (good || pivoted) return finish_factor(h);
+    if (h->last_half_sweep && h->opt_symsweep < 0) {
+      h->no_half_sweep = true;
+      continue;
+    }
+    if (h->opt_factor == 0) {
       try_sweep = false;
       continue;
     }
-    return fail(MIK_ESINGULAR, pivoted ? "singular matrix" : "singular matrix (unpivoted sweep hit a bad pivot; use factor=auto or pivoted)");
+    return finish_factor(h);
   }
   return fail(MIK_ESINGULAR, "singular matrix");
 }

@@ -192,14 +192,15 @@ class _KrigingBase:
     def _regional_linear(self):
         return False
 
-    def _set_problem(self, h, with_drift=True, values=None, pseudo_inv=False):
+    def _set_problem(self, h, with_drift=True, values=None, pseudo_inv=False, exact_values=None, eps=None):
         """H2D of the stations / drift description."""
         self._factor_key = None  # whatever the handle held is replaced
         ca = self._coords_adj
         kw = dict(
             ndim=self._ndim, xs=ca[:, 0], ys=ca[:, 1], zs=ca[:, 2] if self._ndim == 3 else None,
             values=self._values() if values is None else values, model_id=_lib.MODEL_IDS[self.variogram_model],
-            params=self.variogram_model_parameters, eps=self.eps, exact_values=self.exact_values,
+            params=self.variogram_model_parameters, eps=self.eps if eps is None else eps,
+            exact_values=self.exact_values if exact_values is None else exact_values,
             regional_linear=self._regional_linear() if with_drift else False,
             wells=self._wells() if with_drift else None,
             extra_cols=self._station_extra_cols() if with_drift else None,
@@ -287,21 +288,32 @@ class _KrigingBase:
         y = self._values()
         if self.pseudo_inv:
             # core.py:749-750: lstsq per growing subset (duplicated stations); no recursion exists for singular leading
-            # systems, so each station is kriged through the device pseudo-inverse (core._statistics_pseudo_inv)
+            # systems, so each station is kriged through the device pseudo-inverse (core._statistics_pseudo_inv).
+            # N - 1 small factorisations: on ONE device (a device group would exchange every one of them), and with the
+            # rule core._krige applies whatever the object's exact_values says -- b is zeroed at the coincident station with
+            # the fixed tolerance 1e-10 (core.py:728-745).
             full = self._coords_adj
+            if h.n_devices > 1:
+                h = _lib.Handle(h.device)
+                h.set_devices(1)
 
             def subset(i):
                 self._coords_adj = full[:i]
                 try:
-                    self._set_problem(h, with_drift=False, values=y[:i], pseudo_inv=True)
+                    self._set_problem(h, with_drift=False, values=y[:i], pseudo_inv=True, exact_values=True, eps=1e-10)
                 finally:
                     self._coords_adj = full
 
             par = self.variogram_model_parameters
             gamma = ((lambda d: self.variogram_function(par, d)) if self.variogram_model == "custom"
                      else (lambda d: core.variogram_value(self.variogram_model, par, d)))
-            k, ss = core._statistics_pseudo_inv(h, subset, full, y, gamma,
-                                                getattr(self, "coordinates_type", "euclidean") == "geographic")
+            try:
+                k, ss = core._statistics_pseudo_inv(h, subset, full, y, gamma,
+                                                    getattr(self, "coordinates_type", "euclidean") == "geographic")
+            finally:
+                if h is not self._get_handle():
+                    h.close()
+                self._factor_key = None
         else:
             self._set_problem(h, with_drift=False)
             k, ss = h.statistics(y.size)

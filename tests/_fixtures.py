@@ -12,6 +12,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 FUNCS = {
     "uk2d_spec_func": [lambda a, b: a * b, lambda a, b: a**2],
     "uk3d_rl_func": [lambda a, b, c: a * c],
+    "uk3d": [lambda a, b, c: a * c],  # tests/golden/fullsize/uk3d.npz
 }
 
 

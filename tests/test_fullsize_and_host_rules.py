@@ -1,6 +1,7 @@
 """Round-2 parity additions.
 
-* tests/golden/fullsize/c{2,3,4,5}.npz -- BASELINE configs 2-5 at their real station counts: one row slab of >= 16 384
+* tests/golden/fullsize/c{2,3,4,5}.npz (+ uk3d.npz, round 3: UniversalKriging3D, N = 2000, regional_linear + functional drift,
+  anisotropic) -- BASELINE configs 2-5 at their real station counts: one row slab of >= 16 384
   points of each config's own grid + 8 exact-hit nodes, kriged by the REAL reference's backend='vectorized' (config 2 also
   backend='C') -- oracle/make_golden_fullsize.py.  CPU: the oracle is pinned on a sub-sample; GPU: the HIP path on the whole
   slab at |dz| <= 1e-8, |dsigma^2| <= 1e-6, with cond_1(A) printed.
@@ -18,7 +19,7 @@ from tests import _fixtures as fx
 
 Z_TOL, SS_TOL = 1e-8, 1e-6
 FULL = os.path.join(fx.GOLDEN, "fullsize")
-CASES = ("c2", "c3", "c4", "c5")
+CASES = ("c2", "c3", "c4", "c5", "uk3d")
 
 
 def _full(name):
@@ -44,7 +45,7 @@ def _node_points(g):
 def test_oracle_matches_the_reference_at_full_station_count(name):
     g = _full(name)
     st = fx.state_from(name, g)
-    assert st.n == {"c2": 5000, "c3": 2000, "c4": 4000, "c5": 8000}[name]
+    assert st.n == {"c2": 5000, "c3": 2000, "c4": 4000, "c5": 8000, "uk3d": 2000}[name]
     assert g["z"].size >= 16384
     nodes = _node_points(g)
     sel = np.unique(np.concatenate([nodes, np.arange(0, g["z"].size, 37)[:600]]))
