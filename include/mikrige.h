@@ -175,7 +175,7 @@ int  mik_slab_of(int64_t n, int members, int i, int64_t *lo, int64_t *count); /*
  * "pinv_fast" 0/1 = pseudo_inv: try the deflated regular inverse before the Jacobi pseudo-inverse (default 1) ;
  * "verify" 0/1 = probe every inverse the device computes against the matrix itself before it is used (default 1):
  *   res_z = max |A c - [Z; 0]| / max(1, max|Z|) with c = A_inv[:, :n] Z (bounds the error of z: z_g = w_g . (A c)) and
- *   res_inv = max |A_inv A e_j - e_j| over three station columns.  "verify_tol_z" (default 2e-10) / "verify_tol_inv" (2e-9):
+ *   res_inv = max |A_inv A e_j - e_j| over three station columns.  "verify_tol_z" (default 5e-10) / "verify_tol_inv" (1e-8):
  *   a half sweep the library chose by itself that exceeds them is redone as a full sweep, a sweep of factor = auto that
  *   exceeds them by partial pivoting; mik_timing has the residuals, the attempts and the time (0.25 ms at N = 5000) ;
  * "gate" 0/1/-1 = look-ahead sweep: the trailing update of a step starts only once the next diagonal inverse sits on a CU of its

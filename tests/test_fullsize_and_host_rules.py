@@ -282,3 +282,39 @@ def test_hip_masked_points_outside_the_external_drift_grid():
     zin, sin_ = uk.execute("grid", gx[:6], gy, backend="loop")
     assert np.array_equal(np.ma.getdata(z)[:, :6], zin) and np.array_equal(np.ma.getdata(ss)[:, :6], sin_)
     assert np.all(np.ma.getdata(z)[:, 6:] == 0.0) and z.mask[:, 6:].all()
+
+
+# ------------------------------------------------------------------------------------------- GPU: the probe of the inverse
+@pytest.mark.gpu
+def test_ill_conditioned_inverse_is_caught_by_the_probe():
+    """mik_factor probes every inverse it computes (include/mikrige.h, option "verify"): A c against the data vector, X A e_j
+    against e_j.  A benign exponential model at N = 3200 keeps the half sweep the library chose (one attempt); the same
+    stations with a range of 30 domain sizes (cond ~ 1e11) fail the probe twice -- half sweep, full sweep -- and end on
+    partial pivoting, which is what LAPACK does for the reference (scipy.linalg.inv, ok.py:663)."""
+    import pykrige_amd as pa
+
+    rng = np.random.default_rng(100)
+    n = 3200
+    x, y = rng.random(n), rng.random(n)
+    v = np.sin(6 * x) * np.cos(4 * y) + 0.1 * rng.standard_normal(n)
+    gx, gy = np.linspace(0, 1, 23), np.linspace(0, 1, 19)
+    for rng_par, want_attempts, want_path, want_half in ((0.3, 1, 1, 1), (30.0, 3, 2, 0)):
+        st = ko.KrigingState(ndim=2, coords_orig=np.stack([x, y], 1), values=v, model="exponential",
+                             params=ko.internal_parameters("exponential", [1.0, rng_par, 0.0]))
+        zr, sr = ko.execute(st, "grid", gx, gy)
+        a = ko.kriging_matrix(st)
+        cond = float(np.linalg.cond(a, 1))
+        ok = pa.OrdinaryKriging(x, y, v, variogram_model="exponential", variogram_parameters=[1.0, rng_par, 0.0])
+        z, ss = ok.execute("grid", gx, gy, backend="loop")
+        t = ok.last_timing
+        dz, ds = float(np.abs(z - zr).max()), float(np.abs(ss - sr).max())
+        print("range %.1f: cond_1 %.2e attempts %d path %d half %d res_z %.1e res_inv %.1e  |dz| %.1e |dss| %.1e verify %.2f ms"
+              % (rng_par, cond, t["factor_attempts"], t["factor_path"], t["half_sweep"], t["verify_res_z"], t["verify_res_inv"], dz, ds, t["verify_ms"]))
+        assert (t["factor_attempts"], t["factor_path"], t["half_sweep"]) == (want_attempts, want_path, want_half)
+        assert dz <= max(Z_TOL, cond * 1e-15) and ds <= max(SS_TOL, cond * 1e-15)
+        if want_attempts > 1:  # without the probe the sweep's answer would have been used: measurably worse
+            ok._get_handle().set_option("verify", 0)
+            ok._get_handle().set_option("symsweep", 0)
+            z0, ss0 = ok.execute("grid", gx, gy, backend="loop")
+            assert ok.last_timing["factor_attempts"] == 1 and ok.last_timing["factor_path"] == 1
+            assert float(np.abs(ss0 - sr).max()) > 10 * ds
