@@ -130,7 +130,7 @@ typedef struct mik_timing {
   int32_t half_sweep;          /* 1 = the block sweep maintained only the upper block triangle */
   int32_t factor_attempts;     /* factorisations mik_factor ran: 1, or more when a bad pivot / a failed probe sent it to a more
                                   careful path (half sweep -> full sweep -> partial pivoting) */
-  int32_t reserved3;
+  int32_t rhs_overlapped;      /* 1 = two right-hand-side panels: k_rhs of chunk c + 1 ran on a second stream under chunk c's contraction */
   double verify_ms;            /* the probe of the inverse (all attempts) */
   double verify_res_z;         /* max |A c - [Z; 0]| / max(1, max|Z|), c = A_inv[:, :n] Z: bounds the error of z (last attempt) */
   double verify_res_inv;       /* max_j max |A_inv A e_j - e_j| over three station columns (last attempt) */
@@ -161,7 +161,9 @@ int  mik_slab_of(int64_t n, int members, int i, int64_t *lo, int64_t *count); /*
  * "engine" 0 = MFMA f64 contraction, 1 = VALU (v_fma_f64) contraction ; "waves" 4 | 8 = wavefronts per contraction block ;
  * "pairs" 0/1 = symmetric contraction: work is handed out as single tiles (default 0) or as equal-length PAIRS of row
  *   blocks (higher L2 hit rate, measured 2.7 % slower: the kernel is not traffic-bound) ;
- * "chunk" = points per contraction launch (multiple of 128) ;
+ * "chunk" = largest number of points per contraction launch (multiple of 128; the points are cut into equal launches) ;
+ * "rhs_overlap" 0/1 = two right-hand-side panels: K3a of the next chunk runs on a second stream and fills the tail of the
+ *   current chunk's persistent contraction launch (default 1) [MIK_RHS_OVERLAP] ;
  * "lookahead" 0/1/-1 = overlap the next panel's serial chain with the current trailing update in the block sweep
  *   (default -1: from 3 block columns on with the early-diagonal schedule, else from 24) ;
  * "early_diag" -1/0/1/2/4/5 = look-ahead sweep: the next diagonal block is built from 128 panel rows (two distributed 128^3

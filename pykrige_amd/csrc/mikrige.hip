@@ -226,7 +226,7 @@ struct mik_handle {
   DevBuf px, py, pz, extra_rows, z, ss;
   DevBuf grid_axes, grid_idx;  // mik_set_grid: the axes and (masked style) the slab's compacted cell numbers
   // work
-  DevBuf Bt, part, mw_idx, mw_dist, stat_S, stat_x, stat_out, queue;
+  DevBuf Bt, Bt2, part, mw_idx, mw_dist, stat_S, stat_x, stat_out, queue;
   int n_cu = 256;
   int t_state = 0;  // what T holds: 0 nothing, 1 the kriging matrix A (shift 0), 2 its inverse
   // options
@@ -243,6 +243,9 @@ struct mik_handle {
   int opt_mw_lds_cap = 8192;  // largest candidate buffer the moving-window neighbour search keeps in LDS
   mik_timing tm{};
   std::vector<hipEvent_t> evpool;
+  std::vector<hipEvent_t> pr_events;  // predict: per chunk "right-hand sides written" / "contraction done" (two RHS panels)
+  hipEvent_t ev_chunk = nullptr;      // predict: chunk finished on the compute stream (the result copies wait for it)
+XX
   // comm
   ncclComm_t comm = nullptr;
   int nranks = 1, rank = 0;
@@ -549,6 +552,7 @@ static int create_one_body(mik_handle* h, int device) {
   }
   HIPC(hipStreamCreateWithFlags(&h->stream_d2h, hipStreamNonBlocking));
   HIPC(hipEventCreateWithFlags(&h->ev_d2h, hipEventDisableTiming));
+  HIPC(hipEventCreateWithFlags(&h->ev_chunk, hipEventDisableTiming));
   {
     int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) h->n_cu = ncu;
@@ -573,6 +577,8 @@ static int create_one_body(mik_handle* h, int device) {
   if (env) h->alias_ok = atoi(env) != 0;
   env = getenv("MIK_EARLY_DIAG");
   if (env) h->opt_early_diag = atoi(env) < 0 ? -1 : atoi(env);
+  env = getenv("MIK_RHS_OVERLAP");
+  if (env) h->opt_rhs_overlap = atoi(env) ? 1 : 0;
   env = getenv("MIK_ASYNC_EXCHANGE");
   if (env && atoi(env) >= 0 && atoi(env) <= 2) h->opt_async_exchange = atoi(env);
   h->rccl_init_limit = env_seconds("MIK_RCCL_INIT_TIMEOUT", 120.0);
@@ -613,12 +619,14 @@ static void destroy_one(mik_handle* h) {
                     &h->Rt, &h->TKt, &h->Dinv, &h->DinvT, &h->P0, &h->P1, &h->cand0, &h->cand1, &h->pivall, &h->flag,
                     &h->Cold2, &h->Cnew2, &h->Rt2, &h->Dinv2, &h->DinvT2, &h->Dnext, &h->Dcopy, &h->Cb, &h->Rb, &h->grid.gx, &h->grid.gy, &h->grid.gz, &h->grid.orig,
                     &h->grid.cstart,
-                    &h->px, &h->py, &h->pz, &h->grid_axes, &h->grid_idx, &h->Averify, &h->vbuf, &h->extra_rows, &h->z, &h->ss, &h->Bt, &h->part, &h->mw_idx, &h->mw_dist, &h->stat_S, &h->stat_x, &h->stat_out, &h->queue};
+                    &h->px, &h->py, &h->pz, &h->grid_axes, &h->grid_idx, &h->Averify, &h->vbuf, &h->extra_rows, &h->z, &h->ss, &h->Bt, &h->Bt2, &h->part, &h->mw_idx, &h->mw_dist, &h->stat_S, &h->stat_x, &h->stat_out, &h->queue};
   for (DevBuf* b : bufs) b->release();
   h->pin_in.release();
   h->pin_out.release();
   for (hipEvent_t e : h->evpool) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->la_events) (void)hipEventDestroy(e);
+  for (hipEvent_t e : h->pr_events) (void)hipEventDestroy(e);
+  if (h->ev_chunk) (void)hipEventDestroy(h->ev_chunk);
   for (hipEvent_t e : h->xevents) (void)hipEventDestroy(e);
   if (h->ev_d2h) (void)hipEventDestroy(h->ev_d2h);
   if (h->stream_d2h) (void)hipStreamDestroy(h->stream_d2h);
@@ -676,7 +684,7 @@ static int set_group(mik_handle* h, int n) {
     }
     k->is_kid = true;
     k->opt_factor = h->opt_factor, k->opt_sym = h->opt_sym, k->opt_engine = h->opt_engine, k->opt_waves = h->opt_waves;
-    k->opt_chunk = h->opt_chunk, k->opt_symsweep = h->opt_symsweep, k->opt_diag = h->opt_diag, k->opt_lookahead = h->opt_lookahead, k->opt_gate = h->opt_gate, k->opt_fuse_chain = h->opt_fuse_chain, k->opt_early_diag = h->opt_early_diag, k->opt_pinv_fast = h->opt_pinv_fast, k->opt_verify = h->opt_verify, k->verify_tol_z = h->verify_tol_z, k->verify_tol_inv = h->verify_tol_inv;
+    k->opt_chunk = h->opt_chunk, k->opt_symsweep = h->opt_symsweep, k->opt_diag = h->opt_diag, k->opt_lookahead = h->opt_lookahead, k->opt_gate = h->opt_gate, k->opt_fuse_chain = h->opt_fuse_chain, k->opt_early_diag = h->opt_early_diag, k->opt_pinv_fast = h->opt_pinv_fast, k->opt_rhs_overlap = h->opt_rhs_overlap, k->opt_verify = h->opt_verify, k->verify_tol_z = h->verify_tol_z, k->verify_tol_inv = h->verify_tol_inv;
     k->opt_mw_pivot = h->opt_mw_pivot, k->opt_mw_lds_cap = h->opt_mw_lds_cap, k->opt_pairs = h->opt_pairs, k->opt_mw_solver = h->opt_mw_solver;
     k->custom_fn = h->custom_fn, k->custom_user = h->custom_user;
     h->kids.push_back(k);
@@ -768,6 +776,8 @@ int mik_set_option(mik_handle* h, const char* key, double value) {
     h->opt_chunk = ((long)value / 128) * 128;
   } else if (!strcmp(key, "symsweep")) {
     h->opt_symsweep = value < 0.0 ? -1 : (value != 0.0);
+  } else if (!strcmp(key, "rhs_overlap")) {
+    h->opt_rhs_overlap = value != 0.0;
   } else if (!strcmp(key, "verify")) {
     h->opt_verify = value != 0.0;
   } else if (!strcmp(key, "verify_tol_z") || !strcmp(key, "verify_tol_inv")) {
@@ -2263,23 +2273,41 @@ static int one_predict(mik_handle* h) {
   }
   long chunk = std::min<long>(h->opt_chunk, ((npt + 127) / 128) * 128);
   if (h->model == MIK_MODEL_CUSTOM) chunk = std::min<long>(chunk, 16384);  // each chunk's distances visit the host
-  // keep the RHS panel under ~1/8 of device memory
+  // Two RHS panels: k_rhs of chunk c + 1 runs on a second stream while chunk c is contracted -- the contraction is a
+  // persistent launch that owns every SIMD's registers, so what the second stream gets is its TAIL (the CUs whose tile
+  // queue has run dry), and the 9 ms of k_rhs per 10^6 points at config 2 disappear into the launches' drains.
+  const bool overlap = h->opt_rhs_overlap && h->model != MIK_MODEL_CUSTOM;
+  // keep the RHS panels under ~1/4 of device memory
   size_t freeb = 0, totalb = 0;
   HIPC(hipMemGetInfo(&freeb, &totalb));
-  while (chunk > 128 && (size_t)chunk * Mp * sizeof(double) > std::max(freeb, h->Bt.bytes) / 2) chunk = ((chunk / 2 + 127) / 128) * 128;
+  const size_t have = h->Bt.bytes + h->Bt2.bytes;
+  while (chunk > 128 && (size_t)chunk * Mp * sizeof(double) * (overlap ? 2 : 1) > std::max(freeb + have, have) / 2) chunk = ((chunk / 2 + 127) / 128) * 128;
+  // equal chunks: ceil(npt / chunk) launches of the same size (a short last launch drains as long as a full one)
+  long nchunks = (npt + chunk - 1) / chunk;
+  chunk = (((npt + nchunks - 1) / nchunks + 127) / 128) * 128;
+  nchunks = (npt + chunk - 1) / chunk;
   MIKC(h->Bt.ensure(sizeof(double) * (size_t)chunk * Mp));
+  if (overlap && nchunks > 1) MIKC(h->Bt2.ensure(sizeof(double) * (size_t)chunk * Mp));
+  const bool two = overlap && nchunks > 1;
   MIKC(h->part.ensure(sizeof(double) * (size_t)chunk * nIblk));
-  const long nchunks = (npt + chunk - 1) / chunk;
   MIKC(get_events(h, 2 + 4 * (size_t)nchunks));
+  while (h->pr_events.size() < 2 * (size_t)nchunks) {
+    hipEvent_t e;
+    HIPC(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    h->pr_events.push_back(e);
+  }
   const int kend = ((h->M + MIK_BK - 1) / MIK_BK) * MIK_BK;
+  hipStream_t sc = h->stream;                  // contraction, reduction
+  hipStream_t sr = two ? h->stream2 : h->stream;  // right-hand sides
   HIPC(hipStreamWaitEvent(h->stream, h->ev_d2h, 0));  // an earlier predict's result copies still read z / ss
   HIPC(hipEventRecord(h->evpool[0], h->stream));
-  for (long c = 0; c < nchunks; ++c) {
+  if (two) HIPC(hipStreamWaitEvent(sr, h->evpool[0], 0));
+  auto launch_rhs = [&](long c) -> int {
     const long t0 = c * chunk;
     const int nvalid = (int)std::min<long>(chunk, npt - t0);
     const int palloc = ((nvalid + 127) / 128) * 128;
     RhsArgs a{};
-    a.Bt = h->Bt.as<double>();
+    a.Bt = (two && (c & 1)) ? h->Bt2.as<double>() : h->Bt.as<double>();
     a.ld = Mp;
     a.palloc = palloc;
     a.nvalid = nvalid;
@@ -2305,50 +2333,67 @@ static int one_predict(mik_handle* h) {
     a.extra_stride = npt;
     a.cvec = h->cvec.as<double>();
     a.zout = h->z.as<double>() + t0;
-    hipEvent_t e0 = h->evpool[2 + 4 * c], e1 = h->evpool[3 + 4 * c], e2 = h->evpool[4 + 4 * c], e3 = h->evpool[5 + 4 * c];
-    HIPC(hipEventRecord(e0, h->stream));
+    if (two && c >= 2) HIPC(hipStreamWaitEvent(sr, h->pr_events[2 * (c - 2) + 1], 0));  // the contraction that read this panel is done
+    HIPC(hipEventRecord(h->evpool[2 + 4 * c], sr));
     if (h->model == MIK_MODEL_CUSTOM) {
-      DISPATCH_NDIM_FIXED(7, h->geo ? 1 : h->ndim, k_rhs, dim3(palloc / MIK_TP), dim3(256), h->stream, a);
+      DISPATCH_NDIM_FIXED(7, h->geo ? 1 : h->ndim, k_rhs, dim3(palloc / MIK_TP), dim3(256), sr, a);
       MIKC(custom_roundtrip(h, a.Bt, nvalid, h->N, Mp));
-      DISPATCH_NDIM_FIXED(6, h->geo ? 1 : h->ndim, k_rhs, dim3(palloc / MIK_TP), dim3(256), h->stream, a);
+      DISPATCH_NDIM_FIXED(6, h->geo ? 1 : h->ndim, k_rhs, dim3(palloc / MIK_TP), dim3(256), sr, a);
     } else {
-      DISPATCH_MODEL_NDIM(h->model, h->geo ? 1 : h->ndim, k_rhs, dim3(palloc / MIK_TP), dim3(256), h->stream, a);
+      DISPATCH_MODEL_NDIM(h->model, h->geo ? 1 : h->ndim, k_rhs, dim3(palloc / MIK_TP), dim3(256), sr, a);
     }
-    HIPC(hipEventRecord(e1, h->stream));
+    HIPC(hipEventRecord(h->evpool[3 + 4 * c], sr));
+    if (two) HIPC(hipEventRecord(h->pr_events[2 * c], sr));
+    return MIK_OK;
+  };
+  if (two) MIKC(launch_rhs(0));
+  for (long c = 0; c < nchunks; ++c) {
+    const long t0 = c * chunk;
+    const int nvalid = (int)std::min<long>(chunk, npt - t0);
+    const int palloc = ((nvalid + 127) / 128) * 128;
+    if (two) {
+      if (c + 1 < nchunks) MIKC(launch_rhs(c + 1));  // queued behind chunk c's right-hand sides on the second stream
+      HIPC(hipStreamWaitEvent(sc, h->pr_events[2 * c], 0));
+    } else {
+      MIKC(launch_rhs(c));
+    }
+    hipEvent_t e1 = h->evpool[4 + 4 * c], e2 = h->evpool[5 + 4 * c];
+    HIPC(hipEventRecord(e1, sc));
     const long tiles = (long)nIblk * (palloc / 128);
     const unsigned grid = (unsigned)(8 * ((tiles + 7) / 8));
     {
       const double* Ai = h->T.as<double>();
-      const double* Bi = h->Bt.as<double>();
+      const double* Bi = (two && (c & 1)) ? h->Bt2.as<double>() : h->Bt.as<double>();
       double* pp = h->part.as<double>();
       const long ldm = Mp;
       const unsigned sgrid = (unsigned)super_grid(nIblk, palloc / 128);
       if (h->opt_engine == 1) {
-        if (h->opt_sym) hipLaunchKernelGGL(k_contract_valu<true>, dim3(grid), dim3(256), 0, h->stream, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend);
-        else hipLaunchKernelGGL(k_contract_valu<false>, dim3(grid), dim3(256), 0, h->stream, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend);
+        if (h->opt_sym) hipLaunchKernelGGL(k_contract_valu<true>, dim3(grid), dim3(256), 0, sc, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend);
+        else hipLaunchKernelGGL(k_contract_valu<false>, dim3(grid), dim3(256), 0, sc, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend);
       } else {
         // persistent launch: 2 blocks per CU pop tiles from per-XCD sequences (8 counters, zeroed per launch)
         MIKC(h->queue.ensure(8 * sizeof(unsigned long long)));
-        HIPC(hipMemsetAsync(h->queue.p, 0, 8 * sizeof(unsigned long long), h->stream));
+        HIPC(hipMemsetAsync(h->queue.p, 0, 8 * sizeof(unsigned long long), sc));
         unsigned long long* qp = h->queue.as<unsigned long long>();
         const unsigned pgrid = (unsigned)std::min<long>(2L * h->n_cu, (long)sgrid);
         if (h->opt_waves == 8 && h->opt_sym && h->opt_pairs) {
-          hipLaunchKernelGGL((k_contract<true, 2, true, true>), dim3(pgrid), dim3(512), 0, h->stream, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend, qp);
+          hipLaunchKernelGGL((k_contract<true, 2, true, true>), dim3(pgrid), dim3(512), 0, sc, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend, qp);
         } else if (h->opt_waves == 8) {
-          if (h->opt_sym) hipLaunchKernelGGL((k_contract<true, 2>), dim3(pgrid), dim3(512), 0, h->stream, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend, qp);
-          else hipLaunchKernelGGL((k_contract<false, 2>), dim3(pgrid), dim3(512), 0, h->stream, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend, qp);
+          if (h->opt_sym) hipLaunchKernelGGL((k_contract<true, 2>), dim3(pgrid), dim3(512), 0, sc, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend, qp);
+          else hipLaunchKernelGGL((k_contract<false, 2>), dim3(pgrid), dim3(512), 0, sc, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend, qp);
         } else {
-          if (h->opt_sym) hipLaunchKernelGGL((k_contract<true, 4>), dim3(pgrid), dim3(256), 0, h->stream, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend, qp);
-          else hipLaunchKernelGGL((k_contract<false, 4>), dim3(pgrid), dim3(256), 0, h->stream, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend, qp);
+          if (h->opt_sym) hipLaunchKernelGGL((k_contract<true, 4>), dim3(pgrid), dim3(256), 0, sc, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend, qp);
+          else hipLaunchKernelGGL((k_contract<false, 4>), dim3(pgrid), dim3(256), 0, sc, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend, qp);
         }
       }
     }
-    HIPC(hipEventRecord(e2, h->stream));
-    hipLaunchKernelGGL(k_ss_reduce, dim3((nvalid + 255) / 256), dim3(256), 0, h->stream, (const double*)h->part.as<double>(),
+    HIPC(hipEventRecord(e2, sc));
+    if (two) HIPC(hipEventRecord(h->pr_events[2 * c + 1], sc));
+    hipLaunchKernelGGL(k_ss_reduce, dim3((nvalid + 255) / 256), dim3(256), 0, sc, (const double*)h->part.as<double>(),
                        palloc, nIblk, nvalid, h->ss.as<double>() + t0);
     // this chunk's z and sigma^2 leave for the page-locked landing zone while the next chunk is computed
-    HIPC(hipEventRecord(e3, h->stream));
-    HIPC(hipStreamWaitEvent(h->stream_d2h, e3, 0));
+    HIPC(hipEventRecord(h->ev_chunk, sc));
+    HIPC(hipStreamWaitEvent(h->stream_d2h, h->ev_chunk, 0));
     HIPC(hipMemcpyAsync(h->pin_out.as<double>() + t0, h->z.as<double>() + t0, sizeof(double) * nvalid, hipMemcpyDeviceToHost,
                         h->stream_d2h));
     HIPC(hipMemcpyAsync(h->pin_out.as<double>() + npt + t0, h->ss.as<double>() + t0, sizeof(double) * nvalid,
@@ -2368,10 +2413,11 @@ static int one_predict(mik_handle* h) {
   for (long c = 0; c < nchunks; ++c) {
     HIPC(hipEventElapsedTime(&ms, h->evpool[2 + 4 * c], h->evpool[3 + 4 * c]));
     h->tm.rhs_ms += ms;
-    HIPC(hipEventElapsedTime(&ms, h->evpool[3 + 4 * c], h->evpool[4 + 4 * c]));
+    HIPC(hipEventElapsedTime(&ms, h->evpool[4 + 4 * c], h->evpool[5 + 4 * c]));
     h->tm.contract_ms += ms;
   }
   h->tm.contract_launches = nchunks;
+  h->tm.rhs_overlapped = two ? 1 : 0;
   h->have_results = true;
   return MIK_OK;
 }
