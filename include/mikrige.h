@@ -162,8 +162,8 @@ int  mik_slab_of(int64_t n, int members, int i, int64_t *lo, int64_t *count); /*
  * "pairs" 0/1 = symmetric contraction: work is handed out as single tiles (default 0) or as equal-length PAIRS of row
  *   blocks (higher L2 hit rate, measured 2.7 % slower: the kernel is not traffic-bound) ;
  * "chunk" = largest number of points per contraction launch (multiple of 128; the points are cut into equal launches) ;
- * "rhs_overlap" 0/1 = two right-hand-side panels: K3a of the next chunk runs on a second stream and fills the tail of the
- *   current chunk's persistent contraction launch (default 1) [MIK_RHS_OVERLAP] ;
+ * "rhs_overlap" 0/1 = two right-hand-side panels: K3a of the next chunk runs on a second stream while the current chunk is
+ *   contracted (default 0: measured a tie -- the contraction slows down by what K3a takes) [MIK_RHS_OVERLAP] ;
  * "lookahead" 0/1/-1 = overlap the next panel's serial chain with the current trailing update in the block sweep
  *   (default -1: from 3 block columns on with the early-diagonal schedule, else from 24) ;
  * "early_diag" -1/0/1/2/4/5 = look-ahead sweep: the next diagonal block is built from 128 panel rows (two distributed 128^3

@@ -245,7 +245,11 @@ struct mik_handle {
   std::vector<hipEvent_t> evpool;
   std::vector<hipEvent_t> pr_events;  // predict: per chunk "right-hand sides written" / "contraction done" (two RHS panels)
   hipEvent_t ev_chunk = nullptr;      // predict: chunk finished on the compute stream (the result copies wait for it)
-XX
+  // "rhs_overlap": k_rhs of the next chunk on a second stream while the current chunk is contracted (two RHS panels).
+  // Measured (profiles/r03_chunk_and_rhs_overlap_sweep_c2.txt): it does run concurrently -- and the contraction slows down by
+  // exactly the time k_rhs takes (362.8 + 9.1 ms serial = 372.6 ms per 10^6 points; 372.8 ms overlapped): fp64 VALU / HBM-write
+  // work does not hide under fp64 MFMAs on this part.  Off by default; kept as an option for the record.
+  int opt_rhs_overlap = 0;
   // comm
   ncclComm_t comm = nullptr;
   int nranks = 1, rank = 0;
@@ -2273,9 +2277,8 @@ static int one_predict(mik_handle* h) {
   }
   long chunk = std::min<long>(h->opt_chunk, ((npt + 127) / 128) * 128);
   if (h->model == MIK_MODEL_CUSTOM) chunk = std::min<long>(chunk, 16384);  // each chunk's distances visit the host
-  // Two RHS panels: k_rhs of chunk c + 1 runs on a second stream while chunk c is contracted -- the contraction is a
-  // persistent launch that owns every SIMD's registers, so what the second stream gets is its TAIL (the CUs whose tile
-  // queue has run dry), and the 9 ms of k_rhs per 10^6 points at config 2 disappear into the launches' drains.
+  // "rhs_overlap" (off by default, see the option): two RHS panels, k_rhs of chunk c + 1 on a second stream while chunk c is
+  // contracted.
   const bool overlap = h->opt_rhs_overlap && h->model != MIK_MODEL_CUSTOM;
   // keep the RHS panels under ~1/4 of device memory
   size_t freeb = 0, totalb = 0;
