@@ -320,7 +320,7 @@ def make_model(cfg, coords, values):
     return pa.OrdinaryKriging(coords[0], coords[1], values, **kw)
 
 
-MW_KERNELS = {1: "k_mw_chol", 2: "k_mw_solve", 3: "k_mw_solve_big"}
+MW_KERNELS = {1: "k_mw_chol", 2: "k_mw_solve", 3: "k_mw_solve_big", 4: "k_mw_chol_blocked"}
 FACTOR_PATHS = {1: "spd-shift block sweep", 2: "pivoted block gauss-jordan", 3: "caller-supplied inverse", 4: "device pseudo-inverse (jacobi)",
                 5: "deflated inverse (pseudo-inverse of duplicated stations)"}
 
@@ -578,7 +578,7 @@ def main():
                     "algorithmic_bytes_per_point": 12 * kw + 16}
             metric = "kriged grid-points/sec (z + sigma^2), moving window n_closest_points=%d, %s" % (kw, cfg["name"])
             config = {"workload": cfg["name"], "n_closest_points": kw, "stations": cfg["n"], "grid_points_total": npt_total}
-            kernel_prefix = "void mik::" + kname + "<"
+            kernel_prefix = ("void mik::" + kname + "<") if kname in ("k_mw_chol", "k_mw_solve") else "mik::" + kname
         else:
             algo_flops_per_launch = 2.0 * M * M * pts_per_launch  # 2 M^2 per point for w = A_inv . b
             effective = algo_flops_per_launch / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0

@@ -126,7 +126,7 @@ typedef struct mik_timing {
   int32_t rccl_ranks;          /* communicators (= ranks = devices) the RCCL broadcast ran over; 0 if RCCL was not used */
   int32_t mw_kernel;           /* mik_predict_moving_window: the per-point solver that ran (contract_ms is its time): 1 = k_mw_chol
                                   (LDL^T in registers), 2 = k_mw_solve (Gauss-Jordan in registers), 3 = k_mw_solve_big (LU in HBM
-                                  scratch); 0 after mik_predict */
+                                  scratch), 4 = k_mw_chol_blocked (blocked Cholesky, panels in LDS); 0 after mik_predict */
   int32_t half_sweep;          /* 1 = the block sweep maintained only the upper block triangle */
   int32_t factor_attempts;     /* factorisations mik_factor ran: 1, or more when a bad pivot / a failed probe sent it to a more
                                   careful path (half sweep -> full sweep -> partial pivoting) */
@@ -189,6 +189,9 @@ int  mik_slab_of(int64_t n, int members, int i, int64_t *lo, int64_t *count); /*
  *   falling back to pivoting when a local system is not positive definite) ;
  * "mw_solver" 0/1 = moving-window systems by the register-tile LDL^T kernel (default 0, K <= 256) or by the Gauss-Jordan / HBM-LU
  *   kernels of round 1 (1; also what larger windows use) ;
+ * "mw_class" = 100 G + RI: force one thread-grid (G x G threads per point) / register-tile (RI x RI per thread) class of the
+ *   moving-window LDL^T kernel, windows up to G RI (0 = chosen by window size; 1 = the blocked Cholesky kernel of the large
+ *   windows whatever the size; for A/B runs) ;
  * "mw_lds_cap" = largest moving-window candidate buffer kept in LDS (entries, default 8192; 0 forces the HBM lists) ;
  * "exchange" 0..3 = how a device group distributes the inverted matrix: 0 auto (RCCL broadcast, peer copies if RCCL is
  *   unavailable), 1 RCCL broadcast, 2 peer copies (scatter + all-gather over xGMI), 3 none (every device factors) [MIK_EXCHANGE] ;

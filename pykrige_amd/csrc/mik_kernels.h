@@ -2296,13 +2296,14 @@ __global__ void __launch_bounds__((G * G < 256) ? 256 : G * G) k_mw_chol(MwArgs 
   constexpr int T = G * G, NT = T < 256 ? 256 : T, NB = G * RI, ACOL = NB + 4;
   const int K = a.K;
   const int g = threadIdx.x / T, lt = threadIdx.x % T, ty = lt / G, tx = lt % G;
-  constexpr int PER = 2 * ACOL + 5 * NB;
+  constexpr int PER = 2 * ACOL + 9 * NB;
   double* acol = mw_lds + (long)g * PER;  // [2][ACOL]: column c of the trailing matrix by global row, right-hand-side rows at NB..NB+2
   double* csx = acol + 2 * ACOL;
   double* csy = csx + NB;
   double* csz = csy + NB;
   double* bvec = csz + NB;
   double* zsel = bvec + NB;
+  double* ylog = zsel + NB;  // [4][NB]: per step c the three eliminated right-hand-side entries y_q(c) and 1 / d(c)
   const long pt = (long)blockIdx.x * (NT / T) + g;
   const bool live = pt < a.npt;
   auto sync = [&]() {
@@ -2361,7 +2362,6 @@ __global__ void __launch_bounds__((G * G < 256) ? 256 : G * G) k_mw_chol(MwArgs 
     if (col < K) v = (ty == 0) ? bvec[col] + shift : (ty == 1) ? 1.0 : (ty == 2) ? zsel[col] : 0.0;
     rhs[j] = v;
   }
-  double g00 = 0.0, g01 = 0.0, g11 = 0.0, g02 = 0.0, g12 = 0.0;
   int bad = 0;
 #pragma unroll
   for (int cc = 0; cc < RI; ++cc) {
@@ -2373,11 +2373,13 @@ __global__ void __launch_bounds__((G * G < 256) ? 256 : G * G) k_mw_chol(MwArgs 
 #pragma unroll
         for (int i = cc; i < RI; ++i) ab[ty + G * i] = m[i][cc];
         if (ty < 3) ab[NB + ty] = rhs[cc];
+        // the pivot's owner (thread (cx, cx), local tile element (cc, cc)) publishes its reciprocal as well: one wavefront
+        // per step pays for it instead of every one (this kernel is instruction-issue bound: round 3)
+        if (ty == cx) ab[NB + 3] = pivot_recip(m[cc][cc]);
       }
       sync();
-      const double d = ab[c];
-      if (!(d > 0.0)) bad = 2;
-      const double inv = pivot_recip(d);  // this kernel is instruction-issue bound: 5 operations instead of the ~35 of a division
+      const double inv = ab[NB + 3];
+      if (!(inv > 0.0) || !(inv < 1e300)) bad = 2;  // a non-positive (or vanished) pivot
       double u[RI], w[RI];
 #pragma unroll
       for (int i = cc; i < RI; ++i) {
@@ -2386,13 +2388,10 @@ __global__ void __launch_bounds__((G * G < 256) ? 256 : G * G) k_mw_chol(MwArgs 
       }
       if (ty <= cx) u[cc] = 0.0;  // rows / columns <= c of the diagonal local tile are finished
       if (tx <= cx) w[cc] = 0.0;
-      const double y0 = ab[NB], y1 = ab[NB + 1], y2 = ab[NB + 2];
       const double ur = (ty < 3 ? ab[NB + ty] : 0.0) * inv;
-      g00 += y0 * y0 * inv;
-      g01 += y0 * y1 * inv;
-      g11 += y1 * y1 * inv;
-      g02 += y0 * y2 * inv;
-      g12 += y1 * y2 * inv;
+      // the five inner products z and sigma^2 are made of, sum_c y_p(c) y_q(c) / d(c), are formed ONCE at the end from this log
+      // (every thread used to accumulate all five in every step)
+      if (lt < 4) ylog[lt * NB + c] = (lt < 3) ? ab[NB + lt] : inv;
 #pragma unroll
       for (int i = cc; i < RI; ++i)
 #pragma unroll
@@ -2401,11 +2400,250 @@ __global__ void __launch_bounds__((G * G < 256) ? 256 : G * G) k_mw_chol(MwArgs 
       for (int j = cc; j < RI; ++j) rhs[j] -= ur * w[j];
     }
   }
+  sync();
+  double g00 = 0.0, g01 = 0.0, g11 = 0.0, g02 = 0.0, g12 = 0.0;
+  for (int c = lt; c < K; c += T) {
+    const double y0 = ylog[c], y1 = ylog[NB + c], y2 = ylog[2 * NB + c], inv = ylog[3 * NB + c];
+    g00 += y0 * y0 * inv;
+    g01 += y0 * y1 * inv;
+    g11 += y1 * y1 * inv;
+    g02 += y0 * y2 * inv;
+    g12 += y1 * y2 * inv;
+  }
+  constexpr int W = T < 64 ? T : 64;  // lanes of one wavefront that belong to this point
+#pragma unroll
+  for (int o = W / 2; o > 0; o >>= 1) {
+    g00 += __shfl_xor(g00, o);
+    g01 += __shfl_xor(g01, o);
+    g11 += __shfl_xor(g11, o);
+    g02 += __shfl_xor(g02, o);
+    g12 += __shfl_xor(g12, o);
+  }
+  if (T > 64) {  // several wavefronts per point: their partial sums meet in LDS (the column buffers are free now)
+    const int wv = lt >> 6;
+    if ((lt & 63) == 0) {
+      acol[5 * wv + 0] = g00, acol[5 * wv + 1] = g01, acol[5 * wv + 2] = g11, acol[5 * wv + 3] = g02, acol[5 * wv + 4] = g12;
+    }
+    __syncthreads();
+    if (lt == 0) {
+      g00 = g01 = g11 = g02 = g12 = 0.0;
+      for (int q = 0; q < T / 64; ++q) {
+        g00 += acol[5 * q], g01 += acol[5 * q + 1], g11 += acol[5 * q + 2], g02 += acol[5 * q + 3], g12 += acol[5 * q + 4];
+      }
+    }
+  }
   if (live && lt == 0) {
     const double mu = (g01 - 1.0) / g11;
     a.z[pt] = g02 - mu * g12;
     a.ss[pt] = -(g00 - mu * g01) + shift - mu;
     if (bad || !(g11 > 0.0)) atomicOr(a.flag, 2);
+  }
+}
+
+// ---- windows beyond the register classes (K > MIK_MW_CHOL_KMAX): BLOCKED Cholesky of the SPD-shifted local system ----------
+// One 256-thread block per point (grid-strided over the chunk); the (ldc + 64) x ldc system -- lower triangle of
+// C = s 11^T - Gamma padded with identity to ldc = 64 ceil(K / 64), and the three right-hand sides {b + s, 1, Z} as rows
+// ldc..ldc+2 -- sits in a per-block scratch slot (2.4 MB at K = 512: L2 / Infinity-Cache resident).  64-wide panels:
+//   (a) the diagonal block is factored in LDS (64 steps, 256 threads);
+//   (b) every row below it is solved against it by ONE thread (forward substitution, the 64 entries in registers, broadcast
+//       LDS reads of the factor) -- the right-hand-side rows included: their forward substitution is this step;
+//   (c) the trailing matrix is updated in 64 x 64 tiles, both operand panels staged k-major in LDS, a 4 x 4 micro-tile per
+//       thread (two ds_read_b128 per operand and k).
+// z and sigma^2 are the inner products of the three solved rows, as in k_mw_chol (C = L L^T here, so no D^-1).  A
+// non-positive pivot raises flag bit 1 and the call is redone by the pivoted kernel (k_mw_solve_big).  Replaces the unblocked
+// HBM elimination for named variogram models: k = 512 went from 3.9 k to > 100 k points/s (profiles/r03_moving_window_timing.txt).
+// Reference: lib/cok.pyx:98-193 (one dgesv per point), ok.py:929-986.
+#define MIK_MWP 64
+#define MIK_MWP_LD 66  // LDS row stride of the operand panels (even: the 4-element fragment reads are 16-byte aligned)
+__global__ void __launch_bounds__(256, 2) k_mw_chol_blocked(MwArgs a, double* __restrict__ scratch, long slot, int ldc) {
+  extern __shared__ double mwc_lds[];
+  double* LR = mwc_lds;                          // [64][66]: diagonal block (row-major) / row-block operand, k-major
+  double* LS = mwc_lds + MIK_MWP * MIK_MWP_LD;   // [64][66]: column-block operand, k-major
+  __shared__ double red[5][4];
+  __shared__ double rdiag[MIK_MWP];              // 1 / L_jj of the diagonal block being used
+  __shared__ double sh_shift;
+  __shared__ int sh_bad;
+  const int K = a.K, l = threadIdx.x, lane = l & 63, wave = l >> 6;
+  const int nP = ldc / MIK_MWP;
+  double* A = scratch + (long)blockIdx.x * slot;       // (ldc + 64) x ldc
+  double* cs = A + (long)(ldc + MIK_MWP) * ldc;        // coordinates of the selected stations: x | y | z, K each
+  const double* bv = nullptr;
+  for (long pt = blockIdx.x; pt < a.npt; pt += gridDim.x) {
+    __syncthreads();
+    if (l == 0) sh_bad = 0;
+    bv = a.dist + pt * K;  // b = -gamma(d), 0 on an exact hit (k_mw_rhs)
+    double gmax = 0.0;
+    for (int r = l; r < K; r += 256) {
+      const int st = a.idx[pt * K + r];
+      double x = a.sx[st], y = a.sy[st], z = (a.mode == 3) ? a.sz[st] : 0.0;
+      if (a.mode == 1) {
+        const double lat = y * MIK_PI / 180.0;
+        y = cos(lat);
+        z = sin(lat);
+      }
+      cs[r] = x, cs[K + r] = y, cs[2 * K + r] = z;
+      gmax = fmax(gmax, -bv[r]);
+      // right-hand-side rows (columns < K; the padding columns stay 0)
+      A[(long)(ldc + 2) * ldc + r] = a.Z[st];
+    }
+    if (a.v.model < 2) {  // no sill: shift by four times the largest gamma of the window (>= gamma(2 d_k))
+      for (int o = 32; o > 0; o >>= 1) gmax = fmax(gmax, __shfl_xor(gmax, o));
+      if (lane == 0) red[0][wave] = gmax;
+    }
+    __syncthreads();
+    if (l == 0) {
+      double s = a.v.p0 + a.v.p2;
+      if (a.v.model < 2) s = 4.0 * fmax(fmax(red[0][0], red[0][1]), fmax(red[0][2], red[0][3]));
+      if (!(s > 0.0)) s = 1.0;
+      sh_shift = s;
+    }
+    __syncthreads();
+    const double shift = sh_shift;
+    for (int r = l; r < ldc; r += 256) {
+      A[(long)ldc * ldc + r] = r < K ? bv[r] + shift : 0.0;
+      A[(long)(ldc + 1) * ldc + r] = r < K ? 1.0 : 0.0;
+      if (r >= K) A[(long)(ldc + 2) * ldc + r] = 0.0;
+    }
+    // lower triangle of the shifted matrix, identity in the padding
+    for (int r = wave; r < ldc; r += 4) {
+      double* row = A + (long)r * ldc;
+      if (r < K) {
+        const double xr = cs[r], yr = cs[K + r], zr = cs[2 * K + r];
+        for (int c = lane; c <= r; c += 64)
+          row[c] = (c == r) ? shift : shift + mw_entry(a.v, a.mode, xr, yr, zr, cs[c], cs[K + c], cs[2 * K + c]);
+      } else {
+        for (int c = lane; c <= r; c += 64) row[c] = (c == r) ? 1.0 : 0.0;
+      }
+    }
+    __syncthreads();
+    const int nrows = ldc + 3;  // matrix rows + the three right-hand sides
+    for (int p = 0; p < nP; ++p) {
+      const int c0 = p * MIK_MWP;
+      // (a) diagonal block -> LDS, row-major, lower part; Cholesky in place
+      for (int e = l; e < MIK_MWP * MIK_MWP; e += 256) {
+        const int i = e >> 6, k = e & 63;
+        LR[i * MIK_MWP_LD + k] = (k <= i) ? A[(long)(c0 + i) * ldc + c0 + k] : 0.0;
+      }
+      __syncthreads();
+      for (int j = 0; j < MIK_MWP; ++j) {
+        const double d = LR[j * MIK_MWP_LD + j];  // (the barrier at the end of the previous step ordered its updates before this)
+        const double rs = 1.0 / sqrt(d > 0.0 ? d : 1.0);
+        if (l > j && l < MIK_MWP) LR[l * MIK_MWP_LD + j] *= rs;  // the column below the pivot; the pivot itself is not touched yet
+        __syncthreads();
+        if (l == 0) {
+          if (!(d > 0.0)) sh_bad = 1;
+          LR[j * MIK_MWP_LD + j] = d * rs;  // sqrt(d); nobody reads it before the panel solve
+          rdiag[j] = rs;
+        }
+        {  // trailing part of the block: (i, k), j < k <= i < 64
+          const int i = l & 63;
+          const double lij = LR[i * MIK_MWP_LD + j];
+          for (int k = j + 1 + (l >> 6); k <= i; k += 4) LR[i * MIK_MWP_LD + k] -= lij * LR[k * MIK_MWP_LD + j];
+        }
+        __syncthreads();
+      }
+      for (int e = l; e < MIK_MWP * MIK_MWP; e += 256) {  // the factored block goes back (lower part)
+        const int i = e >> 6, k = e & 63;
+        if (k <= i) A[(long)(c0 + i) * ldc + c0 + k] = LR[i * MIK_MWP_LD + k];
+      }
+      // (b) the rows below: x L^T = a  ->  x_j = (a_j - sum_{k<j} x_k L_jk) / L_jj, one row per thread
+      for (int r = c0 + MIK_MWP + l; r < nrows; r += 256) {
+        double* row = A + (long)r * ldc + c0;
+        double x[MIK_MWP];
+#pragma unroll
+        for (int k = 0; k < MIK_MWP; k += 2) {
+          const double2 v = *reinterpret_cast<const double2*>(row + k);
+          x[k] = v.x, x[k + 1] = v.y;
+        }
+#pragma unroll
+        for (int j = 0; j < MIK_MWP; ++j) {
+          double s = x[j];
+#pragma unroll
+          for (int k = 0; k < j; ++k) s -= x[k] * LR[j * MIK_MWP_LD + k];
+          x[j] = s * rdiag[j];
+        }
+#pragma unroll
+        for (int k = 0; k < MIK_MWP; k += 2) *reinterpret_cast<double2*>(row + k) = make_double2(x[k], x[k + 1]);
+      }
+      __syncthreads();
+      // (c) trailing update, tiles (rb, sb) of 64 x 64 with sb <= rb; the right-hand sides are the 3-row block after the matrix
+      const int nb_rows = nP - p - 1;  // matrix row blocks below the panel
+      for (int rb = 0; rb <= nb_rows; ++rb) {
+        const bool rhs_blk = rb == nb_rows;
+        const int r0 = c0 + MIK_MWP + rb * MIK_MWP;  // == ldc for the right-hand-side block
+        if (rhs_blk && nb_rows == 0) break;           // last panel: nothing to the right of it
+        // row-block operand, k-major: LR[k][row]
+        for (int e = l; e < MIK_MWP * MIK_MWP; e += 256) {
+          const int i = e >> 6, k = e & 63;
+          LR[k * MIK_MWP_LD + i] = (!rhs_blk || i < 3) ? A[(long)(r0 + i) * ldc + c0 + k] : 0.0;
+        }
+        const int sb_end = rhs_blk ? nb_rows - 1 : rb;
+        for (int sb = 0; sb <= sb_end; ++sb) {
+          const int s0 = c0 + MIK_MWP + sb * MIK_MWP;
+          __syncthreads();  // LR is staged / the previous tile is done with LS
+          if (!rhs_blk && sb == rb) {
+            for (int e = l; e < MIK_MWP * MIK_MWP_LD; e += 256) LS[e] = LR[e];
+          } else {
+            for (int e = l; e < MIK_MWP * MIK_MWP; e += 256) {
+              const int i = e >> 6, k = e & 63;
+              LS[k * MIK_MWP_LD + i] = A[(long)(s0 + i) * ldc + c0 + k];
+            }
+          }
+          __syncthreads();
+          const int ty = l >> 4, tx = l & 15;
+          if (!rhs_blk || ty == 0) {
+            double acc[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+#pragma unroll 8
+            for (int k = 0; k < MIK_MWP; ++k) {
+              double av[4], bw[4];
+#pragma unroll
+              for (int i = 0; i < 4; ++i) av[i] = LR[k * MIK_MWP_LD + 4 * ty + i], bw[i] = LS[k * MIK_MWP_LD + 4 * tx + i];
+#pragma unroll
+              for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] += av[i] * bw[j];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              if (rhs_blk && i == 3) break;
+              double* out = A + (long)(r0 + 4 * ty + i) * ldc + s0 + 4 * tx;
+              double2 v0 = *reinterpret_cast<double2*>(out), v1 = *reinterpret_cast<double2*>(out + 2);
+              v0.x -= acc[i][0], v0.y -= acc[i][1], v1.x -= acc[i][2], v1.y -= acc[i][3];
+              *reinterpret_cast<double2*>(out) = v0;
+              *reinterpret_cast<double2*>(out + 2) = v1;
+            }
+          }
+        }
+        __syncthreads();  // the tiles of this row block are done with LR
+      }
+      __syncthreads();
+    }
+    // the three solved rows y_q = L^-1 rhs_q; G_pq = y_p . y_q
+    double g00 = 0.0, g01 = 0.0, g11 = 0.0, g02 = 0.0, g12 = 0.0;
+    for (int c = l; c < K; c += 256) {
+      const double y0 = A[(long)ldc * ldc + c], y1 = A[(long)(ldc + 1) * ldc + c], y2 = A[(long)(ldc + 2) * ldc + c];
+      g00 += y0 * y0, g01 += y0 * y1, g11 += y1 * y1, g02 += y0 * y2, g12 += y1 * y2;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      g00 += __shfl_xor(g00, o), g01 += __shfl_xor(g01, o), g11 += __shfl_xor(g11, o), g02 += __shfl_xor(g02, o), g12 += __shfl_xor(g12, o);
+    }
+    if (lane == 0) red[0][wave] = g00, red[1][wave] = g01, red[2][wave] = g11, red[3][wave] = g02, red[4][wave] = g12;
+    __syncthreads();
+    if (l == 0) {
+      g00 = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+      g01 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+      g11 = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+      g02 = red[3][0] + red[3][1] + red[3][2] + red[3][3];
+      g12 = red[4][0] + red[4][1] + red[4][2] + red[4][3];
+      const double mu = (g01 - 1.0) / g11;
+      a.z[pt] = g02 - mu * g12;
+      a.ss[pt] = -(g00 - mu * g01) + shift - mu;
+      if (sh_bad || !(g11 > 0.0)) atomicOr(a.flag, 2);
+    }
   }
 }
 

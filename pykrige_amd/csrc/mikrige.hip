@@ -241,6 +241,7 @@ struct mik_handle {
   int opt_mw_solver = 0;      // 0 = LDL^T of the shifted system in registers (default), 1 = the Gauss-Jordan kernels
   bool mw_force_piv = false;
   int opt_mw_lds_cap = 8192;  // largest candidate buffer the moving-window neighbour search keeps in LDS
+  int opt_mw_class = 0;       // 100 G + RI: force one thread-grid / register-tile class of k_mw_chol (0 = by window size)
   mik_timing tm{};
   std::vector<hipEvent_t> evpool;
   std::vector<hipEvent_t> pr_events;  // predict: per chunk "right-hand sides written" / "contraction done" (two RHS panels)
@@ -505,7 +506,7 @@ template <int G, int RI>
 static int launch_mw_chol(mik_handle* h, const MwArgs& a, long pc) {
   constexpr int T = G * G, NT = T < 256 ? 256 : T, PPB = NT / T, NB = G * RI;
   if (a.K > NB) return fail(MIK_EINVAL, "moving-window LDL^T class too small for this window");
-  const size_t lds = sizeof(double) * (size_t)(2 * (NB + 4) + 5 * NB) * PPB;
+  const size_t lds = sizeof(double) * (size_t)(2 * (NB + 4) + 9 * NB) * PPB;
   const dim3 grid((unsigned)((pc + PPB - 1) / PPB));
   HIPC(hipFuncSetAttribute((const void*)k_mw_chol<G, RI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL((k_mw_chol<G, RI>), grid, dim3(NT), lds, h->stream, a);
@@ -516,6 +517,16 @@ static int launch_mw_chol(mik_handle* h, const MwArgs& a, long pc) {
 #define MIK_MW_CHOL_KMAX 256
 static int dispatch_mw_chol(mik_handle* h, const MwArgs& a, long pc) {
   const int K = a.K;
+  if (h->opt_mw_class) {  // "mw_class" = 100 G + RI: a class forced for A/B runs (scripts/mw_classes.py)
+    switch (h->opt_mw_class) {
+#define MWC(G, RI) case 100 * G + RI: return launch_mw_chol<G, RI>(h, a, pc);
+      MWC(4, 4) MWC(8, 4) MWC(8, 6) MWC(8, 8) MWC(8, 10) MWC(8, 12) MWC(8, 14) MWC(8, 16)
+      MWC(16, 4) MWC(16, 5) MWC(16, 6) MWC(16, 7) MWC(16, 8) MWC(16, 10) MWC(16, 12) MWC(16, 14) MWC(16, 16)
+      MWC(32, 5) MWC(32, 6) MWC(32, 7) MWC(32, 8)
+#undef MWC
+      default: return fail(MIK_EINVAL, "mw_class: no such LDL^T class");
+    }
+  }
   if (K <= 16) return launch_mw_chol<4, 4>(h, a, pc);    // 16 threads per point, 4 points per wavefront
   if (K <= 32) return launch_mw_chol<8, 4>(h, a, pc);    // one wavefront per point from here to K = 64: no workgroup barrier
   if (K <= 48) return launch_mw_chol<8, 6>(h, a, pc);
@@ -689,7 +700,7 @@ static int set_group(mik_handle* h, int n) {
     k->is_kid = true;
     k->opt_factor = h->opt_factor, k->opt_sym = h->opt_sym, k->opt_engine = h->opt_engine, k->opt_waves = h->opt_waves;
     k->opt_chunk = h->opt_chunk, k->opt_symsweep = h->opt_symsweep, k->opt_diag = h->opt_diag, k->opt_lookahead = h->opt_lookahead, k->opt_gate = h->opt_gate, k->opt_fuse_chain = h->opt_fuse_chain, k->opt_early_diag = h->opt_early_diag, k->opt_pinv_fast = h->opt_pinv_fast, k->opt_rhs_overlap = h->opt_rhs_overlap, k->opt_verify = h->opt_verify, k->verify_tol_z = h->verify_tol_z, k->verify_tol_inv = h->verify_tol_inv;
-    k->opt_mw_pivot = h->opt_mw_pivot, k->opt_mw_lds_cap = h->opt_mw_lds_cap, k->opt_pairs = h->opt_pairs, k->opt_mw_solver = h->opt_mw_solver;
+    k->opt_mw_class = h->opt_mw_class, k->opt_mw_pivot = h->opt_mw_pivot, k->opt_mw_lds_cap = h->opt_mw_lds_cap, k->opt_pairs = h->opt_pairs, k->opt_mw_solver = h->opt_mw_solver;
     k->custom_fn = h->custom_fn, k->custom_user = h->custom_user;
     h->kids.push_back(k);
   }
@@ -802,6 +813,8 @@ int mik_set_option(mik_handle* h, const char* key, double value) {
   } else if (!strcmp(key, "mw_solver")) {
     if (value != 0.0 && value != 1.0) return fail(MIK_EINVAL, "mw_solver must be 0 (LDL^T) or 1 (Gauss-Jordan)");
     h->opt_mw_solver = (int)value;
+  } else if (!strcmp(key, "mw_class")) {
+    h->opt_mw_class = (int)value;
   } else if (!strcmp(key, "mw_pivot")) {
     h->opt_mw_pivot = value != 0.0;
   } else if (!strcmp(key, "mw_lds_cap")) {
@@ -2490,8 +2503,11 @@ static int one_predict_mw(mik_handle* h, int n_closest) {
   // three solvers: LDL^T of the shifted system in registers (no pivot search; windows up to 256), Gauss-Jordan in registers
   // with or without implicit partial pivoting (opt_mw_solver = 1, or when the model cannot promise a positive definite
   // station block; windows up to 127), LU with partial pivoting in HBM scratch (any window)
-  const bool chol = !mw_piv && h->opt_mw_solver == 0 && K <= MIK_MW_CHOL_KMAX;
-  const bool big = !chol && K > MIK_MW_KMAX;
+  const bool chol = !mw_piv && h->opt_mw_solver == 0 && K <= MIK_MW_CHOL_KMAX && h->opt_mw_class != 1;
+  // beyond the register classes: blocked Cholesky of the shifted system (one block per point, panels of 64 in LDS, the matrix
+  // in an L2-resident scratch slot); "mw_class" 1 forces it for smaller windows too (A/B runs)
+  const bool cholb = !mw_piv && h->opt_mw_solver == 0 && !chol && K >= 8;
+  const bool big = !chol && !cholb && K > MIK_MW_KMAX;
   long chunk = npt;
   if (K > MIK_MW_KMAX) {  // neighbour lists of 12 K bytes per point: bound them to ~2 GB
     chunk = ((long)(2e9 / (24.0 * K)) / 256) * 256;
@@ -2540,6 +2556,19 @@ static int one_predict_mw(mik_handle* h, int n_closest) {
                          s3 + 2 * (size_t)h->N);
       sx = s3, sy = s3 + h->N, sz = s3 + 2 * (size_t)h->N;
     }
+  }
+  int ldc = 0;
+  long cslot = 0;
+  if (cholb) {
+    ldc = ((K + MIK_MWP - 1) / MIK_MWP) * MIK_MWP;
+    cslot = (long)(ldc + MIK_MWP) * ldc + 3L * K;
+    cslot += cslot & 1;
+    long g = (long)(6e9 / (8.0 * (double)cslot));  // per-block scratch systems, <= ~6 GB in total
+    if (g > 2L * h->n_cu) g = 2L * h->n_cu;
+    if (g > chunk) g = chunk;
+    if (g < 1) g = 1;
+    sgrid = (int)g;
+    MIKC(sysbuf.ensure(sizeof(double) * (size_t)cslot * (size_t)sgrid));
   }
   if (big) {
     const double per = 8.0 * nb * (nb + 1.0);
@@ -2642,6 +2671,11 @@ static int one_predict_mw(mik_handle* h, int n_closest) {
       const int grid = (int)(pc < sgrid ? pc : sgrid);
       HIPC(hipFuncSetAttribute((const void*)k_mw_solve_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(k_mw_solve_big, dim3(grid), dim3(256), lds, h->stream, a, sysbuf.as<double>());
+    } else if (cholb) {
+      const size_t lds = sizeof(double) * 2 * MIK_MWP * MIK_MWP_LD;
+      const int grid = (int)std::min<long>(sgrid, pc);
+      HIPC(hipFuncSetAttribute((const void*)k_mw_chol_blocked, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(k_mw_chol_blocked, dim3(grid), dim3(256), lds, h->stream, a, sysbuf.as<double>(), cslot, ldc);
     } else if (chol) {
       MIKC(dispatch_mw_chol(h, a, pc));
     } else {
@@ -2663,7 +2697,7 @@ static int one_predict_mw(mik_handle* h, int n_closest) {
     h->tm.contract_ms += ms;
   }
   h->tm.contract_launches = solve_chunks;
-  h->tm.mw_kernel = chol ? 1 : (big ? 3 : 2);
+  h->tm.mw_kernel = chol ? 1 : cholb ? 4 : (big ? 3 : 2);
   h->tm.rhs_ms = h->tm.predict_ms - h->tm.contract_ms;  // neighbour search + right-hand sides
   if ((flag & 2) && !mw_piv) {  // a local system was not positive definite after the shift: redo with partial pivoting
     h->mw_force_piv = true;
