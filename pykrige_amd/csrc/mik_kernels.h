@@ -1817,6 +1817,11 @@ k_pinv_gemm(const double* __restrict__ B, const double* __restrict__ W, const do
 // tightens tau.  Any station outside rings 0..r is at least r * cell away, so the search stops as soon as
 // tau <= (r * cell)^2: the work per point follows K, not N.  A 1-cell grid is the plain brute-force scan.
 // Ties are broken by station index (what a scan in index order would keep).
+// First pass with a BOUND (round 3): a cell holds ~max(8, K) stations, so a disc of radius sqrt(tau0) < cell around the
+// point is expected to hold K + 4 sqrt(K) + 2 of them, all inside rings 0 and 1.  Only those become candidates: one scan of
+// the 3 x 3 cells and ONE sort of ~1.5 K entries instead of a cut-back sort for every ~2 K candidates (the sorts were 80 % of
+// the search).  If fewer than K stations lie within the bound (sparse corner, point far outside the stations) the walk starts
+// again without it.
 // CAP (a power of two, >= K + 256) candidates: keys[CAP] doubles then vals[CAP] ints of dynamic LDS.
 struct KnnArgs {
   const double *px, *py, *pz;  // points (this chunk)
@@ -1827,6 +1832,7 @@ struct KnnArgs {
   int N, K, CAP;
   int nx, ny, nz;
   double x0, y0, z0, inv_cell, cell2;  // grid origin, 1 / cell edge, cell edge squared
+  double tau0;                         // first-pass bound on the squared distance (<= cell2), 0 = none: see k_mw_knn
   int* idx_out;
   double* dist_out;
 };
@@ -1845,7 +1851,8 @@ __global__ void __launch_bounds__(64) k_mw_knn(KnnArgs a) {
   for (long t = blockIdx.x; t < a.npt; t += gridDim.x) {
     const double qx = a.px[t], qy = a.py[t], qz = (NDIM == 3) ? a.pz[t] : 0.0;
     int cnt = 0;
-    double tau = 1e300;
+    double tau = a.tau0 > 0.0 ? a.tau0 : 1e300;
+    bool bounded = a.tau0 > 0.0;
     // sort the first S = pow2 >= cnt entries ascending by (distance, station index), keep the best K
     auto cut = [&]() {
       int S = 64;
@@ -1934,6 +1941,13 @@ __global__ void __launch_bounds__(64) k_mw_knn(KnnArgs a) {
       }
       const bool all = cx - r <= 0 && cx + r >= a.nx - 1 && cy - r <= 0 && cy + r >= a.ny - 1 &&
                        (NDIM != 3 || (cz - r <= 0 && cz + r >= a.nz - 1));
+      if (bounded && cnt < K && (r >= 1 || all)) {  // the bound was too tight here: again, without it
+        bounded = false;
+        cnt = 0;
+        tau = 1e300;
+        r = -1;
+        continue;
+      }
       if (cnt >= K || all) cut();
       const double reach = (double)r * (double)r * a.cell2;
       if (all || (cnt == K && tau <= reach)) break;

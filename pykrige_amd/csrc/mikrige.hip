@@ -187,6 +187,8 @@ struct mik_handle {
   struct MwGrid {
     int target = -1;  // stations-per-cell target the grid was built for (-1 = none)
     int nx = 1, ny = 1, nz = 1;
+    int live = 0;          // axes along which the stations spread (a flat 3-D set has 2): the dimension of their density
+    double per_cell = 0;   // mean stations per cell of the grid as built
     double x0 = 0, y0 = 0, z0 = 0, cell = 1;
     DevBuf gx, gy, gz, orig, cstart;
   } grid;
@@ -241,6 +243,7 @@ struct mik_handle {
   int opt_mw_solver = 0;      // 0 = LDL^T of the shifted system in registers (default), 1 = the Gauss-Jordan kernels
   bool mw_force_piv = false;
   int opt_mw_lds_cap = 8192;  // largest candidate buffer the moving-window neighbour search keeps in LDS
+  int opt_mw_knn_bound = 1;   // neighbour search: first pass over the 3 x 3 cells with a distance bound (see k_mw_knn)
   int opt_mw_class = 0;       // 100 G + RI: force one thread-grid / register-tile class of k_mw_chol (0 = by window size)
   mik_timing tm{};
   std::vector<hipEvent_t> evpool;
@@ -486,6 +489,8 @@ static int build_mw_grid(mik_handle* h, int target) {
   G.x0 = lo[0], G.y0 = lo[1], G.z0 = lo[2];
   G.cell = cell;
   G.target = target;
+  G.live = live;
+  G.per_cell = (double)N / ((double)n[0] * n[1] * n[2]);
   return MIK_OK;
 }
 
@@ -520,8 +525,8 @@ static int dispatch_mw_chol(mik_handle* h, const MwArgs& a, long pc) {
   if (h->opt_mw_class) {  // "mw_class" = 100 G + RI: a class forced for A/B runs (scripts/mw_classes.py)
     switch (h->opt_mw_class) {
 #define MWC(G, RI) case 100 * G + RI: return launch_mw_chol<G, RI>(h, a, pc);
-      MWC(4, 4) MWC(8, 4) MWC(8, 6) MWC(8, 8) MWC(8, 10) MWC(8, 12) MWC(8, 14) MWC(8, 16)
-      MWC(16, 4) MWC(16, 5) MWC(16, 6) MWC(16, 7) MWC(16, 8) MWC(16, 10) MWC(16, 12) MWC(16, 14) MWC(16, 16)
+      MWC(4, 4) MWC(8, 4) MWC(8, 6) MWC(8, 8) MWC(8, 10) MWC(8, 11) MWC(8, 12) MWC(8, 13) MWC(8, 14) MWC(8, 16)
+      MWC(16, 4) MWC(16, 5) MWC(16, 6) MWC(16, 7) MWC(16, 8) MWC(16, 9) MWC(16, 10) MWC(16, 11) MWC(16, 12) MWC(16, 13) MWC(16, 14) MWC(16, 16)
       MWC(32, 5) MWC(32, 6) MWC(32, 7) MWC(32, 8)
 #undef MWC
       default: return fail(MIK_EINVAL, "mw_class: no such LDL^T class");
@@ -700,7 +705,7 @@ static int set_group(mik_handle* h, int n) {
     k->is_kid = true;
     k->opt_factor = h->opt_factor, k->opt_sym = h->opt_sym, k->opt_engine = h->opt_engine, k->opt_waves = h->opt_waves;
     k->opt_chunk = h->opt_chunk, k->opt_symsweep = h->opt_symsweep, k->opt_diag = h->opt_diag, k->opt_lookahead = h->opt_lookahead, k->opt_gate = h->opt_gate, k->opt_fuse_chain = h->opt_fuse_chain, k->opt_early_diag = h->opt_early_diag, k->opt_pinv_fast = h->opt_pinv_fast, k->opt_rhs_overlap = h->opt_rhs_overlap, k->opt_verify = h->opt_verify, k->verify_tol_z = h->verify_tol_z, k->verify_tol_inv = h->verify_tol_inv;
-    k->opt_mw_class = h->opt_mw_class, k->opt_mw_pivot = h->opt_mw_pivot, k->opt_mw_lds_cap = h->opt_mw_lds_cap, k->opt_pairs = h->opt_pairs, k->opt_mw_solver = h->opt_mw_solver;
+    k->opt_mw_class = h->opt_mw_class, k->opt_mw_knn_bound = h->opt_mw_knn_bound, k->opt_mw_pivot = h->opt_mw_pivot, k->opt_mw_lds_cap = h->opt_mw_lds_cap, k->opt_pairs = h->opt_pairs, k->opt_mw_solver = h->opt_mw_solver;
     k->custom_fn = h->custom_fn, k->custom_user = h->custom_user;
     h->kids.push_back(k);
   }
@@ -813,6 +818,8 @@ int mik_set_option(mik_handle* h, const char* key, double value) {
   } else if (!strcmp(key, "mw_solver")) {
     if (value != 0.0 && value != 1.0) return fail(MIK_EINVAL, "mw_solver must be 0 (LDL^T) or 1 (Gauss-Jordan)");
     h->opt_mw_solver = (int)value;
+  } else if (!strcmp(key, "mw_knn_bound")) {
+    h->opt_mw_knn_bound = value != 0.0;
   } else if (!strcmp(key, "mw_class")) {
     h->opt_mw_class = (int)value;
   } else if (!strcmp(key, "mw_pivot")) {
@@ -2611,6 +2618,14 @@ static int one_predict_mw(mik_handle* h, int n_closest) {
       ka.x0 = h->grid.x0, ka.y0 = h->grid.y0, ka.z0 = h->grid.z0;
       ka.inv_cell = 1.0 / h->grid.cell;
       ka.cell2 = h->grid.cell * h->grid.cell;
+      ka.tau0 = 0.0;
+      if (h->opt_mw_knn_bound && !h->geo && h->grid.live >= 2 && (long)h->grid.nx * h->grid.ny * h->grid.nz > 1) {
+        // radius of the disc / ball expected to hold K + 4 sqrt(K) + 2 of the ~per_cell stations a cell holds; it must stay
+        // inside the 3 x 3 (x 3) cells around the point's cell
+        const double m = K + 4.0 * std::sqrt((double)K) + 2.0, T = std::max(1.0, h->grid.per_cell);
+        const double r2 = h->grid.live == 3 ? std::pow(m / (4.18879020478639 * T), 2.0 / 3.0) : m / (3.14159265358979 * T);
+        if (r2 <= 1.0) ka.tau0 = r2 * ka.cell2;
+      }
       ka.idx_out = idx;
       ka.dist_out = dist;
       if (three) {

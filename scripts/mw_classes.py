@@ -12,9 +12,9 @@ h = _lib.Handle(0)
 h.set_problem(ndim=2, xs=coords[0], ys=coords[1], zs=None, values=values, model_id=_lib.MODEL_IDS[cfg["model"]],
               params=internal_params(cfg["model"], cfg["params"]))
 rng = np.random.default_rng(0)
-CLASSES = [(8, 4), (8, 6), (8, 8), (8, 10), (8, 12), (8, 14), (8, 16), (16, 4), (16, 5), (16, 6), (16, 7), (16, 8), (16, 10), (16, 12), (16, 14), (16, 16),
+CLASSES = [(8, 4), (8, 6), (8, 8), (8, 10), (8, 11), (8, 12), (8, 13), (8, 14), (16, 5), (16, 6), (16, 7), (16, 8), (16, 9), (16, 10), (16, 11), (16, 12), (16, 13), (16, 14), (16, 16),
            (32, 5), (32, 6), (32, 7), (32, 8)]
-ks = [int(a) for a in sys.argv[1:]] or [40, 50, 64, 72, 80, 96, 100, 112, 128, 144, 160, 192, 200, 224, 256, 257, 320, 512]
+ks = [int(a) for a in sys.argv[1:]] or [72, 80, 88, 96, 100, 104, 112, 128, 144, 160, 176, 192, 200, 208, 224, 256, 257, 320, 512, 1000]
 npt = 200000
 px, py = rng.random(npt), rng.random(npt)
 h.set_points(px, py, None)
@@ -25,7 +25,7 @@ for k in ks:
         h.predict_moving_window(k)
         zref = h.get_results()[0]
     for g, ri in CLASSES + [(0, 1)]:  # (0, 1) = the blocked Cholesky kernel of the large windows ("mw_class" 1)
-        if k > 256 or (g and (g * ri < k or g * ri > 2.2 * k + 32)):
+        if k > 256 or (g and (g * ri < k or g * ri > 1.5 * k + 16)) or (not g and k < 128):
             continue
         h.set_option("mw_class", 100 * g + ri)
         try:
