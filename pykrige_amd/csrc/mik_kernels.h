@@ -2530,7 +2530,6 @@ __global__ void __launch_bounds__(256, 2) k_mw_chol_blocked(MwArgs a, double* __
       }
     }
     __syncthreads();
-    const int nrows = ldc + 3;  // matrix rows + the three right-hand sides
     for (int p = 0; p < nP; ++p) {
       const int c0 = p * MIK_MWP;
       // (a) diagonal block -> LDS, row-major, lower part; Cholesky in place
@@ -2560,24 +2559,44 @@ __global__ void __launch_bounds__(256, 2) k_mw_chol_blocked(MwArgs a, double* __
         const int i = e >> 6, k = e & 63;
         if (k <= i) A[(long)(c0 + i) * ldc + c0 + k] = LR[i * MIK_MWP_LD + k];
       }
-      // (b) the rows below: x L^T = a  ->  x_j = (a_j - sum_{k<j} x_k L_jk) / L_jj, one row per thread
-      for (int r = c0 + MIK_MWP + l; r < nrows; r += 256) {
+      // (b) the rows below: x L^T = a  ->  x_j = (a_j - sum_{k<j} x_k L_jk) / L_jj, one row per thread, 16 entries at a time:
+      // the solved part of the row is read back from the scratch slot (a fully unrolled 64-entry register version spilled)
+      // (rows K..ldc-1 are identity padding: zero in this panel, nothing to solve; the thread index runs over the real rows)
+      for (int rr = l; rr < (K - c0 - MIK_MWP > 0 ? K - c0 - MIK_MWP : 0) + 3; rr += 256) {
+        const int nreal = K - c0 - MIK_MWP > 0 ? K - c0 - MIK_MWP : 0;
+        const int r = rr < nreal ? c0 + MIK_MWP + rr : ldc + (rr - nreal);
         double* row = A + (long)r * ldc + c0;
-        double x[MIK_MWP];
+        for (int sb4 = 0; sb4 < 4; ++sb4) {
+          double x[16];
 #pragma unroll
-        for (int k = 0; k < MIK_MWP; k += 2) {
-          const double2 v = *reinterpret_cast<const double2*>(row + k);
-          x[k] = v.x, x[k + 1] = v.y;
+          for (int k = 0; k < 16; k += 2) {
+            const double2 v = *reinterpret_cast<const double2*>(row + 16 * sb4 + k);
+            x[k] = v.x, x[k + 1] = v.y;
+          }
+          for (int q = 0; q < sb4; ++q) {
+            double xq[16];
+#pragma unroll
+            for (int k = 0; k < 16; k += 2) {
+              const double2 v = *reinterpret_cast<const double2*>(row + 16 * q + k);
+              xq[k] = v.x, xq[k + 1] = v.y;
+            }
+            const double* Lb = LR + (16 * sb4) * MIK_MWP_LD + 16 * q;
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+#pragma unroll
+              for (int k = 0; k < 16; ++k) x[j] -= xq[k] * Lb[j * MIK_MWP_LD + k];
+          }
+          const double* Ld = LR + (16 * sb4) * MIK_MWP_LD + 16 * sb4;
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            double sacc = x[j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) sacc -= x[k] * Ld[j * MIK_MWP_LD + k];
+            x[j] = sacc * rdiag[16 * sb4 + j];
+          }
+#pragma unroll
+          for (int k = 0; k < 16; k += 2) *reinterpret_cast<double2*>(row + 16 * sb4 + k) = make_double2(x[k], x[k + 1]);
         }
-#pragma unroll
-        for (int j = 0; j < MIK_MWP; ++j) {
-          double s = x[j];
-#pragma unroll
-          for (int k = 0; k < j; ++k) s -= x[k] * LR[j * MIK_MWP_LD + k];
-          x[j] = s * rdiag[j];
-        }
-#pragma unroll
-        for (int k = 0; k < MIK_MWP; k += 2) *reinterpret_cast<double2*>(row + k) = make_double2(x[k], x[k + 1]);
       }
       __syncthreads();
       // (c) trailing update, tiles (rb, sb) of 64 x 64 with sb <= rb; the right-hand sides are the 3-row block after the matrix
@@ -2586,6 +2605,7 @@ __global__ void __launch_bounds__(256, 2) k_mw_chol_blocked(MwArgs a, double* __
         const bool rhs_blk = rb == nb_rows;
         const int r0 = c0 + MIK_MWP + rb * MIK_MWP;  // == ldc for the right-hand-side block
         if (rhs_blk && nb_rows == 0) break;           // last panel: nothing to the right of it
+        if (!rhs_blk && r0 >= K) continue;            // a row block of identity padding
         // row-block operand, k-major: LR[k][row]
         for (int e = l; e < MIK_MWP * MIK_MWP; e += 256) {
           const int i = e >> 6, k = e & 63;
@@ -2594,6 +2614,7 @@ __global__ void __launch_bounds__(256, 2) k_mw_chol_blocked(MwArgs a, double* __
         const int sb_end = rhs_blk ? nb_rows - 1 : rb;
         for (int sb = 0; sb <= sb_end; ++sb) {
           const int s0 = c0 + MIK_MWP + sb * MIK_MWP;
+          if (s0 >= K) break;  // column blocks of identity padding (block-uniform)
           __syncthreads();  // LR is staged / the previous tile is done with LS
           if (!rhs_blk && sb == rb) {
             for (int e = l; e < MIK_MWP * MIK_MWP_LD; e += 256) LS[e] = LR[e];

@@ -532,13 +532,23 @@ static int dispatch_mw_chol(mik_handle* h, const MwArgs& a, long pc) {
       default: return fail(MIK_EINVAL, "mw_class: no such LDL^T class");
     }
   }
+  // measured per window size (scripts/mw_classes.py, profiles/r03_mw_classes_after_kernel_changes.txt): one wavefront per point
+  // as long as the register tile stays at RI <= 12 (beyond that the compiler parks values in AGPRs: 2 x slower), then 256
+  // threads per point up to RI = 12, 1024 threads for the last two
   if (K <= 16) return launch_mw_chol<4, 4>(h, a, pc);    // 16 threads per point, 4 points per wavefront
-  if (K <= 32) return launch_mw_chol<8, 4>(h, a, pc);    // one wavefront per point from here to K = 64: no workgroup barrier
+  if (K <= 32) return launch_mw_chol<8, 4>(h, a, pc);    // one wavefront per point from here to K = 96: no workgroup barrier
   if (K <= 48) return launch_mw_chol<8, 6>(h, a, pc);
   if (K <= 64) return launch_mw_chol<8, 8>(h, a, pc);
-  if (K <= 96) return launch_mw_chol<16, 6>(h, a, pc);   // 256 threads per point
+  if (K <= 80) return launch_mw_chol<8, 10>(h, a, pc);
+  if (K <= 88) return launch_mw_chol<8, 11>(h, a, pc);
+  if (K <= 96) return launch_mw_chol<8, 12>(h, a, pc);
+  if (K <= 112) return launch_mw_chol<16, 7>(h, a, pc);  // 256 threads per point
   if (K <= 128) return launch_mw_chol<16, 8>(h, a, pc);
-  if (K <= 192) return launch_mw_chol<32, 6>(h, a, pc);  // 1024 threads per point
+  if (K <= 144) return launch_mw_chol<16, 9>(h, a, pc);
+  if (K <= 160) return launch_mw_chol<16, 10>(h, a, pc);
+  if (K <= 176) return launch_mw_chol<16, 11>(h, a, pc);
+  if (K <= 192) return launch_mw_chol<16, 12>(h, a, pc);
+  if (K <= 224) return launch_mw_chol<32, 7>(h, a, pc);  // 1024 threads per point
   return launch_mw_chol<32, 8>(h, a, pc);                // K <= 256
 }
 
