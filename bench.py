@@ -322,7 +322,7 @@ def make_model(cfg, coords, values):
 
 MW_KERNELS = {1: "k_mw_chol", 2: "k_mw_solve", 3: "k_mw_solve_big", 4: "k_mw_chol_blocked"}
 FACTOR_PATHS = {1: "spd-shift block sweep", 2: "pivoted block gauss-jordan", 3: "caller-supplied inverse", 4: "device pseudo-inverse (jacobi)",
-                5: "deflated inverse (pseudo-inverse of duplicated stations)"}
+                5: "deflated inverse (pseudo-inverse of duplicated stations)", 6: "deflated inverse (numerically found null space)"}
 
 
 def main():

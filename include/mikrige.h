@@ -114,7 +114,7 @@ typedef struct mik_timing {
   double predict_ms;      /* whole mik_predict on the stream */
   int64_t contract_launches;
   double contract_flops_executed; /* flops the contraction kernel really executed (symmetric form: ~M^2/pt) */
-  int32_t factor_path;    /* 1 = unpivoted symmetric block sweep on the SPD-shifted matrix, 2 = pivoted block Gauss-Jordan, 3 = caller-supplied inverse, 4 = device pseudo-inverse (one-sided Jacobi), 5 = pseudo-inverse as the regular inverse of the matrix deflated by the duplicated stations' null space (verified with probe vectors) */
+  int32_t factor_path;    /* 1 = unpivoted symmetric block sweep on the SPD-shifted matrix, 2 = pivoted block Gauss-Jordan, 3 = caller-supplied inverse, 4 = device pseudo-inverse (one-sided Jacobi), 5 = pseudo-inverse as the regular inverse of the matrix deflated by the duplicated stations' null space (verified with probe vectors), 6 = pseudo-inverse as the regular inverse of the matrix deflated by a numerically found null space (shift-and-invert subspace iteration + Rayleigh-Ritz; verified the same way) */
   int32_t symmetric;      /* 1 = contraction used the symmetric half product */
   int32_t engine;         /* 0 = v_mfma_f64_4x4x4_4b_f64 contraction, 1 = v_fma_f64 register-tiled contraction */
   int32_t reserved;       /* mik_get_device_timing: the HIP device index of that group member */
@@ -130,6 +130,7 @@ typedef struct mik_timing {
   int32_t half_sweep;          /* 1 = the block sweep maintained only the upper block triangle */
   int32_t factor_attempts;     /* factorisations mik_factor ran: 1, or more when a bad pivot / a failed probe sent it to a more
                                   careful path (half sweep -> full sweep -> partial pivoting) */
+  int32_t null_dim;            /* factor_path 6: dimension of the null space that was found and deflated */
   int32_t rhs_overlapped;      /* 1 = two right-hand-side panels: k_rhs of chunk c + 1 ran on a second stream under chunk c's contraction */
   double verify_ms;            /* the probe of the inverse (all attempts) */
   double verify_res_z;         /* max |A c - [Z; 0]| / max(1, max|Z|), c = A_inv[:, :n] Z: bounds the error of z (last attempt) */

@@ -54,7 +54,7 @@ class MikTiming(C.Structure):
         ("engine", C.c_int32), ("reserved", C.c_int32),
         ("exchange_ms", C.c_double), ("exchange_path", C.c_int32), ("n_devices", C.c_int32),
         ("exchange_wait_ms", C.c_double), ("exchange_fallbacks", C.c_int32), ("rccl_ranks", C.c_int32),
-        ("mw_kernel", C.c_int32), ("half_sweep", C.c_int32), ("factor_attempts", C.c_int32), ("rhs_overlapped", C.c_int32),
+        ("mw_kernel", C.c_int32), ("half_sweep", C.c_int32), ("factor_attempts", C.c_int32), ("null_dim", C.c_int32), ("rhs_overlapped", C.c_int32),
         ("verify_ms", C.c_double), ("verify_res_z", C.c_double), ("verify_res_inv", C.c_double),
     ]
 

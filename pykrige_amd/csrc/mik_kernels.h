@@ -1633,6 +1633,26 @@ __global__ void __launch_bounds__(256) k_coo_add(double* __restrict__ T, long ld
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e < n) T[(long)ij[2 * e] * ld + ij[2 * e + 1]] += sign * val[e];
 }
+// T[i][i] += v for i < m
+__global__ void __launch_bounds__(256) k_shift_diag(double* __restrict__ T, long ld, int m, double v) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < m) T[(long)i * ld + i] += v;
+}
+// T += sign * sum_k n_k n_k^T over the leading m x m block; the r vectors n_k are the rows of Nv (row length ldn)
+__global__ void __launch_bounds__(256) k_lowrank_add(double* __restrict__ T, long ld, int m, const double* __restrict__ Nv, long ldn, int r,
+                                                     double sign) {
+  const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int i0 = blockIdx.y * 64;
+  if (j >= m) return;
+  for (int ii = threadIdx.x >> 6; ii < 64; ii += 4) {
+    const int i = i0 + ii;
+    if (i >= m) break;
+    double s = 0.0;
+    for (int k = 0; k < r; ++k) s += Nv[(long)k * ldn + i] * Nv[(long)k * ldn + j];
+    T[(long)i * ld + j] += sign * s;
+  }
+}
+
 __global__ void __launch_bounds__(256) k_matvec(const double* __restrict__ A, long ld, int m, const double* __restrict__ x,
                                                 double* __restrict__ y) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;

@@ -1265,71 +1265,17 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
   return MIK_OK;
 }
 
-// Pseudo-inverse without an SVD for the case it exists for: DUPLICATED STATIONS (core.py:33, "redundant points are averaged").
-// With a zero nugget two stations at the same place give two identical rows, i.e. the null vector e_i - e_j; for a symmetric A
-// whose null space has the orthonormal basis N,  A + N N^T  is regular and  pinv(A) = (A + N N^T)^-1 - N N^T.  A group of m
-// coincident stations contributes the projector I_m - 11^T / m on its index set.  So: find the groups on the host (exact
-// coordinate equality -- what makes the reference's distances exactly zero), add the projectors, invert with the ordinary
-// shifted sweep (the station block C + N N^T is positive definite again), subtract them.  Nothing is assumed: the result is
-// VERIFIED with probe vectors -- A X A v = A v to 1e-8 and an estimated condition number far below SciPy's cut-off
-// 1 / (M eps), i.e. no singular value the pseudo-inverse would have dropped -- and on any doubt (other rank deficiencies,
-// near-singular matrices, a flagged pivot) *done stays false and the caller runs the Jacobi pseudo-inverse.
-static int run_deflated_inverse(mik_handle* h, bool* done) {
+// Is the matrix X in T provably the Moore-Penrose inverse of the kriging matrix?  Probe vectors against the matrix itself
+// (assembled again, unshifted, into a scratch buffer): A X A v = A v and X A X v = X v to 1e-8 -- the second condition is what
+// tells the pseudo-inverse from the other generalised inverses pinv(A) + c P with A P = 0 -- and an estimated condition number
+// far below SciPy's cut-off 1 / (M eps), i.e. no singular value the pseudo-inverse would have dropped.
+static int verify_pinv(mik_handle* h, bool* done) {
   *done = false;
-  if (h->model == MIK_MODEL_CUSTOM || !h->opt_pinv_fast) return MIK_OK;
-  const int N = h->N, M = h->M;
+  const int M = h->M;
   const long ld = h->Mp;
-  const double nugget = (h->v.model == 0) ? h->v.p1 : h->v.p2;
-  std::vector<int> ij;
-  std::vector<double> val;
-  if (nugget == 0.0) {
-    std::vector<int> order(N);
-    for (int i = 0; i < N; ++i) order[i] = i;
-    const bool three = h->ndim == 3;
-    auto less = [&](int a, int b) {
-      if (h->hxs[a] != h->hxs[b]) return h->hxs[a] < h->hxs[b];
-      if (h->hys[a] != h->hys[b]) return h->hys[a] < h->hys[b];
-      if (three && h->hzs[a] != h->hzs[b]) return h->hzs[a] < h->hzs[b];
-      return a < b;
-    };
-    auto same = [&](int a, int b) { return h->hxs[a] == h->hxs[b] && h->hys[a] == h->hys[b] && (!three || h->hzs[a] == h->hzs[b]); };
-    std::sort(order.begin(), order.end(), less);
-    for (int s0 = 0; s0 < N;) {
-      int s1 = s0 + 1;
-      while (s1 < N && same(order[s0], order[s1])) ++s1;
-      const int m = s1 - s0;
-      if (m > 1) {
-        if ((long)val.size() + (long)m * m > 4000000L) return MIK_OK;  // absurdly many duplicates: leave it to the general path
-        for (int a = s0; a < s1; ++a)
-          for (int b = s0; b < s1; ++b) {
-            ij.push_back(order[a]);
-            ij.push_back(order[b]);
-            val.push_back((a == b ? 1.0 : 0.0) - 1.0 / m);
-          }
-      }
-      s0 = s1;
-    }
-  }
-  const int ne = (int)val.size();
-  DevBuf dij, dval, A2, vec;
-  if (ne) {
-    MIKC(dij.ensure(sizeof(int) * ij.size()));
-    MIKC(dval.ensure(sizeof(double) * val.size()));
-    HIPC(hipMemcpyAsync(dij.p, ij.data(), sizeof(int) * ij.size(), hipMemcpyHostToDevice, h->stream));
-    HIPC(hipMemcpyAsync(dval.p, val.data(), sizeof(double) * val.size(), hipMemcpyHostToDevice, h->stream));
-  }
-  const double shift = h->shift_guess;
-  MIKC(launch_assemble(h, shift));
-  if (ne) hipLaunchKernelGGL(k_coo_add, dim3((ne + 255) / 256), dim3(256), 0, h->stream, h->T.as<double>(), ld, (const int*)dij.as<int>(),
-                             (const double*)dval.as<double>(), ne, 1.0);
-  int flag = 0;
-  MIKC(run_block_inverse(h, false, N, &flag));
-  if (flag) return MIK_OK;
-  hipLaunchKernelGGL(k_add_diag, dim3(1), dim3(1), 0, h->stream, h->T.as<double>(), ld, M - 1, shift);
-  if (ne) hipLaunchKernelGGL(k_coo_add, dim3((ne + 255) / 256), dim3(256), 0, h->stream, h->T.as<double>(), ld, (const int*)dij.as<int>(),
-                             (const double*)dval.as<double>(), ne, -1.0);
-  // verification against the matrix itself (assembled again, unshifted, into a scratch buffer)
-  MIKC(A2.ensure(sizeof(double) * (size_t)h->Mp * h->Mp));
+  DevBuf vec;
+  MIKC(h->Averify.ensure(sizeof(double) * (size_t)h->Mp * h->Mp));
+  DevBuf& A2 = h->Averify;
   MIKC(launch_assemble(h, 0.0, A2.as<double>()));
   constexpr int NPROBE = 3;
   MIKC(vec.ensure(sizeof(double) * 4 * (size_t)h->Mp));
@@ -1384,6 +1330,73 @@ static int run_deflated_inverse(mik_handle* h, bool* done) {
   return MIK_OK;
 }
 
+
+// Pseudo-inverse without an SVD for the case it exists for: DUPLICATED STATIONS (core.py:33, "redundant points are averaged").
+// With a zero nugget two stations at the same place give two identical rows, i.e. the null vector e_i - e_j; for a symmetric A
+// whose null space has the orthonormal basis N,  A + N N^T  is regular and  pinv(A) = (A + N N^T)^-1 - N N^T.  A group of m
+// coincident stations contributes the projector I_m - 11^T / m on its index set.  So: find the groups on the host (exact
+// coordinate equality -- what makes the reference's distances exactly zero), add the projectors, invert with the ordinary
+// shifted sweep (the station block C + N N^T is positive definite again), subtract them.  Nothing is assumed: the result is
+// VERIFIED with probe vectors -- A X A v = A v to 1e-8 and an estimated condition number far below SciPy's cut-off
+// 1 / (M eps), i.e. no singular value the pseudo-inverse would have dropped -- and on any doubt (other rank deficiencies,
+// near-singular matrices, a flagged pivot) *done stays false and the caller runs the Jacobi pseudo-inverse.
+static int run_deflated_inverse(mik_handle* h, bool* done) {
+  *done = false;
+  if (h->model == MIK_MODEL_CUSTOM || !h->opt_pinv_fast) return MIK_OK;
+  const int N = h->N, M = h->M;
+  const long ld = h->Mp;
+  const double nugget = (h->v.model == 0) ? h->v.p1 : h->v.p2;
+  std::vector<int> ij;
+  std::vector<double> val;
+  if (nugget == 0.0) {
+    std::vector<int> order(N);
+    for (int i = 0; i < N; ++i) order[i] = i;
+    const bool three = h->ndim == 3;
+    auto less = [&](int a, int b) {
+      if (h->hxs[a] != h->hxs[b]) return h->hxs[a] < h->hxs[b];
+      if (h->hys[a] != h->hys[b]) return h->hys[a] < h->hys[b];
+      if (three && h->hzs[a] != h->hzs[b]) return h->hzs[a] < h->hzs[b];
+      return a < b;
+    };
+    auto same = [&](int a, int b) { return h->hxs[a] == h->hxs[b] && h->hys[a] == h->hys[b] && (!three || h->hzs[a] == h->hzs[b]); };
+    std::sort(order.begin(), order.end(), less);
+    for (int s0 = 0; s0 < N;) {
+      int s1 = s0 + 1;
+      while (s1 < N && same(order[s0], order[s1])) ++s1;
+      const int m = s1 - s0;
+      if (m > 1) {
+        if ((long)val.size() + (long)m * m > 4000000L) return MIK_OK;  // absurdly many duplicates: leave it to the general path
+        for (int a = s0; a < s1; ++a)
+          for (int b = s0; b < s1; ++b) {
+            ij.push_back(order[a]);
+            ij.push_back(order[b]);
+            val.push_back((a == b ? 1.0 : 0.0) - 1.0 / m);
+          }
+      }
+      s0 = s1;
+    }
+  }
+  const int ne = (int)val.size();
+  DevBuf dij, dval;
+  if (ne) {
+    MIKC(dij.ensure(sizeof(int) * ij.size()));
+    MIKC(dval.ensure(sizeof(double) * val.size()));
+    HIPC(hipMemcpyAsync(dij.p, ij.data(), sizeof(int) * ij.size(), hipMemcpyHostToDevice, h->stream));
+    HIPC(hipMemcpyAsync(dval.p, val.data(), sizeof(double) * val.size(), hipMemcpyHostToDevice, h->stream));
+  }
+  const double shift = h->shift_guess;
+  MIKC(launch_assemble(h, shift));
+  if (ne) hipLaunchKernelGGL(k_coo_add, dim3((ne + 255) / 256), dim3(256), 0, h->stream, h->T.as<double>(), ld, (const int*)dij.as<int>(),
+                             (const double*)dval.as<double>(), ne, 1.0);
+  int flag = 0;
+  MIKC(run_block_inverse(h, false, N, &flag));
+  if (flag) return MIK_OK;
+  hipLaunchKernelGGL(k_add_diag, dim3(1), dim3(1), 0, h->stream, h->T.as<double>(), ld, M - 1, shift);
+  if (ne) hipLaunchKernelGGL(k_coo_add, dim3((ne + 255) / 256), dim3(256), 0, h->stream, h->T.as<double>(), ld, (const int*)dij.as<int>(),
+                             (const double*)dval.as<double>(), ne, -1.0);
+  return verify_pinv(h, done);
+}
+
 // Probe of the inverse X in T against the matrix itself (assembled again, unshifted, into a scratch buffer):
 //   res_z   = max |A c - [Z; 0]| / max(1, max|Z|)   with c = X[:, :N] Z: every z_g = c.b_g is w_g.(A c) with the kriging weights
 //             w_g of the point (sum 1, |w|_1 of order 1..10), so the error of z is bounded by |w_g|_1 res_z max|Z|;
@@ -1419,6 +1432,201 @@ static int verify_inverse(mik_handle* h, double* res_z, double* res_inv) {
   }
   *res_z = rz / zmax;
   *res_inv = ri;
+  return MIK_OK;
+}
+
+// Pseudo-inverse of a symmetric matrix with a SMALL null space of unknown origin (round 3; e.g. collinear stations under a
+// regional-linear drift: two drift columns become dependent) without a decomposition of the whole matrix:
+//   1. sigma = 1e-7 |A|: (A - sigma I)^-1 by the pivoted block inverse turns the eigenvalues lambda into 1 / (lambda - sigma), so the null
+//      space stands out by a factor |lambda_min| / sigma; two rounds of subspace iteration with b = 24 random vectors;
+//   2. Rayleigh-Ritz of A on that subspace (a b x b symmetric eigenproblem, host Jacobi): Ritz pairs with |theta| and residual below
+//      1e3 M eps |A| are null vectors N (b of them = the null space may be larger than the subspace: give up);
+//   3. pinv(A) = (A + N N^T)^-1 - N N^T (the identity of the duplicated-stations path), pivoted block inverse;
+//   4. verify_pinv: both Penrose conditions and the condition estimate.  On any doubt *done stays false and the caller runs the
+//      one-sided Jacobi pseudo-inverse (7.8 s at M = 4000 against ~0.2 s here).
+static int run_nullspace_inverse(mik_handle* h, bool* done) {
+  *done = false;
+  if (h->model == MIK_MODEL_CUSTOM || !h->opt_pinv_fast) return MIK_OK;
+  const int M = h->M, Mp = h->Mp;
+  const long ld = Mp;
+  constexpr int B = 24;
+  const double eps = 2.220446049250313e-16;
+  const unsigned mg = (unsigned)((M + 3) / 4);
+  MIKC(h->Averify.ensure(sizeof(double) * (size_t)Mp * Mp));
+  MIKC(launch_assemble(h, 0.0, h->Averify.as<double>()));
+  const double* A2 = h->Averify.as<double>();
+  DevBuf dq, dw;
+  MIKC(dq.ensure(sizeof(double) * (size_t)B * Mp));
+  MIKC(dw.ensure(sizeof(double) * (size_t)B * Mp));
+  double* Q = dq.as<double>();
+  double* W = dw.as<double>();
+  std::vector<double> hq((size_t)B * M), hw((size_t)B * M);
+  unsigned long long seed = 0x243F6A8885A308D3ull;
+  auto rnd = [&]() {
+    seed = seed * 6364136223846793005ull + 1442695040888963407ull;
+    return (double)((seed >> 11) & 0xFFFFFFFFull) / 4294967296.0 - 0.5;
+  };
+  auto upload = [&](const std::vector<double>& v, double* dst) -> int {
+    HIPC(hipMemcpy2DAsync(dst, sizeof(double) * Mp, v.data(), sizeof(double) * M, sizeof(double) * M, B, hipMemcpyHostToDevice, h->stream));
+    return MIK_OK;
+  };
+  auto download = [&](std::vector<double>& v, const double* src) -> int {
+    HIPC(hipMemcpy2DAsync(v.data(), sizeof(double) * M, src, sizeof(double) * Mp, sizeof(double) * M, B, hipMemcpyDeviceToHost, h->stream));
+    HIPC(hipStreamSynchronize(h->stream));
+    return MIK_OK;
+  };
+  auto apply = [&](const double* Mat, const double* src, double* dst) {  // dst_k = Mat src_k, k < B (rows of length Mp)
+    for (int k = 0; k < B; ++k)
+      hipLaunchKernelGGL(k_matvec, dim3(mg), dim3(256), 0, h->stream, Mat, ld, M, src + (size_t)k * Mp, dst + (size_t)k * Mp);
+  };
+  auto mgs = [&](std::vector<double>& v) {  // modified Gram-Schmidt (twice) on the B rows of v; false if a row vanishes
+    for (int pass = 0; pass < 2; ++pass)
+      for (int a = 0; a < B; ++a) {
+        double* va = v.data() + (size_t)a * M;
+        for (int b = 0; b < a; ++b) {
+          const double* vb = v.data() + (size_t)b * M;
+          double d = 0.0;
+          for (int i = 0; i < M; ++i) d += va[i] * vb[i];
+          for (int i = 0; i < M; ++i) va[i] -= d * vb[i];
+        }
+        double n2 = 0.0;
+        for (int i = 0; i < M; ++i) n2 += va[i] * va[i];
+        if (!(n2 > 1e-300) || !std::isfinite(n2)) return false;
+        const double inv = 1.0 / std::sqrt(n2);
+        for (int i = 0; i < M; ++i) va[i] *= inv;
+      }
+    return true;
+  };
+  // |A| by a few power iterations
+  double anorm = 0.0;
+  {
+    for (int i = 0; i < M; ++i) hq[i] = rnd();
+    for (int it = 0; it < 6; ++it) {
+      double n2 = 0.0;
+      for (int i = 0; i < M; ++i) n2 += hq[i] * hq[i];
+      const double inv = 1.0 / std::sqrt(n2);
+      for (int i = 0; i < M; ++i) hq[i] *= inv;
+      HIPC(hipMemcpyAsync(Q, hq.data(), sizeof(double) * M, hipMemcpyHostToDevice, h->stream));
+      hipLaunchKernelGGL(k_matvec, dim3(mg), dim3(256), 0, h->stream, A2, ld, M, (const double*)Q, W);
+      HIPC(hipMemcpyAsync(hq.data(), W, sizeof(double) * M, hipMemcpyDeviceToHost, h->stream));
+      HIPC(hipStreamSynchronize(h->stream));
+      n2 = 0.0;
+      for (int i = 0; i < M; ++i) n2 += hq[i] * hq[i];
+      anorm = std::sqrt(n2);
+    }
+  }
+  if (!(anorm > 0.0) || !std::isfinite(anorm)) return MIK_OK;
+  const double tol_null = 1e3 * (double)M * eps * anorm;
+  // 1. (A - sigma I)^-1
+  const double sigma = 1e-7 * anorm;
+  MIKC(launch_assemble(h, 0.0));
+  hipLaunchKernelGGL(k_shift_diag, dim3((M + 255) / 256), dim3(256), 0, h->stream, h->T.as<double>(), ld, M, -sigma);
+  int flag = 0;
+  MIKC(run_block_inverse(h, true, 0, &flag));
+  if (flag) return MIK_OK;
+  for (size_t i = 0; i < hq.size(); ++i) hq[i] = rnd();
+  if (!mgs(hq)) return MIK_OK;
+  for (int round = 0; round < 2; ++round) {
+    MIKC(upload(hq, Q));
+    apply(h->T.as<double>(), Q, W);
+    MIKC(download(hq, W));
+    if (!mgs(hq)) return MIK_OK;
+  }
+  // 2. Rayleigh-Ritz of A on span(Q)
+  MIKC(upload(hq, Q));
+  apply(A2, Q, W);
+  HIPC(hipGetLastError());
+  MIKC(download(hw, W));  // rows: A q_k
+  double H[B][B], S[B][B];
+  for (int a = 0; a < B; ++a)
+    for (int b = 0; b < B; ++b) {
+      double d = 0.0;
+      for (int i = 0; i < M; ++i) d += hq[(size_t)a * M + i] * hw[(size_t)b * M + i];
+      H[a][b] = d;
+      S[a][b] = a == b ? 1.0 : 0.0;
+    }
+  for (int a = 0; a < B; ++a)
+    for (int b = 0; b < a; ++b) H[a][b] = H[b][a] = 0.5 * (H[a][b] + H[b][a]);
+  for (int sweep = 0; sweep < 60; ++sweep) {  // cyclic Jacobi on the B x B matrix
+    double off = 0.0;
+    for (int a = 0; a < B; ++a)
+      for (int b = a + 1; b < B; ++b) off += H[a][b] * H[a][b];
+    if (off <= 1e-60) break;
+    for (int p = 0; p < B; ++p)
+      for (int q = p + 1; q < B; ++q) {
+        if (H[p][q] == 0.0) continue;
+        const double th = (H[q][q] - H[p][p]) / (2.0 * H[p][q]);
+        const double t = (th >= 0.0 ? 1.0 : -1.0) / (std::fabs(th) + std::sqrt(th * th + 1.0));
+        const double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
+        for (int k = 0; k < B; ++k) {
+          const double hkp = H[k][p], hkq = H[k][q];
+          H[k][p] = c * hkp - sn * hkq;
+          H[k][q] = sn * hkp + c * hkq;
+        }
+        for (int k = 0; k < B; ++k) {
+          const double hpk = H[p][k], hqk = H[q][k];
+          H[p][k] = c * hpk - sn * hqk;
+          H[q][k] = sn * hpk + c * hqk;
+        }
+        for (int k = 0; k < B; ++k) {
+          const double skp = S[k][p], skq = S[k][q];
+          S[k][p] = c * skp - sn * skq;
+          S[k][q] = sn * skp + c * skq;
+        }
+      }
+  }
+  std::vector<double> hn;  // null vectors, rows of length M
+  int r = 0;
+  for (int e = 0; e < B; ++e) {
+    const double theta = H[e][e];
+    if (!(std::fabs(theta) <= tol_null)) continue;
+    std::vector<double> y(M, 0.0), ay(M, 0.0);
+    for (int k = 0; k < B; ++k) {
+      const double sk = S[k][e];
+      const double* qk = hq.data() + (size_t)k * M;
+      const double* aq = hw.data() + (size_t)k * M;
+      for (int i = 0; i < M; ++i) y[i] += sk * qk[i], ay[i] += sk * aq[i];
+    }
+    double res2 = 0.0;
+    for (int i = 0; i < M; ++i) res2 += ay[i] * ay[i];
+    if (!(std::sqrt(res2) <= tol_null)) continue;  // small Ritz value, but not an eigenvector of A to that accuracy
+    hn.insert(hn.end(), y.begin(), y.end());
+    ++r;
+  }
+  if (r >= B) return MIK_OK;  // the null space may be larger than the subspace
+  // 3. (A + N N^T)^-1 - N N^T
+  DevBuf dn;
+  if (r > 0) {
+    // re-orthonormalise the null vectors among themselves
+    for (int pass = 0; pass < 2; ++pass)
+      for (int a = 0; a < r; ++a) {
+        double* va = hn.data() + (size_t)a * M;
+        for (int b = 0; b < a; ++b) {
+          const double* vb = hn.data() + (size_t)b * M;
+          double d = 0.0;
+          for (int i = 0; i < M; ++i) d += va[i] * vb[i];
+          for (int i = 0; i < M; ++i) va[i] -= d * vb[i];
+        }
+        double n2 = 0.0;
+        for (int i = 0; i < M; ++i) n2 += va[i] * va[i];
+        if (!(n2 > 0.25)) return MIK_OK;
+        const double inv = 1.0 / std::sqrt(n2);
+        for (int i = 0; i < M; ++i) va[i] *= inv;
+      }
+    MIKC(dn.ensure(sizeof(double) * (size_t)r * M));
+    HIPC(hipMemcpyAsync(dn.p, hn.data(), sizeof(double) * (size_t)r * M, hipMemcpyHostToDevice, h->stream));
+  }
+  MIKC(launch_assemble(h, 0.0));
+  const dim3 lg((M + 63) / 64, (M + 63) / 64);
+  // the projector is scaled to the matrix (|A| N N^T): the deflated matrix keeps the conditioning of A's range
+  const double scale = anorm;
+  if (r > 0) hipLaunchKernelGGL(k_lowrank_add, lg, dim3(256), 0, h->stream, h->T.as<double>(), ld, M, (const double*)dn.as<double>(), (long)M, r, scale);
+  MIKC(run_block_inverse(h, true, 0, &flag));
+  if (flag) return MIK_OK;
+  if (r > 0) hipLaunchKernelGGL(k_lowrank_add, lg, dim3(256), 0, h->stream, h->T.as<double>(), ld, M, (const double*)dn.as<double>(), (long)M, r, -1.0 / scale);
+  HIPC(hipGetLastError());
+  h->tm.null_dim = r;
+  MIKC(verify_pinv(h, done));
   return MIK_OK;
 }
 
@@ -1477,6 +1685,18 @@ static int one_factor(mik_handle* h) {
         HIPC(hipEventElapsedTime(&ms0, h->evpool[0], h->evpool[2]));
         h->tm.invert_ms = ms0;
         h->tm.factor_path = 5;
+        return finish_factor(h);
+      }
+      // any other small null space: found numerically, deflated, verified (factor_path 6)
+      HIPC(hipEventRecord(h->evpool[0], h->stream));
+      MIKC(run_nullspace_inverse(h, &done));
+      if (done) {
+        HIPC(hipEventRecord(h->evpool[2], h->stream));
+        HIPC(hipStreamSynchronize(h->stream));
+        float ms0 = 0.f;
+        HIPC(hipEventElapsedTime(&ms0, h->evpool[0], h->evpool[2]));
+        h->tm.invert_ms = ms0;
+        h->tm.factor_path = 6;
         return finish_factor(h);
       }
     }

@@ -743,9 +743,10 @@ def test_integration_md_stub_runs_as_written():
 
 
 def test_pseudo_inverse_fast_path_refuses_what_it_cannot_prove():
-    """The deflated-inverse shortcut of pseudo_inv covers duplicated stations (zero nugget).  Other rank deficiencies -- here
-    collinear stations under a regional-linear drift, which make two drift columns linearly dependent -- must end in the general
-    Jacobi pseudo-inverse (factor_path 4), and a regular matrix must come back as its plain inverse (factor_path 5)."""
+    """pseudo_inv on a rank deficiency that is NOT duplicated stations -- collinear stations under a regional-linear drift make
+    two drift columns linearly dependent -- : the null space is found numerically and deflated (factor_path 6, round 3), the
+    result is scipy.linalg.pinv's; with the fast paths switched off the one-sided Jacobi pseudo-inverse (factor_path 4) gives
+    the same matrix; and a regular matrix comes back as its plain inverse (factor_path 5)."""
     import scipy.linalg
 
     lib = _lib()
@@ -762,9 +763,34 @@ def test_pseudo_inverse_fast_path_refuses_what_it_cannot_prove():
     h.set_problem(ndim=2, xs=st.coords_adj[:, 0], ys=st.coords_adj[:, 1], zs=None, values=v, model_id=lib.MODEL_IDS["exponential"],
                   params=st.params, regional_linear=True, pseudo_inv=1)
     h.factor()
-    assert h.timing()["factor_path"] == 4
+    t = h.timing()
+    assert t["factor_path"] == 6 and t["null_dim"] == 1, t
     pinv = scipy.linalg.pinv(a)
+    fast = h.get_matrix(1)
+    assert np.abs(fast - pinv).max() <= 1e-8 * np.abs(pinv).max()
+    h.set_option("pinv_fast", 0)
+    h.factor()
+    assert h.timing()["factor_path"] == 4
     assert np.abs(h.get_matrix(1) - pinv).max() <= 1e-8 * np.abs(pinv).max()
+    h.set_option("pinv_fast", 1)
+    # a larger case of the same kind with duplicated stations on top (null space: 1 from the drift + 3 from the duplicates)
+    n2 = 700
+    x2 = rng.random(n2)
+    x2[-3:] = x2[:3]
+    y2l = 0.5 * x2 - 0.1
+    v2 = np.cos(3 * x2) + 0.1 * rng.standard_normal(n2)
+    stb = ko.KrigingState(ndim=2, coords_orig=np.stack([x2, y2l], 1), values=v2, model="exponential",
+                          params=ko.internal_parameters("exponential", [1.0, 0.5, 0.0]), regional_linear=True)
+    ab = ko.kriging_matrix(stb)
+    h.set_problem(ndim=2, xs=stb.coords_adj[:, 0], ys=stb.coords_adj[:, 1], zs=None, values=v2, model_id=lib.MODEL_IDS["exponential"],
+                  params=stb.params, regional_linear=True, pseudo_inv=1)
+    h.factor()
+    t = h.timing()
+    pinvb = scipy.linalg.pinv(ab)
+    print("collinear + duplicates, M = %d: factor_path %d, null_dim %d, invert %.1f ms, max|X - pinv| / max|pinv| = %.1e"
+          % (ab.shape[0], t["factor_path"], t["null_dim"], t["invert_ms"], np.abs(h.get_matrix(1) - pinvb).max() / np.abs(pinvb).max()))
+    assert t["factor_path"] == 6 and t["null_dim"] == 4
+    assert np.abs(h.get_matrix(1) - pinvb).max() <= 1e-8 * np.abs(pinvb).max()
     # regular matrix, pseudo_inv requested: the plain inverse, verified
     y2 = rng.random(n)
     st2 = ko.KrigingState(ndim=2, coords_orig=np.stack([x, y2], 1), values=v, model="exponential",
