@@ -1437,13 +1437,15 @@ static int verify_inverse(mik_handle* h, double* res_z, double* res_inv) {
 
 // Pseudo-inverse of a symmetric matrix with a SMALL null space of unknown origin (round 3; e.g. collinear stations under a
 // regional-linear drift: two drift columns become dependent) without a decomposition of the whole matrix:
-//   1. sigma = 1e-7 |A|: (A - sigma I)^-1 by the pivoted block inverse turns the eigenvalues lambda into 1 / (lambda - sigma), so the null
-//      space stands out by a factor |lambda_min| / sigma; two rounds of subspace iteration with b = 24 random vectors;
-//   2. Rayleigh-Ritz of A on that subspace (a b x b symmetric eigenproblem, host Jacobi): Ritz pairs with |theta| and residual below
-//      1e3 M eps |A| are null vectors N (b of them = the null space may be larger than the subspace: give up);
-//   3. pinv(A) = (A + N N^T)^-1 - N N^T (the identity of the duplicated-stations path), pivoted block inverse;
-//   4. verify_pinv: both Penrose conditions and the condition estimate.  On any doubt *done stays false and the caller runs the
-//      one-sided Jacobi pseudo-inverse (7.8 s at M = 4000 against ~0.2 s here).
+//   1. sigma = 1e-10 |A| (far below any eigenvalue a kriging matrix of cond <= 1e8 has, far above the rounding of the zero ones):
+//      (A - sigma I)^-1 by the pivoted block inverse turns the eigenvalues lambda into 1 / (lambda - sigma), so the null space stands
+//      out by a factor |lambda_min| / sigma; three rounds of subspace iteration with b = 24 random vectors;
+//   2. Rayleigh-Ritz of A on that subspace (a b x b symmetric eigenproblem, host Jacobi): Ritz pairs with |theta| <= 1e-11 |A| and a
+//      small residual are null vectors N (b of them = the null space may be larger than the subspace: give up);
+//   3. pinv(A) = (A + |A| N N^T)^-1 - N N^T / |A| (the identity of the duplicated-stations path), pivoted block inverse;
+//   4. the result is checked where it is most sensitive -- A X u = u for the OTHER Ritz vectors u, the directions of A's smallest
+//      non-zero eigenvalues, to 1e-7 -- and then by verify_pinv (both Penrose conditions on random probes, condition estimate).
+//      On any doubt *done stays false and the caller runs the one-sided Jacobi pseudo-inverse (9.3 s at M = 4000 against ~0.2 s).
 static int run_nullspace_inverse(mik_handle* h, bool* done) {
   *done = false;
   if (h->model == MIK_MODEL_CUSTOM || !h->opt_pinv_fast) return MIK_OK;
@@ -1516,9 +1518,13 @@ static int run_nullspace_inverse(mik_handle* h, bool* done) {
     }
   }
   if (!(anorm > 0.0) || !std::isfinite(anorm)) return MIK_OK;
-  const double tol_null = 1e3 * (double)M * eps * anorm;
+  // "zero" eigenvalue: SciPy's pinv drops singular values below M eps |A| (1e-13 .. 1e-12 |A|).  The null vectors come out of a
+  // shift-and-invert iteration whose accuracy is eps |A| / lambda_min, so the classification here is |theta| <= 1e-11 |A|
+  // with a residual |A y| <= 1e-9 |A|; an eigenvalue between the two cut-offs would make SciPy's own result rounding noise
+  // (1 / lambda >= 1e11), and the checks below send anything that ill-conditioned to the Jacobi path anyway.
+  const double tol_null = std::max(1e3 * (double)M * eps, 1e-11) * anorm, tol_res = 1e-9 * anorm;
   // 1. (A - sigma I)^-1
-  const double sigma = 1e-7 * anorm;
+  const double sigma = 1e-10 * anorm;
   MIKC(launch_assemble(h, 0.0));
   hipLaunchKernelGGL(k_shift_diag, dim3((M + 255) / 256), dim3(256), 0, h->stream, h->T.as<double>(), ld, M, -sigma);
   int flag = 0;
@@ -1526,7 +1532,7 @@ static int run_nullspace_inverse(mik_handle* h, bool* done) {
   if (flag) return MIK_OK;
   for (size_t i = 0; i < hq.size(); ++i) hq[i] = rnd();
   if (!mgs(hq)) return MIK_OK;
-  for (int round = 0; round < 2; ++round) {
+  for (int round = 0; round < 3; ++round) {
     MIKC(upload(hq, Q));
     apply(h->T.as<double>(), Q, W);
     MIKC(download(hq, W));
@@ -1576,10 +1582,13 @@ static int run_nullspace_inverse(mik_handle* h, bool* done) {
       }
   }
   std::vector<double> hn;  // null vectors, rows of length M
+  std::vector<double> hu;  // the other Ritz vectors (directions of the smallest non-zero eigenvalues of A), for the check of step 4
   int r = 0;
+  const bool dbg = getenv("MIK_DEBUG_PINV") != nullptr;
+  if (dbg) fprintf(stderr, "[pinv] M %d |A| %.3e sigma %.3e tol_null %.3e\n", M, anorm, sigma, tol_null);
   for (int e = 0; e < B; ++e) {
     const double theta = H[e][e];
-    if (!(std::fabs(theta) <= tol_null)) continue;
+    if (dbg) fprintf(stderr, "[pinv] ritz %d theta %.3e\n", e, theta);
     std::vector<double> y(M, 0.0), ay(M, 0.0);
     for (int k = 0; k < B; ++k) {
       const double sk = S[k][e];
@@ -1587,9 +1596,14 @@ static int run_nullspace_inverse(mik_handle* h, bool* done) {
       const double* aq = hw.data() + (size_t)k * M;
       for (int i = 0; i < M; ++i) y[i] += sk * qk[i], ay[i] += sk * aq[i];
     }
+    if (!(std::fabs(theta) <= tol_null)) {
+      hu.insert(hu.end(), y.begin(), y.end());
+      continue;
+    }
     double res2 = 0.0;
     for (int i = 0; i < M; ++i) res2 += ay[i] * ay[i];
-    if (!(std::sqrt(res2) <= tol_null)) continue;  // small Ritz value, but not an eigenvector of A to that accuracy
+    if (dbg) fprintf(stderr, "[pinv]   residual %.3e\n", std::sqrt(res2));
+    if (!(std::sqrt(res2) <= tol_res)) return MIK_OK;  // a tiny Ritz value that is not an eigenpair of A to that accuracy: no proof
     hn.insert(hn.end(), y.begin(), y.end());
     ++r;
   }
@@ -1626,6 +1640,28 @@ static int run_nullspace_inverse(mik_handle* h, bool* done) {
   if (r > 0) hipLaunchKernelGGL(k_lowrank_add, lg, dim3(256), 0, h->stream, h->T.as<double>(), ld, M, (const double*)dn.as<double>(), (long)M, r, -1.0 / scale);
   HIPC(hipGetLastError());
   h->tm.null_dim = r;
+  {  // A X u = u on the non-null Ritz vectors
+    const int nu = B - r;
+    hq.assign((size_t)B * M, 0.0);
+    std::copy(hu.begin(), hu.end(), hq.begin());
+    MIKC(upload(hq, Q));
+    apply(h->T.as<double>(), Q, W);   // X u
+    apply(A2, W, Q);                  // A X u
+    HIPC(hipGetLastError());
+    MIKC(download(hw, Q));
+    double worst = 0.0;
+    for (int k = 0; k < nu; ++k) {
+      double d2 = 0.0, n2 = 0.0;
+      for (int i = 0; i < M; ++i) {
+        const double u = hu[(size_t)k * M + i], d = hw[(size_t)k * M + i] - u;
+        d2 += d * d;
+        n2 += u * u;
+      }
+      worst = std::max(worst, std::sqrt(d2 / std::max(n2, 1e-300)));
+    }
+    if (dbg) fprintf(stderr, "[pinv] null_dim %d, worst |A X u - u| / |u| over %d Ritz vectors: %.3e\n", r, nu, worst);
+    if (!(worst <= 1e-7)) return MIK_OK;
+  }
   MIKC(verify_pinv(h, done));
   return MIK_OK;
 }
