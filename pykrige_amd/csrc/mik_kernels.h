@@ -441,11 +441,13 @@ __global__ void __launch_bounds__(256) k_rhs(RhsArgs a) {
 // no staging VGPRs, no ds_write).  Bank conflicts of the fragment reads are removed by an XOR swizzle
 // applied to the per-lane SOURCE address and to the reads: element (row r, k) lives in 16-byte slot
 // ((k>>1) ^ swz(r)) of row r, swz = r & 2 for the A tile and (r>>1) & 7 for the B tile.
-struct GemmSmem {
-  double As[2][MIK_BM][MIK_BK];
+template <int BM>
+struct GemmSmemT {
+  double As[2][BM][MIK_BK];
   double Bs[2][MIK_BN][MIK_BK];
   long next;  // persistent kernels: the queue position broadcast to the block (kept inside the one LDS object)
 };
+typedef GemmSmemT<MIK_BM> GemmSmem;
 
 typedef __attribute__((address_space(1))) const void* mik_gptr_t;
 typedef __attribute__((address_space(3))) void* mik_lptr_t;
@@ -457,15 +459,18 @@ typedef __attribute__((address_space(3))) void* mik_lptr_t;
 // 4 = skip the per-tile barrier, 8 = DMA always re-reads k-tile 0 (cache-resident source).  Results are garbage; the variants exist to price each component.
 // kscale: the accumulators are doubled just before the K tile that starts at kscale is contracted (symmetric
 // form: everything above the diagonal block counts twice); pass a value that is never a tile start to disable.
-template <int NAI, int ABL = 0>
+// BM (round 3, tools/kernel_bench only): rows of the block tile, 128 (library) or 256 -- 16 waves of 32 x 64, one block per CU, the
+// A operand staged in two passes and the B operand in one (the tile-shape experiment of profiles/r03_kernel_bench.txt).
+template <int NAI, int ABL = 0, int BM = MIK_BM>
 __device__ __forceinline__ void gemm_core(const double* __restrict__ Ag, long lda, const double* __restrict__ Bg,
-                                          long ldb, int kbeg, int kend, d4 (&acc)[NAI][4], GemmSmem& sm,
+                                          long ldb, int kbeg, int kend, d4 (&acc)[NAI][4], GemmSmemT<BM>& sm,
                                           int kscale = -1) {
   if (kbeg >= kend) return;  // block-uniform
   constexpr int WROWS = 16 * NAI;            // rows of the wave tile
-  constexpr int NTHR = 64 * 2 * (128 / WROWS);
+  constexpr int NTHR = 64 * 2 * (BM / WROWS);
   constexpr int PROWS = NTHR / 8;            // rows staged per pass (8 threads x 16 B per 128-B row)
-  constexpr int NPASS = 128 / PROWS;
+  constexpr int NPASS = BM / PROWS;          // passes over the A tile
+  constexpr int NPASS_B = MIK_BN / PROWS;    // passes over the B tile (fewer when BM > MIK_BN)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   // staging: thread -> (row lrow + PROWS*p, 16-byte slot tid&7); the SOURCE k-pair is the slot XOR the row's swizzle
@@ -478,11 +483,11 @@ __device__ __forceinline__ void gemm_core(const double* __restrict__ Ag, long ld
 #pragma unroll
   for (int p = 0; p < NPASS; ++p) {
     aoffb[p] = (unsigned)(((long)(lrow + PROWS * p) * lda + ((slot ^ (lrow & 2)) << 1)) * 8);
-    boffb[p] = (unsigned)(((long)(lrow + PROWS * p) * ldb + ((slot ^ ((lrow >> 1) & 7)) << 1)) * 8);
+    boffb[p] = (unsigned)(((long)(lrow + PROWS * (p < NPASS_B ? p : 0)) * ldb + ((slot ^ ((lrow >> 1) & 7)) << 1)) * 8);
   }
   const unsigned ldsA = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)&sm.As[0][wave * 8][0]);
   const unsigned ldsB = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)&sm.Bs[0][wave * 8][0]);
-  constexpr unsigned LDS_PASS = PROWS * MIK_BK * 8, LDS_BUF = MIK_BM * MIK_BK * 8;
+  constexpr unsigned LDS_PASS = PROWS * MIK_BK * 8, LDS_BUF = BM * MIK_BK * 8, LDS_BUF_B = MIK_BN * MIK_BK * 8;
   // LDS-DMA in the saddr form (wave-uniform 64-bit base in SGPRs + 32-bit lane offset), written as inline asm:
   // the builtin always materialises a 64-bit per-lane address (2 v_lshl_add_u64 + v_readfirstlane per piece).
   // M0 (LDS destination) is written in the same statement that uses it; hipcc does not count these loads, so the
@@ -499,13 +504,13 @@ __device__ __forceinline__ void gemm_core(const double* __restrict__ Ag, long ld
     const double* bbase = uniform_ptr(Bgu + k);
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
-      const unsigned la = ldsA + b * LDS_BUF + p * LDS_PASS, lb = ldsB + b * LDS_BUF + p * LDS_PASS;
+      const unsigned la = ldsA + b * LDS_BUF + p * LDS_PASS, lb = ldsB + b * LDS_BUF_B + p * LDS_PASS;
       if (p == 0) {  // the bases come straight from v_readfirstlane: VALU-written SGPR -> VMEM address needs 5 wait states
         asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(aoffb[p]), "s"(abase), "s"(la) : "memory");
         if (!(ABL & 32)) asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(boffb[p]), "s"(bbase), "s"(lb) : "memory");
       } else {
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(aoffb[p]), "s"(abase), "s"(la) : "memory");
-        if (!(ABL & 32)) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(boffb[p]), "s"(bbase), "s"(lb) : "memory");
+        if (!(ABL & 32) && p < NPASS_B) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(boffb[p]), "s"(bbase), "s"(lb) : "memory");
       }
       if (ABL & 32) {
         // experiment (tools/kernel_bench): the B tile is not loaded but GENERATED -- per thread and pass two
@@ -2983,6 +2988,94 @@ k_contract_ablate(const double* __restrict__ Ainv, long lda, const double* __res
 #pragma unroll
     for (int y = 0; y < 4; ++y) s += acc[x][y][0] + acc[x][y][1] + acc[x][y][2] + acc[x][y][3];
   if (s == 1.2345e-300) part[(long)iblk * palloc + tblk * MIK_BN + threadIdx.x % 128] = s;
+}
+
+// tools/kernel_bench only (round 3, the tile-shape experiment): the symmetric contraction with a 256 (rows of A_inv) x 128 (points)
+// block tile -- 16 wavefronts of 32 x 64 on the same MFMA loop, ONE 1024-thread block per CU, 96 KB of LDS, persistent over the
+// same per-XCD tile queue.  Per tile step it requests (256 + 128) x 16 operand doubles for 256 x 128 x 16 multiply-adds, 25 % less
+// than two 128 x 128 tiles.  part[] has one row per 256-row block.  (A 256 x 256 tile does not exist for this register tiling:
+// 16 waves of 32 x 64 cover 256 x 128; 32 x 64 per wave at 128 VGPRs is what lets 4 waves share a SIMD.)
+template <bool SYM>
+__global__ void __launch_bounds__(1024, 1)
+k_contract256(const double* __restrict__ Ainv, long lda, const double* __restrict__ Bt, long ldb, double* __restrict__ part, int palloc,
+              int nIblk /* 256-row blocks */, int kend, unsigned long long* __restrict__ queue) {
+  constexpr int NAI = 2, BM = 256, WROWS = 32, NWM = BM / WROWS;
+  extern __shared__ double smem256[];
+  GemmSmemT<BM>& sm = *reinterpret_cast<GemmSmemT<BM>*>(smem256);
+  unsigned xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  const int xcd = (int)(xcc & 7);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1, lq = lane >> 4, lc = lane & 15;
+  int steal = 0;
+  for (;;) {
+    int iblk, tblk;
+    const int xq = (xcd + steal) & 7;
+    if (threadIdx.x == 0) sm.next = (long)__hip_atomic_fetch_add(&queue[xq], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const long seq = sm.next;
+    const int kind = super_tile_at(nIblk, palloc / MIK_BN, xq, seq, iblk, tblk);
+    __syncthreads();
+    if (kind == 2) {
+      if (++steal == 8) return;
+      continue;
+    }
+    if (kind == 1) continue;
+    const int i0 = iblk * BM, t0 = tblk * MIK_BN;
+    const double* Ag = Ainv + (long)i0 * lda;
+    const double* Bg = Bt + (long)t0 * ldb;
+    d4 acc[NAI][4];
+#pragma unroll
+    for (int x = 0; x < NAI; ++x)
+#pragma unroll
+      for (int y = 0; y < 4; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
+    if (SYM) {
+      const int kd = (i0 + BM) < kend ? (i0 + BM) : kend;
+      gemm_core<NAI, 0, BM>(Ag, lda, Bg, ldb, i0, kend, acc, sm, kd - MIK_BK);
+    } else {
+      gemm_core<NAI, 0, BM>(Ag, lda, Bg, ldb, 0, kend, acc, sm);
+    }
+    double cs[4];
+#pragma unroll
+    for (int bp = 0; bp < 2; ++bp) {
+      double bv[2][4 * NAI];
+#pragma unroll
+      for (int b2 = 0; b2 < 2; ++b2) {
+        const long t = t0 + wn * 64 + (2 * bp + b2) * 16 + lc;
+        const double* brow = Bt + t * ldb + i0 + wm * WROWS + lq;
+#pragma unroll
+        for (int ai = 0; ai < NAI; ++ai)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) bv[b2][ai * 4 + r] = brow[ai * 16 + 4 * r];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int b2 = 0; b2 < 2; ++b2) {
+        const int bi = 2 * bp + b2;
+        double sacc = 0.0;
+#pragma unroll
+        for (int ai = 0; ai < NAI; ++ai)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sacc += bv[b2][ai * 4 + r] * acc[ai][bi][r];
+        sacc += __shfl_xor(sacc, 16);
+        sacc += __shfl_xor(sacc, 32);
+        cs[bi] = sacc;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    double* red = &sm.As[0][0][0];
+    if (lq == 0) {
+#pragma unroll
+      for (int bi = 0; bi < 4; ++bi) red[wm * 128 + wn * 64 + bi * 16 + lc] = cs[bi];
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+      double v = 0.0;
+#pragma unroll
+      for (int w = 0; w < NWM; ++w) v += red[w * 128 + threadIdx.x];
+      part[(long)iblk * palloc + t0 + threadIdx.x] = v;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -67,6 +67,27 @@ int main(int argc,char**argv){
     printf("   symmetric vs full form, sum over row blocks: max|diff| %.3e (max|sum| %.3e)\n",md,mx); }
   ms=timeit([&]{hipMemsetAsync(queue,0,64,0); hipLaunchKernelGGL((k_contract<false,2>),dim3(pgrid),dim3(512),0,0,(const double*)T,(long)Mp,(const double*)Bt,(long)Mp,part,P,nblk,kend,queue);},2);
   printf("k_contract<full> mfma 8 waves/block: %.3f ms  executed %.2f TF/s\n",ms,fl_full/ms*1e-9);
+  // round 3: the tile-shape experiment -- 256 x 128 block tile (16 waves, one 1024-thread block per CU, 96 KB LDS), same MFMA loop
+  if (Mp % 256 == 0) {
+    const int nb256 = Mp / 256;
+    const size_t lds256 = sizeof(GemmSmemT<256>);
+    CK(hipFuncSetAttribute((const void*)k_contract256<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256));
+    CK(hipFuncSetAttribute((const void*)k_contract256<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256));
+    double kext256 = 0; for (int ib = 0; ib < nb256; ++ib) kext256 += (kend - ib * 256 > 0 ? kend - ib * 256 : 0);
+    const double fl_sym256 = 2.0 * 256 * 128 * kext256 * (P / 128);
+    for (int rep = 0; rep < 2; ++rep) {
+      ms=timeit([&]{hipMemsetAsync(queue,0,64,0); hipLaunchKernelGGL((k_contract<true,2>),dim3(pgrid),dim3(512),0,0,(const double*)T,(long)Mp,(const double*)Bt,(long)Mp,part,P,nblk,kend,queue);},3);
+      printf("TILE A/B sym 128x128 (8 waves, 2 blocks/CU, 512 blocks): %.3f ms  executed %.2f TF/s  useful-rate %.2f TF/s\n",ms,fl_sym/ms*1e-9,fl_sym/ms*1e-9*(double)Mp*Mp/2/(128.0*kext_sym));
+      std::vector<double> p128((size_t)P*nblk); CK(hipMemcpy(p128.data(),part,p128.size()*8,hipMemcpyDeviceToHost));
+      ms=timeit([&]{hipMemsetAsync(queue,0,64,0); hipLaunchKernelGGL((k_contract256<true>),dim3(256),dim3(1024),lds256,0,(const double*)T,(long)Mp,(const double*)Bt,(long)Mp,part,P,nb256,kend,queue);},3);
+      printf("TILE A/B sym 256x128 (16 waves, 1 block/CU, 256 blocks): %.3f ms  executed %.2f TF/s  useful-rate %.2f TF/s\n",ms,fl_sym256/ms*1e-9,fl_sym256/ms*1e-9*(double)Mp*Mp/2/(256.0*kext256));
+      std::vector<double> p256((size_t)P*nb256); CK(hipMemcpy(p256.data(),part,p256.size()*8,hipMemcpyDeviceToHost));
+      if (rep == 0) { double md=0, mx=0; for(int t=0;t<P;++t){ double a=0,b=0; for(int ib=0;ib<nblk;++ib) a+=p128[(size_t)ib*P+t]; for(int ib=0;ib<nb256;++ib) b+=p256[(size_t)ib*P+t]; md=fmax(md,fabs(a-b)); mx=fmax(mx,fabs(a)); }
+        printf("   256x128 vs 128x128, sum over row blocks: max|diff| %.3e (max|sum| %.3e)\n",md,mx); }
+      ms=timeit([&]{hipMemsetAsync(queue,0,64,0); hipLaunchKernelGGL((k_contract256<false>),dim3(256),dim3(1024),lds256,0,(const double*)T,(long)Mp,(const double*)Bt,(long)Mp,part,P,nb256,kend,queue);},2);
+      printf("TILE A/B full 256x128 (16 waves, 1 block/CU)            : %.3f ms  executed %.2f TF/s\n",ms,fl_full/ms*1e-9);
+    }
+  }
   ms=timeit([&]{hipMemsetAsync(queue,0,64,0); hipLaunchKernelGGL((k_contract<false,4>),dim3(pgrid),dim3(256),40960,0,(const double*)T,(long)Mp,(const double*)Bt,(long)Mp,part,P,nblk,kend,queue);},2);
   printf("k_contract<full> mfma, ONE block per CU (40 KB dummy dynamic LDS): %.3f ms  executed %.2f TF/s\n",ms,fl_full/ms*1e-9);
   ms=timeit([&]{hipLaunchKernelGGL(k_contract_valu<true>,dim3(vgrid),dim3(256),0,0,(const double*)T,(long)Mp,(const double*)Bt,(long)Mp,part,P,nblk,kend);},3);
