@@ -1053,8 +1053,11 @@ k_panel(const double* __restrict__ A, long lda, const double* __restrict__ Bt, d
 // a, b has been swept), so only the UPPER block triangle i <= j is maintained (half the tiles): part 0 = all upper tiles,
 // part 1 = block column `col` (i <= col) and block row `col` (j >= col) -- what the next panel chain reads --, part 2 =
 // the upper tiles outside those.
-template <bool SYM>
-__global__ void __launch_bounds__(256, 2)
+// NAI = 4: 4 waves per block, wave tile 64 x 64 (228 VGPRs, 2 waves per SIMD); NAI = 2 (round 3): 8 waves, wave tile 32 x 64
+// (<= 128 VGPRs, 4 waves per SIMD to cover the short K loop and the read-modify-write epilogue).  Same accumulation order per
+// entry: bit-identical results.
+template <bool SYM, int NAI = 4>
+__global__ void __launch_bounds__(64 * 2 * (8 / NAI), 2)
 k_update(double* __restrict__ T, long ld, int nblk, int kb, const double* __restrict__ Cold,
          const double* __restrict__ Cnew, const double* __restrict__ Rt, const double* __restrict__ Dinv, int part, int col,
          double* __restrict__ Pout, double* __restrict__ Dcopy = nullptr, int* __restrict__ done_cnt = nullptr) {
@@ -1102,7 +1105,7 @@ k_update(double* __restrict__ T, long ld, int nblk, int kb, const double* __rest
   double* P = (jblk == col || (SYM && iblk == col)) ? Pout : nullptr;
   double* DC = (iblk == col + 1 && jblk == col + 1) ? Dcopy : nullptr;
   if (iblk == kb || jblk == kb) {
-    for (int e = threadIdx.x; e < 128 * 128; e += 256) {
+    for (int e = threadIdx.x; e < 128 * 128; e += 64 * 2 * (8 / NAI)) {
       const int r = e >> 7, c = e & 127;
       double v;
       if (iblk == kb && jblk == kb) v = Dinv[e];
@@ -1116,18 +1119,20 @@ k_update(double* __restrict__ T, long ld, int nblk, int kb, const double* __rest
     }
     return finish();
   }
-  d4 acc[4][4];
+  d4 acc[NAI][4];
 #pragma unroll
-  for (int x = 0; x < 4; ++x)
+  for (int x = 0; x < NAI; ++x)
 #pragma unroll
     for (int y = 0; y < 4; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
-  gemm_core<4>(Cold + (long)i0 * 128, 128, Rt + (long)j0 * 128, 128, 0, 128, acc, sm);
+  gemm_core<NAI>(Cold + (long)i0 * 128, 128, Rt + (long)j0 * 128, 128, 0, 128, acc, sm);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 1, wn = wave & 1, lq = lane >> 4, lc = lane & 15;
+  constexpr int WR = 16 * NAI;  // rows of the wave tile
   // read-modify-write in batches of 16 independent loads, the NEXT batch's loads in flight while this one is subtracted and
   // stored (two register sets): the epilogue pays the memory latency once, not four times
-  double tv[2][4][4];
-  auto tile_ptr = [&](int ai) { return T + (long)(i0 + wm * 64 + ai * 16 + lq) * ld + j0 + wn * 64 + lc; };
+  constexpr int NTV = NAI == 4 ? 2 : 1;  // the 8-wave form keeps ONE batch in registers (128-VGPR budget for 4 waves per SIMD)
+  double tv[NTV][4][4];
+  auto tile_ptr = [&](int ai) { return T + (long)(i0 + wm * WR + ai * 16 + lq) * ld + j0 + wn * 64 + lc; };
   auto load_batch = [&](int ai, double (&dst)[4][4]) {
     const double* tp = tile_ptr(ai);
 #pragma unroll
@@ -1137,22 +1142,23 @@ k_update(double* __restrict__ T, long ld, int nblk, int kb, const double* __rest
   };
   load_batch(0, tv[0]);
 #pragma unroll
-  for (int ai = 0; ai < 4; ++ai) {
-    if (ai + 1 < 4) load_batch(ai + 1, tv[(ai + 1) & 1]);
+  for (int ai = 0; ai < NAI; ++ai) {
+    if (NTV == 1 && ai > 0) load_batch(ai, tv[0]);
+    if (NTV == 2 && ai + 1 < NAI) load_batch(ai + 1, tv[(ai + 1) & 1]);
     __builtin_amdgcn_sched_barrier(0);
     double* tp = tile_ptr(ai);
 #pragma unroll
     for (int bi = 0; bi < 4; ++bi)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const double v = tv[ai & 1][bi][r] - acc[ai][bi][r];
+        const double v = tv[NTV == 2 ? (ai & 1) : 0][bi][r] - acc[ai][bi][r];
         tp[(long)(4 * r) * ld + bi * 16] = v;
         if (P) {
-          const int row = wm * 64 + ai * 16 + lq + 4 * r, cc = wn * 64 + bi * 16 + lc;  // position inside the tile
+          const int row = wm * WR + ai * 16 + lq + 4 * r, cc = wn * 64 + bi * 16 + lc;  // position inside the tile
           if (ptrans) P[(long)(j0 + cc) * 128 + row] = v;
           else P[(long)(i0 + row) * 128 + cc] = v;
         }
-        if (DC) DC[(wm * 64 + ai * 16 + lq + 4 * r) * 128 + wn * 64 + bi * 16 + lc] = v;
+        if (DC) DC[(wm * WR + ai * 16 + lq + 4 * r) * 128 + wn * 64 + bi * 16 + lc] = v;
       }
     __builtin_amdgcn_sched_barrier(0);
   }

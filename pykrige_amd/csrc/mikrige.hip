@@ -220,6 +220,7 @@ struct mik_handle {
   int opt_early_diag = -1; // look-ahead sweep: the next diagonal block is built and inverted ahead of the panel / update stream (-1 = with the look-ahead)
   int opt_gate = -1;       // look-ahead sweep: the trailing update waits until the next diagonal inverse has started and leaves
                            // it a CU of its own (k_gate); -1 = where the serial chain, not the update, is the step period
+  int opt_update_waves = 4; // trailing-update kernel of the block sweep: 4 waves (wave tile 64 x 64) or 8 (32 x 64) per 128 x 128 tile
   int opt_diag = 1;        // diagonal-block inverse variant: 0 = 1024 threads (16 waves x 8 rows), 1 = 16x16 grid, 2 = 16x32, 3 = 32x32
   // points
   long npt_total = 0, npt = 0;
@@ -607,6 +608,8 @@ static int create_one_body(mik_handle* h, int device) {
   if (env) h->alias_ok = atoi(env) != 0;
   env = getenv("MIK_EARLY_DIAG");
   if (env) h->opt_early_diag = atoi(env) < 0 ? -1 : atoi(env);
+  env = getenv("MIK_UPDATE_WAVES");
+  if (env && (atoi(env) == 4 || atoi(env) == 8)) h->opt_update_waves = atoi(env);
   env = getenv("MIK_RHS_OVERLAP");
   if (env) h->opt_rhs_overlap = atoi(env) ? 1 : 0;
   env = getenv("MIK_ASYNC_EXCHANGE");
@@ -714,7 +717,7 @@ static int set_group(mik_handle* h, int n) {
     }
     k->is_kid = true;
     k->opt_factor = h->opt_factor, k->opt_sym = h->opt_sym, k->opt_engine = h->opt_engine, k->opt_waves = h->opt_waves;
-    k->opt_chunk = h->opt_chunk, k->opt_symsweep = h->opt_symsweep, k->opt_diag = h->opt_diag, k->opt_lookahead = h->opt_lookahead, k->opt_gate = h->opt_gate, k->opt_fuse_chain = h->opt_fuse_chain, k->opt_early_diag = h->opt_early_diag, k->opt_pinv_fast = h->opt_pinv_fast, k->opt_rhs_overlap = h->opt_rhs_overlap, k->opt_verify = h->opt_verify, k->verify_tol_z = h->verify_tol_z, k->verify_tol_inv = h->verify_tol_inv;
+    k->opt_chunk = h->opt_chunk, k->opt_symsweep = h->opt_symsweep, k->opt_diag = h->opt_diag, k->opt_update_waves = h->opt_update_waves, k->opt_lookahead = h->opt_lookahead, k->opt_gate = h->opt_gate, k->opt_fuse_chain = h->opt_fuse_chain, k->opt_early_diag = h->opt_early_diag, k->opt_pinv_fast = h->opt_pinv_fast, k->opt_rhs_overlap = h->opt_rhs_overlap, k->opt_verify = h->opt_verify, k->verify_tol_z = h->verify_tol_z, k->verify_tol_inv = h->verify_tol_inv;
     k->opt_mw_class = h->opt_mw_class, k->opt_mw_knn_bound = h->opt_mw_knn_bound, k->opt_mw_pivot = h->opt_mw_pivot, k->opt_mw_lds_cap = h->opt_mw_lds_cap, k->opt_pairs = h->opt_pairs, k->opt_mw_solver = h->opt_mw_solver;
     k->custom_fn = h->custom_fn, k->custom_user = h->custom_user;
     h->kids.push_back(k);
@@ -821,6 +824,9 @@ int mik_set_option(mik_handle* h, const char* key, double value) {
     h->opt_early_diag = value < 0.0 ? -1 : (int)value;  // 1 / 3 = on (streams ordered by events), 2 = with the one-block tile kernels, 4 / 5 = ordered by flags (both sides / update stream only)
   } else if (!strcmp(key, "gate")) {
     h->opt_gate = value < 0.0 ? -1 : (value != 0.0);
+  } else if (!strcmp(key, "update_waves")) {
+    if (value != 4.0 && value != 8.0) return fail(MIK_EINVAL, "update_waves must be 4 or 8");
+    h->opt_update_waves = (int)value;
   } else if (!strcmp(key, "diag")) {
     h->opt_diag = (int)value;
   } else if (!strcmp(key, "lookahead")) {
@@ -1060,14 +1066,20 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
   h->last_half_sweep = symsweep;
   const long ltiles = symsweep ? (long)nblk * (nblk + 1) / 2 : tiles;
   const unsigned ug = (unsigned)(8 * ((ltiles + 7) / 8));
+  const bool upd8 = h->opt_update_waves == 8;
+#define UPDK(SYMV, GRID, STREAM, ...)                                                                                       \
+  do {                                                                                                                      \
+    if (upd8) hipLaunchKernelGGL((k_update<SYMV, 2>), GRID, dim3(512), 0, STREAM, __VA_ARGS__);                             \
+    else hipLaunchKernelGGL((k_update<SYMV, 4>), GRID, dim3(256), 0, STREAM, __VA_ARGS__);                                  \
+  } while (0)
 #define UPDX(GRID, STREAM, CO, CN, R, D, PART, COL, POUT, DCOPY)                                                             \
   do {                                                                                                                       \
     if (symsweep)                                                                                                            \
-      hipLaunchKernelGGL(k_update<true>, GRID, dim3(256), 0, STREAM, T, ld, nblk, kb, (const double*)(CO), (const double*)(CN), \
-                         (const double*)(R), (const double*)(D), PART, COL, POUT, DCOPY);                                    \
+      UPDK(true, GRID, STREAM, T, ld, nblk, kb, (const double*)(CO), (const double*)(CN),                                    \
+           (const double*)(R), (const double*)(D), PART, COL, POUT, DCOPY, (int*)nullptr);                                   \
     else                                                                                                                     \
-      hipLaunchKernelGGL(k_update<false>, GRID, dim3(256), 0, STREAM, T, ld, nblk, kb, (const double*)(CO), (const double*)(CN), \
-                         (const double*)(R), (const double*)(D), PART, COL, POUT, DCOPY);                                    \
+      UPDK(false, GRID, STREAM, T, ld, nblk, kb, (const double*)(CO), (const double*)(CN),                                   \
+           (const double*)(R), (const double*)(D), PART, COL, POUT, DCOPY, (int*)nullptr);                                   \
   } while (0)
 #define UPD(GRID, STREAM, CO, CN, R, D, PART, COL, POUT) UPDX(GRID, STREAM, CO, CN, R, D, PART, COL, POUT, (double*)nullptr)
   const bool early_ok = h->opt_early_diag != 0;
@@ -1182,11 +1194,11 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
         if (kb + 1 < nblk) {
           if (gate_here && kb == 0) hipLaunchKernelGGL(k_gate, dim3(1), dim3(1), 0, h->stream, (const int*)fl, kb + 1, 20000);
           if (symsweep)
-            hipLaunchKernelGGL(k_update<true>, dim3(ug), dim3(256), 0, h->stream, T, ld, nblk, kb, (const double*)cold[set], (const double*)cnew[set],
-                               (const double*)rt[set], (const double*)dinv[set], 0, kb + 1, cold[set ^ 1], dcopy[set ^ 1], flags_s2 ? fl + MIK_F_UCNT + kb : (int*)nullptr);
+            UPDK(true, dim3(ug), h->stream, T, ld, nblk, kb, (const double*)cold[set], (const double*)cnew[set],
+                 (const double*)rt[set], (const double*)dinv[set], 0, kb + 1, cold[set ^ 1], dcopy[set ^ 1], flags_s2 ? fl + MIK_F_UCNT + kb : (int*)nullptr);
           else
-            hipLaunchKernelGGL(k_update<false>, dim3(ug), dim3(256), 0, h->stream, T, ld, nblk, kb, (const double*)cold[set], (const double*)cnew[set],
-                               (const double*)rt[set], (const double*)dinv[set], 0, kb + 1, cold[set ^ 1], dcopy[set ^ 1], flags_s2 ? fl + MIK_F_UCNT + kb : (int*)nullptr);
+            UPDK(false, dim3(ug), h->stream, T, ld, nblk, kb, (const double*)cold[set], (const double*)cnew[set],
+                 (const double*)rt[set], (const double*)dinv[set], 0, kb + 1, cold[set ^ 1], dcopy[set ^ 1], flags_s2 ? fl + MIK_F_UCNT + kb : (int*)nullptr);
           if (!flags_s2) HIPC(hipEventRecord(h->la_events[2 * kb + 2], h->stream));
         } else {
           UPD(dim3(ug), h->stream, cold[set], cnew[set], rt[set], dinv[set], 0, -2, (double*)nullptr);
@@ -1251,6 +1263,7 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
   }
 #undef UPD
 #undef UPDX
+#undef UPDK
   if (symsweep) hipLaunchKernelGGL(k_mirror_upper, dim3(Mp / 64, Mp / 64), dim3(256), 0, h->stream, T, ld, Mp / 64);
   if (pivoted)
     hipLaunchKernelGGL(k_swap_cols, dim3((Mp + 255) / 256), dim3(256), 0, h->stream, T, ld,

@@ -127,6 +127,8 @@ int main(int argc,char**argv){
   const long ut=(long)nblk*nblk; const unsigned ug=(unsigned)(8*((ut+7)/8));
   ms=timeit([&]{hipLaunchKernelGGL(k_update<false>,dim3(ug),dim3(256),0,0,T,(long)Mp,nblk,1,(const double*)Cold,(const double*)Cnew,(const double*)Rt,(const double*)Dinv,0,0,(double*)nullptr);},5);
   printf("k_update: %.1f us  %.2f TF/s\n",ms*1e3, 2.0*Mp*(double)Mp*128/ms*1e-9);
+  ms=timeit([&]{hipLaunchKernelGGL((k_update<false,2>),dim3(ug),dim3(512),0,0,T,(long)Mp,nblk,1,(const double*)Cold,(const double*)Cnew,(const double*)Rt,(const double*)Dinv,0,0,(double*)nullptr,(double*)nullptr,(int*)nullptr);},5);
+  printf("k_update, 8 waves per tile (round 3): %.1f us  %.2f TF/s\n",ms*1e3, 2.0*Mp*(double)Mp*128/ms*1e-9);
   ms=timeit([&]{hipLaunchKernelGGL(k_diag_inv,dim3(1),dim3(1024),0,0,(const double*)T,(long)Mp,0,0,Dinv,DinvT,flag);
                hipLaunchKernelGGL(k_update<false>,dim3(ug),dim3(256),0,0,T,(long)Mp,nblk,1,(const double*)Cold,(const double*)Cnew,(const double*)Rt,(const double*)Dinv,0,0,(double*)nullptr);},5);
   printf("k_diag_inv + k_update interleaved: %.1f us per pair\n",ms*1e3);
