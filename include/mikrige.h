@@ -175,7 +175,8 @@ int  mik_slab_of(int64_t n, int members, int i, int64_t *lo, int64_t *count); /*
  *   MIK_EARLY_DIAG.  Every setting returns the bit-identical inverse ;
  * "fuse_chain" 0/1 = the block-column update leaves the next panel copy in place and the
  *   panel kernel writes R^T itself: two kernels on the serial chain instead of four (default 1) ; "diag" 0..3 = diagonal-block inverse kernel variant (default 1) ;
- * "update_waves" 4 | 8 = wavefronts per 128 x 128 tile of the block sweep's trailing update (wave tile 64 x 64 / 32 x 64; same bits)
+ * "update_waves" 4 | 8 = wavefronts per 128 x 128 tile of the block sweep's trailing update (wave tile 64 x 64 / 32 x 64; same bits;
+ *   default 8)
  *   [MIK_UPDATE_WAVES] ;
  * "pinv_fast" 0/1 = pseudo_inv: try the deflated regular inverse before the Jacobi pseudo-inverse (default 1) ;
  * "verify" 0/1 = probe every inverse the device computes against the matrix itself before it is used (default 1):

@@ -220,7 +220,8 @@ struct mik_handle {
   int opt_early_diag = -1; // look-ahead sweep: the next diagonal block is built and inverted ahead of the panel / update stream (-1 = with the look-ahead)
   int opt_gate = -1;       // look-ahead sweep: the trailing update waits until the next diagonal inverse has started and leaves
                            // it a CU of its own (k_gate); -1 = where the serial chain, not the update, is the step period
-  int opt_update_waves = 4; // trailing-update kernel of the block sweep: 4 waves (wave tile 64 x 64) or 8 (32 x 64) per 128 x 128 tile
+  int opt_update_waves = 8; // trailing-update kernel of the block sweep: 4 waves (wave tile 64 x 64) or 8 (32 x 64, default since round 3:
+                            // -5 % at N=5000 / 8000, same bits: profiles/r03_update_waves_ab.txt) per 128 x 128 tile
   int opt_diag = 1;        // diagonal-block inverse variant: 0 = 1024 threads (16 waves x 8 rows), 1 = 16x16 grid, 2 = 16x32, 3 = 32x32
   // points
   long npt_total = 0, npt = 0;
