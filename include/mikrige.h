@@ -227,6 +227,13 @@ int  mik_set_grid(mik_handle *h, const mik_grid *g);       /* the same for a gri
                                                               anisotropy-adjusted on the device */
 int  mik_predict(mik_handle *h);                           /* K3 over the resident points; results stay in HBM */
 int  mik_get_results(mik_handle *h, double *z_out, double *ss_out); /* D2H, scattered through the mask  */
+int  mik_take_results(mik_handle *h, double **z, double **ss); /* the same without the last copy: *z and *ss point INTO the
+                                                              page-locked landing zone the device wrote (npt doubles each, one
+                                                              allocation, *ss = *z + npt), which now belongs to the caller until
+                                                              mik_release_results(*z); the handle takes another buffer (recycled
+                                                              from released ones) for its next predict.  One device, no mask;
+                                                              otherwise MIK_ESTATE and mik_get_results is the call */
+void mik_release_results(double *z);                       /* gives such a buffer back (any thread) */
 int  mik_synchronize(mik_handle *h);                       /* wait until the handle's stream is idle (every call above
                                                               already blocks; this is the explicit bracket for timing) */
 

@@ -81,6 +81,8 @@ SIGNATURES = {
     "mik_set_grid": (C.c_int, [C.c_void_p, C.POINTER(MikGrid)]),
     "mik_predict": (C.c_int, [C.c_void_p]),
     "mik_get_results": (C.c_int, [C.c_void_p, _dp, _dp]),
+    "mik_take_results": (C.c_int, [C.c_void_p, C.POINTER(_dp), C.POINTER(_dp)]),
+    "mik_release_results": (None, [_dp]),
     "mik_synchronize": (C.c_int, [C.c_void_p]),
     "mik_set_custom_variogram": (C.c_int, [C.c_void_p, VARIOGRAM_FN, C.c_void_p]),
     "mik_predict_moving_window": (C.c_int, [C.c_void_p, C.c_int]),
@@ -143,6 +145,19 @@ def _f64(a):
 
 def _ptr(a):
     return a.ctypes.data_as(_dp) if a is not None else None
+
+
+class _PinnedOwner:
+    """Keeps a page-locked result buffer of the library alive for the NumPy arrays that view it; gives it back when they are gone."""
+
+    def __init__(self, lib, ptr):
+        self._lib, self._ptr = lib, ptr
+
+    def __del__(self):
+        try:
+            self._lib.mik_release_results(self._ptr)
+        except Exception:  # interpreter shutdown
+            pass
 
 
 class Handle:
@@ -297,9 +312,11 @@ class Handle:
         return np.stack(cols, axis=1)
 
     def predict(self):
+        self._taken = None  # the previous results stay valid for whoever holds them; the handle lets go of them
         check(self._lib.mik_predict(self._h))
 
     def predict_moving_window(self, n_closest_points):
+        self._taken = None
         check(self._lib.mik_predict_moving_window(self._h, int(n_closest_points)))
 
     def statistics(self, n):
@@ -334,8 +351,22 @@ class Handle:
         check(self._lib.mik_synchronize(self._h))
 
     def get_results(self):
-        z = np.empty(self._npt, dtype=np.float64)
-        ss = np.empty(self._npt, dtype=np.float64)
+        """(z, sigma^2) of the last predict, flat.  One device and no mask: the arrays ARE the page-locked landing zone the device
+        wrote (mik_take_results; the buffer goes back to the library's pool when the arrays are garbage-collected) -- no copy, no
+        fresh pages.  Otherwise (device groups, masked points, MIK_ZERO_COPY=0): copied / scattered into new arrays."""
+        n = self._npt
+        if getattr(self, "_taken", None) is not None:  # asked again before the next predict: the same arrays
+            return self._taken
+        if n > 0 and os.environ.get("MIK_ZERO_COPY", "1") != "0":
+            zp, sp = _dp(), _dp()
+            if self._lib.mik_take_results(self._h, C.byref(zp), C.byref(sp)) == MIK_OK:
+                buf = (C.c_double * (2 * n)).from_address(C.addressof(zp.contents))
+                buf._mik_owner = _PinnedOwner(self._lib, zp)  # released when the last view of `both` is gone
+                both = np.frombuffer(buf, dtype=np.float64)
+                self._taken = (both[:n], both[n:])
+                return self._taken
+        z = np.empty(n, dtype=np.float64)
+        ss = np.empty(n, dtype=np.float64)
         check(self._lib.mik_get_results(self._h, _ptr(z), _ptr(ss)))
         return z, ss
 

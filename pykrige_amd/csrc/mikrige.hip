@@ -74,6 +74,13 @@ struct DevBuf {
   T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+// Page-locked buffers that left a handle with mik_take_results (the caller's result arrays ARE the landing zone) come back
+// through mik_release_results into a small process-wide pool and are handed to the next handle that needs one: a loop of
+// execute() calls whose results are dropped allocates (and page-locks) nothing in steady state.
+static std::mutex g_pin_mutex;
+static std::vector<std::pair<void*, size_t>> g_pin_pool;
+static std::map<void*, size_t> g_pin_lent;
+
 // page-locked host memory: staging of the point coordinates on their way in, landing zone of z / sigma^2 on their way out
 struct PinBuf {
   void* p = nullptr;
@@ -86,9 +93,31 @@ struct PinBuf {
     if (need <= bytes && p) return MIK_OK;
     release();
     if (need == 0) return MIK_OK;
+    {
+      std::lock_guard<std::mutex> lk(g_pin_mutex);
+      int best = -1;
+      for (size_t i = 0; i < g_pin_pool.size(); ++i)
+        if (g_pin_pool[i].second >= need && g_pin_pool[i].second <= 2 * need + (1u << 20) &&
+            (best < 0 || g_pin_pool[i].second < g_pin_pool[(size_t)best].second))
+          best = (int)i;
+      if (best >= 0) {
+        p = g_pin_pool[(size_t)best].first;
+        bytes = g_pin_pool[(size_t)best].second;
+        g_pin_pool.erase(g_pin_pool.begin() + best);
+        return MIK_OK;
+      }
+    }
     HIPC(hipHostMalloc(&p, need, hipHostMallocPortable));
     bytes = need;
     return MIK_OK;
+  }
+  void* lend() {  // ownership passes to the caller (mik_take_results)
+    std::lock_guard<std::mutex> lk(g_pin_mutex);
+    void* q = p;
+    g_pin_lent[q] = bytes;
+    p = nullptr;
+    bytes = 0;
+    return q;
   }
   void release() {
     if (p) (void)hipHostFree(p);
@@ -2593,6 +2622,7 @@ static int one_predict(mik_handle* h) {
   if (overlap && nchunks > 1) MIKC(h->Bt2.ensure(sizeof(double) * (size_t)chunk * Mp));
   const bool two = overlap && nchunks > 1;
   MIKC(h->part.ensure(sizeof(double) * (size_t)chunk * nIblk));
+  MIKC(h->pin_out.ensure(sizeof(double) * 2 * (size_t)npt));  // (a previous result may have left with mik_take_results)
   MIKC(get_events(h, 2 + 4 * (size_t)nchunks));
   while (h->pr_events.size() < 2 * (size_t)nchunks) {
     hipEvent_t e;
@@ -3001,6 +3031,7 @@ static int one_predict_mw(mik_handle* h, int n_closest) {
     return rc;
   }
   if (flag) return fail(MIK_ESINGULAR, "Singular matrix");  // cok.pyx:176-177
+  MIKC(h->pin_out.ensure(sizeof(double) * 2 * (size_t)npt));
   HIPC(hipMemcpyAsync(h->pin_out.as<double>(), h->z.p, sizeof(double) * npt, hipMemcpyDeviceToHost, h->stream_d2h));
   HIPC(hipMemcpyAsync(h->pin_out.as<double>() + npt, h->ss.p, sizeof(double) * npt, hipMemcpyDeviceToHost, h->stream_d2h));
   HIPC(hipEventRecord(h->ev_d2h, h->stream_d2h));
@@ -3176,6 +3207,33 @@ int mik_get_results(mik_handle* h, double* z_out, double* ss_out) {
     memset(ss_out, 0, sizeof(double) * h->npt_total);
   }
   return for_each_device(h, [=](int, mik_handle* d) { return one_get_results(d, z_out, ss_out); });
+}
+
+int mik_take_results(mik_handle* h, double** z_out, double** ss_out) {
+  if (!h || !z_out || !ss_out) return fail(MIK_EINVAL, "mik_take_results: NULL argument");
+  if (!h->have_results) return fail(MIK_ESTATE, "mik_take_results: predict first");
+  if (!h->kids.empty() || h->masked || !h->scatter.empty() || h->out_off != 0 || h->npt != h->npt_total || h->npt == 0)
+    return fail(MIK_ESTATE, "mik_take_results: only for one device and unmasked points (use mik_get_results)");
+  HIPC(hipSetDevice(h->device));
+  HIPC(hipEventSynchronize(h->ev_d2h));
+  double* base = static_cast<double*>(h->pin_out.lend());
+  *z_out = base;
+  *ss_out = base + h->npt;
+  h->have_results = false;  // they have left the handle
+  return MIK_OK;
+}
+
+void mik_release_results(double* z) {
+  if (!z) return;
+  std::lock_guard<std::mutex> lk(g_pin_mutex);
+  auto it = g_pin_lent.find((void*)z);
+  if (it == g_pin_lent.end()) return;
+  const size_t bytes = it->second;
+  g_pin_lent.erase(it);
+  size_t pooled = 0;
+  for (auto& e : g_pin_pool) pooled += e.second;
+  if (g_pin_pool.size() < 6 && pooled + bytes <= (size_t)2 << 30) g_pin_pool.emplace_back((void*)z, bytes);
+  else (void)hipHostFree(z);
 }
 
 int mik_get_timing(mik_handle* h, mik_timing* out) {

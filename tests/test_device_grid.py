@@ -134,3 +134,50 @@ def test_grid_cell_ranges_tile_the_whole_grid():
         parts.append(h.get_results())
     assert np.array_equal(np.concatenate([p[0] for p in parts]), z.ravel())
     assert np.array_equal(np.concatenate([p[1] for p in parts]), ss.ravel())
+
+
+@pytest.mark.gpu
+def test_results_without_the_last_copy_are_the_same_results():
+    """mik_take_results: the arrays execute() returns ARE the page-locked landing zone (no copy).  Same numbers as the copying
+    path; they stay valid and unchanged through later calls on the same object and after the object is gone; the buffer of a
+    dropped result is recycled."""
+    import gc
+
+    import pykrige_amd as pa
+
+    g = fx.load("ok2d_n2000")
+    ok = pa.OrdinaryKriging(g["x"], g["y"], g["v"], variogram_model="exponential", variogram_parameters=[1.0, 0.3, 0.0])
+    z1, s1 = ok.execute("grid", g["gridx"], g["gridy"], backend="loop")
+    assert not z1.flags.owndata  # a view of the library's buffer
+    os.environ["MIK_ZERO_COPY"] = "0"
+    try:
+        zc, sc = ok.execute("grid", g["gridx"], g["gridy"], backend="loop")
+    finally:
+        del os.environ["MIK_ZERO_COPY"]
+    assert zc.base is None or zc.base.flags.owndata
+    assert np.array_equal(z1, zc) and np.array_equal(s1, sc)
+    keep_z, keep_s = z1.copy(), s1.copy()
+    addr1 = z1.__array_interface__["data"][0]
+    z2, s2 = ok.execute("grid", g["gridx"][::-1].copy(), g["gridy"], backend="loop")  # another call: must not touch z1 / s1
+    assert z2.__array_interface__["data"][0] != addr1
+    assert np.array_equal(z1, keep_z) and np.array_equal(s1, keep_s)
+    assert np.array_equal(z2[:, ::-1], keep_z)
+    del ok
+    gc.collect()
+    assert np.array_equal(z1, keep_z) and np.array_equal(s1, keep_s)  # the handle is gone, the arrays are not
+    # a dropped result's buffer comes back: after z2 / s2 are released the next result lands at one of the two known addresses
+    addr2 = z2.__array_interface__["data"][0]
+    del z2, s2
+    gc.collect()
+    ok2 = pa.OrdinaryKriging(g["x"], g["y"], g["v"], variogram_model="exponential", variogram_parameters=[1.0, 0.3, 0.0])
+    z3, s3 = ok2.execute("grid", g["gridx"], g["gridy"], backend="loop")
+    assert z3.__array_interface__["data"][0] == addr2
+    assert np.array_equal(z3, keep_z)
+    h = ok2._get_handle()
+    a, b = h.get_results()  # asked twice before the next predict: the same arrays again
+    assert a.__array_interface__["data"][0] == z3.__array_interface__["data"][0]
+    # masked style and device groups keep the copying path (scatter through the mask / one slab per device)
+    m = np.zeros((g["gridy"].size, g["gridx"].size), dtype=bool)
+    m[::3, ::2] = True
+    zm, sm = ok2.execute("masked", g["gridx"], g["gridy"], mask=m, backend="loop")
+    assert np.array_equal(np.ma.getdata(zm)[~m], keep_z[~m]) and np.all(np.ma.getdata(zm)[m] == 0.0)
