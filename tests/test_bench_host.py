@@ -97,3 +97,29 @@ def test_live_traffic_collection_degrades_to_a_reason(monkeypatch):
     monkeypatch.setattr(bench.shutil, "which", lambda name: None)
     res, why = bench.collect_traffic_live(["--steps", "1"], "void mik::k_contract")
     assert res is None and "rocprofv3" in why
+
+
+def test_tracked_pmc_summary_contains_the_dominant_kernel():
+    """profiles/k_contract_traffic.json (bench.py's fall-back for roofline.traffic) must cite a TRACKED per-kernel PMC summary that
+    really holds the dominant kernel's counters -- round 2's summary had lost its k_contract rows and nobody noticed."""
+    tj = json.load(open(os.path.join(ROOT, "profiles", "k_contract_traffic.json")))
+    src = tj["source"].split(" ")[0]
+    assert src.startswith("profiles/") and os.path.exists(os.path.join(ROOT, src)), src
+    rows = {}
+    for line in list(open(os.path.join(ROOT, src)))[1:]:
+        f = line.rstrip("\n").rsplit(",", 4)  # kernel names contain commas: the numeric fields are the last four
+        rows.setdefault(f[0], {})[f[1]] = float(f[3])
+    kern = "void mik::" + tj["kernel"]
+    assert kern in rows, "the cited PMC summary has no rows for %s" % kern
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "TCC_HIT_sum", "TCC_MISS_sum"):
+        assert rows[kern].get(ctr, 0.0) > 0.0, "%s: no %s" % (kern, ctr)
+    assert any(k.startswith("void mik::k_rhs<") for k in rows) and "mik::k_ss_reduce" in rows
+    c = rows[kern]
+    assert abs(tj["hbm_bytes_per_launch"] - (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0) <= 1e-6 * tj["hbm_bytes_per_launch"]
+    assert abs(tj["tcc_hit_rate"] - c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])) < 1e-9
+    busy = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
+    assert 0.5 < busy < 1.0 and abs(busy - tj["mfma_busy_fraction"]) < 1e-9
+    # and the bench line of the same evidence run agrees with it to a few per cent (live collection in the same run)
+    b = json.load(open(os.path.join(ROOT, src.replace("_rocprofv3_pmc_per_kernel.csv", ".json"))))
+    assert b["roofline"]["kernel"] == "k_contract" and b["roofline"]["traffic"] is not None
+    assert abs(b["roofline"]["traffic"] - tj["hbm_bytes_per_launch"]) <= 0.05 * tj["hbm_bytes_per_launch"]
