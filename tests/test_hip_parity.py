@@ -742,6 +742,44 @@ def test_integration_md_stub_runs_as_written():
     assert np.all(z[mask] == 0.0) and np.all(ss[mask] == 0.0)
 
 
+def test_integration_md_grid_stub_runs_as_written():
+    """The second stub of INTEGRATION.md section B -- style='grid' / 'masked' through mik_set_grid, the axes instead of the meshgrid
+    -- executed verbatim (after the first stub, which it extends) on an object carrying OrdinaryKriging's attributes, against the
+    reference's stored answer for an ANISOTROPIC fixture with exact hits."""
+    import os
+    import re
+    import types
+
+    lib = _lib()
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", text, flags=re.S)
+    first = next(b for b in blocks if "def _hip_exec(" in b)
+    second = next(b for b in blocks if "def _hip_exec_grid" in b)
+    ns = {}
+    exec(first.replace('C.CDLL("libmikrige.so")', "C.CDLL(%r)" % lib.LIB_PATH), ns)
+    exec(second, ns)
+    name = "ok2d_exponential_exact"
+    g = fx.load(name)
+    st = fx.state_from(name, g)
+
+    def exponential_variogram_model(m, d):  # only its __name__ is read
+        return None
+
+    fake = types.SimpleNamespace(X_ADJUSTED=st.coords_adj[:, 0], Y_ADJUSTED=st.coords_adj[:, 1], Z=st.values,
+                                 variogram_function=exponential_variogram_model, variogram_model_parameters=list(st.params),
+                                 eps=1e-10, exact_values=st.exact_values, anisotropy_scaling=float(st.scaling[0]),
+                                 anisotropy_angle=float(st.angle[0]), XCENTER=float(st.center[0]), YCENTER=float(st.center[1]))
+    z, ss = ns["_hip_exec_grid"](fake, g["gridx"], g["gridy"])
+    assert float(st.scaling[0]) != 1.0 or float(st.angle[0]) != 0.0  # the fixture really is anisotropic
+    np.testing.assert_allclose(z, g["z"], rtol=0, atol=Z_TOL)
+    np.testing.assert_allclose(ss, g["ss"], rtol=0, atol=SS_TOL)
+    rng = np.random.default_rng(5)
+    mask = rng.random(z.shape) < 0.3
+    zm, sm = ns["_hip_exec_grid"](fake, g["gridx"], g["gridy"], mask)
+    np.testing.assert_allclose(zm[~mask], g["z"][~mask], rtol=0, atol=Z_TOL)
+    assert np.all(zm[mask] == 0.0) and np.all(sm[mask] == 0.0)
+
+
 def test_pseudo_inverse_fast_path_refuses_what_it_cannot_prove():
     """pseudo_inv on a rank deficiency that is NOT duplicated stations -- collinear stations under a regional-linear drift make
     two drift columns linearly dependent -- : the null space is found numerically and deflated (factor_path 6, round 3), the
