@@ -13,4 +13,5 @@ cp $S/small_problem_latency.txt $P/${R}_small_problem_latency.txt
 cp $S/inverse_ab.txt $P/${R}_inverse_variants_ab.txt; cp $S/execute_overhead.txt $P/${R}_execute_overhead.txt
 cp $S/reference_benchmark_shapes.txt $P/${R}_reference_benchmark_shapes.txt; cp $S/pmc_per_kernel.csv $P/${R}_bench_c2_rocprofv3_pmc_per_kernel.csv
 cp $S/inverse_timeline_final.txt $P/${R}_inverse_timeline_final_state.txt
+cp $S/randomized_3000.txt $P/${R}_randomized_parity_3000_cases.txt; cp $S/execute_breakdown.txt $P/${R}_execute_breakdown.txt
 python scripts/make_traffic_json.py $P/${R}_bench_c2_rocprofv3_pmc_per_kernel.csv $P/${R}_bench_c2.json > $P/k_contract_traffic.json.tmp && mv $P/k_contract_traffic.json.tmp $P/k_contract_traffic.json

@@ -4,6 +4,7 @@
 OUT=$PWD/gpurun_out/${1:-final}; mkdir -p $OUT; REPO=$PWD
 { nproc; free -g | head -2; rocm-smi --showproductname 2>&1 | head -8; grep -m1 "model name" /proc/cpuinfo; } > $OUT/env.txt 2>&1
 timeout 1200 python -m pytest tests -m gpu -q --tb=short -s > $OUT/pytest_gpu.txt 2>&1; echo "pytest exit $?" >> $OUT/pytest_gpu.txt; tail -3 $OUT/pytest_gpu.txt
+{ echo "MIK_FUZZ_CASES=3000 python -m pytest tests/test_randomized_parity.py -m gpu -q -s   (MI355X, HEAD of round 3: probe-verified inverse, device-generated grids, zero-copy results, new moving-window kernels)"; MIK_FUZZ_CASES=3000 timeout 900 python -m pytest tests/test_randomized_parity.py -m gpu -q -s 2>&1 | tail -6; } > $OUT/randomized_3000.txt 2>&1; tail -2 $OUT/randomized_3000.txt
 timeout 900 python bench.py --steps 5 --warmup 2 > $OUT/bench_c2.json 2> $OUT/bench.err; cut -c1-300 $OUT/bench_c2.json
 for c in 3 4 5; do timeout 900 python bench.py --steps 3 --warmup 1 --config $c > $OUT/bench_c$c.json 2>> $OUT/bench.err; done
 for k in 10 50 100; do timeout 600 python bench.py --steps 3 --warmup 1 --moving-window $k > $OUT/bench_mw$k.json 2>> $OUT/bench.err; done
@@ -13,6 +14,7 @@ timeout 600 python bench.py --gpus 8 --steps 1 --warmup 1 > $OUT/bench_g8.json 2
 timeout 900 python bench.py --gpus 8 --config 5 --steps 1 --warmup 1 > $OUT/bench_g8_c5.json 2>> $OUT/bench.err
 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 2 --steps 2 --warmup 1 > $OUT/bench_2rank.json 2> $OUT/bench_2rank.err
 timeout 300 python scripts/stat_time.py > $OUT/stat_time.txt 2>&1
+timeout 300 python scripts/execute_breakdown.py 2 3 4 > $OUT/execute_breakdown.txt 2>&1
 timeout 300 python scripts/small_problem_latency.py > $OUT/small_problem_latency.txt 2>&1
 timeout 300 python scripts/inverse_lookahead_ab.py > $OUT/inverse_ab.txt 2>&1
 { for g in 1 0; do echo "MIK_DEVICE_GRID=$g"; MIK_DEVICE_GRID=$g timeout 300 python scripts/execute_overhead.py 2 2>&1 | head -2; done; } > $OUT/execute_overhead.txt
