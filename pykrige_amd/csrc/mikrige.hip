@@ -3216,10 +3216,14 @@ int mik_take_results(mik_handle* h, double** z_out, double** ss_out) {
     return fail(MIK_ESTATE, "mik_take_results: only for one device and unmasked points (use mik_get_results)");
   HIPC(hipSetDevice(h->device));
   HIPC(hipEventSynchronize(h->ev_d2h));
+  const size_t bytes = h->pin_out.bytes;
   double* base = static_cast<double*>(h->pin_out.lend());
   *z_out = base;
   *ss_out = base + h->npt;
   h->have_results = false;  // they have left the handle
+  // the landing zone of the NEXT predict now (recycled from the pool, or page-locked here): a loop of execute() calls then
+  // allocates in its first call only, not in the set-up of its second one
+  (void)h->pin_out.ensure(bytes);
   return MIK_OK;
 }
 
