@@ -165,14 +165,16 @@ def test_results_without_the_last_copy_are_the_same_results():
     del ok
     gc.collect()
     assert np.array_equal(z1, keep_z) and np.array_equal(s1, keep_s)  # the handle is gone, the arrays are not
-    # a dropped result's buffer comes back: after z2 / s2 are released the next result lands at one of the two known addresses
-    addr2 = z2.__array_interface__["data"][0]
+    # dropped results' buffers come back: a loop that drops what it gets cycles through a bounded set of buffers
     del z2, s2
     gc.collect()
     ok2 = pa.OrdinaryKriging(g["x"], g["y"], g["v"], variogram_model="exponential", variogram_parameters=[1.0, 0.3, 0.0])
-    z3, s3 = ok2.execute("grid", g["gridx"], g["gridy"], backend="loop")
-    assert z3.__array_interface__["data"][0] == addr2
-    assert np.array_equal(z3, keep_z)
+    seen = set()
+    for _ in range(8):
+        z3, s3 = ok2.execute("grid", g["gridx"], g["gridy"], backend="loop")
+        seen.add(z3.__array_interface__["data"][0])
+        assert np.array_equal(z3, keep_z)
+    assert len(seen) <= 3, seen  # (the one in flight, the one held by the caller, the one being readied)
     h = ok2._get_handle()
     a, b = h.get_results()  # asked twice before the next predict: the same arrays again
     assert a.__array_interface__["data"][0] == z3.__array_interface__["data"][0]
