@@ -328,8 +328,8 @@ FACTOR_PATHS = {1: "spd-shift block sweep", 2: "pivoted block gauss-jordan", 3: 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)  # (the part's clock settles over the first second of load)
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-sample", type=int, default=4096, help="points of the bounded CPU slab")
