@@ -2569,23 +2569,31 @@ __global__ void __launch_bounds__(256, 2) k_mw_chol_blocked(MwArgs a, double* __
         LR[i * MIK_MWP_LD + k] = (k <= i) ? A[(long)(c0 + i) * ldc + c0 + k] : 0.0;
       }
       __syncthreads();
+      // right-looking elimination WITHOUT scaling the pivot column first: (i, k) -= a_ij a_kj / d_j uses the raw column j, which
+      // no later step touches -- one barrier per step instead of two, and no square root or division in the loop (round 3: this
+      // loop was more than half of the kernel at K = 257 .. 512); the columns are scaled to the Cholesky factor in one pass after it
       for (int j = 0; j < MIK_MWP; ++j) {
         const double d = LR[j * MIK_MWP_LD + j];  // (the barrier at the end of the previous step ordered its updates before this)
-        const double rs = 1.0 / sqrt(d > 0.0 ? d : 1.0);
-        if (l > j && l < MIK_MWP) LR[l * MIK_MWP_LD + j] *= rs;  // the column below the pivot; the pivot itself is not touched yet
-        __syncthreads();
+        const double inv = pivot_recip(d > 0.0 ? d : 1.0);
         if (l == 0) {
           if (!(d > 0.0)) sh_bad = 1;
-          LR[j * MIK_MWP_LD + j] = d * rs;  // sqrt(d); nobody reads it before the panel solve
-          rdiag[j] = rs;
+          rdiag[j] = inv;  // 1 / d_j for now
         }
         {  // trailing part of the block: (i, k), j < k <= i < 64
           const int i = l & 63;
-          const double lij = LR[i * MIK_MWP_LD + j];
-          for (int k = j + 1 + (l >> 6); k <= i; k += 4) LR[i * MIK_MWP_LD + k] -= lij * LR[k * MIK_MWP_LD + j];
+          const double aij = LR[i * MIK_MWP_LD + j] * inv;
+          for (int k = j + 1 + (l >> 6); k <= i; k += 4) LR[i * MIK_MWP_LD + k] -= aij * LR[k * MIK_MWP_LD + j];
         }
         __syncthreads();
       }
+      {  // L_ij = a_ij / sqrt(d_j) (i > j), L_jj = sqrt(d_j), rdiag[j] = 1 / L_jj
+        const int j = l & 63;
+        const double rs = sqrt(rdiag[j]);
+        __syncthreads();  // everyone has read 1 / d_j
+        for (int i = j + (l >> 6); i < MIK_MWP; i += 4) LR[i * MIK_MWP_LD + j] *= rs;  // (the diagonal: d_j / sqrt(d_j))
+        if (l < MIK_MWP) rdiag[j] = rs;
+      }
+      __syncthreads();
       for (int e = l; e < MIK_MWP * MIK_MWP; e += 256) {  // the factored block goes back (lower part)
         const int i = e >> 6, k = e & 63;
         if (k <= i) A[(long)(c0 + i) * ldc + c0 + k] = LR[i * MIK_MWP_LD + k];
