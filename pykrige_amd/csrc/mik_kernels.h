@@ -2513,8 +2513,17 @@ __global__ void __launch_bounds__(256, 2) k_mw_chol_blocked(MwArgs a, double* __
   double* A = scratch + (long)blockIdx.x * slot;       // (ldc + 64) x ldc
   double* cs = A + (long)(ldc + MIK_MWP) * ldc;        // coordinates of the selected stations: x | y | z, K each
   const double* bv = nullptr;
+#ifdef MIK_MW_PROFILE
+  long long tph[6] = {0, 0, 0, 0, 0, 0}, tlast = 0;
+#define MWP_TICK(i) do { __syncthreads(); const long long now_ = wall_clock64(); tph[i] += now_ - tlast; tlast = now_; } while (0)
+#else
+#define MWP_TICK(i) do { } while (0)
+#endif
   for (long pt = blockIdx.x; pt < a.npt; pt += gridDim.x) {
     __syncthreads();
+#ifdef MIK_MW_PROFILE
+    tlast = wall_clock64();
+#endif
     if (l == 0) sh_bad = 0;
     bv = a.dist + pt * K;  // b = -gamma(d), 0 on an exact hit (k_mw_rhs)
     double gmax = 0.0;
@@ -2561,6 +2570,7 @@ __global__ void __launch_bounds__(256, 2) k_mw_chol_blocked(MwArgs a, double* __
       }
     }
     __syncthreads();
+    MWP_TICK(0);  // set-up: stations, right-hand sides, matrix fill
     for (int p = 0; p < nP; ++p) {
       const int c0 = p * MIK_MWP;
       // (a) diagonal block -> LDS, row-major, lower part; Cholesky in place
@@ -2598,6 +2608,7 @@ __global__ void __launch_bounds__(256, 2) k_mw_chol_blocked(MwArgs a, double* __
         const int i = e >> 6, k = e & 63;
         if (k <= i) A[(long)(c0 + i) * ldc + c0 + k] = LR[i * MIK_MWP_LD + k];
       }
+      MWP_TICK(1);  // (a) diagonal block
       // (b) the rows below: x L^T = a  ->  x_j = (a_j - sum_{k<j} x_k L_jk) / L_jj, one row per thread, 16 entries at a time:
       // the solved part of the row is read back from the scratch slot (a fully unrolled 64-entry register version spilled)
       // (rows K..ldc-1 are identity padding: zero in this panel, nothing to solve; the thread index runs over the real rows)
@@ -2638,6 +2649,7 @@ __global__ void __launch_bounds__(256, 2) k_mw_chol_blocked(MwArgs a, double* __
         }
       }
       __syncthreads();
+      MWP_TICK(2);  // (b) panel solve
       // (c) trailing update, tiles (rb, sb) of 64 x 64 with sb <= rb; the right-hand sides are the 3-row block after the matrix
       const int nb_rows = nP - p - 1;  // matrix row blocks below the panel
       for (int rb = 0; rb <= nb_rows; ++rb) {
@@ -2695,7 +2707,9 @@ __global__ void __launch_bounds__(256, 2) k_mw_chol_blocked(MwArgs a, double* __
         __syncthreads();  // the tiles of this row block are done with LR
       }
       __syncthreads();
+      MWP_TICK(3);  // (c) trailing update
     }
+    MWP_TICK(4);
     // the three solved rows y_q = L^-1 rhs_q; G_pq = y_p . y_q
     double g00 = 0.0, g01 = 0.0, g11 = 0.0, g02 = 0.0, g12 = 0.0;
     for (int c = l; c < K; c += 256) {
@@ -2718,7 +2732,13 @@ __global__ void __launch_bounds__(256, 2) k_mw_chol_blocked(MwArgs a, double* __
       a.ss[pt] = -(g00 - mu * g01) + shift - mu;
       if (sh_bad || !(g11 > 0.0)) atomicOr(a.flag, 2);
     }
+    MWP_TICK(5);
   }
+#ifdef MIK_MW_PROFILE
+  if (blockIdx.x == 0 && l == 0)
+    printf("[k_mw_chol_blocked K=%d] per block, 100 MHz ticks: set-up %lld | diagonal %lld | panel solve %lld | trailing update %lld | (gap) %lld | reduction %lld\n",
+           K, tph[0], tph[1], tph[2], tph[3], tph[4], tph[5]);
+#endif
 }
 
 // ---- n_closest_points > MIK_MW_KMAX: the same two steps with their working sets in HBM instead of registers / LDS ----
