@@ -311,6 +311,7 @@ struct mik_handle {
   std::chrono::steady_clock::time_point xchg_t0;
   double exchange_wait_ms = 0.0;  // of exchange_ms, what a caller really waited for (the rest overlapped the leader's prediction)
   int exchange_fallbacks = 0, rccl_ranks = 0;
+  int rccl_failures = 0;  // consecutive RCCL exchanges of this handle that FAILED (returned an error; a stall disables RCCL process-wide)
   int opt_async_exchange = 1;  // "async_exchange": mik_factor returns after the leader's K1 + K2; the exchange is joined by the next call
   double rccl_init_limit = 120.0, rccl_bcast_limit = 30.0, peer_limit = 30.0;  // seconds; MIK_RCCL_INIT_TIMEOUT, MIK_RCCL_BCAST_TIMEOUT, MIK_PEER_TIMEOUT
 };
@@ -2242,6 +2243,7 @@ static int join_exchange(mik_handle* h) {
       rc = path == 1 ? MIK_ERCCL : MIK_EHIP;
       abandon_exchange(h, j.get());
     }
+    if (path == 1) h->rccl_failures = rc == MIK_OK ? 0 : h->rccl_failures + 1;
     if (rc == MIK_OK) {
       h->exchange_used = path;
       h->rccl_ranks = j->rccl_ranks;
@@ -2312,6 +2314,12 @@ int mik_factor(mik_handle* h) {
   int path = h->opt_exchange == 2 ? 2 : 1;
   if (path == 1 && h->opt_exchange == 0 && g_rccl_dead.load()) {
     h->exchange_note = "rccl disabled for this process (" + g_rccl_dead_why + ")";
+    ++h->exchange_fallbacks;
+    path = 2;
+  } else if (path == 1 && h->opt_exchange == 0 && h->rccl_failures >= 2) {
+    // RCCL returned an error twice in a row on this handle (it does every time on aliased devices, and a broken set-up may take
+    // seconds to say so): not tried again on it -- peer copies directly
+    h->exchange_note = "rccl failed on the last two exchanges of this handle: not tried again";
     ++h->exchange_fallbacks;
     path = 2;
   }
