@@ -280,6 +280,78 @@ __global__ void __launch_bounds__(256) k_grid_points(GridArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// style='masked' (ok.py:700 np.nonzero(~mask); cok.pyx:57-58): the ascending list of the unmasked cells, built on the device
+// from the caller's byte mask -- count per 4096-cell block, exclusive scan of the counts by one block, ordered write.  The
+// mask buffer is padded with "masked" bytes to a whole number of blocks, so no kernel checks a bound.  Replaces an
+// O(cells) host pass that also had to first-touch 8 bytes per unmasked cell.
+// ------------------------------------------------------------------------------------------------
+#define MIK_MASK_CELLS 4096
+__device__ __forceinline__ unsigned mask_zero_bytes(unsigned w) {
+  return ((w & 0xffu) == 0u) + ((w & 0xff00u) == 0u) + ((w & 0xff0000u) == 0u) + ((w & 0xff000000u) == 0u);
+}
+
+__global__ void __launch_bounds__(256) k_mask_count(const uint4* __restrict__ mask, unsigned* __restrict__ counts) {
+  const uint4 m = mask[(size_t)blockIdx.x * 256 + threadIdx.x];
+  unsigned c = mask_zero_bytes(m.x) + mask_zero_bytes(m.y) + mask_zero_bytes(m.z) + mask_zero_bytes(m.w);
+  for (int o = 32; o; o >>= 1) c += __shfl_down(c, o);
+  __shared__ unsigned w[4];
+  if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) counts[blockIdx.x] = w[0] + w[1] + w[2] + w[3];
+}
+
+// counts[0 .. nblk) -> their exclusive prefix sums in place, counts[nblk] = the total (fewer than 2^32 cells per call)
+__global__ void __launch_bounds__(1024) k_mask_scan(unsigned* counts, long nblk) {
+  __shared__ unsigned ws[16];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  unsigned carry = 0;
+  for (long base = 0; base < nblk; base += 1024) {
+    const long i = base + threadIdx.x;
+    const unsigned v = i < nblk ? counts[i] : 0u;
+    unsigned s = v;
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned t = __shfl_up(s, o);
+      if (lane >= o) s += t;
+    }
+    if (lane == 63) ws[wv] = s;
+    __syncthreads();
+    unsigned before = 0, total = 0;
+    for (int k = 0; k < 16; ++k) {
+      const unsigned x = ws[k];
+      before += k < wv ? x : 0u;
+      total += x;
+    }
+    if (i < nblk) counts[i] = carry + before + s - v;
+    carry += total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) counts[nblk] = carry;
+}
+
+__global__ void __launch_bounds__(256) k_mask_write(const uint4* __restrict__ mask, const unsigned* __restrict__ offs, unsigned* __restrict__ idx) {
+  const uint4 m = mask[(size_t)blockIdx.x * 256 + threadIdx.x];
+  const unsigned c = mask_zero_bytes(m.x) + mask_zero_bytes(m.y) + mask_zero_bytes(m.z) + mask_zero_bytes(m.w);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  unsigned s = c;
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned t = __shfl_up(s, o);
+    if (lane >= o) s += t;
+  }
+  __shared__ unsigned w[4];
+  if (lane == 63) w[wv] = s;
+  __syncthreads();
+  unsigned k = offs[blockIdx.x] + s - c;
+  for (int q = 0; q < wv; ++q) k += w[q];
+  const unsigned cell = blockIdx.x * (unsigned)MIK_MASK_CELLS + threadIdx.x * 16u;
+  const unsigned words[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+      if (((words[q] >> (8 * b)) & 0xffu) == 0u) idx[k++] = cell + 4u * q + b;
+}
+
+// ------------------------------------------------------------------------------------------------
 // K3a: right-hand sides for a chunk of points, written POINT-MAJOR: Bt[t][j], j contiguous, ld = Mp
 // (this is the reference's `b` array layout, ok.py:669, and the "NT" operand layout of k_gemm_nt).
 //   j <  N      : -gamma(|g_t - X_j|), 0 if |d| <= eps and exact_values  (ok.py:665-672, cok.pyx:196-203)

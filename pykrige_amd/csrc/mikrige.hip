@@ -292,7 +292,10 @@ struct mik_handle {
   // points
   long npt_total = 0, npt = 0;
   bool masked = false;  // the caller's mask skipped at least one point: outputs are zero-filled before the scatter
-  std::vector<long> scatter;  // empty = identity
+  std::vector<long> scatter;  // empty = identity (mik_set_points under a mask)
+  const unsigned* scatter32 = nullptr;  // mik_set_grid under a mask: this member's slab of the leader's page-locked index list
+  DevBuf mask_dev, mask_cnt;  // the byte mask (padded to whole blocks) and the per-block counts / offsets of its compaction
+  PinBuf scatter_pin;         // the compacted index list on the host (leader)
   DevBuf px, py, pz, extra_rows, z, ss;
   DevBuf grid_axes, grid_idx;  // mik_set_grid: the axes and (masked style) the slab's compacted cell numbers
   // work
@@ -2425,6 +2428,7 @@ static int one_set_points(mik_handle* h, const mik_points* g, const long* idx, l
   h->out_off = lo;
   if (idx) h->scatter.assign(idx + lo, idx + lo + n);
   else h->scatter.clear();
+  h->scatter32 = nullptr;
   const long cap = std::max<long>(n, 1);
   const int rows = h->ndim + h->nextra;
   MIKC(h->pin_in.ensure(sizeof(double) * (size_t)cap * rows));
@@ -2508,13 +2512,15 @@ int mik_set_points(mik_handle* h, const mik_points* g) {
 // The slab [lo, lo + n) of the unmasked cells of a grid given by its axes, generated on ONE device (k_grid_points).  idx as
 // in one_set_points.  H2D: the axes, the slab's compacted cell numbers (4 bytes per point, masked style only) and the
 // host-evaluated drift rows if the problem has any.
-static int one_set_grid(mik_handle* h, const mik_grid* g, const long* idx, long lo, long n, long first, long ncells) {
+// `idx`: the leader's page-locked list of the unmasked cells (nullptr = no mask); the leader's device copy of it is already in
+// its grid_idx (compact_mask), the other members upload their slab
+static int one_set_grid(mik_handle* h, bool leader, const mik_grid* g, const unsigned* idx, long lo, long n, long first, long ncells) {
   HIPC(hipSetDevice(h->device));
   HIPC(hipStreamSynchronize(h->stream_d2h));  // result copies of an earlier predict still read z / ss
   h->npt = n;
   h->out_off = lo;
-  if (idx) h->scatter.assign(idx + lo, idx + lo + n);
-  else h->scatter.clear();
+  h->scatter.clear();
+  h->scatter32 = idx ? idx + lo : nullptr;
   const long cap = std::max<long>(n, 1);
   const int three = g->ndim == 3;
   const long nax = g->nx + g->ny + (three ? g->nz : 0);
@@ -2526,17 +2532,10 @@ static int one_set_grid(mik_handle* h, const mik_grid* g, const long* idx, long 
   MIKC(h->px.ensure(sizeof(double) * cap));
   MIKC(h->py.ensure(sizeof(double) * cap));
   if (three) MIKC(h->pz.ensure(sizeof(double) * cap));
-  const size_t stage_bytes = std::max(sizeof(double) * (size_t)cap * (size_t)std::max(h->nextra, 1), sizeof(unsigned) * (size_t)cap);
-  if (idx || h->nextra) MIKC(h->pin_in.ensure(stage_bytes));
-  if (idx && n > 0) {
+  if (h->nextra) MIKC(h->pin_in.ensure(sizeof(double) * (size_t)cap * (size_t)h->nextra));
+  if (idx && n > 0 && !leader) {
     MIKC(h->grid_idx.ensure(sizeof(unsigned) * (size_t)cap));
-    unsigned* st = h->pin_in.as<unsigned>();
-    const long* ix = idx + lo;
-    parallel_chunks(n, [&](int, long b, long e) {
-      for (long i = b; i < e; ++i) st[i] = (unsigned)ix[i];
-    });
-    HIPC(hipMemcpyAsync(h->grid_idx.p, st, sizeof(unsigned) * (size_t)n, hipMemcpyHostToDevice, h->stream));
-    HIPC(hipStreamSynchronize(h->stream));  // the staging buffer is reused for the drift rows below
+    HIPC(hipMemcpyAsync(h->grid_idx.p, idx + lo, sizeof(unsigned) * (size_t)n, hipMemcpyHostToDevice, h->stream));
   }
   if (h->nextra) {
     MIKC(h->extra_rows.ensure(sizeof(double) * (size_t)cap * h->nextra));
@@ -2544,7 +2543,7 @@ static int one_set_grid(mik_handle* h, const mik_grid* g, const long* idx, long 
       const double* from = g->extra_rows + (size_t)r * ncells;
       double* stage = h->pin_in.as<double>() + (size_t)r * cap;
       if (idx) {
-        const long* ix = idx + lo;
+        const unsigned* ix = idx + lo;
         parallel_chunks(n, [&](int, long b, long e) {
           for (long i = b; i < e; ++i) stage[i] = from[ix[i]];
         });
@@ -2561,7 +2560,7 @@ static int one_set_grid(mik_handle* h, const mik_grid* g, const long* idx, long 
     a.gz = three ? ax + g->nx + g->ny : nullptr;
     a.nx = g->nx, a.ny = g->ny, a.nz = three ? g->nz : 1;
     a.cell0 = idx ? first : first + lo, a.n = n;
-    a.idx = idx ? h->grid_idx.as<unsigned>() : nullptr;
+    a.idx = idx ? h->grid_idx.as<unsigned>() + (leader ? lo : 0) : nullptr;
     a.ndim = g->ndim, a.adjust = g->adjust ? 1 : 0;
     for (int i = 0; i < 3; ++i) a.c[i] = g->center[i], a.st[i] = g->stretch[i];
     for (int i = 0; i < 9; ++i) a.rot[i] = g->rot[i];
@@ -2575,6 +2574,37 @@ static int one_set_grid(mik_handle* h, const mik_grid* g, const long* idx, long 
   HIPC(hipStreamSynchronize(h->stream));
   h->have_points = true;
   h->have_results = false;
+  return MIK_OK;
+}
+
+// the unmasked cells of mik_set_grid's range, ascending, as 32-bit offsets from its first cell: in the leader's grid_idx (device)
+// and scatter_pin (host, for the other members' slabs, the gathers of host-evaluated drift rows and the scatter of the results)
+static int compact_mask(mik_handle* h, const int8_t* mask, long ncells, long* n_out) {
+  HIPC(hipSetDevice(h->device));
+  HIPC(hipStreamSynchronize(h->stream_d2h));
+  const long nblk = (ncells + MIK_MASK_CELLS - 1) / MIK_MASK_CELLS;
+  const size_t padded = (size_t)nblk * MIK_MASK_CELLS;
+  MIKC(h->pin_in.ensure(padded));
+  MIKC(h->mask_dev.ensure(padded));
+  MIKC(h->mask_cnt.ensure(sizeof(unsigned) * (size_t)(nblk + 1)));
+  host_copy(h->pin_in.p, mask, (size_t)ncells);
+  memset(h->pin_in.as<char>() + ncells, 1, padded - (size_t)ncells);
+  HIPC(hipMemcpyAsync(h->mask_dev.p, h->pin_in.p, padded, hipMemcpyHostToDevice, h->stream));
+  unsigned* cnt = h->mask_cnt.as<unsigned>();
+  hipLaunchKernelGGL(k_mask_count, dim3((unsigned)nblk), dim3(256), 0, h->stream, h->mask_dev.as<uint4>(), cnt);
+  hipLaunchKernelGGL(k_mask_scan, dim3(1), dim3(1024), 0, h->stream, cnt, nblk);
+  HIPC(hipGetLastError());
+  unsigned total = 0;
+  HIPC(hipMemcpyAsync(&total, cnt + nblk, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+  HIPC(hipStreamSynchronize(h->stream));
+  *n_out = (long)total;
+  if (total == 0 || (long)total == ncells) return MIK_OK;
+  MIKC(h->grid_idx.ensure(sizeof(unsigned) * (size_t)total));
+  MIKC(h->scatter_pin.ensure(sizeof(unsigned) * (size_t)total));
+  hipLaunchKernelGGL(k_mask_write, dim3((unsigned)nblk), dim3(256), 0, h->stream, h->mask_dev.as<uint4>(), cnt, h->grid_idx.as<unsigned>());
+  HIPC(hipGetLastError());
+  HIPC(hipMemcpyAsync(h->scatter_pin.p, h->grid_idx.p, sizeof(unsigned) * (size_t)total, hipMemcpyDeviceToHost, h->stream));
+  HIPC(hipStreamSynchronize(h->stream));
   return MIK_OK;
 }
 
@@ -2592,20 +2622,18 @@ int mik_set_grid(mik_handle* h, const mik_grid* g) {
   if (ncells >= 4294967296L) return fail(MIK_EINVAL, "mik_set_grid: more than 2^32 - 1 cells in one call (use cell_first / cell_count)");
   if (h->nextra > 0 && !g->extra_rows) return fail(MIK_EINVAL, "extra_rows missing for host-evaluated drifts");
   h->npt_total = ncells;
-  std::vector<long> idx;
   long n = ncells;
   h->masked = false;
   if (g->mask) {
-    unmasked_positions(g->mask, ncells, idx);
-    n = (long)idx.size();
+    MIKC(compact_mask(h, g->mask, ncells, &n));
     h->masked = n != ncells;
   }
-  const long* ip = h->masked ? idx.data() : nullptr;
+  const unsigned* ip = h->masked ? h->scatter_pin.as<unsigned>() : nullptr;
   const int members = (int)h->kids.size() + 1;
   return for_each_device(h, [&](int i, mik_handle* d) {
     long lo, cnt;
     slab_of(n, members, i, &lo, &cnt);
-    return one_set_grid(d, g, ip, lo, cnt, first, ncells);
+    return one_set_grid(d, i == 0, g, ip, lo, cnt, first, ncells);
   });
 }
 
@@ -3233,6 +3261,16 @@ static int one_get_results(mik_handle* h, double* z_out, double* ss_out) {
   const double* hz = h->pin_out.as<double>();
   const double* hs = hz + n;
   if (n == 0) return MIK_OK;
+  if (h->scatter32) {
+    const unsigned* ix = h->scatter32;
+    parallel_chunks(n, [&](int, long b, long e) {
+      for (long i = b; i < e; ++i) {
+        z_out[ix[i]] = hz[i];
+        ss_out[ix[i]] = hs[i];
+      }
+    });
+    return MIK_OK;
+  }
   if (h->scatter.empty()) {
     host_copy(z_out + h->out_off, hz, sizeof(double) * n);
     host_copy(ss_out + h->out_off, hs, sizeof(double) * n);
@@ -3263,7 +3301,7 @@ int mik_get_results(mik_handle* h, double* z_out, double* ss_out) {
 int mik_take_results(mik_handle* h, double** z_out, double** ss_out) {
   if (!h || !z_out || !ss_out) return fail(MIK_EINVAL, "mik_take_results: NULL argument");
   if (!h->have_results) return fail(MIK_ESTATE, "mik_take_results: predict first");
-  if (!h->kids.empty() || h->masked || !h->scatter.empty() || h->out_off != 0 || h->npt != h->npt_total || h->npt == 0)
+  if (!h->kids.empty() || h->masked || !h->scatter.empty() || h->scatter32 || h->out_off != 0 || h->npt != h->npt_total || h->npt == 0)
     return fail(MIK_ESTATE, "mik_take_results: only for one device and unmasked points (use mik_get_results)");
   HIPC(hipSetDevice(h->device));
   HIPC(hipEventSynchronize(h->ev_d2h));

@@ -20,5 +20,5 @@ for style, kw in (("grid", {}), ("masked", {"mask": mask})):
         z, ss = ok.execute(style, ax, ax, backend="loop", **kw)
         ts.append(time.perf_counter() - t0)
     t = ok.last_timing
-    dev = t["assemble_ms"] + t["invert_ms"] + t["verify_ms"] + t["predict_ms"]
-    print("N=500, %d x %d, style=%-6s: execute() %.1f ms, device phases %.1f ms, the rest %.1f ms" % (n, n, style, min(ts) * 1e3, dev, min(ts) * 1e3 - dev), flush=True)
+    dev = t["predict_ms"]  # the factorization is the cached one (same stations, same model)
+    print("N=500, %d x %d, style=%-6s: execute() %.1f ms, of which mik_predict on the device %.1f ms, the rest %.1f ms" % (n, n, style, ts[-1] * 1e3, dev, ts[-1] * 1e3 - dev), flush=True)

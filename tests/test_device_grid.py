@@ -87,6 +87,43 @@ def test_device_grid_points_equal_the_host_meshgrid(case):
 
 
 @pytest.mark.gpu
+def test_the_list_of_unmasked_cells_is_built_on_the_device_in_meshgrid_order():
+    """style='masked' through mik_set_grid: the byte mask is compacted by k_mask_count / k_mask_scan / k_mask_write (ascending
+    cell order = np.nonzero(~mask), ok.py:700).  Sizes around the 4096-cell block of the kernels, runs of masked cells longer
+    than a block, masks with nothing / everything masked, and the scatter of the results back through the list."""
+    from pykrige_amd import _lib
+
+    rng = np.random.default_rng(11)
+    c, v = fx.synth(2, 40, 2)
+    h = _lib.Handle(0)
+    h.set_problem(ndim=2, xs=c[0], ys=c[1], zs=None, values=v, model_id=4, params=[1.0, 0.3, 0.0])
+    for nx, ny in ((1, 1), (64, 64), (64, 65), (4095, 1), (1, 4097), (300, 211), (1000, 1037)):
+        axes = [np.linspace(0.0, 1.0, nx), np.linspace(0.0, 1.0, ny)]
+        full = np.stack(np.meshgrid(axes[0], axes[1]), -1).reshape(-1, 2)
+        ncell = nx * ny
+        masks = [rng.random(ncell) < 0.5, rng.random(ncell) < 0.999, rng.random(ncell) < 0.001, np.zeros(ncell, bool), np.ones(ncell, bool)]
+        runs = np.zeros(ncell, bool)
+        runs[ncell // 7: ncell // 7 + 9000] = True  # more than two whole blocks with no unmasked cell
+        runs[-1:] = True
+        masks.append(runs)
+        for m in masks:
+            h.set_grid(axes, mask=m)
+            assert int(h._lib.mik_points_resident(h._h)) == int((~m).sum())
+            if (~m).any():
+                assert np.array_equal(h.get_points(2), full[~m])
+            h.factor()
+            h.predict()
+            z, ss = h.get_results()
+            assert z.shape == (ncell,) and np.all(z[m] == 0.0) and np.all(ss[m] == 0.0)
+            if (~m).any():
+                h.set_points(full[~m, 0].copy(), full[~m, 1].copy())
+                h.predict()
+                z2, ss2 = h.get_results()
+                assert np.array_equal(z[~m], z2) and np.array_equal(ss[~m], ss2)
+    h.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", ["ok2d_exponential_exact", "ok2d_spherical_noexact", "ok3d_gaussian_aniso", "uk2d_rl_pl_node",
                                   "uk2d_external_z", "ok2d_masked_points", "ok2d_n2000", "uk3d_rl_func"])
 def test_execute_from_axes_equals_execute_from_host_points(name):
