@@ -178,6 +178,8 @@ int  mik_slab_of(int64_t n, int members, int i, int64_t *lo, int64_t *count); /*
  * "update_waves" 4 | 8 = wavefronts per 128 x 128 tile of the block sweep's trailing update (wave tile 64 x 64 / 32 x 64; same bits;
  *   default 8)
  *   [MIK_UPDATE_WAVES] ;
+ * "panel_rows" 32 | 64 | 128 = rows of the column panel one block of the sweep's panel kernel forms (same bits; default 32:
+ *   four times the blocks of the one-tile form, the kernel sits on the update stream's critical path) [MIK_PANEL_ROWS] ;
  * "pinv_fast" 0/1 = pseudo_inv: try the deflated regular inverse before the Jacobi pseudo-inverse (default 1) ;
  * "verify" 0/1 = probe every inverse the device computes against the matrix itself before it is used (default 1):
  *   res_z = max |A c - [Z; 0]| / max(1, max|Z|) with c = A_inv[:, :n] Z (bounds the error of z: z_g = w_g . (A c)) and

@@ -541,8 +541,9 @@ __device__ __forceinline__ void gemm_core(const double* __restrict__ Ag, long ld
   constexpr int WROWS = 16 * NAI;            // rows of the wave tile
   constexpr int NTHR = 64 * 2 * (BM / WROWS);
   constexpr int PROWS = NTHR / 8;            // rows staged per pass (8 threads x 16 B per 128-B row)
-  constexpr int NPASS = BM / PROWS;          // passes over the A tile
-  constexpr int NPASS_B = MIK_BN / PROWS;    // passes over the B tile (fewer when BM > MIK_BN)
+  constexpr int NPASS_A = BM / PROWS;        // passes over the A tile
+  constexpr int NPASS_B = MIK_BN / PROWS;    // passes over the B tile (fewer when BM > MIK_BN, more when BM < MIK_BN)
+  constexpr int NPASS = NPASS_A > NPASS_B ? NPASS_A : NPASS_B;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   // staging: thread -> (row lrow + PROWS*p, 16-byte slot tid&7); the SOURCE k-pair is the slot XOR the row's swizzle
@@ -554,7 +555,7 @@ __device__ __forceinline__ void gemm_core(const double* __restrict__ Ag, long ld
   unsigned aoffb[NPASS], boffb[NPASS];
 #pragma unroll
   for (int p = 0; p < NPASS; ++p) {
-    aoffb[p] = (unsigned)(((long)(lrow + PROWS * p) * lda + ((slot ^ (lrow & 2)) << 1)) * 8);
+    aoffb[p] = (unsigned)(((long)(lrow + PROWS * (p < NPASS_A ? p : 0)) * lda + ((slot ^ (lrow & 2)) << 1)) * 8);
     boffb[p] = (unsigned)(((long)(lrow + PROWS * (p < NPASS_B ? p : 0)) * ldb + ((slot ^ ((lrow >> 1) & 7)) << 1)) * 8);
   }
   const unsigned ldsA = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)&sm.As[0][wave * 8][0]);
@@ -581,7 +582,7 @@ __device__ __forceinline__ void gemm_core(const double* __restrict__ Ag, long ld
         asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(aoffb[p]), "s"(abase), "s"(la) : "memory");
         if (!(ABL & 32)) asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(boffb[p]), "s"(bbase), "s"(lb) : "memory");
       } else {
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(aoffb[p]), "s"(abase), "s"(la) : "memory");
+        if (p < NPASS_A) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(aoffb[p]), "s"(abase), "s"(la) : "memory");
         if (!(ABL & 32) && p < NPASS_B) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(boffb[p]), "s"(bbase), "s"(lb) : "memory");
       }
       if (ABL & 32) {
@@ -1075,6 +1076,10 @@ __global__ void k_gate(const int* __restrict__ flag, int idx, int max_polls) {
 __global__ void k_wait_ge(int* __restrict__ flag, int idx, int expect) { (void)flag_wait_ge(flag, idx, expect); }
 
 // Out[i][n] = alpha * sum_m A[i][m] * Bt[n][m],  i over Mp rows, n < 128, m < 128 (one tile column)
+// NAI: a block does 32 * NAI rows (4 waves as 2 x 2, wave tile 16 NAI x 64).  NAI = 4 is one 128 x 128 tile per block: 22 us, a
+// CU's MFMA rate, whatever Mp is; NAI = 1 (round 3, the sweep's default) spreads the same accumulation streams over 4 x the
+// blocks -- the panel kernel sits on the update stream's critical path once per step.  Same k order per entry: same bits.
+template <int NAI = 4>
 __global__ void __launch_bounds__(256, 2)
 k_panel(const double* __restrict__ A, long lda, const double* __restrict__ Bt, double alpha,
         double* __restrict__ Out, double* __restrict__ RtOut = nullptr, int k0 = 0, int blk0 = 0, int orow = 0,
@@ -1085,27 +1090,28 @@ k_panel(const double* __restrict__ A, long lda, const double* __restrict__ Bt, d
   // flag (early-diagonal schedule): wait_diag >= 0 -- Bt is the DinvT of diagonal inverse wait_diag, running on the other
   // stream: wait for its flag before touching it; gate_diag >= 0 -- block 0 leaves only when diagonal inverse gate_diag has
   // started (k_gate's hint without its launch: the update behind this kernel then finds that inverse already on its CU)
-  __shared__ GemmSmem sm;
+  constexpr int BMR = 32 * NAI;  // rows per block
+  __shared__ GemmSmemT<BMR> sm;
   if (flag && wait_diag >= 0) {
     if (threadIdx.x == 0) (void)flag_wait_ge(flag, MIK_F_DDONE + wait_diag, 1);
     __syncthreads();
   }
-  const int i0 = (blockIdx.x + blk0) * MIK_BM;
-  d4 acc[4][4];
+  const int i0 = blockIdx.x * BMR + blk0 * MIK_BM;
+  d4 acc[NAI][4];
 #pragma unroll
-  for (int x = 0; x < 4; ++x)
+  for (int x = 0; x < NAI; ++x)
 #pragma unroll
     for (int y = 0; y < 4; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
-  gemm_core<4>(A + (long)i0 * lda, lda, Bt, 128, 0, 128, acc, sm);
+  gemm_core<NAI, 0, BMR>(A + (long)i0 * lda, lda, Bt, 128, 0, 128, acc, sm);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 1, wn = wave & 1, lq = lane >> 4, lc = lane & 15;
 #pragma unroll
-  for (int ai = 0; ai < 4; ++ai)
+  for (int ai = 0; ai < NAI; ++ai)
 #pragma unroll
     for (int bi = 0; bi < 4; ++bi)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int i = i0 + wm * 64 + ai * 16 + lq + 4 * r;
+        const int i = i0 + wm * (16 * NAI) + ai * 16 + lq + 4 * r;
         const int n = wn * 64 + bi * 16 + lc;
         const double v = alpha * acc[ai][bi][r];
         Out[(long)(i - orow) * 128 + n] = v;

@@ -286,6 +286,7 @@ struct mik_handle {
   int opt_early_diag = -1; // look-ahead sweep: the next diagonal block is built and inverted ahead of the panel / update stream (-1 = with the look-ahead)
   int opt_gate = -1;       // look-ahead sweep: the trailing update waits until the next diagonal inverse has started and leaves
                            // it a CU of its own (k_gate); -1 = where the serial chain, not the update, is the step period
+  int opt_panel_rows = 32;  // rows of the column panel one block of k_panel forms: 32 (round 3), 64 or 128 (one tile, the round-1 form)
   int opt_update_waves = 8; // trailing-update kernel of the block sweep: 4 waves (wave tile 64 x 64) or 8 (32 x 64, default since round 3:
                             // -5 % at N=5000 / 8000, same bits: profiles/r03_update_waves_ab.txt) per 128 x 128 tile
   int opt_diag = 1;        // diagonal-block inverse variant: 0 = 1024 threads (16 waves x 8 rows), 1 = 16x16 grid, 2 = 16x32, 3 = 32x32
@@ -681,6 +682,8 @@ static int create_one_body(mik_handle* h, int device) {
   if (env) h->opt_early_diag = atoi(env) < 0 ? -1 : atoi(env);
   env = getenv("MIK_UPDATE_WAVES");
   if (env && (atoi(env) == 4 || atoi(env) == 8)) h->opt_update_waves = atoi(env);
+  env = getenv("MIK_PANEL_ROWS");
+  if (env && (atoi(env) == 32 || atoi(env) == 64 || atoi(env) == 128)) h->opt_panel_rows = atoi(env);
   env = getenv("MIK_RHS_OVERLAP");
   if (env) h->opt_rhs_overlap = atoi(env) ? 1 : 0;
   env = getenv("MIK_ASYNC_EXCHANGE");
@@ -788,7 +791,7 @@ static int set_group(mik_handle* h, int n) {
     }
     k->is_kid = true;
     k->opt_factor = h->opt_factor, k->opt_sym = h->opt_sym, k->opt_engine = h->opt_engine, k->opt_waves = h->opt_waves;
-    k->opt_chunk = h->opt_chunk, k->opt_symsweep = h->opt_symsweep, k->opt_diag = h->opt_diag, k->opt_update_waves = h->opt_update_waves, k->opt_lookahead = h->opt_lookahead, k->opt_gate = h->opt_gate, k->opt_fuse_chain = h->opt_fuse_chain, k->opt_early_diag = h->opt_early_diag, k->opt_pinv_fast = h->opt_pinv_fast, k->opt_rhs_overlap = h->opt_rhs_overlap, k->opt_verify = h->opt_verify, k->verify_tol_z = h->verify_tol_z, k->verify_tol_inv = h->verify_tol_inv;
+    k->opt_chunk = h->opt_chunk, k->opt_symsweep = h->opt_symsweep, k->opt_diag = h->opt_diag, k->opt_update_waves = h->opt_update_waves, k->opt_panel_rows = h->opt_panel_rows, k->opt_lookahead = h->opt_lookahead, k->opt_gate = h->opt_gate, k->opt_fuse_chain = h->opt_fuse_chain, k->opt_early_diag = h->opt_early_diag, k->opt_pinv_fast = h->opt_pinv_fast, k->opt_rhs_overlap = h->opt_rhs_overlap, k->opt_verify = h->opt_verify, k->verify_tol_z = h->verify_tol_z, k->verify_tol_inv = h->verify_tol_inv;
     k->opt_mw_class = h->opt_mw_class, k->opt_mw_knn_bound = h->opt_mw_knn_bound, k->opt_mw_pivot = h->opt_mw_pivot, k->opt_mw_lds_cap = h->opt_mw_lds_cap, k->opt_pairs = h->opt_pairs, k->opt_mw_solver = h->opt_mw_solver;
     k->custom_fn = h->custom_fn, k->custom_user = h->custom_user;
     h->kids.push_back(k);
@@ -898,6 +901,9 @@ int mik_set_option(mik_handle* h, const char* key, double value) {
   } else if (!strcmp(key, "update_waves")) {
     if (value != 4.0 && value != 8.0) return fail(MIK_EINVAL, "update_waves must be 4 or 8");
     h->opt_update_waves = (int)value;
+  } else if (!strcmp(key, "panel_rows")) {
+    if (value != 32.0 && value != 64.0 && value != 128.0) return fail(MIK_EINVAL, "panel_rows must be 32, 64 or 128");
+    h->opt_panel_rows = (int)value;
   } else if (!strcmp(key, "diag")) {
     h->opt_diag = (int)value;
   } else if (!strcmp(key, "lookahead")) {
@@ -1138,6 +1144,13 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
   const long ltiles = symsweep ? (long)nblk * (nblk + 1) / 2 : tiles;
   const unsigned ug = (unsigned)(8 * ((ltiles + 7) / 8));
   const bool upd8 = h->opt_update_waves == 8;
+  // the panel kernel over all Mp rows: 32 * NAI rows per block (k_panel)
+#define PANEL(STREAM, ...)                                                                                                   \
+  do {                                                                                                                       \
+    if (h->opt_panel_rows == 32) hipLaunchKernelGGL((k_panel<1>), dim3(4 * nblk), dim3(256), 0, STREAM, __VA_ARGS__);        \
+    else if (h->opt_panel_rows == 64) hipLaunchKernelGGL((k_panel<2>), dim3(2 * nblk), dim3(256), 0, STREAM, __VA_ARGS__);   \
+    else hipLaunchKernelGGL((k_panel<4>), dim3(nblk), dim3(256), 0, STREAM, __VA_ARGS__);                                    \
+  } while (0)
 #define UPDK(SYMV, GRID, STREAM, ...)                                                                                       \
   do {                                                                                                                      \
     if (upd8) hipLaunchKernelGGL((k_update<SYMV, 2>), GRID, dim3(512), 0, STREAM, __VA_ARGS__);                             \
@@ -1187,8 +1200,7 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
         if (symsweep) hipLaunchKernelGGL(k_copy_panel_sym, dim3(Mp / 64), dim3(256), 0, st, (const double*)T, ld, k0, Mp, cold[set]);
         else hipLaunchKernelGGL(k_copy_panel, dim3(pgrid), dim3(256), 0, st, (const double*)T, ld, k0, Mp, cold[set]);
       }
-      hipLaunchKernelGGL(k_panel, dim3(nblk), dim3(256), 0, st, (const double*)cold[set], 128L, (const double*)dinvT[set], -1.0,
-                         cnew[set], rt[set], k0);
+      PANEL(st, (const double*)cold[set], 128L, (const double*)dinvT[set], -1.0, cnew[set], rt[set], k0, 0, 0, (int*)nullptr, -1, -1);
     };
     const bool early = h->opt_early_diag < 0 ? true : h->opt_early_diag != 0;
     panel_chain(h->stream, 0, 0, false);
@@ -1237,8 +1249,8 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
             else HIPC(hipStreamWaitEvent(s2, h->la_events[2 * kb], 0));
           }
           if (h->opt_early_diag == 2) {  // the library's one-block tile kernels (22 us each: a CU's MFMA rate), kept for comparison
-            hipLaunchKernelGGL(k_panel, dim3(1), dim3(256), 0, s2, (const double*)cold[set], 128L, (const double*)dinvT[set], -1.0, cb, rb,
-                               k0, kb + 1, k1);
+            hipLaunchKernelGGL((k_panel<4>), dim3(1), dim3(256), 0, s2, (const double*)cold[set], 128L, (const double*)dinvT[set], -1.0, cb, rb,
+                               k0, kb + 1, k1, (int*)nullptr, -1, -1);
             hipLaunchKernelGGL(k_next_diag, dim3(1), dim3(256), 0, s2, (const double*)dcopy[set], 128L,
                                (const double*)(cold[set] + (long)k1 * 128), (const double*)rb, dnext);
           } else {  // the same accumulation streams, one per wavefront, over 64 blocks
@@ -1259,8 +1271,8 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
           // loads do not coalesce -- and its 640 blocks delay the chain's 64)
           // k_panel, leaving, polls for diagonal inverse kb+1 to have started (the gate); with flags_s1 it first waits for
           // diagonal inverse kb itself
-          hipLaunchKernelGGL(k_panel, dim3(nblk), dim3(256), 0, h->stream, (const double*)cold[set], 128L, (const double*)dinvT[set], -1.0,
-                             cnew[set], rt[set], k0, 0, 0, fl, flags_s1 ? kb : -1, gate_here ? kb + 1 : -1);
+          PANEL(h->stream, (const double*)cold[set], 128L, (const double*)dinvT[set], -1.0, cnew[set], rt[set], k0, 0, 0, fl, flags_s1 ? kb : -1,
+                gate_here ? kb + 1 : -1);
         }
         if (kb + 1 < nblk) {
           if (gate_here && kb == 0) hipLaunchKernelGGL(k_gate, dim3(1), dim3(1), 0, h->stream, (const int*)fl, kb + 1, 20000);
@@ -1322,16 +1334,17 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
     else hipLaunchKernelGGL(k_copy_panel, dim3(pgrid), dim3(256), 0, h->stream, (const double*)T, ld, k0, Mp,
                             h->Cold.as<double>());
     // unpivoted sweep: the panel kernel writes R^T = -sigma C_new as well (one launch less per step)
-    hipLaunchKernelGGL(k_panel, dim3(nblk), dim3(256), 0, h->stream, (const double*)h->Cold.as<double>(), 128L,
-                       (const double*)h->DinvT.as<double>(), -1.0, h->Cnew.as<double>(), pivoted ? (double*)nullptr : h->Rt.as<double>(), k0);
+    PANEL(h->stream, (const double*)h->Cold.as<double>(), 128L, (const double*)h->DinvT.as<double>(), -1.0, h->Cnew.as<double>(),
+          pivoted ? (double*)nullptr : h->Rt.as<double>(), k0, 0, 0, (int*)nullptr, -1, -1);
     if (pivoted) {
       hipLaunchKernelGGL(k_transpose_rows, dim3(Mp / 64, 2), dim3(256), 0, h->stream, (const double*)T, ld, k0, Mp,
                          h->TKt.as<double>());
-      hipLaunchKernelGGL(k_panel, dim3(nblk), dim3(256), 0, h->stream, (const double*)h->TKt.as<double>(), 128L,
-                         (const double*)h->Dinv.as<double>(), 1.0, h->Rt.as<double>());
+      PANEL(h->stream, (const double*)h->TKt.as<double>(), 128L, (const double*)h->Dinv.as<double>(), 1.0, h->Rt.as<double>(), (double*)nullptr, 0, 0, 0,
+            (int*)nullptr, -1, -1);
     }
     UPD(dim3(ug), h->stream, h->Cold.as<double>(), h->Cnew.as<double>(), h->Rt.as<double>(), h->Dinv.as<double>(), 0, 0, (double*)nullptr);
   }
+#undef PANEL
 #undef UPD
 #undef UPDX
 #undef UPDK

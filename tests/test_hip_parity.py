@@ -208,6 +208,13 @@ def test_block_sweep_variants_agree():
         else:
             assert np.array_equal(a, a.T)
             assert np.abs(a - ref).max() <= 1e-11 * np.abs(ref).max()
+    # rows per block of the panel kernel (32 by default, above): the same accumulation streams on more or fewer blocks
+    for la in (0, 1):
+        for rows in (128, 64, 32):
+            for key, val in (("early_diag", 1), ("lookahead", la), ("fuse_chain", 1), ("diag", 1), ("symsweep", 0), ("gate", 1), ("panel_rows", rows)):
+                h.set_option(key, val)
+            h.factor()
+            np.testing.assert_array_equal(h.get_matrix(1), ref)
 
 
 def test_rccl_single_rank_broadcast_path():
