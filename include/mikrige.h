@@ -174,7 +174,9 @@ int  mik_slab_of(int64_t n, int members, int i, int64_t *lo, int64_t *count); /*
  *   kernel dispatches such as rocprofv3 --pmc: there the wait runs out and mik_factor returns MIK_EHIP).  Environment:
  *   MIK_EARLY_DIAG.  Every setting returns the bit-identical inverse ;
  * "fuse_chain" 0/1 = the block-column update leaves the next panel copy in place and the
- *   panel kernel writes R^T itself: two kernels on the serial chain instead of four (default 1) ; "diag" 0..3 = diagonal-block inverse kernel variant (default 1) ;
+ *   panel kernel writes R^T itself: two kernels on the serial chain instead of four (default 1) ; "diag" 0..4 = diagonal-block inverse kernel variant: 0..3 = 128 barrier-separated
+ *   pivot steps on different thread grids (the same bits), 4 = blocked, 8 sub-steps of 16 pivots with the rank-16 updates on the matrix
+ *   cores (default; equal to rounding, 62 us against 86 us per 128 x 128 block) ;
  * "update_waves" 4 | 8 = wavefronts per 128 x 128 tile of the block sweep's trailing update (wave tile 64 x 64 / 32 x 64; same bits;
  *   default 8)
  *   [MIK_UPDATE_WAVES] ;

@@ -1461,6 +1461,233 @@ __global__ void __launch_bounds__(GY * GX) k_diag_inv_t(const double* __restrict
   diag_done(flag, k0);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Round 3: the diagonal-block inverse BLOCKED -- 8 sub-steps of 16 pivots instead of 128 barrier-separated rank-1 steps.
+// k_diag_inv_t spends half of every pivot step (~750 of 1430 cycles, profiles/r02_diag_probe.txt) in "publish the pivot row and
+// column -> barrier -> read them back", 128 times.  Here the 128 x 128 block lives in the MFMA accumulator layout of gemm_core
+// (4 waves as 2 x 2, wave tile 64 x 64: acc[ai][bi][r] <-> row 64 wm + 16 ai + 4 r + (lane >> 4), column 64 wn + 16 bi + (lane & 15))
+// and a sub-step s (pivots 16 s .. 16 s + 15) is
+//   1. the owners publish the raw column block (128 x 16) and the raw row block (16 x 128, transposed) as K tiles in LDS; barrier
+//   2. the 16 x 16 diagonal sub-block is inverted by Gauss-Jordan INSIDE ONE WAVEFRONT (lane = 4 i + jq holds D[i][4 jq .. 4 jq + 3];
+//      pivot row / column / pivot travel by cross-lane reads, no LDS round trip, no barrier), redundantly by all four waves (they
+//      sit on four SIMDs; nothing else could run meanwhile); wave 0 leaves Dinv (and -Dinv^T) as B tiles; barrier
+//   3. Cnew = -Craw . Dinv (128 x 16) and Rnew^T = Rraw^T . Dinv^T (128 x 16) on the matrix cores, 32 rows per wave; barrier
+//   4. the rank-16 update  M += Cnew . Rraw  of the whole block: ONE K tile of gemm_core's loop (256 MFMAs per wave), then the
+//      column block, row block and diagonal sub-block are overwritten with Cnew, Rnew, Dinv (Gauss-Jordan in place).
+// The same elimination order as k_diag_inv_t (no pivoting either way), sums grouped differently: equal to rounding, not bit
+// for bit.  ~86 KB of LDS (dynamic), which also keeps trailing-update blocks off this block's CU (see k_gate).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int tile_a_idx(int row, int k) { return row * 16 + ((((k >> 1) ^ (row & 2))) << 1) + (k & 1); }
+__device__ __forceinline__ int tile_b_idx(int row, int k) { return row * 16 + ((((k >> 1) ^ ((row >> 1) & 7))) << 1) + (k & 1); }
+#define MIK_DIAGB_LDS_DOUBLES (2048 + 2 * 2048 + 2048 + 2048 + 256 + 256)
+
+// ABL (tools/diag_probe only; 0 in the library): 1 = no pivot loop, 2 = no rank-16 update, 4 = no panel products, 8 = no publish /
+// overwrite, 16 = no barriers -- results are then wrong, only the clock is read.
+template <int ABL = 0>
+__global__ void __launch_bounds__(256) k_diag_inv_b(const double* __restrict__ T, long ld, int k0, int nspd,
+                                                     double* __restrict__ Dinv, double* __restrict__ DinvT,
+                                                     int* __restrict__ flag) {
+  extern __shared__ double diagb_lds[];
+  double* const Craw = diagb_lds;          // [128][16], A swizzle: the raw column block
+  double* const Rt0 = diagb_lds + 2048;    // 2 x [128][16], B swizzle: the raw row block, transposed (alternating)
+  double* const Cn = diagb_lds + 6144;     // [128][16], A swizzle: Cnew
+  double* const Rn = diagb_lds + 8192;     // [128][16], B swizzle: Rn[col][k] = Rnew[k][col]
+  double* const Bd1 = diagb_lds + 10240;   // [16][16], B swizzle: Bd1[c][q] = -Dinv[q][c]
+  double* const Bd2 = Bd1 + 256;           // [16][16], B swizzle: Bd2[k][q] =  Dinv[k][q]
+  diag_started(flag, k0);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1, lq = lane >> 4, lc = lane & 15;
+  const int kq = lane >> 4, ia = lane & 3, jb = lane & 15;  // operand-fragment coordinates (gemm_core)
+  d4 acc[4][4];
+#pragma unroll
+  for (int ai = 0; ai < 4; ++ai)
+#pragma unroll
+    for (int bi = 0; bi < 4; ++bi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        acc[ai][bi][r] = T[(long)(k0 + wm * 64 + 16 * ai + 4 * r + lq) * ld + k0 + wn * 64 + 16 * bi + lc];
+  int bad = 0;
+  // broadcast inside each quad of lanes (DPP quad_perm: no LDS crossbar), and a lane's double read into SGPRs
+  auto quad_bcast = [](double v, auto qc) {
+    constexpr int q = decltype(qc)::value, ctrl = q | (q << 2) | (q << 4) | (q << 6);
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+  };
+  auto lane_value = [](double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+  };
+#pragma unroll 1
+  for (int sb = 0; sb < 2; ++sb) {
+#pragma unroll
+    for (int sq = 0; sq < 4; ++sq) {  // unrolled: the accumulator registers of block column / row sq are named at compile time
+      const int s = 4 * sb + sq;
+      double* const Rt = Rt0 + (sq & 1) * 2048;
+      // 1. publish the raw column block and the raw row block
+      if (!(ABL & 8) && wn == sb) {
+#pragma unroll
+        for (int ai = 0; ai < 4; ++ai)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Craw[tile_a_idx(wm * 64 + 16 * ai + 4 * r + lq, lc)] = acc[ai][sq][r];
+      }
+      if (!(ABL & 8) && wm == sb) {
+#pragma unroll
+        for (int bi = 0; bi < 4; ++bi)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Rt[tile_b_idx(wn * 64 + 16 * bi + lc, 4 * r + lq)] = acc[sq][bi][r];
+      }
+      if (!(ABL & 16)) __syncthreads();
+      // 2. the 16 x 16 diagonal sub-block, inverted inside the wavefront.  The pivot of step p + 1 is known to every lane one
+      // step early (three more uniform values of the current state), so its reciprocal -- five dependent operations -- is formed
+      // while the cross-lane reads of step p + 1 are in flight instead of after them.
+      {
+        const int i = lane >> 2, jq = lane & 3;
+        double a[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) a[c] = Craw[tile_a_idx(16 * s + i, 4 * jq + c)];
+        auto check = [&](double piv, int p) {
+          if (!(fabs(piv) > 1e-300) || !isfinite(piv)) bad |= 1;
+          if ((k0 + 16 * s + p) < nspd && !(piv > 0.0)) bad |= 2;
+        };
+        double pinv = 0.0;
+        if (!(ABL & 1)) {
+          const double piv0 = lane_value(a[0], 0);
+          check(piv0, 0);
+          pinv = pivot_recip(piv0);
+        }
+#pragma unroll
+        for (int p = 0; p < ((ABL & 1) ? 0 : 16); ++p) {
+          const int pr = p & 3, pq = p >> 2;
+          double f;  // D[i][p]
+          switch (pq) {
+            case 0: f = quad_bcast(a[pr], std::integral_constant<int, 0>{}); break;
+            case 1: f = quad_bcast(a[pr], std::integral_constant<int, 1>{}); break;
+            case 2: f = quad_bcast(a[pr], std::integral_constant<int, 2>{}); break;
+            default: f = quad_bcast(a[pr], std::integral_constant<int, 3>{}); break;
+          }
+          double rk[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) rk[c] = __shfl(a[c], 4 * p + jq);  // D[p][4 jq + c]
+          double pinv_next = 0.0;
+          if (p < 15) {
+            const int p1 = p + 1, r1 = p1 & 3, q1 = p1 >> 2;
+            const double d11 = lane_value(a[r1], 4 * p1 + q1);  // D[p+1][p+1]
+            const double d10 = lane_value(a[pr], 4 * p1 + pq);  // D[p+1][p]
+            const double d01 = lane_value(a[r1], 4 * p + q1);   // D[p][p+1]
+            const double pivn = __builtin_fma(-d10, d01 * pinv, d11);  // what the update below leaves at (p+1, p+1), same operations
+            check(pivn, p1);
+            pinv_next = pivot_recip(pivn);
+          }
+#pragma unroll
+          for (int c = 0; c < 4; ++c) rk[c] *= pinv;
+          const bool prow = (i == p), pcol = (jq == pq);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            double v = __builtin_fma(-f, rk[c], a[c]);
+            if (c == pr) v = pcol ? -f * pinv : v;                // pivot column: -a_ip / a_pp
+            v = prow ? ((c == pr && pcol) ? pinv : rk[c]) : v;    // pivot row: a_pj / a_pp, corner 1 / a_pp
+            a[c] = v;
+          }
+          pinv = pinv_next;
+        }
+        if (wave == 0) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            Bd2[tile_b_idx(i, 4 * jq + c)] = a[c];
+            Bd1[tile_b_idx(4 * jq + c, i)] = -a[c];
+          }
+        }
+      }
+      if (!(ABL & 16)) __syncthreads();
+      // 3. Cnew (rows 32 wave ..) and Rnew^T (columns 32 wave ..): 8 groups of 4 rows each, K = 16
+      if (!(ABL & 4)) {
+        const int R0 = 32 * wave;
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+          const double* src = which ? Rt : Craw;
+          const double* bd = which ? Bd2 : Bd1;
+          double pc[8];
+#pragma unroll
+          for (int g = 0; g < 8; ++g) pc[g] = 0.0;
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            const double2 fbd = *reinterpret_cast<const double2*>(bd + tile_b_idx(jb, 8 * m + 2 * kq));
+            double2 fc[8];
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+              const int row = R0 + 4 * g + ia;
+              fc[g] = *reinterpret_cast<const double2*>(src + (which ? tile_b_idx(row, 8 * m + 2 * kq) : tile_a_idx(row, 8 * m + 2 * kq)));
+            }
+#pragma unroll
+            for (int g = 0; g < 8; ++g) pc[g] = __builtin_amdgcn_mfma_f64_4x4x4f64(fc[g].x, fbd.x, pc[g], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 8; ++g) pc[g] = __builtin_amdgcn_mfma_f64_4x4x4f64(fc[g].y, fbd.y, pc[g], 0, 0, 0);
+          }
+#pragma unroll
+          for (int g = 0; g < 8; ++g) {
+            const int row = R0 + 4 * g + lq;
+            if (which) Rn[tile_b_idx(row, lc)] = pc[g];
+            else Cn[tile_a_idx(row, lc)] = pc[g];
+          }
+        }
+      }
+      if (!(ABL & 16)) __syncthreads();
+      // 4. M += Cnew . Rraw: one K tile of gemm_core's loop
+#pragma unroll
+      for (int m = 0; m < ((ABL & 2) ? 0 : 2); ++m) {
+        double2 fa[16], fb[4];
+#pragma unroll
+        for (int x = 0; x < 16; ++x) fa[x] = *reinterpret_cast<const double2*>(Cn + tile_a_idx(wm * 64 + 4 * x + ia, 8 * m + 2 * kq));
+#pragma unroll
+        for (int x = 0; x < 4; ++x) fb[x] = *reinterpret_cast<const double2*>(Rt + tile_b_idx(wn * 64 + 16 * x + jb, 8 * m + 2 * kq));
+#pragma unroll
+        for (int ai = 0; ai < 4; ++ai)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int bi = 0; bi < 4; ++bi)
+              acc[ai][bi][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa[4 * ai + r].x, fb[bi].x, acc[ai][bi][r], 0, 0, 0);
+#pragma unroll
+        for (int ai = 0; ai < 4; ++ai)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int bi = 0; bi < 4; ++bi)
+              acc[ai][bi][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa[4 * ai + r].y, fb[bi].y, acc[ai][bi][r], 0, 0, 0);
+      }
+      // Gauss-Jordan in place: column block <- Cnew, row block <- Rnew, diagonal sub-block <- Dinv
+      if (!(ABL & 8) && wn == sb) {
+#pragma unroll
+        for (int ai = 0; ai < 4; ++ai)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[ai][sq][r] = Cn[tile_a_idx(wm * 64 + 16 * ai + 4 * r + lq, lc)];
+      }
+      if (!(ABL & 8) && wm == sb) {
+#pragma unroll
+        for (int bi = 0; bi < 4; ++bi)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[sq][bi][r] = Rn[tile_b_idx(wn * 64 + 16 * bi + lc, 4 * r + lq)];
+        if (wn == sb) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[sq][sq][r] = Bd2[tile_b_idx(4 * r + lq, lc)];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int ai = 0; ai < 4; ++ai)
+#pragma unroll
+    for (int bi = 0; bi < 4; ++bi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = wm * 64 + 16 * ai + 4 * r + lq, col = wn * 64 + 16 * bi + lc;
+        Dinv[row * 128 + col] = acc[ai][bi][r];
+        DinvT[col * 128 + row] = acc[ai][bi][r];
+      }
+  if (bad && lane == 0) atomicOr(flag, bad);
+  diag_done(flag, k0);
+}
+
 // Out[j][m] = T[k0+m][j]   (transpose of a 128-row panel; general path)
 __global__ void __launch_bounds__(256) k_transpose_rows(const double* __restrict__ T, long ld, int k0, int Mp,
                                                         double* __restrict__ Out) {

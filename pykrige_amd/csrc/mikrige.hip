@@ -289,7 +289,8 @@ struct mik_handle {
   int opt_panel_rows = 32;  // rows of the column panel one block of k_panel forms: 32 (round 3), 64 or 128 (one tile, the round-1 form)
   int opt_update_waves = 8; // trailing-update kernel of the block sweep: 4 waves (wave tile 64 x 64) or 8 (32 x 64, default since round 3:
                             // -5 % at N=5000 / 8000, same bits: profiles/r03_update_waves_ab.txt) per 128 x 128 tile
-  int opt_diag = 1;        // diagonal-block inverse variant: 0 = 1024 threads (16 waves x 8 rows), 1 = 16x16 grid, 2 = 16x32, 3 = 32x32
+  int opt_diag = 4;        // diagonal-block inverse variant: 0 = 1024 threads (16 waves x 8 rows), 1 = 16x16 grid, 2 = 16x32, 3 = 32x32 (all four:
+                           // 128 barrier-separated pivots, the same bits), 4 = blocked, 8 x 16 pivots (round 3; equal to rounding)
   // points
   long npt_total = 0, npt = 0;
   bool masked = false;  // the caller's mask skipped at least one point: outputs are zero-filled before the scatter
@@ -1094,6 +1095,12 @@ static int ensure_factor_buffers(mik_handle* h) {
 static void launch_diag_inv(mik_handle* h, hipStream_t st, const double* T, long ld, int k0, int nspd, double* dinv, double* dinvT,
                             bool own_cu = false) {
   int* flag = h->flag.as<int>();
+  if (h->opt_diag == 4) {  // blocked (round 3): 86 KB of LDS of its own, padded like the others' when it wants the CU to itself
+    const int lds = own_cu ? 100 * 1024 : (int)(sizeof(double) * MIK_DIAGB_LDS_DOUBLES);
+    (void)hipFuncSetAttribute((const void*)k_diag_inv_b<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    hipLaunchKernelGGL(k_diag_inv_b<0>, dim3(1), dim3(256), lds, st, T, ld, k0, nspd, dinv, dinvT, flag);
+    return;
+  }
   if (own_cu && h->opt_diag == 1) {  // keep trailing-update blocks (64 KB of LDS each) off this block's CU: see k_gate
     constexpr int pad = 100 * 1024;
     // per launch: the attribute belongs to the function object of the CURRENT device (device groups factor on several)

@@ -215,6 +215,22 @@ def test_block_sweep_variants_agree():
                 h.set_option(key, val)
             h.factor()
             np.testing.assert_array_equal(h.get_matrix(1), ref)
+    # the blocked diagonal inverse (diag = 4, the default): the same elimination with the sums grouped by 16 pivots -- equal to
+    # rounding to the others, and bit-identical to itself under every schedule
+    ref4 = None
+    for la, sym, gate, fuse, early in ((0, 0, 1, 1, 1), (1, 0, 1, 1, 1), (1, 0, 0, 1, 0), (1, 0, 1, 0, 0), (1, 0, 1, 1, 2), (1, 0, 1, 1, 5), (1, 0, 1, 1, 4), (1, 1, 1, 1, 1), (1, 1, 0, 1, 0)):
+        for key, val in (("early_diag", early), ("lookahead", la), ("fuse_chain", fuse), ("diag", 4), ("symsweep", sym), ("gate", gate), ("panel_rows", 32)):
+            h.set_option(key, val)
+        h.factor()
+        a = h.get_matrix(1)
+        if ref4 is None:
+            ref4 = a
+            assert np.abs(a - ref).max() <= 1e-11 * np.abs(ref).max()
+        elif not sym:
+            np.testing.assert_array_equal(a, ref4)
+        else:
+            assert np.array_equal(a, a.T)
+            assert np.abs(a - ref4).max() <= 1e-11 * np.abs(ref4).max()
 
 
 def test_rccl_single_rank_broadcast_path():

@@ -210,5 +210,24 @@ int main() {
     printf("%-58s %7.1f us  %6.0f cycles/round\n", "128 x 64 independent v_fma_f64, 1 wave per SIMD", ms * 1e3, ms * 1e-3 * 2.4e9 / 128); }
   { float ms = timeit([&]{ hipLaunchKernelGGL((k_fma<64>), dim3(1), dim3(256), 0, 0, D, 1280); }, 20);
     printf("%-58s %7.1f us  %6.0f cycles/round\n", "1280 x 64 independent v_fma_f64, 1 wave per SIMD", ms * 1e3, ms * 1e-3 * 2.4e9 / 1280); }
+  // round 3: the blocked diagonal inverse (k_diag_inv_b), complete and with pieces switched off
+  {
+    double *Dv, *DvT; int* flag;
+    hipMalloc(&Dv, 128 * 128 * 8); hipMalloc(&DvT, 128 * 128 * 8); hipMalloc(&flag, MIK_F_INTS * sizeof(int)); hipMemset(flag, 0, MIK_F_INTS * sizeof(int));
+    const int lds = (int)(sizeof(double) * MIK_DIAGB_LDS_DOUBLES);
+#define PROBEB(ABL, NAME) { (void)hipFuncSetAttribute((const void*)k_diag_inv_b<ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+    float ms = timeit([&]{ hipLaunchKernelGGL((k_diag_inv_b<ABL>), dim3(1), dim3(256), lds, 0, (const double*)T, 128L, 0, 128, Dv, DvT, flag); }, 20); \
+    printf("%-58s %7.1f us  %6.0f cycles/sub-step\n", NAME, ms * 1e3, ms * 1e-3 * 2.4e9 / 8); }
+    PROBEB(0, "blocked inverse (8 x 16 pivots), complete");
+    PROBEB(1, "  without the 16 wave-level pivot steps");
+    PROBEB(2, "  without the rank-16 update (256 MFMAs per wave)");
+    PROBEB(4, "  without the panel products");
+    PROBEB(8, "  without publish / overwrite");
+    PROBEB(16, "  without the barriers");
+    PROBEB(1 | 2, "  without pivots and update");
+    PROBEB(1 | 2 | 4 | 8, "  barriers only");
+    { float ms = timeit([&]{ hipLaunchKernelGGL((k_diag_inv_t<16, 16>), dim3(1), dim3(256), 0, 0, (const double*)T, 128L, 0, 128, Dv, DvT, flag); }, 20);
+      printf("%-58s %7.1f us\n", "k_diag_inv_t<16,16> (128 barrier-separated pivots)", ms * 1e3); }
+  }
   return 0;
 }

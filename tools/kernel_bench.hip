@@ -132,7 +132,7 @@ int main(int argc,char**argv){
   ms=timeit([&]{hipLaunchKernelGGL(k_diag_inv,dim3(1),dim3(1024),0,0,(const double*)T,(long)Mp,0,0,Dinv,DinvT,flag);
                hipLaunchKernelGGL(k_update<false>,dim3(ug),dim3(256),0,0,T,(long)Mp,nblk,1,(const double*)Cold,(const double*)Cnew,(const double*)Rt,(const double*)Dinv,0,0,(double*)nullptr);},5);
   printf("k_diag_inv + k_update interleaved: %.1f us per pair\n",ms*1e3);
-  ms=timeit([&]{hipLaunchKernelGGL(k_panel,dim3(nblk),dim3(256),0,0,(const double*)Cold,128L,(const double*)DinvT,-1.0,Cnew);},5);
+  ms=timeit([&]{hipLaunchKernelGGL(k_panel<4>,dim3(nblk),dim3(256),0,0,(const double*)Cold,128L,(const double*)DinvT,-1.0,Cnew);},5);
   printf("k_panel: %.1f us\n",ms*1e3);
   return 0;
 }
