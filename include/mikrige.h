@@ -162,6 +162,12 @@ int  mik_slab_of(int64_t n, int members, int i, int64_t *lo, int64_t *count); /*
  * "engine" 0 = MFMA f64 contraction, 1 = VALU (v_fma_f64) contraction ; "waves" 4 | 8 = wavefronts per contraction block ;
  * "pairs" 0/1 = symmetric contraction: work is handed out as single tiles (default 0) or as equal-length PAIRS of row
  *   blocks (higher L2 hit rate, measured 2.7 % slower: the kernel is not traffic-bound) ;
+ * "tri" 0/1 = symmetric contraction (8-wave form): the diagonal block of a tile is contracted as a triangle of 16-row groups,
+ *   36 of its 64 (row group, K tile) products (default 1: -1.5 % contraction time, partials equal to 1e-14) [MIK_TRI] ;
+ * "symmetrize" 0/1 = after a full sweep, the pivoted elimination or a pseudo-inverse: A_inv <- (A_inv + A_inv^T) / 2 (default 1).
+ *   The symmetric contraction reads one triangle of A_inv; a quadratic form sees only the symmetric part, so with the average
+ *   in both triangles the half product equals b^T A_inv b of the matrix as eliminated (the half sweep mirrors its triangle
+ *   anyway; an inverse the caller supplies, mik_problem.a_inv, is never touched) ;
  * "chunk" = largest number of points per contraction launch (multiple of 128; the points are cut into equal launches) ;
  * "rhs_overlap" 0/1 = two right-hand-side panels: K3a of the next chunk runs on a second stream while the current chunk is
  *   contracted (default 0: measured a tie -- the contraction slows down by what K3a takes) [MIK_RHS_OVERLAP] ;
@@ -180,6 +186,12 @@ int  mik_slab_of(int64_t n, int members, int i, int64_t *lo, int64_t *count); /*
  * "update_waves" 4 | 8 = wavefronts per 128 x 128 tile of the block sweep's trailing update (wave tile 64 x 64 / 32 x 64; same bits;
  *   default 8)
  *   [MIK_UPDATE_WAVES] ;
+ * "update_map" 0/n = tile order of the sweep's trailing update: 0 = block column by block column (default), n > 1 = n x n
+ *   super-blocks (the ~64 tiles an XCD has in flight share n + n operand panels in its L2 instead of one panel per tile) --
+ *   measured a tie at N = 2000 .. 8000: the update is not bound by its panel reads; same bits [MIK_UPDATE_MAP] ;
+ * "panel_stream" 0/1/-1 = early-diagonal sweep: the panel kernel and the update of the next block column (+ the diagonal tile
+ *   after next) run on a third stream beside the rest of the previous step's trailing update, ordered by events only (default
+ *   -1 = from 24 block columns on; same bits) [MIK_PANEL_STREAM] ;
  * "panel_rows" 32 | 64 | 128 = rows of the column panel one block of the sweep's panel kernel forms (same bits; default 32:
  *   four times the blocks of the one-tile form, the kernel sits on the update stream's critical path) [MIK_PANEL_ROWS] ;
  * "pinv_fast" 0/1 = pseudo_inv: try the deflated regular inverse before the Jacobi pseudo-inverse (default 1) ;

@@ -513,6 +513,14 @@ __global__ void __launch_bounds__(256) k_rhs(RhsArgs a) {
 // no staging VGPRs, no ds_write).  Bank conflicts of the fragment reads are removed by an XOR swizzle
 // applied to the per-lane SOURCE address and to the reads: element (row r, k) lives in 16-byte slot
 // ((k>>1) ^ swz(r)) of row r, swz = r & 2 for the A tile and (r>>1) & 7 for the B tile.
+// row group of a wave inside the block tile.  TRI with 8 waves of 32 x 64: the waves that share a SIMD (w and w + 4) get the
+// row groups {0, 3} and {1, 2}, whose triangular diagonal-block work is equal (15 + 3 and 11 + 7 of 64 products).
+template <int NAI, int BM, bool TRI>
+__device__ __forceinline__ int gemm_wm(int wave) {
+  const int x = wave >> 1;
+  return (TRI && NAI == 2 && BM == 128) ? (x ^ (x >> 1)) : x;
+}
+
 template <int BM>
 struct GemmSmemT {
   double As[2][BM][MIK_BK];
@@ -533,10 +541,16 @@ typedef __attribute__((address_space(3))) void* mik_lptr_t;
 // form: everything above the diagonal block counts twice); pass a value that is never a tile start to disable.
 // BM (round 3, tools/kernel_bench only): rows of the block tile, 128 (library) or 256 -- 16 waves of 32 x 64, one block per CU, the
 // A operand staged in two passes and the B operand in one (the tile-shape experiment of profiles/r03_kernel_bench.txt).
-template <int NAI, int ABL = 0, int BM = MIK_BM>
+// TRI (round 3, symmetric contraction): the K range ends with the tile's DIAGONAL block [ktri, ktri + 128) and only its upper
+// triangle is contracted, at the granularity of the 16-row accumulator groups: group g of the block (rows ktri + 16 g ..) takes
+// the K tiles above its own 16 x 16 diagonal square with weight 2, the square itself with weight 1 and skips the tiles below
+// it (their mirror images have been counted twice).  "Weight 2" = the group's accumulators are doubled when the loop reaches
+// its square, as kscale does for the whole tile.  36 of the 64 (group, K tile) products of a diagonal block remain; the
+// branches are wave-uniform.  Groups are dealt to the waves so that the two waves sharing a SIMD (w, w + 4) keep 18 each.
+template <int NAI, int ABL = 0, int BM = MIK_BM, bool TRI = false>
 __device__ __forceinline__ void gemm_core(const double* __restrict__ Ag, long lda, const double* __restrict__ Bg,
                                           long ldb, int kbeg, int kend, d4 (&acc)[NAI][4], GemmSmemT<BM>& sm,
-                                          int kscale = -1) {
+                                          int kscale = -1, int ktri = 0) {
   if (kbeg >= kend) return;  // block-uniform
   constexpr int WROWS = 16 * NAI;            // rows of the wave tile
   constexpr int NTHR = 64 * 2 * (BM / WROWS);
@@ -545,7 +559,7 @@ __device__ __forceinline__ void gemm_core(const double* __restrict__ Ag, long ld
   constexpr int NPASS_B = MIK_BN / PROWS;    // passes over the B tile (fewer when BM > MIK_BN, more when BM < MIK_BN)
   constexpr int NPASS = NPASS_A > NPASS_B ? NPASS_A : NPASS_B;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = gemm_wm<NAI, BM, TRI>(wave), wn = wave & 1;
   // staging: thread -> (row lrow + PROWS*p, 16-byte slot tid&7); the SOURCE k-pair is the slot XOR the row's swizzle
   // (A tile: r & 2; B tile: (r>>1) & 7 -- see the fragment reads below).  Both are pass-independent.
   // Addresses are split into a wave-uniform 64-bit base (Ag + k, advanced with scalar adds) and per-lane 32-bit
@@ -620,7 +634,8 @@ __device__ __forceinline__ void gemm_core(const double* __restrict__ Ag, long ld
   drain();
   __syncthreads();
   int buf = 0;
-  for (int k = kend - MIK_BK; k >= kbeg; k -= MIK_BK) {
+  const int kmain = TRI ? (ktri + 128 > kbeg ? ktri + 128 : kbeg) : kbeg;  // TRI: the diagonal block has a loop of its own
+  for (int k = kend - MIK_BK; k >= kmain; k -= MIK_BK) {
     if (k > kbeg && !(ABL & 1)) stage((ABL & 8) ? 0 : k - MIK_BK, buf ^ 1);
     const double* as = &sm.As[buf][0][0];
     const double* bs = &sm.Bs[buf][0][0];
@@ -666,6 +681,53 @@ __device__ __forceinline__ void gemm_core(const double* __restrict__ Ag, long ld
     drain();  // the tile staged at the top of this iteration has had the whole compute phase to land
     if (!(ABL & 4)) __syncthreads();
     buf ^= 1;
+  }
+  if (TRI) {
+    // The diagonal block.  This wave's rows are wm*WROWS + 16 ai: accumulator group ai has its 16 x 16 diagonal square in K tile
+    // gd0 + ai of the block; in K tile kt the groups ai <= kt - gd0 take part (wave-uniform branches), a group is doubled when
+    // the loop reaches its square.  One group at a time: fragments of 16 rows, 16 + 16 MFMAs (dependent ones 16 issues apart).
+    const int gd0 = __builtin_amdgcn_readfirstlane(wm * NAI);
+    const int ktop = (ktri + 128 < kend ? ktri + 128 : kend) - MIK_BK;
+    for (int k = ktop; k >= kbeg; k -= MIK_BK) {
+      if (k > kbeg) stage(k - MIK_BK, buf ^ 1);
+      const double* as = &sm.As[buf][0][0];
+      const double* bs = &sm.Bs[buf][0][0];
+      const int alive = ((k - ktri) >> 4) - gd0 + 1;  // groups ai < alive take part in this K tile
+#pragma unroll
+      for (int ai = 0; ai < NAI; ++ai)
+        if (alive == ai + 1) {
+#pragma unroll
+          for (int y = 0; y < 4; ++y) acc[ai][y] *= 2.0;
+        }
+      if (alive > 0) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          double2 fb[4];
+#pragma unroll
+          for (int x = 0; x < 4; ++x) fb[x] = *reinterpret_cast<const double2*>(bs + boff[m] + 16 * x * MIK_BK);
+#pragma unroll
+          for (int ai = 0; ai < NAI; ++ai)
+            if (ai < alive) {
+              double2 fa[4];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) fa[r] = *reinterpret_cast<const double2*>(as + aoff[m] + 4 * (4 * ai + r) * MIK_BK);
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int bi = 0; bi < 4; ++bi)
+                  acc[ai][bi][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa[r].x, fb[bi].x, acc[ai][bi][r], 0, 0, 0);
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int bi = 0; bi < 4; ++bi)
+                  acc[ai][bi][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa[r].y, fb[bi].y, acc[ai][bi][r], 0, 0, 0);
+            }
+        }
+      }
+      drain();
+      __syncthreads();
+      buf ^= 1;
+    }
   }
 }
 
@@ -754,7 +816,9 @@ __device__ __forceinline__ bool super_tile(int nIblk, int nTblk, int& iblk, int&
 // busy once tile lengths differ (symmetric form: 1..nIblk K blocks): measured 8 % of the MFMA rate.
 // PERSIST = false is the one-block-per-tile form (grid = super_grid(), queue unused), kept for A/B measurements.
 // PAIR (symmetric + persistent only): the queue hands out pairs of row blocks of equal total length (pair_unit_at).
-template <bool SYM, int NAI, bool PERSIST = true, bool PAIR = false>
+// TRI (symmetric form only): the diagonal block is contracted as a triangle of 16-row groups (gemm_core), 36 instead of 64
+// group products per diagonal block.
+template <bool SYM, int NAI, bool PERSIST = true, bool PAIR = false, bool TRI = false>
 __global__ void __launch_bounds__(64 * 2 * (8 / NAI), 2 * (4 / NAI))
 k_contract(const double* __restrict__ Ainv, long lda, const double* __restrict__ Bt, long ldb,
            double* __restrict__ part, int palloc, int nIblk, int kend, unsigned long long* __restrict__ queue) {
@@ -764,9 +828,10 @@ k_contract(const double* __restrict__ Ainv, long lda, const double* __restrict__
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
   const int xcd = (int)(xcc & 7);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = wave >> 1, wn = wave & 1, lq = lane >> 4, lc = lane & 15;
+  const int wm = gemm_wm<NAI, MIK_BM, TRI>(wave), wn = wave & 1, lq = lane >> 4, lc = lane & 15;
   int steal = 0;  // 0 = own XCD's sequence; then the other seven in turn: every tile is done whatever the placement
   static_assert(!PAIR || (SYM && PERSIST), "pair units exist for the symmetric persistent form");
+  static_assert(!TRI || SYM, "the triangular diagonal block belongs to the symmetric form");
   for (;;) {
   int iblk, tblk, pair_p = 0;
   if (PERSIST) {
@@ -805,7 +870,9 @@ k_contract(const double* __restrict__ Ainv, long lda, const double* __restrict__
   if (SYM) {  // result = diag + 2 * offdiag: one K loop downwards from kend; the off-diagonal part is doubled
               // when the loop enters the diagonal block (k < i0 + 128), which is contracted last
     const int kd = (i0 + MIK_BM) < kend ? (i0 + MIK_BM) : kend;
-    gemm_core<NAI>(Ag, lda, Bg, ldb, i0, kend, acc, sm, kd - MIK_BK);
+    if (TRI) gemm_core<NAI, 0, MIK_BM, true>(Ag, lda, Bg, ldb, i0, kend, acc, sm, -1, i0);  // (a short last block: groups
+                                                                                             // beyond kend hold padding rows, b = 0)
+    else gemm_core<NAI>(Ag, lda, Bg, ldb, i0, kend, acc, sm, kd - MIK_BK);
   } else {
     gemm_core<NAI>(Ag, lda, Bg, ldb, 0, kend, acc, sm);
   }
@@ -1138,7 +1205,11 @@ template <bool SYM, int NAI = 4>
 __global__ void __launch_bounds__(64 * 2 * (8 / NAI), 2)
 k_update(double* __restrict__ T, long ld, int nblk, int kb, const double* __restrict__ Cold,
          const double* __restrict__ Cnew, const double* __restrict__ Rt, const double* __restrict__ Dinv, int part, int col,
-         double* __restrict__ Pout, double* __restrict__ Dcopy = nullptr, int* __restrict__ done_cnt = nullptr) {
+         double* __restrict__ Pout, double* __restrict__ Dcopy = nullptr, int* __restrict__ done_cnt = nullptr,
+         const int2* __restrict__ tilemap = nullptr) {
+  // tilemap (nullable; round 3): position -> (iblk, jblk) of parts 0 / 2 / 4, written by the host (update_tile_map): the tiles in
+  // the order of 8 x 8 super-blocks, so that the ~64 tiles an XCD works on at a time share 8 + 8 operand panels (2 MB of its 4 MB
+  // L2) instead of a whole block column's worth (one C panel per tile: 8 MB at N = 8000, re-fetched over the fabric every column)
   // Pout (nullable): the updated block column `col` is ALSO written as the next step's column panel
   // P[row][0..127] (what k_copy_panel / k_copy_panel_sym would read back out of T: tiles of the block row `col` go in transposed),
   // so that the next panel chain starts with the diagonal inverse instead of a copy kernel.
@@ -1153,8 +1224,14 @@ k_update(double* __restrict__ T, long ld, int nblk, int kb, const double* __rest
       if (threadIdx.x == 0) __hip_atomic_fetch_add(done_cnt, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
   };
+  // part = 3 / 4 (round 3, the panel stream of the sweep): part 1 plus the diagonal tile (col + 1, col + 1) as block `nblk` of
+  // the launch -- everything the next panel kernel AND the chain of the diagonal inverse after next read (Pout, Dcopy) -- /
+  // part 2 without that tile.
   int iblk, jblk;
-  if (part == 1) {
+  if (part == 3 && (int)blockIdx.x == nblk) {
+    if (col + 1 >= nblk) return finish();
+    iblk = jblk = col + 1;
+  } else if (part == 1 || part == 3) {
     if ((int)blockIdx.x >= nblk) return finish();
     if (SYM && (int)blockIdx.x > col) {
       iblk = col;
@@ -1163,6 +1240,14 @@ k_update(double* __restrict__ T, long ld, int nblk, int kb, const double* __rest
       iblk = blockIdx.x;
       jblk = col;
     }
+  } else if (tilemap) {
+    const long L = xcd_tile(SYM ? (long)nblk * (nblk + 1) / 2 : (long)nblk * nblk);
+    if (L < 0) return finish();
+    const int2 ij = tilemap[L];
+    iblk = ij.x;
+    jblk = ij.y;
+    if ((part == 2 || part == 4) && (jblk == col || (SYM && iblk == col))) return finish();
+    if (part == 4 && iblk == col + 1 && jblk == col + 1) return finish();
   } else if (SYM) {
     const long L = xcd_tile((long)nblk * (nblk + 1) / 2);
     if (L < 0) return finish();
@@ -1170,13 +1255,15 @@ k_update(double* __restrict__ T, long ld, int nblk, int kb, const double* __rest
     while ((long)jblk * (jblk + 1) / 2 > L) --jblk;            // guard the float estimate
     while ((long)(jblk + 1) * (jblk + 2) / 2 <= L) ++jblk;
     iblk = (int)(L - (long)jblk * (jblk + 1) / 2);             // i <= j: the upper block triangle
-    if (part == 2 && (iblk == col || jblk == col)) return finish();
+    if ((part == 2 || part == 4) && (iblk == col || jblk == col)) return finish();
+    if (part == 4 && iblk == col + 1 && jblk == col + 1) return finish();
   } else {
     const long L = xcd_tile((long)nblk * nblk);
     if (L < 0) return finish();
     iblk = (int)(L / nblk);
     jblk = (int)(L % nblk);
-    if (part == 2 && jblk == col) return finish();
+    if ((part == 2 || part == 4) && jblk == col) return finish();
+    if (part == 4 && iblk == col + 1 && jblk == col + 1) return finish();
   }
   const int i0 = iblk * MIK_BM, j0 = jblk * MIK_BN, k0 = kb * 128;
   const bool ptrans = SYM && iblk == col && jblk != col;  // a tile of the block ROW col: panel rows = its columns
@@ -1896,6 +1983,28 @@ __global__ void __launch_bounds__(256) k_mirror_upper(double* __restrict__ T, lo
   for (int e = threadIdx.x; e < 64 * 64; e += 256) {
     const int r = e >> 6, c = e & 63;
     if (bi < bj || c < r) T[(long)(bj * 64 + r) * ld + bi * 64 + c] = tile[c][r];
+  }
+}
+
+// after a FULL sweep (or the pivoted elimination): T <- (T + T^T) / 2.  The inverse of the symmetric kriging matrix is symmetric;
+// the computed one is so only up to rounding (cond . eps), and the symmetric contraction reads one triangle: on an ill-conditioned
+// system (power variogram + drift terms) the two triangles differ by more than the sigma^2 bar at exact-hit points, where
+// b^T X b is a difference of large terms.  A quadratic form sees only the symmetric part of X, so with the average in both
+// triangles the half product equals the full one to rounding (round 3).  64 x 64 tile pairs, like k_mirror_upper.
+__global__ void __launch_bounds__(256) k_symmetrize(double* __restrict__ T, long ld, int nblk64) {
+  __shared__ double up[64][65], lo[64][65];
+  const int bi = blockIdx.y, bj = blockIdx.x;
+  if (bi > bj) return;
+  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    up[r][c] = T[(long)(bi * 64 + r) * ld + bj * 64 + c];
+    lo[r][c] = T[(long)(bj * 64 + r) * ld + bi * 64 + c];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    T[(long)(bi * 64 + r) * ld + bj * 64 + c] = 0.5 * (up[r][c] + lo[c][r]);
+    if (bi < bj) T[(long)(bj * 64 + r) * ld + bi * 64 + c] = 0.5 * (up[c][r] + lo[r][c]);
   }
 }
 

@@ -261,6 +261,11 @@ struct mik_handle {
   // factor
   DevBuf T, cvec, Cold, Cnew, Rt, TKt, Dinv, DinvT, P0, P1, cand0, cand1, pivall, flag;
   DevBuf Cold2, Cnew2, Rt2, Dinv2, DinvT2;  // second panel set of the look-ahead sweep
+  DevBuf Dinv3, DinvT3;                     // third diagonal-inverse set (panel-stream schedule)
+  DevBuf tilemap;                           // k_update's tile order (update_tile_map)
+  int tilemap_key[3] = {0, 0, 0};
+  hipStream_t stream3 = nullptr;            // panel stream of the sweep (panel kernel + block-column update), high priority
+  std::vector<hipEvent_t> ps_events;
   DevBuf Dnext, Dcopy, Cb, Rb;              // early-diagonal chain: 128 x 128 scratch (next diagonal block, its source tile, one block of panel rows)
   hipStream_t stream2 = nullptr;            // the look-ahead branch (next panel) runs here
   std::vector<hipEvent_t> la_events;
@@ -286,6 +291,13 @@ struct mik_handle {
   int opt_early_diag = -1; // look-ahead sweep: the next diagonal block is built and inverted ahead of the panel / update stream (-1 = with the look-ahead)
   int opt_gate = -1;       // look-ahead sweep: the trailing update waits until the next diagonal inverse has started and leaves
                            // it a CU of its own (k_gate); -1 = where the serial chain, not the update, is the step period
+  // round 3: the panel kernel and the update of the NEXT block column run on a third stream beside the trailing update of the
+  // step before (events only): -1 = from 24 block columns on, 0 = off, 1 = wherever the early-diagonal schedule runs
+  int opt_panel_stream = -1;
+  // tile order of the trailing update: 0 = the kernel's own (column by column; default), n > 1 = n x n super-blocks (the tiles an
+  // XCD has in flight share n + n operand panels in its L2).  Measured a tie at every size (profiles/r03_k2_panel_stream_ab.txt):
+  // the update is not bound by its panel reads.
+  int opt_update_map = 0;
   int opt_panel_rows = 32;  // rows of the column panel one block of k_panel forms: 32 (round 3), 64 or 128 (one tile, the round-1 form)
   int opt_update_waves = 8; // trailing-update kernel of the block sweep: 4 waves (wave tile 64 x 64) or 8 (32 x 64, default since round 3:
                             // -5 % at N=5000 / 8000, same bits: profiles/r03_update_waves_ab.txt) per 128 x 128 tile
@@ -310,6 +322,10 @@ struct mik_handle {
   // (profiles/r02_contract_pairs_vs_tiles.txt): L2 hit rate 28 % -> 47 %, fabric reads -19 %, and 2.7 % SLOWER -- co-resident
   // blocks then reach their epilogues together and stop covering each other's bubbles; the kernel is not traffic-bound.  Off.
   int opt_pairs = 0;
+  // symmetric contraction (8-wave form): the diagonal block of a tile is contracted as a triangle of 16-row groups -- 36 of
+  // its 64 (group, K tile) products (round 3; gemm_core TRI).  0 = the whole diagonal block.
+  int opt_tri = 1;
+  int opt_symmetrize = 1;  // T <- (T + T^T) / 2 after a full sweep / the pivoted elimination (k_symmetrize); 0 = as eliminated
   int opt_factor = 0, opt_sym = 1, opt_engine = 0;  // engine: 0 = v_mfma_f64 contraction, 1 = v_fma_f64 (VALU) contraction
   long opt_chunk = 131072;
   int opt_mw_pivot = 0;       // 1 = always solve the moving-window systems with partial pivoting
@@ -653,6 +669,7 @@ static int create_one_body(mik_handle* h, int device) {
     int lo = 0, hi = 0;  // the look-ahead branch is the critical path: give it the dispatcher's highest priority
     HIPC(hipDeviceGetStreamPriorityRange(&lo, &hi));
     HIPC(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, hi));
+    HIPC(hipStreamCreateWithPriority(&h->stream3, hipStreamNonBlocking, hi));
   }
   HIPC(hipStreamCreateWithFlags(&h->stream_d2h, hipStreamNonBlocking));
   HIPC(hipEventCreateWithFlags(&h->ev_d2h, hipEventDisableTiming));
@@ -675,6 +692,12 @@ static int create_one_body(mik_handle* h, int device) {
   if (env) h->opt_symsweep = atoi(env) < 0 ? -1 : atoi(env) ? 1 : 0;
   env = getenv("MIK_PAIRS");
   if (env) h->opt_pairs = atoi(env) ? 1 : 0;
+  env = getenv("MIK_UPDATE_MAP");
+  if (env) h->opt_update_map = atoi(env);
+  env = getenv("MIK_PANEL_STREAM");
+  if (env) h->opt_panel_stream = atoi(env) < 0 ? -1 : atoi(env) ? 1 : 0;
+  env = getenv("MIK_TRI");
+  if (env) h->opt_tri = atoi(env) ? 1 : 0;
   env = getenv("MIK_EXCHANGE");
   if (env) h->opt_exchange = !strcmp(env, "rccl") ? 1 : !strcmp(env, "peer") ? 2 : !strcmp(env, "redundant") ? 3 : 0;
   env = getenv("MIK_ALIAS_DEVICES");
@@ -725,7 +748,7 @@ static void destroy_one(mik_handle* h) {
   h->xsum.release();
   DevBuf* bufs[] = {&h->xs, &h->ys, &h->zs, &h->vals, &h->wells, &h->extra_cols, &h->T, &h->cvec, &h->Cold, &h->Cnew,
                     &h->Rt, &h->TKt, &h->Dinv, &h->DinvT, &h->P0, &h->P1, &h->cand0, &h->cand1, &h->pivall, &h->flag,
-                    &h->Cold2, &h->Cnew2, &h->Rt2, &h->Dinv2, &h->DinvT2, &h->Dnext, &h->Dcopy, &h->Cb, &h->Rb, &h->grid.gx, &h->grid.gy, &h->grid.gz, &h->grid.orig,
+                    &h->Cold2, &h->Cnew2, &h->Rt2, &h->Dinv2, &h->DinvT2, &h->Dinv3, &h->DinvT3, &h->tilemap, &h->Dnext, &h->Dcopy, &h->Cb, &h->Rb, &h->grid.gx, &h->grid.gy, &h->grid.gz, &h->grid.orig,
                     &h->grid.cstart,
                     &h->px, &h->py, &h->pz, &h->grid_axes, &h->grid_idx, &h->Averify, &h->vbuf, &h->extra_rows, &h->z, &h->ss, &h->Bt, &h->Bt2, &h->part, &h->mw_idx, &h->mw_dist, &h->stat_S, &h->stat_x, &h->stat_out, &h->queue};
   for (DevBuf* b : bufs) b->release();
@@ -733,12 +756,14 @@ static void destroy_one(mik_handle* h) {
   h->pin_out.release();
   for (hipEvent_t e : h->evpool) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->la_events) (void)hipEventDestroy(e);
+  for (hipEvent_t e : h->ps_events) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->pr_events) (void)hipEventDestroy(e);
   if (h->ev_chunk) (void)hipEventDestroy(h->ev_chunk);
   for (hipEvent_t e : h->xevents) (void)hipEventDestroy(e);
   if (h->ev_d2h) (void)hipEventDestroy(h->ev_d2h);
   if (h->stream_d2h) (void)hipStreamDestroy(h->stream_d2h);
   if (h->stream2) (void)hipStreamDestroy(h->stream2);
+  if (h->stream3) (void)hipStreamDestroy(h->stream3);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -792,8 +817,8 @@ static int set_group(mik_handle* h, int n) {
     }
     k->is_kid = true;
     k->opt_factor = h->opt_factor, k->opt_sym = h->opt_sym, k->opt_engine = h->opt_engine, k->opt_waves = h->opt_waves;
-    k->opt_chunk = h->opt_chunk, k->opt_symsweep = h->opt_symsweep, k->opt_diag = h->opt_diag, k->opt_update_waves = h->opt_update_waves, k->opt_panel_rows = h->opt_panel_rows, k->opt_lookahead = h->opt_lookahead, k->opt_gate = h->opt_gate, k->opt_fuse_chain = h->opt_fuse_chain, k->opt_early_diag = h->opt_early_diag, k->opt_pinv_fast = h->opt_pinv_fast, k->opt_rhs_overlap = h->opt_rhs_overlap, k->opt_verify = h->opt_verify, k->verify_tol_z = h->verify_tol_z, k->verify_tol_inv = h->verify_tol_inv;
-    k->opt_mw_class = h->opt_mw_class, k->opt_mw_knn_bound = h->opt_mw_knn_bound, k->opt_mw_pivot = h->opt_mw_pivot, k->opt_mw_lds_cap = h->opt_mw_lds_cap, k->opt_pairs = h->opt_pairs, k->opt_mw_solver = h->opt_mw_solver;
+    k->opt_chunk = h->opt_chunk, k->opt_symsweep = h->opt_symsweep, k->opt_diag = h->opt_diag, k->opt_update_waves = h->opt_update_waves, k->opt_panel_rows = h->opt_panel_rows, k->opt_panel_stream = h->opt_panel_stream, k->opt_update_map = h->opt_update_map, k->opt_lookahead = h->opt_lookahead, k->opt_gate = h->opt_gate, k->opt_fuse_chain = h->opt_fuse_chain, k->opt_early_diag = h->opt_early_diag, k->opt_pinv_fast = h->opt_pinv_fast, k->opt_rhs_overlap = h->opt_rhs_overlap, k->opt_verify = h->opt_verify, k->verify_tol_z = h->verify_tol_z, k->verify_tol_inv = h->verify_tol_inv;
+    k->opt_mw_class = h->opt_mw_class, k->opt_mw_knn_bound = h->opt_mw_knn_bound, k->opt_mw_pivot = h->opt_mw_pivot, k->opt_mw_lds_cap = h->opt_mw_lds_cap, k->opt_pairs = h->opt_pairs, k->opt_tri = h->opt_tri, k->opt_symmetrize = h->opt_symmetrize, k->opt_mw_solver = h->opt_mw_solver;
     k->custom_fn = h->custom_fn, k->custom_user = h->custom_user;
     h->kids.push_back(k);
   }
@@ -876,6 +901,10 @@ int mik_set_option(mik_handle* h, const char* key, double value) {
     h->opt_engine = (int)value;
   } else if (!strcmp(key, "pairs")) {
     h->opt_pairs = value != 0.0;
+  } else if (!strcmp(key, "tri")) {
+    h->opt_tri = value != 0.0;
+  } else if (!strcmp(key, "symmetrize")) {
+    h->opt_symmetrize = value != 0.0;
   } else if (!strcmp(key, "waves")) {
     if (value != 4.0 && value != 8.0) return fail(MIK_EINVAL, "waves must be 4 or 8");
     h->opt_waves = (int)value;
@@ -902,6 +931,10 @@ int mik_set_option(mik_handle* h, const char* key, double value) {
   } else if (!strcmp(key, "update_waves")) {
     if (value != 4.0 && value != 8.0) return fail(MIK_EINVAL, "update_waves must be 4 or 8");
     h->opt_update_waves = (int)value;
+  } else if (!strcmp(key, "update_map")) {
+    h->opt_update_map = (int)value;
+  } else if (!strcmp(key, "panel_stream")) {
+    h->opt_panel_stream = value < 0.0 ? -1 : (value != 0.0);
   } else if (!strcmp(key, "panel_rows")) {
     if (value != 32.0 && value != 64.0 && value != 128.0) return fail(MIK_EINVAL, "panel_rows must be 32, 64 or 128");
     h->opt_panel_rows = (int)value;
@@ -1116,6 +1149,29 @@ static void launch_diag_inv(mik_handle* h, hipStream_t st, const double* T, long
   }
 }
 
+// k_update's tilemap: the tiles of the (upper triangle of the) block grid, super-block by super-block (sb x sb tiles, rows of
+// super-blocks, inside one column by column), invalid positions skipped -- a plain permutation of the kernel's own enumeration,
+// so xcd_tile() still hands every XCD an equal, contiguous share.  Cached per (nblk, sym, sb).
+static int update_tile_map(mik_handle* h, int nblk, bool sym, int sb) {
+  if (h->tilemap_key[0] == nblk && h->tilemap_key[1] == (int)sym && h->tilemap_key[2] == sb) return MIK_OK;
+  std::vector<int2> map;
+  map.reserve(sym ? (size_t)nblk * (nblk + 1) / 2 : (size_t)nblk * nblk);
+  const int ns = (nblk + sb - 1) / sb;
+  for (int I = 0; I < ns; ++I)
+    for (int J = sym ? I : 0; J < ns; ++J)
+      for (int dj = 0; dj < sb; ++dj)
+        for (int di = 0; di < sb; ++di) {
+          const int i = I * sb + di, j = J * sb + dj;
+          if (i >= nblk || j >= nblk || (sym && i > j)) continue;
+          map.push_back(make_int2(i, j));
+        }
+  MIKC(h->tilemap.ensure(sizeof(int2) * map.size()));
+  HIPC(hipMemcpyAsync(h->tilemap.p, map.data(), sizeof(int2) * map.size(), hipMemcpyHostToDevice, h->stream));
+  HIPC(hipStreamSynchronize(h->stream));  // (map is a local)
+  h->tilemap_key[0] = nblk, h->tilemap_key[1] = (int)sym, h->tilemap_key[2] = sb;
+  return MIK_OK;
+}
+
 // unpivoted (path 1) or pivoted (path 2) block Gauss-Jordan on T in place
 static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_out) {
   const int Mp = h->Mp, nblk = Mp / 128;
@@ -1151,6 +1207,12 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
   const long ltiles = symsweep ? (long)nblk * (nblk + 1) / 2 : tiles;
   const unsigned ug = (unsigned)(8 * ((ltiles + 7) / 8));
   const bool upd8 = h->opt_update_waves == 8;
+  // tile order of the trailing update: optionally n x n super-blocks (k_update's tilemap)
+  const int2* tmap = nullptr;
+  if (!pivoted && h->opt_update_map > 1) {
+    MIKC(update_tile_map(h, nblk, symsweep, h->opt_update_map));
+    tmap = h->tilemap.as<int2>();
+  }
   // the panel kernel over all Mp rows: 32 * NAI rows per block (k_panel)
 #define PANEL(STREAM, ...)                                                                                                   \
   do {                                                                                                                       \
@@ -1160,8 +1222,8 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
   } while (0)
 #define UPDK(SYMV, GRID, STREAM, ...)                                                                                       \
   do {                                                                                                                      \
-    if (upd8) hipLaunchKernelGGL((k_update<SYMV, 2>), GRID, dim3(512), 0, STREAM, __VA_ARGS__);                             \
-    else hipLaunchKernelGGL((k_update<SYMV, 4>), GRID, dim3(256), 0, STREAM, __VA_ARGS__);                                  \
+    if (upd8) hipLaunchKernelGGL((k_update<SYMV, 2>), GRID, dim3(512), 0, STREAM, __VA_ARGS__, tmap);                       \
+    else hipLaunchKernelGGL((k_update<SYMV, 4>), GRID, dim3(256), 0, STREAM, __VA_ARGS__, tmap);                            \
   } while (0)
 #define UPDX(GRID, STREAM, CO, CN, R, D, PART, COL, POUT, DCOPY)                                                             \
   do {                                                                                                                       \
@@ -1247,6 +1309,71 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
       const bool flags_s1 = (h->opt_early_diag == 4 || h->opt_early_diag == 5) && nblk <= 128;
       const bool flags_s2 = flags_s1 && h->opt_early_diag == 4;
       int* fl = h->flag.as<int>();
+      const bool pstream = !flags_s1 && h->opt_early_diag != 2 && (h->opt_panel_stream < 0 ? nblk >= 24 : h->opt_panel_stream != 0);
+      if (pstream) {
+        // Panel-stream schedule (round 3).  The update stream of the schedule below carries k_panel + the whole update, one after
+        // the other, and from ~4000 stations on it is the step period.  Here the update of a step is cut into the tiles the NEXT
+        // step's head reads -- block column / row kb + 1 and the diagonal tile (kb + 2, kb + 2): "column part", k_update part 3 --
+        // and the rest (part 4), and three streams run
+        //   s1:  [panel kb ready]                          rest of update kb
+        //   s3:  [diagonal inverse kb]  k_panel kb  ->  [rest kb-1 done]  column part of update kb
+        //   s2:  [column part kb-1 done]  two 128^3 products -> diagonal inverse kb+1           (as below)
+        // so that s1 is trailing updates back to back and the panel kernel (26 us at a tenth of the MFMA rate) and the small
+        // column launch overlap them.  Only events order the streams.  The rest of update kb-1 still reads the diagonal inverse
+        // kb-1 while kb+1 is being formed: three Dinv sets.  Same tiles, same kernels, same accumulation order: same bits.
+        MIKC(h->Dinv3.ensure(sizeof(double) * 128 * 128));
+        MIKC(h->DinvT3.ensure(sizeof(double) * 128 * 128));
+        while (h->ps_events.size() < 4 * (size_t)nblk + 4) {
+          hipEvent_t e;
+          HIPC(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+          h->ps_events.push_back(e);
+        }
+        double* dv[3] = {h->Dinv.as<double>(), h->Dinv2.as<double>(), h->Dinv3.as<double>()};
+        double* dvT[3] = {h->DinvT.as<double>(), h->DinvT2.as<double>(), h->DinvT3.as<double>()};
+        auto evD = [&](int kb) { return h->ps_events[4 * kb]; };      // diagonal inverse kb done (s2)
+        auto evP = [&](int kb) { return h->ps_events[4 * kb + 1]; };  // panel kb done (s3)
+        auto evC = [&](int kb) { return h->ps_events[4 * kb + 2]; };  // column part of update kb done (s3)
+        auto evR = [&](int kb) { return h->ps_events[4 * kb + 3]; };  // rest of update kb done (s1)
+        hipStream_t s1 = h->stream, s2 = h->stream2, s3 = h->stream3;
+        HIPC(hipStreamWaitEvent(s3, h->la_events[0], 0));  // panel set 0, diagonal inverse 0 (dv[0]) and dcopy[0] are there
+        for (int kb = 0; kb < nblk; ++kb) {
+          const int set = kb & 1, k0 = kb * 128, k1 = k0 + 128, d3 = kb % 3, d3n = (kb + 1) % 3;
+          if (kb + 1 < nblk) {  // s2: diagonal inverse kb + 1
+            if (kb > 0) HIPC(hipStreamWaitEvent(s2, evC(kb - 1), 0));
+            hipLaunchKernelGGL(k_gemm128<0>, dim3(64), dim3(256), 0, s2, (const double*)(cold[set] + (long)k1 * 128), (const double*)dvT[d3],
+                               -1.0, (const double*)nullptr, 0L, rb);
+            hipLaunchKernelGGL(k_gemm128<1>, dim3(64), dim3(256), 0, s2, (const double*)(cold[set] + (long)k1 * 128), (const double*)rb, 0.0,
+                               (const double*)dcopy[set], 128L, dnext);
+            const double* dview = (const double*)((uintptr_t)dnext - sizeof(double) * ((size_t)k1 * 128 + (size_t)k1));
+            launch_diag_inv(h, s2, dview, 128L, k1, nspd, dv[d3n], dvT[d3n], gate);
+            HIPC(hipEventRecord(evD(kb + 1), s2));
+          }
+          if (kb > 0) {  // s3: panel kb (its column panel was left by the column part of update kb - 1, on this stream)
+            HIPC(hipStreamWaitEvent(s3, evD(kb), 0));
+            PANEL(s3, (const double*)cold[set], 128L, (const double*)dvT[d3], -1.0, cnew[set], rt[set], k0, 0, 0, (int*)nullptr, -1, -1);
+            HIPC(hipEventRecord(evP(kb), s3));
+          }
+          if (kb + 1 < nblk) {  // s3: column part of update kb
+            if (kb > 0) HIPC(hipStreamWaitEvent(s3, evR(kb - 1), 0));
+            if (symsweep)
+              UPDK(true, dim3(nblk + 1), s3, T, ld, nblk, kb, (const double*)cold[set], (const double*)cnew[set], (const double*)rt[set],
+                   (const double*)dv[d3], 3, kb + 1, cold[set ^ 1], dcopy[set ^ 1], (int*)nullptr);
+            else
+              UPDK(false, dim3(nblk + 1), s3, T, ld, nblk, kb, (const double*)cold[set], (const double*)cnew[set], (const double*)rt[set],
+                   (const double*)dv[d3], 3, kb + 1, cold[set ^ 1], dcopy[set ^ 1], (int*)nullptr);
+            HIPC(hipEventRecord(evC(kb), s3));
+          }
+          if (kb > 0) HIPC(hipStreamWaitEvent(s1, evP(kb), 0));  // s1: the rest (last step: everything)
+          const int part = kb + 1 < nblk ? 4 : 0, colarg = kb + 1 < nblk ? kb + 1 : -2;
+          if (symsweep)
+            UPDK(true, dim3(ug), s1, T, ld, nblk, kb, (const double*)cold[set], (const double*)cnew[set], (const double*)rt[set],
+                 (const double*)dv[d3], part, colarg, (double*)nullptr, (double*)nullptr, (int*)nullptr);
+          else
+            UPDK(false, dim3(ug), s1, T, ld, nblk, kb, (const double*)cold[set], (const double*)cnew[set], (const double*)rt[set],
+                 (const double*)dv[d3], part, colarg, (double*)nullptr, (double*)nullptr, (int*)nullptr);
+          if (kb + 1 < nblk) HIPC(hipEventRecord(evR(kb), s1));
+        }
+      } else
       for (int kb = 0; kb < nblk; ++kb) {
         const int set = kb & 1, k0 = kb * 128, k1 = k0 + 128;
         if (kb + 1 < nblk) {
@@ -1778,6 +1905,10 @@ static int launch_cvec(mik_handle* h) {
 }
 
 static int finish_factor(mik_handle* h) {
+  // the pseudo-inverse paths (4: Jacobi, 5 / 6: deflated sweeps, verified by the Penrose conditions) end here with a matrix that
+  // is symmetric up to rounding: average the triangles as after a full sweep (the caller's own inverse, path 3, is left alone)
+  if (h->opt_symmetrize && h->tm.factor_path >= 4 && h->tm.factor_path <= 6)
+    hipLaunchKernelGGL(k_symmetrize, dim3(h->Mp / 64, h->Mp / 64), dim3(256), 0, h->stream, h->T.as<double>(), (long)h->Mp, h->Mp / 64);
   MIKC(launch_cvec(h));
   HIPC(hipStreamSynchronize(h->stream));
   h->have_factor = true;
@@ -1873,6 +2004,10 @@ static int one_factor(mik_handle* h) {
     int flag = 0;
     MIKC(run_block_inverse(h, pivoted, pivoted ? 0 : h->N, &flag));
     if (!pivoted) hipLaunchKernelGGL(k_add_diag, dim3(1), dim3(1), 0, h->stream, h->T.as<double>(), (long)h->Mp, h->M - 1, shift);
+    // the half sweep leaves an exactly symmetric matrix (mirrored); every other elimination one that is symmetric up to
+    // rounding: average the triangles (k_symmetrize) -- the symmetric contraction reads one of them
+    if (!h->last_half_sweep && h->opt_symmetrize)
+      hipLaunchKernelGGL(k_symmetrize, dim3(h->Mp / 64, h->Mp / 64), dim3(256), 0, h->stream, h->T.as<double>(), (long)h->Mp, h->Mp / 64);
     HIPC(hipEventRecord(h->evpool[2], h->stream));
     HIPC(hipStreamSynchronize(h->stream));
     float ms = 0.f;
@@ -2807,7 +2942,8 @@ static int one_predict(mik_handle* h) {
         if (h->opt_waves == 8 && h->opt_sym && h->opt_pairs) {
           hipLaunchKernelGGL((k_contract<true, 2, true, true>), dim3(pgrid), dim3(512), 0, sc, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend, qp);
         } else if (h->opt_waves == 8) {
-          if (h->opt_sym) hipLaunchKernelGGL((k_contract<true, 2>), dim3(pgrid), dim3(512), 0, sc, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend, qp);
+          if (h->opt_sym && h->opt_tri) hipLaunchKernelGGL((k_contract<true, 2, true, false, true>), dim3(pgrid), dim3(512), 0, sc, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend, qp);
+          else if (h->opt_sym) hipLaunchKernelGGL((k_contract<true, 2>), dim3(pgrid), dim3(512), 0, sc, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend, qp);
           else hipLaunchKernelGGL((k_contract<false, 2>), dim3(pgrid), dim3(512), 0, sc, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend, qp);
         } else {
           if (h->opt_sym) hipLaunchKernelGGL((k_contract<true, 4>), dim3(pgrid), dim3(256), 0, sc, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend, qp);
@@ -2827,8 +2963,16 @@ static int one_predict(mik_handle* h) {
     HIPC(hipMemcpyAsync(h->pin_out.as<double>() + npt + t0, h->ss.as<double>() + t0, sizeof(double) * nvalid,
                         hipMemcpyDeviceToHost, h->stream_d2h));
     // executed flops of this launch: per tile 2*128*128*(k extent)
+    // (triangular diagonal blocks: nt (nt + 1) / 2 products of 16 rows x 16 k instead of 8 nt, nt = K tiles of the block)
+    const bool tri = h->opt_engine != 1 && h->opt_waves == 8 && h->opt_sym && !h->opt_pairs && h->opt_tri;
     double kext = 0.0;
-    for (int ib = 0; ib < nIblk; ++ib) kext += h->opt_sym ? std::max(0, kend - ib * 128) : kend;
+    for (int ib = 0; ib < nIblk; ++ib) {
+      const int ext = h->opt_sym ? std::max(0, kend - ib * 128) : kend;
+      if (tri) {
+        const int nt = std::min(ext, 128) / 16;
+        kext += (ext - 16 * nt) + 16.0 * (nt * (nt + 1) / 2) / 8.0;
+      } else kext += ext;
+    }
     h->tm.contract_flops_executed += 2.0 * 128.0 * 128.0 * kext * (palloc / 128);
   }
   HIPC(hipGetLastError());

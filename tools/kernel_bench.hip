@@ -3,6 +3,7 @@
 #include "mik_kernels.h"
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 using namespace mik;
 #define CK(x) do{hipError_t e=(x); if(e!=hipSuccess){printf("HIP error %s at %d\n",hipGetErrorString(e),__LINE__);return 1;}}while(0)
@@ -39,6 +40,22 @@ int main(int argc,char**argv){
   for(int w=0;w<2;++w) hipMemsetAsync(queue,0,64,0); hipLaunchKernelGGL((k_contract<true,4>),dim3(pgrid),dim3(256),0,0,(const double*)T,(long)Mp,(const double*)Bt,(long)Mp,part,P,nblk,kend,queue);
   hipDeviceSynchronize();
   float ms;
+  if(argc>4 && !strcmp(argv[4],"tri")){  // round 3: triangular diagonal blocks (gemm_core TRI) against the whole-block form, alternating
+    std::vector<double> a((size_t)P*nblk), b((size_t)P*nblk);
+    double kext_tri=0; for(int ib=0;ib<nblk;++ib){ int ext=kend-ib*128; if(ext<0) ext=0; int nt=(ext<128?ext:128)/16; kext_tri+=(ext-16*nt)+16.0*(nt*(nt+1)/2)/8.0; }
+    const double fl_tri=2.0*128*128*kext_tri*(P/128);
+    for(int rep=0;rep<3;++rep){
+      ms=timeit([&]{hipMemsetAsync(queue,0,64,0); hipLaunchKernelGGL((k_contract<true,2>),dim3(pgrid),dim3(512),0,0,(const double*)T,(long)Mp,(const double*)Bt,(long)Mp,part,P,nblk,kend,queue);},3);
+      printf("A/B sym 8-wave, whole diagonal blocks     : %.3f ms  executed %.2f TF/s  useful-equivalent %.2f TF/s\n",ms,fl_sym/ms*1e-9,fl_full/2/ms*1e-9);
+      if(rep==0) CK(hipMemcpy(a.data(),part,a.size()*8,hipMemcpyDeviceToHost));
+      ms=timeit([&]{hipMemsetAsync(queue,0,64,0); hipLaunchKernelGGL((k_contract<true,2,true,false,true>),dim3(pgrid),dim3(512),0,0,(const double*)T,(long)Mp,(const double*)Bt,(long)Mp,part,P,nblk,kend,queue);},3);
+      printf("A/B sym 8-wave, triangular diagonal blocks: %.3f ms  executed %.2f TF/s  useful-equivalent %.2f TF/s\n",ms,fl_tri/ms*1e-9,fl_full/2/ms*1e-9);
+      if(rep==0) CK(hipMemcpy(b.data(),part,b.size()*8,hipMemcpyDeviceToHost));
+    }
+    double md=0,mx=0; for(size_t i=0;i<a.size();++i){ md=fmax(md,fabs(a[i]-b[i])); mx=fmax(mx,fabs(a[i])); }
+    printf("   partials, triangular vs whole diagonal blocks: max|diff| %.3e (max|partial| %.3e)\n",md,mx);
+    return 0;
+  }
   ms=timeit([&]{hipMemsetAsync(queue,0,64,0); hipLaunchKernelGGL((k_contract<true,4>),dim3(pgrid),dim3(256),0,0,(const double*)T,(long)Mp,(const double*)Bt,(long)Mp,part,P,nblk,kend,queue);},3);
   printf("k_contract<sym>  mfma : %.3f ms  executed %.2f TF/s  effective(2M^2) %.2f TF/s\n",ms,fl_sym/ms*1e-9,fl_full/ms*1e-9);
   std::vector<double> refsym((size_t)P*nblk); CK(hipMemcpy(refsym.data(),part,refsym.size()*8,hipMemcpyDeviceToHost));  // symmetric-form partials (4-wave)
