@@ -233,6 +233,64 @@ def test_block_sweep_variants_agree():
             assert np.abs(a - ref4).max() <= 1e-11 * np.abs(ref4).max()
 
 
+def test_panel_stream_and_tile_map_return_the_same_bits():
+    """Round 3: the sweep's third stream (k_panel + the update of the next block column beside the rest of the previous update) and
+    the super-block tile order of the trailing update are schedules: bit-identical inverses, full and half sweep; a full sweep
+    ends symmetrized (A_inv = (A_inv + A_inv^T) / 2, what the symmetric contraction reads one triangle of)."""
+    g = fx.load("ok2d_n2000")
+    st = fx.state_from("ok2d_n2000", g)
+    h = _handle_for(st)
+    h.set_option("factor", 1)
+    for sym in (0, 1):
+        ref = None
+        for ps, umap, early in ((0, 0, 1), (1, 0, 1), (1, 8, 1), (0, 4, 1), (1, 16, 1), (1, 0, 0)):
+            for key, val in (("symsweep", sym), ("panel_stream", ps), ("update_map", umap), ("early_diag", early), ("lookahead", 1)):
+                h.set_option(key, val)
+            h.factor()
+            a = h.get_matrix(1)
+            assert np.array_equal(a, a.T)
+            if ref is None:
+                ref = a
+            else:
+                np.testing.assert_array_equal(a, ref)
+    # as eliminated (symmetrize = 0) the full sweep's triangles differ by rounding, and the average is what the default returns
+    for key, val in (("symsweep", 0), ("panel_stream", 1), ("update_map", 0), ("symmetrize", 0)):
+        h.set_option(key, val)
+    h.factor()
+    raw = h.get_matrix(1)
+    assert not np.array_equal(raw, raw.T)
+    h.set_option("symmetrize", 1)
+    h.factor()
+    np.testing.assert_array_equal(h.get_matrix(1), 0.5 * (raw + raw.T))
+
+
+def test_triangular_diagonal_blocks_of_the_contraction():
+    """Round 3: the symmetric contraction takes the diagonal block of a tile as a triangle of 16-row groups (option tri): sigma^2
+    equal to the whole-block form to rounding, z untouched (it is a separate dot product), for a station count that leaves a short last
+    block and for one that does not."""
+    for name in ("ok2d_n2000", "ok2d_exponential_exact"):
+        g = fx.load(name)
+        st = fx.state_from(name, g)
+        out = []
+        for tri in (0, 1):
+            h = _handle_for(st)
+            h.set_option("tri", tri)
+            h.factor()
+            rng = np.random.default_rng(5)
+            n = 1000
+            xs, ys = st.coords_adj[:, 0], st.coords_adj[:, 1]
+            px = rng.uniform(xs.min(), xs.max(), n)
+            py = rng.uniform(ys.min(), ys.max(), n)
+            px[:8], py[:8] = xs[:8], ys[:8]  # exact hits: sigma^2 = 0 is a difference of large terms
+            h.set_points(px, py)
+            h.predict()
+            out.append(tuple(np.array(v) for v in h.get_results()))
+            h.close()
+        np.testing.assert_array_equal(out[0][0], out[1][0])
+        scale = max(1.0, float(np.abs(out[0][1]).max()))
+        assert np.abs(out[0][1] - out[1][1]).max() <= 1e-11 * scale
+
+
 def test_rccl_single_rank_broadcast_path():
     """The multi-GPU exchange with world size 1: dlopen(librccl), ncclCommInitRank, ncclBroadcast of the
     inverse + c on the handle's stream.  (More ranks cannot be had on a 1-GPU box; tests/test_dist_gloo.py
