@@ -587,15 +587,20 @@ def main():
                     "achieved": executed, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": executed / FP64_MFMA_PEAK_TFLOPS,
                     "peak_measured": FP64_MFMA_MEASURED_TFLOPS, "frac_of_measured_peak": executed / FP64_MFMA_MEASURED_TFLOPS,
                     "effective_tflops": effective, "effective_frac": effective / FP64_MFMA_PEAK_TFLOPS,
+                    "useful_tflops": effective / 2.0, "useful_frac": effective / 2.0 / FP64_MFMA_PEAK_TFLOPS,
                     "traffic": None, "traffic_unit": "bytes per launch (HBM-side: 2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction)",
                     "note": "achieved / frac = flops the kernel EXECUTES (symmetric half product, ~M^2 per point) over the fp64 matrix "
                             "peak: a true fraction.  effective_* = the reference's 2 M^2 flops per point (SURVEY 8d) over the same "
-                            "time: the rate a full product would need to match this kernel; it can exceed the peak.",
+                            "time: the rate a full product would need to match this kernel; it can exceed the peak.  useful_* = M^2 "
+                            "flops per point (the quadratic form over one triangle) over the same time: <= achieved, and the "
+                            "number to compare across kernel versions (round 3's triangular diagonal blocks issue 2 % fewer "
+                            "flops for the same result: achieved went down, useful_* and points/s went up).",
                     "avg_launch_ms": avg_launch_s * 1e3, "launches_per_step": launches / K,
                     "algorithmic_flops_per_point": 2.0 * M * M, "useful_flops_per_point": float(M) * M,
                     "executed_flops_per_point": tsum["contract_flops_executed"] / max(1.0, pts_per_launch * launches),
                     "flops_note": "algorithmic = the reference's w = A_inv.b (2 M^2, ok.py:679); useful = the quadratic form b^T A_inv b "
-                                  "over one triangle (M^2); executed = useful + the mirrored halves of the 128 x 128 diagonal blocks"}
+                                  "over one triangle (M^2); executed = what the kernel issues: useful + the mirrored halves of the 16 x 16 diagonal "
+                                  "squares (option tri = 1, the default; of the whole 128 x 128 diagonal blocks with tri = 0)"}
             metric = ("kriged grid-points/sec (z + sigma^2), OK2D N=5000 on 1000x1000 grid" if args.config == 2
                       else "kriged grid-points/sec (z + sigma^2), " + cfg["name"])
             config = {"workload": cfg["name"], "stations": cfg["n"], "matrix_order": M,

@@ -746,8 +746,14 @@ __device__ __forceinline__ long xcd_tile(long total) {
 // blocks of a supertile are adjacent, so in the symmetric form their K extents differ by at most
 // MIK_SI-1 blocks and (K running downwards from kend) they stream the panels in near lockstep.
 // False = padding slot.
-#define MIK_SI 4
-#define MIK_ST 16
+// Shape (round 3, profiles/r03_supertile_shape_ab.txt): 16 row blocks x 4 point blocks.  Rounds 1-2 used 4 x 16; measured in one
+// run at config-2 size (symmetric form, 65 536 points): 1 x 64 25.9 ms, 2 x 32 25.0, 4 x 16 25.0, 8 x 8 24.65, 16 x 4 24.5, 32 x 2
+// 24.5, 64 x 1 25.3 -- the tall shapes re-read a point panel of B (HBM; the inverse sits in the Infinity Cache) 2.5 x per launch
+// instead of 10 x.  -1.4 % at N = 8000, a tie at N = 2000.
+#ifndef MIK_SI  // (tools/kernel_bench builds other shapes with -DMIK_SI=.. -DMIK_ST=..; MIK_SI * MIK_ST = 64)
+#define MIK_SI 16
+#define MIK_ST 4
+#endif
 __host__ __device__ inline long super_tiles_total(int nIblk, int nTblk) {
   return (long)((nIblk + MIK_SI - 1) / MIK_SI) * ((nTblk + MIK_ST - 1) / MIK_ST) * 64;
 }
