@@ -504,6 +504,12 @@ __global__ void __launch_bounds__(256) k_rhs(RhsArgs a) {
 // acc[ai][bi][r] <-> row 16*ai + 4*r + (l>>4), column 16*bi + (l&15) of the wave tile.
 // K is staged in tiles of 16 through double-buffered LDS by LDS-DMA, one barrier per tile.
 // ------------------------------------------------------------------------------------------------
+#ifndef MIK_CP_A
+#define MIK_CP_A ""
+#endif
+#ifndef MIK_CP_B
+#define MIK_CP_B ""
+#endif
 #define MIK_BM 128
 #define MIK_BN 128
 #define MIK_BK 16
@@ -592,12 +598,13 @@ __device__ __forceinline__ void gemm_core(const double* __restrict__ Ag, long ld
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
       const unsigned la = ldsA + b * LDS_BUF + p * LDS_PASS, lb = ldsB + b * LDS_BUF_B + p * LDS_PASS;
+      // MIK_CP_A / MIK_CP_B: cache-policy modifiers of the two operand streams (tools/kernel_bench experiments: " nt", " sc1", ..)
       if (p == 0) {  // the bases come straight from v_readfirstlane: VALU-written SGPR -> VMEM address needs 5 wait states
-        asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(aoffb[p]), "s"(abase), "s"(la) : "memory");
-        if (!(ABL & 32)) asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(boffb[p]), "s"(bbase), "s"(lb) : "memory");
+        asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" MIK_CP_A ::"v"(aoffb[p]), "s"(abase), "s"(la) : "memory");
+        if (!(ABL & 32)) asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" MIK_CP_B ::"v"(boffb[p]), "s"(bbase), "s"(lb) : "memory");
       } else {
-        if (p < NPASS_A) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(aoffb[p]), "s"(abase), "s"(la) : "memory");
-        if (!(ABL & 32) && p < NPASS_B) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(boffb[p]), "s"(bbase), "s"(lb) : "memory");
+        if (p < NPASS_A) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" MIK_CP_A ::"v"(aoffb[p]), "s"(abase), "s"(la) : "memory");
+        if (!(ABL & 32) && p < NPASS_B) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" MIK_CP_B ::"v"(boffb[p]), "s"(bbase), "s"(lb) : "memory");
       }
       if (ABL & 32) {
         // experiment (tools/kernel_bench): the B tile is not loaded but GENERATED -- per thread and pass two
