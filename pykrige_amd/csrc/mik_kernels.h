@@ -519,12 +519,11 @@ __global__ void __launch_bounds__(256) k_rhs(RhsArgs a) {
 // no staging VGPRs, no ds_write).  Bank conflicts of the fragment reads are removed by an XOR swizzle
 // applied to the per-lane SOURCE address and to the reads: element (row r, k) lives in 16-byte slot
 // ((k>>1) ^ swz(r)) of row r, swz = r & 2 for the A tile and (r>>1) & 7 for the B tile.
-// row group of a wave inside the block tile.  TRI with 8 waves of 32 x 64: the waves that share a SIMD (w and w + 4) get the
-// row groups {0, 3} and {1, 2}, whose triangular diagonal-block work is equal (15 + 3 and 11 + 7 of 64 products).
+// row group of a wave inside the block tile.  (Dealing the row groups so that the two waves sharing a SIMD have equal triangular
+// diagonal-block work -- {0, 3} / {1, 2} -- was measured: no difference, 23.95 vs 23.93 ms per launch.)
 template <int NAI, int BM, bool TRI>
 __device__ __forceinline__ int gemm_wm(int wave) {
-  const int x = wave >> 1;
-  return (TRI && NAI == 2 && BM == 128) ? (x ^ (x >> 1)) : x;
+  return wave >> 1;
 }
 
 template <int BM>
@@ -552,7 +551,7 @@ typedef __attribute__((address_space(3))) void* mik_lptr_t;
 // the K tiles above its own 16 x 16 diagonal square with weight 2, the square itself with weight 1 and skips the tiles below
 // it (their mirror images have been counted twice).  "Weight 2" = the group's accumulators are doubled when the loop reaches
 // its square, as kscale does for the whole tile.  36 of the 64 (group, K tile) products of a diagonal block remain; the
-// branches are wave-uniform.  Groups are dealt to the waves so that the two waves sharing a SIMD (w, w + 4) keep 18 each.
+// branches are wave-uniform.
 template <int NAI, int ABL = 0, int BM = MIK_BM, bool TRI = false>
 __device__ __forceinline__ void gemm_core(const double* __restrict__ Ag, long lda, const double* __restrict__ Bg,
                                           long ldb, int kbeg, int kend, d4 (&acc)[NAI][4], GemmSmemT<BM>& sm,
@@ -774,8 +773,19 @@ __device__ __forceinline__ int super_tile_at(int nIblk, int nTblk, int xcd, long
   if (s >= nsuper) return 2;
   const int r = (int)(seq & 63);
   const int nTg = (nTblk + MIK_ST - 1) / MIK_ST;
-  iblk = (int)(s / nTg) * MIK_SI + (r % MIK_SI);
-  tblk = (int)(s % nTg) * MIK_ST + (r / MIK_SI);
+#ifdef MIK_DEAL_ROWFAST  // experiment: consecutive supertiles (= the 8 XCDs at one time) are the row groups of ONE point group
+  const int nRg = (nIblk + MIK_SI - 1) / MIK_SI;
+  const int rg = (int)(s % nRg), tg = (int)(s / nRg);
+#else
+  const int rg = (int)(s / nTg), tg = (int)(s % nTg);
+#endif
+#ifdef MIK_POP_ROWFAST  // rounds 1-2: consecutive queue positions walk the row blocks of one point block
+  iblk = rg * MIK_SI + (r % MIK_SI);
+  tblk = tg * MIK_ST + (r / MIK_SI);
+#else  // consecutive positions walk the point blocks of one row block (round 3: -0.8 % per launch, and the shape then hardly matters)
+  iblk = rg * MIK_SI + (r / MIK_ST);
+  tblk = tg * MIK_ST + (r % MIK_ST);
+#endif
   return (iblk < nIblk && tblk < nTblk) ? 0 : 1;
 }
 
