@@ -1229,7 +1229,12 @@ __global__ void __launch_bounds__(64 * 2 * (8 / NAI), 2)
 k_update(double* __restrict__ T, long ld, int nblk, int kb, const double* __restrict__ Cold,
          const double* __restrict__ Cnew, const double* __restrict__ Rt, const double* __restrict__ Dinv, int part, int col,
          double* __restrict__ Pout, double* __restrict__ Dcopy = nullptr, int* __restrict__ done_cnt = nullptr,
-         const int2* __restrict__ tilemap = nullptr) {
+         const int2* __restrict__ tilemap = nullptr, int atomic_rmw = 0) {
+  // atomic_rmw (round 3): a tile that only has to become T - C R^T (no panel copy, no diagonal copy) sends its 128 x 128 products
+  // to memory as fp64 atomic adds of -acc (global_atomic_add_f64, no return value) instead of load / subtract / store: the
+  // read-modify-write then happens in the L2 while the wavefronts are already in the next tile's K loop -- the epilogue's memory
+  // latency was not overlapped with anything before (the two resident blocks of a CU run their phases in step).  T + (-x) rounds
+  // exactly like T - x and every entry receives one update per launch: same bits.
   // tilemap (nullable; round 3): position -> (iblk, jblk) of parts 0 / 2 / 4, written by the host (update_tile_map): the tiles in
   // the order of 8 x 8 super-blocks, so that the ~64 tiles an XCD works on at a time share 8 + 8 operand panels (2 MB of its 4 MB
   // L2) instead of a whole block column's worth (one C panel per tile: 8 MB at N = 8000, re-fetched over the fabric every column)
@@ -1321,6 +1326,18 @@ k_update(double* __restrict__ T, long ld, int nblk, int kb, const double* __rest
   constexpr int NTV = NAI == 4 ? 2 : 1;  // the 8-wave form keeps ONE batch in registers (128-VGPR budget for 4 waves per SIMD)
   double tv[NTV][4][4];
   auto tile_ptr = [&](int ai) { return T + (long)(i0 + wm * WR + ai * 16 + lq) * ld + j0 + wn * 64 + lc; };
+  if (atomic_rmw && !P && !DC) {  // block-uniform
+#pragma unroll
+    for (int ai = 0; ai < NAI; ++ai) {
+      double* tp = tile_ptr(ai);
+#pragma unroll
+      for (int bi = 0; bi < 4; ++bi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          (void)__hip_atomic_fetch_add(tp + (long)(4 * r) * ld + bi * 16, -acc[ai][bi][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return finish();
+  }
   auto load_batch = [&](int ai, double (&dst)[4][4]) {
     const double* tp = tile_ptr(ai);
 #pragma unroll

@@ -298,6 +298,8 @@ struct mik_handle {
   // XCD has in flight share n + n operand panels in its L2).  Measured a tie at every size (profiles/r03_k2_panel_stream_ab.txt):
   // the update is not bound by its panel reads.
   int opt_update_map = 0;
+  // trailing update: tiles without a panel / diagonal copy go to memory as fp64 atomic adds (k_update atomic_rmw; same bits)
+  int opt_update_atomic = 1;
   int opt_panel_rows = 32;  // rows of the column panel one block of k_panel forms: 32 (round 3), 64 or 128 (one tile, the round-1 form)
   int opt_update_waves = 8; // trailing-update kernel of the block sweep: 4 waves (wave tile 64 x 64) or 8 (32 x 64, default since round 3:
                             // -5 % at N=5000 / 8000, same bits: profiles/r03_update_waves_ab.txt) per 128 x 128 tile
@@ -692,6 +694,8 @@ static int create_one_body(mik_handle* h, int device) {
   if (env) h->opt_symsweep = atoi(env) < 0 ? -1 : atoi(env) ? 1 : 0;
   env = getenv("MIK_PAIRS");
   if (env) h->opt_pairs = atoi(env) ? 1 : 0;
+  env = getenv("MIK_UPDATE_ATOMIC");
+  if (env) h->opt_update_atomic = atoi(env) ? 1 : 0;
   env = getenv("MIK_UPDATE_MAP");
   if (env) h->opt_update_map = atoi(env);
   env = getenv("MIK_PANEL_STREAM");
@@ -817,7 +821,7 @@ static int set_group(mik_handle* h, int n) {
     }
     k->is_kid = true;
     k->opt_factor = h->opt_factor, k->opt_sym = h->opt_sym, k->opt_engine = h->opt_engine, k->opt_waves = h->opt_waves;
-    k->opt_chunk = h->opt_chunk, k->opt_symsweep = h->opt_symsweep, k->opt_diag = h->opt_diag, k->opt_update_waves = h->opt_update_waves, k->opt_panel_rows = h->opt_panel_rows, k->opt_panel_stream = h->opt_panel_stream, k->opt_update_map = h->opt_update_map, k->opt_lookahead = h->opt_lookahead, k->opt_gate = h->opt_gate, k->opt_fuse_chain = h->opt_fuse_chain, k->opt_early_diag = h->opt_early_diag, k->opt_pinv_fast = h->opt_pinv_fast, k->opt_rhs_overlap = h->opt_rhs_overlap, k->opt_verify = h->opt_verify, k->verify_tol_z = h->verify_tol_z, k->verify_tol_inv = h->verify_tol_inv;
+    k->opt_chunk = h->opt_chunk, k->opt_symsweep = h->opt_symsweep, k->opt_diag = h->opt_diag, k->opt_update_waves = h->opt_update_waves, k->opt_panel_rows = h->opt_panel_rows, k->opt_panel_stream = h->opt_panel_stream, k->opt_update_map = h->opt_update_map, k->opt_update_atomic = h->opt_update_atomic, k->opt_lookahead = h->opt_lookahead, k->opt_gate = h->opt_gate, k->opt_fuse_chain = h->opt_fuse_chain, k->opt_early_diag = h->opt_early_diag, k->opt_pinv_fast = h->opt_pinv_fast, k->opt_rhs_overlap = h->opt_rhs_overlap, k->opt_verify = h->opt_verify, k->verify_tol_z = h->verify_tol_z, k->verify_tol_inv = h->verify_tol_inv;
     k->opt_mw_class = h->opt_mw_class, k->opt_mw_knn_bound = h->opt_mw_knn_bound, k->opt_mw_pivot = h->opt_mw_pivot, k->opt_mw_lds_cap = h->opt_mw_lds_cap, k->opt_pairs = h->opt_pairs, k->opt_tri = h->opt_tri, k->opt_symmetrize = h->opt_symmetrize, k->opt_mw_solver = h->opt_mw_solver;
     k->custom_fn = h->custom_fn, k->custom_user = h->custom_user;
     h->kids.push_back(k);
@@ -931,6 +935,8 @@ int mik_set_option(mik_handle* h, const char* key, double value) {
   } else if (!strcmp(key, "update_waves")) {
     if (value != 4.0 && value != 8.0) return fail(MIK_EINVAL, "update_waves must be 4 or 8");
     h->opt_update_waves = (int)value;
+  } else if (!strcmp(key, "update_atomic")) {
+    h->opt_update_atomic = value != 0.0;
   } else if (!strcmp(key, "update_map")) {
     h->opt_update_map = (int)value;
   } else if (!strcmp(key, "panel_stream")) {
@@ -1207,6 +1213,7 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
   const long ltiles = symsweep ? (long)nblk * (nblk + 1) / 2 : tiles;
   const unsigned ug = (unsigned)(8 * ((ltiles + 7) / 8));
   const bool upd8 = h->opt_update_waves == 8;
+  const int uatomic = pivoted ? 0 : h->opt_update_atomic;  // plain tiles of the trailing update as fp64 atomic adds (k_update)
   // tile order of the trailing update: optionally n x n super-blocks (k_update's tilemap)
   const int2* tmap = nullptr;
   if (!pivoted && h->opt_update_map > 1) {
@@ -1222,8 +1229,8 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
   } while (0)
 #define UPDK(SYMV, GRID, STREAM, ...)                                                                                       \
   do {                                                                                                                      \
-    if (upd8) hipLaunchKernelGGL((k_update<SYMV, 2>), GRID, dim3(512), 0, STREAM, __VA_ARGS__, tmap);                       \
-    else hipLaunchKernelGGL((k_update<SYMV, 4>), GRID, dim3(256), 0, STREAM, __VA_ARGS__, tmap);                            \
+    if (upd8) hipLaunchKernelGGL((k_update<SYMV, 2>), GRID, dim3(512), 0, STREAM, __VA_ARGS__, tmap, uatomic);              \
+    else hipLaunchKernelGGL((k_update<SYMV, 4>), GRID, dim3(256), 0, STREAM, __VA_ARGS__, tmap, uatomic);                   \
   } while (0)
 #define UPDX(GRID, STREAM, CO, CN, R, D, PART, COL, POUT, DCOPY)                                                             \
   do {                                                                                                                       \
