@@ -298,8 +298,9 @@ struct mik_handle {
   // XCD has in flight share n + n operand panels in its L2).  Measured a tie at every size (profiles/r03_k2_panel_stream_ab.txt):
   // the update is not bound by its panel reads.
   int opt_update_map = 0;
-  // trailing update: tiles without a panel / diagonal copy go to memory as fp64 atomic adds (k_update atomic_rmw; same bits)
-  int opt_update_atomic = 1;
+  // trailing update: tiles without a panel / diagonal copy go to memory as fp64 atomic adds (k_update atomic_rmw; same bits).
+  // Measured SLOWER (N=5000 4.39 -> 4.84 ms, N=8000 13.98 -> 15.96 ms: the L2's fp64 atomic rate, not latency, is the bound): off.
+  int opt_update_atomic = 0;
   int opt_panel_rows = 32;  // rows of the column panel one block of k_panel forms: 32 (round 3), 64 or 128 (one tile, the round-1 form)
   int opt_update_waves = 8; // trailing-update kernel of the block sweep: 4 waves (wave tile 64 x 64) or 8 (32 x 64, default since round 3:
                             // -5 % at N=5000 / 8000, same bits: profiles/r03_update_waves_ab.txt) per 128 x 128 tile
