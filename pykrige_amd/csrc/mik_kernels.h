@@ -2789,8 +2789,12 @@ __global__ void __launch_bounds__(256) k_mw_solve(MwArgs a) {
 // which cost more than its FMAs).  Per step the G owners of column c publish it through double-buffered LDS; with at most 64
 // threads per point the point lives inside one wavefront and no workgroup barrier is needed at all.
 // A non-positive pivot raises flag bit 1 (the host reruns the call with the pivoted kernel).
+// (second launch-bound = wavefronts per SIMD the register allocation must allow: the one-wavefront-per-point classes beyond
+// RI = 12 otherwise take 256 VGPRs + a few AGPRs, which halves the occupancy -- measured 2 x slower)
+#define MIK_MWC_WAVES(G, RI) (((G) == 8 && (RI) >= 13) ? 2 : 1)
+#define MIK_MWC_LEAN(G, RI) ((G) == 8 && (RI) >= 13)
 template <int G, int RI>
-__global__ void __launch_bounds__((G * G < 256) ? 256 : G * G) k_mw_chol(MwArgs a) {
+__global__ void __launch_bounds__((G * G < 256) ? 256 : G * G, MIK_MWC_WAVES(G, RI)) k_mw_chol(MwArgs a) {
   extern __shared__ double mw_lds[];
   constexpr int T = G * G, NT = T < 256 ? 256 : T, NB = G * RI, ACOL = NB + 4;
   const int K = a.K;
@@ -2882,19 +2886,29 @@ __global__ void __launch_bounds__((G * G < 256) ? 256 : G * G) k_mw_chol(MwArgs 
       double u[RI], w[RI];
 #pragma unroll
       for (int i = cc; i < RI; ++i) {
-        u[i] = ab[ty + G * i] * inv;
+        if (!MIK_MWC_LEAN(G, RI)) u[i] = ab[ty + G * i] * inv;
         w[i] = ab[tx + G * i];
       }
-      if (ty <= cx) u[cc] = 0.0;  // rows / columns <= c of the diagonal local tile are finished
+      if (!MIK_MWC_LEAN(G, RI) && ty <= cx) u[cc] = 0.0;  // rows / columns <= c of the diagonal local tile are finished
       if (tx <= cx) w[cc] = 0.0;
       const double ur = (ty < 3 ? ab[NB + ty] : 0.0) * inv;
       // the five inner products z and sigma^2 are made of, sum_c y_p(c) y_q(c) / d(c), are formed ONCE at the end from this log
       // (every thread used to accumulate all five in every step)
       if (lt < 4) ylog[lt * NB + c] = (lt < 3) ? ab[NB + lt] : inv;
+      if (MIK_MWC_LEAN(G, RI)) {  // the largest one-wavefront tiles: the row factors are read as they are used (RI fewer live doubles)
 #pragma unroll
-      for (int i = cc; i < RI; ++i)
+        for (int i = cc; i < RI; ++i) {
+          double ui = ab[ty + G * i] * inv;
+          if (i == cc && ty <= cx) ui = 0.0;
 #pragma unroll
-        for (int j = cc; j <= i; ++j) m[i][j] -= u[i] * w[j];
+          for (int j = cc; j <= i; ++j) m[i][j] -= ui * w[j];
+        }
+      } else {
+#pragma unroll
+        for (int i = cc; i < RI; ++i)
+#pragma unroll
+          for (int j = cc; j <= i; ++j) m[i][j] -= u[i] * w[j];
+      }
 #pragma unroll
       for (int j = cc; j < RI; ++j) rhs[j] -= ur * w[j];
     }

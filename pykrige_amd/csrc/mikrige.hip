@@ -626,8 +626,8 @@ static int dispatch_mw_chol(mik_handle* h, const MwArgs& a, long pc) {
     }
   }
   // measured per window size (scripts/mw_classes.py, profiles/r03_mw_classes_after_kernel_changes.txt): one wavefront per point
-  // as long as the register tile stays at RI <= 12 (beyond that the compiler parks values in AGPRs: 2 x slower), then 256
-  // threads per point up to RI = 12, 1024 threads for the last two
+  // as long as the register tile stays at RI <= 13 (RI = 13 only with the lean update below; beyond that the kernel needs more
+  // than 256 registers and the occupancy halves: 2 x slower), then 256 threads per point up to RI = 12, 1024 threads for the last two
   if (K <= 16) return launch_mw_chol<4, 4>(h, a, pc);    // 16 threads per point, 4 points per wavefront
   if (K <= 32) return launch_mw_chol<8, 4>(h, a, pc);    // one wavefront per point from here to K = 96: no workgroup barrier
   if (K <= 48) return launch_mw_chol<8, 6>(h, a, pc);
@@ -635,6 +635,10 @@ static int dispatch_mw_chol(mik_handle* h, const MwArgs& a, long pc) {
   if (K <= 80) return launch_mw_chol<8, 10>(h, a, pc);
   if (K <= 88) return launch_mw_chol<8, 11>(h, a, pc);
   if (K <= 96) return launch_mw_chol<8, 12>(h, a, pc);
+  // RI = 13 in one wavefront (round 3, second session): held to 2 wavefronts per SIMD by its launch bound, row factors read as
+  // they are used (MIK_MWC_LEAN): 8 spilled registers instead of 24 AGPRs and half the occupancy -- k = 100: 10.9 ms per 2e5
+  // points against 13.5 for {16,7}.  {8,14} ties with {16,7} at k = 112 (14.5 / 14.2 ms): not used.
+  if (K <= 104) return launch_mw_chol<8, 13>(h, a, pc);
   if (K <= 112) return launch_mw_chol<16, 7>(h, a, pc);  // 256 threads per point
   if (K <= 128) return launch_mw_chol<16, 8>(h, a, pc);
   if (K <= 144) return launch_mw_chol<16, 9>(h, a, pc);
