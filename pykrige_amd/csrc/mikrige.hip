@@ -619,7 +619,7 @@ static int dispatch_mw_chol(mik_handle* h, const MwArgs& a, long pc) {
     switch (h->opt_mw_class) {
 #define MWC(G, RI) case 100 * G + RI: return launch_mw_chol<G, RI>(h, a, pc);
       MWC(4, 4) MWC(8, 4) MWC(8, 6) MWC(8, 8) MWC(8, 10) MWC(8, 11) MWC(8, 12) MWC(8, 13) MWC(8, 14) MWC(8, 16)
-      MWC(16, 4) MWC(16, 5) MWC(16, 6) MWC(16, 7) MWC(16, 8) MWC(16, 9) MWC(16, 10) MWC(16, 11) MWC(16, 12) MWC(16, 13) MWC(16, 14) MWC(16, 16)
+      MWC(16, 4) MWC(16, 5) MWC(16, 6) MWC(16, 7) MWC(16, 8) MWC(16, 9) MWC(16, 10) MWC(16, 11) MWC(16, 12) MWC(16, 13) MWC(16, 14) MWC(16, 15) MWC(16, 16)
       MWC(32, 5) MWC(32, 6) MWC(32, 7) MWC(32, 8)
 #undef MWC
       default: return fail(MIK_EINVAL, "mw_class: no such LDL^T class");
@@ -645,8 +645,11 @@ static int dispatch_mw_chol(mik_handle* h, const MwArgs& a, long pc) {
   if (K <= 160) return launch_mw_chol<16, 10>(h, a, pc);
   if (K <= 176) return launch_mw_chol<16, 11>(h, a, pc);
   if (K <= 192) return launch_mw_chol<16, 12>(h, a, pc);
-  if (K <= 224) return launch_mw_chol<32, 7>(h, a, pc);  // 1024 threads per point
-  return launch_mw_chol<32, 8>(h, a, pc);                // K <= 256
+  // second session of round 3: RI = 13 / 14 on 256 threads, held to 2 wavefronts per SIMD (launch bound + lean update): k = 200
+  // 113 -> 65 ms per 2e5 points, k = 224 123 -> 88 ms -- they replace the 1024-thread class {32,7}
+  if (K <= 208) return launch_mw_chol<16, 13>(h, a, pc);
+  if (K <= 224) return launch_mw_chol<16, 14>(h, a, pc);
+  return launch_mw_chol<32, 8>(h, a, pc);                // K <= 256: 1024 threads per point
 }
 
 extern "C" {
