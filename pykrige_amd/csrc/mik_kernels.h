@@ -2792,10 +2792,14 @@ __global__ void __launch_bounds__(256) k_mw_solve(MwArgs a) {
 // (second launch-bound = wavefronts per SIMD the register allocation must allow: the one-wavefront-per-point classes beyond
 // RI = 12 otherwise take 256 VGPRs + a few AGPRs, which halves the occupancy -- measured 2 x slower)
 #ifndef MIK_MWC_WAVES
-#define MIK_MWC_WAVES(G, RI) (((G) == 8 && (RI) >= 13) ? 2 : ((G) == 16 && (RI) == 8) ? 4 : ((G) == 16 && ((RI) == 9 || (RI) == 10)) ? 3 : ((G) == 16 && (RI) >= 11) ? 2 : 1)
+#define MIK_MWC_WAVES(G, RI)                                                                                                        \
+  (((G) == 8 && (RI) >= 13) ? 2 : ((G) == 8 && (RI) == 10) ? 3 : ((G) == 8 && (RI) == 8) ? 4 : ((G) == 8 && (RI) == 6) ? 5 :         \
+   ((G) == 16 && (RI) == 8) ? 4 : ((G) == 16 && ((RI) == 9 || (RI) == 10)) ? 3 : ((G) == 16 && (RI) >= 11) ? 2 : 1)
 // lean update (row factors read from LDS as they are used instead of held: RI fewer live doubles) where it buys a wavefront per
 // SIMD; elsewhere it costs 1-2 % (profiles/r03_mw_classes_after_kernel_changes.txt)
-#define MIK_MWC_LEAN(G, RI) (((G) == 8 && (RI) >= 13) || ((G) == 16 && ((RI) == 8 || (RI) == 10 || (RI) >= 13)) || ((G) == 32 && (RI) == 8))
+#define MIK_MWC_LEAN(G, RI)                                                                                                         \
+  (((G) == 8 && ((RI) >= 13 || (RI) == 10 || (RI) == 8 || (RI) == 6)) || ((G) == 16 && ((RI) == 8 || (RI) == 10 || (RI) >= 13)) ||  \
+   ((G) == 32 && (RI) == 8))
 #endif
 template <int G, int RI>
 __global__ void __launch_bounds__((G * G < 256) ? 256 : G * G, MIK_MWC_WAVES(G, RI)) k_mw_chol(MwArgs a) {
