@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmikrige.so")
+# (MIK_LIB_PATH: a developer switch for A/B runs of two builds on one GPU box; the product loads the in-tree library)
+LIB_PATH = os.environ.get("MIK_LIB_PATH") or os.path.join(_HERE, "libmikrige.so")
 
 MIK_OK, MIK_EINVAL, MIK_ESINGULAR, MIK_EHIP, MIK_ERCCL, MIK_ESTATE = 0, -1, -2, -3, -4, -5
 MODEL_IDS = {"linear": 0, "power": 1, "gaussian": 2, "spherical": 3, "exponential": 4, "hole-effect": 5, "custom": 6}

@@ -1224,8 +1224,13 @@ k_panel(const double* __restrict__ A, long lda, const double* __restrict__ Bt, d
 // NAI = 4: 4 waves per block, wave tile 64 x 64 (228 VGPRs, 2 waves per SIMD); NAI = 2 (round 3): 8 waves, wave tile 32 x 64
 // (<= 128 VGPRs, 4 waves per SIMD to cover the short K loop and the read-modify-write epilogue).  Same accumulation order per
 // entry: bit-identical results.
+// register sets of the read-modify-write epilogue: two for the 4-wave form; the 8-wave form (128-VGPR budget) keeps ONE -- with two
+// it spills 25 registers and the inverse is 12-14 % slower (N=5000 4.33 -> 4.90 ms; profiles/r03_k2_panel_stream_ab.txt)
+#ifndef MIK_UPD_NTV
+#define MIK_UPD_NTV(NAI) ((NAI) == 4 ? 2 : 1)
+#endif
 template <bool SYM, int NAI = 4>
-__global__ void __launch_bounds__(64 * 2 * (8 / NAI), 2)
+__global__ void __launch_bounds__(64 * 2 * (8 / NAI), NAI == 2 ? 4 : 2)
 k_update(double* __restrict__ T, long ld, int nblk, int kb, const double* __restrict__ Cold,
          const double* __restrict__ Cnew, const double* __restrict__ Rt, const double* __restrict__ Dinv, int part, int col,
          double* __restrict__ Pout, double* __restrict__ Dcopy = nullptr, int* __restrict__ done_cnt = nullptr,
@@ -1323,7 +1328,7 @@ k_update(double* __restrict__ T, long ld, int nblk, int kb, const double* __rest
   constexpr int WR = 16 * NAI;  // rows of the wave tile
   // read-modify-write in batches of 16 independent loads, the NEXT batch's loads in flight while this one is subtracted and
   // stored (two register sets): the epilogue pays the memory latency once, not four times
-  constexpr int NTV = NAI == 4 ? 2 : 1;  // the 8-wave form keeps ONE batch in registers (128-VGPR budget for 4 waves per SIMD)
+  constexpr int NTV = MIK_UPD_NTV(NAI);  // register sets of the epilogue (the 8-wave form has a 128-VGPR budget for 4 waves per SIMD)
   double tv[NTV][4][4];
   auto tile_ptr = [&](int ai) { return T + (long)(i0 + wm * WR + ai * 16 + lq) * ld + j0 + wn * 64 + lc; };
   if (atomic_rmw && !P && !DC) {  // block-uniform
