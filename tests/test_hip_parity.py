@@ -759,6 +759,28 @@ def test_moving_window_cell_grid_against_kdtree(case):
     np.testing.assert_allclose(ss, sr, rtol=0, atol=1e-6)
 
 
+@pytest.mark.parametrize("k", [24, 40, 56, 72, 84, 92, 100, 104, 110, 124, 140, 156, 170, 188, 204, 220, 250])
+def test_moving_window_every_register_class_against_the_oracle(k):
+    """One window size per class {G, RI} of the LDL^T kernel (mikrige.hip::dispatch_mw_chol): {8,4} .. {8,13} on one wavefront,
+    {16,7} .. {16,14} on 256 threads, {32,8} on 1024 -- the classes whose register allocation round 3 pinned (launch bounds, lean
+    update) among them -- against the oracle's cKDTree + dense solve of the same windows (ok.py:929-986)."""
+    import pykrige_amd as pa
+
+    rng = np.random.default_rng(1000 + k)
+    n = 320
+    c = rng.random((n, 2))
+    v = np.sin(5 * c[:, 0]) + np.cos(3 * c[:, 1]) + 0.1 * rng.standard_normal(n)
+    pts = rng.random((48, 2))
+    pts[:4] = c[:4]  # exact hits
+    model, user = ("spherical", [1.0, 0.7, 0.05]) if k % 8 else ("exponential", [1.0, 0.5, 0.02])
+    st = ko.KrigingState(ndim=2, coords_orig=c, values=v, model=model, params=ko.internal_parameters(model, user), scaling=[1.0], angle=[0.0])
+    zr, sr = ko.solve_points_moving_window(st, ko.adjust_for_anisotropy(pts.copy(), st.center, st.scaling, st.angle), k)
+    m = pa.OrdinaryKriging(c[:, 0], c[:, 1], v, variogram_model=model, variogram_parameters=user)
+    z, ss = m.execute("points", pts[:, 0], pts[:, 1], backend="loop", n_closest_points=k)
+    np.testing.assert_allclose(z, zr, rtol=0, atol=Z_TOL)
+    np.testing.assert_allclose(ss, sr, rtol=0, atol=SS_TOL)
+
+
 def test_moving_window_many_stations_without_the_full_matrix():
     """300 000 stations: the reference's moving window would first build a 720 GB kriging matrix (ok.py:975); here the
     neighbour search runs on the cell grid and each point's system comes from coordinates.  Checked on 256 points against
