@@ -67,7 +67,8 @@ typedef struct mik_problem {
   const double *wells;      /* n_wells x 3 row-major: adjusted x, adjusted y, strength */
   const double *extra_cols; /* n_extra x n row-major: those drift terms evaluated at the stations */
   const double *a_inv;      /* optional (M x M, M = n + ndrift + 1): an inverse supplied by the caller, used as is;
-                               NULL = invert on device */
+                               NULL = invert on device.  It is the inverse of a symmetric matrix: the symmetric
+                               contraction (option "symmetric", default) reads its upper triangle only */
   int32_t geographic;       /* coordinates_type == 'geographic' (ordinary 2D only): xs/ys and px/py are lon/lat in
                                degrees, distances are great-circle degrees (core.py:36-97; ok.py:634-640, 990-996) */
   int32_t pseudo_inv;       /* self.pseudo_inv: 0 = inverse; 1 = 'pinv', 2 = 'pinvh' (core.py:33 P_INV): Moore-Penrose
