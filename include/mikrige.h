@@ -165,6 +165,8 @@ int  mik_slab_of(int64_t n, int members, int i, int64_t *lo, int64_t *count); /*
  *   blocks (higher L2 hit rate, measured 2.7 % slower: the kernel is not traffic-bound) ;
  * "tri" 0/1 = symmetric contraction (8-wave form): the diagonal block of a tile is contracted as a triangle of 16-row groups,
  *   36 of its 64 (row group, K tile) products (default 1: -1.5 % contraction time, partials equal to 1e-14) [MIK_TRI] ;
+ * "prefetch" 0/1 = symmetric contraction with "tri": a block pops its next tile before the epilogue of the current one and sends
+ *   that tile's first K tile to LDS meanwhile (same partial sums; measured a tie, default 0) [MIK_PREFETCH] ;
  * "symmetrize" 0/1 = after a full sweep, the pivoted elimination or a pseudo-inverse: A_inv <- (A_inv + A_inv^T) / 2 (default 1).
  *   The symmetric contraction reads one triangle of A_inv; a quadratic form sees only the symmetric part, so with the average
  *   in both triangles the half product equals b^T A_inv b of the matrix as eliminated (the half sweep mirrors its triangle

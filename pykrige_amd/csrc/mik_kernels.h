@@ -555,7 +555,9 @@ typedef __attribute__((address_space(3))) void* mik_lptr_t;
 template <int NAI, int ABL = 0, int BM = MIK_BM, bool TRI = false>
 __device__ __forceinline__ void gemm_core(const double* __restrict__ Ag, long lda, const double* __restrict__ Bg,
                                           long ldb, int kbeg, int kend, d4 (&acc)[NAI][4], GemmSmemT<BM>& sm,
-                                          int kscale = -1, int ktri = 0) {
+                                          int kscale = -1, int ktri = 0, bool prestaged = false) {
+  // prestaged (k_contract PRE): the first K tile (kend - 16) has already been sent to LDS buffer 1 by gemm_prefetch_first()
+  // while the block was in the previous tile's epilogue; the loop starts there instead of staging it now
   if (kbeg >= kend) return;  // block-uniform
   constexpr int WROWS = 16 * NAI;            // rows of the wave tile
   constexpr int NTHR = 64 * 2 * (BM / WROWS);
@@ -636,10 +638,11 @@ __device__ __forceinline__ void gemm_core(const double* __restrict__ Ag, long ld
   }
   // K runs DOWNWARDS (kend-16, kend-32, .. kbeg): in the symmetric contraction every tile then starts at
   // the same k = kend, so the tiles of a supertile stream the same operand panels in near lockstep (L2 reuse).
-  stage(kend - MIK_BK, 0);
+  int buf = 0;
+  if (prestaged) buf = 1;  // block-uniform
+  else stage(kend - MIK_BK, 0);
   drain();
   __syncthreads();
-  int buf = 0;
   const int kmain = TRI ? (ktri + 128 > kbeg ? ktri + 128 : kbeg) : kbeg;  // TRI: the diagonal block has a loop of its own
   for (int k = kend - MIK_BK; k >= kmain; k -= MIK_BK) {
     if (k > kbeg && !(ABL & 1)) stage((ABL & 8) ? 0 : k - MIK_BK, buf ^ 1);
@@ -734,6 +737,35 @@ __device__ __forceinline__ void gemm_core(const double* __restrict__ Ag, long ld
       __syncthreads();
       buf ^= 1;
     }
+  }
+}
+
+// The first K tile (k = kend - 16) of a 128 x 128 tile into LDS buffer 1, asynchronously: gemm_core's own staging (same thread ->
+// (row, slot) map, swizzles and LDS-DMA form, BM = 128), issued by a block that is about to run its previous tile's epilogue --
+// that tile's K loop has ended with a barrier, the epilogue reduces through buffer 0.  Nothing is waited for here: the next
+// gemm_core call (prestaged = true) drains and synchronises before it reads the buffer.
+template <int NAI>
+__device__ __forceinline__ void gemm_prefetch_first(const double* __restrict__ Ag, long lda, const double* __restrict__ Bg, long ldb,
+                                                    int k, GemmSmem& sm) {
+  constexpr int WROWS = 16 * NAI, NTHR = 64 * 2 * (MIK_BM / WROWS), PROWS = NTHR / 8, NPASS = MIK_BM / PROWS;
+  const int tid = threadIdx.x, wave = tid >> 6, lrow = tid >> 3, slot = tid & 7;
+  const unsigned ldsA = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)&sm.As[1][wave * 8][0]);
+  const unsigned ldsB = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)&sm.Bs[1][wave * 8][0]);
+  constexpr unsigned LDS_PASS = PROWS * MIK_BK * 8;
+  auto uniform_ptr = [](const double* q) {
+    const unsigned long long v = (unsigned long long)(uintptr_t)q;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<const double*>((uintptr_t)(((unsigned long long)hi << 32) | lo));
+  };
+  const double* abase = uniform_ptr(Ag + k);
+  const double* bbase = uniform_ptr(Bg + k);
+#pragma unroll
+  for (int p = 0; p < NPASS; ++p) {
+    const unsigned ao = (unsigned)(((long)(lrow + PROWS * p) * lda + ((slot ^ (lrow & 2)) << 1)) * 8);
+    const unsigned bo = (unsigned)(((long)(lrow + PROWS * p) * ldb + ((slot ^ ((lrow >> 1) & 7)) << 1)) * 8);
+    const unsigned la = ldsA + p * LDS_PASS, lb = ldsB + p * LDS_PASS;
+    asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" MIK_CP_A ::"v"(ao), "s"(abase), "s"(la) : "memory");
+    asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" MIK_CP_B ::"v"(bo), "s"(bbase), "s"(lb) : "memory");
   }
 }
 
@@ -841,7 +873,10 @@ __device__ __forceinline__ bool super_tile(int nIblk, int nTblk, int& iblk, int&
 // PAIR (symmetric + persistent only): the queue hands out pairs of row blocks of equal total length (pair_unit_at).
 // TRI (symmetric form only): the diagonal block is contracted as a triangle of 16-row groups (gemm_core), 36 instead of 64
 // group products per diagonal block.
-template <bool SYM, int NAI, bool PERSIST = true, bool PAIR = false, bool TRI = false>
+// PRE (persistent, single tiles): the block pops its NEXT tile before the epilogue of the current one and sends that tile's first
+// K tile to LDS (gemm_prefetch_first) -- the queue pop and the first operand fetch of a tile, ~3 us during which the block issued
+// nothing, now run under the epilogue's own memory latency.
+template <bool SYM, int NAI, bool PERSIST = true, bool PAIR = false, bool TRI = false, bool PRE = false>
 __global__ void __launch_bounds__(64 * 2 * (8 / NAI), 2 * (4 / NAI))
 k_contract(const double* __restrict__ Ainv, long lda, const double* __restrict__ Bt, long ldb,
            double* __restrict__ part, int palloc, int nIblk, int kend, unsigned long long* __restrict__ queue) {
@@ -855,95 +890,126 @@ k_contract(const double* __restrict__ Ainv, long lda, const double* __restrict__
   int steal = 0;  // 0 = own XCD's sequence; then the other seven in turn: every tile is done whatever the placement
   static_assert(!PAIR || (SYM && PERSIST), "pair units exist for the symmetric persistent form");
   static_assert(!TRI || SYM, "the triangular diagonal block belongs to the symmetric form");
-  for (;;) {
-  int iblk, tblk, pair_p = 0;
-  if (PERSIST) {
-    const int xq = (xcd + steal) & 7;
-    if (threadIdx.x == 0)
-      sm.next = (long)__hip_atomic_fetch_add(&queue[xq], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    const long seq = sm.next;
-    const int kind = PAIR ? pair_unit_at(nIblk, palloc / MIK_BN, xq, seq, pair_p, tblk)
-                          : super_tile_at(nIblk, palloc / MIK_BN, xq, seq, iblk, tblk);
-    __syncthreads();  // everyone has read sm.next (and the previous tile's `red`) before anything is overwritten
-    if (kind == 2) {  // this sequence is exhausted: help the next XCD's (correctness never depends on XCC_ID)
-      if (++steal == 8) return;
-      continue;
-    }
-    if (kind == 1) continue;
-  } else if (!super_tile(nIblk, palloc / MIK_BN, iblk, tblk)) {
-    return;
-  }
-  for (int half = 0; half < (PAIR ? 2 : 1); ++half) {  // PAIR: the long tile of the pair, then the short one
-  if (PAIR) {
-    iblk = half == 0 ? pair_p : nIblk - 1 - pair_p;
-    if (half == 1) {
-      if (iblk == pair_p) break;  // odd nIblk: the middle row block has no partner
-      __syncthreads();            // the first tile's `red` has been read before the staging LDS is filled again
-    }
-  }
-  const int i0 = iblk * MIK_BM, t0 = tblk * MIK_BN;
-  const double* Ag = Ainv + (long)i0 * lda;
-  const double* Bg = Bt + (long)t0 * ldb;
-  d4 acc[NAI][4];
+  static_assert(!PRE || (PERSIST && !PAIR), "the prefetch belongs to the persistent single-tile form");
+  // one tile's K loop into acc
+  auto contract_tile = [&](int iblk, int tblk, d4 (&acc)[NAI][4], bool prestaged) {
+    const int i0 = iblk * MIK_BM, t0 = tblk * MIK_BN;
+    const double* Ag = Ainv + (long)i0 * lda;
+    const double* Bg = Bt + (long)t0 * ldb;
 #pragma unroll
-  for (int x = 0; x < NAI; ++x)
+    for (int x = 0; x < NAI; ++x)
 #pragma unroll
-    for (int y = 0; y < 4; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
-  if (SYM) {  // result = diag + 2 * offdiag: one K loop downwards from kend; the off-diagonal part is doubled
-              // when the loop enters the diagonal block (k < i0 + 128), which is contracted last
-    const int kd = (i0 + MIK_BM) < kend ? (i0 + MIK_BM) : kend;
-    if (TRI) gemm_core<NAI, 0, MIK_BM, true>(Ag, lda, Bg, ldb, i0, kend, acc, sm, -1, i0);  // (a short last block: groups
-                                                                                             // beyond kend hold padding rows, b = 0)
-    else gemm_core<NAI>(Ag, lda, Bg, ldb, i0, kend, acc, sm, kd - MIK_BK);
-  } else {
-    gemm_core<NAI>(Ag, lda, Bg, ldb, 0, kend, acc, sm);
-  }
+      for (int y = 0; y < 4; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
+    if (SYM) {  // result = diag + 2 * offdiag: one K loop downwards from kend; the off-diagonal part is doubled
+                // when the loop enters the diagonal block (k < i0 + 128), which is contracted last
+      const int kd = (i0 + MIK_BM) < kend ? (i0 + MIK_BM) : kend;
+      if (TRI) gemm_core<NAI, 0, MIK_BM, true>(Ag, lda, Bg, ldb, i0, kend, acc, sm, -1, i0, prestaged);  // (a short last block: groups
+                                                                                                          // beyond kend hold padding rows, b = 0)
+      else gemm_core<NAI>(Ag, lda, Bg, ldb, i0, kend, acc, sm, kd - MIK_BK, 0, prestaged);
+    } else {
+      gemm_core<NAI>(Ag, lda, Bg, ldb, 0, kend, acc, sm, -1, 0, prestaged);
+    }
+  };
   // epilogue: column sums of B .* W over this wave's rows; independent loads issued in batches
   // (the fragment registers are dead here); without the scheduling barriers hipcc serialises
   // load -> wait -> fma once per element (~1 us each)
-  double cs[4];
+  auto epilogue = [&](int iblk, int tblk, d4 (&acc)[NAI][4]) {
+    const int i0 = iblk * MIK_BM, t0 = tblk * MIK_BN;
+    double cs[4];
 #pragma unroll
-  for (int bp = 0; bp < 2; ++bp) {
-    double bv[2][4 * NAI];
+    for (int bp = 0; bp < 2; ++bp) {
+      double bv[2][4 * NAI];
 #pragma unroll
-    for (int b2 = 0; b2 < 2; ++b2) {
-      const long t = t0 + wn * 64 + (2 * bp + b2) * 16 + lc;
-      const double* brow = Bt + t * ldb + i0 + wm * WROWS + lq;
+      for (int b2 = 0; b2 < 2; ++b2) {
+        const long t = t0 + wn * 64 + (2 * bp + b2) * 16 + lc;
+        const double* brow = Bt + t * ldb + i0 + wm * WROWS + lq;
 #pragma unroll
-      for (int ai = 0; ai < NAI; ++ai)
+        for (int ai = 0; ai < NAI; ++ai)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) bv[b2][ai * 4 + r] = brow[ai * 16 + 4 * r];
+          for (int r = 0; r < 4; ++r) bv[b2][ai * 4 + r] = brow[ai * 16 + 4 * r];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int b2 = 0; b2 < 2; ++b2) {
+        const int bi = 2 * bp + b2;
+        double s = 0.0;
+#pragma unroll
+        for (int ai = 0; ai < NAI; ++ai)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s += bv[b2][ai * 4 + r] * acc[ai][bi][r];
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        cs[bi] = s;
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    __builtin_amdgcn_sched_barrier(0);
+    double* red = &sm.As[0][0][0];  // gemm_core ended with a barrier: staging LDS is free (PRE: buffer 1 is being filled)
+    if (lq == 0) {
 #pragma unroll
-    for (int b2 = 0; b2 < 2; ++b2) {
-      const int bi = 2 * bp + b2;
-      double s = 0.0;
-#pragma unroll
-      for (int ai = 0; ai < NAI; ++ai)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) s += bv[b2][ai * 4 + r] * acc[ai][bi][r];
-      s += __shfl_xor(s, 16);
-      s += __shfl_xor(s, 32);
-      cs[bi] = s;
+      for (int bi = 0; bi < 4; ++bi) red[wm * 128 + wn * 64 + bi * 16 + lc] = cs[bi];
     }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  double* red = &sm.As[0][0][0];  // gemm_core ended with a barrier: staging LDS is free
-  if (lq == 0) {
+    __syncthreads();
+    if (threadIdx.x < 128) {
+      double v = 0.0;
 #pragma unroll
-    for (int bi = 0; bi < 4; ++bi) red[wm * 128 + wn * 64 + bi * 16 + lc] = cs[bi];
+      for (int w = 0; w < NWM; ++w) v += red[w * 128 + threadIdx.x];
+      part[(long)iblk * palloc + t0 + threadIdx.x] = v;
+    }
+  };
+  // next position of the tile queues: false when all eight sequences are exhausted
+  auto pop = [&](int& iblk, int& tblk, int& pair_p) -> bool {
+    for (;;) {
+      const int xq = (xcd + steal) & 7;
+      if (threadIdx.x == 0)
+        sm.next = (long)__hip_atomic_fetch_add(&queue[xq], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      const long seq = sm.next;
+      const int kind = PAIR ? pair_unit_at(nIblk, palloc / MIK_BN, xq, seq, pair_p, tblk)
+                            : super_tile_at(nIblk, palloc / MIK_BN, xq, seq, iblk, tblk);
+      __syncthreads();  // everyone has read sm.next (and the previous tile's `red`) before anything is overwritten
+      if (kind == 2) {  // this sequence is exhausted: help the next XCD's (correctness never depends on XCC_ID)
+        if (++steal == 8) return false;
+        continue;
+      }
+      if (kind == 1) continue;
+      return true;
+    }
+  };
+  if (PRE) {
+    int iblk = 0, tblk = 0, dummy = 0;
+    bool have = pop(iblk, tblk, dummy), pre = false;
+    while (have) {
+      d4 acc[NAI][4];
+      contract_tile(iblk, tblk, acc, pre);
+      int ni = 0, nt = 0;
+      const bool more = pop(ni, nt, dummy);  // (its barriers also order this tile's K loop before the prefetch's LDS writes)
+      if (more)
+        gemm_prefetch_first<NAI>(Ainv + (long)ni * MIK_BM * lda, lda, Bt + (long)nt * MIK_BN * ldb, ldb, kend - MIK_BK, sm);
+      epilogue(iblk, tblk, acc);
+      iblk = ni, tblk = nt, have = more, pre = more;
+    }
+    return;
   }
-  __syncthreads();
-  if (threadIdx.x < 128) {
-    double v = 0.0;
-#pragma unroll
-    for (int w = 0; w < NWM; ++w) v += red[w * 128 + threadIdx.x];
-    part[(long)iblk * palloc + t0 + threadIdx.x] = v;
-  }
-  }  // half
-  if (!PERSIST) return;
+  for (;;) {
+    int iblk = 0, tblk = 0, pair_p = 0;
+    if (PERSIST) {
+      if (!pop(iblk, tblk, pair_p)) return;
+    } else if (!super_tile(nIblk, palloc / MIK_BN, iblk, tblk)) {
+      return;
+    }
+    for (int half = 0; half < (PAIR ? 2 : 1); ++half) {  // PAIR: the long tile of the pair, then the short one
+      if (PAIR) {
+        iblk = half == 0 ? pair_p : nIblk - 1 - pair_p;
+        if (half == 1) {
+          if (iblk == pair_p) break;  // odd nIblk: the middle row block has no partner
+          __syncthreads();            // the first tile's `red` has been read before the staging LDS is filled again
+        }
+      }
+      d4 acc[NAI][4];
+      contract_tile(iblk, tblk, acc, false);
+      epilogue(iblk, tblk, acc);
+    }
+    if (!PERSIST) return;
   }  // for (;;): next tile of this XCD's sequence
 }
 

@@ -328,6 +328,9 @@ struct mik_handle {
   // symmetric contraction (8-wave form): the diagonal block of a tile is contracted as a triangle of 16-row groups -- 36 of
   // its 64 (group, K tile) products (round 3; gemm_core TRI).  0 = the whole diagonal block.
   int opt_tri = 1;
+  // symmetric contraction with triangular diagonal blocks: the next tile is popped, and its first K tile sent to LDS, before the
+  // epilogue of the current one (k_contract PRE)
+  int opt_prefetch = 0;
   int opt_symmetrize = 1;  // T <- (T + T^T) / 2 after a full sweep / the pivoted elimination (k_symmetrize); 0 = as eliminated
   int opt_factor = 0, opt_sym = 1, opt_engine = 0;  // engine: 0 = v_mfma_f64 contraction, 1 = v_fma_f64 (VALU) contraction
   long opt_chunk = 131072;
@@ -710,6 +713,8 @@ static int create_one_body(mik_handle* h, int device) {
   if (env) h->opt_panel_stream = atoi(env) < 0 ? -1 : atoi(env) ? 1 : 0;
   env = getenv("MIK_TRI");
   if (env) h->opt_tri = atoi(env) ? 1 : 0;
+  env = getenv("MIK_PREFETCH");
+  if (env) h->opt_prefetch = atoi(env) ? 1 : 0;
   env = getenv("MIK_EXCHANGE");
   if (env) h->opt_exchange = !strcmp(env, "rccl") ? 1 : !strcmp(env, "peer") ? 2 : !strcmp(env, "redundant") ? 3 : 0;
   env = getenv("MIK_ALIAS_DEVICES");
@@ -830,7 +835,7 @@ static int set_group(mik_handle* h, int n) {
     k->is_kid = true;
     k->opt_factor = h->opt_factor, k->opt_sym = h->opt_sym, k->opt_engine = h->opt_engine, k->opt_waves = h->opt_waves;
     k->opt_chunk = h->opt_chunk, k->opt_symsweep = h->opt_symsweep, k->opt_diag = h->opt_diag, k->opt_update_waves = h->opt_update_waves, k->opt_panel_rows = h->opt_panel_rows, k->opt_panel_stream = h->opt_panel_stream, k->opt_update_map = h->opt_update_map, k->opt_update_atomic = h->opt_update_atomic, k->opt_lookahead = h->opt_lookahead, k->opt_gate = h->opt_gate, k->opt_fuse_chain = h->opt_fuse_chain, k->opt_early_diag = h->opt_early_diag, k->opt_pinv_fast = h->opt_pinv_fast, k->opt_rhs_overlap = h->opt_rhs_overlap, k->opt_verify = h->opt_verify, k->verify_tol_z = h->verify_tol_z, k->verify_tol_inv = h->verify_tol_inv;
-    k->opt_mw_class = h->opt_mw_class, k->opt_mw_knn_bound = h->opt_mw_knn_bound, k->opt_mw_pivot = h->opt_mw_pivot, k->opt_mw_lds_cap = h->opt_mw_lds_cap, k->opt_pairs = h->opt_pairs, k->opt_tri = h->opt_tri, k->opt_symmetrize = h->opt_symmetrize, k->opt_mw_solver = h->opt_mw_solver;
+    k->opt_mw_class = h->opt_mw_class, k->opt_mw_knn_bound = h->opt_mw_knn_bound, k->opt_mw_pivot = h->opt_mw_pivot, k->opt_mw_lds_cap = h->opt_mw_lds_cap, k->opt_pairs = h->opt_pairs, k->opt_tri = h->opt_tri, k->opt_prefetch = h->opt_prefetch, k->opt_symmetrize = h->opt_symmetrize, k->opt_mw_solver = h->opt_mw_solver;
     k->custom_fn = h->custom_fn, k->custom_user = h->custom_user;
     h->kids.push_back(k);
   }
@@ -915,6 +920,8 @@ int mik_set_option(mik_handle* h, const char* key, double value) {
     h->opt_pairs = value != 0.0;
   } else if (!strcmp(key, "tri")) {
     h->opt_tri = value != 0.0;
+  } else if (!strcmp(key, "prefetch")) {
+    h->opt_prefetch = value != 0.0;
   } else if (!strcmp(key, "symmetrize")) {
     h->opt_symmetrize = value != 0.0;
   } else if (!strcmp(key, "waves")) {
@@ -2957,7 +2964,8 @@ static int one_predict(mik_handle* h) {
         if (h->opt_waves == 8 && h->opt_sym && h->opt_pairs) {
           hipLaunchKernelGGL((k_contract<true, 2, true, true>), dim3(pgrid), dim3(512), 0, sc, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend, qp);
         } else if (h->opt_waves == 8) {
-          if (h->opt_sym && h->opt_tri) hipLaunchKernelGGL((k_contract<true, 2, true, false, true>), dim3(pgrid), dim3(512), 0, sc, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend, qp);
+          if (h->opt_sym && h->opt_tri && h->opt_prefetch) hipLaunchKernelGGL((k_contract<true, 2, true, false, true, true>), dim3(pgrid), dim3(512), 0, sc, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend, qp);
+          else if (h->opt_sym && h->opt_tri) hipLaunchKernelGGL((k_contract<true, 2, true, false, true>), dim3(pgrid), dim3(512), 0, sc, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend, qp);
           else if (h->opt_sym) hipLaunchKernelGGL((k_contract<true, 2>), dim3(pgrid), dim3(512), 0, sc, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend, qp);
           else hipLaunchKernelGGL((k_contract<false, 2>), dim3(pgrid), dim3(512), 0, sc, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend, qp);
         } else {
