@@ -80,7 +80,7 @@ typedef struct mik_problem {
 /* The prediction points handed to _exec_vector: adjusted coordinates (SoA), mask, drift rows. */
 typedef struct mik_points {
   int64_t npt;
-  const double *px, *py, *pz; /* anisotropy-ADJUSTED point coordinates; pz NULL if ndim==2 */
+  const double *px, *py, *pz; /* anisotropy-ADJUSTED point coordinates (or raw ones followed by mik_adjust_points); pz NULL if ndim==2 */
   const int8_t *mask;         /* nullable; nonzero = skip the point (outputs stay 0.0, cok.pyx:25-26,57-58) */
   const double *extra_rows;   /* n_extra x npt row-major: host-evaluated drift terms at the points; nullable if n_extra==0 */
 } mik_points;
@@ -247,6 +247,13 @@ int  mik_set_points(mik_handle *h, const mik_points *g);   /* H2D of the (unmask
 int  mik_set_grid(mik_handle *h, const mik_grid *g);       /* the same for a grid given by its axes: H2D of the axes (and
                                                               the compacted cell indices of a mask), points generated and
                                                               anisotropy-adjusted on the device */
+int  mik_adjust_points(mik_handle *h, const double center[3], const double rot[9], const double stretch[3]);
+                                                           /* style='points' (round 3): mik_set_points was handed the RAW
+                                                              coordinates; apply the anisotropy adjustment (core.py:120-193
+                                                              _adjust_for_anisotropy, what execute() does on the host at
+                                                              ok.py:879-885) to them in place on the device -- same
+                                                              arithmetic and argument meaning as mik_grid's center / rot /
+                                                              stretch.  Not for points generated by mik_set_grid */
 int  mik_predict(mik_handle *h);                           /* K3 over the resident points; results stay in HBM */
 int  mik_get_results(mik_handle *h, double *z_out, double *ss_out); /* D2H, scattered through the mask  */
 int  mik_take_results(mik_handle *h, double **z, double **ss); /* the same without the last copy: *z and *ss point INTO the

@@ -80,6 +80,7 @@ SIGNATURES = {
     "mik_factor": (C.c_int, [C.c_void_p]),
     "mik_set_points": (C.c_int, [C.c_void_p, C.POINTER(MikPoints)]),
     "mik_set_grid": (C.c_int, [C.c_void_p, C.POINTER(MikGrid)]),
+    "mik_adjust_points": (C.c_int, [C.c_void_p, _dp, _dp, _dp]),
     "mik_predict": (C.c_int, [C.c_void_p]),
     "mik_get_results": (C.c_int, [C.c_void_p, _dp, _dp]),
     "mik_take_results": (C.c_int, [C.c_void_p, C.POINTER(_dp), C.POINTER(_dp)]),
@@ -272,6 +273,16 @@ class Handle:
         g.extra_rows = _ptr(er)
         self._npt = px.size
         check(self._lib.mik_set_points(self._h, C.byref(g)))
+
+    def adjust_points(self, center, rot, stretch):
+        """Anisotropy adjustment of the points set_points uploaded raw, in place on the device (mik_adjust_points)."""
+        c = np.zeros(3)
+        c[:len(center)] = np.asarray(center, dtype=np.float64)
+        r = np.zeros(9)
+        r[:np.size(rot)] = np.asarray(rot, dtype=np.float64).ravel()
+        st = np.ones(3)
+        st[:len(stretch)] = np.asarray(stretch, dtype=np.float64)
+        check(self._lib.mik_adjust_points(self._h, _ptr(c), _ptr(r), _ptr(st)))
 
     def set_grid(self, axes, center=None, rot=None, stretch=None, mask=None, extra_rows=None, cell_range=None):
         """The prediction points of style='grid' / 'masked' from their axes (mik_set_grid): meshgrid order and anisotropy

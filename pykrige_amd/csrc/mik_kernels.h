@@ -240,19 +240,27 @@ struct GridArgs {
   int ndim, adjust;
   double c[3], rot[9], st[3];  // centre, rotation (row-major d x d), diagonal of the stretch matrix
   double *px, *py, *pz;
+  int from_points;  // 1 = the raw coordinates are already in px / py / pz (mik_adjust_points): transform them in place
 };
 
 __global__ void __launch_bounds__(256) k_grid_points(GridArgs a) {
   const long t = (long)blockIdx.x * 256 + threadIdx.x;
   if (t >= a.n) return;
-  const long cell = a.cell0 + (a.idx ? (long)a.idx[t] : t);
-  const long ix = cell % a.nx, r = cell / a.nx;
-  double x = a.gx[ix], y, z = 0.0;
-  if (a.ndim == 3) {
-    y = a.gy[r % a.ny];
-    z = a.gz[r / a.ny];
+  double x, y, z = 0.0;
+  if (a.from_points) {
+    x = a.px[t];
+    y = a.py[t];
+    if (a.ndim == 3) z = a.pz[t];
   } else {
-    y = a.gy[r];
+    const long cell = a.cell0 + (a.idx ? (long)a.idx[t] : t);
+    const long ix = cell % a.nx, r = cell / a.nx;
+    x = a.gx[ix];
+    if (a.ndim == 3) {
+      y = a.gy[r % a.ny];
+      z = a.gz[r / a.ny];
+    } else {
+      y = a.gy[r];
+    }
   }
   if (a.adjust) {
     // __dmul_rn / __dadd_rn: never contracted into FMAs (hipcc contracts a * b + c by default); only the accumulation of

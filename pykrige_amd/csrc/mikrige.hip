@@ -285,6 +285,7 @@ struct mik_handle {
   double verify_tol_z = 5e-10, verify_tol_inv = 1e-8;  // calibrated: profiles/r03_inverse_probe_calibration.txt (true |dz| <= 9 res_z, |dss| <= 50 res_inv over 481 runs)
   bool no_half_sweep = false;  // transient: this attempt must not use the half sweep
   bool last_half_sweep = false;
+  bool points_from_grid = false;  // the resident points were generated by mik_set_grid (mik_adjust_points refuses them)
   DevBuf Averify, vbuf;
   std::vector<double> hvals;   // host copy of the station values (the probe compares A c with them)
   int opt_fuse_chain = 1;  // look-ahead sweep: the column update writes the next panel copy too (no copy kernel on the chain)
@@ -2638,6 +2639,7 @@ static int one_set_points(mik_handle* h, const mik_points* g, const long* idx, l
   MIKC(h->pin_out.ensure(sizeof(double) * 2 * (size_t)cap));
   HIPC(hipStreamSynchronize(h->stream));
   h->have_points = true;
+  h->points_from_grid = false;
   h->have_results = false;
   return MIK_OK;
 }
@@ -2750,6 +2752,7 @@ static int one_set_grid(mik_handle* h, bool leader, const mik_grid* g, const uns
   MIKC(h->pin_out.ensure(sizeof(double) * 2 * (size_t)cap));
   HIPC(hipStreamSynchronize(h->stream));
   h->have_points = true;
+  h->points_from_grid = true;
   h->have_results = false;
   return MIK_OK;
 }
@@ -2811,6 +2814,26 @@ int mik_set_grid(mik_handle* h, const mik_grid* g) {
     long lo, cnt;
     slab_of(n, members, i, &lo, &cnt);
     return one_set_grid(d, i == 0, g, ip, lo, cnt, first, ncells);
+  });
+}
+
+// style='points': the anisotropy adjustment (core.py:120-193) of coordinates mik_set_points uploaded RAW, in place on every member's
+// slab -- k_grid_points' arithmetic (the reference's order, dot products accumulated like np.dot) without the meshgrid
+int mik_adjust_points(mik_handle* h, const double center[3], const double rot[9], const double stretch[3]) {
+  if (!h || !center || !rot || !stretch) return fail(MIK_EINVAL, "mik_adjust_points: NULL argument");
+  if (!h->have_points || h->points_from_grid) return fail(MIK_ESTATE, "mik_adjust_points: set the points with mik_set_points first");
+  return for_each_device(h, [&](int, mik_handle* m) -> int {
+    HIPC(hipSetDevice(m->device));
+    if (m->npt == 0) return MIK_OK;
+    GridArgs a{};
+    a.from_points = 1, a.adjust = 1, a.ndim = m->ndim, a.n = m->npt;
+    for (int i = 0; i < 3; ++i) a.c[i] = center[i], a.st[i] = stretch[i];
+    for (int i = 0; i < 9; ++i) a.rot[i] = rot[i];
+    a.px = m->px.as<double>(), a.py = m->py.as<double>(), a.pz = m->ndim == 3 ? m->pz.as<double>() : nullptr;
+    hipLaunchKernelGGL(k_grid_points, dim3((unsigned)((m->npt + 255) / 256)), dim3(256), 0, m->stream, a);
+    HIPC(hipGetLastError());
+    HIPC(hipStreamSynchronize(m->stream));
+    return MIK_OK;
   });
 }
 

@@ -27,11 +27,12 @@ class _Pts:
     need the adjusted coordinates on the host), or a grid described by its axes and generated on the device (mik_set_grid:
     the meshgrid and the anisotropy adjustment of ok.py:863-885 never exist on the host)."""
 
-    __slots__ = ("arrays", "axes", "center", "rot", "stretch", "mask", "extra", "shape", "npt")
+    __slots__ = ("arrays", "axes", "center", "rot", "stretch", "mask", "extra", "shape", "npt", "raw")
 
-    def __init__(self, shape, mask, extra, arrays=None, axes=None, center=None, rot=None, stretch=None):
+    def __init__(self, shape, mask, extra, arrays=None, axes=None, center=None, rot=None, stretch=None, raw=False):
         self.shape, self.mask, self.extra = shape, mask, extra
         self.arrays, self.axes, self.center, self.rot, self.stretch = arrays, axes, center, rot, stretch
+        self.raw = raw  # `arrays` are the coordinates as given: the device applies center / rot / stretch (mik_adjust_points)
         self.npt = int(np.prod(shape))
 
     def load(self, h, ndim, cell_range=None, with_extra=True):
@@ -48,6 +49,8 @@ class _Pts:
             return
         a = self.arrays if cell_range is None else self.arrays[sl]
         h.set_points(a[:, 0], a[:, 1], a[:, 2] if ndim == 3 else None, mask=mask, extra_rows=extra)
+        if self.raw:
+            h.adjust_points(self.center, self.rot, self.stretch)
 
 
 class _KrigingBase:
@@ -259,8 +262,16 @@ class _KrigingBase:
         (functional drifts) or MIK_DEVICE_GRID=0 asks for the host meshgrid."""
         if (style not in ("grid", "masked") or _os.environ.get("MIK_DEVICE_GRID", "1") == "0"
                 or getattr(self, "functional_drift", False)):
-            pts_adj, shape, mask, extra = self._prepare_points(style, axes, mask, specified_drift_arrays, backend)
-            return _Pts(shape, mask, extra, arrays=pts_adj)
+            # coordinate arrays.  Round 3: they too are adjusted on the device (mik_adjust_points; the host only stacks them) unless
+            # a functional drift needs the adjusted coordinates here, the coordinates are geographic (no adjustment at all,
+            # ok.py:892-896) or MIK_DEVICE_POINTS=0 asks for the host adjustment
+            raw = (not getattr(self, "functional_drift", False) and getattr(self, "coordinates_type", "euclidean") != "geographic"
+                   and _os.environ.get("MIK_DEVICE_POINTS", "1") != "0")
+            pts, shape, mask, extra = self._prepare_points(style, axes, mask, specified_drift_arrays, backend, adjust=not raw)
+            if not raw:
+                return _Pts(shape, mask, extra, arrays=pts)
+            rot, stretch = core.anisotropy_matrices(self._ndim, self._scaling(), self._angle())
+            return _Pts(shape, mask, extra, arrays=pts, center=self._center(), rot=rot, stretch=stretch, raw=True)
         axes, shape, mask = self._grid_from(style, axes, mask)
         extra = self._grid_rows(style, axes, shape, mask, specified_drift_arrays, backend)
         if getattr(self, "coordinates_type", "euclidean") == "geographic":
@@ -271,10 +282,11 @@ class _KrigingBase:
     def _grid_rows(self, style, axes, shape, mask, specified_drift_arrays, backend):
         return None  # host-evaluated drift rows of a grid: universal kriging only
 
-    def _prepare_points(self, style, axes, mask, specified_drift_arrays=None, backend="vectorized"):
-        """Everything execute() does on the host before the solve: returns (pts_adj, shape, mask, extra_rows)."""
+    def _prepare_points(self, style, axes, mask, specified_drift_arrays=None, backend="vectorized", adjust=True):
+        """Everything execute() does on the host before the solve: returns (pts_adj, shape, mask, extra_rows); adjust=False
+        leaves the anisotropy adjustment of the coordinates to the device (mik_adjust_points)."""
         pts, shape, mask = self._points_from(style, axes, mask)
-        if getattr(self, "coordinates_type", "euclidean") == "geographic":
+        if getattr(self, "coordinates_type", "euclidean") == "geographic" or not adjust:
             return pts, shape, mask, None  # no anisotropy correction in spherical coordinates (ok.py:892-896)
         return core.adjust_for_anisotropy(pts, self._center(), self._scaling(), self._angle()), shape, mask, None
 
@@ -711,7 +723,7 @@ class UniversalKriging(OrdinaryKriging):
         rows.extend(self._spec_rows(style, shape, int(np.prod(shape)), specified_drift_arrays))
         return np.array(rows, dtype=np.float64) if rows else None
 
-    def _prepare_points(self, style, axes, mask, specified_drift_arrays=None, backend="vectorized"):
+    def _prepare_points(self, style, axes, mask, specified_drift_arrays=None, backend="vectorized", adjust=True):
         pts, shape, mask = self._points_from(style, axes, mask)
         rows = []
         if self.external_Z_drift:  # on ORIGINAL coordinates (uk.py:967-971)
@@ -725,6 +737,8 @@ class UniversalKriging(OrdinaryKriging):
             else:
                 rows.append(self._calculate_data_point_zscalars(pts[:, 0], pts[:, 1]))
         rows.extend(self._spec_rows(style, shape, pts.shape[0], specified_drift_arrays))
+        if not adjust:  # (never with functional drifts: _prepare) the device adjusts the coordinates
+            return pts, shape, mask, (np.array(rows, dtype=np.float64) if rows else None)
         pts_adj = core.adjust_for_anisotropy(pts, self._center(), self._scaling(), self._angle())
         if self.functional_drift:
             rows.extend(np.asarray(f(pts_adj[:, 0], pts_adj[:, 1]), dtype=np.float64) for f in self.functional_drift_terms)
@@ -875,9 +889,11 @@ class UniversalKriging3D(OrdinaryKriging3D):
         rows = self._spec_rows(style, shape, int(np.prod(shape)), specified_drift_arrays)
         return np.array(rows, dtype=np.float64) if rows else None
 
-    def _prepare_points(self, style, axes, mask, specified_drift_arrays=None, backend="vectorized"):
+    def _prepare_points(self, style, axes, mask, specified_drift_arrays=None, backend="vectorized", adjust=True):
         pts, shape, mask = self._points_from(style, axes, mask)
         rows = self._spec_rows(style, shape, pts.shape[0], specified_drift_arrays)
+        if not adjust:  # (never with functional drifts: _prepare) the device adjusts the coordinates
+            return pts, shape, mask, (np.array(rows, dtype=np.float64) if rows else None)
         pts_adj = core.adjust_for_anisotropy(pts, self._center(), self._scaling(), self._angle())
         if self.functional_drift:
             rows.extend(np.asarray(f(pts_adj[:, 0], pts_adj[:, 1], pts_adj[:, 2]), dtype=np.float64)

@@ -220,3 +220,77 @@ def test_results_without_the_last_copy_are_the_same_results():
     m[::3, ::2] = True
     zm, sm = ok2.execute("masked", g["gridx"], g["gridy"], mask=m, backend="loop")
     assert np.array_equal(np.ma.getdata(zm)[~m], keep_z[~m]) and np.all(np.ma.getdata(zm)[m] == 0.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["2d_iso", "2d_aniso", "3d_aniso"])
+def test_device_adjusted_points_equal_the_host_adjustment(case):
+    """mik_adjust_points (round 3): coordinates uploaded raw by mik_set_points and adjusted in place on the device are the ones
+    core.adjust_for_anisotropy (core.py:120-193) computes on the host -- to the last place of the coordinate scale, like the
+    device-generated grids; with a mask (compaction before the adjustment) and through a 3-member group as well."""
+    from pykrige_amd import _lib, core
+
+    rng = np.random.default_rng(11)
+    nd = 3 if case.startswith("3d") else 2
+    n = 5000
+    P = rng.random((n, nd)) * 9 - 2
+    center = list(rng.random(nd) * 4)
+    sc, an = {"2d_iso": ([1.0], [0.0]), "2d_aniso": ([0.37], [-123.4]), "3d_aniso": ([1.5, 2.0], [10.0, 20.0, 30.0])}[case]
+    want = core.adjust_for_anisotropy(P.copy(), center, sc, an)
+    rot, st = core.anisotropy_matrices(nd, sc, an)
+    c, v = fx.synth(1, 50, nd)
+    for members, mask in ((1, None), (1, rng.random(n) < 0.3), (3, None)):
+        h = _lib.Handle(0)
+        if members > 1:
+            h.set_devices(members, alias=True)
+        h.set_problem(ndim=nd, xs=c[0], ys=c[1], zs=c[2] if nd == 3 else None, values=v, model_id=4, params=[1.0, 0.3, 0.0])
+        h.set_points(P[:, 0], P[:, 1], P[:, 2] if nd == 3 else None, mask=mask)
+        h.adjust_points(center, rot, st)
+        got = h.get_points(nd)
+        ref = want if mask is None else want[~mask]
+        scale = np.spacing(np.abs(ref).max(axis=0))[None, :]
+        assert got.shape == ref.shape
+        assert (np.abs(got - ref) / scale).max() <= 2.0
+        if case == "2d_iso":
+            assert np.array_equal(got, ref)
+        h.close()
+    # a grid's points are generated adjusted: the call refuses them
+    h = _lib.Handle(0)
+    h.set_problem(ndim=nd, xs=c[0], ys=c[1], zs=c[2] if nd == 3 else None, values=v, model_id=4, params=[1.0, 0.3, 0.0])
+    h.set_grid([np.linspace(0, 1, 5)] * nd, center, rot, st)
+    with pytest.raises(Exception):
+        h.adjust_points(center, rot, st)
+    h.close()
+
+
+@pytest.mark.gpu
+def test_execute_points_is_the_same_with_device_and_host_adjustment(monkeypatch):
+    """style='points' (and every host-built point list): execute() with the coordinates adjusted on the device equals execute()
+    with MIK_DEVICE_POINTS=0 (host adjustment, as the reference does at ok.py:879-885) on anisotropic fixtures, 2-D and 3-D, UK
+    with specified drift arrays included."""
+    import pykrige_amd as pa
+
+    rng = np.random.default_rng(3)
+    n = 150
+    x, y, zc = rng.random(n) * 10, rng.random(n) * 6, rng.random(n) * 3
+    v = np.sin(x) + 0.3 * y + 0.1 * rng.standard_normal(n)
+    px, py, pz = rng.random(400) * 10, rng.random(400) * 6, rng.random(400) * 3
+    px[:5], py[:5], pz[:5] = x[:5], y[:5], zc[:5]  # exact hits must stay exact hits
+    models = [
+        (pa.OrdinaryKriging(x, y, v, variogram_model="exponential", variogram_parameters=[1.0, 4.0, 0.01], anisotropy_scaling=2.5,
+                            anisotropy_angle=33.0), (px, py), {}),
+        (pa.UniversalKriging(x, y, v, variogram_model="spherical", variogram_parameters=[1.0, 5.0, 0.0], anisotropy_scaling=0.6,
+                             anisotropy_angle=-71.0, drift_terms=["regional_linear", "specified"], specified_drift=[x * y]),
+         (px, py), {"specified_drift_arrays": [px * py]}),
+        (pa.OrdinaryKriging3D(x, y, zc, v, variogram_model="gaussian", variogram_parameters=[1.0, 3.0, 0.05], anisotropy_scaling_y=1.5,
+                              anisotropy_scaling_z=0.7, anisotropy_angle_x=10.0, anisotropy_angle_y=20.0, anisotropy_angle_z=30.0),
+         (px, py, pz), {}),
+    ]
+    for m, pts, kw in models:
+        monkeypatch.setenv("MIK_DEVICE_POINTS", "1")
+        z1, s1 = m.execute("points", *pts, **kw)
+        monkeypatch.setenv("MIK_DEVICE_POINTS", "0")
+        z0, s0 = m.execute("points", *pts, **kw)
+        np.testing.assert_allclose(np.ma.getdata(z1), np.ma.getdata(z0), rtol=0, atol=1e-11)
+        np.testing.assert_allclose(np.ma.getdata(s1), np.ma.getdata(s0), rtol=0, atol=1e-11)
+        assert np.abs(np.ma.getdata(s1)[:5]).max() <= 1e-9 or m.variogram_model_parameters[-1] > 0  # exact hits (zero nugget)
