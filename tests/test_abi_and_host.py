@@ -318,3 +318,52 @@ def test_anisotropy_adjustment_is_bit_identical_to_the_reference():
         X, c, s, a, Y = g["X" + d], list(g["c" + d]), list(g["s" + d]), list(g["a" + d]), g["Y" + d]
         assert np.array_equal(core.adjust_for_anisotropy(X.copy(), c, s, a), Y)
         assert np.array_equal(ko.adjust_for_anisotropy(X.copy(), c, s, a), Y)
+
+
+def test_point_lists_go_to_the_device_raw_unless_the_host_needs_them_adjusted(monkeypatch):
+    """Host routing of execute()'s point branch (no GPU): coordinate arrays are handed over RAW with the anisotropy matrices
+    (mik_adjust_points does what ok.py:879-885 does on the host) -- except with functional drifts (their callables take the adjusted
+    coordinates, uk.py:1290-1296), geographic coordinates (never adjusted, ok.py:892-896) and MIK_DEVICE_POINTS=0; the matrices
+    reproduce core.adjust_for_anisotropy entry for entry."""
+    import pykrige_amd as pa
+    from pykrige_amd import core
+
+    rng = np.random.default_rng(3)
+    n = 60
+    x, y, zc = rng.random(n) * 10, rng.random(n) * 6, rng.random(n) * 3
+    v = np.sin(x) + 0.3 * y
+    px, py, pz = rng.random(40) * 10, rng.random(40) * 6, rng.random(40) * 3
+    monkeypatch.delenv("MIK_DEVICE_POINTS", raising=False)
+    monkeypatch.delenv("MIK_DEVICE_GRID", raising=False)
+    ok = pa.OrdinaryKriging(x, y, v, variogram_model="exponential", variogram_parameters=[1.0, 4.0, 0.01], anisotropy_scaling=2.5,
+                            anisotropy_angle=33.0)
+    want = core.adjust_for_anisotropy(np.stack((px, py), 1), ok._center(), ok._scaling(), ok._angle())
+    P = ok._prepare("points", (px, py), None)
+    assert P.raw and np.array_equal(P.arrays, np.stack((px, py), 1))
+    Y = np.dot(np.diag(P.stretch), np.dot(P.rot, (P.arrays - np.asarray(P.center)[None, :]).T)).T + np.asarray(P.center)[None, :]
+    assert np.array_equal(Y, want)
+    monkeypatch.setenv("MIK_DEVICE_POINTS", "0")
+    P = ok._prepare("points", (px, py), None)
+    assert not P.raw and np.array_equal(P.arrays, want)
+    monkeypatch.delenv("MIK_DEVICE_POINTS")
+    uk = pa.UniversalKriging(x, y, v, variogram_model="spherical", variogram_parameters=[1.0, 5.0, 0.0], anisotropy_scaling=0.6,
+                             anisotropy_angle=-71.0, drift_terms=["regional_linear", "specified"], specified_drift=[x * y])
+    P = uk._prepare("points", (px, py), None, [px * py], "vectorized")
+    assert P.raw and P.extra.shape == (1, 40) and np.array_equal(P.extra[0], px * py)
+    uf = pa.UniversalKriging(x, y, v, variogram_model="spherical", variogram_parameters=[1.0, 5.0, 0.0], anisotropy_scaling=0.6,
+                             anisotropy_angle=-71.0, drift_terms=["functional"], functional_drift=[lambda a, b: a * b])
+    P = uf._prepare("points", (px, py), None, None, "vectorized")
+    adj = core.adjust_for_anisotropy(np.stack((px, py), 1), uf._center(), uf._scaling(), uf._angle())
+    assert not P.raw and np.array_equal(P.arrays, adj) and np.array_equal(P.extra[0], adj[:, 0] * adj[:, 1])
+    k3 = pa.OrdinaryKriging3D(x, y, zc, v, variogram_model="gaussian", variogram_parameters=[1.0, 3.0, 0.05], anisotropy_scaling_y=1.5,
+                              anisotropy_scaling_z=0.7, anisotropy_angle_x=10.0, anisotropy_angle_y=20.0, anisotropy_angle_z=30.0)
+    P = k3._prepare("points", (px, py, pz), None)
+    assert P.raw and P.arrays.shape == (40, 3) and np.asarray(P.rot).shape == (3, 3) and list(P.stretch) == [1.0, 1.5, 0.7]
+    geo = pa.OrdinaryKriging(x * 10, y * 10, v, variogram_model="linear", variogram_parameters=[1.0, 0.0], coordinates_type="geographic")
+    assert not geo._prepare("points", (px, py), None).raw
+    # a grid built on the host (MIK_DEVICE_GRID=0) is a point list like any other
+    monkeypatch.setenv("MIK_DEVICE_GRID", "0")
+    gx, gy = np.linspace(0, 10, 7), np.linspace(0, 6, 5)
+    mask = rng.random((5, 7)) < 0.3
+    P = ok._prepare("masked", (gx, gy), mask)
+    assert P.raw and P.arrays.shape == (35, 2) and P.mask.shape == (35,)
