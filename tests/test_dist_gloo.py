@@ -56,6 +56,12 @@ class OracleHandle:
         self.pts = np.stack([px, py] + ([pz] if pz is not None else []), 1)
         self.mask = mask
 
+    def adjust_points(self, center, rot, stretch):
+        """mik_adjust_points restated with NumPy: the anisotropy transform of coordinates set_points took raw."""
+        c = np.asarray(center, float)[None, :]
+        self.pts = (np.diag(stretch) @ (np.asarray(rot) @ (self.pts - c).T)).T + c
+        self.calls.append("adjust_points")
+
     def set_grid(self, axes, center=None, rot=None, stretch=None, mask=None, extra_rows=None, cell_range=None):
         """mik_set_grid restated with NumPy: the reference's flattened meshgrid, the anisotropy transform, a cell range."""
         if len(axes) == 2:
@@ -120,7 +126,18 @@ def _worker(rank, world, port, q):
         ok_grid = bool(np.allclose(z, zr, atol=1e-12) and np.allclose(ss, sr, atol=1e-12) and z.shape == (9, 13))
         ok_mask = bool(np.allclose(np.ma.getdata(zm)[~mask], zr[~mask], atol=1e-12) and np.all(np.ma.getdata(zm)[mask] == 0.0)
                        and isinstance(zm, np.ma.MaskedArray))
-        q.put((rank, ok_grid, ok_mask, len(hdl.pts), hdl.calls.count("factor")))
+        # style='points' on an anisotropic model: every rank uploads its slab RAW and the handle adjusts it (mik_adjust_points)
+        oka = pa.OrdinaryKriging(x, y, v, variogram_model="exponential", variogram_parameters=[1.0, 0.3, 0.01], anisotropy_scaling=2.0,
+                                 anisotropy_angle=30.0)
+        hda = OracleHandle()
+        exa = ShardedExecutor(oka, group=dist.group.WORLD, handle_factory=lambda: hda)
+        ppx, ppy = rng.random(37), rng.random(37)
+        zp, ssp = exa.execute("points", ppx, ppy, backend="loop")
+        sta = ko.KrigingState(ndim=2, coords_orig=np.stack([x, y], 1), values=v, model="exponential",
+                              params=ko.internal_parameters("exponential", [1.0, 0.3, 0.01]), scaling=[2.0], angle=[30.0])
+        zpr, spr = ko.execute(sta, "points", ppx, ppy)
+        ok_pts = bool(np.allclose(zp, zpr, atol=1e-12) and np.allclose(ssp, spr, atol=1e-12) and hda.calls.count("adjust_points") == 1)
+        q.put((rank, ok_grid, ok_mask and ok_pts, len(hdl.pts), hdl.calls.count("factor")))
     finally:
         dist.destroy_process_group()
 
