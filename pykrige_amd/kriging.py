@@ -285,7 +285,7 @@ class _KrigingBase:
     def _prepare_points(self, style, axes, mask, specified_drift_arrays=None, backend="vectorized", adjust=True):
         """Everything execute() does on the host before the solve: returns (pts_adj, shape, mask, extra_rows); adjust=False
         leaves the anisotropy adjustment of the coordinates to the device (mik_adjust_points)."""
-        pts, shape, mask = self._points_from(style, axes, mask)
+        pts, shape, mask = self._points_from(style, axes, mask, columns=not adjust)
         if getattr(self, "coordinates_type", "euclidean") == "geographic" or not adjust:
             return pts, shape, mask, None  # no anisotropy correction in spherical coordinates (ok.py:892-896)
         return core.adjust_for_anisotropy(pts, self._center(), self._scaling(), self._angle()), shape, mask, None
@@ -463,8 +463,10 @@ class _KrigingBase:
         gz, gy, gx = np.meshgrid(axes[2], axes[1], axes[0], indexing="ij")
         return np.stack((gx.ravel(), gy.ravel(), gz.ravel()), axis=1)
 
-    def _points_from(self, style, axes, mask):
-        """Reference meshgrid order and mask handling (ok.py:849-878; ok3d.py:841-876)."""
+    def _points_from(self, style, axes, mask, columns=False):
+        """Reference meshgrid order and mask handling (ok.py:849-878; ok3d.py:841-876).  columns=True (style='points' whose
+        coordinates go to the device raw): the (n, d) array is laid out column by column, so that the three coordinate arrays
+        the C ABI takes are contiguous views of it (no second host copy of npt x d doubles)."""
         if style != "grid" and style != "masked" and style != "points":
             raise ValueError("style argument must be 'grid', 'points', or 'masked'")
         if style in ("grid", "masked"):
@@ -477,7 +479,12 @@ class _KrigingBase:
                 raise ValueError("xpoints and ypoints%s must have same dimensions when treated as listing "
                                  "discrete points." % (", zpoints" if self._ndim == 3 else ""))
             shape = (sizes[0],)
-            pts = np.stack(axes, axis=1)
+            if columns:
+                pts = np.empty((sizes[0], len(axes)), dtype=np.float64, order="F")
+                for k, a in enumerate(axes):
+                    pts[:, k] = a
+            else:
+                pts = np.stack(axes, axis=1)
             mask = None
         return pts, shape, mask
 
@@ -724,7 +731,7 @@ class UniversalKriging(OrdinaryKriging):
         return np.array(rows, dtype=np.float64) if rows else None
 
     def _prepare_points(self, style, axes, mask, specified_drift_arrays=None, backend="vectorized", adjust=True):
-        pts, shape, mask = self._points_from(style, axes, mask)
+        pts, shape, mask = self._points_from(style, axes, mask, columns=not adjust)
         rows = []
         if self.external_Z_drift:  # on ORIGINAL coordinates (uk.py:967-971)
             if mask is not None and backend != "vectorized":
@@ -890,7 +897,7 @@ class UniversalKriging3D(OrdinaryKriging3D):
         return np.array(rows, dtype=np.float64) if rows else None
 
     def _prepare_points(self, style, axes, mask, specified_drift_arrays=None, backend="vectorized", adjust=True):
-        pts, shape, mask = self._points_from(style, axes, mask)
+        pts, shape, mask = self._points_from(style, axes, mask, columns=not adjust)
         rows = self._spec_rows(style, shape, pts.shape[0], specified_drift_arrays)
         if not adjust:  # (never with functional drifts: _prepare) the device adjusts the coordinates
             return pts, shape, mask, (np.array(rows, dtype=np.float64) if rows else None)
