@@ -39,6 +39,18 @@ def _selftest(mode, members=4, init=0.6, bcast=0.6):
     return int(rc), rep, int(rc2), rep2, float(dt), time.time() - t0
 
 
+def _timeout_report(rep, phase, limit):
+    """'timeout phase=<phase> after <t> s; ...': the wait ran out in that phase, no earlier than its limit and (on a loaded test host
+    the waiting thread may be scheduled late) well before the OTHER limit or any multiple of this one could have expired."""
+    import re
+
+    m = re.match(r"timeout phase=%s after ([0-9.]+) s" % phase, rep)
+    assert m, rep
+    t = float(m.group(1))
+    assert limit - 0.01 <= t <= limit + 1.5, rep
+    return True
+
+
 def test_exchange_with_a_working_rccl_reports_its_ranks():
     rc, rep, rc2, rep2, dt, _ = _selftest("ok", members=8)
     assert rc == 0 and rep == "ok ranks=8" and rc2 == 0 and rep2 == "ok ranks=8"  # communicators are cached: the second one too
@@ -47,24 +59,24 @@ def test_exchange_with_a_working_rccl_reports_its_ranks():
 
 def test_comm_init_that_never_returns_is_abandoned_within_the_limit():
     rc, rep, rc2, rep2, dt, wall = _selftest("hang_init")
-    assert rc == -4 and rep.startswith("timeout phase=init after 0.6") and "rccl_dead=1" in rep, rep
+    assert rc == -4 and _timeout_report(rep, "init", 0.6) and "rccl_dead=1" in rep, rep
     # RCCL is not tried again in this process: the second exchange fails at once instead of waiting out another limit
     assert rc2 == -4 and "RCCL disabled for this process" in rep2 and "ncclCommInitAll" in rep2, rep2
-    assert dt < 3.0 and wall < 60.0  # and the process exits although a worker thread is still stuck inside the stand-in
+    assert dt < 6.0 and wall < 60.0  # and the process exits although a worker thread is still stuck inside the stand-in
 
 
 def test_broadcast_that_never_returns_is_abandoned_within_the_limit():
     rc, rep, rc2, rep2, dt, _ = _selftest("hang_bcast", init=5.0, bcast=0.5)
-    assert rc == -4 and rep.startswith("timeout phase=bcast after 0.5"), rep  # the init limit (5 s) was NOT what expired
+    assert rc == -4 and _timeout_report(rep, "bcast", 0.5), rep  # the init limit (5 s) was NOT what expired
     assert rc2 == -4 and "RCCL disabled" in rep2 and "ncclBroadcast" in rep2
-    assert dt < 3.0
+    assert dt < 6.0
 
 
 def test_comm_init_that_fails_is_an_error_not_a_wait():
     rc, rep, rc2, rep2, dt, _ = _selftest("fail_init", init=30.0, bcast=30.0)
     assert rc == -4 and rep.startswith("failed:") and "CommInitAll" in rep
     assert rc2 == -4 and rep2.startswith("failed:")  # a failure (not a stall) does not disable RCCL: it is simply tried again
-    assert dt < 3.0
+    assert dt < 6.0
 
 
 # ------------------------------------------------------------------------------------------------ on the GPU
