@@ -367,3 +367,68 @@ def test_point_lists_go_to_the_device_raw_unless_the_host_needs_them_adjusted(mo
     mask = rng.random((5, 7)) < 0.3
     P = ok._prepare("masked", (gx, gy), mask)
     assert P.raw and P.arrays.shape == (35, 2) and P.mask.shape == (35,)
+
+
+def _kernel_metadata():
+    """{mangled kernel name: {vgpr_count, agpr_count, private_segment_fixed_size, group_segment_fixed_size}} of the gfx950 code object
+    inside the built library (the clang offload bundle in .hip_fatbin, read with llvm-readelf --notes)."""
+    import struct
+    import subprocess
+    import tempfile
+
+    readelf = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    lib = os.path.join(ROOT, "pykrige_amd", "libmikrige.so")
+    if not (os.path.exists(readelf) and os.path.exists(lib)):
+        pytest.skip("needs the built library and ROCm's llvm-readelf")
+    blob = open(lib, "rb").read()
+    at = blob.find(b"__CLANG_OFFLOAD_BUNDLE__")
+    assert at >= 0
+    n = struct.unpack_from("<Q", blob, at + 24)[0]
+    off, elf = at + 32, None
+    for _ in range(n):
+        o, s, ts = struct.unpack_from("<QQQ", blob, off)
+        off += 24
+        triple = blob[off:off + ts].decode()
+        off += ts
+        if "gfx950" in triple:
+            elf = blob[at + o:at + o + s]
+    assert elf is not None and elf[:4] == b"\x7fELF", "no gfx950 code object in the library"
+    with tempfile.NamedTemporaryFile(suffix=".co") as f:
+        f.write(elf)
+        f.flush()
+        notes = subprocess.run([readelf, "--notes", f.name], capture_output=True, text=True, check=True).stdout
+    out = {}
+    for block in notes.split("\n  - .agpr_count:")[1:]:
+        block = ".agpr_count:" + block
+        get = lambda key: int(re.search(r"\.%s:\s+(\d+)" % key, block).group(1))
+        name = re.search(r"\.name:\s+(\S+)", block).group(1)
+        out[name] = {k: get(k) for k in ("vgpr_count", "agpr_count", "private_segment_fixed_size", "group_segment_fixed_size")}
+    return out
+
+
+def test_kernel_register_budgets_of_the_built_library():
+    """The occupancy the hot kernels were tuned for is a property of the BUILD (registers per wavefront, spills, LDS per block), so it
+    is pinned here without a GPU: the contraction and the 8-wave trailing update at 128 VGPRs (4 wavefronts per SIMD = two 8-wave
+    blocks per CU, 64 KB of LDS each), no spills inside them beyond the few bytes of per-tile state; every moving-window class the
+    dispatcher uses within the register budget of the wavefronts per SIMD its launch bound promises (round 3: the class table's
+    cliffs were occupancy cliffs -- 256 VGPRs + AGPRs meant one wavefront per SIMD), none of them parking values in AGPRs."""
+    md = _kernel_metadata()
+
+    def one(pattern):
+        hits = [v for k, v in md.items() if re.fullmatch(pattern, k)]
+        assert len(hits) == 1, (pattern, len(hits))
+        return hits[0]
+
+    k = one(r"_ZN3mik10k_contractILb1ELi2ELb1ELb0ELb1ELb0EEEv.*")  # symmetric, 8 waves, persistent, triangular diagonal blocks: the default
+    assert k["vgpr_count"] <= 128 and k["agpr_count"] == 0 and k["private_segment_fixed_size"] <= 64 and k["group_segment_fixed_size"] <= 65544, k
+    for sym in (0, 1):
+        k = one(r"_ZN3mik8k_updateILb%dELi2EEEv.*" % sym)
+        assert k["vgpr_count"] <= 128 and k["agpr_count"] == 0 and k["private_segment_fixed_size"] == 0, k
+    # VGPR budget per wavefront for w wavefronts per SIMD (512 registers per lane and SIMD, allocated in blocks of 8)
+    budget = {1: 512, 2: 256, 3: 168, 4: 128, 5: 96, 6: 80, 7: 72, 8: 64}
+    classes = {(4, 4): 7, (8, 4): 7, (8, 6): 5, (8, 8): 4, (8, 10): 3, (8, 11): 2, (8, 12): 2, (8, 13): 2, (16, 7): 4, (16, 8): 4, (16, 9): 3,
+               (16, 10): 3, (16, 11): 2, (16, 12): 2, (16, 13): 2, (16, 14): 2, (32, 8): 4}
+    for (g, ri), waves in classes.items():
+        k = one(r"_ZN3mik9k_mw_cholILi%dELi%dEEEvNS_6MwArgsE" % (g, ri))
+        assert k["agpr_count"] == 0 and k["vgpr_count"] <= budget[waves], ((g, ri), waves, k)
+        assert k["private_segment_fixed_size"] <= 160, ((g, ri), k)  # {16,14} spills 33 registers, the others at most a handful
