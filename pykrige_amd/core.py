@@ -66,6 +66,12 @@ def great_circle_distance(lon1, lat1, lon2, lat2):
                                       s1 * s2 + c1 * c2 * cd)
 
 
+def euclid3_to_great_circle(euclid3_distance):
+    """Chord length between two points of the unit sphere -> their great-circle distance in degrees (core.py:100-117): what turns
+    the KD-tree's 3-D distances of a geographic moving window back into the distances the variogram takes."""
+    return 180.0 - 360.0 / np.pi * np.arccos(0.5 * np.asarray(euclid3_distance, dtype=np.float64))
+
+
 def make_variogram_parameter_list(model, params):
     """User parameters (list or dict) -> internal list; None stays None (= 'fit it')."""
     if params is None:
@@ -303,3 +309,49 @@ def calcQ2(epsilon):
 
 def calc_cR(Q2, sigma):
     return Q2 * np.exp(np.sum(np.log(sigma**2)) / sigma.shape[0])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The reference's private names for the host helpers above and for the constructor-time variogram estimation (core.py:120, 196,
+# 379, 538, 582), same arguments and return values, so that code written against pykrige.core keeps running.
+# ---------------------------------------------------------------------------------------------------------------------
+_adjust_for_anisotropy = adjust_for_anisotropy
+_make_variogram_parameter_list = make_variogram_parameter_list
+
+
+def _variogram_residuals(params, x, y, variogram_function, weight):
+    """core.py:538-579: residuals of variogram_function(params, x) against y, optionally lag-weighted."""
+    from . import variogram_fit
+
+    return variogram_fit.residuals(params, x, y, variogram_function, weight)
+
+
+def _calculate_variogram_model(lags, semivariance, variogram_model, variogram_function, weight):
+    """core.py:582-651: the fitted parameters (internal order: slope, nugget / scale, exponent, nugget / psill, range, nugget)."""
+    from . import variogram_fit
+
+    return variogram_fit.calculate(lags, semivariance, variogram_model, variogram_function, weight)
+
+
+def _initialize_variogram_model(X, y, variogram_model, variogram_model_parameters, variogram_function, nlags, weight,
+                                coordinates_type):
+    """core.py:379-535: experimental semivariogram of (X, y) in nlags equal-width bins, and the model parameters -- the caller's
+    (their number checked) or fitted.  Returns (lags, semivariance, variogram_model_parameters)."""
+    from . import variogram_fit
+
+    X, y = np.asarray(X, dtype=np.float64), np.asarray(y, dtype=np.float64)
+    if coordinates_type == "geographic":
+        if X.shape[1] != 2:
+            raise ValueError("Geographic coordinate type only supported for 2D datasets.")
+    elif coordinates_type != "euclidean":
+        raise ValueError("Specified coordinate type '%s' is not supported." % coordinates_type)
+    lags, semivariance = variogram_fit.experimental_variogram(X, y, nlags, coordinates_type)
+    if variogram_model_parameters is not None:
+        if variogram_model == "linear" and len(variogram_model_parameters) != 2:
+            raise ValueError("Exactly two parameters required for linear variogram model.")
+        if variogram_model in ("power", "spherical", "exponential", "gaussian", "hole-effect") and len(variogram_model_parameters) != 3:
+            raise ValueError("Exactly three parameters required for %s variogram model" % variogram_model)
+        return lags, semivariance, variogram_model_parameters
+    if variogram_model == "custom":
+        raise ValueError("Variogram parameters must be specified when implementing custom variogram model.")
+    return lags, semivariance, _calculate_variogram_model(lags, semivariance, variogram_model, variogram_function, weight)

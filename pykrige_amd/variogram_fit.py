@@ -38,9 +38,11 @@ def experimental_variogram(coords, values, nlags, coordinates_type="euclidean"):
     return np.array(lags), np.array(semis)
 
 
-def _residuals(params, lags, semis, model, weight):
-    r = core.variogram_value(model, params, lags) - semis
-    if weight:  # logistic weights centred at 70 % of the lag range
+def residuals(params, lags, semis, gamma, weight):
+    """Misfit of the model curve gamma(params, lags) against the binned semivariances (core.py:538-579 _variogram_residuals);
+    weight: logistic weights centred at 70 % of the lag range, normalised to sum 1."""
+    r = gamma(params, lags) - semis
+    if weight:
         span = np.amax(lags) - np.amin(lags)
         k = 2.1972 / (0.1 * span)
         x0 = 0.7 * span + np.amin(lags)
@@ -49,9 +51,16 @@ def _residuals(params, lags, semis, model, weight):
     return r
 
 
-def fit(coords, values, model, nlags=6, weight=False, coordinates_type="euclidean", binned=None):
-    """binned = (lags, semivariance) already computed (on the device); None -> bin here on the host."""
-    lags, semis = binned if binned is not None else experimental_variogram(coords, values, nlags, coordinates_type)
+def _residuals(params, lags, semis, model, weight):
+    return residuals(params, lags, semis, lambda p, d: core.variogram_value(model, p, d), weight)
+
+
+def calculate(lags, semis, model, gamma=None, weight=False):
+    """Bounded soft-L1 least-squares fit of the model to (lags, semis) -> parameters in the internal order
+    (core.py:582-651 _calculate_variogram_model); gamma(params, lags) = the model curve (None: the named model's)."""
+    lags, semis = np.asarray(lags, dtype=np.float64), np.asarray(semis, dtype=np.float64)
+    if gamma is None:
+        gamma = lambda p, d: core.variogram_value(model, p, d)  # noqa: E731
     smax, smin, lmax, lmin = np.amax(semis), np.amin(semis), np.amax(lags), np.amin(lags)
     if model == "linear":
         x0 = [(smax - smin) / (lmax - lmin), smin]
@@ -62,5 +71,10 @@ def fit(coords, values, model, nlags=6, weight=False, coordinates_type="euclidea
     else:
         x0 = [smax - smin, 0.25 * lmax, smin]
         bounds = ([0.0, 0.0, 0.0], [10.0 * smax, lmax, smax])
-    res = least_squares(_residuals, x0, bounds=bounds, loss="soft_l1", args=(lags, semis, model, weight))
-    return lags, semis, list(res.x)
+    return least_squares(residuals, x0, bounds=bounds, loss="soft_l1", args=(lags, semis, gamma, weight)).x
+
+
+def fit(coords, values, model, nlags=6, weight=False, coordinates_type="euclidean", binned=None):
+    """binned = (lags, semivariance) already computed (on the device); None -> bin here on the host."""
+    lags, semis = binned if binned is not None else experimental_variogram(coords, values, nlags, coordinates_type)
+    return lags, semis, list(calculate(lags, semis, model, None, weight))

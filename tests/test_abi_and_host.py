@@ -432,3 +432,67 @@ def test_kernel_register_budgets_of_the_built_library():
         k = one(r"_ZN3mik9k_mw_cholILi%dELi%dEEEvNS_6MwArgsE" % (g, ri))
         assert k["agpr_count"] == 0 and k["vgpr_count"] <= budget[waves], ((g, ri), waves, k)
         assert k["private_segment_fixed_size"] <= 160, ((g, ri), k)  # {16,14} spills 33 registers, the others at most a handful
+
+
+def test_reference_private_core_helpers_and_their_known_answers():
+    """pykrige_amd.core carries the reference's private host helpers under their own names (core.py:100, 120, 196, 379, 538, 582); the
+    reference's tests of them hold known answers (test_core.py:184-376 variogram estimation, 2691-2747 great-circle code with
+    geopy-derived distances), restated here."""
+    from pykrige_amd import core
+    from pykrige_amd import variogram_models as vm
+
+    # test_core.py:304-376: fitted parameters (internal order) of hand-made semivariograms
+    lag = np.array([1.0, 2.0, 3.0, 4.0])
+    for semis, model, fn, weight, want, tol in (
+            ([2.05, 2.95, 4.05, 4.95], "linear", vm.linear_variogram_model, False, [0.98, 1.05], 0.01),
+            ([2.05, 2.95, 4.05, 4.95], "linear", vm.linear_variogram_model, True, [0.98, 1.05], 0.01),
+            ([1.0, 2.8284271, 5.1961524, 8.0], "power", vm.power_variogram_model, False, [1.0, 1.5, 0.0], 0.001),
+            ([1.0, 1.4142, 1.7321, 2.0], "power", vm.power_variogram_model, False, [1.0, 0.5, 0.0], 0.001),
+            ([1.2642, 1.7293, 1.9004, 1.9634], "exponential", vm.exponential_variogram_model, False, [2.0, 3.0, 0.0], 0.001),
+            ([0.5769, 1.4872, 1.9065, 1.9914], "gaussian", vm.gaussian_variogram_model, False, [2.0, 3.0, 0.0], 0.001),
+            ([3.33060952, 3.85063879, 3.96667301, 3.99256374], "exponential", vm.exponential_variogram_model, False, [3.0, 2.0, 1.0], 0.001),
+            ([2.60487044, 3.85968813, 3.99694817, 3.99998564], "gaussian", vm.gaussian_variogram_model, False, [3.0, 2.0, 1.0], 0.001)):
+        res = core._calculate_variogram_model(lag, np.array(semis), model, fn, weight)
+        np.testing.assert_allclose(res, want, tol, tol)
+    # test_core.py:184-301: parameter counts, coordinate types, and the binned semivariogram of four points on a line
+    xy = np.array([[0.0, 0.0], [1.0, 0.5], [2.0, 2.0], [0.3, 1.7], [1.1, 0.2]])
+    zz = np.array([1.0, 2.0, 0.5, 1.5, 0.7])
+    for model, params, ctype in (("linear", [0.0], "euclidean"), ("spherical", [0.0], "euclidean"), ("spherical", [0.0, 0.0, 0.0], "tacos")):
+        with pytest.raises(ValueError):
+            core._initialize_variogram_model(xy, zz, model, params, model, 6, False, ctype)
+    with pytest.raises(ValueError):  # geographic coordinates are 2-D only
+        core._initialize_variogram_model(np.hstack((xy, xy[:, :1])), zz, "linear", [0.0, 0.0], "linear", 6, False, "geographic")
+    with pytest.raises(ValueError):
+        core._initialize_variogram_model(xy, zz, "custom", None, None, 6, False, "euclidean")
+    x = np.array([1.0 + n / np.sqrt(2) for n in range(4)])
+    lags, semi, params = core._initialize_variogram_model(np.vstack((x, x)).T, np.arange(1.0, 5.0), "linear", [0.0, 0.0], "linear", 6, False,
+                                                          "euclidean")
+    np.testing.assert_allclose(lags, [1.0, 2.0, 3.0])
+    np.testing.assert_allclose(semi, [0.5, 2.0, 4.5])
+    assert params == [0.0, 0.0]
+    line = np.array([1.0, 2.0, 3.0, 4.0])
+    lags, semi, _ = core._initialize_variogram_model(np.vstack((line, line, line)).T, line, "linear", [0.0, 0.0], "linear", 3, False, "euclidean")
+    np.testing.assert_allclose(lags, np.sqrt(3.0) * np.array([1.0, 2.0, 3.0]))
+    np.testing.assert_allclose(semi, [0.5, 2.0, 4.5])
+    lags, semi, fitted = core._initialize_variogram_model(xy, zz, "linear", None, vm.linear_variogram_model, 3, False, "euclidean")
+    assert len(fitted) == 2 and np.all(np.isfinite(fitted))
+    # test_core.py:2691-2747: great-circle distances against geopy's, and the chord <-> arc conversion against them
+    lon = np.array([7.0, 7.0, 187.0, 73.231])
+    lat = np.array([13.23, 13.2301, -13.23, -79.3])
+    d_ref = np.array([[0.0, 1e-4, 180.0, 98.744848317171801], [1e-4, 0.0, 179.9999, 98.744946828324345],
+                      [180.0, 179.9999, 0.0, 81.255151682828213], [98.744848317171801, 98.744946828324345, 81.255151682828213, 0.0]])
+    d = np.array([[core.great_circle_distance(lon[i], lat[i], lon[j], lat[j]) for j in range(4)] for i in range(4)])
+    np.testing.assert_allclose(d, d_ref)
+    assert np.all(d >= 0.0) and np.all(d <= 180.0) and np.allclose(d, d.T) and np.allclose(np.diag(d), 0.0)
+    glon, glat = np.meshgrid(np.linspace(0, 360.0, 20), np.linspace(-90.0, 90.0, 20))
+    rad = np.pi / 180.0
+    for i in range(4):
+        dx = np.cos(rad * glon) * np.cos(rad * glat) - np.cos(rad * lon[i]) * np.cos(rad * lat[i])
+        dy = np.sin(rad * glon) * np.cos(rad * glat) - np.sin(rad * lon[i]) * np.cos(rad * lat[i])
+        dz = np.sin(rad * glat) - np.sin(rad * lat[i])
+        np.testing.assert_allclose(core.great_circle_distance(lon[i], lat[i], glon, glat),
+                                   core.euclid3_to_great_circle(np.sqrt(dx**2 + dy**2 + dz**2)), rtol=1e-5)
+    # the aliases are the functions the classes use
+    assert core._adjust_for_anisotropy is core.adjust_for_anisotropy and core._make_variogram_parameter_list is core.make_variogram_parameter_list
+    r = core._variogram_residuals([1.0, 0.0], lag, lag + 0.5, vm.linear_variogram_model, False)
+    np.testing.assert_allclose(r, -0.5)
