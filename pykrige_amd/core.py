@@ -311,6 +311,24 @@ def calc_cR(Q2, sigma):
     return Q2 * np.exp(np.sum(np.log(sigma**2)) / sigma.shape[0])
 
 
+eps = 1.0e-10  # core.py:30: the reference's cut-off for "is this distance zero"
+
+
+def _scipy_pinv(kind):
+    def f(a):
+        import scipy.linalg as spl
+
+        return getattr(spl, kind)(a)
+
+    f.__name__ = kind
+    return f
+
+
+# core.py:33: the pseudo-inverse routines `pseudo_inv_type` names, as host callables for code that indexes the table itself;
+# the classes run the pseudo-inverse on the device (mik_problem.pseudo_inv)
+P_INV = {"pinv": _scipy_pinv("pinv"), "pinvh": _scipy_pinv("pinvh")}
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # The reference's private names for the host helpers above and for the constructor-time variogram estimation (core.py:120, 196,
 # 379, 538, 582), same arguments and return values, so that code written against pykrige.core keeps running.

@@ -20,6 +20,7 @@ import numpy as np
 
 from . import _lib
 from . import core
+from . import variogram_models
 
 
 class _Pts:
@@ -56,6 +57,16 @@ class _Pts:
 class _KrigingBase:
     eps = 1.0e-10  # ok.py:177, uk.py:210
     UNBIAS = True  # uk.py:208
+    # ok.py:178-185: the named models as functions (m, d) -> gamma; what `variogram_function` is for a named model.  The device
+    # evaluates them itself (variogram_model selects the kernel); the functions are for callers that plot or inspect the fit.
+    variogram_dict = {
+        "linear": variogram_models.linear_variogram_model,
+        "power": variogram_models.power_variogram_model,
+        "gaussian": variogram_models.gaussian_variogram_model,
+        "spherical": variogram_models.spherical_variogram_model,
+        "exponential": variogram_models.exponential_variogram_model,
+        "hole-effect": variogram_models.hole_effect_variogram_model,
+    }
     _ndim = 2
     _universal = False
     _backends = ("vectorized", "loop", "hip")
@@ -81,6 +92,8 @@ class _KrigingBase:
             self.variogram_function = variogram_function  # evaluated on the host (it is Python), geometry stays on the device
         elif variogram_model not in core.MODELS:
             raise ValueError("Specified variogram model '%s' is not supported." % variogram_model)
+        else:
+            self.variogram_function = self.variogram_dict[variogram_model]  # ok.py:253
         if not isinstance(exact_values, bool):
             raise ValueError("exact_values has to be boolean True or False")
         self.exact_values = exact_values
@@ -159,7 +172,7 @@ class _KrigingBase:
         elif variogram_model not in core.MODELS:
             raise ValueError("Specified variogram model '%s' is not supported." % variogram_model)
         else:
-            self.variogram_function = None
+            self.variogram_function = self.variogram_dict[variogram_model]
         self.variogram_model = variogram_model
         if getattr(self, "coordinates_type", "euclidean") == "geographic":
             if anisotropy.get("anisotropy_scaling", 1.0) != 1.0 and anisotropy["anisotropy_scaling"] != self.anisotropy_scaling:

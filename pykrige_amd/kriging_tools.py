@@ -166,3 +166,12 @@ def read_zmap_grid(filename):
     z = np.asarray(values).reshape(nx, ny).T[::-1]  # columns north-to-south in the file
     dx, dy = (x1 - x0) / (nx - 1), (y1 - y0) / (ny - 1)
     return z, np.arange(x0, x0 + nx * dx, dx), np.arange(y0, y0 + ny * dy, dy), (dx, dy), no_data, coord_sys
+
+
+def space_back_to_front(string):
+    """kriging_tools.py:462-464 (a helper for ZMAP header fields): a blank-padded token comes back right-aligned -- the text around
+    the token (the token = the string without its blanks, taken as ONE separator) followed by the token.  Same corner cases as
+    the reference: a string whose non-blank characters are not contiguous is returned with the token appended, an all-blank
+    string raises ValueError (empty separator)."""
+    token = string.replace(" ", "")
+    return "".join(string.rsplit(token)) + token

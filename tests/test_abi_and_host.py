@@ -496,3 +496,53 @@ def test_reference_private_core_helpers_and_their_known_answers():
     assert core._adjust_for_anisotropy is core.adjust_for_anisotropy and core._make_variogram_parameter_list is core.make_variogram_parameter_list
     r = core._variogram_residuals([1.0, 0.0], lag, lag + 0.5, vm.linear_variogram_model, False)
     np.testing.assert_allclose(r, -0.5)
+
+
+def test_api_surface_of_the_reference_modules_is_present():
+    """Every function, class, public method and class attribute the reference's modules of this path define (parsed from
+    /root/reference when it is there; the list below otherwise) exists under the same name in pykrige_amd -- except the three
+    private kernels of execute() whose arguments ARE the objects this design never builds (the npt x N distance matrix `bd`):
+    _exec_vector / _exec_loop / _exec_loop_moving_window are replaced by the device path behind execute() itself."""
+    import importlib
+
+    import pykrige_amd as pa
+    from pykrige_amd import core, kriging_tools
+
+    replaced = {"_exec_vector", "_exec_loop", "_exec_loop_moving_window"}
+    ref = "/root/reference/src/pykrige/"
+    if os.path.isdir(ref):
+        import ast
+
+        for mod in ("ok", "uk", "ok3d", "uk3d", "variogram_models", "kriging_tools", "compat", "rk", "ck", "core"):
+            ours = importlib.import_module("pykrige_amd." + mod)
+            for node in ast.parse(open(ref + mod + ".py").read()).body:
+                if isinstance(node, ast.FunctionDef):
+                    assert hasattr(ours, node.name), (mod, node.name)
+                elif isinstance(node, ast.ClassDef):
+                    cls = getattr(ours, node.name)
+                    for sub in node.body:
+                        names = []
+                        if isinstance(sub, ast.FunctionDef):
+                            names = [sub.name]
+                        elif isinstance(sub, ast.Assign):
+                            names = [t.id for t in sub.targets if isinstance(t, ast.Name)]
+                        for name in names:
+                            assert name in replaced or hasattr(cls, name), (mod, node.name, name)
+                elif isinstance(node, ast.Assign):
+                    for t in node.targets:
+                        if isinstance(t, ast.Name) and not t.id.startswith("__"):
+                            assert hasattr(ours, t.id), (mod, t.id)
+    # the same facts without the reference tree (the GPU box, a user's machine)
+    for cls in (pa.OrdinaryKriging, pa.UniversalKriging, pa.OrdinaryKriging3D, pa.UniversalKriging3D):
+        assert sorted(cls.variogram_dict) == ["exponential", "gaussian", "hole-effect", "linear", "power", "spherical"]
+        for name in ("execute", "update_variogram_model", "display_variogram_model", "get_variogram_points", "switch_verbose", "switch_plotting",
+                     "get_epsilon_residuals", "plot_epsilon_residuals", "get_statistics", "print_statistics", "eps"):
+            assert hasattr(cls, name), (cls.__name__, name)
+    ok = pa.OrdinaryKriging([0.0, 1.0, 2.0], [0.0, 1.0, 0.5], [1.0, 2.0, 3.0], variogram_model="linear", variogram_parameters=[1.0, 0.1])
+    # ok.py:253: for a named model `variogram_function` is that model's function (callers plot the fit with it)
+    np.testing.assert_allclose(ok.variogram_function(ok.variogram_model_parameters, np.array([1.0, 2.0])), [1.1, 2.1])
+    assert core.eps == 1.0e-10 and sorted(core.P_INV) == ["pinv", "pinvh"]
+    np.testing.assert_allclose(core.P_INV["pinvh"](np.diag([2.0, 0.0])), np.diag([0.5, 0.0]))
+    assert kriging_tools.space_back_to_front(" 12.5  ") == "   12.5" and kriging_tools.space_back_to_front("abc") == "abc"
+    with pytest.raises(ValueError):
+        kriging_tools.space_back_to_front("   ")
