@@ -100,8 +100,10 @@ typedef struct mik_grid {
   double rot[9];               /* rotation matrix of core.py:150-154 / 166-187, row-major ndim x ndim (leading entries) */
   double stretch[3];           /* diagonal of the stretch matrix: 1, scaling  /  1, scaling_y, scaling_z */
   int64_t cell_first, cell_count; /* krige only cells cell_first .. cell_first + cell_count - 1 of the flattened grid (one
-                                  rank's slab when the caller shards: pykrige_amd.dist); cell_count = 0: the whole grid.
-                                  mask, extra_rows and the outputs of mik_get_results are relative to this range */
+                                  rank's slab when the caller shards: pykrige_amd.dist); cell_count = -1: the whole grid
+                                  (cell_first ignored); cell_count = 0: an EMPTY range -- nothing is kriged (a rank of a run
+                                  with more ranks than cells).  mask, extra_rows and the outputs of mik_get_results are
+                                  relative to this range */
   const int8_t *mask;          /* nullable; one byte per cell of the range, flattened like the cells; nonzero = skip */
   const double *extra_rows;    /* n_extra x (cells of the range) row-major host-evaluated drift terms; nullable if n_extra == 0 */
 } mik_grid;
@@ -136,6 +138,13 @@ typedef struct mik_timing {
   double verify_ms;            /* the probe of the inverse (all attempts) */
   double verify_res_z;         /* max |A c - [Z; 0]| / max(1, max|Z|), c = A_inv[:, :n] Z: bounds the error of z (last attempt) */
   double verify_res_inv;       /* max_j max |A_inv A e_j - e_j| over three station columns (last attempt) */
+  int32_t sparse;              /* 1 = mik_predict ran the range-aware contraction (compact-support variogram: option "sparse") */
+  int32_t stations_sorted;     /* 1 = the factor holds the stations in Hilbert-curve order (mik_get_matrix un-permutes) */
+  double sparse_tiles;         /* range-aware contraction: tiles (active row block x point block) contracted, all launches */
+  double sparse_tiles_dense;   /*   ... and the tiles the dense symmetric contraction runs for the same points */
+  double sparse_ktiles;        /* off-diagonal K tiles (16 stations x 128 rows x 128 points) contracted, summed over the tiles */
+  double sparse_ktiles_dense;  /*   ... and of the dense symmetric contraction */
+  double sparse_lists_ms;      /* candidate test + flag -> list kernels (k_sp_cand, k_sp_lists, k_sp_tiles), summed */
 } mik_timing;
 
 int  mik_device_count(void);
@@ -161,6 +170,14 @@ int  mik_slab_of(int64_t n, int members, int i, int64_t *lo, int64_t *count); /*
 
 /* options: "factor" 0=auto 1=sweep 2=pivoted ; "symmetric" 0/1 (contraction uses A_inv symmetry) ;
  * "engine" 0 = MFMA f64 contraction, 1 = VALU (v_fma_f64) contraction ; "waves" 4 | 8 = wavefronts per contraction block ;
+ * "sparse" -1/0/1/2 = range-aware contraction for variograms with compact support (the reference's spherical model is constant
+ *   beyond its range, variogram_models.py:56-70).  With u = [1_N; 0] and s = psill + nugget the right-hand side is b = -s u + delta,
+ *   delta_k = s - gamma(d_k) = 0 for every station beyond the range, and because A e_last = u:  z = c . delta  and
+ *   sigma^2 = 2 s - delta^T A_inv delta  exactly.  The stations are laid out along a Hilbert curve, K3a writes delta and flags the
+ *   (128 points x 16 stations) tiles that hold a nonzero, K3b contracts only those (k_contract_sp).  -1 (default) = 1 = on for the
+ *   spherical model (not with pseudo_inv, a caller's a_inv or geographic coordinates: those run the dense contraction), 0 = off,
+ *   2 = Hilbert-ordered stations with the dense contraction (A/B of the order alone).  Takes effect at the
+ *   next mik_factor [MIK_SPARSE] ;
  * "pairs" 0/1 = symmetric contraction: work is handed out as single tiles (default 0) or as equal-length PAIRS of row
  *   blocks (higher L2 hit rate, measured 2.7 % slower: the kernel is not traffic-bound) ;
  * "tri" 0/1 = symmetric contraction (8-wave form): the diagonal block of a tile is contracted as a triangle of 16-row groups,
@@ -242,6 +259,9 @@ typedef void (*mik_variogram_fn)(void *user, double *d_inout, int64_t rows, int6
 int  mik_set_custom_variogram(mik_handle *h, mik_variogram_fn fn, void *user);
 
 int  mik_set_problem(mik_handle *h, const mik_problem *p); /* H2D of stations/values/drifts            */
+int  mik_station_order(const mik_problem *p, int32_t *order_out); /* the Hilbert-curve order option "sparse" lays the stations out
+                                                              in: order_out[i] = index (in p's arrays) of the station at position i.
+                                                              Diagnostic; needs no GPU.  Only xs / ys / zs, n and ndim of p are read */
 int  mik_factor(mik_handle *h);                            /* K1 + K2 (+ c = A_inv[:, :n].Z) on device   */
 int  mik_set_points(mik_handle *h, const mik_points *g);   /* H2D of the (unmasked) points              */
 int  mik_set_grid(mik_handle *h, const mik_grid *g);       /* the same for a grid given by its axes: H2D of the axes (and

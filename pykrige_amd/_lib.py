@@ -57,6 +57,9 @@ class MikTiming(C.Structure):
         ("exchange_wait_ms", C.c_double), ("exchange_fallbacks", C.c_int32), ("rccl_ranks", C.c_int32),
         ("mw_kernel", C.c_int32), ("half_sweep", C.c_int32), ("factor_attempts", C.c_int32), ("null_dim", C.c_int32), ("rhs_overlapped", C.c_int32),
         ("verify_ms", C.c_double), ("verify_res_z", C.c_double), ("verify_res_inv", C.c_double),
+        ("sparse", C.c_int32), ("stations_sorted", C.c_int32),
+        ("sparse_tiles", C.c_double), ("sparse_tiles_dense", C.c_double),
+        ("sparse_ktiles", C.c_double), ("sparse_ktiles_dense", C.c_double), ("sparse_lists_ms", C.c_double),
     ]
 
     def as_dict(self):
@@ -77,6 +80,7 @@ SIGNATURES = {
     "mik_get_device_timing": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(MikTiming)]),
     "mik_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double]),
     "mik_set_problem": (C.c_int, [C.c_void_p, C.POINTER(MikProblem)]),
+    "mik_station_order": (C.c_int, [C.POINTER(MikProblem), C.POINTER(C.c_int32)]),
     "mik_factor": (C.c_int, [C.c_void_p]),
     "mik_set_points": (C.c_int, [C.c_void_p, C.POINTER(MikPoints)]),
     "mik_set_grid": (C.c_int, [C.c_void_p, C.POINTER(MikGrid)]),
@@ -234,6 +238,7 @@ class Handle:
         p.geographic = int(bool(geographic))
         p.pseudo_inv = int(pseudo_inv)
         self._keep = [xs, ys, zs, values, wells, extra_cols, a_inv]
+        self._taken = None
         check(self._lib.mik_set_problem(self._h, C.byref(p)))
         self._keep = []
 
@@ -272,6 +277,7 @@ class Handle:
         g.mask = m8.ctypes.data_as(C.POINTER(C.c_int8)) if m8 is not None else None
         g.extra_rows = _ptr(er)
         self._npt = px.size
+        self._taken = None  # results of an earlier predict no longer belong to the resident points
         check(self._lib.mik_set_points(self._h, C.byref(g)))
 
     def adjust_points(self, center, rot, stretch):
@@ -301,7 +307,7 @@ class Handle:
             g.stretch = (C.c_double * 3)(*([float(v) for v in stretch] + [1.0] * (3 - nd)))
         ncell = int(g.nx) * int(g.ny) * int(g.nz)
         first, count = (0, ncell) if cell_range is None else (int(cell_range[0]), int(cell_range[1]))
-        g.cell_first, g.cell_count = (first, count) if cell_range is not None else (0, 0)
+        g.cell_first, g.cell_count = (first, count) if cell_range is not None else (0, -1)  # -1 = the whole grid; 0 = an empty range
         m8 = None
         if mask is not None:
             m8 = np.ascontiguousarray(np.asarray(mask).ravel()).view(np.int8) if np.asarray(mask).dtype == np.bool_ else \
@@ -310,10 +316,11 @@ class Handle:
                 raise ValueError("mask length must equal the number of cells")
         er = None
         if extra_rows is not None and np.size(extra_rows):
-            er = _f64(extra_rows).reshape(-1, count)
+            er = _f64(extra_rows).reshape(-1, count) if count > 0 else None
         g.mask = m8.ctypes.data_as(C.POINTER(C.c_int8)) if m8 is not None else None
         g.extra_rows = _ptr(er)
         self._npt = count
+        self._taken = None  # results of an earlier predict no longer belong to the resident points
         check(self._lib.mik_set_grid(self._h, C.byref(g)))
 
     def get_points(self, ndim):
@@ -411,6 +418,19 @@ class Handle:
     def exchange_note(self):
         """Why exchange paths of the last factor() were given up ('' if none were)."""
         return (self._lib.mik_exchange_note(self._h) or b"").decode("utf-8", "replace")
+
+
+def station_order(xs, ys, zs=None):
+    """The Hilbert-curve order option "sparse" lays the stations out in (mik_station_order): order[i] = index of the station at
+    position i.  Diagnostic; needs no GPU."""
+    xs, ys = _f64(xs), _f64(ys)
+    zs = _f64(zs) if zs is not None else None
+    p = MikProblem()
+    p.ndim, p.n = (3 if zs is not None else 2), xs.size
+    p.xs, p.ys, p.zs = _ptr(xs), _ptr(ys), _ptr(zs)
+    out = np.zeros(xs.size, dtype=np.int32)
+    check(load().mik_station_order(C.byref(p), out.ctypes.data_as(C.POINTER(C.c_int32))))
+    return out
 
 
 def slab_of(n, members, i):

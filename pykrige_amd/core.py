@@ -69,7 +69,9 @@ def great_circle_distance(lon1, lat1, lon2, lat2):
 def euclid3_to_great_circle(euclid3_distance):
     """Chord length between two points of the unit sphere -> their great-circle distance in degrees (core.py:100-117): what turns
     the KD-tree's 3-D distances of a geographic moving window back into the distances the variogram takes."""
-    return 180.0 - 360.0 / np.pi * np.arccos(0.5 * np.asarray(euclid3_distance, dtype=np.float64))
+    # chords that round above the diameter are the diameter (core.py:115-116: "eliminate some possible numerical errors")
+    d = np.minimum(np.asarray(euclid3_distance, dtype=np.float64), 2.0)
+    return 180.0 - 360.0 / np.pi * np.arccos(0.5 * d)
 
 
 def make_variogram_parameter_list(model, params):

@@ -386,9 +386,15 @@ struct RhsArgs {
   long extra_stride;
   const double* cvec;
   double* zout;  // chunk base
+  // SP (range-aware contraction, see k_contract_sp): delta = b + sill on the station entries; only the candidate station blocks
+  // of the point block are computed and stored; flags[point block][K tile] = 1 where a nonzero was written
+  const unsigned char* cand;  // [point block][nIblk]
+  unsigned char* flags;       // [point block][nK16]
+  int nIblk, nK16;
+  double sill;
 };
 
-template <int MODEL, int NDIM>
+template <int MODEL, int NDIM, bool SP = false>
 __global__ void __launch_bounds__(256) k_rhs(RhsArgs a) {
   __shared__ double red[4][MIK_TP];
   const int t0 = blockIdx.x * MIK_TP;
@@ -413,6 +419,7 @@ __global__ void __launch_bounds__(256) k_rhs(RhsArgs a) {
 
   for (int j = threadIdx.x; j < a.Mp; j += 256) {
     double val[MIK_TP];
+    if (SP && !a.cand[(long)(t0 >> 7) * a.nIblk + (j >> 7)]) continue;  // wave-uniform: a wave covers 64 consecutive j
     if (j < a.N) {
       const double sx = a.xs[j];
       double sy = a.ys[j];
@@ -457,7 +464,7 @@ __global__ void __launch_bounds__(256) k_rhs(RhsArgs a) {
           g = -vario<MODEL, true>(a.v, d, s2);
           if (a.exact && ((MODEL == 2) ? (s2 <= a.eps * a.eps) : (d <= a.eps))) g = 0.0;
         }
-        val[q] = g;
+        val[q] = SP ? a.sill + g : g;  // SP: beyond the range g = -(psill + nugget) = -sill exactly, delta = 0 exactly
       }
     } else if (j < a.N + a.p) {
       int c = j - a.N;
@@ -482,11 +489,18 @@ __global__ void __launch_bounds__(256) k_rhs(RhsArgs a) {
       for (int q = 0; q < MIK_TP; ++q) val[q] = one;
     }
     const double cj = (j < a.M) ? a.cvec[j] : 0.0;
+    bool nz = false;
 #pragma unroll
     for (int q = 0; q < MIK_TP; ++q) {
       const double v = ok[q] ? val[q] : 0.0;
       a.Bt[(long)(t0 + q) * a.ld + j] = v;
       zacc[q] += cj * v;
+      if (SP) nz = nz || v != 0.0;
+    }
+    if (SP) {  // 16 lanes = one K tile; every writer writes the same 1
+      const unsigned long long m = __ballot(nz);
+      const int l = threadIdx.x & 63;
+      if ((l & 15) == 0 && ((m >> l) & 0xffffULL) != 0) a.flags[(long)(t0 >> 7) * a.nK16 + (j >> 4)] = 1;
     }
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1187,6 +1201,417 @@ __global__ void __launch_bounds__(256) k_ss_reduce(const double* __restrict__ pa
   double s = 0.0;
   for (int b = 0; b < nIblk; ++b) s += part[(long)b * palloc + t];
   ss[t] = -s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Range-aware contraction for variograms with COMPACT SUPPORT (round 4).  The reference's spherical model is constant beyond
+// its range (variogram_models.py:56-70): gamma(d) = s = psill + nugget for d > range.  With u = [1_N; 0] the right-hand side of
+// ok.py:669-673 / uk.py:949-981 is b = -s u + delta, where delta_k = s - gamma(d_k) for the stations (EXACTLY zero beyond the
+// range; = s at an exact hit, whose b_k is zeroed), delta = b on the drift rows and on the last row.  The kriging matrix has
+// A e_last = u (its last column is [1_N; 0], ok.py:645-647, uk.py:915-918), hence A^-1 u = e_last and
+//     x = A^-1 b = -s e_last + A^-1 delta ,   z = [Z;0] . x = c . delta ,
+//     sigma^2 = -b . x = 2 s - delta^T A^-1 delta        (u . e_last = 0,  u . A^-1 delta = delta_last = 1 = delta . e_last)
+// -- the same two numbers from a vector that is mostly zeros.  The stations are laid out along a Hilbert curve (mik_set_problem), so
+// 16 consecutive stations are neighbours in space; k_rhs<.., SP> writes delta and records, per block of 128 points, which K tiles
+// (16 stations) hold a nonzero; k_sp_lists turns the flags into lists; k_contract_sp contracts, for every ACTIVE row block of a
+// point block, only the active K tiles above it and the row block's own (triangular) diagonal block.  Nothing is thresholded:
+// a skipped product is a product with exact zeros.
+// ------------------------------------------------------------------------------------------------
+
+// candidates: which 128-station blocks can hold a station within `radius` of any of the 128 points of a point block (bounding
+// boxes; a superset of the truth).  k_rhs computes and stores only these; everything else is delta = 0 and is never read.
+// sbox: per station block lo[3], hi[3] (host, mik_set_problem).  One 128-thread block per point block.
+__global__ void __launch_bounds__(128) k_sp_cand(const double* __restrict__ px, const double* __restrict__ py,
+                                                 const double* __restrict__ pz, int nvalid, const double* __restrict__ sbox,
+                                                 int nIblk, int nforced_from, double radius, unsigned char* __restrict__ cand) {
+  __shared__ double red[6][2];
+  const int tb = blockIdx.x, t = tb * 128 + threadIdx.x;
+  const bool ok = t < nvalid;
+  double lo[3], hi[3];
+  const double c[3] = {ok ? px[t] : 0.0, ok ? py[t] : 0.0, (ok && pz) ? pz[t] : 0.0};
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    lo[d] = ok ? c[d] : 1e300;
+    hi[d] = ok ? c[d] : -1e300;
+    for (int o = 32; o > 0; o >>= 1) {
+      lo[d] = fmin(lo[d], __shfl_xor(lo[d], o));
+      hi[d] = fmax(hi[d], __shfl_xor(hi[d], o));
+    }
+    if ((threadIdx.x & 63) == 0) {
+      red[d][threadIdx.x >> 6] = lo[d];
+      red[3 + d][threadIdx.x >> 6] = hi[d];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    lo[d] = fmin(red[d][0], red[d][1]);
+    hi[d] = fmax(red[3 + d][0], red[3 + d][1]);
+  }
+  const double r2 = radius * radius * (1.0 + 1e-9);
+  for (int jb = threadIdx.x; jb < nIblk; jb += 128) {
+    const double* sb = sbox + 6 * jb;
+    double d2 = 0.0;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const double gap = fmax(0.0, fmax(sb[d] - hi[d], lo[d] - sb[3 + d]));
+      d2 += gap * gap;
+    }
+    cand[(long)tb * nIblk + jb] = (jb >= nforced_from || d2 <= r2) ? 1 : 0;
+  }
+}
+
+// flags (one byte per point block and K tile, written by k_rhs SP) -> per point block: the ascending list of active K tiles
+// (klist, as k / 16), the ascending list of active ROW blocks (rows: a row block is active when any of its 8 K tiles is), and
+// for each active row block the position in klist of the first K tile beyond it (rstart).  One wavefront per point block.
+__global__ void __launch_bounds__(64) k_sp_lists(const unsigned char* __restrict__ flags, int nK16, int nIblk,
+                                                 unsigned short* __restrict__ klist, int* __restrict__ kcount,
+                                                 unsigned short* __restrict__ rows, unsigned short* __restrict__ rstart,
+                                                 int* __restrict__ nrows) {
+  const int tb = blockIdx.x, lane = threadIdx.x;
+  const unsigned char* f = flags + (long)tb * nK16;
+  unsigned short* kl = klist + (long)tb * nK16;
+  unsigned short* rw = rows + (long)tb * nIblk;
+  unsigned short* rs = rstart + (long)tb * nIblk;
+  int nk = 0, nr = 0;
+  for (int base = 0; base < nK16; base += 64) {
+    const int k16 = base + lane;
+    const bool on = k16 < nK16 && f[k16] != 0;
+    const unsigned long long m = __ballot(on);
+    if (on) kl[nk + __popcll(m & ((1ULL << lane) - 1ULL))] = (unsigned short)k16;
+    // the 8 row blocks this batch covers: lane l < 8 looks at byte l of the mask
+    const bool ract = lane < 8 && ((m >> (8 * lane)) & 0xffULL) != 0 && (base / 8 + lane) < nIblk;
+    const unsigned long long rm = __ballot(ract);
+    if (ract) {
+      const int pos = nr + __popcll(rm & ((1ULL << lane) - 1ULL));
+      rw[pos] = (unsigned short)(base / 8 + lane);
+      const unsigned long long upto = lane == 7 ? m : (m & ((1ULL << (8 * (lane + 1))) - 1ULL));
+      rs[pos] = (unsigned short)(nk + __popcll(upto));
+    }
+    nk += __popcll(m);
+    nr += __popcll(rm);
+  }
+  if (lane == 0) {
+    kcount[tb] = nk;
+    nrows[tb] = nr;
+  }
+}
+
+// The tile sequences of k_contract_sp.  Point blocks are taken in groups of MIK_ST; group g belongs to XCD g % 8 (adjacent point
+// blocks have nearly the same active sets: the tiles an XCD has in flight share their row panels of A_inv and their B panels in
+// its L2).  Inside a group: row position ascending (= longest K loops first), point block fast.  tiles[] entry = tblk << 10 | rpos.
+// xoff[x] .. xoff[x + 1] = XCD x's range of tiles[].  stats: [0] tiles, [1] off-diagonal K tiles summed over the tiles.
+// One block of 1024 threads (<= 1024 point blocks per launch).
+__global__ void __launch_bounds__(1024) k_sp_tiles(const int* __restrict__ nrows, const int* __restrict__ kcount,
+                                                   const unsigned short* __restrict__ rstart, int nIblk, int nTblk,
+                                                   unsigned* __restrict__ tiles, int* __restrict__ xoff,
+                                                   unsigned long long* __restrict__ stats) {
+  __shared__ int gcnt[1024 / MIK_ST + 1], goff[1024 / MIK_ST + 1], xtot[9];
+  __shared__ unsigned long long ksum;
+  const int nG = (nTblk + MIK_ST - 1) / MIK_ST;
+  const int g = threadIdx.x;
+  if (g == 0) ksum = 0ULL;
+  __syncthreads();
+  if (g < nG) {
+    int c = 0;
+    unsigned long long ks = 0ULL;
+    for (int q = 0; q < MIK_ST; ++q) {
+      const int tb = g * MIK_ST + q;
+      if (tb >= nTblk) break;
+      const int nr = nrows[tb], nk = kcount[tb];
+      c += nr;
+      for (int r = 0; r < nr; ++r) ks += (unsigned long long)(nk - rstart[(long)tb * nIblk + r]);
+    }
+    gcnt[g] = c;
+    atomicAdd(&ksum, ks);
+  }
+  __syncthreads();
+  if (g < 8) {  // exclusive scan of the groups of XCD g
+    int s = 0;
+    for (int q = g; q < nG; q += 8) {
+      goff[q] = s;
+      s += gcnt[q];
+    }
+    xtot[g] = s;
+  }
+  __syncthreads();
+  if (g == 0) {
+    int s = 0;
+    for (int x = 0; x < 8; ++x) {
+      const int c = xtot[x];
+      xoff[x] = s;
+      s += c;
+    }
+    xoff[8] = s;
+    stats[0] = (unsigned long long)s;
+    stats[1] = ksum;
+  }
+  __syncthreads();
+  if (g < nG) {
+    int xbase = 0;
+    for (int x = 0; x < (g & 7); ++x) xbase += xtot[x];
+    unsigned* out = tiles + xbase + goff[g];
+    int nr[MIK_ST], maxr = 0;
+    for (int q = 0; q < MIK_ST; ++q) {
+      const int tb = g * MIK_ST + q;
+      nr[q] = tb < nTblk ? nrows[tb] : 0;
+      maxr = nr[q] > maxr ? nr[q] : maxr;
+    }
+    int w = 0;
+    for (int r = 0; r < maxr; ++r)
+      for (int q = 0; q < MIK_ST; ++q)
+        if (r < nr[q]) out[w++] = ((unsigned)(g * MIK_ST + q) << 10) | (unsigned)r;
+  }
+}
+
+// ss[t] = 2 s - sum over the active row blocks of the point's block  (see the identity above)
+__global__ void __launch_bounds__(256) k_ss_reduce_sp(const double* __restrict__ part, int palloc, const int* __restrict__ nrows,
+                                                      int nvalid, double two_s, double* __restrict__ ss) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= nvalid) return;
+  const int nr = nrows[t >> 7];
+  double s = 0.0;
+  for (int r = 0; r < nr; ++r) s += part[(long)r * palloc + t];
+  ss[t] = two_s - s;
+}
+
+// The tile loop of the range-aware contraction: gemm_core's staging (LDS-DMA, saddr form), LDS image, fragment reads and MFMA
+// order (NAI 16-row groups per wave, block tile 128 x 128, K tiles of 16) with the K tiles taken from a LIST: entries
+// [vlo, vhi) of kl (k / 16, ascending; all beyond the tile's row block) downwards, then the row block's own diagonal block
+// [ktri, min(ktri + 128, kend)) as a triangle of 16-row groups exactly as gemm_core<.., TRI> does it (a group's accumulators
+// are doubled when the loop reaches its 16 x 16 square).
+template <int NAI>
+__device__ __forceinline__ void gemm_core_sp(const double* __restrict__ Ag, long lda, const double* __restrict__ Bg, long ldb,
+                                             const unsigned short* kl, int vlo, int vhi, int ktri, int kend, d4 (&acc)[NAI][4],
+                                             GemmSmem& sm) {
+  constexpr int WROWS = 16 * NAI;
+  constexpr int NTHR = 64 * 2 * (MIK_BM / WROWS);
+  constexpr int PROWS = NTHR / 8;
+  constexpr int NPASS = MIK_BM / PROWS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lrow = tid >> 3, slot = tid & 7;
+  unsigned aoffb[NPASS], boffb[NPASS];
+#pragma unroll
+  for (int p = 0; p < NPASS; ++p) {
+    aoffb[p] = (unsigned)(((long)(lrow + PROWS * p) * lda + ((slot ^ (lrow & 2)) << 1)) * 8);
+    boffb[p] = (unsigned)(((long)(lrow + PROWS * p) * ldb + ((slot ^ ((lrow >> 1) & 7)) << 1)) * 8);
+  }
+  const unsigned ldsA = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)&sm.As[0][wave * 8][0]);
+  const unsigned ldsB = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)&sm.Bs[0][wave * 8][0]);
+  constexpr unsigned LDS_PASS = PROWS * MIK_BK * 8, LDS_BUF = MIK_BM * MIK_BK * 8;
+  auto uniform_ptr = [](const double* q) {
+    const unsigned long long v = (unsigned long long)(uintptr_t)q;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<const double*>((uintptr_t)(((unsigned long long)hi << 32) | lo));
+  };
+  const double* Agu = uniform_ptr(Ag);
+  const double* Bgu = uniform_ptr(Bg);
+  auto stage = [&](int k, int b) {
+    const double* abase = uniform_ptr(Agu + k);
+    const double* bbase = uniform_ptr(Bgu + k);
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+      const unsigned la = ldsA + b * LDS_BUF + p * LDS_PASS, lb = ldsB + b * LDS_BUF + p * LDS_PASS;
+      if (p == 0) {
+        asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(aoffb[p]), "s"(abase), "s"(la) : "memory");
+        asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(boffb[p]), "s"(bbase), "s"(lb) : "memory");
+      } else {
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(aoffb[p]), "s"(abase), "s"(la) : "memory");
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(boffb[p]), "s"(bbase), "s"(lb) : "memory");
+      }
+    }
+  };
+  auto drain = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+  const int kq = lane >> 4, ia = lane & 3, jb = lane & 15;
+  int aoff[2], boff[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    aoff[m] = (wm * WROWS + ia) * MIK_BK + (((4 * m + kq) ^ (ia & 2)) << 1);
+    boff[m] = (wn * 64 + jb) * MIK_BK + (((4 * m + kq) ^ ((jb >> 1) & 7)) << 1);
+  }
+  const int ktop = (ktri + 128 < kend ? ktri + 128 : kend) - MIK_BK;  // first K tile of the diagonal block
+  int buf = 0;
+  stage(vhi > vlo ? 16 * (int)kl[vhi - 1] : ktop, 0);
+  drain();
+  __syncthreads();
+  for (int v = vhi - 1; v >= vlo; --v) {
+    stage(v > vlo ? 16 * (int)kl[v - 1] : ktop, buf ^ 1);
+    const double* as = &sm.As[buf][0][0];
+    const double* bs = &sm.Bs[buf][0][0];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      double2 fa[4 * NAI], fb[4];
+#pragma unroll
+      for (int x = 0; x < 4 * NAI; ++x) fa[x] = *reinterpret_cast<const double2*>(as + aoff[m] + 4 * x * MIK_BK);
+#pragma unroll
+      for (int x = 0; x < 4; ++x) fb[x] = *reinterpret_cast<const double2*>(bs + boff[m] + 16 * x * MIK_BK);
+#pragma unroll
+      for (int ai = 0; ai < NAI; ++ai)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int bi = 0; bi < 4; ++bi)
+            acc[ai][bi][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa[4 * ai + r].x, fb[bi].x, acc[ai][bi][r], 0, 0, 0);
+#pragma unroll
+      for (int ai = 0; ai < NAI; ++ai)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int bi = 0; bi < 4; ++bi)
+            acc[ai][bi][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa[4 * ai + r].y, fb[bi].y, acc[ai][bi][r], 0, 0, 0);
+    }
+    drain();
+    __syncthreads();
+    buf ^= 1;
+  }
+  // the diagonal block (gemm_core TRI)
+  const int gd0 = __builtin_amdgcn_readfirstlane(wm * NAI);
+  for (int k = ktop; k >= ktri; k -= MIK_BK) {
+    if (k > ktri) stage(k - MIK_BK, buf ^ 1);
+    const double* as = &sm.As[buf][0][0];
+    const double* bs = &sm.Bs[buf][0][0];
+    const int alive = ((k - ktri) >> 4) - gd0 + 1;
+#pragma unroll
+    for (int ai = 0; ai < NAI; ++ai)
+      if (alive == ai + 1) {
+#pragma unroll
+        for (int y = 0; y < 4; ++y) acc[ai][y] *= 2.0;
+      }
+    if (alive > 0) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        double2 fb[4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) fb[x] = *reinterpret_cast<const double2*>(bs + boff[m] + 16 * x * MIK_BK);
+#pragma unroll
+        for (int ai = 0; ai < NAI; ++ai)
+          if (ai < alive) {
+            double2 fa[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) fa[r] = *reinterpret_cast<const double2*>(as + aoff[m] + 4 * (4 * ai + r) * MIK_BK);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+              for (int bi = 0; bi < 4; ++bi)
+                acc[ai][bi][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa[r].x, fb[bi].x, acc[ai][bi][r], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+              for (int bi = 0; bi < 4; ++bi)
+                acc[ai][bi][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa[r].y, fb[bi].y, acc[ai][bi][r], 0, 0, 0);
+          }
+      }
+    }
+    drain();
+    __syncthreads();
+    buf ^= 1;
+  }
+}
+
+#define MIK_SP_MAXK16 4096  // K tiles a point block's list can hold in LDS (Mp <= 65536)
+struct SpArgs {
+  const double* Ainv;
+  long lda;
+  const double* Bt;
+  long ldb;
+  double* part;
+  int palloc, kend, nIblk, nK16;
+  const unsigned short* klist;   // [tblk][nK16]
+  const int* kcount;             // [tblk]
+  const unsigned short* rows;    // [tblk][nIblk]
+  const unsigned short* rstart;  // [tblk][nIblk]
+  const unsigned* tiles;
+  const int* xoff;               // [9]
+  unsigned long long* queue;     // [8]
+};
+
+// Persistent like k_contract: 2 blocks per CU pop tiles from the sequence of the XCD they run on, then from the others'.
+// Tile = (point block tblk, position rpos in its list of active row blocks): W = A_inv[row block, active K tiles] . delta, fused
+// epilogue part[rpos][t] = sum_i delta_ti W_it (k_contract's, indexed by the position instead of the row block).
+template <int NAI>
+__global__ void __launch_bounds__(64 * 2 * (8 / NAI), 2 * (4 / NAI)) k_contract_sp(SpArgs a) {
+  constexpr int WROWS = 16 * NAI, NWM = 128 / WROWS;
+  __shared__ GemmSmem sm;
+  __shared__ unsigned short skl[MIK_SP_MAXK16];
+  unsigned xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  const int xcd = (int)(xcc & 7);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1, lq = lane >> 4, lc = lane & 15;
+  int steal = 0;
+  for (;;) {
+    // next position of the tile queues
+    unsigned entry = 0;
+    for (;;) {
+      const int xq = (xcd + steal) & 7;
+      if (threadIdx.x == 0) sm.next = (long)__hip_atomic_fetch_add(&a.queue[xq], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      const long seq = sm.next;
+      const int lo = a.xoff[xq], hi = a.xoff[xq + 1];
+      const bool have = seq < (long)(hi - lo);
+      if (have) entry = a.tiles[lo + seq];
+      __syncthreads();  // everyone has read sm.next (and the previous tile's `red`, and is out of its K loop: skl is free)
+      if (have) break;
+      if (++steal == 8) return;
+    }
+    const int tblk = (int)(entry >> 10), rpos = (int)(entry & 1023u);
+    const int iblk = a.rows[(long)tblk * a.nIblk + rpos];
+    const int vlo = a.rstart[(long)tblk * a.nIblk + rpos], vhi = a.kcount[tblk];
+    {  // this tile's part of the K-tile list into LDS
+      const unsigned short* src = a.klist + (long)tblk * a.nK16;
+      for (int v = vlo + (int)threadIdx.x; v < vhi; v += (int)blockDim.x) skl[v] = src[v];
+    }
+    __syncthreads();
+    const int i0 = iblk * MIK_BM, t0 = tblk * MIK_BN;
+    d4 acc[NAI][4];
+#pragma unroll
+    for (int x = 0; x < NAI; ++x)
+#pragma unroll
+      for (int y = 0; y < 4; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
+    gemm_core_sp<NAI>(a.Ainv + (long)i0 * a.lda, a.lda, a.Bt + (long)t0 * a.ldb, a.ldb, skl, vlo, vhi, i0, a.kend, acc, sm);
+    // epilogue (k_contract's)
+    double cs[4];
+#pragma unroll
+    for (int bp = 0; bp < 2; ++bp) {
+      double bv[2][4 * NAI];
+#pragma unroll
+      for (int b2 = 0; b2 < 2; ++b2) {
+        const long t = t0 + wn * 64 + (2 * bp + b2) * 16 + lc;
+        const double* brow = a.Bt + t * a.ldb + i0 + wm * WROWS + lq;
+#pragma unroll
+        for (int ai = 0; ai < NAI; ++ai)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) bv[b2][ai * 4 + r] = brow[ai * 16 + 4 * r];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int b2 = 0; b2 < 2; ++b2) {
+        const int bi = 2 * bp + b2;
+        double s = 0.0;
+#pragma unroll
+        for (int ai = 0; ai < NAI; ++ai)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s += bv[b2][ai * 4 + r] * acc[ai][bi][r];
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        cs[bi] = s;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    double* red = &sm.As[0][0][0];
+    if (lq == 0) {
+#pragma unroll
+      for (int bi = 0; bi < 4; ++bi) red[wm * 128 + wn * 64 + bi * 16 + lc] = cs[bi];
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+      double v = 0.0;
+#pragma unroll
+      for (int w = 0; w < NWM; ++w) v += red[w * 128 + threadIdx.x];
+      a.part[(long)rpos * a.palloc + t0 + threadIdx.x] = v;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -248,6 +248,15 @@ struct mik_handle {
   void* custom_user = nullptr;
   std::vector<double> host_ainv;
   DevBuf xs, ys, zs, vals, wells, extra_cols;
+  // range-aware contraction (compact-support variogram, round 4): the dense path keeps a second copy of the stations laid out
+  // along a Hilbert curve (sort_perm[i] = caller's index of the station at position i) and the bounding boxes of its
+  // 128-station blocks.  factor_sorted says which order the factor in T (and c) is in.
+  bool sort_ok = false, factor_sorted = false;
+  std::vector<int> sort_perm;
+  std::vector<double> hvals_s;
+  DevBuf xs_s, ys_s, zs_s, vals_s, extra_cols_s, sbox;
+  int opt_sparse = -1;  // "sparse": -1 = auto (= 1: on for compact-support models), 0 = off, 1 = on, 2 = sorted stations, dense contraction
+  DevBuf sp_cand, sp_flags, sp_klist, sp_kcount, sp_nrows, sp_rows, sp_rstart, sp_tiles, sp_xoff, sp_stats;
   std::vector<double> hxs, hys, hzs;  // host copies of the station coordinates (the moving-window cell grid is built on the host)
   // moving-window neighbour search: stations sorted into a uniform grid of cells
   struct MwGrid {
@@ -286,6 +295,7 @@ struct mik_handle {
   bool no_half_sweep = false;  // transient: this attempt must not use the half sweep
   bool last_half_sweep = false;
   bool points_from_grid = false;  // the resident points were generated by mik_set_grid (mik_adjust_points refuses them)
+  bool points_adjusted = false;   // mik_adjust_points has transformed the resident points (a second call would transform them twice)
   DevBuf Averify, vbuf;
   std::vector<double> hvals;   // host copy of the station values (the probe compares A c with them)
   int opt_fuse_chain = 1;  // look-ahead sweep: the column update writes the next panel copy too (no copy kernel on the chain)
@@ -706,6 +716,8 @@ static int create_one_body(mik_handle* h, int device) {
   if (env) h->opt_symsweep = atoi(env) < 0 ? -1 : atoi(env) ? 1 : 0;
   env = getenv("MIK_PAIRS");
   if (env) h->opt_pairs = atoi(env) ? 1 : 0;
+  env = getenv("MIK_SPARSE");
+  if (env && atoi(env) >= -1 && atoi(env) <= 2) h->opt_sparse = atoi(env);
   env = getenv("MIK_UPDATE_ATOMIC");
   if (env) h->opt_update_atomic = atoi(env) ? 1 : 0;
   env = getenv("MIK_UPDATE_MAP");
@@ -768,7 +780,9 @@ static void destroy_one(mik_handle* h) {
                     &h->Rt, &h->TKt, &h->Dinv, &h->DinvT, &h->P0, &h->P1, &h->cand0, &h->cand1, &h->pivall, &h->flag,
                     &h->Cold2, &h->Cnew2, &h->Rt2, &h->Dinv2, &h->DinvT2, &h->Dinv3, &h->DinvT3, &h->tilemap, &h->Dnext, &h->Dcopy, &h->Cb, &h->Rb, &h->grid.gx, &h->grid.gy, &h->grid.gz, &h->grid.orig,
                     &h->grid.cstart,
-                    &h->px, &h->py, &h->pz, &h->grid_axes, &h->grid_idx, &h->Averify, &h->vbuf, &h->extra_rows, &h->z, &h->ss, &h->Bt, &h->Bt2, &h->part, &h->mw_idx, &h->mw_dist, &h->stat_S, &h->stat_x, &h->stat_out, &h->queue};
+                    &h->px, &h->py, &h->pz, &h->grid_axes, &h->grid_idx, &h->Averify, &h->vbuf, &h->extra_rows, &h->z, &h->ss, &h->Bt, &h->Bt2, &h->part, &h->mw_idx, &h->mw_dist, &h->stat_S, &h->stat_x, &h->stat_out, &h->queue,
+                    &h->xs_s, &h->ys_s, &h->zs_s, &h->vals_s, &h->extra_cols_s, &h->sbox, &h->sp_cand, &h->sp_flags, &h->sp_klist, &h->sp_kcount,
+                    &h->sp_nrows, &h->sp_rows, &h->sp_rstart, &h->sp_tiles, &h->sp_xoff, &h->sp_stats};
   for (DevBuf* b : bufs) b->release();
   h->pin_in.release();
   h->pin_out.release();
@@ -917,6 +931,9 @@ int mik_set_option(mik_handle* h, const char* key, double value) {
   } else if (!strcmp(key, "engine")) {
     if (value != 0.0 && value != 1.0) return fail(MIK_EINVAL, "engine must be 0 (mfma) or 1 (valu)");
     h->opt_engine = (int)value;
+  } else if (!strcmp(key, "sparse")) {
+    if (value != -1.0 && value != 0.0 && value != 1.0 && value != 2.0) return fail(MIK_EINVAL, "sparse must be -1 (auto), 0, 1 or 2");
+    h->opt_sparse = (int)value;
   } else if (!strcmp(key, "pairs")) {
     h->opt_pairs = value != 0.0;
   } else if (!strcmp(key, "tri")) {
@@ -983,6 +1000,123 @@ int mik_set_option(mik_handle* h, const char* key, double value) {
 }
 
 int64_t mik_matrix_order(mik_handle* h) { return h ? h->M : 0; }
+
+// Hilbert-curve index of a lattice point (Skilling, "Programming the Hilbert curve", AIP Conf. Proc. 707 (2004): axes ->
+// transposed index, in place; then the bits are interleaved, X[0] first).  n axes, b bits each.
+static uint64_t hilbert_key(uint32_t* X, int n, int b) {
+  const uint32_t Mtop = 1u << (b - 1);
+  for (uint32_t Q = Mtop; Q > 1; Q >>= 1) {
+    const uint32_t P = Q - 1;
+    for (int i = 0; i < n; ++i) {
+      if (X[i] & Q) X[0] ^= P;
+      else {
+        const uint32_t t = (X[0] ^ X[i]) & P;
+        X[0] ^= t;
+        X[i] ^= t;
+      }
+    }
+  }
+  for (int i = 1; i < n; ++i) X[i] ^= X[i - 1];
+  uint32_t t = 0;
+  for (uint32_t Q = Mtop; Q > 1; Q >>= 1)
+    if (X[n - 1] & Q) t ^= Q - 1;
+  for (int i = 0; i < n; ++i) X[i] ^= t;
+  uint64_t key = 0;
+  for (int bit = b - 1; bit >= 0; --bit)
+    for (int i = 0; i < n; ++i) key = (key << 1) | ((X[i] >> bit) & 1u);
+  return key;
+}
+
+// order[i] = index of the station at position i of the Hilbert-curve order (ties by index: deterministic on every rank / member)
+static void hilbert_order(int ndim, long n, const double* xs, const double* ys, const double* zs, std::vector<int>& order) {
+  const double* c[3] = {xs, ys, zs};
+  double lo[3] = {0, 0, 0}, ext = 0.0;
+  for (int d = 0; d < ndim; ++d) {
+    double a = 1e300, b = -1e300;
+    for (long i = 0; i < n; ++i) {
+      a = std::min(a, c[d][i]);
+      b = std::max(b, c[d][i]);
+    }
+    lo[d] = a;
+    ext = std::max(ext, b - a);
+  }
+  const int bits = 16;
+  const double scale = (ext > 0.0 && std::isfinite(ext)) ? (double)((1u << bits) - 1) / ext : 0.0;  // one scale: cells are cubes
+  std::vector<std::pair<uint64_t, int>> keys((size_t)n);
+  for (long i = 0; i < n; ++i) {
+    uint32_t X[3] = {0, 0, 0};
+    for (int d = 0; d < ndim; ++d) {
+      const double q = (c[d][i] - lo[d]) * scale;
+      X[d] = (uint32_t)std::min<double>((double)((1u << bits) - 1), std::max(0.0, std::isfinite(q) ? q : 0.0));
+    }
+    keys[(size_t)i] = {hilbert_key(X, ndim, bits), (int)i};
+  }
+  std::sort(keys.begin(), keys.end());
+  order.resize((size_t)n);
+  for (long i = 0; i < n; ++i) order[(size_t)i] = keys[(size_t)i].second;
+}
+
+int mik_station_order(const mik_problem* p, int32_t* order_out) {
+  if (!p || !order_out) return fail(MIK_EINVAL, "mik_station_order: NULL argument");
+  if ((p->ndim != 2 && p->ndim != 3) || p->n < 1 || !p->xs || !p->ys || (p->ndim == 3 && !p->zs))
+    return fail(MIK_EINVAL, "mik_station_order: station arrays missing");
+  std::vector<int> order;
+  hilbert_order(p->ndim, p->n, p->xs, p->ys, p->zs, order);
+  for (long i = 0; i < p->n; ++i) order_out[i] = order[(size_t)i];
+  return MIK_OK;
+}
+
+static int upload_sorted_stations(mik_handle* h, const mik_problem* p) {
+  const long N = h->N;
+  hilbert_order(h->ndim, N, p->xs, p->ys, p->zs, h->sort_perm);
+  const size_t nb = sizeof(double) * (size_t)N;
+  std::vector<double> tmp((size_t)N);
+  auto up = [&](DevBuf& dst, const double* src) -> int {
+    MIKC(dst.ensure(nb));
+    for (long i = 0; i < N; ++i) tmp[(size_t)i] = src[h->sort_perm[(size_t)i]];
+    HIPC(hipMemcpyAsync(dst.p, tmp.data(), nb, hipMemcpyHostToDevice, h->stream));
+    HIPC(hipStreamSynchronize(h->stream));  // tmp is reused
+    return MIK_OK;
+  };
+  MIKC(up(h->xs_s, p->xs));
+  MIKC(up(h->ys_s, p->ys));
+  if (h->ndim == 3) MIKC(up(h->zs_s, p->zs));
+  MIKC(up(h->vals_s, p->values));
+  h->hvals_s = tmp;
+  if (h->nextra) {
+    MIKC(h->extra_cols_s.ensure(nb * h->nextra));
+    for (int c = 0; c < h->nextra; ++c) {
+      for (long i = 0; i < N; ++i) tmp[(size_t)i] = p->extra_cols[(size_t)c * N + h->sort_perm[(size_t)i]];
+      HIPC(hipMemcpyAsync(h->extra_cols_s.as<double>() + (size_t)c * N, tmp.data(), nb, hipMemcpyHostToDevice, h->stream));
+      HIPC(hipStreamSynchronize(h->stream));
+    }
+  }
+  // bounding boxes of the 128-station blocks: lo[3], hi[3] each (blocks without stations: an empty box, never near anything)
+  const int nIblk = h->Mp / 128;
+  std::vector<double> box((size_t)nIblk * 6);
+  const double* c[3] = {p->xs, p->ys, p->zs};
+  for (int b = 0; b < nIblk; ++b) {
+    double* q = box.data() + (size_t)b * 6;
+    for (int d = 0; d < 3; ++d) {
+      q[d] = d < h->ndim ? 1e300 : 0.0;
+      q[3 + d] = d < h->ndim ? -1e300 : 0.0;
+    }
+    for (long i = (long)b * 128; i < std::min<long>(N, (long)(b + 1) * 128); ++i)
+      for (int d = 0; d < h->ndim; ++d) {
+        const double v = c[d][h->sort_perm[(size_t)i]];
+        q[d] = std::min(q[d], v);
+        q[3 + d] = std::max(q[3 + d], v);
+      }
+  }
+  MIKC(h->sbox.ensure(sizeof(double) * box.size()));
+  HIPC(hipMemcpyAsync(h->sbox.p, box.data(), sizeof(double) * box.size(), hipMemcpyHostToDevice, h->stream));
+  HIPC(hipStreamSynchronize(h->stream));
+  return MIK_OK;
+}
+
+// the order the next factor will be in: "sparse" -1 (auto) / 1 / 2 = Hilbert-curve order wherever the problem allows it
+// (measured even at N = 100: the four small list kernels per launch cost less than the dense tiles they save)
+static bool want_sorted(const mik_handle* h) { return h->sort_ok && h->opt_sparse != 0; }
 
 static int one_set_problem(mik_handle* h, const mik_problem* p) {
   if (!h || !p) return fail(MIK_EINVAL, "mik_set_problem: NULL argument");
@@ -1073,6 +1207,13 @@ static int one_set_problem(mik_handle* h, const mik_problem* p) {
   h->pinv = p->pseudo_inv;
   if (h->host_inv) h->host_ainv.assign(p->a_inv, p->a_inv + (size_t)h->M * h->M);
   else h->host_ainv.clear();
+  // compact-support model (spherical: gamma constant beyond the range): a second copy of the stations in Hilbert-curve order for
+  // the range-aware contraction (k_contract_sp).  Not with a pseudo-inverse (A+ u != e_last), a caller's inverse (its order is the
+  // caller's) or geographic coordinates (lon / lat boxes are not distance boxes).
+  h->sort_ok = h->model == MIK_MODEL_SPHERICAL && !h->geo && !h->pinv && !h->host_inv && h->Mp / 16 <= MIK_SP_MAXK16 &&
+               std::isfinite(v.p1) && v.p1 > 0.0 && std::isfinite(v.p0 + v.p2);
+  h->factor_sorted = false;
+  if (h->sort_ok) MIKC(upload_sorted_stations(h, p));
   HIPC(hipStreamSynchronize(h->stream));
   h->have_problem = true;
   h->have_factor = false;
@@ -1109,7 +1250,7 @@ static int custom_roundtrip(mik_handle* h, double* dev, long rows, long cols, lo
   return MIK_OK;
 }
 
-static int launch_assemble(mik_handle* h, double shift, double* dst = nullptr) {
+static int launch_assemble(mik_handle* h, double shift, double* dst = nullptr, bool sorted = false) {
   AsmArgs a{};
   a.T = dst ? dst : h->T.as<double>();
   a.ld = h->Mp;
@@ -1118,16 +1259,16 @@ static int launch_assemble(mik_handle* h, double shift, double* dst = nullptr) {
   a.M = h->M;
   a.Mp = h->Mp;
   a.ndim = h->ndim;
-  a.xs = h->xs.as<double>();
-  a.ys = h->ys.as<double>();
-  a.zs = h->zs.as<double>();
+  a.xs = sorted ? h->xs_s.as<double>() : h->xs.as<double>();
+  a.ys = sorted ? h->ys_s.as<double>() : h->ys.as<double>();
+  a.zs = sorted ? h->zs_s.as<double>() : h->zs.as<double>();
   a.v = h->v;
   a.shift = shift;
   a.rl = h->rl;
   a.nwells = h->nwells;
   a.nextra = h->nextra;
   a.wells = h->wells.as<double>();
-  a.extra = h->extra_cols.as<double>();
+  a.extra = sorted ? h->extra_cols_s.as<double>() : h->extra_cols.as<double>();
   dim3 grid(h->Mp / 64, h->Mp / 64);
   if (h->model == MIK_MODEL_CUSTOM) {
     DISPATCH_NDIM_FIXED(7, h->geo ? 1 : h->ndim, k_assemble, grid, dim3(256), h->stream, a);  // distances
@@ -1662,7 +1803,8 @@ static int verify_inverse(mik_handle* h, double* res_z, double* res_inv) {
   const long ld = Mp;
   MIKC(h->Averify.ensure(sizeof(double) * (size_t)Mp * Mp));
   MIKC(h->vbuf.ensure(sizeof(double) * 4 * (size_t)Mp));
-  MIKC(launch_assemble(h, 0.0, h->Averify.as<double>()));
+  MIKC(launch_assemble(h, 0.0, h->Averify.as<double>(), h->factor_sorted));
+  const std::vector<double>& hv = h->factor_sorted ? h->hvals_s : h->hvals;
   const double* A2 = h->Averify.as<double>();
   double* y = h->vbuf.as<double>();
   const unsigned mg = (unsigned)((M + 3) / 4);
@@ -1675,9 +1817,9 @@ static int verify_inverse(mik_handle* h, double* res_z, double* res_inv) {
   HIPC(hipMemcpyAsync(host.data(), y, sizeof(double) * host.size(), hipMemcpyDeviceToHost, h->stream));
   HIPC(hipStreamSynchronize(h->stream));
   double zmax = 1.0, rz = 0.0, ri = 0.0;
-  for (int i = 0; i < N; ++i) zmax = std::max(zmax, std::fabs(h->hvals[i]));
+  for (int i = 0; i < N; ++i) zmax = std::max(zmax, std::fabs(hv[i]));
   for (int i = 0; i < M; ++i) {
-    const double d = std::fabs(host[i] - (i < N ? h->hvals[i] : 0.0));
+    const double d = std::fabs(host[i] - (i < N ? hv[i] : 0.0));
     rz = std::max(rz, std::isfinite(d) ? d : 1e300);
     for (int k = 0; k < 3; ++k) {
       const double e = std::fabs(host[(size_t)(k + 1) * Mp + i] - (i == cols[k] ? 1.0 : 0.0));
@@ -1922,7 +2064,8 @@ static int run_nullspace_inverse(mik_handle* h, bool* done) {
 
 static int launch_cvec(mik_handle* h) {
   hipLaunchKernelGGL(k_cvec, dim3((h->Mp + 3) / 4), dim3(256), 0, h->stream, (const double*)h->T.as<double>(),
-                     (long)h->Mp, h->M, h->N, (const double*)h->vals.as<double>(), h->cvec.as<double>(), h->Mp);
+                     (long)h->Mp, h->M, h->N, (const double*)(h->factor_sorted ? h->vals_s.as<double>() : h->vals.as<double>()),
+                     h->cvec.as<double>(), h->Mp);
   HIPC(hipGetLastError());
   return MIK_OK;
 }
@@ -1957,6 +2100,7 @@ static int one_factor(mik_handle* h) {
   HIPC(hipSetDevice(h->device));
   h->t_state = 0;
   h->have_factor = false;
+  h->factor_sorted = want_sorted(h);
   MIKC(ensure_factor_buffers(h));
   MIKC(get_events(h, 4));
   h->tm.assemble_ms = h->tm.invert_ms = 0.0;
@@ -2022,7 +2166,7 @@ static int one_factor(mik_handle* h) {
     const double shift = pivoted ? 0.0 : h->shift_guess;
     ++h->tm.factor_attempts;
     HIPC(hipEventRecord(h->evpool[0], h->stream));
-    MIKC(launch_assemble(h, shift));
+    MIKC(launch_assemble(h, shift, nullptr, h->factor_sorted));
     HIPC(hipEventRecord(h->evpool[1], h->stream));
     int flag = 0;
     MIKC(run_block_inverse(h, pivoted, pivoted ? 0 : h->N, &flag));
@@ -2432,6 +2576,7 @@ static void mark_kids_factored(mik_handle* h) {
     k->have_factor = true;
     k->t_state = 2;
     k->have_results = false;
+    k->factor_sorted = h->factor_sorted;  // (the member sorted its own copy of the stations the same way in mik_set_problem)
     k->tm.factor_path = h->tm.factor_path;
     k->tm.assemble_ms = k->tm.invert_ms = 0.0;
   }
@@ -2590,6 +2735,18 @@ int mik_get_matrix(mik_handle* h, int which, double* out) {
   if (which == 1 && !h->have_factor) return fail(MIK_ESTATE, "mik_get_matrix: not factored");
   MIKC(join_exchange(h));
   HIPC(hipSetDevice(h->device));
+  if (which == 1 && h->factor_sorted) {  // the factor is in Hilbert-curve station order: hand it out in the caller's
+    const long M = h->M, N = h->N;
+    std::vector<double> tmp((size_t)M * M);
+    HIPC(hipMemcpy2D(tmp.data(), sizeof(double) * M, h->T.p, sizeof(double) * h->Mp, sizeof(double) * M, M, hipMemcpyDeviceToHost));
+    auto orig = [&](long i) { return i < N ? (long)h->sort_perm[(size_t)i] : i; };
+    for (long i = 0; i < M; ++i) {
+      double* dst = out + orig(i) * M;
+      const double* src = tmp.data() + (size_t)i * M;
+      for (long j = 0; j < M; ++j) dst[orig(j)] = src[j];
+    }
+    return MIK_OK;
+  }
   HIPC(hipMemcpy2D(out, sizeof(double) * h->M, h->T.p, sizeof(double) * h->Mp, sizeof(double) * h->M, h->M,
                    hipMemcpyDeviceToHost));
   return MIK_OK;
@@ -2640,6 +2797,7 @@ static int one_set_points(mik_handle* h, const mik_points* g, const long* idx, l
   HIPC(hipStreamSynchronize(h->stream));
   h->have_points = true;
   h->points_from_grid = false;
+  h->points_adjusted = false;
   h->have_results = false;
   return MIK_OK;
 }
@@ -2796,15 +2954,18 @@ int mik_set_grid(mik_handle* h, const mik_grid* g) {
   if (!g->gx || !g->gy || (g->ndim == 3 && !g->gz)) return fail(MIK_EINVAL, "mik_set_grid: axis arrays missing");
   const double cells = (double)g->nx * (double)g->ny * (g->ndim == 3 ? (double)g->nz : 1.0);
   if (cells >= 9.0e15) return fail(MIK_EINVAL, "mik_set_grid: grid too large");
-  const long first = g->cell_count > 0 ? g->cell_first : 0;
-  const long ncells = g->cell_count > 0 ? g->cell_count : (long)cells;
-  if (first < 0 || g->cell_count < 0 || (double)first + (double)ncells > cells) return fail(MIK_EINVAL, "mik_set_grid: cell range outside the grid");
+  // cell_count < 0 (write -1): the whole grid; 0: an EMPTY range (a rank of a sharded run with more ranks than cells) -- nothing is
+  // kriged, mik_get_results writes nothing
+  const bool whole = g->cell_count < 0;
+  const long first = whole ? 0 : g->cell_first;
+  const long ncells = whole ? (long)cells : g->cell_count;
+  if (first < 0 || (double)first + (double)ncells > cells) return fail(MIK_EINVAL, "mik_set_grid: cell range outside the grid");
   if (ncells >= 4294967296L) return fail(MIK_EINVAL, "mik_set_grid: more than 2^32 - 1 cells in one call (use cell_first / cell_count)");
-  if (h->nextra > 0 && !g->extra_rows) return fail(MIK_EINVAL, "extra_rows missing for host-evaluated drifts");
+  if (h->nextra > 0 && !g->extra_rows && ncells > 0) return fail(MIK_EINVAL, "extra_rows missing for host-evaluated drifts");
   h->npt_total = ncells;
   long n = ncells;
   h->masked = false;
-  if (g->mask) {
+  if (g->mask && ncells > 0) {
     MIKC(compact_mask(h, g->mask, ncells, &n));
     h->masked = n != ncells;
   }
@@ -2822,6 +2983,8 @@ int mik_set_grid(mik_handle* h, const mik_grid* g) {
 int mik_adjust_points(mik_handle* h, const double center[3], const double rot[9], const double stretch[3]) {
   if (!h || !center || !rot || !stretch) return fail(MIK_EINVAL, "mik_adjust_points: NULL argument");
   if (!h->have_points || h->points_from_grid) return fail(MIK_ESTATE, "mik_adjust_points: set the points with mik_set_points first");
+  if (h->points_adjusted) return fail(MIK_ESTATE, "mik_adjust_points: the resident points have already been adjusted");
+  h->points_adjusted = true;
   return for_each_device(h, [&](int, mik_handle* m) -> int {
     HIPC(hipSetDevice(m->device));
     if (m->npt == 0) return MIK_OK;
@@ -2881,9 +3044,16 @@ static int one_predict(mik_handle* h) {
   }
   long chunk = std::min<long>(h->opt_chunk, ((npt + 127) / 128) * 128);
   if (h->model == MIK_MODEL_CUSTOM) chunk = std::min<long>(chunk, 16384);  // each chunk's distances visit the host
+  // range-aware contraction (k_contract_sp): the factor is in Hilbert-curve station order and the variogram has compact support
+  const bool sparse = h->factor_sorted && h->opt_sparse != 2 && h->opt_sparse != 0 && h->opt_engine == 0;
+  if (sparse) chunk = std::min<long>(chunk, 131072);  // k_sp_tiles: at most 1024 point blocks per launch
+  const int nK16 = Mp / 16;
+  h->tm.sparse = sparse ? 1 : 0;
+  h->tm.stations_sorted = h->factor_sorted ? 1 : 0;
+  h->tm.sparse_tiles = h->tm.sparse_tiles_dense = h->tm.sparse_ktiles = h->tm.sparse_ktiles_dense = h->tm.sparse_lists_ms = 0.0;
   // "rhs_overlap" (off by default, see the option): two RHS panels, k_rhs of chunk c + 1 on a second stream while chunk c is
   // contracted.
-  const bool overlap = h->opt_rhs_overlap && h->model != MIK_MODEL_CUSTOM;
+  const bool overlap = h->opt_rhs_overlap && h->model != MIK_MODEL_CUSTOM && !sparse;
   // keep the RHS panels under ~1/4 of device memory
   size_t freeb = 0, totalb = 0;
   HIPC(hipMemGetInfo(&freeb, &totalb));
@@ -2898,7 +3068,22 @@ static int one_predict(mik_handle* h) {
   const bool two = overlap && nchunks > 1;
   MIKC(h->part.ensure(sizeof(double) * (size_t)chunk * nIblk));
   MIKC(h->pin_out.ensure(sizeof(double) * 2 * (size_t)npt));  // (a previous result may have left with mik_take_results)
-  MIKC(get_events(h, 2 + 4 * (size_t)nchunks));
+  MIKC(get_events(h, 2 + 6 * (size_t)nchunks));
+  std::vector<unsigned long long> sp_host;
+  if (sparse) {
+    const size_t nTb = (size_t)chunk / 128;
+    MIKC(h->sp_cand.ensure(nTb * nIblk));
+    MIKC(h->sp_flags.ensure(nTb * nK16));
+    MIKC(h->sp_klist.ensure(sizeof(unsigned short) * nTb * nK16));
+    MIKC(h->sp_kcount.ensure(sizeof(int) * nTb));
+    MIKC(h->sp_nrows.ensure(sizeof(int) * nTb));
+    MIKC(h->sp_rows.ensure(sizeof(unsigned short) * nTb * nIblk));
+    MIKC(h->sp_rstart.ensure(sizeof(unsigned short) * nTb * nIblk));
+    MIKC(h->sp_tiles.ensure(sizeof(unsigned) * nTb * nIblk));
+    MIKC(h->sp_xoff.ensure(sizeof(int) * 9));
+    MIKC(h->sp_stats.ensure(sizeof(unsigned long long) * 2 * (size_t)nchunks));
+    sp_host.assign(2 * (size_t)nchunks, 0ULL);
+  }
   while (h->pr_events.size() < 2 * (size_t)nchunks) {
     hipEvent_t e;
     HIPC(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -2927,9 +3112,9 @@ static int one_predict(mik_handle* h) {
     a.M = h->M;
     a.Mp = Mp;
     a.ndim = h->ndim;
-    a.xs = h->xs.as<double>();
-    a.ys = h->ys.as<double>();
-    a.zs = h->zs.as<double>();
+    a.xs = h->factor_sorted ? h->xs_s.as<double>() : h->xs.as<double>();
+    a.ys = h->factor_sorted ? h->ys_s.as<double>() : h->ys.as<double>();
+    a.zs = h->factor_sorted ? h->zs_s.as<double>() : h->zs.as<double>();
     a.v = h->v;
     a.exact = h->exact;
     a.eps = h->eps;
@@ -2942,6 +3127,23 @@ static int one_predict(mik_handle* h) {
     a.cvec = h->cvec.as<double>();
     a.zout = h->z.as<double>() + t0;
     if (two && c >= 2) HIPC(hipStreamWaitEvent(sr, h->pr_events[2 * (c - 2) + 1], 0));  // the contraction that read this panel is done
+    if (sparse) {
+      // candidates (bounding boxes), cleared flags, then delta for the candidate blocks only
+      a.cand = h->sp_cand.as<unsigned char>();
+      a.flags = h->sp_flags.as<unsigned char>();
+      a.nIblk = nIblk;
+      a.nK16 = nK16;
+      a.sill = h->v.p0 + h->v.p2;
+      HIPC(hipEventRecord(h->evpool[2 + 4 * nchunks + 2 * c], sr));
+      hipLaunchKernelGGL(k_sp_cand, dim3(palloc / 128), dim3(128), 0, sr, a.px, a.py, a.pz, nvalid, (const double*)h->sbox.as<double>(), nIblk,
+                         h->N / 128, std::max(h->v.p1, h->eps), h->sp_cand.as<unsigned char>());
+      HIPC(hipMemsetAsync(h->sp_flags.p, 0, (size_t)(palloc / 128) * nK16, sr));
+      HIPC(hipEventRecord(h->evpool[2 + 4 * c], sr));
+      if (h->ndim == 3) hipLaunchKernelGGL((k_rhs<3, 3, true>), dim3(palloc / MIK_TP), dim3(256), 0, sr, a);
+      else hipLaunchKernelGGL((k_rhs<3, 2, true>), dim3(palloc / MIK_TP), dim3(256), 0, sr, a);
+      HIPC(hipEventRecord(h->evpool[3 + 4 * c], sr));
+      return MIK_OK;
+    }
     HIPC(hipEventRecord(h->evpool[2 + 4 * c], sr));
     if (h->model == MIK_MODEL_CUSTOM) {
       DISPATCH_NDIM_FIXED(7, h->geo ? 1 : h->ndim, k_rhs, dim3(palloc / MIK_TP), dim3(256), sr, a);
@@ -2966,6 +3168,49 @@ static int one_predict(mik_handle* h) {
       MIKC(launch_rhs(c));
     }
     hipEvent_t e1 = h->evpool[4 + 4 * c], e2 = h->evpool[5 + 4 * c];
+    if (sparse) {
+      const int nTb = palloc / 128;
+      hipLaunchKernelGGL(k_sp_lists, dim3(nTb), dim3(64), 0, sc, (const unsigned char*)h->sp_flags.as<unsigned char>(), nK16, nIblk,
+                         h->sp_klist.as<unsigned short>(), h->sp_kcount.as<int>(), h->sp_rows.as<unsigned short>(),
+                         h->sp_rstart.as<unsigned short>(), h->sp_nrows.as<int>());
+      hipLaunchKernelGGL(k_sp_tiles, dim3(1), dim3(1024), 0, sc, (const int*)h->sp_nrows.as<int>(), (const int*)h->sp_kcount.as<int>(),
+                         (const unsigned short*)h->sp_rstart.as<unsigned short>(), nIblk, nTb, h->sp_tiles.as<unsigned>(),
+                         h->sp_xoff.as<int>(), h->sp_stats.as<unsigned long long>() + 2 * c);
+      HIPC(hipEventRecord(h->evpool[3 + 4 * nchunks + 2 * c], sc));
+      MIKC(h->queue.ensure(8 * sizeof(unsigned long long)));
+      HIPC(hipMemsetAsync(h->queue.p, 0, 8 * sizeof(unsigned long long), sc));
+      SpArgs sa{};
+      sa.Ainv = h->T.as<double>();
+      sa.lda = Mp;
+      sa.Bt = h->Bt.as<double>();
+      sa.ldb = Mp;
+      sa.part = h->part.as<double>();
+      sa.palloc = palloc;
+      sa.kend = kend;
+      sa.nIblk = nIblk;
+      sa.nK16 = nK16;
+      sa.klist = h->sp_klist.as<unsigned short>();
+      sa.kcount = h->sp_kcount.as<int>();
+      sa.rows = h->sp_rows.as<unsigned short>();
+      sa.rstart = h->sp_rstart.as<unsigned short>();
+      sa.tiles = h->sp_tiles.as<unsigned>();
+      sa.xoff = h->sp_xoff.as<int>();
+      sa.queue = h->queue.as<unsigned long long>();
+      HIPC(hipEventRecord(e1, sc));
+      hipLaunchKernelGGL((k_contract_sp<2>), dim3((unsigned)std::min<long>(2L * h->n_cu, (long)nTb * nIblk)), dim3(512), 0, sc, sa);
+      HIPC(hipEventRecord(e2, sc));
+      hipLaunchKernelGGL(k_ss_reduce_sp, dim3((nvalid + 255) / 256), dim3(256), 0, sc, (const double*)h->part.as<double>(), palloc,
+                         (const int*)h->sp_nrows.as<int>(), nvalid, 2.0 * (h->v.p0 + h->v.p2), h->ss.as<double>() + t0);
+      HIPC(hipEventRecord(h->ev_chunk, sc));
+      HIPC(hipStreamWaitEvent(h->stream_d2h, h->ev_chunk, 0));
+      HIPC(hipMemcpyAsync(h->pin_out.as<double>() + t0, h->z.as<double>() + t0, sizeof(double) * nvalid, hipMemcpyDeviceToHost,
+                          h->stream_d2h));
+      HIPC(hipMemcpyAsync(h->pin_out.as<double>() + npt + t0, h->ss.as<double>() + t0, sizeof(double) * nvalid,
+                          hipMemcpyDeviceToHost, h->stream_d2h));
+      h->tm.sparse_tiles_dense += (double)nTb * nIblk;
+      h->tm.sparse_ktiles_dense += (double)nTb * (kend / 16.0) * (nIblk - 1) / 2.0;  // off-diagonal K tiles of the dense symmetric form (about)
+      continue;
+    }
     HIPC(hipEventRecord(e1, sc));
     const long tiles = (long)nIblk * (palloc / 128);
     const unsigned grid = (unsigned)(8 * ((tiles + 7) / 8));
@@ -3033,6 +3278,23 @@ static int one_predict(mik_handle* h) {
     h->tm.rhs_ms += ms;
     HIPC(hipEventElapsedTime(&ms, h->evpool[4 + 4 * c], h->evpool[5 + 4 * c]));
     h->tm.contract_ms += ms;
+  }
+  if (sparse) {
+    HIPC(hipMemcpy(sp_host.data(), h->sp_stats.p, sizeof(unsigned long long) * sp_host.size(), hipMemcpyDeviceToHost));
+    const int ntl = (kend - (nIblk - 1) * 128) / 16;  // K tiles of the (short) last block
+    for (long c = 0; c < nchunks; ++c) {
+      HIPC(hipEventElapsedTime(&ms, h->evpool[2 + 4 * nchunks + 2 * c], h->evpool[2 + 4 * c]));
+      h->tm.sparse_lists_ms += ms;
+      HIPC(hipEventElapsedTime(&ms, h->evpool[3 + 4 * c], h->evpool[3 + 4 * nchunks + 2 * c]));
+      h->tm.sparse_lists_ms += ms;
+      const long nTb = (std::min<long>(chunk, npt - c * chunk) + 127) / 128;
+      const double tiles = (double)sp_host[2 * c], offk = (double)sp_host[2 * c + 1];
+      h->tm.sparse_tiles += tiles;
+      h->tm.sparse_ktiles += offk;
+      // executed flops: off-diagonal K tiles are 128 x 16 x 128 products; a diagonal block is nt (nt + 1) / 2 products of 16 rows x 16 k
+      // x 128 points (nt = 8, or the short last block's -- every point block has that row block: the last row is the 1 of ok.py:673)
+      h->tm.contract_flops_executed += 2.0 * 128.0 * 16.0 * 128.0 * offk + 2.0 * 16.0 * 16.0 * 128.0 * (36.0 * std::max(0.0, tiles - (double)nTb) + (ntl * (ntl + 1) / 2) * (double)nTb);
+    }
   }
   h->tm.contract_launches = nchunks;
   h->tm.rhs_overlapped = two ? 1 : 0;
@@ -3513,6 +3775,17 @@ int mik_take_results(mik_handle* h, double** z_out, double** ss_out) {
   if (!h->have_results) return fail(MIK_ESTATE, "mik_take_results: predict first");
   if (!h->kids.empty() || h->masked || !h->scatter.empty() || h->scatter32 || h->out_off != 0 || h->npt != h->npt_total || h->npt == 0)
     return fail(MIK_ESTATE, "mik_take_results: only for one device and unmasked points (use mik_get_results)");
+  {  // page-locked memory out on loan is bounded (a caller that keeps many results -- time steps, CV folds -- would otherwise pin
+     // without limit): beyond MIK_PIN_LENT_CAP bytes (default 4 GiB) the copying mik_get_results is the call
+    static const double cap = env_seconds("MIK_PIN_LENT_CAP", 4294967296.0);
+    size_t lent = 0;
+    {
+      std::lock_guard<std::mutex> lk(g_pin_mutex);
+      for (const auto& kv : g_pin_lent) lent += kv.second;
+    }
+    if ((double)lent + (double)h->pin_out.bytes > cap)
+      return fail(MIK_ESTATE, "mik_take_results: page-locked memory on loan would exceed MIK_PIN_LENT_CAP (use mik_get_results)");
+  }
   HIPC(hipSetDevice(h->device));
   HIPC(hipEventSynchronize(h->ev_d2h));
   const size_t bytes = h->pin_out.bytes;
@@ -3721,6 +3994,7 @@ int mik_bcast_factor(mik_handle* h, int root) {
     g_rccl_dead.store(true);
   }
   MIKC(rc);
+  if (h->rank != root) h->factor_sorted = want_sorted(h);  // the root decided by the same rule on the same problem and options
   h->have_factor = true;
   h->t_state = 2;
   h->have_results = false;

@@ -1,0 +1,209 @@
+"""Range-aware contraction for the reference's compact-support variogram (spherical: constant beyond the range,
+variogram_models.py:56-70): sigma^2 = 2 s - delta^T A_inv delta, z = c . delta with delta = b + s u (include/mikrige.h, option
+"sparse"; k_rhs<.., SP>, k_sp_*, k_contract_sp).
+
+CPU: the identity itself on the oracle's matrices, and the Hilbert-curve station order (mik_station_order needs no GPU).
+GPU: the sparse path against the oracle, against the dense path of the same library, and against the reference's stored answers
+(every spherical fixture; the full-size config-5 slab), at BASELINE's tolerances |dz| <= 1e-8, |dsigma^2| <= 1e-6."""
+import numpy as np
+import pytest
+
+from oracle import kriging_oracle as ko
+from tests import _fixtures as fx
+
+Z_TOL, SS_TOL = 1e-8, 1e-6
+
+
+# ---------------------------------------------------------------------------------------------- CPU
+def test_identity_on_the_oracle_matrices():
+    """delta = b + s u  =>  sigma^2 = 2 s - delta^T A^-1 delta and z = c . delta, with and without drift rows (uk.py:915-918: the last
+    column of the matrix is [1_N; 0] there too)."""
+    rng = np.random.default_rng(7)
+    n = 400
+    x, y = rng.random(n), rng.random(n)
+    v = np.sin(6 * x) * np.cos(4 * y) + 0.1 * rng.standard_normal(n)
+    par = [1.0, 0.25, 0.02]
+    for rl in (False, True):
+        st = ko.KrigingState(ndim=2, coords_orig=np.stack([x, y], 1), values=v, model="spherical",
+                             params=ko.internal_parameters("spherical", par), regional_linear=rl)
+        a = ko.kriging_matrix(st)
+        ainv = np.linalg.inv(a)
+        px, py = rng.random(50), rng.random(50)
+        px[:3], py[:3] = x[:3], y[:3]  # exact hits: b_k = 0, delta_k = s
+        zr, sr = ko.execute(st, "points", px, py)
+        s = par[0]  # user parameters are [full sill, range, nugget]: s = psill + nugget
+        m = a.shape[0]
+        for t in range(50):
+            d = np.hypot(x - px[t], y - py[t])
+            gam = ko.variogram(st.model, st.params, d)
+            b = np.zeros(m)
+            b[:n] = -gam
+            b[:n][d <= 1e-10] = 0.0
+            if rl:
+                b[n], b[n + 1] = px[t], py[t]
+            b[m - 1] = 1.0
+            delta = b.copy()
+            delta[:n] += s
+            assert np.all(delta[:n][d > par[1]] == 0.0)  # exactly zero beyond the range
+            c = ainv[:, :n] @ v
+            assert abs(c @ delta - zr[t]) < 1e-9
+            assert abs(2 * s - delta @ ainv @ delta - sr[t]) < 1e-9
+
+
+def test_station_order_is_a_hilbert_curve():
+    """On a 2^k lattice consecutive stations of the order are lattice neighbours (2-D and 3-D); on random stations 16 consecutive
+    ones are spatially compact; the order is a permutation and deterministic."""
+    from pykrige_amd import _lib
+
+    k = 16
+    gx, gy = np.meshgrid(np.arange(k, dtype=float), np.arange(k, dtype=float))
+    o = _lib.station_order(gx.ravel(), gy.ravel())
+    assert sorted(o.tolist()) == list(range(k * k))
+    step = np.abs(np.diff(gx.ravel()[o])) + np.abs(np.diff(gy.ravel()[o]))
+    assert np.all(step == 1.0)
+    k = 8
+    g3 = np.stack(np.meshgrid(*[np.arange(k, dtype=float)] * 3, indexing="ij"), -1).reshape(-1, 3)
+    o = _lib.station_order(g3[:, 0], g3[:, 1], g3[:, 2])
+    assert sorted(o.tolist()) == list(range(k ** 3))
+    assert np.all(np.abs(np.diff(g3[o], axis=0)).sum(1) == 1.0)
+    rng = np.random.default_rng(5)
+    x, y = rng.random(8000), rng.random(8000)
+    o = _lib.station_order(x, y)
+    assert np.array_equal(o, _lib.station_order(x, y))
+    xs, ys = x[o].reshape(-1, 16), y[o].reshape(-1, 16)
+    diam = np.hypot(xs.max(1) - xs.min(1), ys.max(1) - ys.min(1))
+    assert np.median(diam) < 4.0 * np.sqrt(16 / 8000.0)  # a random 16-subset would span the unit square
+
+
+# ---------------------------------------------------------------------------------------------- GPU
+def _run(m, style, args, sparse, chunk=None, **kw):
+    h = m._get_handle()
+    h.set_option("sparse", sparse)
+    if chunk:
+        h.set_option("chunk", chunk)
+    z, ss = m.execute(style, *args, **kw)
+    return np.ma.getdata(z), np.ma.getdata(ss), dict(m.last_timing)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["ok2d", "ok2d_short_range", "uk2d", "ok3d", "uk3d_aniso", "ok2d_noexact", "ok2d_aniso"])
+def test_sparse_contraction_against_oracle_and_dense(case):
+    import pykrige_amd as pa
+
+    rng = np.random.default_rng(11)
+    n = 1500
+    if case in ("ok3d", "uk3d_aniso"):
+        (x, y, zc), v = fx.synth(3, n, 3)
+        axes = [np.linspace(0, 1, 23), np.linspace(0, 1, 19), np.linspace(0, 1, 11)]
+        for k in range(6):
+            x[k], y[k], zc[k] = axes[0][3 * k], axes[1][2 * k], axes[2][k]
+        par = [1.0, 0.35, 0.02]
+        if case == "ok3d":
+            m = pa.OrdinaryKriging3D(x, y, zc, v, variogram_model="spherical", variogram_parameters=par)
+            st = ko.KrigingState(ndim=3, coords_orig=np.stack([x, y, zc], 1), values=v, model="spherical",
+                                 params=ko.internal_parameters("spherical", par), scaling=[1.0, 1.0], angle=[0.0, 0.0, 0.0])
+        else:
+            m = pa.UniversalKriging3D(x, y, zc, v, variogram_model="spherical", variogram_parameters=par, drift_terms=["regional_linear"],
+                                      anisotropy_scaling_y=1.4, anisotropy_scaling_z=0.8, anisotropy_angle_x=10.0, anisotropy_angle_y=20.0,
+                                      anisotropy_angle_z=30.0)
+            st = ko.KrigingState(ndim=3, coords_orig=np.stack([x, y, zc], 1), values=v, model="spherical",
+                                 params=ko.internal_parameters("spherical", par), scaling=[1.4, 0.8], angle=[10.0, 20.0, 30.0],
+                                 regional_linear=True)
+    else:
+        (x, y), v = fx.synth(2, n, 2)
+        axes = [np.linspace(0, 1, 161), np.linspace(0, 1, 53)]
+        for k in range(8):
+            x[k], y[k] = axes[0][15 * k + 1], axes[1][3 * k + 2]
+        par = [1.0, 0.08, 0.0] if case == "ok2d_short_range" else [1.0, 0.2, 0.01]
+        kw = dict(exact_values=False) if case == "ok2d_noexact" else {}
+        okw = dict(exact_values=False) if case == "ok2d_noexact" else {}
+        if case == "ok2d_aniso":
+            kw.update(anisotropy_scaling=2.5, anisotropy_angle=35.0)
+            okw.update(scaling=[2.5], angle=[35.0])
+        if case == "uk2d":
+            wells = [[0.3137, 0.7219, 1.0], [0.6621, 0.2483, -0.5]]
+            m = pa.UniversalKriging(x, y, v, variogram_model="spherical", variogram_parameters=par,
+                                    drift_terms=["regional_linear", "point_log"], point_drift=wells)
+            st = ko.KrigingState(ndim=2, coords_orig=np.stack([x, y], 1), values=v, model="spherical",
+                                 params=ko.internal_parameters("spherical", par), regional_linear=True, point_log=np.array(wells))
+        else:
+            m = pa.OrdinaryKriging(x, y, v, variogram_model="spherical", variogram_parameters=par, **kw)
+            st = ko.KrigingState(ndim=2, coords_orig=np.stack([x, y], 1), values=v, model="spherical",
+                                 params=ko.internal_parameters("spherical", par), **okw)
+    zr, sr = ko.execute(st, "grid", *axes)
+    zd, sd, td = _run(m, "grid", axes, 0)
+    assert td["sparse"] == 0 and td["stations_sorted"] == 0
+    for chunk in (131072, 2048):
+        zs, ss, ts = _run(m, "grid", axes, 1, chunk=chunk)
+        assert ts["sparse"] == 1 and ts["stations_sorted"] == 1
+        assert 0 < ts["sparse_tiles"] <= ts["sparse_tiles_dense"]
+        assert np.abs(zs - zr).max() <= Z_TOL and np.abs(ss - sr).max() <= SS_TOL, (np.abs(zs - zr).max(), np.abs(ss - sr).max())
+        assert np.abs(zs - zd).max() <= Z_TOL and np.abs(ss - sd).max() <= SS_TOL
+    if case == "ok2d_short_range":
+        assert ts["sparse_tiles"] < 0.6 * ts["sparse_tiles_dense"], ts  # range 0.08 of the unit square: most tiles are skipped
+    # Hilbert-ordered stations with the dense contraction (option 2): the order alone changes nothing beyond rounding
+    zo, so, to = _run(m, "grid", axes, 2)
+    assert to["sparse"] == 0 and to["stations_sorted"] == 1
+    assert np.abs(zo - zr).max() <= Z_TOL and np.abs(so - sr).max() <= SS_TOL
+    # points and masked styles through the sparse path (points in random order: every block is active; still exact)
+    pts = [rng.random(700) for _ in axes]
+    zp, sp = ko.execute(st, "points", *pts)
+    zs, ss, ts = _run(m, "points", pts, 1)
+    assert ts["sparse"] == 1
+    assert np.abs(zs - zp).max() <= Z_TOL and np.abs(ss - sp).max() <= SS_TOL
+    if len(axes) == 2:
+        mask = rng.random((axes[1].size, axes[0].size)) < 0.4
+        zs, ss, ts = _run(m, "masked", axes, 1, mask=mask)
+        assert ts["sparse"] == 1
+        assert np.abs(zs - zr)[~mask].max() <= Z_TOL and np.abs(ss - sr)[~mask].max() <= SS_TOL
+
+
+@pytest.mark.gpu
+def test_sparse_factor_is_handed_out_in_the_callers_order():
+    """mik_get_matrix(1) un-permutes the Hilbert-ordered factor: equal to the dense path's inverse and to LAPACK's."""
+    from tests.test_hip_parity import _handle_for
+
+    (x, y), v = fx.synth(4, 500, 2)
+    st = ko.KrigingState(ndim=2, coords_orig=np.stack([x, y], 1), values=v, model="spherical",
+                         params=ko.internal_parameters("spherical", [1.0, 0.3, 0.02]), regional_linear=True)
+    ref = np.linalg.inv(ko.kriging_matrix(st))
+    for sparse in (0, 1):
+        h = _handle_for(st, sparse=sparse)
+        h.factor()
+        got = h.get_matrix(1)
+        assert np.abs(got - ref).max() <= 1e-9 * np.abs(ref).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", [n for n in fx.names() if "spherical" in n])
+def test_sparse_path_on_the_reference_fixtures(name):
+    """Every spherical execute fixture of the real reference through the sparse path (forced: they are small)."""
+    g = fx.load(name)
+    m = fx.amd_model_from(name, g)
+    m._get_handle().set_option("sparse", 1)
+    z, ss = m.execute("grid", *fx.grid_args(g))
+    assert m.last_timing["sparse"] == 1
+    scale = max(1.0, float(np.abs(g["z"]).max()))
+    assert np.abs(np.ma.getdata(z) - g["z"]).max() <= Z_TOL * scale
+    assert np.abs(np.ma.getdata(ss) - g["ss"]).max() <= SS_TOL * scale
+
+
+@pytest.mark.gpu
+def test_sparse_path_in_a_device_group():
+    """A 3-member group (aliased onto the one GPU): the members sort their copies of the stations the same way, the broadcast
+    factor is in that order; results equal one device's bit for bit."""
+    import pykrige_amd as pa
+
+    (x, y), v = fx.synth(9, 1300, 2)
+    axes = [np.linspace(0, 1, 140), np.linspace(0, 1, 37)]
+    outs = []
+    for ndev in (1, 3):
+        m = pa.OrdinaryKriging(x, y, v, variogram_model="spherical", variogram_parameters=[1.0, 0.15, 0.01])
+        h = m._get_handle()
+        h.set_option("sparse", 1)
+        if ndev > 1:
+            h.set_devices(ndev, alias=True)
+        z, ss = m.execute("grid", *axes)
+        assert m.last_timing["sparse"] == 1
+        outs.append((np.ma.getdata(z).copy(), np.ma.getdata(ss).copy()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
