@@ -283,6 +283,43 @@ class _SharedResults:
             self.shm, self.npt = None, -1
 
 
+def _ranks_share_a_node(pg):
+    """True when every rank can open a shared-memory segment rank 0 created and reads rank 0's nonce in it.  (Comparing host
+    names is not enough: cloned images and containers named alike share a name without sharing /dev/shm; results would then
+    silently be each node's own slabs.)"""
+    from multiprocessing import shared_memory
+
+    shm, name, nonce = None, None, None
+    if pg.rank == 0:
+        try:
+            nonce = os.urandom(16)
+            shm = shared_memory.SharedMemory(create=True, size=16)
+            shm.buf[:16] = nonce
+            name = shm.name
+        except Exception:  # noqa: BLE001
+            shm, name = None, None
+    name, nonce = pg.broadcast_object((name, nonce), src=0)
+    ok = name is not None
+    if ok and pg.rank != 0:
+        try:
+            other = shared_memory.SharedMemory(name=name)
+            try:
+                from multiprocessing import resource_tracker
+
+                resource_tracker.unregister(other._name, "shared_memory")  # the creator unlinks
+            except Exception:  # noqa: BLE001
+                pass
+            ok = bytes(other.buf[:16]) == nonce
+            other.close()
+        except Exception:  # noqa: BLE001
+            ok = False
+    oks = pg.all_gather_object(bool(ok))  # (also: nobody still has the probe open when rank 0 unlinks it)
+    if shm is not None:
+        shm.close()
+        shm.unlink()
+    return all(oks)
+
+
 class ShardedExecutor:
     """execute() of a pykrige_amd kriging object with the points sharded over the ranks of a process group: group=None
     builds a `SocketGroup` from the launcher's environment (no torch); a `SocketGroup` or a torch.distributed group can be
@@ -313,8 +350,7 @@ class ShardedExecutor:
         if self.exchange == "rccl_bcast":
             self.exchange = init_rccl(self._handle, self.pg)
         # a shared-memory segment only exists on ONE node: ranks on different hosts gather through the group instead
-        hosts = self.pg.all_gather_object(socket.gethostname()) if self.world > 1 else [socket.gethostname()]
-        self.single_node = len(set(hosts)) == 1
+        self.single_node = _ranks_share_a_node(self.pg) if self.world > 1 else True
         self._shared = _SharedResults(self.pg)
 
     def close(self):

@@ -294,3 +294,32 @@ def test_execute_points_is_the_same_with_device_and_host_adjustment(monkeypatch)
         np.testing.assert_allclose(np.ma.getdata(z1), np.ma.getdata(z0), rtol=0, atol=1e-11)
         np.testing.assert_allclose(np.ma.getdata(s1), np.ma.getdata(s0), rtol=0, atol=1e-11)
         assert np.abs(np.ma.getdata(s1)[:5]).max() <= 1e-9 or m.variogram_model_parameters[-1] > 0  # exact hits (zero nugget)
+
+
+@pytest.mark.gpu
+def test_empty_cell_range_is_empty_not_the_whole_grid():
+    """mik_grid.cell_count = 0 is an EMPTY range (a rank of a sharded run with more ranks than cells), -1 the whole grid (round-3
+    advisor finding: 0 used to mean the whole grid, and the caller's zero-length result arrays were overrun)."""
+    from pykrige_amd import _lib
+
+    rng = np.random.default_rng(3)
+    x, y, v = rng.random(40), rng.random(40), rng.random(40)
+    h = _lib.Handle(0)
+    h.set_problem(ndim=2, xs=x, ys=y, zs=None, values=v, model_id=_lib.MODEL_IDS["exponential"], params=[0.9, 0.3, 0.1])
+    h.factor()
+    gx, gy = np.linspace(0, 1, 7), np.linspace(0, 1, 5)
+    h.set_grid((gx, gy))
+    h.predict()
+    zall, sall = (a.copy() for a in h.get_results())
+    assert zall.size == 35
+    for mask in (None, np.zeros(0, dtype=bool)):
+        h.set_grid((gx, gy), cell_range=(35, 0), mask=mask)
+        assert h._lib.mik_points_resident(h._h) == 0
+        h.predict()
+        z, ss = h.get_results()
+        assert z.size == 0 and ss.size == 0
+    h.set_grid((gx, gy), cell_range=(10, 5))
+    h.predict()
+    z, ss = h.get_results()
+    assert np.array_equal(z, zall[10:15]) and np.array_equal(ss, sall[10:15])
+    h.close()

@@ -169,7 +169,13 @@ def _sock_worker(rank, world, port, q):
         zwr, swr = ko.solve_points_moving_window(st, np.stack([a.ravel() for a in np.meshgrid(g[2], g[1], g[0], indexing="ij")][::-1], 1), 7)
         okw = np.allclose(zw.ravel(), zwr, atol=1e-12) and np.allclose(sw.ravel(), swr, atol=1e-12) and hdl.calls[-1] == "predict_moving_window" \
             and hdl.calls.count("factor") == 1
-        q.put((rank, bool(okw and np.allclose(z, zr, atol=1e-12) and np.allclose(ss, sr, atol=1e-12) and z.shape == (3, 4, 5)), len(hdl.pts)))
+        npts3 = len(hdl.pts)
+        # more ranks than cells (round-3 advisor finding): a 2-cell grid on 3 ranks leaves the last rank an EMPTY slab -- cell_range
+        # (lo, 0) must mean "nothing", not "the whole grid"
+        z2, ss2 = ex.execute("grid", np.array([0.25, 0.75]), np.array([0.5]), np.array([0.5]), backend="loop")
+        z2r, s2r = ko.execute(st, "grid", np.array([0.25, 0.75]), np.array([0.5]), np.array([0.5]))
+        ok2 = z2.shape == (1, 1, 2) and np.allclose(z2, z2r, atol=1e-12) and np.allclose(ss2, s2r, atol=1e-12) and len(hdl.pts) == (1 if rank < 2 else 0)
+        q.put((rank, bool(ok2 and okw and np.allclose(z, zr, atol=1e-12) and np.allclose(ss, sr, atol=1e-12) and z.shape == (3, 4, 5)), npts3))
     finally:
         pg.close()
 
