@@ -90,22 +90,39 @@ def shard_points(cfg, rank, world):
     return [X.ravel(), Y.ravel(), Z.ravel()]
 
 
-def row_slab(cfg, min_points):
-    """>= min_points points of the config's own grid as whole rows from the middle of it (the
-    reference is timed on row slabs via style='grid' with a y-subrange), in the reference's meshgrid order."""
+def row_slab_axes(cfg, min_points):
+    """Axes of a row slab of the config's own grid with >= min_points points, whole rows from the middle of it (BASELINE.md
+    section 3: the reference is timed on row slabs via style='grid' with a y-subrange)."""
     g = cfg["grid"]
     nx = g[0]
+    rows = int(np.ceil(min_points / nx))
     if cfg["ndim"] == 2:
         ny_all = 4096 if cfg["n"] == 8000 else g[1]  # config 5's grid is 4096 x 4096 (CONFIGS holds one GPU's 512 rows)
-        rows = int(np.ceil(min_points / nx))
-        gy = np.linspace(0.0, 1.0, ny_all)[ny_all // 2:ny_all // 2 + rows]
-        X, Y = np.meshgrid(np.linspace(0.0, 1.0, nx), gy)
+        return [np.linspace(0.0, 1.0, nx), np.linspace(0.0, 1.0, ny_all)[ny_all // 2:ny_all // 2 + rows]]
+    return [np.linspace(0.0, 1.0, nx), np.linspace(0.0, 1.0, g[1])[g[1] // 4:g[1] // 4 + rows],
+            np.linspace(0.0, 1.0, g[2])[g[2] // 2:g[2] // 2 + 1]]
+
+
+def row_slab(cfg, min_points):
+    """The points of row_slab_axes in the reference's meshgrid order."""
+    ax = row_slab_axes(cfg, min_points)
+    if cfg["ndim"] == 2:
+        X, Y = np.meshgrid(ax[0], ax[1])
         return np.stack([X.ravel(), Y.ravel()], 1)
-    rows = int(np.ceil(min_points / nx))
-    gy = np.linspace(0.0, 1.0, g[1])[g[1] // 4:g[1] // 4 + rows]
-    gz = np.linspace(0.0, 1.0, g[2])[g[2] // 2:g[2] // 2 + 1]
-    Z, Y, X = np.meshgrid(gz, gy, np.linspace(0.0, 1.0, nx), indexing="ij")
+    Z, Y, X = np.meshgrid(ax[2], ax[1], ax[0], indexing="ij")
     return np.stack([X.ravel(), Y.ravel(), Z.ravel()], 1)
+
+
+def reference_model(pk, cfg, coords, values):
+    """The REAL reference's class for a config (oracle/ref_package.py: the package as written upstream, staged by
+    oracle/build_ref.sh), constructor statistics stubbed as BASELINE.md section 3 prescribes."""
+    kw = dict(variogram_model=cfg["model"], variogram_parameters=list(cfg["params"]))
+    if cfg["ndim"] == 3:
+        return pk.ok3d.OrdinaryKriging3D(coords[0], coords[1], coords[2], values, **kw)
+    if cfg.get("rl") or cfg.get("wells"):
+        terms = (["regional_linear"] if cfg.get("rl") else []) + (["point_log"] if cfg.get("wells") else [])
+        return pk.uk.UniversalKriging(coords[0], coords[1], values, drift_terms=terms, point_drift=cfg.get("wells"), **kw)
+    return pk.ok.OrdinaryKriging(coords[0], coords[1], values, **kw)
 
 
 def host_description():
@@ -214,6 +231,29 @@ def cpu_baseline(cfg, coords, values, sample_pts, window=None, full=False):
            "what": "NumPy/SciPy restatement of backend='vectorized' (oracle/kriging_oracle.py), 4096-point dgemm slabs, best of %d" % repeats,
            "full_grid_projection": npt_full / (t_mat + t_inv + npt_full * t_vec / n_slab)}
     out["vectorized"] = vec
+    # backend='vectorized' of the reference ITSELF (ok.py:650-683, uk.py:922-1009, ok3d.py:624-657 as written upstream: the staged
+    # package, oracle/ref_package.py) on the same slab through execute('grid', slab axes): kind "reference" for every config
+    from oracle import ref_package as rp
+
+    zv_ref = None
+    if rp.available():
+        try:
+            pk = rp.import_reference(stub_statistics=True)
+            rm = reference_model(pk, cfg, coords, values)
+            slab_axes = row_slab_axes(cfg, n_slab)
+            t_ref, (zr_, sr_) = best_of(lambda: rm.execute("grid", *slab_axes, backend="vectorized"), repeats)
+            zv_ref, ssv_ref = np.ma.getdata(zr_).ravel(), np.ma.getdata(sr_).ravel()
+            t_steady = max(t_ref - t_mat - t_inv, 1e-9)
+            vec = {"value": n_slab / t_ref, "steady_state": n_slab / t_steady, "kind": "reference", "cores": vec["cores"],
+                   "what": "the reference's own %s.execute('grid', row slab, backend='vectorized') (staged package, _find_statistics "
+                           "stubbed), best of %d, incl. its matrix assembly and scipy.linalg.inv" % (type(rm).__name__, repeats),
+                   "full_grid_projection": npt_full / (t_mat + t_inv + npt_full * t_steady / n_slab),
+                   "port_vs_reference_max_abs_dz": float(np.abs(zv - zv_ref).max()),
+                   "port_vs_reference_max_abs_dss": float(np.abs(ssv - ssv_ref).max()), "port": vec}
+            out["vectorized"] = vec
+            zv, ssv = zv_ref, ssv_ref
+        except Exception as e:  # noqa: BLE001
+            vec["reference_error"] = repr(e)[:200]
     if use_c:
         # thread sweep on the loop's hot operation itself -- one dgemv of the Fortran-ordered inverse per point
         # (cok.pyx:41, 71-83) -- so that the choice is not blurred by the inverse the native call repeats every time
@@ -253,7 +293,7 @@ def cpu_baseline(cfg, coords, values, sample_pts, window=None, full=False):
                    c_vs_vectorized_max_abs_dss=float(np.abs(ss - ssv).max()))
     else:
         z, ss = zv, ssv
-        out.update(value=vec["value"], cores=vec["cores"], kind="port", sample="%d-point row slab of the same grid: %s" % (n_slab, vec["what"]),
+        out.update(value=vec["value"], cores=vec["cores"], kind=vec["kind"], sample="%d-point row slab of the same grid: %s" % (n_slab, vec["what"]),
                    steady_state=vec["steady_state"], full_grid_projection=vec["full_grid_projection"])
     return out, (pts, z, ss)
 
@@ -320,6 +360,95 @@ def make_model(cfg, coords, values):
     return pa.OrdinaryKriging(coords[0], coords[1], values, **kw)
 
 
+def sparse_summary(t):
+    """mik_timing's account of the range-aware contraction (last execute()): tiles contracted / tiles of the dense symmetric form."""
+    return {"tiles_contracted": t["sparse_tiles"], "tiles_dense": t["sparse_tiles_dense"],
+            "tile_fraction": t["sparse_tiles"] / max(1.0, t["sparse_tiles_dense"]),
+            "offdiag_ktiles_contracted": t["sparse_ktiles"], "offdiag_ktiles_dense": t["sparse_ktiles_dense"],
+            "ktile_fraction": t["sparse_ktiles"] / max(1.0, t["sparse_ktiles_dense"]),
+            "list_kernels_ms": t["sparse_lists_ms"], "stations_in_hilbert_order": bool(t["stations_sorted"])}
+
+
+def golden_slab(cno):
+    """tests/golden/fullsize/c<cno>.npz: a >= 16 384-point row slab of the config's own grid kriged by the REAL reference
+    (oracle/make_golden_fullsize.py), with the stations it used (8 of them moved onto grid nodes)."""
+    f = os.path.join(ROOT, "tests", "golden", "fullsize", "c%d.npz" % cno)
+    with np.load(f, allow_pickle=False) as g:
+        return {k: g[k] for k in g.files}
+
+
+def other_config_line(cno, window=None, steps=3, warmup=1):
+    """One of BASELINE's other configurations under the same clock as the headline (round-3 review: only config 2 was driver-timed):
+    `steps` execute('grid') calls of the drop-in class after `warmup`, MIK_FACTOR_CACHE=0, no CPU leg, no PMC; then the stored
+    reference slab of that configuration (tests/golden/fullsize) kriged by the same class and compared."""
+    cfg = CONFIGS[cno]
+    ndim = cfg["ndim"]
+    coords, values = synth(cfg["seed"], cfg["n"], ndim)
+    axes = grid_axes(cfg, 1)
+    npt = int(np.prod([a.size for a in axes]))
+    m = make_model(cfg, coords, values)
+    hh = m._get_handle()
+    kw = dict(backend="loop")
+    if window:
+        kw["n_closest_points"] = window
+    for _ in range(warmup):
+        m.execute("grid", *axes, **kw)
+    hh.synchronize()
+    acc = dict(contract_ms=0.0, contract_flops_executed=0.0, contract_launches=0, invert_ms=0.0, rhs_ms=0.0, predict_ms=0.0)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        m.execute("grid", *axes, **kw)
+        for k in acc:
+            acc[k] += m.last_timing[k]
+    hh.synchronize()
+    dt = time.perf_counter() - t0
+    last = dict(m.last_timing)
+    M = cfg["n"] + (ndim if cfg.get("rl") else 0) + (len(cfg["wells"]) if cfg.get("wells") else 0) + 1
+    line = {"workload": cfg["name"] + (", moving window n_closest_points=%d" % window if window else ""), "value": npt * steps / dt,
+            "unit": "grid-points/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup, "grid_points": npt,
+            "phases_ms_per_step": {"invert": acc["invert_ms"] / steps, "rhs": acc["rhs_ms"] / steps, "contract": acc["contract_ms"] / steps,
+                                   "predict_total": acc["predict_ms"] / steps}}
+    if window:
+        nn = window + 1.0
+        flops_pt = 2.0 / 3.0 * nn ** 3 + 2.0 * nn ** 2  # the reference's dgesv per point (cok.pyx:165)
+        ach = flops_pt * npt * steps / (acc["contract_ms"] * 1e-3) / 1e12 if acc["contract_ms"] > 0 else 0.0
+        line["roofline"] = {"bound": "mfma", "kernel": MW_KERNELS.get(last.get("mw_kernel"), "?"), "achieved": ach, "unit": "TFLOP/s",
+                            "peak": FP64_MFMA_PEAK_TFLOPS, "frac": ach / FP64_MFMA_PEAK_TFLOPS, "algorithmic_flops_per_point": flops_pt}
+    else:
+        ach = acc["contract_flops_executed"] / (acc["contract_ms"] * 1e-3) / 1e12 if acc["contract_ms"] > 0 else 0.0
+        useful = float(M) * M * npt * steps / (acc["contract_ms"] * 1e-3) / 1e12 if acc["contract_ms"] > 0 else 0.0
+        line["roofline"] = {"bound": "mfma", "kernel": "k_contract_sp" if last.get("sparse") else "k_contract", "achieved": ach,
+                            "unit": "TFLOP/s", "peak": FP64_MFMA_PEAK_TFLOPS, "frac": ach / FP64_MFMA_PEAK_TFLOPS,
+                            "useful_tflops": useful, "avg_launch_ms": acc["contract_ms"] / max(1, acc["contract_launches"])}
+        if last.get("sparse"):
+            line["roofline"]["sparse"] = sparse_summary(last)
+    # parity on the stored reference slab
+    try:
+        import pykrige_amd as pa
+
+        if window:
+            with np.load(os.path.join(ROOT, "tests", "golden", "fullsize", "mw_c2.npz"), allow_pickle=False) as f:
+                g = {k: f[k] for k in f.files}
+            gm = pa.OrdinaryKriging(g["x"], g["y"], g["v"], variogram_model=str(g["model"]), variogram_parameters=g["params_user"].tolist())
+            z, ss = gm.execute("grid", g["gridx"], g["gridy"], backend="loop", n_closest_points=window)
+            zr, sr, src = g["z_k%d" % window], g["ss_k%d" % window], "tests/golden/fullsize/mw_c2.npz (reference backend='C')"
+        else:
+            g = golden_slab(cno)
+            gcfg = dict(cfg)
+            gm = make_model(gcfg, [g["x"], g["y"]] + ([g["zc"]] if ndim == 3 else []), g["v"])
+            z, ss = gm.execute("grid", *([g["gridx"], g["gridy"]] + ([g["gridz"]] if ndim == 3 else [])), backend="loop")
+            zr, sr, src = g["z"], g["ss"], "tests/golden/fullsize/c%d.npz (reference backend='vectorized')" % cno
+        line["max_abs_dz"] = float(np.abs(np.ma.getdata(z) - zr).max())
+        line["max_abs_dss"] = float(np.abs(np.ma.getdata(ss) - sr).max())
+        line["parity_points"] = int(zr.size)
+        line["parity_source"] = src
+        gm._get_handle().close()
+    except Exception as e:  # noqa: BLE001
+        line["parity_error"] = repr(e)[:200]
+    hh.close()
+    return line
+
+
 MW_KERNELS = {1: "k_mw_chol", 2: "k_mw_solve", 3: "k_mw_solve_big", 4: "k_mw_chol_blocked"}
 FACTOR_PATHS = {1: "spd-shift block sweep", 2: "pivoted block gauss-jordan", 3: "caller-supplied inverse", 4: "device pseudo-inverse (jacobi)",
                 5: "deflated inverse (pseudo-inverse of duplicated stations)", 6: "deflated inverse (numerically found null space)"}
@@ -346,6 +475,15 @@ def main():
     ap.add_argument("--factor", choices=["auto", "sweep", "lu"], default=None, help="force the inverse path")
     ap.add_argument("--moving-window", type=int, default=None, metavar="K",
                     help="time moving-window kriging (n_closest_points=K) on the same workload instead (not the headline metric)")
+    ap.add_argument("--sparse", type=int, default=None, choices=[-1, 0, 1, 2],
+                    help="library option 'sparse' (range-aware contraction of the spherical model; default: the library's, on)")
+    ap.add_argument("--no-trials", action="store_true", default=os.environ.get("MIK_BENCH_TRIALS", "1") == "0",
+                    help="device groups: skip the exchange / overlap trials before the timed loop (also MIK_BENCH_TRIALS=0)")
+    ap.add_argument("--pretrial-budget", type=float, default=float(os.environ.get("MIK_BENCH_PRETRIAL_BUDGET", "60")), metavar="S",
+                    help="device groups: wall-clock seconds the trials before the timed loop may take in total (default 60); what "
+                         "does not fit is skipped and config.factor_exchange_trial says so")
+    ap.add_argument("--no-other", action="store_true",
+                    help="default run (config 2, 1 GPU): do not time BASELINE configs 3-5 and the moving window after the headline")
     args = ap.parse_args()
     inner = os.environ.get("MIK_BENCH_INNER") == "1"  # a rocprofv3 pass of collect_traffic_live: no CPU leg, no recursion
 
@@ -444,6 +582,8 @@ def main():
             hh.set_option("engine", 1 if args.engine == "valu" else 0)
         if args.factor is not None:
             hh.set_option("factor", {"auto": 0, "sweep": 1, "lu": 2}[args.factor])
+        if args.sparse is not None:
+            hh.set_option("sparse", args.sparse)
         return m, hh
 
     progress["stage"] = "create the kriging object and its device handle"
@@ -459,11 +599,25 @@ def main():
     # best for the broadcast and costs N-1 redundant O(M^3) factorisations of energy).  Every trial is bounded by the
     # library's own limits (a stalled RCCL call is abandoned, reported, and the next path runs).
     exchange, trial, executor = "none", None, None
-    if group > 1 and not kw:
+    if group > 1 and not kw and args.no_trials:
+        trial = {"skipped": "--no-trials / MIK_BENCH_TRIALS=0: the default exchange path is timed as it comes"}
+    elif group > 1 and not kw:
+        # ONE wall-clock budget over everything that runs before the timed loop (the first real multi-GPU node meets code that has
+        # only ever run on aliased devices: worst case every trial waits out a limit).  When it is spent the remaining trials are
+        # skipped, the default path is timed, and the line says so.
         progress["stage"] = "exchange trials of the device group"
-        trial = {}
+        t_trials = time.perf_counter()
+        budget = max(0.0, args.pretrial_budget)
+        trial = {"budget_s": budget}
+
+        def budget_left():
+            return budget - (time.perf_counter() - t_trials)
+
         model._set_problem(h)
         for name in ("rccl", "peer", "redundant"):
+            if budget_left() <= 0.0:
+                trial.setdefault("skipped_for_budget", []).append(name)
+                continue
             try:
                 h.set_option("exchange", EXCHANGE_CODES[name])
                 h.set_option("async_exchange", 0)  # the trial times factor + exchange as one blocking call
@@ -484,8 +638,13 @@ def main():
         # copy-engine transfers; 2 overlaps any.  Measured here on the hardware at hand, outside the timed region; the faster one runs.
         progress["stage"] = "overlap trial of the device group"
         try:
+            if budget_left() <= 0.0:
+                trial.setdefault("skipped_for_budget", []).append("overlap")
+                raise StopIteration
             model.execute("grid", *axes, **exe_kw)
-            if model.last_timing["exchange_path"] == 1:
+            if model.last_timing["exchange_path"] == 1 and budget_left() <= 0.0:
+                trial.setdefault("skipped_for_budget", []).append("overlap")
+            elif model.last_timing["exchange_path"] == 1:
                 ov = {}
                 for mode in (1, 2):
                     h.set_option("async_exchange", mode)
@@ -497,8 +656,11 @@ def main():
                 h.set_option("async_exchange", pick)
                 trial["execute_ms_leader_waits_for_rccl"], trial["execute_ms_leader_overlaps_rccl"] = ov[1], ov[2]
                 trial["async_exchange_used"] = pick
+        except StopIteration:
+            pass
         except Exception as e:  # noqa: BLE001
             trial["overlap_trial_error"] = repr(e)[:300]
+        trial["spent_s"] = time.perf_counter() - t_trials
     elif world > 1:
         progress["stage"] = "process group / RCCL set-up of the ranks"
         from pykrige_amd.dist import ShardedExecutor
@@ -583,7 +745,7 @@ def main():
             algo_flops_per_launch = 2.0 * M * M * pts_per_launch  # 2 M^2 per point for w = A_inv . b
             effective = algo_flops_per_launch / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0
             executed = tsum["contract_flops_executed"] / (tsum["contract_ms"] * 1e-3) / 1e12 if tsum["contract_ms"] > 0 else 0.0
-            roof = {"bound": "mfma", "kernel": "k_contract_valu" if last.get("engine") else "k_contract",
+            roof = {"bound": "mfma", "kernel": "k_contract_valu" if last.get("engine") else "k_contract_sp" if last.get("sparse") else "k_contract",
                     "achieved": executed, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": executed / FP64_MFMA_PEAK_TFLOPS,
                     "peak_measured": FP64_MFMA_MEASURED_TFLOPS, "frac_of_measured_peak": executed / FP64_MFMA_MEASURED_TFLOPS,
                     "effective_tflops": effective, "effective_frac": effective / FP64_MFMA_PEAK_TFLOPS,
@@ -601,6 +763,12 @@ def main():
                     "flops_note": "algorithmic = the reference's w = A_inv.b (2 M^2, ok.py:679); useful = the quadratic form b^T A_inv b "
                                   "over one triangle (M^2); executed = what the kernel issues: useful + the mirrored halves of the 16 x 16 diagonal "
                                   "squares (option tri = 1, the default; of the whole 128 x 128 diagonal blocks with tri = 0)"}
+            if last.get("sparse"):
+                roof["sparse"] = sparse_summary(last)
+                roof["note"] += ("  RANGE-AWARE CONTRACTION (spherical model): sigma^2 = 2 s - delta^T A_inv delta over the tiles that hold a "
+                                 "nonzero of delta = b + s u only; achieved / frac still count the flops EXECUTED over the kernel's time -- "
+                                 "shorter K loops, so frac is below the dense kernel's while points/s is a multiple of it; useful_* keeps "
+                                 "the dense M^2 count per point (the cross-version number: it may exceed the peak here).")
             metric = ("kriged grid-points/sec (z + sigma^2), OK2D N=5000 on 1000x1000 grid" if args.config == 2
                       else "kriged grid-points/sec (z + sigma^2), " + cfg["name"])
             config = {"workload": cfg["name"], "stations": cfg["n"], "matrix_order": M,
@@ -706,6 +874,17 @@ def main():
                 zg, ssg = (np.asarray(a).ravel() for a in res)
                 out["checksum"] = {"z_sum": float(zg.sum()), "ss_sum": float(ssg.sum()),
                                    "grid_vs_points_max_abs_dz": float(np.abs(zg - zz).max()), "grid_vs_points_max_abs_dss": float(np.abs(ssg - sss).max())}
+        if n_gpus == 1 and world == 1 and not inner and not kw and args.config == 2 and not args.no_other:
+            # BASELINE's other configurations and the moving window under the same clock (3 steps, 1 warm-up each; parity against
+            # the stored reference slabs).  Keys are pinned by tests/test_bench_host.py.
+            out["other_configs"] = {}
+            for key, cno, win in (("config3", 3, None), ("config4", 4, None), ("config5", 5, None),
+                                  ("moving_window_k10", 2, 10), ("moving_window_k100", 2, 100)):
+                progress["stage"] = "other_configs: " + key
+                try:
+                    out["other_configs"][key] = other_config_line(cno, win)
+                except Exception as e:  # noqa: BLE001
+                    out["other_configs"][key] = {"value": None, "error": repr(e)[:300]}
         if n_gpus == 1 and not args.no_cpu and not inner:
             progress["stage"] = "cpu_baseline leg"
             try:

@@ -110,5 +110,27 @@ def main():
             name, z.size, cond1, os.path.getsize(os.path.join(OUT, name + ".npz")), time.time() - t0), flush=True)
 
 
+def moving_window_c2():
+    """round 4: the moving window at BASELINE config 2's station count -- the stations and the row slab of fullsize/c2.npz (17 rows
+    x 1000, 8 stations on nodes), kriged by the reference's backend='C' (cKDTree.query + lib/cok.pyx _c_exec_loop_moving_window,
+    ok.py:929-986) with n_closest_points = 10 and 100; bench.py checks its moving-window lines against these."""
+    _import_reference(True)
+    from pykrige.ok import OrdinaryKriging
+
+    g = np.load(os.path.join(OUT, "c2.npz"))
+    k = OrdinaryKriging(g["x"], g["y"], g["v"], variogram_model=str(g["model"]), variogram_parameters=g["params_user"].tolist())
+    kw = dict(x=g["x"], y=g["y"], v=g["v"], model=str(g["model"]), params_user=g["params_user"], gridx=g["gridx"], gridy=g["gridy"],
+              windows=np.array([10, 100]))
+    for w in (10, 100):
+        t0 = time.time()
+        z, ss = k.execute("grid", g["gridx"], g["gridy"], backend="C", n_closest_points=w)
+        kw["z_k%d" % w], kw["ss_k%d" % w] = np.asarray(z, dtype=np.float64), np.asarray(ss, dtype=np.float64)
+        print("mw_c2 k=%d: %d points, %.0f s" % (w, z.size, time.time() - t0), flush=True)
+    np.savez_compressed(os.path.join(OUT, "mw_c2.npz"), **kw)
+
+
 if __name__ == "__main__":
-    main()
+    if "--moving-window" in sys.argv:
+        moving_window_c2()
+    else:
+        main()

@@ -123,3 +123,42 @@ def test_tracked_pmc_summary_contains_the_dominant_kernel():
     b = json.load(open(os.path.join(ROOT, src.replace("_rocprofv3_pmc_per_kernel.csv", ".json"))))
     assert b["roofline"]["kernel"] == "k_contract" and b["roofline"]["traffic"] is not None
     assert abs(b["roofline"]["traffic"] - tj["hbm_bytes_per_launch"]) <= 0.05 * tj["hbm_bytes_per_launch"]
+
+
+def test_other_configs_key_set_and_trial_flags_are_pinned():
+    """Round 4: the default N = 1 run also times BASELINE configs 3, 4, 5 and the moving window (k = 10, 100) and checks each against
+    the stored reference slab; the line's key set is what the driver's BENCH record will show."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for key in ("config3", "config4", "config5", "moving_window_k10", "moving_window_k100"):
+        assert '("%s",' % key in src
+    for field in ('"value"', '"ms_per_step"', '"roofline"', '"max_abs_dz"', '"max_abs_dss"', '"parity_source"'):
+        assert field in src[src.index("def other_config_line"):src.index("MW_KERNELS = {")]
+    assert 'out["other_configs"]' in src
+    for flag in ("--no-trials", "--pretrial-budget", "--no-other", "--sparse", "MIK_BENCH_TRIALS"):
+        assert flag in src
+    # the stored slabs those checks read exist and are the configs' own
+    for cno, n in ((3, 2000), (4, 4000), (5, 8000)):
+        g = bench.golden_slab(cno)
+        assert g["x"].size == n == bench.CONFIGS[cno]["n"] and g["z"].size >= 16384
+        assert str(g["model"]) == bench.CONFIGS[cno]["model"] and g["params_user"].tolist() == bench.CONFIGS[cno]["params"]
+    mw = np.load(os.path.join(ROOT, "tests", "golden", "fullsize", "mw_c2.npz"))
+    assert mw["x"].size == bench.CONFIGS[2]["n"] and mw["windows"].tolist() == [10, 100]
+
+
+def test_cpu_leg_times_the_reference_itself_where_it_is_staged():
+    """cpu_baseline on a tiny stand-in config: with oracle/_ref/pykrige_py.zip staged (oracle/build_ref.sh) the vectorized leg is the
+    reference's own execute() -- kind "reference" -- and agrees with the port; the slab axes are the slab's points."""
+    from oracle import ref_package as rp
+
+    if not rp.available():
+        import pytest
+
+        pytest.skip("oracle/_ref/pykrige_py.zip not staged")
+    for cno, extra in ((3, {}), (4, {})):
+        cfg = dict(bench.CONFIGS[cno], n=120, grid=tuple(min(g, 24) for g in bench.CONFIGS[cno]["grid"]), **extra)
+        coords, values = bench.synth(cfg["seed"], cfg["n"], cfg["ndim"])
+        out, (pts, z, ss) = bench.cpu_baseline(cfg, coords, values, 96, full=False)
+        assert out["kind"] == "reference" and out["vectorized"]["kind"] == "reference", out
+        assert out["vectorized"]["port_vs_reference_max_abs_dz"] < 1e-9 and out["vectorized"]["port_vs_reference_max_abs_dss"] < 1e-9
+        ax = bench.row_slab_axes(cfg, 96)
+        assert pts.shape[0] == int(np.prod([a.size for a in ax])) == z.size

@@ -160,3 +160,36 @@ def test_forced_rccl_that_hangs_is_an_error_not_a_hang():
     o, wall = _gpu_case("hang_bcast", exchange=1)
     assert not o["ok"] and "RuntimeError" in o["err"] and "did not finish within" in o["err"], o
     assert wall < 120.0
+
+
+@pytest.mark.gpu
+def test_bench_with_eight_members_survives_a_hanging_rccl_within_its_budget():
+    """The first real 8-GPU run, rehearsed: `bench.py --gpus 8 --config 5` as the SCALE driver starts it (eight members, here aliased
+    onto the one GPU) against an RCCL whose ncclCommInitAll never returns.  One valid JSON line must come out, the exchange that
+    ran is named with the reason the default one was given up, and the trials before the timed loop respect their wall-clock
+    budget (--pretrial-budget; --no-trials skips them)."""
+    import json
+
+    _, hip = _standins()
+    assert os.path.exists(hip), "the HIP stand-in needs hipcc"
+    env = dict(os.environ, MIK_RCCL_LIB=hip, STANDIN_RCCL_MODE="hang_init", MIK_RCCL_ALLOW_ALIAS="1", MIK_RCCL_INIT_TIMEOUT="2.0",
+               MIK_RCCL_BCAST_TIMEOUT="2.0", MIK_PEER_TIMEOUT="30")
+    for extra, budget in ((["--pretrial-budget", "5"], 5.0), (["--no-trials"], None)):
+        t0 = time.time()
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--config", "5", "--steps", "1", "--warmup", "0",
+                            "--no-cpu"] + extra, capture_output=True, text=True, timeout=600, env=env)
+        wall = time.time() - t0
+        assert r.returncode == 0, r.stderr[-1500:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout[-500:]
+        o = json.loads(lines[0])
+        assert o["value"] and o["n_gpus"] == 8 and o["config"]["grid_points_total"] == 8 * 4096 * 512
+        fx_ = o["config"]["factor_exchange"]
+        assert fx_.startswith("peer_scatter_allgather") and ("did not finish within" in fx_ or "rccl disabled" in fx_), fx_
+        tr = o["config"]["factor_exchange_trial"]
+        if budget is None:
+            assert "skipped" in tr
+        else:
+            # a trial in flight when the budget runs out finishes (its own waits are bounded by the library's limits); nothing new starts
+            assert tr["budget_s"] == budget and tr["spent_s"] < budget + 45.0, tr
+        assert wall < 300.0, wall

@@ -66,6 +66,22 @@ def test_oracle_matches_the_reference_at_full_station_count(name):
         assert np.abs(g["z_c"] - g["z"]).max() < 1e-9 and np.abs(g["ss_c"] - g["ss"]).max() < 1e-9
 
 
+def test_oracle_moving_window_matches_the_reference_at_config2_size():
+    """fullsize/mw_c2.npz (round 4): config 2's 5000 stations, a 17 000-point row slab, the reference's backend='C' with
+    n_closest_points = 10 and 100 (cKDTree.query + lib/cok.pyx:98-193).  The oracle's window restatement on a sub-sample."""
+    g = _full("mw_c2")
+    assert g["x"].size == 5000 and g["z_k10"].size >= 16384
+    st = ko.KrigingState(ndim=2, coords_orig=np.stack([g["x"], g["y"]], 1), values=g["v"], model=str(g["model"]),
+                         params=ko.internal_parameters(str(g["model"]), g["params_user"].tolist()))
+    X, Y = np.meshgrid(g["gridx"], g["gridy"])
+    sel = np.arange(0, X.size, 53)[:300]
+    pts = np.stack([X.ravel(), Y.ravel()], 1)[sel]
+    for w in (10, 100):
+        z, ss = ko.solve_points_moving_window(st, pts, w)
+        np.testing.assert_allclose(z, g["z_k%d" % w].ravel()[sel], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(ss, g["ss_k%d" % w].ravel()[sel], rtol=0, atol=1e-9)
+
+
 # ------------------------------------------------------------------------------------------- CPU: host rules
 @pytest.mark.parametrize("variant", ["asc", "descy", "descxy", "perm"])
 def test_external_z_lookup_follows_the_reference_index_rule(variant):
@@ -153,6 +169,19 @@ def test_hip_matches_the_reference_on_a_full_size_slab(name, variant):
         zc, sc = m.execute("grid", *fx.grid_args(g), backend="C")
         assert type(zc) is np.ndarray
         assert np.abs(zc - g["z_c"]).max() <= Z_TOL and np.abs(sc - g["ss_c"]).max() <= SS_TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("window", [10, 100])
+def test_hip_moving_window_matches_the_reference_at_config2_size(window):
+    import pykrige_amd as pa
+
+    g = _full("mw_c2")
+    m = pa.OrdinaryKriging(g["x"], g["y"], g["v"], variogram_model=str(g["model"]), variogram_parameters=g["params_user"].tolist())
+    for backend in ("C", "loop"):
+        z, ss = m.execute("grid", g["gridx"], g["gridy"], backend=backend, n_closest_points=window)
+        assert np.abs(np.asarray(z) - g["z_k%d" % window]).max() <= Z_TOL
+        assert np.abs(np.asarray(ss) - g["ss_k%d" % window]).max() <= SS_TOL
 
 
 @pytest.mark.gpu
