@@ -178,6 +178,13 @@ int  mik_slab_of(int64_t n, int members, int i, int64_t *lo, int64_t *count); /*
  *   spherical model (not with pseudo_inv, a caller's a_inv or geographic coordinates: those run the dense contraction), 0 = off,
  *   2 = Hilbert-ordered stations with the dense contraction (A/B of the order alone).  Takes effect at the
  *   next mik_factor [MIK_SPARSE] ;
+ * "drift_eq" 0/1 = drift equilibration (default 1): every drift term enters the matrix and the right-hand sides as s_j (f_j - c_j),
+ *   c_j = its mean and 1 / s_j = its largest deviation over the stations (wells excepted).  With the unbiasedness row present
+ *   span{1, f_j} = span{1, s_j (f_j - c_j)}: the stations' kriging weights, z and sigma^2 are those of the reference's system
+ *   (uk.py:861-920, 949-981) -- A' = S A S^T, b' = S b -- but coordinates of 1e6 no longer share a matrix with semivariances of 1e2
+ *   (the reference's own KT3D test case: cond(A) 3e14 -> 2e6; the unpivoted sweep's |dz| 6e-9 -> 2e-11).  Not with pseudo_inv
+ *   (a pseudo-inverse is not invariant under S) or a caller's a_inv.  mik_get_matrix(1) hands out the inverse of the
+ *   reference's matrix, S^T A'^-1 S ;
  * "pairs" 0/1 = symmetric contraction: work is handed out as single tiles (default 0) or as equal-length PAIRS of row
  *   blocks (higher L2 hit rate, measured 2.7 % slower: the kernel is not traffic-bound) ;
  * "tri" 0/1 = symmetric contraction (8-wave form): the diagonal block of a tile is contracted as a triangle of 16-row groups,

@@ -99,9 +99,15 @@ struct AsmArgs {
   int rl, nwells, nextra;
   const double* wells;  // nwells x 3
   const double* extra;  // nextra x N
+  // drift equilibration (round 4; nullptr = the reference's raw matrix): drift term j enters as (f_j - dsc[2j]) * dsc[2j + 1].
+  // With the unbiasedness row present, span{1, f_j} = span{1, s_j (f_j - c_j)}: the kriging weights of the stations, z and sigma^2
+  // are unchanged (A' = S A S^T, b' = S b with S = I outside the drift rows), while coordinates of 1e6 next to semivariances of
+  // 1e2 (UTM stations under a regional-linear drift: cond(A) 3e14 on the reference's own KT3D test case) no longer sit in one
+  // matrix (cond 2e6 there).  mik_get_matrix undoes it.
+  const double* dsc;
 };
 
-__device__ __forceinline__ double station_drift(const AsmArgs& a, int c, int s) {
+__device__ __forceinline__ double station_drift_raw(const AsmArgs& a, int c, int s) {
   if (a.rl) {
     if (c < a.ndim) return c == 0 ? a.xs[s] : (c == 1 ? a.ys[s] : a.zs[s]);
     c -= a.ndim;
@@ -109,6 +115,10 @@ __device__ __forceinline__ double station_drift(const AsmArgs& a, int c, int s) 
   if (c < a.nwells) return well_drift(a.xs[s], a.ys[s], a.wells + 3 * c);
   c -= a.nwells;
   return a.extra[(long)c * a.N + s];
+}
+__device__ __forceinline__ double station_drift(const AsmArgs& a, int c, int s) {
+  const double v = station_drift_raw(a, c, s);
+  return a.dsc ? (v - a.dsc[2 * c]) * a.dsc[2 * c + 1] : v;
 }
 
 template <int MODEL, int NDIM>
@@ -392,6 +402,7 @@ struct RhsArgs {
   unsigned char* flags;       // [point block][nK16]
   int nIblk, nK16;
   double sill;
+  const double* dsc;  // drift equilibration, as in AsmArgs (nullptr = raw drift values)
 };
 
 template <int MODEL, int NDIM, bool SP = false>
@@ -468,6 +479,7 @@ __global__ void __launch_bounds__(256) k_rhs(RhsArgs a) {
       }
     } else if (j < a.N + a.p) {
       int c = j - a.N;
+      const double dc = a.dsc ? a.dsc[2 * c] : 0.0, ds = a.dsc ? a.dsc[2 * c + 1] : 1.0;
       int kind = 2;  // 0 regional-linear, 1 well, 2 extra
       if (a.rl) {
         if (c < a.ndim) kind = 0; else c -= a.ndim;
@@ -481,7 +493,7 @@ __global__ void __launch_bounds__(256) k_rhs(RhsArgs a) {
         if (kind == 0) dv = (c == 0) ? qx[q] : (c == 1 ? qy[q] : qz[q]);
         else if (kind == 1) dv = well_drift(qx[q], qy[q], a.wells + 3 * c);
         else dv = ok[q] ? a.extra[(long)c * a.extra_stride + t0 + q] : 0.0;
-        val[q] = dv;
+        val[q] = a.dsc ? (dv - dc) * ds : dv;
       }
     } else {
       const double one = (j == a.N + a.p) ? 1.0 : 0.0;

@@ -252,6 +252,12 @@ struct mik_handle {
   // along a Hilbert curve (sort_perm[i] = caller's index of the station at position i) and the bounding boxes of its
   // 128-station blocks.  factor_sorted says which order the factor in T (and c) is in.
   bool sort_ok = false, factor_sorted = false;
+  // drift equilibration (AsmArgs::dsc): per drift term (centre, scale) from the station values; the factor path assembles with it
+  // (not with a pseudo-inverse -- pinv(S A S^T) is not S^-T pinv(A) S^-1 -- nor with a caller's inverse); factor_eq = T is in that form
+  bool drift_eq = false, factor_eq = false;
+  std::vector<double> hdsc;
+  DevBuf dsc;
+  int opt_drift_eq = 1;  // "drift_eq": 0 = assemble the drift columns as the reference does
   std::vector<int> sort_perm;
   std::vector<double> hvals_s;
   DevBuf xs_s, ys_s, zs_s, vals_s, extra_cols_s, sbox;
@@ -934,6 +940,8 @@ int mik_set_option(mik_handle* h, const char* key, double value) {
   } else if (!strcmp(key, "sparse")) {
     if (value != -1.0 && value != 0.0 && value != 1.0 && value != 2.0) return fail(MIK_EINVAL, "sparse must be -1 (auto), 0, 1 or 2");
     h->opt_sparse = (int)value;
+  } else if (!strcmp(key, "drift_eq")) {
+    h->opt_drift_eq = value != 0.0;
   } else if (!strcmp(key, "pairs")) {
     h->opt_pairs = value != 0.0;
   } else if (!strcmp(key, "tri")) {
@@ -1214,6 +1222,35 @@ static int one_set_problem(mik_handle* h, const mik_problem* p) {
                std::isfinite(v.p1) && v.p1 > 0.0 && std::isfinite(v.p0 + v.p2);
   h->factor_sorted = false;
   if (h->sort_ok) MIKC(upload_sorted_stations(h, p));
+  // drift equilibration: centre = mean, scale = 1 / max |f - centre| of each drift term over the stations (wells: left alone --
+  // their logarithms are O(1..10) already)
+  h->drift_eq = h->p > 0 && !h->pinv && !h->host_inv;
+  h->factor_eq = false;
+  if (h->drift_eq) {
+    h->hdsc.assign(2 * (size_t)h->p, 0.0);
+    for (int j = 0; j < h->p; ++j) h->hdsc[2 * j + 1] = 1.0;
+    auto fit = [&](int j, const double* col) {
+      double mean = 0.0;
+      for (long i = 0; i < h->N; ++i) mean += col[i];
+      mean /= (double)h->N;
+      double dev = 0.0;
+      for (long i = 0; i < h->N; ++i) dev = std::max(dev, std::fabs(col[i] - mean));
+      if (std::isfinite(mean) && std::isfinite(dev) && dev > 0.0) {
+        h->hdsc[2 * j] = mean;
+        h->hdsc[2 * j + 1] = 1.0 / dev;
+      }
+    };
+    int j = 0;
+    if (h->rl) {
+      fit(j++, p->xs);
+      fit(j++, p->ys);
+      if (h->ndim == 3) fit(j++, p->zs);
+    }
+    j += h->nwells;
+    for (int c = 0; c < h->nextra; ++c) fit(j++, p->extra_cols + (size_t)c * h->N);
+    MIKC(h->dsc.ensure(sizeof(double) * h->hdsc.size()));
+    HIPC(hipMemcpyAsync(h->dsc.p, h->hdsc.data(), sizeof(double) * h->hdsc.size(), hipMemcpyHostToDevice, h->stream));
+  }
   HIPC(hipStreamSynchronize(h->stream));
   h->have_problem = true;
   h->have_factor = false;
@@ -1250,7 +1287,7 @@ static int custom_roundtrip(mik_handle* h, double* dev, long rows, long cols, lo
   return MIK_OK;
 }
 
-static int launch_assemble(mik_handle* h, double shift, double* dst = nullptr, bool sorted = false) {
+static int launch_assemble(mik_handle* h, double shift, double* dst = nullptr, bool sorted = false, bool eq = false) {
   AsmArgs a{};
   a.T = dst ? dst : h->T.as<double>();
   a.ld = h->Mp;
@@ -1269,6 +1306,7 @@ static int launch_assemble(mik_handle* h, double shift, double* dst = nullptr, b
   a.nextra = h->nextra;
   a.wells = h->wells.as<double>();
   a.extra = sorted ? h->extra_cols_s.as<double>() : h->extra_cols.as<double>();
+  a.dsc = eq ? h->dsc.as<double>() : nullptr;
   dim3 grid(h->Mp / 64, h->Mp / 64);
   if (h->model == MIK_MODEL_CUSTOM) {
     DISPATCH_NDIM_FIXED(7, h->geo ? 1 : h->ndim, k_assemble, grid, dim3(256), h->stream, a);  // distances
@@ -1803,7 +1841,7 @@ static int verify_inverse(mik_handle* h, double* res_z, double* res_inv) {
   const long ld = Mp;
   MIKC(h->Averify.ensure(sizeof(double) * (size_t)Mp * Mp));
   MIKC(h->vbuf.ensure(sizeof(double) * 4 * (size_t)Mp));
-  MIKC(launch_assemble(h, 0.0, h->Averify.as<double>(), h->factor_sorted));
+  MIKC(launch_assemble(h, 0.0, h->Averify.as<double>(), h->factor_sorted, h->factor_eq));
   const std::vector<double>& hv = h->factor_sorted ? h->hvals_s : h->hvals;
   const double* A2 = h->Averify.as<double>();
   double* y = h->vbuf.as<double>();
@@ -2101,6 +2139,7 @@ static int one_factor(mik_handle* h) {
   h->t_state = 0;
   h->have_factor = false;
   h->factor_sorted = want_sorted(h);
+  h->factor_eq = h->drift_eq && h->opt_drift_eq;
   MIKC(ensure_factor_buffers(h));
   MIKC(get_events(h, 4));
   h->tm.assemble_ms = h->tm.invert_ms = 0.0;
@@ -2166,7 +2205,7 @@ static int one_factor(mik_handle* h) {
     const double shift = pivoted ? 0.0 : h->shift_guess;
     ++h->tm.factor_attempts;
     HIPC(hipEventRecord(h->evpool[0], h->stream));
-    MIKC(launch_assemble(h, shift, nullptr, h->factor_sorted));
+    MIKC(launch_assemble(h, shift, nullptr, h->factor_sorted, h->factor_eq));
     HIPC(hipEventRecord(h->evpool[1], h->stream));
     int flag = 0;
     MIKC(run_block_inverse(h, pivoted, pivoted ? 0 : h->N, &flag));
@@ -2577,6 +2616,7 @@ static void mark_kids_factored(mik_handle* h) {
     k->t_state = 2;
     k->have_results = false;
     k->factor_sorted = h->factor_sorted;  // (the member sorted its own copy of the stations the same way in mik_set_problem)
+    k->factor_eq = h->factor_eq;
     k->tm.factor_path = h->tm.factor_path;
     k->tm.assemble_ms = k->tm.invert_ms = 0.0;
   }
@@ -2735,11 +2775,35 @@ int mik_get_matrix(mik_handle* h, int which, double* out) {
   if (which == 1 && !h->have_factor) return fail(MIK_ESTATE, "mik_get_matrix: not factored");
   MIKC(join_exchange(h));
   HIPC(hipSetDevice(h->device));
-  if (which == 1 && h->factor_sorted) {  // the factor is in Hilbert-curve station order: hand it out in the caller's
+  if (which == 1 && (h->factor_sorted || h->factor_eq)) {
+    // the factor is in Hilbert-curve station order and / or of the matrix with equilibrated drift rows A' = S A S^T: hand out
+    // A^-1 = S^T A'^-1 S in the caller's station order.  S = I except S[N + j][N + j] = s_j, S[N + j][M - 1] = -s_j c_j.
     const long M = h->M, N = h->N;
     std::vector<double> tmp((size_t)M * M);
     HIPC(hipMemcpy2D(tmp.data(), sizeof(double) * M, h->T.p, sizeof(double) * h->Mp, sizeof(double) * M, M, hipMemcpyDeviceToHost));
-    auto orig = [&](long i) { return i < N ? (long)h->sort_perm[(size_t)i] : i; };
+    if (h->factor_eq) {
+      for (long i = 0; i < M; ++i) {  // R = T S: column N + j scaled, the last column takes the centres
+        double* r = tmp.data() + (size_t)i * M;
+        double add = 0.0;
+        for (int j = 0; j < h->p; ++j) {
+          add -= r[N + j] * h->hdsc[2 * j + 1] * h->hdsc[2 * j];
+          r[N + j] *= h->hdsc[2 * j + 1];
+        }
+        r[M - 1] += add;
+      }
+      double* last = tmp.data() + (size_t)(M - 1) * M;  // S^T R: the same on the rows
+      for (int j = 0; j < h->p; ++j) {
+        double* r = tmp.data() + (size_t)(N + j) * M;
+        for (long k = 0; k < M; ++k) {
+          last[k] -= r[k] * h->hdsc[2 * j + 1] * h->hdsc[2 * j];
+        }
+      }
+      for (int j = 0; j < h->p; ++j) {
+        double* r = tmp.data() + (size_t)(N + j) * M;
+        for (long k = 0; k < M; ++k) r[k] *= h->hdsc[2 * j + 1];
+      }
+    }
+    auto orig = [&](long i) { return (h->factor_sorted && i < N) ? (long)h->sort_perm[(size_t)i] : i; };
     for (long i = 0; i < M; ++i) {
       double* dst = out + orig(i) * M;
       const double* src = tmp.data() + (size_t)i * M;
@@ -3115,6 +3179,7 @@ static int one_predict(mik_handle* h) {
     a.xs = h->factor_sorted ? h->xs_s.as<double>() : h->xs.as<double>();
     a.ys = h->factor_sorted ? h->ys_s.as<double>() : h->ys.as<double>();
     a.zs = h->factor_sorted ? h->zs_s.as<double>() : h->zs.as<double>();
+    a.dsc = h->factor_eq ? h->dsc.as<double>() : nullptr;
     a.v = h->v;
     a.exact = h->exact;
     a.eps = h->eps;
@@ -3994,7 +4059,10 @@ int mik_bcast_factor(mik_handle* h, int root) {
     g_rccl_dead.store(true);
   }
   MIKC(rc);
-  if (h->rank != root) h->factor_sorted = want_sorted(h);  // the root decided by the same rule on the same problem and options
+  if (h->rank != root) {  // the root decided by the same rules on the same problem and options
+    h->factor_sorted = want_sorted(h);
+    h->factor_eq = h->drift_eq && h->opt_drift_eq;
+  }
   h->have_factor = true;
   h->t_state = 2;
   h->have_results = false;

@@ -645,6 +645,10 @@ class UniversalKriging(OrdinaryKriging):
                                  exact_values=exact_values, pseudo_inv=pseudo_inv, pseudo_inv_type=pseudo_inv_type)
         if drift_terms is None:
             drift_terms = []
+        if specified_drift is None:  # uk.py:254-257, uk3d.py:249-252: an omitted list is an EMPTY list (-> ValueError, not TypeError)
+            specified_drift = []
+        if functional_drift is None:
+            functional_drift = []
         self.regional_linear_drift = "regional_linear" in drift_terms
         self.external_Z_drift = "external_Z" in drift_terms
         if self.external_Z_drift:
@@ -861,6 +865,10 @@ class UniversalKriging3D(OrdinaryKriging3D):
                                    pseudo_inv=pseudo_inv, pseudo_inv_type=pseudo_inv_type)
         if drift_terms is None:
             drift_terms = []
+        if specified_drift is None:  # uk.py:254-257, uk3d.py:249-252: an omitted list is an EMPTY list (-> ValueError, not TypeError)
+            specified_drift = []
+        if functional_drift is None:
+            functional_drift = []
         self.regional_linear_drift = "regional_linear" in drift_terms
         self.specified_drift = "specified" in drift_terms
         if self.specified_drift:

@@ -1,4 +1,5 @@
-"""The reference's OWN test-suite judging the drop-in: /root/reference/tests/test_core.py (48 tests) and test_api.py run unmodified
+"""The reference's OWN test-suite judging the drop-in: /root/reference/tests/test_core.py (48 tests), test_api.py and the
+scikit-learn wrappers' tests (test_regression_krige.py, test_classification_krige.py) run unmodified
 with `pykrige` -> `pykrige_amd` (an import shim in a conftest.py written next to the unpacked tests).  The suite is staged by
 oracle/build_ref.sh as oracle/_ref/reference_tests.zip (git-ignored build output; absent -> skipped) and unpacked into pytest's
 tmp_path only.  Every test that does not pass is listed below with the reason; nothing else may fail."""
@@ -56,7 +57,7 @@ def _run(tmp_path, files):
 def test_reference_suite_passes_against_the_drop_in(tmp_path):
     if not os.path.exists(TESTS_ZIP):
         pytest.skip("oracle/_ref/reference_tests.zip not staged (oracle/build_ref.sh needs /root/reference)")
-    res, tail = _run(tmp_path, ["test_core.py", "test_api.py"])
+    res, tail = _run(tmp_path, ["test_core.py", "test_api.py", "test_regression_krige.py", "test_classification_krige.py"])
     passed = sorted(k for k, v in res.items() if v[0] == "passed")
     failed = {k: v[1] for k, v in res.items() if v[0] == "failed"}
     skipped = {k: v[1] for k, v in res.items() if v[0] == "skipped"}
@@ -67,5 +68,7 @@ def test_reference_suite_passes_against_the_drop_in(tmp_path):
         print("  skipped %s: %s" % (k, v))
     unexpected = {k: v for k, v in failed.items() if k.split("[")[0] not in EXPECTED_NOT_PASSING}
     assert not unexpected, (unexpected, tail)
-    core_passed = [k for k in passed if not k.startswith("test_krige")]
-    assert len(core_passed) >= 45, (len(core_passed), sorted(failed), sorted(skipped))
+    assert len(passed) >= 48, (len(passed), sorted(failed), sorted(skipped))
+    # the only tests that may be skipped: GSTools is not installed on the box; the housing data set needs a network
+    for k, why in skipped.items():
+        assert "gstools" in why or "california housing" in why, (k, why)
