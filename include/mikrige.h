@@ -242,6 +242,13 @@ int  mik_slab_of(int64_t n, int members, int i, int64_t *lo, int64_t *count); /*
  * "mw_knn_bound" 0/1 = moving-window neighbour search: the first pass takes only stations within the radius expected to hold
  *   K + 4 sqrt(K) + 2 of them (one scan of the 3 x 3 cells, one sort), falling back to the unbounded ring walk where that
  *   finds fewer than K (default 1) ;
+ * "mw_static" 0/1 = moving-window LDL^T kernel instantiated with the variogram model as a compile-time constant (linear, gaussian,
+ *   spherical, exponential; Euclidean coordinates; default 1).  The dynamic form inlines the great-circle distance and all six models
+ *   at every element of the register tile: 1.3 MB of set-up code per kernel, streamed through a 64 KB instruction cache by every point ;
+ * "mw_knn_lane" 0/1 = moving-window neighbour search for windows <= 16 over spatially ordered points (default 1): first one LANE per point -- the 64 consecutive points
+ *   of a wavefront (the rows of a grid) scan the box of station cells that covers their 3 x 3 (x 3) neighbourhoods and keep their
+ *   nearest in registers by sorted insertion (no candidate buffer, no sort); points it cannot finish (sparse corners, scattered
+ *   point lists) go to the wave-per-point search ;
  * "mw_class" = 100 G + RI: force one thread-grid (G x G threads per point) / register-tile (RI x RI per thread) class of the
  *   moving-window LDL^T kernel, windows up to G RI (0 = chosen by window size; 1 = the blocked Cholesky kernel of the large
  *   windows whatever the size; for A/B runs) ;

@@ -2836,7 +2836,135 @@ struct KnnArgs {
   double tau0;                         // first-pass bound on the squared distance (<= cell2), 0 = none: see k_mw_knn
   int* idx_out;
   double* dist_out;
+  // round 4: k_mw_knn_lane leaves the points it could not finish in todo[0 .. *todo_count); k_mw_knn then walks that list instead
+  // of all points (todo == nullptr: all points)
+  int* todo;
+  int* todo_count;
 };
+
+// Neighbour search for SMALL windows (K <= KMAX <= 32) over points that arrive in spatial order (the rows of a grid): one LANE
+// per point.  The 64 consecutive points of a wavefront share the box of station cells that covers all their 3 x 3 (x 3)
+// neighbourhoods; its stations are staged through LDS 64 at a time (one coalesced load per batch) and every lane keeps its KMAX
+// nearest -- ascending by (squared distance, station index), the order k_mw_knn and cKDTree.query produce -- in registers by
+// sorted insertion with compile-time indices: no candidate buffer, no bitonic sort, one pass (the wave-per-point kernel spends
+// ~80 % of its time sorting ~1.5 K candidates per point).  A lane is done when its K-th distance is within its distance to the
+// box's nearest open side (no station outside the box can be closer); lanes that are not -- sparse corners, points far outside
+// the stations, waves whose points are scattered (a shuffled point list) -- are appended to `todo` and finished by k_mw_knn.
+// Reference: cKDTree.query(k) of ok.py:957-960 / ok3d.py:904-908.
+template <int NDIM, int KMAX>
+__global__ void __launch_bounds__(64) k_mw_knn_lane(KnnArgs a) {
+  __shared__ double sx[64], sy[64], sz[64];
+  __shared__ int sid[64];
+  const int l = threadIdx.x, K = a.K;
+  constexpr int MAXCELLS = (NDIM == 3) ? 125 : 40;
+  auto wmin = [](int v) {
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+    return v;
+  };
+  auto wmax = [](int v) {
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+    return v;
+  };
+  for (long base = (long)blockIdx.x * 64; base < a.npt; base += (long)gridDim.x * 64) {
+    const long t = base + l;
+    const bool ok = t < a.npt;
+    const long ts = ok ? t : base;  // padding lanes shadow the wave's first point (they write nothing)
+    const double qx = a.px[ts], qy = a.py[ts], qz = (NDIM == 3) ? a.pz[ts] : 0.0;
+    const int cx = min(a.nx - 1, max(0, (int)floor((qx - a.x0) * a.inv_cell)));
+    const int cy = min(a.ny - 1, max(0, (int)floor((qy - a.y0) * a.inv_cell)));
+    const int cz = (NDIM == 3) ? min(a.nz - 1, max(0, (int)floor((qz - a.z0) * a.inv_cell))) : 0;
+    const int xa = max(0, wmin(cx) - 1), xb = min(a.nx - 1, wmax(cx) + 1);
+    const int ya = max(0, wmin(cy) - 1), yb = min(a.ny - 1, wmax(cy) + 1);
+    const int za = (NDIM == 3) ? max(0, wmin(cz) - 1) : 0, zb = (NDIM == 3) ? min(a.nz - 1, wmax(cz) + 1) : 0;
+    const long cells = (long)(xb - xa + 1) * (yb - ya + 1) * (zb - za + 1);
+    bool done = false;
+    double key[KMAX];
+    int id[KMAX];
+    if (cells <= MAXCELLS) {  // wave-uniform
+#pragma unroll
+      for (int q = 0; q < KMAX; ++q) {
+        key[q] = 1e300;
+        id[q] = 0x7fffffff;
+      }
+      for (int z = za; z <= zb; ++z)
+        for (int y = ya; y <= yb; ++y) {
+          const long row = ((long)z * a.ny + y) * a.nx;
+          const int beg = a.cstart[row + xa], end = a.cstart[row + xb + 1];
+          for (int j0 = beg; j0 < end; j0 += 64) {
+            const int j = j0 + l;
+            if (j < end) {
+              sx[l] = a.gx[j];
+              sy[l] = a.gy[j];
+              if (NDIM == 3) sz[l] = a.gz[j];
+              sid[l] = a.orig[j];
+            }
+            __syncthreads();
+            const int n = min(64, end - j0);
+            for (int s = 0; s < n; ++s) {
+              const double dx = qx - sx[s], dy = qy - sy[s];
+              double d2 = dx * dx + dy * dy;
+              if (NDIM == 3) {
+                const double dz = qz - sz[s];
+                d2 += dz * dz;
+              }
+              const int st = sid[s];
+              if (d2 < key[KMAX - 1] || (d2 == key[KMAX - 1] && st < id[KMAX - 1])) {
+                bool placed = false;
+#pragma unroll
+                for (int q = KMAX - 1; q > 0; --q) {
+                  if (!placed) {
+                    const bool sh = d2 < key[q - 1] || (d2 == key[q - 1] && st < id[q - 1]);
+                    key[q] = sh ? key[q - 1] : d2;
+                    id[q] = sh ? id[q - 1] : st;
+                    placed = !sh;
+                  }
+                }
+                if (!placed) {
+                  key[0] = d2;
+                  id[0] = st;
+                }
+              }
+            }
+            __syncthreads();
+          }
+        }
+      // the K-th nearest so far (K - 1 is not a compile-time index)
+      double tau = 1e300;
+#pragma unroll
+      for (int q = 0; q < KMAX; ++q)
+        if (q == K - 1) tau = key[q];
+      // distance to the nearest OPEN side of the box (a side at the edge of the grid is closed: no station lies beyond it)
+      const double cell = 1.0 / a.inv_cell;
+      double reach = 1e300;
+      if (xa > 0) reach = fmin(reach, qx - (a.x0 + xa * cell));
+      if (xb < a.nx - 1) reach = fmin(reach, (a.x0 + (xb + 1) * cell) - qx);
+      if (ya > 0) reach = fmin(reach, qy - (a.y0 + ya * cell));
+      if (yb < a.ny - 1) reach = fmin(reach, (a.y0 + (yb + 1) * cell) - qy);
+      if (NDIM == 3) {
+        if (za > 0) reach = fmin(reach, qz - (a.z0 + za * cell));
+        if (zb < a.nz - 1) reach = fmin(reach, (a.z0 + (zb + 1) * cell) - qz);
+      }
+      // (the cell edges are recomputed here with a different rounding than the binning used: keep a relative margin)
+      done = tau < 1e300 && reach > 0.0 && tau <= reach * reach * (1.0 - 1e-9);
+    }
+    if (ok && done) {
+#pragma unroll
+      for (int q = 0; q < KMAX; ++q)
+        if (q < K) {
+          a.idx_out[t * K + q] = id[q];
+          a.dist_out[t * K + q] = sqrt(key[q]);
+        }
+    }
+    const bool later = ok && !done;
+    const unsigned long long m = __ballot(later);
+    if (m) {
+      int pos = 0;
+      if (l == 0) pos = atomicAdd(a.todo_count, __popcll(m));
+      pos = __shfl(pos, 0);
+      if (later) a.todo[pos + __popcll(m & ((1ULL << l) - 1ULL))] = (int)t;
+    }
+  }
+}
 
 template <int NDIM>
 __global__ void __launch_bounds__(64) k_mw_knn(KnnArgs a) {
@@ -2849,7 +2977,9 @@ __global__ void __launch_bounds__(64) k_mw_knn(KnnArgs a) {
   // cut back to the best K as soon as ~2K candidates are in (an early, small sort tightens tau for the rest of the scan),
   // at the latest when the next trip's 256 stations might not fit
   const int cut_at = min(CAP - 256, max(2 * K, 192));
-  for (long t = blockIdx.x; t < a.npt; t += gridDim.x) {
+  const long nwork = a.todo ? (long)*a.todo_count : (long)a.npt;
+  for (long w = blockIdx.x; w < nwork; w += gridDim.x) {
+    const long t = a.todo ? (long)a.todo[w] : w;
     const double qx = a.px[t], qy = a.py[t], qz = (NDIM == 3) ? a.pz[t] : 0.0;
     int cnt = 0;
     double tau = a.tau0 > 0.0 ? a.tau0 : 1e300;
@@ -3004,6 +3134,18 @@ __device__ __forceinline__ double mw_entry(const Vario& v, int mode, double x1, 
     d = sqrt(d2);
   }
   return -vario_dyn(v, d, d2);
+}
+
+// The same with the variogram model a COMPILE-TIME constant (MODEL >= 0; Euclidean coordinates): round 4.  mw_entry inlines the
+// great-circle distance and all six models -- ~960 instructions per call site -- and k_mw_chol calls it once per register-tile
+// element: its {8,13} class was 195 000 instructions (1.26 MB) of straight-line set-up code in front of a 4 000-instruction
+// elimination loop, every point streaming it through a 64 KB instruction cache.  With the model fixed an entry is ~40 instructions.
+template <int MODEL>
+__device__ __forceinline__ double mw_entry_t(const Vario& v, int mode, double x1, double y1, double z1, double x2, double y2, double z2) {
+  if (MODEL < 0) return mw_entry(v, mode, x1, y1, z1, x2, y2, z2);
+  const double dx = x1 - x2, dy = y1 - y2, dz = z1 - z2;  // z = 0 in 2-D
+  const double d2 = dx * dx + dy * dy + dz * dz;
+  return -vario<(MODEL < 0 ? 0 : MODEL), false>(v, sqrt(d2), d2);
 }
 
 // custom variogram, moving window: distances between the selected stations of every point, [point][row][col]
@@ -3309,15 +3451,16 @@ __global__ void __launch_bounds__(256) k_mw_solve(MwArgs a) {
 // RI = 12 otherwise take 256 VGPRs + a few AGPRs, which halves the occupancy -- measured 2 x slower)
 #ifndef MIK_MWC_WAVES
 #define MIK_MWC_WAVES(G, RI)                                                                                                        \
-  (((G) == 8 && (RI) >= 13) ? 2 : ((G) == 8 && (RI) == 10) ? 3 : ((G) == 8 && (RI) == 8) ? 4 : ((G) == 8 && (RI) == 6) ? 5 :         \
+  (((G) == 4 && (RI) >= 11) ? 2 : ((G) == 4 && (RI) >= 9) ? 3 : ((G) == 4 && (RI) >= 7) ? 4 : ((G) == 4 && (RI) >= 5) ? 5 :          \
+   ((G) == 8 && (RI) >= 13) ? 2 : ((G) == 8 && (RI) == 10) ? 3 : ((G) == 8 && (RI) == 8) ? 4 : ((G) == 8 && (RI) == 6) ? 5 :         \
    ((G) == 16 && (RI) == 8) ? 4 : ((G) == 16 && ((RI) == 9 || (RI) == 10)) ? 3 : ((G) == 16 && (RI) >= 11) ? 2 : 1)
 // lean update (row factors read from LDS as they are used instead of held: RI fewer live doubles) where it buys a wavefront per
 // SIMD; elsewhere it costs 1-2 % (profiles/r03_mw_classes_after_kernel_changes.txt)
 #define MIK_MWC_LEAN(G, RI)                                                                                                         \
-  (((G) == 8 && ((RI) >= 13 || (RI) == 10 || (RI) == 8 || (RI) == 6)) || ((G) == 16 && ((RI) == 8 || (RI) == 10 || (RI) >= 13)) ||  \
+  (((G) == 4 && (RI) >= 6) || ((G) == 8 && ((RI) >= 13 || (RI) == 10 || (RI) == 8 || (RI) == 6)) || ((G) == 16 && ((RI) == 8 || (RI) == 10 || (RI) >= 13)) ||  \
    ((G) == 32 && (RI) == 8))
 #endif
-template <int G, int RI>
+template <int G, int RI, int MODEL = -1>
 __global__ void __launch_bounds__((G * G < 256) ? 256 : G * G, MIK_MWC_WAVES(G, RI)) k_mw_chol(MwArgs a) {
   extern __shared__ double mw_lds[];
   constexpr int T = G * G, NT = T < 256 ? 256 : T, NB = G * RI, ACOL = NB + 4;
@@ -3378,7 +3521,7 @@ __global__ void __launch_bounds__((G * G < 256) ? 256 : G * G, MIK_MWC_WAVES(G, 
       const int col = tx + G * j;
       double v = (row == col) ? 1.0 : 0.0;  // padding rows / columns: identity
       if (row < K && col < K)
-        v = (row == col) ? shift : shift + mw_entry(a.v, a.mode, csx[row], csy[row], csz[row], csx[col], csy[col], csz[col]);
+        v = (row == col) ? shift : shift + mw_entry_t<MODEL>(a.v, a.mode, csx[row], csy[row], csz[row], csx[col], csy[col], csz[col]);
       m[i][j] = v;
     }
   }

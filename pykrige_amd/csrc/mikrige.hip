@@ -301,6 +301,8 @@ struct mik_handle {
   bool no_half_sweep = false;  // transient: this attempt must not use the half sweep
   bool last_half_sweep = false;
   bool points_from_grid = false;  // the resident points were generated by mik_set_grid (mik_adjust_points refuses them)
+  double pts_step = -1.0;         // median step between consecutive resident points (largest coordinate difference; -1 = unknown):
+                                  // tells the moving-window search whether 64 consecutive points are neighbours in space
   bool points_adjusted = false;   // mik_adjust_points has transformed the resident points (a second call would transform them twice)
   DevBuf Averify, vbuf;
   std::vector<double> hvals;   // host copy of the station values (the probe compares A c with them)
@@ -356,6 +358,8 @@ struct mik_handle {
   bool mw_force_piv = false;
   int opt_mw_lds_cap = 8192;  // largest candidate buffer the moving-window neighbour search keeps in LDS
   int opt_mw_knn_bound = 1;   // neighbour search: first pass over the 3 x 3 cells with a distance bound (see k_mw_knn)
+  int opt_mw_static = 1;      // k_mw_chol instantiated with the variogram model as a compile-time constant where possible (0: the dynamic form, for A/B)
+  int opt_mw_knn_lane = 1;    // neighbour search, windows <= 32: one lane per point first (k_mw_knn_lane), k_mw_knn for what it leaves
   int opt_mw_class = 0;       // 100 G + RI: force one thread-grid / register-tile class of k_mw_chol (0 = by window size)
   mik_timing tm{};
   std::vector<hipEvent_t> evpool;
@@ -626,8 +630,22 @@ static int launch_mw_chol(mik_handle* h, const MwArgs& a, long pc) {
   if (a.K > NB) return fail(MIK_EINVAL, "moving-window LDL^T class too small for this window");
   const size_t lds = sizeof(double) * (size_t)(2 * (NB + 4) + 9 * NB) * PPB;
   const dim3 grid((unsigned)((pc + PPB - 1) / PPB));
-  HIPC(hipFuncSetAttribute((const void*)k_mw_chol<G, RI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL((k_mw_chol<G, RI>), grid, dim3(NT), lds, h->stream, a);
+  // the variogram model as a compile-time constant where the problem allows it (Euclidean coordinates; the four models whose
+  // shifted station block is positive definite and cheap): the set-up code of the kernel shrinks 20-fold (mw_entry_t)
+#define MWC_LAUNCH(MODEL)                                                                                                   \
+  do {                                                                                                                      \
+    HIPC(hipFuncSetAttribute((const void*)k_mw_chol<G, RI, MODEL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));  \
+    hipLaunchKernelGGL((k_mw_chol<G, RI, MODEL>), grid, dim3(NT), lds, h->stream, a);                                       \
+  } while (0)
+  const int sm = (a.mode == 1 || !h->opt_mw_static) ? -1 : a.v.model;
+  switch (sm) {
+    case 0: MWC_LAUNCH(0); break;
+    case 2: MWC_LAUNCH(2); break;
+    case 3: MWC_LAUNCH(3); break;
+    case 4: MWC_LAUNCH(4); break;
+    default: MWC_LAUNCH(-1); break;
+  }
+#undef MWC_LAUNCH
   return MIK_OK;
 }
 
@@ -638,9 +656,11 @@ static int dispatch_mw_chol(mik_handle* h, const MwArgs& a, long pc) {
   if (h->opt_mw_class) {  // "mw_class" = 100 G + RI: a class forced for A/B runs (scripts/mw_classes.py)
     switch (h->opt_mw_class) {
 #define MWC(G, RI) case 100 * G + RI: return launch_mw_chol<G, RI>(h, a, pc);
-      MWC(4, 4) MWC(8, 4) MWC(8, 6) MWC(8, 8) MWC(8, 10) MWC(8, 11) MWC(8, 12) MWC(8, 13) MWC(8, 14) MWC(8, 16)
-      MWC(16, 4) MWC(16, 5) MWC(16, 6) MWC(16, 7) MWC(16, 8) MWC(16, 9) MWC(16, 10) MWC(16, 11) MWC(16, 12) MWC(16, 13) MWC(16, 14) MWC(16, 15) MWC(16, 16)
-      MWC(32, 5) MWC(32, 6) MWC(32, 7) MWC(32, 8)
+      // (round 4: the classes that lost every A/B of rounds 2-3 -- {8,14}, {8,16}, {16,4..6}, {16,15}, {16,16}, {32,5..7} -- are no longer
+      // built: each was a 100 000-instruction kernel; profiles/r03_mw_classes_*.txt keep their measurements)
+      MWC(4, 4) MWC(4, 6) MWC(4, 8) MWC(4, 10) MWC(4, 13) MWC(8, 4) MWC(8, 6) MWC(8, 8) MWC(8, 10) MWC(8, 11) MWC(8, 12) MWC(8, 13)
+      MWC(16, 7) MWC(16, 8) MWC(16, 9) MWC(16, 10) MWC(16, 11) MWC(16, 12) MWC(16, 13) MWC(16, 14)
+      MWC(32, 8)
 #undef MWC
       default: return fail(MIK_EINVAL, "mw_class: no such LDL^T class");
     }
@@ -649,8 +669,13 @@ static int dispatch_mw_chol(mik_handle* h, const MwArgs& a, long pc) {
   // as long as the register tile stays at RI <= 13 (RI = 13 only with the lean update below; beyond that the kernel needs more
   // than 256 registers and the occupancy halves: 2 x slower), then 256 threads per point up to RI = 12, 1024 threads for the last two
   if (K <= 16) return launch_mw_chol<4, 4>(h, a, pc);    // 16 threads per point, 4 points per wavefront
-  if (K <= 32) return launch_mw_chol<8, 4>(h, a, pc);    // one wavefront per point from here to K = 96: no workgroup barrier
-  if (K <= 48) return launch_mw_chol<8, 6>(h, a, pc);
+  // round 4 (profiles/r04_mw_classes_g4.txt): 16 threads per point keep winning while the tile fits -- k = 24: {4,6} 0.37 ms per
+  // 2e5 points against {8,4} 0.76; k = 32: {4,8} 0.70 / 0.93; k = 40: {4,10} 1.39 / {8,6} 1.50; k = 50: {4,13} 2.15 / {8,8} 2.54
+  if (K <= 24) return launch_mw_chol<4, 6>(h, a, pc);
+  if (K <= 32) return launch_mw_chol<4, 8>(h, a, pc);
+  if (K <= 40) return launch_mw_chol<4, 10>(h, a, pc);
+  if (K <= 48) return launch_mw_chol<8, 6>(h, a, pc);    // one wavefront per point from here to K = 104: no workgroup barrier
+  if (K <= 52) return launch_mw_chol<4, 13>(h, a, pc);
   if (K <= 64) return launch_mw_chol<8, 8>(h, a, pc);
   if (K <= 80) return launch_mw_chol<8, 10>(h, a, pc);
   if (K <= 88) return launch_mw_chol<8, 11>(h, a, pc);
@@ -994,6 +1019,10 @@ int mik_set_option(mik_handle* h, const char* key, double value) {
     h->opt_mw_solver = (int)value;
   } else if (!strcmp(key, "mw_knn_bound")) {
     h->opt_mw_knn_bound = value != 0.0;
+  } else if (!strcmp(key, "mw_knn_lane")) {
+    h->opt_mw_knn_lane = value != 0.0;
+  } else if (!strcmp(key, "mw_static")) {
+    h->opt_mw_static = value != 0.0;
   } else if (!strcmp(key, "mw_class")) {
     h->opt_mw_class = (int)value;
   } else if (!strcmp(key, "mw_pivot")) {
@@ -2859,6 +2888,22 @@ static int one_set_points(mik_handle* h, const mik_points* g, const long* idx, l
   MIKC(h->ss.ensure(sizeof(double) * cap));
   MIKC(h->pin_out.ensure(sizeof(double) * 2 * (size_t)cap));
   HIPC(hipStreamSynchronize(h->stream));
+  {  // median step between consecutive points, from <= 1024 sampled pairs (see pts_step)
+    h->pts_step = -1.0;
+    if (n >= 2) {
+      const long ns = std::min<long>(1024, n - 1);
+      std::vector<double> st((size_t)ns);
+      for (long q = 0; q < ns; ++q) {
+        const long i = (long)((double)q * (double)(n - 1) / (double)ns);
+        const long a0 = idx ? idx[lo + i] : lo + i, a1 = idx ? idx[lo + i + 1] : lo + i + 1;
+        double m = 0.0;
+        for (int d = 0; d < h->ndim; ++d) m = std::max(m, std::fabs(src[d][a1] - src[d][a0]));
+        st[(size_t)q] = std::isfinite(m) ? m : 1e300;
+      }
+      std::nth_element(st.begin(), st.begin() + ns / 2, st.end());
+      h->pts_step = st[(size_t)(ns / 2)];
+    }
+  }
   h->have_points = true;
   h->points_from_grid = false;
   h->points_adjusted = false;
@@ -2973,6 +3018,8 @@ static int one_set_grid(mik_handle* h, bool leader, const mik_grid* g, const uns
   MIKC(h->ss.ensure(sizeof(double) * cap));
   MIKC(h->pin_out.ensure(sizeof(double) * 2 * (size_t)cap));
   HIPC(hipStreamSynchronize(h->stream));
+  // consecutive points of a grid are one x step apart (meshgrid order; compacted cells of a masked grid mostly so)
+  h->pts_step = g->nx > 1 ? std::fabs(g->gx[g->nx / 2] - g->gx[g->nx / 2 - 1]) : (g->ny > 1 ? std::fabs(g->gy[g->ny / 2] - g->gy[g->ny / 2 - 1]) : 0.0);
   h->have_points = true;
   h->points_from_grid = true;
   h->have_results = false;
@@ -3453,7 +3500,7 @@ static int one_predict_mw(mik_handle* h, int n_closest) {
   MIKC(h->mw_dist.ensure(sizeof(double) * (size_t)chunk * K));
   MIKC(h->flag.ensure(sizeof(int)));
   HIPC(hipMemsetAsync(h->flag.p, 0, sizeof(int), h->stream));
-  DevBuf su, pu, wd, wi, sysbuf, gtab, gvec;
+  DevBuf su, pu, wd, wi, sysbuf, gtab, gvec, todo;
   if (custom) {
     MIKC(gtab.ensure(sizeof(double) * (size_t)chunk * K * K));
     MIKC(gvec.ensure(sizeof(double) * (size_t)chunk * K));
@@ -3550,6 +3597,22 @@ static int one_predict_mw(mik_handle* h, int n_closest) {
       }
       ka.idx_out = idx;
       ka.dist_out = dist;
+      // (measured, profiles/r04_mw_knn_ab.txt: rows of a grid, k = 10: search + rhs 2.65 -> 0.62 ms per 1e6 points, bit-identical; a
+      // 32-entry list per lane only ties with the wave-per-point search, and a shuffled point list sends every lane to the list --
+      // one same-address atomic per wavefront, +0.3 ms -- hence K <= 16 and the coherence test: 64 consecutive points must span
+      // few cells, judged from the median step between consecutive points that mik_set_points / mik_set_grid recorded)
+      if (h->opt_mw_knn_lane && K <= 16 && (long)h->grid.nx * h->grid.ny * h->grid.nz > 1 && h->pts_step >= 0.0 &&
+          64.0 * h->pts_step * (h->geo ? MIK_PI / 180.0 : 1.0) <= 10.0 * h->grid.cell) {
+        // small windows: one lane per point over the box of cells its wavefront's 64 consecutive points share (k_mw_knn_lane); the
+        // wave-per-point kernel below then only walks the list of points that pass left unfinished
+        MIKC(todo.ensure(sizeof(int) * ((size_t)pc + 1)));
+        ka.todo_count = todo.as<int>();
+        ka.todo = todo.as<int>() + 1;
+        HIPC(hipMemsetAsync(ka.todo_count, 0, sizeof(int), h->stream));
+        const unsigned lgrid = (unsigned)std::min<long>((pc + 63) / 64, 64L * h->n_cu);
+        if (three) hipLaunchKernelGGL((k_mw_knn_lane<3, 16>), dim3(lgrid), dim3(64), 0, h->stream, ka);
+        else hipLaunchKernelGGL((k_mw_knn_lane<2, 16>), dim3(lgrid), dim3(64), 0, h->stream, ka);
+      }
       if (three) {
         HIPC(hipFuncSetAttribute((const void*)k_mw_knn<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)klds));
         hipLaunchKernelGGL(k_mw_knn<3>, dim3(wgrid), dim3(64), klds, h->stream, ka);

@@ -12,7 +12,7 @@ h = _lib.Handle(0)
 h.set_problem(ndim=2, xs=coords[0], ys=coords[1], zs=None, values=values, model_id=_lib.MODEL_IDS[cfg["model"]],
               params=internal_params(cfg["model"], cfg["params"]))
 rng = np.random.default_rng(0)
-CLASSES = [(8, 4), (8, 6), (8, 8), (8, 10), (8, 11), (8, 12), (8, 13), (8, 14), (16, 5), (16, 6), (16, 7), (16, 8), (16, 9), (16, 10), (16, 11), (16, 12), (16, 13), (16, 14), (16, 15), (16, 16),
+CLASSES = [(4, 4), (4, 6), (4, 8), (4, 10), (4, 12), (4, 13), (8, 4), (8, 6), (8, 8), (8, 10), (8, 11), (8, 12), (8, 13), (8, 14), (16, 5), (16, 6), (16, 7), (16, 8), (16, 9), (16, 10), (16, 11), (16, 12), (16, 13), (16, 14), (16, 15), (16, 16),
            (32, 5), (32, 6), (32, 7), (32, 8)]
 ks = [int(a) for a in sys.argv[1:]] or [72, 80, 88, 96, 100, 104, 112, 128, 144, 160, 176, 192, 200, 208, 224, 256, 257, 320, 512, 1000]
 npt = 200000
