@@ -835,6 +835,18 @@ def main():
                                               + ("; " + roof["traffic_source"] if roof.get("traffic_source") else ""))
             except Exception:
                 pass
+        if not kw and not last.get("sparse") and not last.get("engine") and last.get("symmetric"):
+            # how much of `traffic` is HBM: no Infinity-Cache hit / miss counter exists on gfx950, so the split is made by L2-miss latency
+            # in a run of its own (scripts/gpu_hbm_split.sh) and quoted from its tracked summary, scaled to this launch's points
+            try:
+                hj = json.load(open(os.path.join(ROOT, "profiles", "k_contract_hbm_split.json")))
+                if hj["workload"] == cfg["name"]:
+                    sc = pts_per_launch / hj["points_per_launch"]
+                    roof["traffic_hbm"] = [v * sc for v in hj["traffic_hbm_bytes_per_launch_by_latency"]]
+                    roof["traffic_hbm_source"] = ("from_profile (NOT collected in this run; lower .. upper estimate, bytes per launch): " + hj["source"]
+                                                  + "; the rest of `traffic` are Infinity-Cache hits")
+            except Exception:
+                pass
         if not kw:
             # compulsory bytes of one launch: the inverse once, the RHS panel (8 M per point) in, 8 M/128 partial sums per point out
             roof["algorithmic_bytes_per_launch"] = 8.0 * (M * M + pts_per_launch * (M + M / 128.0))

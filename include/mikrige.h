@@ -178,6 +178,10 @@ int  mik_slab_of(int64_t n, int members, int i, int64_t *lo, int64_t *count); /*
  *   spherical model (not with pseudo_inv, a caller's a_inv or geographic coordinates: those run the dense contraction), 0 = off,
  *   2 = Hilbert-ordered stations with the dense contraction (A/B of the order alone).  Takes effect at the
  *   next mik_factor [MIK_SPARSE] ;
+ * "sparse_lanes" 1/2 = range-aware contraction: its launches alternate between two lanes (two streams, two sets of work buffers and
+ *   right-hand-side panels), so that the candidate / right-hand-side / list kernels of a launch and the tail of the previous
+ *   launch's tile queue overlap.  Measured 2 % faster at config 5 for a second right-hand-side panel: default 1 = one launch after
+ *   the other ;
  * "drift_eq" 0/1 = drift equilibration (default 1): every drift term enters the matrix and the right-hand sides as s_j (f_j - c_j),
  *   c_j = its mean and 1 / s_j = its largest deviation over the stations (wells excepted).  With the unbiasedness row present
  *   span{1, f_j} = span{1, s_j (f_j - c_j)}: the stations' kriging weights, z and sigma^2 are those of the reference's system

@@ -263,6 +263,12 @@ struct mik_handle {
   DevBuf xs_s, ys_s, zs_s, vals_s, extra_cols_s, sbox;
   int opt_sparse = -1;  // "sparse": -1 = auto (= 1: on for compact-support models), 0 = off, 1 = on, 2 = sorted stations, dense contraction
   DevBuf sp_cand, sp_flags, sp_klist, sp_kcount, sp_nrows, sp_rows, sp_rstart, sp_tiles, sp_xoff, sp_stats;
+  // second set (with Bt2): the launches of the range-aware contraction alternate between two lanes on two streams, so that the
+  // candidate / right-hand-side / list kernels of one launch and the tail of the previous launch's tile queue overlap
+  DevBuf sp2_cand, sp2_flags, sp2_klist, sp2_kcount, sp2_nrows, sp2_rows, sp2_rstart, sp2_tiles, sp2_xoff, part2, queue2;
+  int opt_sparse_lanes = 1;  // "sparse_lanes": 1 = one launch after the other on one stream (default), 2 = two lanes.  Measured
+                             // (profiles/r04_sparse_lanes_ab.txt): config-5 slab 64.6 -> 63.4 ms, bench grid 96.3 -> 94.0 ms -- 2 % for a
+                             // second 8.4 GB panel and per-launch times that no longer add up: off
   std::vector<double> hxs, hys, hzs;  // host copies of the station coordinates (the moving-window cell grid is built on the host)
   // moving-window neighbour search: stations sorted into a uniform grid of cells
   struct MwGrid {
@@ -813,7 +819,8 @@ static void destroy_one(mik_handle* h) {
                     &h->grid.cstart,
                     &h->px, &h->py, &h->pz, &h->grid_axes, &h->grid_idx, &h->Averify, &h->vbuf, &h->extra_rows, &h->z, &h->ss, &h->Bt, &h->Bt2, &h->part, &h->mw_idx, &h->mw_dist, &h->stat_S, &h->stat_x, &h->stat_out, &h->queue,
                     &h->xs_s, &h->ys_s, &h->zs_s, &h->vals_s, &h->extra_cols_s, &h->sbox, &h->sp_cand, &h->sp_flags, &h->sp_klist, &h->sp_kcount,
-                    &h->sp_nrows, &h->sp_rows, &h->sp_rstart, &h->sp_tiles, &h->sp_xoff, &h->sp_stats};
+                    &h->sp_nrows, &h->sp_rows, &h->sp_rstart, &h->sp_tiles, &h->sp_xoff, &h->sp_stats, &h->sp2_cand, &h->sp2_flags, &h->sp2_klist, &h->sp2_kcount,
+                    &h->sp2_nrows, &h->sp2_rows, &h->sp2_rstart, &h->sp2_tiles, &h->sp2_xoff, &h->part2, &h->queue2, &h->dsc};
   for (DevBuf* b : bufs) b->release();
   h->pin_in.release();
   h->pin_out.release();
@@ -965,6 +972,9 @@ int mik_set_option(mik_handle* h, const char* key, double value) {
   } else if (!strcmp(key, "sparse")) {
     if (value != -1.0 && value != 0.0 && value != 1.0 && value != 2.0) return fail(MIK_EINVAL, "sparse must be -1 (auto), 0, 1 or 2");
     h->opt_sparse = (int)value;
+  } else if (!strcmp(key, "sparse_lanes")) {
+    if (value != 1.0 && value != 2.0) return fail(MIK_EINVAL, "sparse_lanes must be 1 or 2");
+    h->opt_sparse_lanes = (int)value;
   } else if (!strcmp(key, "drift_eq")) {
     h->opt_drift_eq = value != 0.0;
   } else if (!strcmp(key, "pairs")) {
@@ -3165,11 +3175,12 @@ static int one_predict(mik_handle* h) {
   // "rhs_overlap" (off by default, see the option): two RHS panels, k_rhs of chunk c + 1 on a second stream while chunk c is
   // contracted.
   const bool overlap = h->opt_rhs_overlap && h->model != MIK_MODEL_CUSTOM && !sparse;
+  const bool lanes2_wanted = sparse && h->opt_sparse_lanes == 2;
   // keep the RHS panels under ~1/4 of device memory
   size_t freeb = 0, totalb = 0;
   HIPC(hipMemGetInfo(&freeb, &totalb));
   const size_t have = h->Bt.bytes + h->Bt2.bytes;
-  while (chunk > 128 && (size_t)chunk * Mp * sizeof(double) * (overlap ? 2 : 1) > std::max(freeb + have, have) / 2) chunk = ((chunk / 2 + 127) / 128) * 128;
+  while (chunk > 128 && (size_t)chunk * Mp * sizeof(double) * ((overlap || lanes2_wanted) ? 2 : 1) > std::max(freeb + have, have) / 2) chunk = ((chunk / 2 + 127) / 128) * 128;
   // equal chunks: ceil(npt / chunk) launches of the same size (a short last launch drains as long as a full one)
   long nchunks = (npt + chunk - 1) / chunk;
   chunk = (((npt + nchunks - 1) / nchunks + 127) / 128) * 128;
@@ -3181,17 +3192,33 @@ static int one_predict(mik_handle* h) {
   MIKC(h->pin_out.ensure(sizeof(double) * 2 * (size_t)npt));  // (a previous result may have left with mik_take_results)
   MIKC(get_events(h, 2 + 6 * (size_t)nchunks));
   std::vector<unsigned long long> sp_host;
+  const bool lanes2 = lanes2_wanted && nchunks > 1;
+  struct SpLane {
+    DevBuf *cand, *flags, *klist, *kcount, *nrows, *rows, *rstart, *tiles, *xoff, *part, *queue, *Bt;
+    hipStream_t st;
+  };
+  SpLane lane[2] = {{&h->sp_cand, &h->sp_flags, &h->sp_klist, &h->sp_kcount, &h->sp_nrows, &h->sp_rows, &h->sp_rstart, &h->sp_tiles, &h->sp_xoff,
+                     &h->part, &h->queue, &h->Bt, h->stream},
+                    {&h->sp2_cand, &h->sp2_flags, &h->sp2_klist, &h->sp2_kcount, &h->sp2_nrows, &h->sp2_rows, &h->sp2_rstart, &h->sp2_tiles,
+                     &h->sp2_xoff, &h->part2, &h->queue2, &h->Bt2, h->stream2}};
   if (sparse) {
     const size_t nTb = (size_t)chunk / 128;
-    MIKC(h->sp_cand.ensure(nTb * nIblk));
-    MIKC(h->sp_flags.ensure(nTb * nK16));
-    MIKC(h->sp_klist.ensure(sizeof(unsigned short) * nTb * nK16));
-    MIKC(h->sp_kcount.ensure(sizeof(int) * nTb));
-    MIKC(h->sp_nrows.ensure(sizeof(int) * nTb));
-    MIKC(h->sp_rows.ensure(sizeof(unsigned short) * nTb * nIblk));
-    MIKC(h->sp_rstart.ensure(sizeof(unsigned short) * nTb * nIblk));
-    MIKC(h->sp_tiles.ensure(sizeof(unsigned) * nTb * nIblk));
-    MIKC(h->sp_xoff.ensure(sizeof(int) * 9));
+    for (int L = 0; L < (lanes2 ? 2 : 1); ++L) {
+      MIKC(lane[L].cand->ensure(nTb * nIblk));
+      MIKC(lane[L].flags->ensure(nTb * nK16));
+      MIKC(lane[L].klist->ensure(sizeof(unsigned short) * nTb * nK16));
+      MIKC(lane[L].kcount->ensure(sizeof(int) * nTb));
+      MIKC(lane[L].nrows->ensure(sizeof(int) * nTb));
+      MIKC(lane[L].rows->ensure(sizeof(unsigned short) * nTb * nIblk));
+      MIKC(lane[L].rstart->ensure(sizeof(unsigned short) * nTb * nIblk));
+      MIKC(lane[L].tiles->ensure(sizeof(unsigned) * nTb * nIblk));
+      MIKC(lane[L].xoff->ensure(sizeof(int) * 9));
+      MIKC(lane[L].queue->ensure(8 * sizeof(unsigned long long)));
+      if (L == 1) {
+        MIKC(h->Bt2.ensure(sizeof(double) * (size_t)chunk * Mp));
+        MIKC(h->part2.ensure(sizeof(double) * (size_t)chunk * nIblk));
+      }
+    }
     MIKC(h->sp_stats.ensure(sizeof(unsigned long long) * 2 * (size_t)nchunks));
     sp_host.assign(2 * (size_t)nchunks, 0ULL);
   }
@@ -3205,7 +3232,7 @@ static int one_predict(mik_handle* h) {
   hipStream_t sr = two ? h->stream2 : h->stream;  // right-hand sides
   HIPC(hipStreamWaitEvent(h->stream, h->ev_d2h, 0));  // an earlier predict's result copies still read z / ss
   HIPC(hipEventRecord(h->evpool[0], h->stream));
-  if (two) HIPC(hipStreamWaitEvent(sr, h->evpool[0], 0));
+  if (two || lanes2) HIPC(hipStreamWaitEvent(h->stream2, h->evpool[0], 0));
   auto launch_rhs = [&](long c) -> int {
     const long t0 = c * chunk;
     const int nvalid = (int)std::min<long>(chunk, npt - t0);
@@ -3241,19 +3268,22 @@ static int one_predict(mik_handle* h) {
     if (two && c >= 2) HIPC(hipStreamWaitEvent(sr, h->pr_events[2 * (c - 2) + 1], 0));  // the contraction that read this panel is done
     if (sparse) {
       // candidates (bounding boxes), cleared flags, then delta for the candidate blocks only
-      a.cand = h->sp_cand.as<unsigned char>();
-      a.flags = h->sp_flags.as<unsigned char>();
+      const SpLane& ln = lane[lanes2 ? (c & 1) : 0];
+      hipStream_t ss = ln.st;
+      a.Bt = ln.Bt->as<double>();
+      a.cand = ln.cand->as<unsigned char>();
+      a.flags = ln.flags->as<unsigned char>();
       a.nIblk = nIblk;
       a.nK16 = nK16;
       a.sill = h->v.p0 + h->v.p2;
-      HIPC(hipEventRecord(h->evpool[2 + 4 * nchunks + 2 * c], sr));
-      hipLaunchKernelGGL(k_sp_cand, dim3(palloc / 128), dim3(128), 0, sr, a.px, a.py, a.pz, nvalid, (const double*)h->sbox.as<double>(), nIblk,
-                         h->N / 128, std::max(h->v.p1, h->eps), h->sp_cand.as<unsigned char>());
-      HIPC(hipMemsetAsync(h->sp_flags.p, 0, (size_t)(palloc / 128) * nK16, sr));
-      HIPC(hipEventRecord(h->evpool[2 + 4 * c], sr));
-      if (h->ndim == 3) hipLaunchKernelGGL((k_rhs<3, 3, true>), dim3(palloc / MIK_TP), dim3(256), 0, sr, a);
-      else hipLaunchKernelGGL((k_rhs<3, 2, true>), dim3(palloc / MIK_TP), dim3(256), 0, sr, a);
-      HIPC(hipEventRecord(h->evpool[3 + 4 * c], sr));
+      HIPC(hipEventRecord(h->evpool[2 + 4 * nchunks + 2 * c], ss));
+      hipLaunchKernelGGL(k_sp_cand, dim3(palloc / 128), dim3(128), 0, ss, a.px, a.py, a.pz, nvalid, (const double*)h->sbox.as<double>(), nIblk,
+                         h->N / 128, std::max(h->v.p1, h->eps), ln.cand->as<unsigned char>());
+      HIPC(hipMemsetAsync(ln.flags->p, 0, (size_t)(palloc / 128) * nK16, ss));
+      HIPC(hipEventRecord(h->evpool[2 + 4 * c], ss));
+      if (h->ndim == 3) hipLaunchKernelGGL((k_rhs<3, 3, true>), dim3(palloc / MIK_TP), dim3(256), 0, ss, a);
+      else hipLaunchKernelGGL((k_rhs<3, 2, true>), dim3(palloc / MIK_TP), dim3(256), 0, ss, a);
+      HIPC(hipEventRecord(h->evpool[3 + 4 * c], ss));
       return MIK_OK;
     }
     HIPC(hipEventRecord(h->evpool[2 + 4 * c], sr));
@@ -3282,37 +3312,39 @@ static int one_predict(mik_handle* h) {
     hipEvent_t e1 = h->evpool[4 + 4 * c], e2 = h->evpool[5 + 4 * c];
     if (sparse) {
       const int nTb = palloc / 128;
-      hipLaunchKernelGGL(k_sp_lists, dim3(nTb), dim3(64), 0, sc, (const unsigned char*)h->sp_flags.as<unsigned char>(), nK16, nIblk,
-                         h->sp_klist.as<unsigned short>(), h->sp_kcount.as<int>(), h->sp_rows.as<unsigned short>(),
-                         h->sp_rstart.as<unsigned short>(), h->sp_nrows.as<int>());
-      hipLaunchKernelGGL(k_sp_tiles, dim3(1), dim3(1024), 0, sc, (const int*)h->sp_nrows.as<int>(), (const int*)h->sp_kcount.as<int>(),
-                         (const unsigned short*)h->sp_rstart.as<unsigned short>(), nIblk, nTb, h->sp_tiles.as<unsigned>(),
-                         h->sp_xoff.as<int>(), h->sp_stats.as<unsigned long long>() + 2 * c);
+      const SpLane& ln = lane[lanes2 ? (c & 1) : 0];
+      hipStream_t sc = ln.st;  // (shadows the dense path's stream: this launch lives on its lane's)
+      hipLaunchKernelGGL(k_sp_lists, dim3(nTb), dim3(64), 0, sc, (const unsigned char*)ln.flags->as<unsigned char>(), nK16, nIblk,
+                         ln.klist->as<unsigned short>(), ln.kcount->as<int>(), ln.rows->as<unsigned short>(),
+                         ln.rstart->as<unsigned short>(), ln.nrows->as<int>());
+      hipLaunchKernelGGL(k_sp_tiles, dim3(1), dim3(1024), 0, sc, (const int*)ln.nrows->as<int>(), (const int*)ln.kcount->as<int>(),
+                         (const unsigned short*)ln.rstart->as<unsigned short>(), nIblk, nTb, ln.tiles->as<unsigned>(),
+                         ln.xoff->as<int>(), h->sp_stats.as<unsigned long long>() + 2 * c);
       HIPC(hipEventRecord(h->evpool[3 + 4 * nchunks + 2 * c], sc));
-      MIKC(h->queue.ensure(8 * sizeof(unsigned long long)));
-      HIPC(hipMemsetAsync(h->queue.p, 0, 8 * sizeof(unsigned long long), sc));
+      HIPC(hipMemsetAsync(ln.queue->p, 0, 8 * sizeof(unsigned long long), sc));
       SpArgs sa{};
       sa.Ainv = h->T.as<double>();
       sa.lda = Mp;
-      sa.Bt = h->Bt.as<double>();
+      sa.Bt = ln.Bt->as<double>();
       sa.ldb = Mp;
-      sa.part = h->part.as<double>();
+      sa.part = ln.part->as<double>();
       sa.palloc = palloc;
       sa.kend = kend;
       sa.nIblk = nIblk;
       sa.nK16 = nK16;
-      sa.klist = h->sp_klist.as<unsigned short>();
-      sa.kcount = h->sp_kcount.as<int>();
-      sa.rows = h->sp_rows.as<unsigned short>();
-      sa.rstart = h->sp_rstart.as<unsigned short>();
-      sa.tiles = h->sp_tiles.as<unsigned>();
-      sa.xoff = h->sp_xoff.as<int>();
-      sa.queue = h->queue.as<unsigned long long>();
+      sa.klist = ln.klist->as<unsigned short>();
+      sa.kcount = ln.kcount->as<int>();
+      sa.rows = ln.rows->as<unsigned short>();
+      sa.rstart = ln.rstart->as<unsigned short>();
+      sa.tiles = ln.tiles->as<unsigned>();
+      sa.xoff = ln.xoff->as<int>();
+      sa.queue = ln.queue->as<unsigned long long>();
       HIPC(hipEventRecord(e1, sc));
       hipLaunchKernelGGL((k_contract_sp<2>), dim3((unsigned)std::min<long>(2L * h->n_cu, (long)nTb * nIblk)), dim3(512), 0, sc, sa);
       HIPC(hipEventRecord(e2, sc));
-      hipLaunchKernelGGL(k_ss_reduce_sp, dim3((nvalid + 255) / 256), dim3(256), 0, sc, (const double*)h->part.as<double>(), palloc,
-                         (const int*)h->sp_nrows.as<int>(), nvalid, 2.0 * (h->v.p0 + h->v.p2), h->ss.as<double>() + t0);
+      hipLaunchKernelGGL(k_ss_reduce_sp, dim3((nvalid + 255) / 256), dim3(256), 0, sc, (const double*)ln.part->as<double>(), palloc,
+                         (const int*)ln.nrows->as<int>(), nvalid, 2.0 * (h->v.p0 + h->v.p2), h->ss.as<double>() + t0);
+      if (lanes2 && (c & 1)) HIPC(hipEventRecord(h->pr_events[0], sc));  // lane 1's latest launch (joined below)
       HIPC(hipEventRecord(h->ev_chunk, sc));
       HIPC(hipStreamWaitEvent(h->stream_d2h, h->ev_chunk, 0));
       HIPC(hipMemcpyAsync(h->pin_out.as<double>() + t0, h->z.as<double>() + t0, sizeof(double) * nvalid, hipMemcpyDeviceToHost,
@@ -3379,6 +3411,7 @@ static int one_predict(mik_handle* h) {
     h->tm.contract_flops_executed += 2.0 * 128.0 * 128.0 * kext * (palloc / 128);
   }
   HIPC(hipGetLastError());
+  if (lanes2) HIPC(hipStreamWaitEvent(h->stream, h->pr_events[0], 0));  // the handle's stream ends behind both lanes
   HIPC(hipEventRecord(h->evpool[1], h->stream));
   HIPC(hipEventRecord(h->ev_d2h, h->stream_d2h));
   HIPC(hipStreamSynchronize(h->stream));

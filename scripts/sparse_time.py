@@ -24,10 +24,10 @@ def synth(seed, n, ndim):
     return c, v + 0.1 * rng.standard_normal(n)
 
 
-def run(name, n, grid, params, ndim=2, seed=5, reps=2, modes=(0, 1)):
+def run(name, n, grid, params, ndim=2, seed=5, reps=3, modes=(0, 1, 11)):
     c, v = synth(seed, n, ndim)
     axes = [np.linspace(0.0, 1.0, g) for g in grid]
-    if ndim == 2 and n == 8000:
+    if ndim == 2 and n == 8000 and grid[1] == 512:
         axes[1] = np.linspace(0.0, 1.0, 4096)[:grid[1]]  # config 5: one GPU's 512 rows of the 4096 x 4096 grid
     res = {}
     for sparse in modes:
@@ -35,7 +35,8 @@ def run(name, n, grid, params, ndim=2, seed=5, reps=2, modes=(0, 1)):
             m = pa.OrdinaryKriging(c[0], c[1], v, variogram_model="spherical", variogram_parameters=params)
         else:
             m = pa.OrdinaryKriging3D(c[0], c[1], c[2], v, variogram_model="spherical", variogram_parameters=params)
-        m._get_handle().set_option("sparse", sparse)
+        m._get_handle().set_option("sparse", 1 if sparse else 0)  # mode 11 = sparse with ONE lane (option sparse_lanes), 1 = the default two
+        m._get_handle().set_option("sparse_lanes", 1 if sparse == 11 else 2)
         best = None
         for _ in range(reps):
             t0 = time.perf_counter()
@@ -46,7 +47,7 @@ def run(name, n, grid, params, ndim=2, seed=5, reps=2, modes=(0, 1)):
         res[sparse] = (np.ma.getdata(z).copy(), np.ma.getdata(ss).copy(), best)
         t = best[1]
         npt = z.size
-        print("%-34s sparse=%d  execute %8.2f ms  %7.3f M points/s | invert %6.2f rhs %7.2f contract %8.2f lists %5.2f ms | "
+        print("%-34s sparse=%2d  execute %8.2f ms  %7.3f M points/s | invert %6.2f rhs %7.2f contract %8.2f lists %5.2f ms | "
               "tiles %d / %d  ktiles %.3g / %.3g | executed %.1f TFLOP/s" % (
                   name, sparse, 1e3 * best[0], npt / best[0] / 1e6, t["invert_ms"], t["rhs_ms"], t["contract_ms"], t["sparse_lists_ms"],
                   t["sparse_tiles"], t["sparse_tiles_dense"], t["sparse_ktiles"], t["sparse_ktiles_dense"],
@@ -59,6 +60,7 @@ def run(name, n, grid, params, ndim=2, seed=5, reps=2, modes=(0, 1)):
 if __name__ == "__main__":
     quick = "--quick" in sys.argv
     run("c5 slab N=8000 4096x512 r=0.2", 8000, (4096, 512), [1.0, 0.2, 0.01])
+    run("c5 bench grid (y over 0..1)", 8000, (4096, 513), [1.0, 0.2, 0.01])
     if not quick:
         run("N=8000 4096x512 r=0.05", 8000, (4096, 512), [1.0, 0.05, 0.01])
         run("N=8000 4096x512 r=0.6", 8000, (4096, 512), [1.0, 0.6, 0.01])

@@ -323,3 +323,66 @@ def test_empty_cell_range_is_empty_not_the_whole_grid():
     z, ss = h.get_results()
     assert np.array_equal(z, zall[10:15]) and np.array_equal(ss, sall[10:15])
     h.close()
+
+
+@pytest.mark.gpu
+def test_adjusting_the_resident_points_twice_is_refused_and_stale_results_are_not_handed_out():
+    """Round-3 advisor findings: a second mik_adjust_points on the same points would apply the anisotropy transform twice (now
+    MIK_ESTATE); Handle.get_results after new points were set must not return the previous predict's arrays."""
+    from pykrige_amd import _lib
+
+    rng = np.random.default_rng(4)
+    x, y, v = rng.random(30), rng.random(30), rng.random(30)
+    h = _lib.Handle(0)
+    h.set_problem(ndim=2, xs=x, ys=y, zs=None, values=v, model_id=_lib.MODEL_IDS["exponential"], params=[0.9, 0.3, 0.1])
+    h.factor()
+    px, py = rng.random(50), rng.random(50)
+    h.set_points(px, py)
+    rot = np.array([[np.cos(0.3), -np.sin(0.3)], [np.sin(0.3), np.cos(0.3)]])
+    h.adjust_points([0.5, 0.5], rot, [1.0, 2.0])
+    with pytest.raises(RuntimeError):
+        h.adjust_points([0.5, 0.5], rot, [1.0, 2.0])
+    h.predict()
+    z1, _ = h.get_results()
+    h.set_points(px[:20], py[:20])  # new points: the old results are gone
+    with pytest.raises(RuntimeError):
+        h.get_results()
+    h.adjust_points([0.5, 0.5], rot, [1.0, 2.0])  # fresh points may be adjusted again
+    h.predict()
+    z2, _ = h.get_results()
+    assert z2.size == 20 and np.array_equal(z2, z1[:20])
+    h.close()
+
+
+@pytest.mark.gpu
+def test_page_locked_results_on_loan_are_capped():
+    """mik_take_results lends the page-locked landing zone to the caller; beyond MIK_PIN_LENT_CAP bytes on loan it refuses and the
+    copying mik_get_results serves the call (round-3 advisor finding: a caller keeping many results pinned without limit)."""
+    import subprocess
+    import sys
+
+    code = '''
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np
+from pykrige_amd import _lib
+rng = np.random.default_rng(1)
+x, y, v = rng.random(40), rng.random(40), rng.random(40)
+h = _lib.Handle(0)
+h.set_problem(ndim=2, xs=x, ys=y, zs=None, values=v, model_id=_lib.MODEL_IDS["exponential"], params=[0.9, 0.3, 0.1])
+h.factor()
+h.set_points(rng.random(4096), rng.random(4096))
+kept, owned = [], 0
+for i in range(6):
+    h.predict()
+    z, ss = h.get_results()
+    kept.append((z, ss))
+    owned += int(z.base is not None and not z.flags.owndata)   # a view of the lent buffer
+assert all(np.array_equal(kept[0][0], k[0]) for k in kept)
+print("LENT", owned)
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    # each result = 2 x 4096 doubles = 64 KiB; a cap of 200 000 bytes allows three on loan
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, MIK_PIN_LENT_CAP="200000"))
+    assert r.returncode == 0, r.stderr[-800:]
+    lent = int([ln for ln in r.stdout.splitlines() if ln.startswith("LENT")][-1].split()[1])
+    assert 1 <= lent <= 3, lent
