@@ -229,6 +229,9 @@ int  mik_slab_of(int64_t n, int members, int i, int64_t *lo, int64_t *count); /*
  * "panel_rows" 32 | 64 | 128 = rows of the column panel one block of the sweep's panel kernel forms (same bits; default 32:
  *   four times the blocks of the one-tile form, the kernel sits on the update stream's critical path) [MIK_PANEL_ROWS] ;
  * "pinv_fast" 0/1 = pseudo_inv: try the deflated regular inverse before the Jacobi pseudo-inverse (default 1) ;
+ * "pinv_block" -1/0/1 = the Jacobi pseudo-inverse (factor_path 4) in its block form (default -1 = from 1536 rows on; 1 = always): rows in blocks of 32 sorted by norm, per
+ *   pair of blocks one pass for the 64 x 64 Gram matrix, its eigenproblem by a two-sided Jacobi in LDS, one pass for the block
+ *   rotation of B and W -- ~3 M / 32 passes over the matrix per sweep instead of ~2 M (0 = one row pair per workgroup, rounds 1-3) ;
  * "verify" 0/1 = probe every inverse the device computes against the matrix itself before it is used (default 1):
  *   res_z = max |A c - [Z; 0]| / max(1, max|Z|) with c = A_inv[:, :n] Z (bounds the error of z: z_g = w_g . (A c)) and
  *   res_inv = max |A_inv A e_j - e_j| over three station columns.  "verify_tol_z" (default 5e-10) / "verify_tol_inv" (1e-8):

@@ -2743,6 +2743,235 @@ k_jac_step(double* __restrict__ B, double* __restrict__ W, long ld, int n, int m
   }
 }
 
+// ---- BLOCK one-sided Jacobi (round 4): the general pseudo-inverse without a pass over the matrix per row pair ---------------------
+// The scalar form above streams B and W once per round of the tournament, M - 1 rounds per sweep: 9.3 s at M = 4000.  Here the rows
+// are taken in blocks of MIK_BJ_B = 32 (sorted by norm at the start of every sweep: de Rijk's ordering, which the Gram route needs for
+// its accuracy -- scripts/prototype_block_jacobi.py, profiles/r03_block_jacobi_prototype_cpu.txt); a round pairs the blocks off, and
+// for every pair X (64 rows x M)
+//   k_bj_gram      G = X X^T in one pass over the 64 rows (column slices on separate workgroups),
+//   k_bj_eig       if some pair of live rows is further from orthogonal than `tol`, the 64 x 64 symmetric eigenproblem
+//                  G = Q diag Q^T by a two-sided cyclic Jacobi in LDS (relative accuracy on graded matrices: a norm-wise
+//                  eigensolver loses the small singular values the pseudo-inverse is made of),
+//   k_bj_rotate    X <- Q^T X for the rows of B and of W (second pass),
+// so a sweep streams the matrix ~3 (M / 32 - 1) times instead of ~2 (M - 1) times, and pairs already orthogonal cost one pass.
+// order[] = row numbers sorted by norm, padded with -1 to whole blocks (and to an even number of blocks).
+#define MIK_BJ_B 32
+#define MIK_BJ_LD 65  // LDS row stride of the 64 x 64 matrices (odd: rows and columns are both walked)
+// the pair of blocks (or of rows) that slot `b` of round `r` of a round-robin tournament over m (even) players holds
+__device__ __forceinline__ void bj_pair(int m, int r, int b, int& lo, int& hi) {
+  int i = r, j = m - 1;
+  if (b > 0) {
+    i = (r + b) % (m - 1);
+    j = (r - b + (m - 1)) % (m - 1);
+  }
+  lo = i < j ? i : j;
+  hi = i < j ? j : i;
+}
+// G = X X^T of a pair's 64 rows over ONE slice of the columns (grid: pairs x slices; the slices' partial sums are added in a fixed order
+// by k_bj_eig: deterministic, no atomics): 16 x 16 threads, 4 x 4 entries each, the slice staged 64 columns at a time (column-major in LDS)
+__global__ void __launch_bounds__(64)
+k_bj_gram(const double* __restrict__ B, long ld, int n, const int* __restrict__ order, int nb, int round, int nslice,
+          double* __restrict__ Gpart) {
+  // ONE wavefront per (pair, slice): 8 x 8 threads with 8 x 8 entries each -- 16 LDS reads per 64 multiply-adds (the 16 x 16 x (4 x 4)
+  // form of the first version read 8 per 16 and was bound by the LDS pipe: 254 us per round at M = 4000, now ~2 x less)
+  __shared__ double Xs[64 * MIK_BJ_LD];
+  __shared__ int idx[64];
+  const int t = threadIdx.x, ty = t >> 3, tx = t & 7;
+  int bi, bj;
+  bj_pair(nb, round, blockIdx.x, bi, bj);
+  idx[t] = order[(t < 32 ? bi : bj) * MIK_BJ_B + (t & 31)];
+  __syncthreads();
+  const int per = (((n + nslice - 1) / nslice + 63) / 64) * 64;
+  const int cbeg = blockIdx.y * per, cend = min(n, cbeg + per);
+  double acc[8][8] = {};
+  for (int c0 = cbeg; c0 < cend; c0 += 64) {
+    for (int r = 0; r < 64; ++r) {  // one row per pass: 64 consecutive columns (coalesced)
+      const int row = idx[r], c = c0 + t;
+      Xs[t * MIK_BJ_LD + r] = (row >= 0 && c < cend) ? B[(long)row * ld + c] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int c = 0; c < 64; ++c) {
+      double a[8], b[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        a[u] = Xs[c * MIK_BJ_LD + 8 * ty + u];
+        b[u] = Xs[c * MIK_BJ_LD + 8 * tx + u];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int w = 0; w < 8; ++w) acc[u][w] += a[u] * b[w];
+    }
+    __syncthreads();
+  }
+  double* go = Gpart + ((long)blockIdx.x * nslice + blockIdx.y) * 64 * 64;
+#pragma unroll
+  for (int u = 0; u < 8; ++u)
+#pragma unroll
+    for (int w = 0; w < 8; ++w) go[(8 * ty + u) * 64 + 8 * tx + w] = acc[u][w];
+}
+
+// the pair's Gram matrix (sum of the slices), the test whether its live rows are orthogonal already, and if not its eigenvectors
+__global__ void __launch_bounds__(256)
+k_bj_eig(const double* __restrict__ Gpart, int nslice, double dead2, double tol, int max_inner, double* __restrict__ Qbuf,
+         int* __restrict__ active, unsigned long long* __restrict__ worst) {
+  extern __shared__ double bj_lds[];
+  double* G = bj_lds;                     // [64][65]
+  double* Q = G + 64 * MIK_BJ_LD;         // [64][65]
+  __shared__ double cs[32][2];
+  __shared__ int pq[32][2];
+  __shared__ double red[4];
+  __shared__ int flag;
+  const int t = threadIdx.x, ty = t >> 4, tx = t & 15;
+  double acc[4][4];
+  {
+    const double* gi = Gpart + (long)blockIdx.x * nslice * 64 * 64;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        double v = 0.0;
+        for (int sl = 0; sl < nslice; ++sl) v += gi[(long)sl * 64 * 64 + (4 * ty + u) * 64 + 4 * tx + w];
+        acc[u][w] = v;
+      }
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      G[(4 * ty + u) * MIK_BJ_LD + 4 * tx + w] = acc[u][w];
+      Q[(4 * ty + u) * MIK_BJ_LD + 4 * tx + w] = (4 * ty + u == 4 * tx + w) ? 1.0 : 0.0;
+    }
+  __syncthreads();
+  // how far from orthogonal are the live rows of this pair?  (rows below a hundredth of the cut-off are the null space: noise)
+  double far = 0.0;
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const int p = 4 * ty + u, q = 4 * tx + w;
+      const double gp = G[p * MIK_BJ_LD + p], gq = G[q * MIK_BJ_LD + q];
+      if (p != q && gp > dead2 && gq > dead2) far = fmax(far, fabs(acc[u][w]) / sqrt(gp * gq));
+    }
+  for (int o = 32; o > 0; o >>= 1) far = fmax(far, __shfl_xor(far, o));
+  if ((t & 63) == 0) red[t >> 6] = far;
+  __syncthreads();
+  if (t == 0) {
+    far = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    atomicMax(worst, (unsigned long long)__double_as_longlong(far));
+    flag = far > tol ? 1 : 0;
+    active[blockIdx.x] = flag;
+  }
+  __syncthreads();
+  if (!flag) return;
+  // two-sided cyclic Jacobi on G (64 players, 63 rounds of 32 disjoint rotations per sweep), eigenvectors accumulated in Q.  A round:
+  // 32 threads form the rotations; then G <- J^T G J as 32 x 32 independent 2 x 2 blocks (block (k1, k2) = rows of pair k1, columns of
+  // pair k2: R_k1^T [..] R_k2, in place) and Q <- Q J column pair by column pair -- one barrier-separated phase, not two.  Rotations are
+  // applied down to 1e-16 relative; the sweeps end when none exceeded 1e-15 (below that they chase rounding noise for ever).
+  // max_inner: while the rows are still far from orthogonal the outer iteration does not need the eigenvectors of THIS Gram matrix
+  // to full accuracy -- any orthogonal Q is a valid step, and the first sweeps of a Jacobi iteration do most of the work
+  for (int sweep = 0; sweep < max_inner; ++sweep) {
+    if (t == 0) flag = 0;
+    __syncthreads();
+    for (int r = 0; r < 63; ++r) {
+      if (t < 32) {
+        int p, q;
+        bj_pair(64, r, t, p, q);
+        const double app = G[p * MIK_BJ_LD + p], aqq = G[q * MIK_BJ_LD + q], apq = G[p * MIK_BJ_LD + q];
+        const double den = sqrt(fabs(app * aqq));
+        double c = 1.0, sn = 0.0;
+        if (den > 0.0 && fabs(apq) > 1e-16 * den) {
+          const double zeta = (aqq - app) / (2.0 * apq);
+          const double tt = ((zeta >= 0.0) ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+          c = 1.0 / sqrt(1.0 + tt * tt);
+          sn = c * tt;
+          if (fabs(apq) > 1e-15 * den) flag = 1;
+        }
+        pq[t][0] = p, pq[t][1] = q;
+        cs[t][0] = c, cs[t][1] = sn;
+      }
+      __syncthreads();
+      for (int e = t; e < 32 * 32; e += 256) {  // 2 x 2 blocks of G
+        const int k1 = e >> 5, k2 = e & 31;
+        const int p1 = pq[k1][0], q1 = pq[k1][1], p2 = pq[k2][0], q2 = pq[k2][1];
+        const double c1 = cs[k1][0], s1 = cs[k1][1], c2 = cs[k2][0], s2 = cs[k2][1];
+        const double gpp = G[p1 * MIK_BJ_LD + p2], gpq = G[p1 * MIK_BJ_LD + q2], gqp = G[q1 * MIK_BJ_LD + p2], gqq = G[q1 * MIK_BJ_LD + q2];
+        // rows:  [p1; q1] <- [c1 -s1; s1 c1] [p1; q1]
+        const double rpp = c1 * gpp - s1 * gqp, rpq = c1 * gpq - s1 * gqq, rqp = s1 * gpp + c1 * gqp, rqq = s1 * gpq + c1 * gqq;
+        // columns: [p2 q2] <- [p2 q2] [c2 s2; -s2 c2]
+        G[p1 * MIK_BJ_LD + p2] = c2 * rpp - s2 * rpq;
+        G[p1 * MIK_BJ_LD + q2] = s2 * rpp + c2 * rpq;
+        G[q1 * MIK_BJ_LD + p2] = c2 * rqp - s2 * rqq;
+        G[q1 * MIK_BJ_LD + q2] = s2 * rqp + c2 * rqq;
+      }
+      for (int e = t; e < 32 * 64; e += 256) {  // Q <- Q J
+        const int k = e >> 6, row = e & 63, p = pq[k][0], q = pq[k][1];
+        const double c = cs[k][0], sn = cs[k][1];
+        const double qp = Q[row * MIK_BJ_LD + p], qq = Q[row * MIK_BJ_LD + q];
+        Q[row * MIK_BJ_LD + p] = c * qp - sn * qq;
+        Q[row * MIK_BJ_LD + q] = sn * qp + c * qq;
+      }
+      __syncthreads();
+    }
+    if (!flag) break;  // (everyone reads it between the last barrier above and the next one)
+    __syncthreads();
+  }
+  double* qo = Qbuf + (long)blockIdx.x * 64 * 64;
+  for (int e = t; e < 64 * 64; e += 256) qo[e] = Q[(e >> 6) * MIK_BJ_LD + (e & 63)];
+}
+
+// X <- Q^T X for the 64 rows of an active pair and a chunk of 64 columns, both matrices (z = 0: B, 1: W): a 64 x 64 x 64 product from
+// LDS, 16 x 16 threads with 4 x 4 outputs each (rows 4 ty .., columns 4 tx ..).  (One wavefront with 8 x 8 outputs per thread, the form
+// that sped up k_bj_gram, was measured 2.7 x SLOWER here -- 661 against 242 us per round at M = 4000: Q and the X chunk are 64 KB of LDS
+// per wavefront, two wavefronts per CU.)
+__global__ void __launch_bounds__(256)
+k_bj_rotate(double* __restrict__ Bm, double* __restrict__ Wm, long ld, int ncols, const int* __restrict__ order, int nb, int round,
+            const double* __restrict__ Qbuf, const int* __restrict__ active) {
+  if (!active[blockIdx.x]) return;
+  __shared__ double Qs[64 * 64];  // Q[k][i]
+  __shared__ double Xs[64 * 64];  // X[k][c]
+  __shared__ int idx[64];
+  const int t = threadIdx.x, ty = t >> 4, tx = t & 15;
+  int bi, bj;
+  bj_pair(nb, round, blockIdx.x, bi, bj);
+  if (t < 64) idx[t] = order[(t < 32 ? bi : bj) * MIK_BJ_B + (t & 31)];
+  const double* qi = Qbuf + (long)blockIdx.x * 64 * 64;
+  for (int e = t; e < 64 * 64; e += 256) Qs[e] = qi[e];
+  __syncthreads();
+  double* X = blockIdx.z ? Wm : Bm;
+  const int c0 = blockIdx.y * 64;
+  for (int e = t; e < 64 * 64; e += 256) {
+    const int k = e >> 6, c = c0 + (e & 63), row = idx[k];
+    Xs[e] = (row >= 0 && c < ncols) ? X[(long)row * ld + c] : 0.0;
+  }
+  __syncthreads();
+  double acc[4][4] = {};
+#pragma unroll 8
+  for (int k = 0; k < 64; ++k) {
+    double a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      a[u] = Qs[k * 64 + 4 * ty + u];
+      b[u] = Xs[k * 64 + 4 * tx + u];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int w = 0; w < 4; ++w) acc[u][w] += a[u] * b[w];
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int row = idx[4 * ty + u];
+    if (row < 0) continue;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const int c = c0 + 4 * tx + w;
+      if (c < ncols) X[(long)row * ld + c] = acc[u][w];
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256) k_rownorm2(const double* __restrict__ B, long ld, int n, double* __restrict__ out) {
   const int r = blockIdx.x;
   double acc = 0.0;

@@ -299,6 +299,7 @@ struct mik_handle {
   // (verify_inverse) -- an ill-conditioned set-up of those models falls back to the full sweep by itself.
   int opt_symsweep = -1;  // -1 = auto, 0 = off, 1 = on
   int opt_pinv_fast = 1;   // pseudo_inv: try the deflated regular inverse (duplicated stations) before the Jacobi pseudo-inverse
+  int opt_pinv_block = -1; // the Jacobi pseudo-inverse in its block form (k_bj_*: round 4): -1 = from 1536 rows on, 1 = always, 0 = one row pair per workgroup (rounds 1-3)
   // every inverse the device computes is PROBED before it is used (verify_inverse): A c against the data vector (bounds the
   // error of z) and X A e_j against e_j for three station columns (the sigma^2 side).  A failed probe sends the factorisation
   // to the next more careful path: half sweep -> full sweep -> partial pivoting.
@@ -482,7 +483,102 @@ static int launch_mw_solve(mik_handle* h, const MwArgs& a, long pc, bool piv) {
 
 // Moore-Penrose pseudo-inverse of the assembled matrix in T (leading M x M block, row length Mp; the padding columns of
 // those rows are zero), in place.  Cyclic one-sided Jacobi until every row pair is orthogonal to 1e-15, then B^T D W.
+// The general pseudo-inverse by a BLOCK one-sided Jacobi (round 4; kernels and algebra: mik_kernels.h k_bj_*).  Same result as
+// run_pseudo_inverse_scalar below -- B = W A with mutually orthogonal rows, pinv(A) = B^T diag(1 / sigma_i^2 | sigma_i > M eps sigma_max) W
+// -- from ~3 M / 32 passes over the matrix per sweep instead of ~2 M.
+static int run_pseudo_inverse_scalar(mik_handle* h);
 static int run_pseudo_inverse(mik_handle* h) {
+  // measured (profiles/r04_pseudo_inverse_block_jacobi.txt): M = 501 100 ms against 55 ms scalar, M = 1001 277 / 255, M = 2001 615 / 1180,
+  // M = 4001 1.5 s / 9.3 s -- the block form from 1536 rows on unless the caller says otherwise
+  if (h->opt_pinv_block == 0 || (h->opt_pinv_block < 0 && h->M < 1536)) return run_pseudo_inverse_scalar(h);
+  const int n = h->M;
+  const long ld = h->Mp;
+  int nb = (n + MIK_BJ_B - 1) / MIK_BJ_B;
+  nb += nb & 1;
+  if (nb < 2) nb = 2;
+  const int npairs = nb / 2;
+  DevBuf W, out, sig, worst, order, qbuf, active;
+  MIKC(W.ensure(sizeof(double) * (size_t)n * ld));
+  MIKC(out.ensure(sizeof(double) * (size_t)n * ld));
+  MIKC(sig.ensure(sizeof(double) * (size_t)n));
+  MIKC(worst.ensure(sizeof(unsigned long long)));
+  MIKC(order.ensure(sizeof(int) * (size_t)nb * MIK_BJ_B));
+  MIKC(qbuf.ensure(sizeof(double) * 64 * 64 * (size_t)npairs));
+  MIKC(active.ensure(sizeof(int) * (size_t)npairs));
+  double* B = h->T.as<double>();
+  hipLaunchKernelGGL(k_set_identity, dim3((unsigned)(((long)n * ld + 255) / 256)), dim3(256), 0, h->stream, W.as<double>(), ld, n);
+  std::vector<double> s2(n), d(n);
+  std::vector<int> ord((size_t)nb * MIK_BJ_B);
+  const double eps = 2.220446049250313e-16;
+  const size_t lds = sizeof(double) * 2 * 64 * MIK_BJ_LD;
+  HIPC(hipFuncSetAttribute((const void*)k_bj_eig, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int nslice = std::max(1, std::min(16, n / 256));  // column slices of the Gram pass: 62 pairs alone leave three quarters of the CUs idle
+  DevBuf gpart;
+  MIKC(gpart.ensure(sizeof(double) * 64 * 64 * (size_t)npairs * nslice));
+  bool converged = false;
+  int sweeps = 0;
+  double last_off = 1.0;
+  // orthogonal to 4e-15: the cosines themselves are 4000-term sums -- their rounding noise sits at 1e-15 and the iteration would
+  // chase it for sweeps (measured at M = 4001: 1.4e-15, 1.0e-15, 0.999e-15 in the last three of 19 sweeps;
+  // 2.0e-15, 1.98e-15 after the Gram sums were regrouped)
+  const double bj_tol = 4e-15;
+  for (int sweep = 0; sweep < 40 && !converged; ++sweep, ++sweeps) {
+    const int max_inner = last_off > 1e-3 ? 3 : 30;
+    hipLaunchKernelGGL(k_rownorm2, dim3(n), dim3(256), 0, h->stream, (const double*)B, ld, n, sig.as<double>());
+    HIPC(hipMemcpyAsync(s2.data(), sig.p, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+    HIPC(hipStreamSynchronize(h->stream));
+    double smax2 = 0.0;
+    for (double v : s2) smax2 = std::max(smax2, std::isfinite(v) ? v : 0.0);
+    if (!(smax2 > 0.0)) return fail(MIK_ESINGULAR, "pseudo-inverse: the matrix is zero or not finite");
+    // rows sorted by norm, largest first (ties by index: deterministic), cut into blocks of 32, padded with -1
+    for (int i = 0; i < n; ++i) ord[(size_t)i] = i;
+    std::stable_sort(ord.begin(), ord.begin() + n, [&](int a, int b) { return s2[(size_t)a] > s2[(size_t)b]; });
+    for (size_t i = (size_t)n; i < ord.size(); ++i) ord[i] = -1;
+    HIPC(hipMemcpyAsync(order.p, ord.data(), sizeof(int) * ord.size(), hipMemcpyHostToDevice, h->stream));
+    HIPC(hipMemsetAsync(worst.p, 0, sizeof(unsigned long long), h->stream));
+    // rows below a hundredth of the cut-off M eps sigma_max are the null space: their angles are rounding noise
+    const double dead2 = (0.01 * (double)n * eps) * (0.01 * (double)n * eps) * smax2;
+    for (int round = 0; round < nb - 1; ++round) {
+      hipLaunchKernelGGL(k_bj_gram, dim3(npairs, nslice), dim3(64), 0, h->stream, (const double*)B, ld, n, (const int*)order.as<int>(), nb, round,
+                         nslice, gpart.as<double>());
+      hipLaunchKernelGGL(k_bj_eig, dim3(npairs), dim3(256), lds, h->stream, (const double*)gpart.as<double>(), nslice, dead2, bj_tol, max_inner,
+                         qbuf.as<double>(), active.as<int>(), worst.as<unsigned long long>());
+      hipLaunchKernelGGL(k_bj_rotate, dim3(npairs, (unsigned)((n + 63) / 64), 2), dim3(256), 0, h->stream, B, W.as<double>(), ld, n,
+                         (const int*)order.as<int>(), nb, round, (const double*)qbuf.as<double>(), (const int*)active.as<int>());
+    }
+    HIPC(hipGetLastError());
+    unsigned long long bits = 0;
+    HIPC(hipMemcpyAsync(&bits, worst.p, sizeof bits, hipMemcpyDeviceToHost, h->stream));
+    HIPC(hipStreamSynchronize(h->stream));
+    double off;
+    memcpy(&off, &bits, sizeof off);
+    converged = off < bj_tol;
+    last_off = off;
+    if (getenv("MIK_DEBUG_PINV")) fprintf(stderr, "block Jacobi sweep %d: largest cosine between live rows %.3e (inner sweeps <= %d)\n", sweep, off, max_inner);
+  }
+  if (!converged) return fail(MIK_ESINGULAR, "pseudo-inverse: block Jacobi iteration did not converge");
+  h->tm.null_dim = 0;
+  hipLaunchKernelGGL(k_rownorm2, dim3(n), dim3(256), 0, h->stream, (const double*)B, ld, n, sig.as<double>());
+  HIPC(hipMemcpyAsync(s2.data(), sig.p, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+  HIPC(hipStreamSynchronize(h->stream));
+  double smax = 0.0;
+  for (double v : s2) smax = std::max(smax, sqrt(v));
+  const double cut = (double)n * eps * smax;  // scipy.linalg.pinv / pinvh: rtol = max(M, N) * eps
+  for (int i = 0; i < n; ++i) d[i] = (sqrt(s2[i]) > cut) ? 1.0 / s2[i] : 0.0;
+  HIPC(hipMemcpyAsync(sig.p, d.data(), sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+  const unsigned tiles = (unsigned)((n + 63) / 64);
+  hipLaunchKernelGGL(k_pinv_gemm, dim3(tiles, tiles), dim3(256), 0, h->stream, (const double*)B, (const double*)W.as<double>(),
+                     (const double*)sig.as<double>(), ld, n, out.as<double>());
+  HIPC(hipMemsetAsync(h->T.p, 0, h->T.bytes, h->stream));
+  HIPC(hipMemcpy2DAsync(h->T.p, sizeof(double) * ld, out.p, sizeof(double) * ld, sizeof(double) * n, n, hipMemcpyDeviceToDevice,
+                        h->stream));
+  HIPC(hipStreamSynchronize(h->stream));
+  HIPC(hipGetLastError());
+  return MIK_OK;
+}
+
+// the scalar form (rounds 1-3; option "pinv_block" 0): one row pair per block, one launch per round of the tournament
+static int run_pseudo_inverse_scalar(mik_handle* h) {
   const int n = h->M, m = n + (n & 1);
   const long ld = h->Mp;
   DevBuf W, out, sig, maxoff;
@@ -1002,6 +1098,8 @@ int mik_set_option(mik_handle* h, const char* key, double value) {
     (key[11] == 'z' ? h->verify_tol_z : h->verify_tol_inv) = value;
   } else if (!strcmp(key, "pinv_fast")) {
     h->opt_pinv_fast = value != 0.0;
+  } else if (!strcmp(key, "pinv_block")) {
+    h->opt_pinv_block = value < 0.0 ? -1 : (value != 0.0);
   } else if (!strcmp(key, "fuse_chain")) {
     h->opt_fuse_chain = value != 0.0;
   } else if (!strcmp(key, "early_diag")) {

@@ -181,6 +181,44 @@ def test_device_pseudo_inverse_against_scipy(n, drift, fast):
     np.testing.assert_allclose(ss, sr, rtol=0, atol=SS_TOL)
 
 
+@pytest.mark.parametrize("case", ["duplicates", "collinear_drift", "both"])
+def test_block_jacobi_pseudo_inverse_against_scipy_and_the_scalar_form(case):
+    """Round 4: the general pseudo-inverse as a BLOCK one-sided Jacobi (k_bj_gram / k_bj_eig / k_bj_rotate, option pinv_block = 1, the default
+    from 1536 rows on) on the hard inputs of the CPU prototype -- duplicated stations with a zero nugget, collinear stations under a
+    regional-linear drift, both (cond 5e7 on the range) -- against scipy.linalg.pinv (core.py:33 P_INV) and the scalar form; odd orders
+    (block padding), ranks M - 1 .. M - 6."""
+    import scipy.linalg
+
+    lib = _lib()
+    rng = np.random.default_rng(12)
+    if case == "duplicates":
+        (x, y), v = fx.synth(4301, 301, 2)
+        x[-6:], y[-6:] = x[:6], y[:6]
+        kw, okw, par = {}, {}, [1.0, 0.5, 0.0]
+    else:
+        n = 350
+        x = rng.random(n)
+        if case == "both":
+            x[-3:] = x[:3]
+        y, v = 0.5 * x - 0.1, np.cos(3 * x)
+        kw, okw, par = dict(regional_linear=True), dict(regional_linear=True), ([1.0, 0.5, 0.0] if case == "both" else [1.0, 0.5, 0.02])
+    st = ko.KrigingState(ndim=2, coords_orig=np.stack([x, y], 1), values=v, model="exponential", params=ko.internal_parameters("exponential", par), **okw)
+    ref = scipy.linalg.pinv(ko.kriging_matrix(st))
+    got = {}
+    for block in (1, 0):
+        h = lib.Handle(0)
+        h.set_option("pinv_fast", 0)
+        h.set_option("pinv_block", block)
+        h.set_problem(ndim=2, xs=x, ys=y, zs=None, values=v, model_id=lib.MODEL_IDS["exponential"], params=st.params, pseudo_inv=1, **kw)
+        h.factor()
+        assert h.timing()["factor_path"] == 4
+        got[block] = h.get_matrix(1)
+        h.close()
+    scale = np.abs(ref).max()
+    assert np.abs(got[1] - ref).max() <= 1e-9 * scale, np.abs(got[1] - ref).max() / scale
+    assert np.abs(got[1] - got[0]).max() <= 1e-9 * scale
+
+
 def test_block_sweep_variants_agree():
     """Options of the unpivoted block sweep: diagonal-block kernel variants and the look-ahead schedule return the
     bit-identical inverse; the opt-in half (upper-triangle) sweep returns an exactly symmetric one within 1e-11 of it."""
