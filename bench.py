@@ -366,7 +366,14 @@ def sparse_summary(t):
             "tile_fraction": t["sparse_tiles"] / max(1.0, t["sparse_tiles_dense"]),
             "offdiag_ktiles_contracted": t["sparse_ktiles"], "offdiag_ktiles_dense": t["sparse_ktiles_dense"],
             "ktile_fraction": t["sparse_ktiles"] / max(1.0, t["sparse_ktiles_dense"]),
-            "list_kernels_ms": t["sparse_lists_ms"], "stations_in_hilbert_order": bool(t["stations_sorted"])}
+            "list_kernels_ms": t["sparse_lists_ms"], "stations_in_hilbert_order": bool(t["stations_sorted"]),
+            "tile_rows": ("eight gathered 16-row groups (k_contract_spg)" if t.get("sparse_rows") == 16
+                          else "aligned blocks of 128 rows (k_contract_sp)"),
+            "triangle_products_16x16x128": t.get("sparse_diag_products", 0.0)}
+
+
+def sparse_kernel(t):
+    return "k_contract_spg" if t.get("sparse_rows") == 16 else "k_contract_sp"
 
 
 def golden_slab(cno):
@@ -417,7 +424,7 @@ def other_config_line(cno, window=None, steps=3, warmup=1):
     else:
         ach = acc["contract_flops_executed"] / (acc["contract_ms"] * 1e-3) / 1e12 if acc["contract_ms"] > 0 else 0.0
         useful = float(M) * M * npt * steps / (acc["contract_ms"] * 1e-3) / 1e12 if acc["contract_ms"] > 0 else 0.0
-        line["roofline"] = {"bound": "mfma", "kernel": "k_contract_sp" if last.get("sparse") else "k_contract", "achieved": ach,
+        line["roofline"] = {"bound": "mfma", "kernel": sparse_kernel(last) if last.get("sparse") else "k_contract", "achieved": ach,
                             "unit": "TFLOP/s", "peak": FP64_MFMA_PEAK_TFLOPS, "frac": ach / FP64_MFMA_PEAK_TFLOPS,
                             "useful_tflops": useful, "avg_launch_ms": acc["contract_ms"] / max(1, acc["contract_launches"])}
         if last.get("sparse"):
@@ -477,6 +484,9 @@ def main():
                     help="time moving-window kriging (n_closest_points=K) on the same workload instead (not the headline metric)")
     ap.add_argument("--sparse", type=int, default=None, choices=[-1, 0, 1, 2],
                     help="library option 'sparse' (range-aware contraction of the spherical model; default: the library's, on)")
+    ap.add_argument("--sparse-rows", type=int, default=None, choices=[-1, 16, 128],
+                    help="library option 'sparse_rows' (range-aware contraction: tiles of eight gathered 16-row groups, or aligned "
+                         "128-row blocks; default: the library's, 16)")
     ap.add_argument("--no-trials", action="store_true", default=os.environ.get("MIK_BENCH_TRIALS", "1") == "0",
                     help="device groups: skip the exchange / overlap trials before the timed loop (also MIK_BENCH_TRIALS=0)")
     ap.add_argument("--pretrial-budget", type=float, default=float(os.environ.get("MIK_BENCH_PRETRIAL_BUDGET", "60")), metavar="S",
@@ -584,6 +594,8 @@ def main():
             hh.set_option("factor", {"auto": 0, "sweep": 1, "lu": 2}[args.factor])
         if args.sparse is not None:
             hh.set_option("sparse", args.sparse)
+        if args.sparse_rows is not None:
+            hh.set_option("sparse_rows", args.sparse_rows)
         return m, hh
 
     progress["stage"] = "create the kriging object and its device handle"
@@ -745,7 +757,7 @@ def main():
             algo_flops_per_launch = 2.0 * M * M * pts_per_launch  # 2 M^2 per point for w = A_inv . b
             effective = algo_flops_per_launch / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0
             executed = tsum["contract_flops_executed"] / (tsum["contract_ms"] * 1e-3) / 1e12 if tsum["contract_ms"] > 0 else 0.0
-            roof = {"bound": "mfma", "kernel": "k_contract_valu" if last.get("engine") else "k_contract_sp" if last.get("sparse") else "k_contract",
+            roof = {"bound": "mfma", "kernel": "k_contract_valu" if last.get("engine") else sparse_kernel(last) if last.get("sparse") else "k_contract",
                     "achieved": executed, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": executed / FP64_MFMA_PEAK_TFLOPS,
                     "peak_measured": FP64_MFMA_MEASURED_TFLOPS, "frac_of_measured_peak": executed / FP64_MFMA_MEASURED_TFLOPS,
                     "effective_tflops": effective, "effective_frac": effective / FP64_MFMA_PEAK_TFLOPS,

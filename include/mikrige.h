@@ -145,6 +145,10 @@ typedef struct mik_timing {
   double sparse_ktiles;        /* off-diagonal K tiles (16 stations x 128 rows x 128 points) contracted, summed over the tiles */
   double sparse_ktiles_dense;  /*   ... and of the dense symmetric contraction */
   double sparse_lists_ms;      /* candidate test + flag -> list kernels (k_sp_cand, k_sp_lists, k_sp_tiles), summed */
+  double sparse_diag_products; /* (16-row group x 16-station K tile x 128 points) products of the tiles' triangular parts, all launches */
+  int32_t sparse_rows;         /* rows of a tile of the range-aware contraction: 16 = eight gathered 16-row groups (k_contract_spg),
+                                  128 = aligned row blocks (k_contract_sp), 0 = dense contraction (option "sparse_rows") */
+  int32_t reserved2;
 } mik_timing;
 
 int  mik_device_count(void);
@@ -178,6 +182,11 @@ int  mik_slab_of(int64_t n, int members, int i, int64_t *lo, int64_t *count); /*
  *   spherical model (not with pseudo_inv, a caller's a_inv or geographic coordinates: those run the dense contraction), 0 = off,
  *   2 = Hilbert-ordered stations with the dense contraction (A/B of the order alone).  Takes effect at the
  *   next mik_factor [MIK_SPARSE] ;
+ * "sparse_rows" -1/16/128 = range-aware contraction: a tile's 128 rows of A_inv are eight GATHERED active 16-row groups of the point
+ *   block's list (16: k_contract_spg -- the list of active K tiles is also the list of active row groups; tile r takes entries
+ *   [8r, 8r + 8) as rows, the entries beyond as K tiles, then its own groups as a triangle) or an ALIGNED block of 128 rows that is
+ *   contracted whole when any of its eight groups is active (128: k_contract_sp; active blocks are ~79 % full at BASELINE config
+ *   5).  -1 (default) = 16 wherever 32-bit DMA offsets reach every row (Mp <= 23168), else 128 [MIK_SPARSE_ROWS] ;
  * "sparse_lanes" 1/2 = range-aware contraction: its launches alternate between two lanes (two streams, two sets of work buffers and
  *   right-hand-side panels), so that the candidate / right-hand-side / list kernels of a launch and the tail of the previous
  *   launch's tile queue overlap.  Measured 2 % faster at config 5 for a second right-hand-side panel: default 1 = one launch after

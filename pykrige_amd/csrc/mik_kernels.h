@@ -570,6 +570,7 @@ typedef GemmSmemT<MIK_BM> GemmSmem;
 
 typedef __attribute__((address_space(1))) const void* mik_gptr_t;
 typedef __attribute__((address_space(3))) void* mik_lptr_t;
+typedef __attribute__((address_space(4))) const unsigned mik_cu32_t;  // a dword in the constant address space (uniform loads -> s_load)
 
 // NAI = 16-row groups per wave: 4 -> wave tile 64 x 64, 4 waves (256 threads); 2 -> wave tile 32 x 64,
 // 8 waves (512 threads).  The block tile is 128 x 128 either way.
@@ -1622,6 +1623,452 @@ __global__ void __launch_bounds__(64 * 2 * (8 / NAI), 2 * (4 / NAI)) k_contract_
 #pragma unroll
       for (int w = 0; w < NWM; ++w) v += red[w * 128 + threadIdx.x];
       a.part[(long)rpos * a.palloc + t0 + threadIdx.x] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Range-aware contraction, GATHERED ROW GROUPS (round 4, second session; option "sparse_rows" 16).  k_contract_sp above takes the
+// rows of A_inv in aligned blocks of 128: a row block is contracted whole when one of its eight 16-station groups is in range
+// (active row blocks are 79 % full at BASELINE config 5).  Here a tile's 128 rows are ANY eight active 16-row groups: the ascending
+// list of a point block's active K tiles (klist) is also the list of its active row groups, tile r takes entries [8r, 8r + 8) as
+// rows and entries [8r + 8, nk) as its off-diagonal K tiles, then its own eight groups as the triangular diagonal part (the group
+// in list position j is contracted with the K tiles of positions >= j: doubled accumulators + the 16 x 16 square, as gemm_core's
+// TRI form does inside an aligned block).  Skipped groups and K tiles hold exact zeros of delta, so this is the same sum.
+// What else differs from k_contract_sp:
+//  * rows are dealt to the LDS image so that wave-row wm owns list positions {wm, wm + 4}: the triangular part then needs
+//    2+2+2+2+1+1+1+1 = 12 group-steps per wave instead of 15 (the per-K-tile barrier makes a step as long as its busiest wave);
+//  * a tile arrives as ONE 32-byte record written by k_sp_tiles_g (tile id, nk, the first two K tiles, the eight row groups):
+//    the queue position of the NEXT tile is fetched (atomic) when the current tile starts, its record is read and its first K
+//    tile sent to LDS before the current tile's epilogue -- the pop -> metadata -> list -> first-fetch chain of k_contract_sp
+//    (about six dependent memory round trips per ~35-K-tile tile) is one LDS broadcast;
+//  * K-tile ids are read from the list in global memory two steps ahead (one wave-uniform load per step, waited for by the
+//    step's own drain): no list in LDS, no list copy.
+// 32-bit LDS-DMA offsets address the whole inverse here (rows are anywhere): the host takes this form only while Mp * lda * 8 < 2^32.
+// ------------------------------------------------------------------------------------------------
+
+// flags -> klist / kcount as k_sp_lists, and the number of 128-row tiles of gathered groups: ceil(nk / 8)
+__global__ void __launch_bounds__(64) k_sp_lists_g(const unsigned char* __restrict__ flags, int nK16,
+                                                   unsigned short* __restrict__ klist, int* __restrict__ kcount,
+                                                   int* __restrict__ ntiles) {
+  const int tb = blockIdx.x, lane = threadIdx.x;
+  const unsigned char* f = flags + (long)tb * nK16;
+  unsigned short* kl = klist + (long)tb * nK16;
+  int nk = 0;
+  for (int base = 0; base < nK16; base += 64) {
+    const int k16 = base + lane;
+    const bool on = k16 < nK16 && f[k16] != 0;
+    const unsigned long long m = __ballot(on);
+    if (on) kl[nk + __popcll(m & ((1ULL << lane) - 1ULL))] = (unsigned short)k16;
+    nk += __popcll(m);
+  }
+  if (lane == 0) {
+    kcount[tb] = nk;
+    ntiles[tb] = (nk + 7) / 8;
+  }
+}
+
+// Tile records of k_contract_spg, in k_sp_tiles' order (groups of MIK_ST point blocks, group g on XCD g % 8, inside a group tile
+// position ascending = longest K loops first, point block fast).  Record (two uint4):
+//   [0] = {tblk << 10 | r, nk, klist[nk - 1], klist[nk - 2]}      [1] = the eight row groups klist[8 r .. 8 r + 7] (u16 each)
+// stats: [0] tiles, [1] off-diagonal K tiles summed over the tiles, [2] (row group, K tile) products of the triangular parts.
+__global__ void __launch_bounds__(1024) k_sp_tiles_g(const int* __restrict__ ntiles, const int* __restrict__ kcount,
+                                                     const unsigned short* __restrict__ klist, int nK16, int nTblk,
+                                                     uint4* __restrict__ recs, int* __restrict__ xoff,
+                                                     unsigned long long* __restrict__ stats) {
+  __shared__ int gcnt[1024 / MIK_ST + 1], goff[1024 / MIK_ST + 1], xtot[9];
+  __shared__ unsigned long long ksum, dsum;
+  const int nG = (nTblk + MIK_ST - 1) / MIK_ST;
+  const int g = threadIdx.x;
+  if (g == 0) ksum = 0ULL, dsum = 0ULL;
+  __syncthreads();
+  if (g < nG) {
+    int c = 0;
+    unsigned long long ks = 0ULL, ds = 0ULL;
+    for (int q = 0; q < MIK_ST; ++q) {
+      const int tb = g * MIK_ST + q;
+      if (tb >= nTblk) break;
+      const int nk = kcount[tb], full = nk / 8, rem = nk - 8 * full;
+      c += ntiles[tb];
+      ks += (unsigned long long)((long)full * nk - 4L * full * (full + 1));  // sum over full tiles r of nk - 8 (r + 1)
+      ds += (unsigned long long)(36 * full + rem * (rem + 1) / 2);
+    }
+    gcnt[g] = c;
+    atomicAdd(&ksum, ks);
+    atomicAdd(&dsum, ds);
+  }
+  __syncthreads();
+  if (g < 8) {  // exclusive scan of the groups of XCD g
+    int s = 0;
+    for (int q = g; q < nG; q += 8) {
+      goff[q] = s;
+      s += gcnt[q];
+    }
+    xtot[g] = s;
+  }
+  __syncthreads();
+  if (g == 0) {
+    int s = 0;
+    for (int x = 0; x < 8; ++x) {
+      const int c = xtot[x];
+      xoff[x] = s;
+      s += c;
+    }
+    xoff[8] = s;
+    stats[0] = (unsigned long long)s;
+    stats[1] = ksum;
+    stats[2] = dsum;
+  }
+  __syncthreads();
+  const int tb = threadIdx.x;  // one thread per point block writes that block's records
+  if (tb < nTblk) {
+    const int gg = tb / MIK_ST, q = tb % MIK_ST;
+    int xbase = 0;
+    for (int x = 0; x < (gg & 7); ++x) xbase += xtot[x];
+    int nr[MIK_ST];
+    for (int qq = 0; qq < MIK_ST; ++qq) {
+      const int t2 = gg * MIK_ST + qq;
+      nr[qq] = t2 < nTblk ? ntiles[t2] : 0;
+    }
+    const int nk = kcount[tb];
+    const unsigned short* kl = klist + (long)tb * nK16;
+    const unsigned k1 = nk >= 1 ? kl[nk - 1] : 0u, k2 = nk >= 2 ? kl[nk - 2] : 0u;
+    int w = xbase + goff[gg];
+    for (int r = 0; r < nr[q]; ++r) {  // (tiles of the other point blocks beyond nr[q] lie behind this block's last one or belong to them)
+      int before = 0, all = 0;
+      for (int qq = 0; qq < MIK_ST; ++qq) {
+        const int on = nr[qq] > r ? 1 : 0;
+        all += on;
+        if (qq < q) before += on;
+      }
+      uint4* out = recs + 2L * (w + before);
+      out[0] = make_uint4(((unsigned)tb << 10) | (unsigned)r, (unsigned)nk, k1, k2);
+      out[1] = *reinterpret_cast<const uint4*>(kl + 8 * r);  // 16-byte aligned: nK16 is a multiple of 8
+      w += all;
+    }
+  }
+}
+
+struct SpgArgs {
+  const double* Ainv;
+  long lda;
+  const double* Bt;
+  long ldb;
+  double* part;
+  int palloc, nK16;
+  const unsigned short* klist;  // [tblk][nK16]
+  const uint4* recs;            // tile records (k_sp_tiles_g)
+  const int* xoff;              // [9]
+  unsigned long long* queue;    // [8], zeroed per launch (the low words are the counters)
+};
+
+template <int NAI>
+__global__ void __launch_bounds__(64 * 2 * (8 / NAI), 2 * (4 / NAI)) k_contract_spg(SpgArgs a) {
+  static_assert(NAI == 2, "8 waves: 4 wave-rows of two 16-row groups x 2 wave-columns of 64 points");
+  constexpr int WROWS = 16 * NAI, NWM = 128 / WROWS;
+  constexpr int NTHR = 64 * 2 * (MIK_BM / WROWS), PROWS = NTHR / 8, NPASS = MIK_BM / PROWS;
+  constexpr unsigned LDS_PASS = PROWS * MIK_BK * 8, LDS_BUF = MIK_BM * MIK_BK * 8;
+  __shared__ GemmSmem sm;
+  __shared__ uint4 srec[4];  // two tile records: the current tile's and the next one's
+  __shared__ int sst[4];     // thread 0's queue state: [0] sequences tried, [1] first record and [2] record count of the current sequence
+  unsigned xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  const int xcd = (int)(xcc & 7);
+  // The kernel sits at its register budget (128 VGPRs = 4 wavefronts per SIMD) inside the K loop; nothing lane-dependent may stay
+  // live across it except what the loop itself needs.  The wave index is kept in a scalar register, the lane index is re-derived
+  // (v_mbcnt, opaque to the optimiser) wherever the code between two K loops needs it.
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int wm = wave >> 1, wn = wave & 1;
+  auto lane_now = []() -> int {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+  };
+  const unsigned ldsA = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)&sm.As[0][wave * 8][0]);
+  const unsigned ldsB = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)&sm.Bs[0][wave * 8][0]);
+  auto uniform_ptr = [](const double* q) {
+    const unsigned long long v = (unsigned long long)(uintptr_t)q;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<const double*>((uintptr_t)(((unsigned long long)hi << 32) | lo));
+  };
+  auto drain = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+  const double* Agu = uniform_ptr(a.Ainv);
+  // what the K loop needs per lane: the DMA source offsets of its two staged rows of each operand, its fragment offsets in the LDS image
+  // (one register each where gemm_core keeps two: the second pass of the B operand is the first one PROWS rows further down -- a
+  // scalar base; the fragment offsets of the upper K half are aoff + 8 -- an instruction offset -- and boff ^ 8 -- one XOR per step)
+  unsigned aoffb[NPASS], boffb;
+  int aoff, boff;
+  {
+    const int lane = (int)(threadIdx.x & 63), tid = wave * 64 + lane;
+    const int lrow = tid >> 3, slot = tid & 7;
+    boffb = (unsigned)(((long)lrow * a.ldb + ((slot ^ ((lrow >> 1) & 7)) << 1)) * 8);
+    const int kq = lane >> 4, ia = lane & 3, jb = lane & 15;
+    aoff = (wm * WROWS + ia) * MIK_BK + ((kq ^ (ia & 2)) << 1);          // m = 1: (4 + kq) ^ (ia & 2) = 4 + (kq ^ (ia & 2))
+    boff = (wn * 64 + jb) * MIK_BK + ((kq ^ ((jb >> 1) & 7)) << 1);      // m = 1: ((4 + kq) ^ s) << 1 = ((kq ^ s) << 1) ^ 8
+  }
+  auto boff_hi = [&]() -> int {  // boff ^ 8 formed per K step (the empty asm keeps it from being hoisted into a register of its own)
+    int b = boff;
+    asm volatile("" : "+v"(b));
+    return b ^ 8;
+  };
+  // LDS row slot s (16 rows) holds the row group of list position (s >> 1) + 4 (s & 1): wave-row wm owns positions wm and wm + 4
+  auto group_of = [](const uint4& r1, int gi) -> unsigned {
+    const unsigned w = gi < 2 ? r1.x : gi < 4 ? r1.y : gi < 6 ? r1.z : r1.w;
+    return (w >> (16 * (gi & 1))) & 0xffffu;
+  };
+  auto stage = [&](const double* Bgu, int k, int b) {
+    const double* abase = uniform_ptr(Agu + k);
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+      const double* bbase = uniform_ptr(Bgu + (long)(PROWS * p) * a.ldb + k);
+      const unsigned la = ldsA + b * LDS_BUF + p * LDS_PASS, lb = ldsB + b * LDS_BUF + p * LDS_PASS;
+      if (p == 0) {
+        asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(aoffb[p]), "s"(abase), "s"(la) : "memory");
+        asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(boffb), "s"(bbase), "s"(lb) : "memory");
+      } else {
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(aoffb[p]), "s"(abase), "s"(la) : "memory");
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(boffb), "s"(bbase), "s"(lb) : "memory");
+      }
+    }
+  };
+  // Thread 0 owns the queue, one tile ahead.  fetch_next() sits right behind the first barrier of a tile's K loop: it pops the position
+  // of the NEXT tile (atomic) and reads that tile's record into the other half of srec -- wavefront 0 waits two L2 round trips there
+  // while the other wavefronts of its SIMD use the matrix pipe, and catches up inside the same K step.  (Keeping the atomic's result
+  // in a register until the tile ends does not work: hipcc waits for it at once and spills it.)  acquire(), after the K loop, then
+  // finds the record in LDS; only when a sequence has run out does it walk on to the next XCD's (a few times per block and launch).
+  constexpr unsigned REC_END = 0xffffffffu, REC_MORE = 0xfffffffeu;
+  auto fetch = [&](int xq) { return __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(&a.queue[xq]), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  int cur = 1;  // srec[2 cur], srec[2 cur + 1] = the current tile's record
+  auto fetch_next = [&]() {
+    if (threadIdx.x == 0) {
+      const int steal = sst[0];
+      uint4 r0 = make_uint4(REC_END, 0u, 0u, 0u), r1 = make_uint4(0u, 0u, 0u, 0u);
+      if (steal < 8) {
+        const unsigned seq = fetch((xcd + steal) & 7);
+        if (seq < (unsigned)sst[2]) {
+          const uint4* rp = a.recs + 2L * (sst[1] + (long)seq);
+          r0 = rp[0];
+          r1 = rp[1];
+        } else {
+          r0.x = REC_MORE;
+        }
+      }
+      srec[2 * (cur ^ 1)] = r0;
+      srec[2 * (cur ^ 1) + 1] = r1;
+    }
+  };
+  auto acquire = [&]() -> bool {  // one barrier; block-uniform result
+    if (threadIdx.x == 0 && srec[2 * (cur ^ 1)].x == REC_MORE) {
+      uint4 r0 = make_uint4(REC_END, 0u, 0u, 0u), r1 = make_uint4(0u, 0u, 0u, 0u);
+      int steal = sst[0];
+      while (++steal < 8) {
+        const int xq = (xcd + steal) & 7;  // help the next XCD's sequence
+        const int qlo = a.xoff[xq], qcnt = a.xoff[xq + 1] - qlo;
+        const unsigned seq = fetch(xq);
+        if (seq < (unsigned)qcnt) {
+          const uint4* rp = a.recs + 2L * (qlo + (long)seq);
+          r0 = rp[0];
+          r1 = rp[1];
+          sst[1] = qlo;
+          sst[2] = qcnt;
+          break;
+        }
+      }
+      sst[0] = steal;
+      srec[2 * (cur ^ 1)] = r0;
+      srec[2 * (cur ^ 1) + 1] = r1;
+    }
+    __syncthreads();
+    cur ^= 1;
+    return __builtin_amdgcn_readfirstlane(srec[2 * cur].x) != REC_END;
+  };
+  // the current tile's state: block- or wave-uniform values in scalar registers
+  int tblk, rpos, n, ksec, erow[NAI];
+  const mik_cu32_t* ksrc;  // the point block's list from this tile's first group on (16-byte aligned), as dwords in the CONSTANT address
+                           // space: a uniform load from there is a scalar load (s_load_dword: no vector registers, no vmcnt); the list
+                           // was written by an earlier kernel and is not modified during this one
+  const double* Bgu;
+  auto list_at = [&](int i) -> int { return (int)((ksrc[i >> 1] >> (16 * (i & 1))) & 0xffffu); };
+  auto adopt = [&]() {  // srec -> the state above, first K tile into buffer 1 (nothing is waited for)
+    const uint4 r0 = srec[2 * cur], r1 = srec[2 * cur + 1];
+    const unsigned tile = __builtin_amdgcn_readfirstlane(r0.x);
+    tblk = (int)(tile >> 10);
+    rpos = (int)(tile & 1023u);
+    const int nk = __builtin_amdgcn_readfirstlane((int)r0.y), g0 = 8 * rpos;
+    const int kfirst = __builtin_amdgcn_readfirstlane((int)r0.z);
+    n = nk - g0;  // K tiles of this tile: n - 8 off-diagonal ones, then its own min(n, 8) groups
+    ksec = __builtin_amdgcn_readfirstlane((int)r0.w);
+    const int ng = n < 8 ? n : 8;
+    {  // byte offsets (relative to A_inv) of this thread's two staged rows
+      const int tid = wave * 64 + lane_now(), lrow = tid >> 3, slot = tid & 7;
+#pragma unroll
+      for (int p = 0; p < NPASS; ++p) {
+        const int R = lrow + PROWS * p, s = R >> 4;
+        int gi = (s >> 1) + 4 * (s & 1);
+        gi = gi < ng ? gi : ng - 1;  // a short last tile: the missing groups alias its last one (their accumulators stay zero)
+        const long grow = 16L * (long)group_of(r1, gi) + (R & 15);
+        aoffb[p] = (unsigned)((grow * a.lda + ((slot ^ (lrow & 2)) << 1)) * 8);
+      }
+    }
+#pragma unroll
+    for (int ai = 0; ai < NAI; ++ai) {
+      int gi = wm + 4 * ai;
+      gi = gi < ng ? gi : ng - 1;
+      erow[ai] = __builtin_amdgcn_readfirstlane(16 * (int)group_of(r1, gi));  // wave-uniform (wm)
+    }
+    ksrc = (const mik_cu32_t*)(uintptr_t)(a.klist + (long)tblk * a.nK16 + g0);
+    Bgu = uniform_ptr(a.Bt + (long)tblk * MIK_BN * a.ldb);
+    stage(Bgu, 16 * kfirst, 1);
+  };
+  if (threadIdx.x == 0) {
+    const int lo = a.xoff[xcd];
+    sst[0] = 0;
+    sst[1] = lo;
+    sst[2] = a.xoff[xcd + 1] - lo;
+  }
+  fetch_next();
+  bool have = acquire();
+  if (have) adopt();
+  while (have) {
+    d4 acc[NAI][4];
+#pragma unroll
+    for (int x = 0; x < NAI; ++x)
+#pragma unroll
+      for (int y = 0; y < 4; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
+    // K loop over list positions w = n - 1 .. 0 (relative to the tile's first group); position w's K tile is in buffer `buf`
+    int buf = 1, w = n - 1;
+    int kn = ksec;  // K tile of position w - 1
+    drain();
+    __syncthreads();
+    fetch_next();
+    for (; w >= 8; --w) {
+      stage(Bgu, 16 * kn, buf ^ 1);
+      int kn2 = 0;
+      if (w >= 2) kn2 = list_at(w - 2);  // scalar load, in flight during this step's MFMAs
+      const double* as = &sm.As[buf][0][0] + aoff;
+      const double* bs = &sm.Bs[buf][0][0];
+      const int bo[2] = {boff, boff_hi()};
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        double2 fa[4 * NAI], fb[4];
+#pragma unroll
+        for (int x = 0; x < 4 * NAI; ++x) fa[x] = *reinterpret_cast<const double2*>(as + 8 * m + 4 * x * MIK_BK);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) fb[x] = *reinterpret_cast<const double2*>(bs + bo[m] + 16 * x * MIK_BK);
+#pragma unroll
+        for (int ai = 0; ai < NAI; ++ai)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int bi = 0; bi < 4; ++bi)
+              acc[ai][bi][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa[4 * ai + r].x, fb[bi].x, acc[ai][bi][r], 0, 0, 0);
+#pragma unroll
+        for (int ai = 0; ai < NAI; ++ai)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int bi = 0; bi < 4; ++bi)
+              acc[ai][bi][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa[4 * ai + r].y, fb[bi].y, acc[ai][bi][r], 0, 0, 0);
+      }
+      drain();
+      __syncthreads();
+      buf ^= 1;
+      kn = kn2;
+    }
+    // the tile's own groups: position w's K tile meets the groups of positions <= w; a group's accumulators are doubled when the
+    // loop reaches its own 16 x 16 square (everything above it counts twice)
+    for (; w >= 0; --w) {
+      if (w >= 1) stage(Bgu, 16 * kn, buf ^ 1);
+      int kn2 = 0;
+      if (w >= 2) kn2 = list_at(w - 2);
+      const double* as = &sm.As[buf][0][0] + aoff;
+      const double* bs = &sm.Bs[buf][0][0];
+      const int bo[2] = {boff, boff_hi()};
+#pragma unroll
+      for (int ai = 0; ai < NAI; ++ai)
+        if (w == wm + 4 * ai) {
+#pragma unroll
+          for (int y = 0; y < 4; ++y) acc[ai][y] *= 2.0;
+        }
+      if (w >= wm) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          double2 fb[4];
+#pragma unroll
+          for (int x = 0; x < 4; ++x) fb[x] = *reinterpret_cast<const double2*>(bs + bo[m] + 16 * x * MIK_BK);
+#pragma unroll
+          for (int ai = 0; ai < NAI; ++ai)
+            if (w >= wm + 4 * ai) {
+              double2 fa[4];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) fa[r] = *reinterpret_cast<const double2*>(as + 8 * m + 4 * (4 * ai + r) * MIK_BK);
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int bi = 0; bi < 4; ++bi)
+                  acc[ai][bi][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa[r].x, fb[bi].x, acc[ai][bi][r], 0, 0, 0);
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int bi = 0; bi < 4; ++bi)
+                  acc[ai][bi][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa[r].y, fb[bi].y, acc[ai][bi][r], 0, 0, 0);
+            }
+        }
+      }
+      drain();
+      __syncthreads();
+      buf ^= 1;
+      kn = kn2;
+    }
+    // the next tile: record -> LDS (one barrier), its first K tile on the way to buffer 1 while this tile's epilogue runs
+    const int t0 = tblk * MIK_BN, rp = rpos;
+    int er[NAI];
+#pragma unroll
+    for (int ai = 0; ai < NAI; ++ai) er[ai] = erow[ai];
+    have = acquire();
+    if (have) adopt();
+    // epilogue (k_contract's): part[r][t] = sum over this tile's rows of delta_ti W_it
+    const int lane = lane_now(), lq = lane >> 4, lc = lane & 15;
+    double cs[4];
+#pragma unroll
+    for (int bp = 0; bp < 2; ++bp) {
+      double bv[2][4 * NAI];
+#pragma unroll
+      for (int b2 = 0; b2 < 2; ++b2) {
+        const long t = t0 + wn * 64 + (2 * bp + b2) * 16 + lc;
+        const double* brow = a.Bt + t * a.ldb + lq;
+#pragma unroll
+        for (int ai = 0; ai < NAI; ++ai)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) bv[b2][ai * 4 + r] = brow[er[ai] + 4 * r];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int b2 = 0; b2 < 2; ++b2) {
+        const int bi = 2 * bp + b2;
+        double s = 0.0;
+#pragma unroll
+        for (int ai = 0; ai < NAI; ++ai)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s += bv[b2][ai * 4 + r] * acc[ai][bi][r];
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        cs[bi] = s;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    double* red = &sm.As[0][0][0];  // the K loop ended with a barrier; buffer 1 is being filled for the next tile
+    if (lq == 0) {
+#pragma unroll
+      for (int bi = 0; bi < 4; ++bi) red[wm * 128 + wn * 64 + bi * 16 + lc] = cs[bi];
+    }
+    __syncthreads();
+    if (wave < 2) {
+      const int c = wave * 64 + lane;
+      double v = 0.0;
+#pragma unroll
+      for (int x = 0; x < NWM; ++x) v += red[x * 128 + c];
+      a.part[(long)rp * a.palloc + t0 + c] = v;
     }
   }
 }

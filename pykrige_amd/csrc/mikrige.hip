@@ -262,10 +262,12 @@ struct mik_handle {
   std::vector<double> hvals_s;
   DevBuf xs_s, ys_s, zs_s, vals_s, extra_cols_s, sbox;
   int opt_sparse = -1;  // "sparse": -1 = auto (= 1: on for compact-support models), 0 = off, 1 = on, 2 = sorted stations, dense contraction
-  DevBuf sp_cand, sp_flags, sp_klist, sp_kcount, sp_nrows, sp_rows, sp_rstart, sp_tiles, sp_xoff, sp_stats;
+  DevBuf sp_cand, sp_flags, sp_klist, sp_kcount, sp_nrows, sp_rows, sp_rstart, sp_tiles, sp_xoff, sp_stats, sp_recs;
+  int opt_sparse_rows = -1;  // "sparse_rows": 16 = tiles of gathered 16-row groups (k_contract_spg), 128 = aligned row blocks (k_contract_sp),
+                             // -1 = auto: 16 wherever 32-bit offsets address the inverse (Mp * Mp * 8 < 2^32)
   // second set (with Bt2): the launches of the range-aware contraction alternate between two lanes on two streams, so that the
   // candidate / right-hand-side / list kernels of one launch and the tail of the previous launch's tile queue overlap
-  DevBuf sp2_cand, sp2_flags, sp2_klist, sp2_kcount, sp2_nrows, sp2_rows, sp2_rstart, sp2_tiles, sp2_xoff, part2, queue2;
+  DevBuf sp2_cand, sp2_flags, sp2_klist, sp2_kcount, sp2_nrows, sp2_rows, sp2_rstart, sp2_tiles, sp2_xoff, part2, queue2, sp2_recs;
   int opt_sparse_lanes = 1;  // "sparse_lanes": 1 = one launch after the other on one stream (default), 2 = two lanes.  Measured
                              // (profiles/r04_sparse_lanes_ab.txt): config-5 slab 64.6 -> 63.4 ms, bench grid 96.3 -> 94.0 ms -- 2 % for a
                              // second 8.4 GB panel and per-launch times that no longer add up: off
@@ -851,6 +853,8 @@ static int create_one_body(mik_handle* h, int device) {
   if (env) h->opt_pairs = atoi(env) ? 1 : 0;
   env = getenv("MIK_SPARSE");
   if (env && atoi(env) >= -1 && atoi(env) <= 2) h->opt_sparse = atoi(env);
+  env = getenv("MIK_SPARSE_ROWS");
+  if (env && (atoi(env) == -1 || atoi(env) == 16 || atoi(env) == 128)) h->opt_sparse_rows = atoi(env);
   env = getenv("MIK_UPDATE_ATOMIC");
   if (env) h->opt_update_atomic = atoi(env) ? 1 : 0;
   env = getenv("MIK_UPDATE_MAP");
@@ -916,7 +920,7 @@ static void destroy_one(mik_handle* h) {
                     &h->px, &h->py, &h->pz, &h->grid_axes, &h->grid_idx, &h->Averify, &h->vbuf, &h->extra_rows, &h->z, &h->ss, &h->Bt, &h->Bt2, &h->part, &h->mw_idx, &h->mw_dist, &h->stat_S, &h->stat_x, &h->stat_out, &h->queue,
                     &h->xs_s, &h->ys_s, &h->zs_s, &h->vals_s, &h->extra_cols_s, &h->sbox, &h->sp_cand, &h->sp_flags, &h->sp_klist, &h->sp_kcount,
                     &h->sp_nrows, &h->sp_rows, &h->sp_rstart, &h->sp_tiles, &h->sp_xoff, &h->sp_stats, &h->sp2_cand, &h->sp2_flags, &h->sp2_klist, &h->sp2_kcount,
-                    &h->sp2_nrows, &h->sp2_rows, &h->sp2_rstart, &h->sp2_tiles, &h->sp2_xoff, &h->part2, &h->queue2, &h->dsc};
+                    &h->sp2_nrows, &h->sp2_rows, &h->sp2_rstart, &h->sp2_tiles, &h->sp2_xoff, &h->part2, &h->queue2, &h->dsc, &h->sp_recs, &h->sp2_recs};
   for (DevBuf* b : bufs) b->release();
   h->pin_in.release();
   h->pin_out.release();
@@ -1068,6 +1072,9 @@ int mik_set_option(mik_handle* h, const char* key, double value) {
   } else if (!strcmp(key, "sparse")) {
     if (value != -1.0 && value != 0.0 && value != 1.0 && value != 2.0) return fail(MIK_EINVAL, "sparse must be -1 (auto), 0, 1 or 2");
     h->opt_sparse = (int)value;
+  } else if (!strcmp(key, "sparse_rows")) {
+    if (value != -1.0 && value != 16.0 && value != 128.0) return fail(MIK_EINVAL, "sparse_rows must be -1 (auto), 16 or 128");
+    h->opt_sparse_rows = (int)value;
   } else if (!strcmp(key, "sparse_lanes")) {
     if (value != 1.0 && value != 2.0) return fail(MIK_EINVAL, "sparse_lanes must be 1 or 2");
     h->opt_sparse_lanes = (int)value;
@@ -3267,9 +3274,13 @@ static int one_predict(mik_handle* h) {
   const bool sparse = h->factor_sorted && h->opt_sparse != 2 && h->opt_sparse != 0 && h->opt_engine == 0;
   if (sparse) chunk = std::min<long>(chunk, 131072);  // k_sp_tiles: at most 1024 point blocks per launch
   const int nK16 = Mp / 16;
+  // tiles of gathered 16-row groups (k_contract_spg) wherever 32-bit LDS-DMA offsets reach every row of the inverse
+  const bool gathered = sparse && h->opt_sparse_rows != 128 && (double)Mp * (double)Mp * 8.0 < 4294967296.0;
   h->tm.sparse = sparse ? 1 : 0;
+  h->tm.sparse_rows = sparse ? (gathered ? 16 : 128) : 0;
   h->tm.stations_sorted = h->factor_sorted ? 1 : 0;
   h->tm.sparse_tiles = h->tm.sparse_tiles_dense = h->tm.sparse_ktiles = h->tm.sparse_ktiles_dense = h->tm.sparse_lists_ms = 0.0;
+  h->tm.sparse_diag_products = 0.0;
   // "rhs_overlap" (off by default, see the option): two RHS panels, k_rhs of chunk c + 1 on a second stream while chunk c is
   // contracted.
   const bool overlap = h->opt_rhs_overlap && h->model != MIK_MODEL_CUSTOM && !sparse;
@@ -3292,13 +3303,13 @@ static int one_predict(mik_handle* h) {
   std::vector<unsigned long long> sp_host;
   const bool lanes2 = lanes2_wanted && nchunks > 1;
   struct SpLane {
-    DevBuf *cand, *flags, *klist, *kcount, *nrows, *rows, *rstart, *tiles, *xoff, *part, *queue, *Bt;
+    DevBuf *cand, *flags, *klist, *kcount, *nrows, *rows, *rstart, *tiles, *xoff, *part, *queue, *Bt, *recs;
     hipStream_t st;
   };
   SpLane lane[2] = {{&h->sp_cand, &h->sp_flags, &h->sp_klist, &h->sp_kcount, &h->sp_nrows, &h->sp_rows, &h->sp_rstart, &h->sp_tiles, &h->sp_xoff,
-                     &h->part, &h->queue, &h->Bt, h->stream},
+                     &h->part, &h->queue, &h->Bt, &h->sp_recs, h->stream},
                     {&h->sp2_cand, &h->sp2_flags, &h->sp2_klist, &h->sp2_kcount, &h->sp2_nrows, &h->sp2_rows, &h->sp2_rstart, &h->sp2_tiles,
-                     &h->sp2_xoff, &h->part2, &h->queue2, &h->Bt2, h->stream2}};
+                     &h->sp2_xoff, &h->part2, &h->queue2, &h->Bt2, &h->sp2_recs, h->stream2}};
   if (sparse) {
     const size_t nTb = (size_t)chunk / 128;
     for (int L = 0; L < (lanes2 ? 2 : 1); ++L) {
@@ -3307,9 +3318,13 @@ static int one_predict(mik_handle* h) {
       MIKC(lane[L].klist->ensure(sizeof(unsigned short) * nTb * nK16));
       MIKC(lane[L].kcount->ensure(sizeof(int) * nTb));
       MIKC(lane[L].nrows->ensure(sizeof(int) * nTb));
-      MIKC(lane[L].rows->ensure(sizeof(unsigned short) * nTb * nIblk));
-      MIKC(lane[L].rstart->ensure(sizeof(unsigned short) * nTb * nIblk));
-      MIKC(lane[L].tiles->ensure(sizeof(unsigned) * nTb * nIblk));
+      if (gathered) {
+        MIKC(lane[L].recs->ensure(32 * nTb * nIblk));  // ceil(nk / 8) <= nK16 / 8 = nIblk tiles per point block
+      } else {
+        MIKC(lane[L].rows->ensure(sizeof(unsigned short) * nTb * nIblk));
+        MIKC(lane[L].rstart->ensure(sizeof(unsigned short) * nTb * nIblk));
+        MIKC(lane[L].tiles->ensure(sizeof(unsigned) * nTb * nIblk));
+      }
       MIKC(lane[L].xoff->ensure(sizeof(int) * 9));
       MIKC(lane[L].queue->ensure(8 * sizeof(unsigned long long)));
       if (L == 1) {
@@ -3317,8 +3332,8 @@ static int one_predict(mik_handle* h) {
         MIKC(h->part2.ensure(sizeof(double) * (size_t)chunk * nIblk));
       }
     }
-    MIKC(h->sp_stats.ensure(sizeof(unsigned long long) * 2 * (size_t)nchunks));
-    sp_host.assign(2 * (size_t)nchunks, 0ULL);
+    MIKC(h->sp_stats.ensure(sizeof(unsigned long long) * 4 * (size_t)nchunks));
+    sp_host.assign(4 * (size_t)nchunks, 0ULL);
   }
   while (h->pr_events.size() < 2 * (size_t)nchunks) {
     hipEvent_t e;
@@ -3412,12 +3427,20 @@ static int one_predict(mik_handle* h) {
       const int nTb = palloc / 128;
       const SpLane& ln = lane[lanes2 ? (c & 1) : 0];
       hipStream_t sc = ln.st;  // (shadows the dense path's stream: this launch lives on its lane's)
-      hipLaunchKernelGGL(k_sp_lists, dim3(nTb), dim3(64), 0, sc, (const unsigned char*)ln.flags->as<unsigned char>(), nK16, nIblk,
-                         ln.klist->as<unsigned short>(), ln.kcount->as<int>(), ln.rows->as<unsigned short>(),
-                         ln.rstart->as<unsigned short>(), ln.nrows->as<int>());
-      hipLaunchKernelGGL(k_sp_tiles, dim3(1), dim3(1024), 0, sc, (const int*)ln.nrows->as<int>(), (const int*)ln.kcount->as<int>(),
-                         (const unsigned short*)ln.rstart->as<unsigned short>(), nIblk, nTb, ln.tiles->as<unsigned>(),
-                         ln.xoff->as<int>(), h->sp_stats.as<unsigned long long>() + 2 * c);
+      if (gathered) {
+        hipLaunchKernelGGL(k_sp_lists_g, dim3(nTb), dim3(64), 0, sc, (const unsigned char*)ln.flags->as<unsigned char>(), nK16,
+                           ln.klist->as<unsigned short>(), ln.kcount->as<int>(), ln.nrows->as<int>());
+        hipLaunchKernelGGL(k_sp_tiles_g, dim3(1), dim3(1024), 0, sc, (const int*)ln.nrows->as<int>(), (const int*)ln.kcount->as<int>(),
+                           (const unsigned short*)ln.klist->as<unsigned short>(), nK16, nTb, ln.recs->as<uint4>(), ln.xoff->as<int>(),
+                           h->sp_stats.as<unsigned long long>() + 4 * c);
+      } else {
+        hipLaunchKernelGGL(k_sp_lists, dim3(nTb), dim3(64), 0, sc, (const unsigned char*)ln.flags->as<unsigned char>(), nK16, nIblk,
+                           ln.klist->as<unsigned short>(), ln.kcount->as<int>(), ln.rows->as<unsigned short>(),
+                           ln.rstart->as<unsigned short>(), ln.nrows->as<int>());
+        hipLaunchKernelGGL(k_sp_tiles, dim3(1), dim3(1024), 0, sc, (const int*)ln.nrows->as<int>(), (const int*)ln.kcount->as<int>(),
+                           (const unsigned short*)ln.rstart->as<unsigned short>(), nIblk, nTb, ln.tiles->as<unsigned>(),
+                           ln.xoff->as<int>(), h->sp_stats.as<unsigned long long>() + 4 * c);
+      }
       HIPC(hipEventRecord(h->evpool[3 + 4 * nchunks + 2 * c], sc));
       HIPC(hipMemsetAsync(ln.queue->p, 0, 8 * sizeof(unsigned long long), sc));
       SpArgs sa{};
@@ -3438,7 +3461,23 @@ static int one_predict(mik_handle* h) {
       sa.xoff = ln.xoff->as<int>();
       sa.queue = ln.queue->as<unsigned long long>();
       HIPC(hipEventRecord(e1, sc));
-      hipLaunchKernelGGL((k_contract_sp<2>), dim3((unsigned)std::min<long>(2L * h->n_cu, (long)nTb * nIblk)), dim3(512), 0, sc, sa);
+      if (gathered) {
+        SpgArgs ga{};
+        ga.Ainv = sa.Ainv;
+        ga.lda = Mp;
+        ga.Bt = sa.Bt;
+        ga.ldb = Mp;
+        ga.part = sa.part;
+        ga.palloc = palloc;
+        ga.nK16 = nK16;
+        ga.klist = sa.klist;
+        ga.recs = ln.recs->as<uint4>();
+        ga.xoff = sa.xoff;
+        ga.queue = sa.queue;
+        hipLaunchKernelGGL((k_contract_spg<2>), dim3((unsigned)std::min<long>(2L * h->n_cu, (long)nTb * nIblk)), dim3(512), 0, sc, ga);
+      } else {
+        hipLaunchKernelGGL((k_contract_sp<2>), dim3((unsigned)std::min<long>(2L * h->n_cu, (long)nTb * nIblk)), dim3(512), 0, sc, sa);
+      }
       HIPC(hipEventRecord(e2, sc));
       hipLaunchKernelGGL(k_ss_reduce_sp, dim3((nvalid + 255) / 256), dim3(256), 0, sc, (const double*)ln.part->as<double>(), palloc,
                          (const int*)ln.nrows->as<int>(), nvalid, 2.0 * (h->v.p0 + h->v.p2), h->ss.as<double>() + t0);
@@ -3531,12 +3570,15 @@ static int one_predict(mik_handle* h) {
       HIPC(hipEventElapsedTime(&ms, h->evpool[3 + 4 * c], h->evpool[3 + 4 * nchunks + 2 * c]));
       h->tm.sparse_lists_ms += ms;
       const long nTb = (std::min<long>(chunk, npt - c * chunk) + 127) / 128;
-      const double tiles = (double)sp_host[2 * c], offk = (double)sp_host[2 * c + 1];
+      const double tiles = (double)sp_host[4 * c], offk = (double)sp_host[4 * c + 1];
       h->tm.sparse_tiles += tiles;
       h->tm.sparse_ktiles += offk;
       // executed flops: off-diagonal K tiles are 128 x 16 x 128 products; a diagonal block is nt (nt + 1) / 2 products of 16 rows x 16 k
-      // x 128 points (nt = 8, or the short last block's -- every point block has that row block: the last row is the 1 of ok.py:673)
-      h->tm.contract_flops_executed += 2.0 * 128.0 * 16.0 * 128.0 * offk + 2.0 * 16.0 * 16.0 * 128.0 * (36.0 * std::max(0.0, tiles - (double)nTb) + (ntl * (ntl + 1) / 2) * (double)nTb);
+      // x 128 points (nt = 8, or the short last block's -- every point block has that row block: the last row is the 1 of ok.py:673;
+      // gathered groups: k_sp_tiles_g counted the products of the triangular parts, short last tiles included)
+      const double diagp = gathered ? (double)sp_host[4 * c + 2] : 36.0 * std::max(0.0, tiles - (double)nTb) + (ntl * (ntl + 1) / 2) * (double)nTb;
+      h->tm.sparse_diag_products += diagp;
+      h->tm.contract_flops_executed += 2.0 * 128.0 * 16.0 * 128.0 * offk + 2.0 * 16.0 * 16.0 * 128.0 * diagp;
     }
   }
   h->tm.contract_launches = nchunks;

@@ -1,6 +1,6 @@
 """Range-aware contraction for the reference's compact-support variogram (spherical: constant beyond the range,
 variogram_models.py:56-70): sigma^2 = 2 s - delta^T A_inv delta, z = c . delta with delta = b + s u (include/mikrige.h, option
-"sparse"; k_rhs<.., SP>, k_sp_*, k_contract_sp).
+"sparse", "sparse_rows"; k_rhs<.., SP>, k_sp_*, k_contract_sp, k_contract_spg).
 
 CPU: the identity itself on the oracle's matrices, and the Hilbert-curve station order (mik_station_order needs no GPU).
 GPU: the sparse path against the oracle, against the dense path of the same library, and against the reference's stored answers
@@ -75,10 +75,61 @@ def test_station_order_is_a_hilbert_curve():
     assert np.median(diam) < 4.0 * np.sqrt(16 / 8000.0)  # a random 16-subset would span the unit square
 
 
+def test_gathered_row_groups_reproduce_the_quadratic_form():
+    """The tiling of k_contract_spg (option "sparse_rows" 16), restated in NumPy: the ascending list of a point block's active K tiles
+    (16 stations each) is also the list of its active 16-row groups; tile r takes list entries [8r, 8r + 8) as its rows, walks the
+    entries beyond them downwards as full K tiles, then its own groups as a triangle -- the group in list position j meets the K tiles
+    of positions >= j, its accumulator doubled when the walk reaches its own 16 x 16 square.  The sum over the tiles is
+    delta^T A delta over the active groups, i.e. over everything (the inactive groups hold exact zeros).  Also the order in which
+    k_sp_tiles_g lays the tile records of a group of four point blocks out (tile position ascending, point block fast)."""
+    rng = np.random.default_rng(3)
+    ng_all, npts = 45, 24
+    m = 16 * ng_all
+    a = rng.standard_normal((m, m))
+    a = a + a.T
+    for nk in (1, 5, 8, 9, 16, 23, 45):
+        active = np.sort(rng.choice(ng_all, nk, replace=False))
+        delta = np.zeros((m, npts))
+        for g in active:
+            delta[16 * g:16 * g + 16] = rng.standard_normal((16, npts))
+        want = np.einsum("it,ij,jt->t", delta, a, delta)
+        got = np.zeros(npts)
+        for r in range((nk + 7) // 8):
+            g0, n = 8 * r, nk - 8 * r
+            ngr = min(n, 8)
+            acc = np.zeros((8, 16, npts))
+            for w in range(n - 1, -1, -1):  # list positions relative to the tile's first group
+                kt = active[g0 + w]
+                dk = delta[16 * kt:16 * kt + 16]
+                for gi in range(ngr):
+                    rows = slice(16 * active[g0 + gi], 16 * active[g0 + gi] + 16)
+                    if w >= 8:
+                        acc[gi] += a[rows, 16 * kt:16 * kt + 16] @ dk
+                    elif w >= gi:
+                        if w == gi:
+                            acc[gi] *= 2.0
+                        acc[gi] += a[rows, 16 * kt:16 * kt + 16] @ dk
+            for gi in range(ngr):
+                got += np.einsum("it,it->t", delta[16 * active[g0 + gi]:16 * active[g0 + gi] + 16], acc[gi])
+        assert np.allclose(got, want, rtol=1e-12, atol=1e-9), nk
+    # record placement inside one group of MIK_ST = 4 point blocks: every thread computes its own tiles' slots
+    for nr in ([3, 3, 3, 3], [5, 1, 0, 2], [1, 7, 7, 2], [0, 0, 4, 0]):
+        order = [(r, q) for r in range(max(nr)) for q in range(4) if r < nr[q]]  # what one serial writer would produce
+        slots = {}
+        for q in range(4):
+            w = 0
+            for r in range(nr[q]):
+                on = [1 if nr[qq] > r else 0 for qq in range(4)]
+                slots[w + sum(on[:q])] = (r, q)
+                w += sum(on)
+        assert [slots[i] for i in range(len(order))] == order, nr
+
+
 # ---------------------------------------------------------------------------------------------- GPU
-def _run(m, style, args, sparse, chunk=None, **kw):
+def _run(m, style, args, sparse, chunk=None, rows=None, **kw):
     h = m._get_handle()
     h.set_option("sparse", sparse)
+    h.set_option("sparse_rows", -1 if rows is None else rows)
     if chunk:
         h.set_option("chunk", chunk)
     z, ss = m.execute(style, *args, **kw)
@@ -133,12 +184,19 @@ def test_sparse_contraction_against_oracle_and_dense(case):
     zr, sr = ko.execute(st, "grid", *axes)
     zd, sd, td = _run(m, "grid", axes, 0)
     assert td["sparse"] == 0 and td["stations_sorted"] == 0
-    for chunk in (131072, 2048):
-        zs, ss, ts = _run(m, "grid", axes, 1, chunk=chunk)
+    for chunk, rows in ((131072, None), (2048, None), (131072, 128), (2048, 16)):
+        zs, ss, ts = _run(m, "grid", axes, 1, chunk=chunk, rows=rows)
         assert ts["sparse"] == 1 and ts["stations_sorted"] == 1
+        assert ts["sparse_rows"] == (rows or 16)  # gathered 16-row groups are the default
         assert 0 < ts["sparse_tiles"] <= ts["sparse_tiles_dense"]
         assert np.abs(zs - zr).max() <= Z_TOL and np.abs(ss - sr).max() <= SS_TOL, (np.abs(zs - zr).max(), np.abs(ss - sr).max())
         assert np.abs(zs - zd).max() <= Z_TOL and np.abs(ss - sd).max() <= SS_TOL
+        if rows == 128:
+            t128 = ts
+        elif chunk == 131072:
+            t16 = ts
+    # gathered groups never execute more than aligned blocks do: fewer or equal off-diagonal K tiles and triangle products
+    assert t16["sparse_ktiles"] <= t128["sparse_ktiles"] and t16["sparse_diag_products"] <= t128["sparse_diag_products"], (t16, t128)
     if case == "ok2d_short_range":
         assert ts["sparse_tiles"] < 0.6 * ts["sparse_tiles_dense"], ts  # range 0.08 of the unit square: most tiles are skipped
     # Hilbert-ordered stations with the dense contraction (option 2): the order alone changes nothing beyond rounding
