@@ -369,7 +369,8 @@ def sparse_summary(t):
             "list_kernels_ms": t["sparse_lists_ms"], "stations_in_hilbert_order": bool(t["stations_sorted"]),
             "tile_rows": ("eight gathered 16-row groups (k_contract_spg)" if t.get("sparse_rows") == 16
                           else "aligned blocks of 128 rows (k_contract_sp)"),
-            "triangle_products_16x16x128": t.get("sparse_diag_products", 0.0)}
+            "triangle_products_16x16x128": t.get("sparse_diag_products", 0.0),
+            "points_in_hilbert_order_per_launch": bool(t.get("points_sorted")), "sort_points_ms": t.get("sort_points_ms", 0.0)}
 
 
 def sparse_kernel(t):
@@ -487,6 +488,9 @@ def main():
     ap.add_argument("--sparse-rows", type=int, default=None, choices=[-1, 16, 128],
                     help="library option 'sparse_rows' (range-aware contraction: tiles of eight gathered 16-row groups, or aligned "
                          "128-row blocks; default: the library's, 16)")
+    ap.add_argument("--sort-points", type=int, default=None, choices=[-1, 0, 1],
+                    help="library option 'sort_points' (range-aware contraction over the points of every launch in Hilbert-curve order; "
+                         "default: the library's, on)")
     ap.add_argument("--no-trials", action="store_true", default=os.environ.get("MIK_BENCH_TRIALS", "1") == "0",
                     help="device groups: skip the exchange / overlap trials before the timed loop (also MIK_BENCH_TRIALS=0)")
     ap.add_argument("--pretrial-budget", type=float, default=float(os.environ.get("MIK_BENCH_PRETRIAL_BUDGET", "60")), metavar="S",
@@ -596,6 +600,8 @@ def main():
             hh.set_option("sparse", args.sparse)
         if args.sparse_rows is not None:
             hh.set_option("sparse_rows", args.sparse_rows)
+        if args.sort_points is not None:
+            hh.set_option("sort_points", args.sort_points)
         return m, hh
 
     progress["stage"] = "create the kriging object and its device handle"

@@ -148,7 +148,9 @@ typedef struct mik_timing {
   double sparse_diag_products; /* (16-row group x 16-station K tile x 128 points) products of the tiles' triangular parts, all launches */
   int32_t sparse_rows;         /* rows of a tile of the range-aware contraction: 16 = eight gathered 16-row groups (k_contract_spg),
                                   128 = aligned row blocks (k_contract_sp), 0 = dense contraction (option "sparse_rows") */
-  int32_t reserved2;
+  int32_t points_sorted;       /* 1 = the range-aware contraction ran over the points of every launch in Hilbert-curve order (option
+                                  "sort_points") */
+  double sort_points_ms;       /* the device sort of the points (k_ps_*), when this mik_predict had to run it (part of predict_ms) */
 } mik_timing;
 
 int  mik_device_count(void);
@@ -187,6 +189,12 @@ int  mik_slab_of(int64_t n, int members, int i, int64_t *lo, int64_t *count); /*
  *   [8r, 8r + 8) as rows, the entries beyond as K tiles, then its own groups as a triangle) or an ALIGNED block of 128 rows that is
  *   contracted whole when any of its eight groups is active (128: k_contract_sp; active blocks are ~79 % full at BASELINE config
  *   5).  -1 (default) = 16 wherever 32-bit DMA offsets reach every row (Mp <= 23168), else 128 [MIK_SPARSE_ROWS] ;
+ * "sort_points" -1/0/1 = range-aware contraction: the points of every launch (one chunk of the resident point list) are put in
+ *   Hilbert-curve order among themselves on the device (k_ps_*: 20-bit keys, stable two-pass radix sort, all launches' segments
+ *   side by side) and kriged in that order -- a block of 128 consecutive points is then a compact patch whatever order the caller's
+ *   list or grid is in (a shuffled list, a row of a 3-D grid), and the contraction's cost grows with the square of the stations in
+ *   range of a block.  z and sigma^2 come back in the caller's order.  -1 (default) = 1 = on with the range-aware contraction,
+ *   0 = off [MIK_SORT_POINTS] ;
  * "sparse_lanes" 1/2 = range-aware contraction: its launches alternate between two lanes (two streams, two sets of work buffers and
  *   right-hand-side panels), so that the candidate / right-hand-side / list kernels of a launch and the tail of the previous
  *   launch's tile queue overlap.  Measured 2 % faster at config 5 for a second right-hand-side panel: default 1 = one launch after

@@ -60,7 +60,8 @@ class MikTiming(C.Structure):
         ("sparse", C.c_int32), ("stations_sorted", C.c_int32),
         ("sparse_tiles", C.c_double), ("sparse_tiles_dense", C.c_double),
         ("sparse_ktiles", C.c_double), ("sparse_ktiles_dense", C.c_double), ("sparse_lists_ms", C.c_double),
-        ("sparse_diag_products", C.c_double), ("sparse_rows", C.c_int32), ("reserved2", C.c_int32),
+        ("sparse_diag_products", C.c_double), ("sparse_rows", C.c_int32), ("points_sorted", C.c_int32),
+        ("sort_points_ms", C.c_double),
     ]
 
     def as_dict(self):

@@ -403,6 +403,8 @@ struct RhsArgs {
   int nIblk, nK16;
   double sill;
   const double* dsc;  // drift equilibration, as in AsmArgs (nullptr = raw drift values)
+  const unsigned* perm;  // SP, nullable: the chunk's points in sorted order -- point t of the chunk is point perm[t] of the WHOLE list;
+                         // px / py / pz / extra / zout are then the list's base pointers, not the chunk's (option "sort_points")
 };
 
 template <int MODEL, int NDIM, bool SP = false>
@@ -411,10 +413,12 @@ __global__ void __launch_bounds__(256) k_rhs(RhsArgs a) {
   const int t0 = blockIdx.x * MIK_TP;
   double qx[MIK_TP], qy[MIK_TP], qz[MIK_TP];
   bool ok[MIK_TP];
+  long pidx[MIK_TP];  // where point q's coordinates, host-evaluated drift values and z live
 #pragma unroll
   for (int q = 0; q < MIK_TP; ++q) {
     ok[q] = (t0 + q) < a.nvalid;
-    const int idx = ok[q] ? t0 + q : 0;
+    const long idx = (SP && a.perm) ? (long)a.perm[ok[q] ? t0 + q : 0] : (long)(ok[q] ? t0 + q : 0);
+    pidx[q] = idx;
     qx[q] = a.px[idx];
     qy[q] = a.py[idx];
     qz[q] = (NDIM == 3) ? a.pz[idx] : 0.0;
@@ -492,7 +496,7 @@ __global__ void __launch_bounds__(256) k_rhs(RhsArgs a) {
         double dv;
         if (kind == 0) dv = (c == 0) ? qx[q] : (c == 1 ? qy[q] : qz[q]);
         else if (kind == 1) dv = well_drift(qx[q], qy[q], a.wells + 3 * c);
-        else dv = ok[q] ? a.extra[(long)c * a.extra_stride + t0 + q] : 0.0;
+        else dv = ok[q] ? a.extra[(long)c * a.extra_stride + (SP ? pidx[q] : (long)(t0 + q))] : 0.0;
         val[q] = a.dsc ? (dv - dc) * ds : dv;
       }
     } else {
@@ -523,8 +527,10 @@ __global__ void __launch_bounds__(256) k_rhs(RhsArgs a) {
     if (lane == 0) red[wave][q] = s;
   }
   __syncthreads();
-  if (threadIdx.x < MIK_TP && (t0 + (int)threadIdx.x) < a.nvalid)
-    a.zout[t0 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  if (threadIdx.x < MIK_TP && (t0 + (int)threadIdx.x) < a.nvalid) {
+    const long o = (SP && a.perm) ? (long)a.perm[t0 + threadIdx.x] : (long)(t0 + threadIdx.x);
+    a.zout[o] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1234,14 +1240,17 @@ __global__ void __launch_bounds__(256) k_ss_reduce(const double* __restrict__ pa
 // candidates: which 128-station blocks can hold a station within `radius` of any of the 128 points of a point block (bounding
 // boxes; a superset of the truth).  k_rhs computes and stores only these; everything else is delta = 0 and is never read.
 // sbox: per station block lo[3], hi[3] (host, mik_set_problem).  One 128-thread block per point block.
+// perm (nullable): the launch's points in sorted order, perm[t] = index into px / py / pz (then chunk-independent base pointers)
 __global__ void __launch_bounds__(128) k_sp_cand(const double* __restrict__ px, const double* __restrict__ py,
                                                  const double* __restrict__ pz, int nvalid, const double* __restrict__ sbox,
-                                                 int nIblk, int nforced_from, double radius, unsigned char* __restrict__ cand) {
+                                                 int nIblk, int nforced_from, double radius, unsigned char* __restrict__ cand,
+                                                 const unsigned* __restrict__ perm) {
   __shared__ double red[6][2];
   const int tb = blockIdx.x, t = tb * 128 + threadIdx.x;
   const bool ok = t < nvalid;
   double lo[3], hi[3];
-  const double c[3] = {ok ? px[t] : 0.0, ok ? py[t] : 0.0, (ok && pz) ? pz[t] : 0.0};
+  const long ti = (ok && perm) ? (long)perm[t] : t;
+  const double c[3] = {ok ? px[ti] : 0.0, ok ? py[ti] : 0.0, (ok && pz) ? pz[ti] : 0.0};
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
     lo[d] = ok ? c[d] : 1e300;
@@ -1379,13 +1388,14 @@ __global__ void __launch_bounds__(1024) k_sp_tiles(const int* __restrict__ nrows
 
 // ss[t] = 2 s - sum over the active row blocks of the point's block  (see the identity above)
 __global__ void __launch_bounds__(256) k_ss_reduce_sp(const double* __restrict__ part, int palloc, const int* __restrict__ nrows,
-                                                      int nvalid, double two_s, double* __restrict__ ss) {
+                                                      int nvalid, double two_s, double* __restrict__ ss,
+                                                      const unsigned* __restrict__ perm) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= nvalid) return;
   const int nr = nrows[t >> 7];
   double s = 0.0;
   for (int r = 0; r < nr; ++r) s += part[(long)r * palloc + t];
-  ss[t] = two_s - s;
+  ss[perm ? (long)perm[t] : (long)t] = two_s - s;  // (perm: ss is then the whole list's base, see k_ps_*)
 }
 
 // The tile loop of the range-aware contraction: gemm_core's staging (LDS-DMA, saddr form), LDS image, fragment reads and MFMA
@@ -2069,6 +2079,199 @@ __global__ void __launch_bounds__(64 * 2 * (8 / NAI), 2 * (4 / NAI)) k_contract_
 #pragma unroll
       for (int x = 0; x < NWM; ++x) v += red[x * 128 + c];
       a.part[(long)rp * a.palloc + t0 + c] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Point order of the range-aware contraction (round 4, second session; option "sort_points").  The contraction's unit is a block of
+// 128 consecutive points; what it costs grows with the SQUARE of the number of stations within range of any of them, so a block
+// should be a compact patch: a row segment of a 3-D grid (128 of 200 cells) sees most of the domain, a shuffled point list all of
+// it.  The points of every launch (one chunk: a segment of the point list) are therefore put in Hilbert-curve order among
+// themselves: perm[s] = index of the point at sorted position s, s and perm[s] in the same chunk -- so a launch still produces a
+// contiguous range of results and its copy to the host still overlaps the next launch.  k_sp_cand / k_rhs<SP> / k_ss_reduce_sp
+// read coordinates and write z, sigma^2 through perm; nothing else knows.  The sort: 2 x 10-bit (3-D: 3 x 6-bit) Hilbert keys
+// relative to the segment's bounding box (cubic cells), a stable LSD radix sort with 10-bit digits in two passes, segments side
+// by side in every launch (k_ps_bbox, k_ps_keys, then k_ps_hist / k_ps_scan / k_ps_scatter per pass).  Stable + keys that only
+// depend on the coordinates = the same order on every device, run and rank.
+// ------------------------------------------------------------------------------------------------
+
+// Hilbert-curve index of a lattice point (Skilling, "Programming the Hilbert curve", AIP Conf. Proc. 707 (2004): axes ->
+// transposed index, in place; then the bits are interleaved, X[0] first).  n axes, b bits each.  (Host: the station order.)
+__host__ __device__ inline uint64_t hilbert_key(uint32_t* X, int n, int b) {
+  const uint32_t Mtop = 1u << (b - 1);
+  for (uint32_t Q = Mtop; Q > 1; Q >>= 1) {
+    const uint32_t P = Q - 1;
+    for (int i = 0; i < n; ++i) {
+      if (X[i] & Q) X[0] ^= P;
+      else {
+        const uint32_t t = (X[0] ^ X[i]) & P;
+        X[0] ^= t;
+        X[i] ^= t;
+      }
+    }
+  }
+  for (int i = 1; i < n; ++i) X[i] ^= X[i - 1];
+  uint32_t t = 0;
+  for (uint32_t Q = Mtop; Q > 1; Q >>= 1)
+    if (X[n - 1] & Q) t ^= Q - 1;
+  for (int i = 0; i < n; ++i) X[i] ^= t;
+  uint64_t key = 0;
+  for (int bit = b - 1; bit >= 0; --bit)
+    for (int i = 0; i < n; ++i) key = (key << 1) | ((X[i] >> bit) & 1u);
+  return key;
+}
+
+#define MIK_PS_DB 10                 // digit bits of the radix sort
+#define MIK_PS_TILE 4096             // keys per block of the histogram / scatter kernels (4 wavefronts x 1024 consecutive keys)
+__host__ __device__ inline int ps_bits(int ndim) { return ndim == 3 ? 6 : 10; }  // per axis: 18- / 20-bit keys = two digits
+
+// box[seg] = {lo x, lo y, lo z, scale}: bounding box of segment seg = points [seg chunk, min(npt, (seg + 1) chunk)), scale = lattice
+// cells per unit length (one scale for all axes: cubic cells; 0 for a degenerate or non-finite extent)
+__global__ void __launch_bounds__(1024) k_ps_bbox(const double* __restrict__ px, const double* __restrict__ py,
+                                                  const double* __restrict__ pz, long npt, long chunk, int bits,
+                                                  double* __restrict__ box) {
+  __shared__ double red[6][16];
+  const long lo = (long)blockIdx.x * chunk, hi = (lo + chunk < npt) ? lo + chunk : npt;
+  double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+  for (long t = lo + threadIdx.x; t < hi; t += 1024) {
+    const double c[3] = {px[t], py[t], pz ? pz[t] : 0.0};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      mn[d] = fmin(mn[d], c[d]);  // (fmin / fmax drop a NaN coordinate)
+      mx[d] = fmax(mx[d], c[d]);
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    for (int o = 32; o > 0; o >>= 1) {
+      mn[d] = fmin(mn[d], __shfl_xor(mn[d], o));
+      mx[d] = fmax(mx[d], __shfl_xor(mx[d], o));
+    }
+    if (lane == 0) {
+      red[d][wave] = mn[d];
+      red[3 + d][wave] = mx[d];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double ext = 0.0;
+    for (int d = 0; d < 3; ++d) {
+      double a = 1e300, b = -1e300;
+      for (int w = 0; w < 16; ++w) {
+        a = fmin(a, red[d][w]);
+        b = fmax(b, red[3 + d][w]);
+      }
+      box[4 * blockIdx.x + d] = a;
+      ext = fmax(ext, b - a);
+    }
+    box[4 * blockIdx.x + 3] = (ext > 0.0 && ext < 1e300) ? (double)((1u << bits) - 1) / ext : 0.0;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_ps_keys(const double* __restrict__ px, const double* __restrict__ py,
+                                                 const double* __restrict__ pz, long npt, long chunk, int ndim, int bits,
+                                                 const double* __restrict__ box, unsigned* __restrict__ key,
+                                                 unsigned* __restrict__ idx) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= npt) return;
+  const double* bx = box + 4 * (t / chunk);
+  const double c[3] = {px[t], py[t], (ndim == 3) ? pz[t] : 0.0};
+  const double top = (double)((1u << bits) - 1);
+  uint32_t X[3] = {0u, 0u, 0u};
+  for (int d = 0; d < ndim; ++d) {
+    const double q = (c[d] - bx[d]) * bx[3];
+    X[d] = (uint32_t)fmin(top, fmax(0.0, (q == q) ? q : 0.0));
+  }
+  key[t] = (unsigned)hilbert_key(X, ndim, bits);
+  idx[t] = (unsigned)t;
+}
+
+// digit counts of every block of MIK_PS_TILE keys: table[(seg << DB | digit) * bps + block of the segment]
+__global__ void __launch_bounds__(256) k_ps_hist(const unsigned* __restrict__ key, long npt, long chunk, int bps, int shift,
+                                                 unsigned* __restrict__ table) {
+  __shared__ unsigned h[1 << MIK_PS_DB];
+  const int seg = blockIdx.x / bps, b = blockIdx.x % bps;
+  const long send = ((long)(seg + 1) * chunk < npt) ? (long)(seg + 1) * chunk : npt;
+  const long lo = (long)seg * chunk + (long)b * MIK_PS_TILE, hi = (lo + MIK_PS_TILE < send) ? lo + MIK_PS_TILE : send;
+  for (int d = threadIdx.x; d < (1 << MIK_PS_DB); d += 256) h[d] = 0u;
+  __syncthreads();
+  for (long t = lo + threadIdx.x; t < hi; t += 256) atomicAdd(&h[(key[t] >> shift) & ((1u << MIK_PS_DB) - 1u)], 1u);
+  __syncthreads();
+  for (int d = threadIdx.x; d < (1 << MIK_PS_DB); d += 256) table[(((long)seg << MIK_PS_DB) | d) * bps + b] = h[d];
+}
+
+// exclusive scan of a segment's table (digit major, block minor): one block per segment, thread d owns digit d's row
+__global__ void __launch_bounds__(1 << MIK_PS_DB) k_ps_scan(unsigned* __restrict__ table, int bps) {
+  __shared__ unsigned wsum[(1 << MIK_PS_DB) / 64];
+  unsigned* row = table + (((long)blockIdx.x << MIK_PS_DB) | threadIdx.x) * bps;
+  unsigned tot = 0u;
+  for (int b = 0; b < bps; ++b) tot += row[b];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned inc = tot;  // inclusive scan over the digits: within the wavefront, then over the wavefronts
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned v = __shfl_up(inc, o);
+    if (lane >= o) inc += v;
+  }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  unsigned base = 0u;
+  for (int w = 0; w < wave; ++w) base += wsum[w];
+  unsigned run = base + inc - tot;
+  for (int b = 0; b < bps; ++b) {
+    const unsigned c = row[b];
+    row[b] = run;
+    run += c;
+  }
+}
+
+// stable scatter of one pass: wavefront w of a block owns the block's keys [1024 w, 1024 w + 1024) and walks them 64 at a time
+__global__ void __launch_bounds__(256) k_ps_scatter(const unsigned* __restrict__ key, const unsigned* __restrict__ idx, long npt,
+                                                    long chunk, int bps, int shift, const unsigned* __restrict__ table,
+                                                    unsigned* __restrict__ key_out, unsigned* __restrict__ idx_out) {
+  __shared__ unsigned wh[4][1 << MIK_PS_DB];
+  const int seg = blockIdx.x / bps, b = blockIdx.x % bps;
+  const long send = ((long)(seg + 1) * chunk < npt) ? (long)(seg + 1) * chunk : npt;
+  const long lo = (long)seg * chunk + (long)b * MIK_PS_TILE, hi = (lo + MIK_PS_TILE < send) ? lo + MIK_PS_TILE : send;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long wlo = lo + 1024L * wave, whi = (wlo + 1024 < hi) ? wlo + 1024 : hi;
+  const unsigned dmask = (1u << MIK_PS_DB) - 1u;
+  for (int d = threadIdx.x; d < 4 * (1 << MIK_PS_DB); d += 256) (&wh[0][0])[d] = 0u;
+  __syncthreads();
+  for (long t = wlo + lane; t < whi; t += 64) atomicAdd(&wh[wave][(key[t] >> shift) & dmask], 1u);
+  __syncthreads();
+  for (int d = threadIdx.x; d < (1 << MIK_PS_DB); d += 256) {  // counts -> first output position of every (wavefront, digit)
+    unsigned base = table[(((long)seg << MIK_PS_DB) | d) * bps + b];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const unsigned c = wh[w][d];
+      wh[w][d] = base;
+      base += c;
+    }
+  }
+  __syncthreads();
+  volatile unsigned* run = &wh[wave][0];
+  const long out0 = (long)seg * chunk;
+  for (long t0 = wlo; t0 < whi; t0 += 64) {
+    const long t = t0 + lane;
+    const bool valid = t < whi;
+    const unsigned k = valid ? key[t] : 0u, d = (k >> shift) & dmask;
+    unsigned long long same = __ballot(valid);  // lanes with this lane's digit
+#pragma unroll
+    for (int bit = 0; bit < MIK_PS_DB; ++bit) {
+      const bool on = (d >> bit) & 1u;
+      const unsigned long long m = __ballot(on);
+      same &= on ? m : ~m;
+    }
+    const int rank = __popcll(same & ((1ULL << lane) - 1ULL));
+    const unsigned old = valid ? run[d] : 0u;
+    __builtin_amdgcn_wave_barrier();
+    if (valid && rank == 0) run[d] = old + (unsigned)__popcll(same);
+    __builtin_amdgcn_wave_barrier();
+    if (valid) {
+      key_out[out0 + old + rank] = k;
+      idx_out[out0 + old + rank] = idx[t];
     }
   }
 }

@@ -263,6 +263,10 @@ struct mik_handle {
   DevBuf xs_s, ys_s, zs_s, vals_s, extra_cols_s, sbox;
   int opt_sparse = -1;  // "sparse": -1 = auto (= 1: on for compact-support models), 0 = off, 1 = on, 2 = sorted stations, dense contraction
   DevBuf sp_cand, sp_flags, sp_klist, sp_kcount, sp_nrows, sp_rows, sp_rstart, sp_tiles, sp_xoff, sp_stats, sp_recs;
+  int opt_sort_points = -1;  // "sort_points": range-aware contraction over the points of every launch in Hilbert-curve order (k_ps_*): -1 = auto = 1, 0 = off
+  DevBuf ps_key[2], ps_idx[2], ps_table, ps_box;
+  bool ps_valid = false;     // ps_idx[0] holds the order of the resident points for launches of ps_chunk points
+  long ps_chunk = 0;
   int opt_sparse_rows = -1;  // "sparse_rows": 16 = tiles of gathered 16-row groups (k_contract_spg), 128 = aligned row blocks (k_contract_sp),
                              // -1 = auto: 16 wherever 32-bit offsets address the inverse (Mp * Mp * 8 < 2^32)
   // second set (with Bt2): the launches of the range-aware contraction alternate between two lanes on two streams, so that the
@@ -373,6 +377,7 @@ struct mik_handle {
   mik_timing tm{};
   std::vector<hipEvent_t> evpool;
   std::vector<hipEvent_t> pr_events;  // predict: per chunk "right-hand sides written" / "contraction done" (two RHS panels)
+  hipEvent_t ev_sort = nullptr;       // predict: the points of every launch are in order (k_ps_*: timed, and the second lane waits for it)
   hipEvent_t ev_chunk = nullptr;      // predict: chunk finished on the compute stream (the result copies wait for it)
   // "rhs_overlap": k_rhs of the next chunk on a second stream while the current chunk is contracted (two RHS panels).
   // Measured (profiles/r03_chunk_and_rhs_overlap_sweep_c2.txt): it does run concurrently -- and the contraction slows down by
@@ -833,6 +838,7 @@ static int create_one_body(mik_handle* h, int device) {
   HIPC(hipStreamCreateWithFlags(&h->stream_d2h, hipStreamNonBlocking));
   HIPC(hipEventCreateWithFlags(&h->ev_d2h, hipEventDisableTiming));
   HIPC(hipEventCreateWithFlags(&h->ev_chunk, hipEventDisableTiming));
+  HIPC(hipEventCreate(&h->ev_sort));
   {
     int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) h->n_cu = ncu;
@@ -853,6 +859,8 @@ static int create_one_body(mik_handle* h, int device) {
   if (env) h->opt_pairs = atoi(env) ? 1 : 0;
   env = getenv("MIK_SPARSE");
   if (env && atoi(env) >= -1 && atoi(env) <= 2) h->opt_sparse = atoi(env);
+  env = getenv("MIK_SORT_POINTS");
+  if (env && atoi(env) >= -1 && atoi(env) <= 1) h->opt_sort_points = atoi(env);
   env = getenv("MIK_SPARSE_ROWS");
   if (env && (atoi(env) == -1 || atoi(env) == 16 || atoi(env) == 128)) h->opt_sparse_rows = atoi(env);
   env = getenv("MIK_UPDATE_ATOMIC");
@@ -920,7 +928,7 @@ static void destroy_one(mik_handle* h) {
                     &h->px, &h->py, &h->pz, &h->grid_axes, &h->grid_idx, &h->Averify, &h->vbuf, &h->extra_rows, &h->z, &h->ss, &h->Bt, &h->Bt2, &h->part, &h->mw_idx, &h->mw_dist, &h->stat_S, &h->stat_x, &h->stat_out, &h->queue,
                     &h->xs_s, &h->ys_s, &h->zs_s, &h->vals_s, &h->extra_cols_s, &h->sbox, &h->sp_cand, &h->sp_flags, &h->sp_klist, &h->sp_kcount,
                     &h->sp_nrows, &h->sp_rows, &h->sp_rstart, &h->sp_tiles, &h->sp_xoff, &h->sp_stats, &h->sp2_cand, &h->sp2_flags, &h->sp2_klist, &h->sp2_kcount,
-                    &h->sp2_nrows, &h->sp2_rows, &h->sp2_rstart, &h->sp2_tiles, &h->sp2_xoff, &h->part2, &h->queue2, &h->dsc, &h->sp_recs, &h->sp2_recs};
+                    &h->sp2_nrows, &h->sp2_rows, &h->sp2_rstart, &h->sp2_tiles, &h->sp2_xoff, &h->part2, &h->queue2, &h->dsc, &h->sp_recs, &h->sp2_recs, &h->ps_key[0], &h->ps_key[1], &h->ps_idx[0], &h->ps_idx[1], &h->ps_table, &h->ps_box};
   for (DevBuf* b : bufs) b->release();
   h->pin_in.release();
   h->pin_out.release();
@@ -929,6 +937,7 @@ static void destroy_one(mik_handle* h) {
   for (hipEvent_t e : h->ps_events) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->pr_events) (void)hipEventDestroy(e);
   if (h->ev_chunk) (void)hipEventDestroy(h->ev_chunk);
+  if (h->ev_sort) (void)hipEventDestroy(h->ev_sort);
   for (hipEvent_t e : h->xevents) (void)hipEventDestroy(e);
   if (h->ev_d2h) (void)hipEventDestroy(h->ev_d2h);
   if (h->stream_d2h) (void)hipStreamDestroy(h->stream_d2h);
@@ -1072,6 +1081,9 @@ int mik_set_option(mik_handle* h, const char* key, double value) {
   } else if (!strcmp(key, "sparse")) {
     if (value != -1.0 && value != 0.0 && value != 1.0 && value != 2.0) return fail(MIK_EINVAL, "sparse must be -1 (auto), 0, 1 or 2");
     h->opt_sparse = (int)value;
+  } else if (!strcmp(key, "sort_points")) {
+    if (value != -1.0 && value != 0.0 && value != 1.0) return fail(MIK_EINVAL, "sort_points must be -1 (auto), 0 or 1");
+    h->opt_sort_points = (int)value;
   } else if (!strcmp(key, "sparse_rows")) {
     if (value != -1.0 && value != 16.0 && value != 128.0) return fail(MIK_EINVAL, "sparse_rows must be -1 (auto), 16 or 128");
     h->opt_sparse_rows = (int)value;
@@ -1153,32 +1165,7 @@ int mik_set_option(mik_handle* h, const char* key, double value) {
 
 int64_t mik_matrix_order(mik_handle* h) { return h ? h->M : 0; }
 
-// Hilbert-curve index of a lattice point (Skilling, "Programming the Hilbert curve", AIP Conf. Proc. 707 (2004): axes ->
-// transposed index, in place; then the bits are interleaved, X[0] first).  n axes, b bits each.
-static uint64_t hilbert_key(uint32_t* X, int n, int b) {
-  const uint32_t Mtop = 1u << (b - 1);
-  for (uint32_t Q = Mtop; Q > 1; Q >>= 1) {
-    const uint32_t P = Q - 1;
-    for (int i = 0; i < n; ++i) {
-      if (X[i] & Q) X[0] ^= P;
-      else {
-        const uint32_t t = (X[0] ^ X[i]) & P;
-        X[0] ^= t;
-        X[i] ^= t;
-      }
-    }
-  }
-  for (int i = 1; i < n; ++i) X[i] ^= X[i - 1];
-  uint32_t t = 0;
-  for (uint32_t Q = Mtop; Q > 1; Q >>= 1)
-    if (X[n - 1] & Q) t ^= Q - 1;
-  for (int i = 0; i < n; ++i) X[i] ^= t;
-  uint64_t key = 0;
-  for (int bit = b - 1; bit >= 0; --bit)
-    for (int i = 0; i < n; ++i) key = (key << 1) | ((X[i] >> bit) & 1u);
-  return key;
-}
-
+// (hilbert_key: mik_kernels.h -- the device sorts the points of a launch with the same function)
 // order[i] = index of the station at position i of the Hilbert-curve order (ties by index: deterministic on every rank / member)
 static void hilbert_order(int ndim, long n, const double* xs, const double* ys, const double* zs, std::vector<int>& order) {
   const double* c[3] = {xs, ys, zs};
@@ -3022,6 +3009,7 @@ static int one_set_points(mik_handle* h, const mik_points* g, const long* idx, l
   h->have_points = true;
   h->points_from_grid = false;
   h->points_adjusted = false;
+  h->ps_valid = false;
   h->have_results = false;
   return MIK_OK;
 }
@@ -3137,6 +3125,7 @@ static int one_set_grid(mik_handle* h, bool leader, const mik_grid* g, const uns
   h->pts_step = g->nx > 1 ? std::fabs(g->gx[g->nx / 2] - g->gx[g->nx / 2 - 1]) : (g->ny > 1 ? std::fabs(g->gy[g->ny / 2] - g->gy[g->ny / 2 - 1]) : 0.0);
   h->have_points = true;
   h->points_from_grid = true;
+  h->ps_valid = false;
   h->have_results = false;
   return MIK_OK;
 }
@@ -3211,6 +3200,7 @@ int mik_adjust_points(mik_handle* h, const double center[3], const double rot[9]
   if (!h->have_points || h->points_from_grid) return fail(MIK_ESTATE, "mik_adjust_points: set the points with mik_set_points first");
   if (h->points_adjusted) return fail(MIK_ESTATE, "mik_adjust_points: the resident points have already been adjusted");
   h->points_adjusted = true;
+  h->ps_valid = false;
   return for_each_device(h, [&](int, mik_handle* m) -> int {
     HIPC(hipSetDevice(m->device));
     if (m->npt == 0) return MIK_OK;
@@ -3252,6 +3242,37 @@ int64_t mik_points_resident(mik_handle* h) {
   return n;
 }
 
+// Hilbert-curve order of the resident points inside every launch of `chunk` points (k_ps_*, mik_kernels.h): ps_idx[0][s] = index of
+// the point at sorted position s.  On the handle's stream; two radix passes of 10-bit digits, all segments side by side.
+static int sort_points(mik_handle* h, long chunk, long nchunks) {
+  const long npt = h->npt;
+  const int bits = ps_bits(h->ndim), bps = (int)((chunk + MIK_PS_TILE - 1) / MIK_PS_TILE);
+  for (int q = 0; q < 2; ++q) {
+    MIKC(h->ps_key[q].ensure(sizeof(unsigned) * (size_t)npt));
+    MIKC(h->ps_idx[q].ensure(sizeof(unsigned) * (size_t)npt));
+  }
+  MIKC(h->ps_table.ensure(sizeof(unsigned) * (size_t)nchunks * (1u << MIK_PS_DB) * (size_t)bps));
+  MIKC(h->ps_box.ensure(sizeof(double) * 4 * (size_t)nchunks));
+  const double *px = h->px.as<double>(), *py = h->py.as<double>(), *pz = h->ndim == 3 ? h->pz.as<double>() : nullptr;
+  hipStream_t st = h->stream;
+  hipLaunchKernelGGL(k_ps_bbox, dim3((unsigned)nchunks), dim3(1024), 0, st, px, py, pz, npt, chunk, bits, h->ps_box.as<double>());
+  hipLaunchKernelGGL(k_ps_keys, dim3((unsigned)((npt + 255) / 256)), dim3(256), 0, st, px, py, pz, npt, chunk, h->ndim, bits,
+                     (const double*)h->ps_box.as<double>(), h->ps_key[0].as<unsigned>(), h->ps_idx[0].as<unsigned>());
+  for (int pass = 0; pass < 2; ++pass) {
+    const unsigned* kin = h->ps_key[pass].as<unsigned>();
+    const unsigned* iin = h->ps_idx[pass].as<unsigned>();
+    hipLaunchKernelGGL(k_ps_hist, dim3((unsigned)(nchunks * bps)), dim3(256), 0, st, kin, npt, chunk, bps, MIK_PS_DB * pass,
+                       h->ps_table.as<unsigned>());
+    hipLaunchKernelGGL(k_ps_scan, dim3((unsigned)nchunks), dim3(1 << MIK_PS_DB), 0, st, h->ps_table.as<unsigned>(), bps);
+    hipLaunchKernelGGL(k_ps_scatter, dim3((unsigned)(nchunks * bps)), dim3(256), 0, st, kin, iin, npt, chunk, bps, MIK_PS_DB * pass,
+                       (const unsigned*)h->ps_table.as<unsigned>(), h->ps_key[pass ^ 1].as<unsigned>(), h->ps_idx[pass ^ 1].as<unsigned>());
+  }
+  HIPC(hipGetLastError());
+  h->ps_valid = true;
+  h->ps_chunk = chunk;
+  return MIK_OK;
+}
+
 static int one_predict(mik_handle* h) {
   if (!h || !h->have_factor) return fail(MIK_ESTATE, "mik_predict: factor first");
   if (!h->have_points) return fail(MIK_ESTATE, "mik_predict: set points first");
@@ -3281,6 +3302,10 @@ static int one_predict(mik_handle* h) {
   h->tm.stations_sorted = h->factor_sorted ? 1 : 0;
   h->tm.sparse_tiles = h->tm.sparse_tiles_dense = h->tm.sparse_ktiles = h->tm.sparse_ktiles_dense = h->tm.sparse_lists_ms = 0.0;
   h->tm.sparse_diag_products = 0.0;
+  // the points of every launch in Hilbert-curve order among themselves (compact point blocks: option "sort_points")
+  const bool sortpts = sparse && h->opt_sort_points != 0;
+  h->tm.points_sorted = sortpts ? 1 : 0;
+  h->tm.sort_points_ms = 0.0;
   // "rhs_overlap" (off by default, see the option): two RHS panels, k_rhs of chunk c + 1 on a second stream while chunk c is
   // contracted.
   const bool overlap = h->opt_rhs_overlap && h->model != MIK_MODEL_CUSTOM && !sparse;
@@ -3345,7 +3370,15 @@ static int one_predict(mik_handle* h) {
   hipStream_t sr = two ? h->stream2 : h->stream;  // right-hand sides
   HIPC(hipStreamWaitEvent(h->stream, h->ev_d2h, 0));  // an earlier predict's result copies still read z / ss
   HIPC(hipEventRecord(h->evpool[0], h->stream));
+  bool sorted_now = false;
+  if (sortpts && !(h->ps_valid && h->ps_chunk == chunk)) {
+    MIKC(sort_points(h, chunk, nchunks));
+    HIPC(hipEventRecord(h->ev_sort, h->stream));
+    sorted_now = true;
+  }
+  const unsigned* perm_all = sortpts ? h->ps_idx[0].as<unsigned>() : nullptr;
   if (two || lanes2) HIPC(hipStreamWaitEvent(h->stream2, h->evpool[0], 0));
+  if (lanes2 && sorted_now) HIPC(hipStreamWaitEvent(h->stream2, h->ev_sort, 0));
   auto launch_rhs = [&](long c) -> int {
     const long t0 = c * chunk;
     const int nvalid = (int)std::min<long>(chunk, npt - t0);
@@ -3389,9 +3422,17 @@ static int one_predict(mik_handle* h) {
       a.nIblk = nIblk;
       a.nK16 = nK16;
       a.sill = h->v.p0 + h->v.p2;
+      if (perm_all) {  // sorted order: the chunk's points are reached through perm, from the list's base pointers
+        a.perm = perm_all + t0;
+        a.px = h->px.as<double>();
+        a.py = h->py.as<double>();
+        a.pz = h->ndim == 3 ? h->pz.as<double>() : nullptr;
+        a.extra = h->nextra ? h->extra_rows.as<double>() : nullptr;
+        a.zout = h->z.as<double>();
+      }
       HIPC(hipEventRecord(h->evpool[2 + 4 * nchunks + 2 * c], ss));
       hipLaunchKernelGGL(k_sp_cand, dim3(palloc / 128), dim3(128), 0, ss, a.px, a.py, a.pz, nvalid, (const double*)h->sbox.as<double>(), nIblk,
-                         h->N / 128, std::max(h->v.p1, h->eps), ln.cand->as<unsigned char>());
+                         h->N / 128, std::max(h->v.p1, h->eps), ln.cand->as<unsigned char>(), a.perm);
       HIPC(hipMemsetAsync(ln.flags->p, 0, (size_t)(palloc / 128) * nK16, ss));
       HIPC(hipEventRecord(h->evpool[2 + 4 * c], ss));
       if (h->ndim == 3) hipLaunchKernelGGL((k_rhs<3, 3, true>), dim3(palloc / MIK_TP), dim3(256), 0, ss, a);
@@ -3480,7 +3521,8 @@ static int one_predict(mik_handle* h) {
       }
       HIPC(hipEventRecord(e2, sc));
       hipLaunchKernelGGL(k_ss_reduce_sp, dim3((nvalid + 255) / 256), dim3(256), 0, sc, (const double*)ln.part->as<double>(), palloc,
-                         (const int*)ln.nrows->as<int>(), nvalid, 2.0 * (h->v.p0 + h->v.p2), h->ss.as<double>() + t0);
+                         (const int*)ln.nrows->as<int>(), nvalid, 2.0 * (h->v.p0 + h->v.p2),
+                         perm_all ? h->ss.as<double>() : h->ss.as<double>() + t0, perm_all ? perm_all + t0 : (const unsigned*)nullptr);
       if (lanes2 && (c & 1)) HIPC(hipEventRecord(h->pr_events[0], sc));  // lane 1's latest launch (joined below)
       HIPC(hipEventRecord(h->ev_chunk, sc));
       HIPC(hipStreamWaitEvent(h->stream_d2h, h->ev_chunk, 0));
@@ -3555,6 +3597,10 @@ static int one_predict(mik_handle* h) {
   float ms = 0.f;
   HIPC(hipEventElapsedTime(&ms, h->evpool[0], h->evpool[1]));
   h->tm.predict_ms = ms;
+  if (sorted_now) {
+    HIPC(hipEventElapsedTime(&ms, h->evpool[0], h->ev_sort));
+    h->tm.sort_points_ms = ms;
+  }
   for (long c = 0; c < nchunks; ++c) {
     HIPC(hipEventElapsedTime(&ms, h->evpool[2 + 4 * c], h->evpool[3 + 4 * c]));
     h->tm.rhs_ms += ms;

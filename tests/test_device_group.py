@@ -186,7 +186,7 @@ def test_environment_variable_alone_makes_execute_multi_device():
         "import sys, numpy as np; sys.path.insert(0, %r)\n"
         "import pykrige_amd as pa\n"
         "rng = np.random.default_rng(5); x, y, v = rng.random(300), rng.random(300), rng.random(300)\n"
-        "ok = pa.OrdinaryKriging(x, y, v, variogram_model='spherical', variogram_parameters=[1.0, 0.5, 0.05])\n"
+        "ok = pa.OrdinaryKriging(x, y, v, variogram_model='exponential', variogram_parameters=[1.0, 0.5, 0.05])\n"
         "z, ss = ok.execute('grid', np.linspace(0, 1, 40), np.linspace(0, 1, 30), backend='loop')\n"
         "print(ok.last_timing['n_devices'], repr(float(z.sum())), repr(float(ss.sum())))\n" % root)
     outs = []

@@ -217,6 +217,53 @@ def test_sparse_contraction_against_oracle_and_dense(case):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ndim", [2, 3])
+def test_sorted_points_make_any_point_order_compact(ndim):
+    """Option "sort_points" (k_ps_*): the points of every launch are kriged in Hilbert-curve order among themselves, results come back
+    in the caller's order.  A shuffled point list (every block of 128 consecutive points sees the whole domain) then costs what a
+    sorted one costs; a 3-D grid's row segments become compact patches.  Same answers as the oracle and as the unsorted run."""
+    import pykrige_amd as pa
+
+    rng = np.random.default_rng(23)
+    n, npts = 1500, 30000
+    coords, v = fx.synth(6, n, ndim)
+    par = [1.0, 0.1, 0.01] if ndim == 2 else [1.0, 0.25, 0.01]
+    if ndim == 2:
+        m = pa.OrdinaryKriging(coords[0], coords[1], v, variogram_model="spherical", variogram_parameters=par)
+        st = ko.KrigingState(ndim=2, coords_orig=np.stack(coords, 1), values=v, model="spherical", params=ko.internal_parameters("spherical", par))
+    else:
+        m = pa.UniversalKriging3D(coords[0], coords[1], coords[2], v, variogram_model="spherical", variogram_parameters=par,
+                                  drift_terms=["regional_linear"])
+        st = ko.KrigingState(ndim=3, coords_orig=np.stack(coords, 1), values=v, model="spherical", params=ko.internal_parameters("spherical", par),
+                             scaling=[1.0, 1.0], angle=[0.0, 0.0, 0.0], regional_linear=True)
+    pts = [rng.random(npts) for _ in range(ndim)]
+    for k in range(5):  # exact hits
+        for d in range(ndim):
+            pts[d][7 * k] = coords[d][k]
+    zr, sr = ko.execute(st, "points", *pts)
+    out = {}
+    for sort, chunk in ((0, None), (1, None), (1, 4096 + 128)):  # (a chunk that is no multiple of the sort's 4096-key blocks)
+        h = m._get_handle()
+        h.set_option("sort_points", sort)
+        z, ss, t = _run(m, "points", pts, 1, chunk=chunk or 131072)
+        assert t["sparse"] == 1 and t["points_sorted"] == sort
+        assert np.abs(z - zr).max() <= Z_TOL and np.abs(ss - sr).max() <= SS_TOL, (sort, chunk, np.abs(z - zr).max(), np.abs(ss - sr).max())
+        out[(sort, chunk)] = t
+    assert out[(1, None)]["sparse_ktiles"] < 0.5 * out[(0, None)]["sparse_ktiles"], out  # compact blocks: a fraction of the K tiles
+    # a grid through the sorted path, every style's bookkeeping (masked: compacted points)
+    axes = [np.linspace(0, 1, 57), np.linspace(0, 1, 41)] + ([np.linspace(0, 1, 13)] if ndim == 3 else [])
+    zg, sg = ko.execute(st, "grid", *axes)
+    m._get_handle().set_option("sort_points", 1)
+    z, ss, t = _run(m, "grid", axes, 1, chunk=2048)
+    assert t["points_sorted"] == 1
+    assert np.abs(z - zg).max() <= Z_TOL and np.abs(ss - sg).max() <= SS_TOL
+    if ndim == 2:
+        mask = rng.random((axes[1].size, axes[0].size)) < 0.3
+        z, ss, t = _run(m, "masked", axes, 1, mask=mask)
+        assert np.abs(z - zg)[~mask].max() <= Z_TOL and np.abs(ss - sg)[~mask].max() <= SS_TOL
+
+
+@pytest.mark.gpu
 def test_sparse_factor_is_handed_out_in_the_callers_order():
     """mik_get_matrix(1) un-permutes the Hilbert-ordered factor: equal to the dense path's inverse and to LAPACK's."""
     from tests.test_hip_parity import _handle_for
@@ -249,19 +296,26 @@ def test_sparse_path_on_the_reference_fixtures(name):
 @pytest.mark.gpu
 def test_sparse_path_in_a_device_group():
     """A 3-member group (aliased onto the one GPU): the members sort their copies of the stations the same way, the broadcast
-    factor is in that order; results equal one device's bit for bit."""
+    factor is in that order; results equal one device's bit for bit while the points are kriged in the caller's order
+    (sort_points = 0: the same blocks of 128 points whatever the slabs), and to rounding when every member puts the points of ITS
+    launches in Hilbert order (sort_points = 1, the default: a block's partial sums follow the block's list of active stations)."""
     import pykrige_amd as pa
 
     (x, y), v = fx.synth(9, 1300, 2)
     axes = [np.linspace(0, 1, 140), np.linspace(0, 1, 37)]
-    outs = []
-    for ndev in (1, 3):
-        m = pa.OrdinaryKriging(x, y, v, variogram_model="spherical", variogram_parameters=[1.0, 0.15, 0.01])
-        h = m._get_handle()
-        h.set_option("sparse", 1)
-        if ndev > 1:
-            h.set_devices(ndev, alias=True)
-        z, ss = m.execute("grid", *axes)
-        assert m.last_timing["sparse"] == 1
-        outs.append((np.ma.getdata(z).copy(), np.ma.getdata(ss).copy()))
-    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    for sort in (0, 1):
+        outs = []
+        for ndev in (1, 3):
+            m = pa.OrdinaryKriging(x, y, v, variogram_model="spherical", variogram_parameters=[1.0, 0.15, 0.01])
+            h = m._get_handle()
+            h.set_option("sparse", 1)
+            h.set_option("sort_points", sort)
+            if ndev > 1:
+                h.set_devices(ndev, alias=True)
+            z, ss = m.execute("grid", *axes)
+            assert m.last_timing["sparse"] == 1 and m.last_timing["points_sorted"] == sort
+            outs.append((np.ma.getdata(z).copy(), np.ma.getdata(ss).copy()))
+        if sort == 0:
+            assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+        else:
+            assert np.abs(outs[0][0] - outs[1][0]).max() <= 1e-11 and np.abs(outs[0][1] - outs[1][1]).max() <= 1e-11
