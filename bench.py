@@ -488,6 +488,7 @@ def main():
     ap.add_argument("--sparse-rows", type=int, default=None, choices=[-1, 16, 128],
                     help="library option 'sparse_rows' (range-aware contraction: tiles of eight gathered 16-row groups, or aligned "
                          "128-row blocks; default: the library's, 16)")
+    ap.add_argument("--sparse-lanes", type=int, default=None, choices=[1, 2], help="library option 'sparse_lanes' (default: the library's, 1)")
     ap.add_argument("--sort-points", type=int, default=None, choices=[-1, 0, 1],
                     help="library option 'sort_points' (range-aware contraction over the points of every launch in Hilbert-curve order; "
                          "default: the library's, on)")
@@ -602,6 +603,8 @@ def main():
             hh.set_option("sparse_rows", args.sparse_rows)
         if args.sort_points is not None:
             hh.set_option("sort_points", args.sort_points)
+        if args.sparse_lanes is not None:
+            hh.set_option("sparse_lanes", args.sparse_lanes)
         return m, hh
 
     progress["stage"] = "create the kriging object and its device handle"

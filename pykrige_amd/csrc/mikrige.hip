@@ -998,6 +998,7 @@ static int set_group(mik_handle* h, int n) {
     k->opt_factor = h->opt_factor, k->opt_sym = h->opt_sym, k->opt_engine = h->opt_engine, k->opt_waves = h->opt_waves;
     k->opt_chunk = h->opt_chunk, k->opt_symsweep = h->opt_symsweep, k->opt_diag = h->opt_diag, k->opt_update_waves = h->opt_update_waves, k->opt_panel_rows = h->opt_panel_rows, k->opt_panel_stream = h->opt_panel_stream, k->opt_update_map = h->opt_update_map, k->opt_update_atomic = h->opt_update_atomic, k->opt_lookahead = h->opt_lookahead, k->opt_gate = h->opt_gate, k->opt_fuse_chain = h->opt_fuse_chain, k->opt_early_diag = h->opt_early_diag, k->opt_pinv_fast = h->opt_pinv_fast, k->opt_rhs_overlap = h->opt_rhs_overlap, k->opt_verify = h->opt_verify, k->verify_tol_z = h->verify_tol_z, k->verify_tol_inv = h->verify_tol_inv;
     k->opt_mw_class = h->opt_mw_class, k->opt_mw_knn_bound = h->opt_mw_knn_bound, k->opt_mw_pivot = h->opt_mw_pivot, k->opt_mw_lds_cap = h->opt_mw_lds_cap, k->opt_pairs = h->opt_pairs, k->opt_tri = h->opt_tri, k->opt_prefetch = h->opt_prefetch, k->opt_symmetrize = h->opt_symmetrize, k->opt_mw_solver = h->opt_mw_solver;
+    k->opt_sparse = h->opt_sparse, k->opt_sparse_lanes = h->opt_sparse_lanes, k->opt_sparse_rows = h->opt_sparse_rows, k->opt_sort_points = h->opt_sort_points, k->opt_drift_eq = h->opt_drift_eq;
     k->custom_fn = h->custom_fn, k->custom_user = h->custom_user;
     h->kids.push_back(k);
   }
@@ -1230,8 +1231,8 @@ static int upload_sorted_stations(mik_handle* h, const mik_problem* p) {
       HIPC(hipStreamSynchronize(h->stream));
     }
   }
-  // bounding boxes of the 128-station blocks: lo[3], hi[3] each (blocks without stations: an empty box, never near anything)
-  const int nIblk = h->Mp / 128;
+  // bounding boxes of the K tiles (16 consecutive stations): lo[3], hi[3] each (tiles without stations: an empty box, never near anything)
+  const int nIblk = h->Mp / 16;
   std::vector<double> box((size_t)nIblk * 6);
   const double* c[3] = {p->xs, p->ys, p->zs};
   for (int b = 0; b < nIblk; ++b) {
@@ -1240,7 +1241,7 @@ static int upload_sorted_stations(mik_handle* h, const mik_problem* p) {
       q[d] = d < h->ndim ? 1e300 : 0.0;
       q[3 + d] = d < h->ndim ? -1e300 : 0.0;
     }
-    for (long i = (long)b * 128; i < std::min<long>(N, (long)(b + 1) * 128); ++i)
+    for (long i = (long)b * 16; i < std::min<long>(N, (long)(b + 1) * 16); ++i)
       for (int d = 0; d < h->ndim; ++d) {
         const double v = c[d][h->sort_perm[(size_t)i]];
         q[d] = std::min(q[d], v);
@@ -3338,7 +3339,7 @@ static int one_predict(mik_handle* h) {
   if (sparse) {
     const size_t nTb = (size_t)chunk / 128;
     for (int L = 0; L < (lanes2 ? 2 : 1); ++L) {
-      MIKC(lane[L].cand->ensure(nTb * nIblk));
+      MIKC(lane[L].cand->ensure(nTb * nK16));
       MIKC(lane[L].flags->ensure(nTb * nK16));
       MIKC(lane[L].klist->ensure(sizeof(unsigned short) * nTb * nK16));
       MIKC(lane[L].kcount->ensure(sizeof(int) * nTb));
@@ -3431,8 +3432,8 @@ static int one_predict(mik_handle* h) {
         a.zout = h->z.as<double>();
       }
       HIPC(hipEventRecord(h->evpool[2 + 4 * nchunks + 2 * c], ss));
-      hipLaunchKernelGGL(k_sp_cand, dim3(palloc / 128), dim3(128), 0, ss, a.px, a.py, a.pz, nvalid, (const double*)h->sbox.as<double>(), nIblk,
-                         h->N / 128, std::max(h->v.p1, h->eps), ln.cand->as<unsigned char>(), a.perm);
+      hipLaunchKernelGGL(k_sp_cand, dim3(palloc / 128), dim3(128), 0, ss, a.px, a.py, a.pz, nvalid, (const double*)h->sbox.as<double>(), nK16,
+                         h->N / 16, (h->M + 15) / 16, std::max(h->v.p1, h->eps), ln.cand->as<unsigned char>(), a.perm);
       HIPC(hipMemsetAsync(ln.flags->p, 0, (size_t)(palloc / 128) * nK16, ss));
       HIPC(hipEventRecord(h->evpool[2 + 4 * c], ss));
       if (h->ndim == 3) hipLaunchKernelGGL((k_rhs<3, 3, true>), dim3(palloc / MIK_TP), dim3(256), 0, ss, a);
