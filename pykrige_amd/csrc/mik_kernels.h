@@ -818,6 +818,13 @@ __device__ __forceinline__ long xcd_tile(long total) {
   const long L = (long)(blockIdx.x % 8) * per + blockIdx.x / 8;
   return L < total ? L : -1;
 }
+// the same ranges walked from their ends: XCD x's q-th block takes the q-th tile from the END of the XCD's range
+__device__ __forceinline__ long xcd_tile_rev(long total) {
+  const long per = (total + 7) / 8;
+  const long x = blockIdx.x % 8, q = blockIdx.x / 8;
+  const long cnt = (total - x * per < per) ? total - x * per : per;
+  return q < cnt ? x * per + (cnt - 1 - q) : -1;
+}
 
 // Supertile order for the contraction: each XCD's contiguous range of logical tiles is cut into
 // supertiles of MIK_SI row blocks x MIK_ST point blocks = 64 tiles = what 32 CUs x 2 blocks hold at once.
@@ -1241,12 +1248,13 @@ __global__ void __launch_bounds__(256) k_ss_reduce(const double* __restrict__ pa
 // points of a point block (bounding boxes; a superset of the truth).  k_rhs computes and stores only these; everything else is
 // delta = 0 and is never read.  (Round 4, second session: per K tile; per 128-station block before -- 20-25 % fewer entries of
 // delta are computed and written.)  sbox: per K tile lo[3], hi[3] (host, mik_set_problem); tiles [nforced_from, nforced_to) hold the
-// drift rows and the last row and are always candidates.  One 128-thread block per point block.
+// drift rows and the last row and are always candidates.  whole128: candidates in whole aligned groups of eight K tiles (the form
+// with aligned 128-row blocks reads every K tile of an active block).  One 128-thread block per point block.
 // perm (nullable): the launch's points in sorted order, perm[t] = index into px / py / pz (then chunk-independent base pointers)
 __global__ void __launch_bounds__(128) k_sp_cand(const double* __restrict__ px, const double* __restrict__ py,
                                                  const double* __restrict__ pz, int nvalid, const double* __restrict__ sbox,
                                                  int nK16, int nforced_from, int nforced_to, double radius,
-                                                 unsigned char* __restrict__ cand, const unsigned* __restrict__ perm) {
+                                                 unsigned char* __restrict__ cand, const unsigned* __restrict__ perm, int whole128) {
   __shared__ double red[6][2];
   const int tb = blockIdx.x, t = tb * 128 + threadIdx.x;
   const bool ok = t < nvalid;
@@ -1281,7 +1289,12 @@ __global__ void __launch_bounds__(128) k_sp_cand(const double* __restrict__ px, 
       const double gap = fmax(0.0, fmax(sb[d] - hi[d], lo[d] - sb[3 + d]));
       d2 += gap * gap;
     }
-    cand[(long)tb * nK16 + jb] = ((jb >= nforced_from && jb < nforced_to) || (jb < nforced_from && d2 <= r2)) ? 1 : 0;
+    bool c = (jb >= nforced_from && jb < nforced_to) || (jb < nforced_from && d2 <= r2);
+    if (whole128) {  // k_contract_sp reads whole aligned blocks of 128 rows / 8 K tiles: a candidate makes its seven neighbours candidates
+      const unsigned long long m = __ballot(c);  // (jb = lane mod 8 inside a group of eight: nK16 and the stride are multiples of 8)
+      c = ((m >> (threadIdx.x & 56)) & 0xffULL) != 0ULL;
+    }
+    cand[(long)tb * nK16 + jb] = c ? 1 : 0;
   }
 }
 
@@ -2445,7 +2458,9 @@ k_update(double* __restrict__ T, long ld, int nblk, int kb, const double* __rest
     if ((part == 2 || part == 4) && (jblk == col || (SYM && iblk == col))) return finish();
     if (part == 4 && iblk == col + 1 && jblk == col + 1) return finish();
   } else if (SYM) {
-    const long L = xcd_tile((long)nblk * (nblk + 1) / 2);
+    // (atomic_rmw bit 1, option "update_rev": odd steps walk every XCD's tile range from its end -- the whole upper triangle is streamed
+    // once per step, cyclically; a memory-side cache smaller than it keeps nothing of a cyclic stream, but most of a back-and-forth one)
+    const long L = ((atomic_rmw & 2) && (kb & 1)) ? xcd_tile_rev((long)nblk * (nblk + 1) / 2) : xcd_tile((long)nblk * (nblk + 1) / 2);
     if (L < 0) return finish();
     jblk = (int)((sqrt(8.0 * (double)L + 1.0) - 1.0) * 0.5);
     while ((long)jblk * (jblk + 1) / 2 > L) --jblk;            // guard the float estimate
@@ -2494,7 +2509,7 @@ k_update(double* __restrict__ T, long ld, int nblk, int kb, const double* __rest
   constexpr int NTV = MIK_UPD_NTV(NAI);  // register sets of the epilogue (the 8-wave form has a 128-VGPR budget for 4 waves per SIMD)
   double tv[NTV][4][4];
   auto tile_ptr = [&](int ai) { return T + (long)(i0 + wm * WR + ai * 16 + lq) * ld + j0 + wn * 64 + lc; };
-  if (atomic_rmw && !P && !DC) {  // block-uniform
+  if ((atomic_rmw & 1) && !P && !DC) {  // block-uniform
 #pragma unroll
     for (int ai = 0; ai < NAI; ++ai) {
       double* tp = tile_ptr(ai);

@@ -330,6 +330,7 @@ struct mik_handle {
   // XCD has in flight share n + n operand panels in its L2).  Measured a tie at every size (profiles/r03_k2_panel_stream_ab.txt):
   // the update is not bound by its panel reads.
   int opt_update_map = 0;
+  int opt_update_rev = 0;  // "update_rev": the half sweep's trailing update walks its tiles backwards on odd steps (k_update)
   // trailing update: tiles without a panel / diagonal copy go to memory as fp64 atomic adds (k_update atomic_rmw; same bits).
   // Measured SLOWER (N=5000 4.39 -> 4.84 ms, N=8000 13.98 -> 15.96 ms: the L2's fp64 atomic rate, not latency, is the bound): off.
   int opt_update_atomic = 0;
@@ -865,6 +866,8 @@ static int create_one_body(mik_handle* h, int device) {
   if (env && (atoi(env) == -1 || atoi(env) == 16 || atoi(env) == 128)) h->opt_sparse_rows = atoi(env);
   env = getenv("MIK_UPDATE_ATOMIC");
   if (env) h->opt_update_atomic = atoi(env) ? 1 : 0;
+  env = getenv("MIK_UPDATE_REV");
+  if (env) h->opt_update_rev = atoi(env) ? 1 : 0;
   env = getenv("MIK_UPDATE_MAP");
   if (env) h->opt_update_map = atoi(env);
   env = getenv("MIK_PANEL_STREAM");
@@ -996,7 +999,7 @@ static int set_group(mik_handle* h, int n) {
     }
     k->is_kid = true;
     k->opt_factor = h->opt_factor, k->opt_sym = h->opt_sym, k->opt_engine = h->opt_engine, k->opt_waves = h->opt_waves;
-    k->opt_chunk = h->opt_chunk, k->opt_symsweep = h->opt_symsweep, k->opt_diag = h->opt_diag, k->opt_update_waves = h->opt_update_waves, k->opt_panel_rows = h->opt_panel_rows, k->opt_panel_stream = h->opt_panel_stream, k->opt_update_map = h->opt_update_map, k->opt_update_atomic = h->opt_update_atomic, k->opt_lookahead = h->opt_lookahead, k->opt_gate = h->opt_gate, k->opt_fuse_chain = h->opt_fuse_chain, k->opt_early_diag = h->opt_early_diag, k->opt_pinv_fast = h->opt_pinv_fast, k->opt_rhs_overlap = h->opt_rhs_overlap, k->opt_verify = h->opt_verify, k->verify_tol_z = h->verify_tol_z, k->verify_tol_inv = h->verify_tol_inv;
+    k->opt_chunk = h->opt_chunk, k->opt_symsweep = h->opt_symsweep, k->opt_diag = h->opt_diag, k->opt_update_waves = h->opt_update_waves, k->opt_panel_rows = h->opt_panel_rows, k->opt_panel_stream = h->opt_panel_stream, k->opt_update_map = h->opt_update_map, k->opt_update_rev = h->opt_update_rev, k->opt_update_atomic = h->opt_update_atomic, k->opt_lookahead = h->opt_lookahead, k->opt_gate = h->opt_gate, k->opt_fuse_chain = h->opt_fuse_chain, k->opt_early_diag = h->opt_early_diag, k->opt_pinv_fast = h->opt_pinv_fast, k->opt_rhs_overlap = h->opt_rhs_overlap, k->opt_verify = h->opt_verify, k->verify_tol_z = h->verify_tol_z, k->verify_tol_inv = h->verify_tol_inv;
     k->opt_mw_class = h->opt_mw_class, k->opt_mw_knn_bound = h->opt_mw_knn_bound, k->opt_mw_pivot = h->opt_mw_pivot, k->opt_mw_lds_cap = h->opt_mw_lds_cap, k->opt_pairs = h->opt_pairs, k->opt_tri = h->opt_tri, k->opt_prefetch = h->opt_prefetch, k->opt_symmetrize = h->opt_symmetrize, k->opt_mw_solver = h->opt_mw_solver;
     k->opt_sparse = h->opt_sparse, k->opt_sparse_lanes = h->opt_sparse_lanes, k->opt_sparse_rows = h->opt_sparse_rows, k->opt_sort_points = h->opt_sort_points, k->opt_drift_eq = h->opt_drift_eq;
     k->custom_fn = h->custom_fn, k->custom_user = h->custom_user;
@@ -1131,6 +1134,8 @@ int mik_set_option(mik_handle* h, const char* key, double value) {
     h->opt_update_waves = (int)value;
   } else if (!strcmp(key, "update_atomic")) {
     h->opt_update_atomic = value != 0.0;
+  } else if (!strcmp(key, "update_rev")) {
+    h->opt_update_rev = value != 0.0;
   } else if (!strcmp(key, "update_map")) {
     h->opt_update_map = (int)value;
   } else if (!strcmp(key, "panel_stream")) {
@@ -1540,7 +1545,8 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
   const long ltiles = symsweep ? (long)nblk * (nblk + 1) / 2 : tiles;
   const unsigned ug = (unsigned)(8 * ((ltiles + 7) / 8));
   const bool upd8 = h->opt_update_waves == 8;
-  const int uatomic = pivoted ? 0 : h->opt_update_atomic;  // plain tiles of the trailing update as fp64 atomic adds (k_update)
+  const int uatomic = (pivoted ? 0 : h->opt_update_atomic) | (h->opt_update_rev ? 2 : 0);  // bit 0: plain tiles of the trailing update as
+                                                                                           // fp64 atomic adds, bit 1: odd steps backwards (k_update)
   // tile order of the trailing update: optionally n x n super-blocks (k_update's tilemap)
   const int2* tmap = nullptr;
   if (!pivoted && h->opt_update_map > 1) {
@@ -3433,7 +3439,7 @@ static int one_predict(mik_handle* h) {
       }
       HIPC(hipEventRecord(h->evpool[2 + 4 * nchunks + 2 * c], ss));
       hipLaunchKernelGGL(k_sp_cand, dim3(palloc / 128), dim3(128), 0, ss, a.px, a.py, a.pz, nvalid, (const double*)h->sbox.as<double>(), nK16,
-                         h->N / 16, (h->M + 15) / 16, std::max(h->v.p1, h->eps), ln.cand->as<unsigned char>(), a.perm);
+                         h->N / 16, (h->M + 15) / 16, std::max(h->v.p1, h->eps), ln.cand->as<unsigned char>(), a.perm, gathered ? 0 : 1);
       HIPC(hipMemsetAsync(ln.flags->p, 0, (size_t)(palloc / 128) * nK16, ss));
       HIPC(hipEventRecord(h->evpool[2 + 4 * c], ss));
       if (h->ndim == 3) hipLaunchKernelGGL((k_rhs<3, 3, true>), dim3(palloc / MIK_TP), dim3(256), 0, ss, a);
