@@ -2291,6 +2291,26 @@ __global__ void __launch_bounds__(256) k_ps_scatter(const unsigned* __restrict__
   }
 }
 
+// coordinates in sorted order / results back in the caller's order (moving window over sorted points: mikrige.hip, one_predict_mw)
+__global__ void __launch_bounds__(256) k_ps_gather(const unsigned* __restrict__ perm, long npt, const double* __restrict__ x,
+                                                   const double* __restrict__ y, const double* __restrict__ z,
+                                                   double* __restrict__ xs, double* __restrict__ ys, double* __restrict__ zs) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= npt) return;
+  const long s = perm[t];
+  xs[t] = x[s];
+  ys[t] = y[s];
+  if (z) zs[t] = z[s];
+}
+__global__ void __launch_bounds__(256) k_ps_unsort(const unsigned* __restrict__ perm, long npt, const double* __restrict__ a_s,
+                                                   const double* __restrict__ b_s, double* __restrict__ a, double* __restrict__ b) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= npt) return;
+  const long s = perm[t];
+  a[s] = a_s[t];
+  b[s] = b_s[t];
+}
+
 // ------------------------------------------------------------------------------------------------
 // K2: block Gauss-Jordan inverse, block size 128.  For diagonal block K (rows/cols k0..k0+127):
 //   Dinv = T_KK^-1 (k_diag_inv) ; Cold = T[:,K] ; Cnew = -Cold.Dinv ; Rt = (Dinv.T[K,:])^T

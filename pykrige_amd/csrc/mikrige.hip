@@ -259,12 +259,13 @@ struct mik_handle {
   DevBuf dsc;
   int opt_drift_eq = 1;  // "drift_eq": 0 = assemble the drift columns as the reference does
   std::vector<int> sort_perm;
+  bool stations_same = false;  // mik_set_problem: the station coordinates are the previous problem's (sort_perm is kept)
   std::vector<double> hvals_s;
   DevBuf xs_s, ys_s, zs_s, vals_s, extra_cols_s, sbox;
   int opt_sparse = -1;  // "sparse": -1 = auto (= 1: on for compact-support models), 0 = off, 1 = on, 2 = sorted stations, dense contraction
   DevBuf sp_cand, sp_flags, sp_klist, sp_kcount, sp_nrows, sp_rows, sp_rstart, sp_tiles, sp_xoff, sp_stats, sp_recs;
   int opt_sort_points = -1;  // "sort_points": range-aware contraction over the points of every launch in Hilbert-curve order (k_ps_*): -1 = auto = 1, 0 = off
-  DevBuf ps_key[2], ps_idx[2], ps_table, ps_box;
+  DevBuf ps_key[2], ps_idx[2], ps_table, ps_box, ps_x, ps_y, ps_z, ps_zs, ps_sss;
   bool ps_valid = false;     // ps_idx[0] holds the order of the resident points for launches of ps_chunk points
   long ps_chunk = 0;
   int opt_sparse_rows = -1;  // "sparse_rows": 16 = tiles of gathered 16-row groups (k_contract_spg), 128 = aligned row blocks (k_contract_sp),
@@ -314,6 +315,7 @@ struct mik_handle {
   bool no_half_sweep = false;  // transient: this attempt must not use the half sweep
   bool last_half_sweep = false;
   bool points_from_grid = false;  // the resident points were generated by mik_set_grid (mik_adjust_points refuses them)
+  double pts_extent = -1.0;       // largest coordinate extent of the resident points (from the same sample / the grid's axes; -1 = unknown)
   double pts_step = -1.0;         // median step between consecutive resident points (largest coordinate difference; -1 = unknown):
                                   // tells the moving-window search whether 64 consecutive points are neighbours in space
   bool points_adjusted = false;   // mik_adjust_points has transformed the resident points (a second call would transform them twice)
@@ -330,7 +332,8 @@ struct mik_handle {
   // XCD has in flight share n + n operand panels in its L2).  Measured a tie at every size (profiles/r03_k2_panel_stream_ab.txt):
   // the update is not bound by its panel reads.
   int opt_update_map = 0;
-  int opt_update_rev = 0;  // "update_rev": the half sweep's trailing update walks its tiles backwards on odd steps (k_update)
+  int opt_update_rev = -1;  // "update_rev": the half sweep's trailing update walks its tiles backwards on odd steps (k_update): -1 = auto =
+                            // from 45 block columns on (the upper triangle no longer fits half of the 256 MB memory-side cache), 0 / 1
   // trailing update: tiles without a panel / diagonal copy go to memory as fp64 atomic adds (k_update atomic_rmw; same bits).
   // Measured SLOWER (N=5000 4.39 -> 4.84 ms, N=8000 13.98 -> 15.96 ms: the L2's fp64 atomic rate, not latency, is the bound): off.
   int opt_update_atomic = 0;
@@ -867,7 +870,7 @@ static int create_one_body(mik_handle* h, int device) {
   env = getenv("MIK_UPDATE_ATOMIC");
   if (env) h->opt_update_atomic = atoi(env) ? 1 : 0;
   env = getenv("MIK_UPDATE_REV");
-  if (env) h->opt_update_rev = atoi(env) ? 1 : 0;
+  if (env) h->opt_update_rev = atoi(env) < 0 ? -1 : atoi(env) ? 1 : 0;
   env = getenv("MIK_UPDATE_MAP");
   if (env) h->opt_update_map = atoi(env);
   env = getenv("MIK_PANEL_STREAM");
@@ -931,7 +934,7 @@ static void destroy_one(mik_handle* h) {
                     &h->px, &h->py, &h->pz, &h->grid_axes, &h->grid_idx, &h->Averify, &h->vbuf, &h->extra_rows, &h->z, &h->ss, &h->Bt, &h->Bt2, &h->part, &h->mw_idx, &h->mw_dist, &h->stat_S, &h->stat_x, &h->stat_out, &h->queue,
                     &h->xs_s, &h->ys_s, &h->zs_s, &h->vals_s, &h->extra_cols_s, &h->sbox, &h->sp_cand, &h->sp_flags, &h->sp_klist, &h->sp_kcount,
                     &h->sp_nrows, &h->sp_rows, &h->sp_rstart, &h->sp_tiles, &h->sp_xoff, &h->sp_stats, &h->sp2_cand, &h->sp2_flags, &h->sp2_klist, &h->sp2_kcount,
-                    &h->sp2_nrows, &h->sp2_rows, &h->sp2_rstart, &h->sp2_tiles, &h->sp2_xoff, &h->part2, &h->queue2, &h->dsc, &h->sp_recs, &h->sp2_recs, &h->ps_key[0], &h->ps_key[1], &h->ps_idx[0], &h->ps_idx[1], &h->ps_table, &h->ps_box};
+                    &h->sp2_nrows, &h->sp2_rows, &h->sp2_rstart, &h->sp2_tiles, &h->sp2_xoff, &h->part2, &h->queue2, &h->dsc, &h->sp_recs, &h->sp2_recs, &h->ps_key[0], &h->ps_key[1], &h->ps_idx[0], &h->ps_idx[1], &h->ps_table, &h->ps_box, &h->ps_x, &h->ps_y, &h->ps_z, &h->ps_zs, &h->ps_sss};
   for (DevBuf* b : bufs) b->release();
   h->pin_in.release();
   h->pin_out.release();
@@ -1135,7 +1138,7 @@ int mik_set_option(mik_handle* h, const char* key, double value) {
   } else if (!strcmp(key, "update_atomic")) {
     h->opt_update_atomic = value != 0.0;
   } else if (!strcmp(key, "update_rev")) {
-    h->opt_update_rev = value != 0.0;
+    h->opt_update_rev = value < 0.0 ? -1 : value != 0.0 ? 1 : 0;
   } else if (!strcmp(key, "update_map")) {
     h->opt_update_map = (int)value;
   } else if (!strcmp(key, "panel_stream")) {
@@ -1213,7 +1216,7 @@ int mik_station_order(const mik_problem* p, int32_t* order_out) {
 
 static int upload_sorted_stations(mik_handle* h, const mik_problem* p) {
   const long N = h->N;
-  hilbert_order(h->ndim, N, p->xs, p->ys, p->zs, h->sort_perm);
+  if (!(h->stations_same && (long)h->sort_perm.size() == N)) hilbert_order(h->ndim, N, p->xs, p->ys, p->zs, h->sort_perm);
   const size_t nb = sizeof(double) * (size_t)N;
   std::vector<double> tmp((size_t)N);
   auto up = [&](DevBuf& dst, const double* src) -> int {
@@ -1310,6 +1313,13 @@ static int one_set_problem(mik_handle* h, const mik_problem* p) {
   MIKC(h->xs.ensure(nb));
   MIKC(h->ys.ensure(nb));
   MIKC(h->vals.ensure(nb));
+  {  // the same station coordinates as at the last mik_set_problem (the class sets the problem at every execute()): their Hilbert order
+     // is a function of the coordinates alone and is kept
+    const size_t cb = sizeof(double) * (size_t)h->N;
+    h->stations_same = h->hxs.size() == (size_t)h->N && h->hys.size() == (size_t)h->N && !memcmp(h->hxs.data(), p->xs, cb) &&
+                       !memcmp(h->hys.data(), p->ys, cb) &&
+                       (p->ndim == 3 ? (h->hzs.size() == (size_t)h->N && !memcmp(h->hzs.data(), p->zs, cb)) : h->hzs.empty());
+  }
   h->hvals.assign(p->values, p->values + h->N);
   h->hxs.assign(p->xs, p->xs + h->N);
   h->hys.assign(p->ys, p->ys + h->N);
@@ -1545,7 +1555,7 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
   const long ltiles = symsweep ? (long)nblk * (nblk + 1) / 2 : tiles;
   const unsigned ug = (unsigned)(8 * ((ltiles + 7) / 8));
   const bool upd8 = h->opt_update_waves == 8;
-  const int uatomic = (pivoted ? 0 : h->opt_update_atomic) | (h->opt_update_rev ? 2 : 0);  // bit 0: plain tiles of the trailing update as
+  const int uatomic = (pivoted ? 0 : h->opt_update_atomic) | ((h->opt_update_rev < 0 ? nblk >= 45 : h->opt_update_rev != 0) ? 2 : 0);  // bit 0: plain tiles of the trailing update as
                                                                                            // fp64 atomic adds, bit 1: odd steps backwards (k_update)
   // tile order of the trailing update: optionally n x n super-blocks (k_update's tilemap)
   const int2* tmap = nullptr;
@@ -2997,18 +3007,23 @@ static int one_set_points(mik_handle* h, const mik_points* g, const long* idx, l
   MIKC(h->ss.ensure(sizeof(double) * cap));
   MIKC(h->pin_out.ensure(sizeof(double) * 2 * (size_t)cap));
   HIPC(hipStreamSynchronize(h->stream));
-  {  // median step between consecutive points, from <= 1024 sampled pairs (see pts_step)
-    h->pts_step = -1.0;
+  {  // median step between consecutive points, from <= 1024 sampled pairs (see pts_step); the sample's extent
+    h->pts_step = h->pts_extent = -1.0;
     if (n >= 2) {
       const long ns = std::min<long>(1024, n - 1);
       std::vector<double> st((size_t)ns);
+      double elo[3] = {1e300, 1e300, 1e300}, ehi[3] = {-1e300, -1e300, -1e300};
       for (long q = 0; q < ns; ++q) {
         const long i = (long)((double)q * (double)(n - 1) / (double)ns);
         const long a0 = idx ? idx[lo + i] : lo + i, a1 = idx ? idx[lo + i + 1] : lo + i + 1;
         double m = 0.0;
-        for (int d = 0; d < h->ndim; ++d) m = std::max(m, std::fabs(src[d][a1] - src[d][a0]));
+        for (int d = 0; d < h->ndim; ++d) {
+          m = std::max(m, std::fabs(src[d][a1] - src[d][a0]));
+          if (std::isfinite(src[d][a0])) elo[d] = std::min(elo[d], src[d][a0]), ehi[d] = std::max(ehi[d], src[d][a0]);
+        }
         st[(size_t)q] = std::isfinite(m) ? m : 1e300;
       }
+      for (int d = 0; d < h->ndim; ++d) h->pts_extent = std::max(h->pts_extent, ehi[d] - elo[d]);
       std::nth_element(st.begin(), st.begin() + ns / 2, st.end());
       h->pts_step = st[(size_t)(ns / 2)];
     }
@@ -3130,6 +3145,8 @@ static int one_set_grid(mik_handle* h, bool leader, const mik_grid* g, const uns
   HIPC(hipStreamSynchronize(h->stream));
   // consecutive points of a grid are one x step apart (meshgrid order; compacted cells of a masked grid mostly so)
   h->pts_step = g->nx > 1 ? std::fabs(g->gx[g->nx / 2] - g->gx[g->nx / 2 - 1]) : (g->ny > 1 ? std::fabs(g->gy[g->ny / 2] - g->gy[g->ny / 2 - 1]) : 0.0);
+  h->pts_extent = std::max(g->nx > 1 ? std::fabs(g->gx[g->nx - 1] - g->gx[0]) : 0.0, g->ny > 1 ? std::fabs(g->gy[g->ny - 1] - g->gy[0]) : 0.0);
+  if (g->ndim == 3 && g->nz > 1) h->pts_extent = std::max(h->pts_extent, std::fabs(g->gz[g->nz - 1] - g->gz[0]));
   h->have_points = true;
   h->points_from_grid = true;
   h->ps_valid = false;
@@ -3746,8 +3763,37 @@ static int one_predict_mw(mik_handle* h, int n_closest) {
   int cap = 512;  // candidate buffer of the wave-per-point neighbour search: a power of two >= K + 256
   while (cap < K + 256) cap <<= 1;
   const bool wave_knn = cap <= h->opt_mw_lds_cap;  // default 8192 = 96 KB of LDS; beyond that the lists live in HBM
+  // Small windows over a point list in no spatial order (round 4, second session): the lane-per-point search below needs 64
+  // consecutive points to share a few cells of the station grid.  The points are then put in Hilbert-curve order on the device
+  // (k_ps_*: the sorter of the range-aware contraction), searched and solved in that order -- coordinates gathered once, z and
+  // sigma^2 scattered back at the end -- so a shuffled list costs what the rows of a grid cost.
+  bool mw_sorted = false;
+  double *zout = h->z.as<double>(), *ssout = h->ss.as<double>();
   if (wave_knn) {
     MIKC(build_mw_grid(h, std::max(8, std::min(K, 256))));
+    const bool cells = (long)h->grid.nx * h->grid.ny * h->grid.nz > 1;
+    const bool coherent = h->pts_step >= 0.0 && 64.0 * h->pts_step <= 10.0 * h->grid.cell;
+    if (h->opt_mw_knn_lane && h->opt_sort_points != 0 && K <= 16 && cells && !h->geo && !custom && !coherent && h->pts_extent > 0.0 &&
+        npt >= 4096) {
+      const double spacing = h->pts_extent / std::pow((double)npt, 1.0 / h->ndim);  // of a sorted list: a wavefront's 64 points are a patch
+      if (12.0 * spacing <= 10.0 * h->grid.cell) {                                   // ~8 spacings across
+        const long schunk = std::min<long>(((npt + 127) / 128) * 128, 1L << 20);
+        if (!(h->ps_valid && h->ps_chunk == schunk)) MIKC(sort_points(h, schunk, (npt + schunk - 1) / schunk));
+        const size_t nbp = sizeof(double) * (size_t)npt;
+        MIKC(h->ps_x.ensure(nbp));
+        MIKC(h->ps_y.ensure(nbp));
+        if (h->ndim == 3) MIKC(h->ps_z.ensure(nbp));
+        MIKC(h->ps_zs.ensure(nbp));
+        MIKC(h->ps_sss.ensure(nbp));
+        hipLaunchKernelGGL(k_ps_gather, dim3((unsigned)((npt + 255) / 256)), dim3(256), 0, h->stream, (const unsigned*)h->ps_idx[0].as<unsigned>(),
+                           npt, qx, qy, h->ndim == 3 ? qz : (const double*)nullptr, h->ps_x.as<double>(), h->ps_y.as<double>(),
+                           h->ndim == 3 ? h->ps_z.as<double>() : (double*)nullptr);
+        qx = h->ps_x.as<double>(), qy = h->ps_y.as<double>();
+        if (h->ndim == 3) qz = h->ps_z.as<double>();
+        zout = h->ps_zs.as<double>(), ssout = h->ps_sss.as<double>();
+        mw_sorted = true;
+      }
+    }
   } else {
     MIKC(wd.ensure(sizeof(double) * (size_t)chunk * K));
     MIKC(wi.ensure(sizeof(int) * (size_t)chunk * K));
@@ -3827,8 +3873,8 @@ static int one_predict_mw(mik_handle* h, int n_closest) {
       // 32-entry list per lane only ties with the wave-per-point search, and a shuffled point list sends every lane to the list --
       // one same-address atomic per wavefront, +0.3 ms -- hence K <= 16 and the coherence test: 64 consecutive points must span
       // few cells, judged from the median step between consecutive points that mik_set_points / mik_set_grid recorded)
-      if (h->opt_mw_knn_lane && K <= 16 && (long)h->grid.nx * h->grid.ny * h->grid.nz > 1 && h->pts_step >= 0.0 &&
-          64.0 * h->pts_step * (h->geo ? MIK_PI / 180.0 : 1.0) <= 10.0 * h->grid.cell) {
+      if (h->opt_mw_knn_lane && K <= 16 && (long)h->grid.nx * h->grid.ny * h->grid.nz > 1 &&
+          (mw_sorted || (h->pts_step >= 0.0 && 64.0 * h->pts_step * (h->geo ? MIK_PI / 180.0 : 1.0) <= 10.0 * h->grid.cell))) {
         // small windows: one lane per point over the box of cells its wavefront's 64 consecutive points share (k_mw_knn_lane); the
         // wave-per-point kernel below then only walks the list of points that pass left unfinished
         MIKC(todo.ensure(sizeof(int) * ((size_t)pc + 1)));
@@ -3864,8 +3910,8 @@ static int one_predict_mw(mik_handle* h, int n_closest) {
     a.v = h->v;
     a.exact = h->exact;
     a.eps = h->eps;
-    a.z = h->z.as<double>() + p0;
-    a.ss = h->ss.as<double>() + p0;
+    a.z = zout + p0;
+    a.ss = ssout + p0;
     a.flag = h->flag.as<int>();
     {  // right-hand sides in place over the distances
       const long ne = pc * K;
@@ -3911,6 +3957,10 @@ static int one_predict_mw(mik_handle* h, int n_closest) {
     ++solve_chunks;
     HIPC(hipGetLastError());
   }
+  if (mw_sorted)  // back to the caller's order
+    hipLaunchKernelGGL(k_ps_unsort, dim3((unsigned)((npt + 255) / 256)), dim3(256), 0, h->stream, (const unsigned*)h->ps_idx[0].as<unsigned>(), npt,
+                       (const double*)zout, (const double*)ssout, h->z.as<double>(), h->ss.as<double>());
+  h->tm.points_sorted = mw_sorted ? 1 : 0;
   int flag = 0;
   HIPC(hipMemcpyAsync(&flag, h->flag.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIPC(hipEventRecord(h->evpool[1], h->stream));

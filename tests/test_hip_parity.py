@@ -797,6 +797,38 @@ def test_moving_window_cell_grid_against_kdtree(case):
     np.testing.assert_allclose(ss, sr, rtol=0, atol=1e-6)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("ndim", [2, 3])
+def test_moving_window_over_a_shuffled_point_list_is_sorted_on_the_device(ndim):
+    """Small windows over points in no spatial order (the sklearn-side default n_closest_points = 10 on a scattered list): the
+    library puts the points in Hilbert-curve order on the device (k_ps_*, the sorter of the range-aware contraction), runs the
+    lane-per-point neighbour search on compact wavefronts and scatters z / sigma^2 back.  A point's result does not depend on its
+    neighbours in the list: bit-identical to the unsorted run, and the oracle's on a sample."""
+    import pykrige_amd as pa
+
+    rng = np.random.default_rng(31)
+    n, npts, k = 3000, 40000, 10
+    c = rng.random((n, ndim))
+    v = np.sin(5 * c[:, 0]) + np.cos(3 * c[:, 1]) + 0.1 * rng.standard_normal(n)
+    pts = rng.random((npts, ndim))
+    pts[:4] = c[:4]  # exact hits
+    cls = pa.OrdinaryKriging if ndim == 2 else pa.OrdinaryKriging3D
+    outs = []
+    for sort in (1, 0):
+        m = cls(*[c[:, d] for d in range(ndim)], v, variogram_model="exponential", variogram_parameters=[1.0, 0.4, 0.02])
+        m._get_handle().set_option("sort_points", sort)
+        z, ss = m.execute("points", *[pts[:, d] for d in range(ndim)], backend="loop", n_closest_points=k)
+        assert m.last_timing["points_sorted"] == sort, m.last_timing
+        outs.append((np.asarray(z).copy(), np.asarray(ss).copy()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    st = ko.KrigingState(ndim=ndim, coords_orig=c, values=v, model="exponential", params=ko.internal_parameters("exponential", [1.0, 0.4, 0.02]),
+                         scaling=[1.0] * (ndim - 1), angle=[0.0] * (2 * ndim - 3))
+    sel = np.concatenate([np.arange(8), rng.choice(npts, 300, replace=False)])
+    zr, sr = ko.solve_points_moving_window(st, ko.adjust_for_anisotropy(pts[sel].copy(), st.center, st.scaling, st.angle), k)
+    np.testing.assert_allclose(outs[0][0][sel], zr, rtol=0, atol=1e-8)
+    np.testing.assert_allclose(outs[0][1][sel], sr, rtol=0, atol=1e-6)
+
+
 @pytest.mark.parametrize("k", [24, 40, 56, 72, 84, 92, 100, 104, 110, 124, 140, 156, 170, 188, 204, 220, 250])
 def test_moving_window_every_register_class_against_the_oracle(k):
     """One window size per class {G, RI} of the LDL^T kernel (mikrige.hip::dispatch_mw_chol): {8,4} .. {8,13} on one wavefront,
