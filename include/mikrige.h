@@ -193,8 +193,9 @@ int  mik_slab_of(int64_t n, int members, int i, int64_t *lo, int64_t *count); /*
  *   Hilbert-curve order among themselves on the device (k_ps_*: 20-bit keys, stable two-pass radix sort, all launches' segments
  *   side by side) and kriged in that order -- a block of 128 consecutive points is then a compact patch whatever order the caller's
  *   list or grid is in (a shuffled list, a row of a 3-D grid), and the contraction's cost grows with the square of the stations in
- *   range of a block.  z and sigma^2 come back in the caller's order.  -1 (default) = 1 = on with the range-aware contraction,
- *   0 = off [MIK_SORT_POINTS] ;
+ *   range of a block.  z and sigma^2 come back in the caller's order.  -1 (default) = on with the range-aware contraction from 4096 points and
+ *   512 matrix rows on (below that the seven sort launches cost more than they save), 1 = always, 0 = off.  With the sort on, sigma^2
+ *   of the range-aware path depends to rounding (~1e-13) on how the points are cut into launches and slabs [MIK_SORT_POINTS] ;
  * "sparse_lanes" 1/2 = range-aware contraction: its launches alternate between two lanes (two streams, two sets of work buffers and
  *   right-hand-side panels), so that the candidate / right-hand-side / list kernels of a launch and the tail of the previous
  *   launch's tile queue overlap.  Measured 2 % faster at config 5 for a second right-hand-side panel: default 1 = one launch after

@@ -264,6 +264,28 @@ def test_sorted_points_make_any_point_order_compact(ndim):
 
 
 @pytest.mark.gpu
+def test_sorted_points_on_degenerate_point_lists():
+    """The device sort of the points (k_ps_*) on lists it has little to work with: one point, 63 / 129 points (below and just above one
+    block), all points identical (no extent: every key is 0, the stable sort is the identity), points on a line, a launch size of 128.
+    Same answers as the dense contraction of the same library."""
+    import pykrige_amd as pa
+
+    rng = np.random.default_rng(41)
+    (x, y), v = fx.synth(12, 700, 2)
+    m = pa.OrdinaryKriging(x, y, v, variogram_model="spherical", variogram_parameters=[1.0, 0.2, 0.01])
+    lists = {"one": (np.array([0.4]), np.array([0.6])), "63": (rng.random(63), rng.random(63)), "129": (rng.random(129), rng.random(129)),
+             "identical": (np.full(300, 0.37), np.full(300, 0.52)), "line": (rng.random(500), np.full(500, 0.25)),
+             "station": (np.full(200, x[3]), np.full(200, y[3]))}
+    for name, pts in lists.items():
+        zd, sd, td = _run(m, "points", list(pts), 0)
+        for chunk in (131072, 128):
+            m._get_handle().set_option("sort_points", 1)
+            zs, ss, ts = _run(m, "points", list(pts), 1, chunk=chunk)
+            assert ts["sparse"] == 1 and ts["points_sorted"] == 1, (name, ts)
+            assert np.abs(zs - zd).max() <= Z_TOL and np.abs(ss - sd).max() <= SS_TOL, (name, chunk, np.abs(zs - zd).max(), np.abs(ss - sd).max())
+
+
+@pytest.mark.gpu
 def test_sparse_factor_is_handed_out_in_the_callers_order():
     """mik_get_matrix(1) un-permutes the Hilbert-ordered factor: equal to the dense path's inverse and to LAPACK's."""
     from tests.test_hip_parity import _handle_for
