@@ -5,6 +5,9 @@
 //   K3a k_rhs                 right-hand sides b_g for a chunk of points (+ z_g = c.b_g), written point-major
 //   K3b k_contract            sigma^2_g = -b_g^T A_inv b_g as a dense contraction on v_mfma_f64_4x4x4_4b_f64
 //       (k_contract_valu: the same contraction on v_fma_f64, kept as an independent second engine)
+//       compact-support (spherical) variogram: k_rhs<.., SP> writes delta = b + s u, k_sp_cand / k_sp_lists_g / k_sp_tiles_g build the
+//       lists of active K tiles and the tile records, k_contract_spg contracts tiles of eight gathered 16-row groups (k_contract_sp:
+//       aligned 128-row blocks), k_ps_* put the points of every launch in Hilbert-curve order (device radix sort)
 //   gemm_core                 the shared MFMA tile loop: LDS-DMA staging, XOR-swizzled LDS, ds_read_b128 fragments
 //   k_mw_knn, k_mw_solve      moving-window kriging (n_closest_points)
 //   k_stat_*                  variogram-fit statistics (bordered-inverse recursion)
