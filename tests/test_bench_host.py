@@ -134,7 +134,7 @@ def test_other_configs_key_set_and_trial_flags_are_pinned():
     for field in ('"value"', '"ms_per_step"', '"roofline"', '"max_abs_dz"', '"max_abs_dss"', '"parity_source"'):
         assert field in src[src.index("def other_config_line"):src.index("MW_KERNELS = {")]
     assert 'out["other_configs"]' in src
-    for flag in ("--no-trials", "--pretrial-budget", "--no-other", "--sparse", "MIK_BENCH_TRIALS"):
+    for flag in ("--no-trials", "--pretrial-budget", "--no-other", "--sparse", "--sparse-rows", "--sort-points", "--sparse-lanes", "MIK_BENCH_TRIALS"):
         assert flag in src
     # the stored slabs those checks read exist and are the configs' own
     for cno, n in ((3, 2000), (4, 4000), (5, 8000)):
