@@ -268,6 +268,9 @@ struct mik_handle {
   DevBuf ps_key[2], ps_idx[2], ps_table, ps_box, ps_x, ps_y, ps_z, ps_zs, ps_sss;
   bool ps_valid = false;     // ps_idx[0] holds the order of the resident points for launches of ps_chunk points
   long ps_chunk = 0;
+  int opt_sparse_epi = 0;    // "sparse_epilogue": k_contract_spg forms a group's term of the quadratic form from global memory after the K loop (0,
+                             // default) or from the B tile in LDS at the group's own K step (1: no operand reads in the epilogue -- measured 1.7 %
+                             // SLOWER at config 5, 43.1 against 42.4 ms of contraction: the extra registers of the triangle loop cost more)
   int opt_sparse_rows = -1;  // "sparse_rows": 16 = tiles of gathered 16-row groups (k_contract_spg), 128 = aligned row blocks (k_contract_sp),
                              // -1 = auto: 16 wherever 32-bit offsets address the inverse (Mp * Mp * 8 < 2^32)
   // second set (with Bt2): the launches of the range-aware contraction alternate between two lanes on two streams, so that the
@@ -865,6 +868,8 @@ static int create_one_body(mik_handle* h, int device) {
   if (env && atoi(env) >= -1 && atoi(env) <= 2) h->opt_sparse = atoi(env);
   env = getenv("MIK_SORT_POINTS");
   if (env && atoi(env) >= -1 && atoi(env) <= 1) h->opt_sort_points = atoi(env);
+  env = getenv("MIK_SPARSE_EPILOGUE");
+  if (env) h->opt_sparse_epi = atoi(env) ? 1 : 0;
   env = getenv("MIK_SPARSE_ROWS");
   if (env && (atoi(env) == -1 || atoi(env) == 16 || atoi(env) == 128)) h->opt_sparse_rows = atoi(env);
   env = getenv("MIK_UPDATE_ATOMIC");
@@ -1004,7 +1009,7 @@ static int set_group(mik_handle* h, int n) {
     k->opt_factor = h->opt_factor, k->opt_sym = h->opt_sym, k->opt_engine = h->opt_engine, k->opt_waves = h->opt_waves;
     k->opt_chunk = h->opt_chunk, k->opt_symsweep = h->opt_symsweep, k->opt_diag = h->opt_diag, k->opt_update_waves = h->opt_update_waves, k->opt_panel_rows = h->opt_panel_rows, k->opt_panel_stream = h->opt_panel_stream, k->opt_update_map = h->opt_update_map, k->opt_update_rev = h->opt_update_rev, k->opt_update_atomic = h->opt_update_atomic, k->opt_lookahead = h->opt_lookahead, k->opt_gate = h->opt_gate, k->opt_fuse_chain = h->opt_fuse_chain, k->opt_early_diag = h->opt_early_diag, k->opt_pinv_fast = h->opt_pinv_fast, k->opt_rhs_overlap = h->opt_rhs_overlap, k->opt_verify = h->opt_verify, k->verify_tol_z = h->verify_tol_z, k->verify_tol_inv = h->verify_tol_inv;
     k->opt_mw_class = h->opt_mw_class, k->opt_mw_knn_bound = h->opt_mw_knn_bound, k->opt_mw_pivot = h->opt_mw_pivot, k->opt_mw_lds_cap = h->opt_mw_lds_cap, k->opt_pairs = h->opt_pairs, k->opt_tri = h->opt_tri, k->opt_prefetch = h->opt_prefetch, k->opt_symmetrize = h->opt_symmetrize, k->opt_mw_solver = h->opt_mw_solver;
-    k->opt_sparse = h->opt_sparse, k->opt_sparse_lanes = h->opt_sparse_lanes, k->opt_sparse_rows = h->opt_sparse_rows, k->opt_sort_points = h->opt_sort_points, k->opt_drift_eq = h->opt_drift_eq;
+    k->opt_sparse = h->opt_sparse, k->opt_sparse_lanes = h->opt_sparse_lanes, k->opt_sparse_rows = h->opt_sparse_rows, k->opt_sparse_epi = h->opt_sparse_epi, k->opt_sort_points = h->opt_sort_points, k->opt_drift_eq = h->opt_drift_eq;
     k->custom_fn = h->custom_fn, k->custom_user = h->custom_user;
     h->kids.push_back(k);
   }
@@ -1091,6 +1096,8 @@ int mik_set_option(mik_handle* h, const char* key, double value) {
   } else if (!strcmp(key, "sort_points")) {
     if (value != -1.0 && value != 0.0 && value != 1.0) return fail(MIK_EINVAL, "sort_points must be -1 (auto), 0 or 1");
     h->opt_sort_points = (int)value;
+  } else if (!strcmp(key, "sparse_epilogue")) {
+    h->opt_sparse_epi = value != 0.0;
   } else if (!strcmp(key, "sparse_rows")) {
     if (value != -1.0 && value != 16.0 && value != 128.0) return fail(MIK_EINVAL, "sparse_rows must be -1 (auto), 16 or 128");
     h->opt_sparse_rows = (int)value;
@@ -3541,7 +3548,8 @@ static int one_predict(mik_handle* h) {
         ga.recs = ln.recs->as<uint4>();
         ga.xoff = sa.xoff;
         ga.queue = sa.queue;
-        hipLaunchKernelGGL((k_contract_spg<2>), dim3((unsigned)std::min<long>(2L * h->n_cu, (long)nTb * nIblk)), dim3(512), 0, sc, ga);
+        if (h->opt_sparse_epi) hipLaunchKernelGGL((k_contract_spg<2, true>), dim3((unsigned)std::min<long>(2L * h->n_cu, (long)nTb * nIblk)), dim3(512), 0, sc, ga);
+        else hipLaunchKernelGGL((k_contract_spg<2, false>), dim3((unsigned)std::min<long>(2L * h->n_cu, (long)nTb * nIblk)), dim3(512), 0, sc, ga);
       } else {
         hipLaunchKernelGGL((k_contract_sp<2>), dim3((unsigned)std::min<long>(2L * h->n_cu, (long)nTb * nIblk)), dim3(512), 0, sc, sa);
       }

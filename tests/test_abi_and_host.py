@@ -423,8 +423,9 @@ def test_kernel_register_budgets_of_the_built_library():
     assert k["vgpr_count"] <= 128 and k["agpr_count"] == 0 and k["private_segment_fixed_size"] <= 64 and k["group_segment_fixed_size"] <= 65544, k
     # the range-aware contraction over gathered row groups (round 4, second session): the same budget, and no scratch beyond the queue's
     # steal path (a scratch access inside its K loops makes hipcc wait for vmcnt(0) right behind the step's DMA: no overlap at all)
-    k = one(r"_ZN3mik14k_contract_spgILi2EEEvNS_7SpgArgsE")
-    assert k["vgpr_count"] <= 128 and k["agpr_count"] == 0 and k["private_segment_fixed_size"] <= 32 and k["group_segment_fixed_size"] <= 65700, k
+    for epi in (1, 0):
+        k = one(r"_ZN3mik14k_contract_spgILi2ELb%dEEEvNS_7SpgArgsE" % epi)
+        assert k["vgpr_count"] <= 128 and k["agpr_count"] == 0 and k["private_segment_fixed_size"] <= 32 and k["group_segment_fixed_size"] <= 65700, k
     for sym in (0, 1):
         k = one(r"_ZN3mik8k_updateILb%dELi2EEEv.*" % sym)
         assert k["vgpr_count"] <= 128 and k["agpr_count"] == 0 and k["private_segment_fixed_size"] == 0, k
