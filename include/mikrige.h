@@ -189,6 +189,8 @@ int  mik_slab_of(int64_t n, int members, int i, int64_t *lo, int64_t *count); /*
  *   [8r, 8r + 8) as rows, the entries beyond as K tiles, then its own groups as a triangle) or an ALIGNED block of 128 rows that is
  *   contracted whole when any of its eight groups is active (128: k_contract_sp; active blocks are ~79 % full at BASELINE config
  *   5).  -1 (default) = 16 wherever 32-bit DMA offsets reach every row (Mp <= 23168), else 128 [MIK_SPARSE_ROWS] ;
+ * "sparse_group" 1..16 = k_contract_spg's queue order: point blocks per group (a group's tiles run on one XCD, tile position ascending
+ *   = longest K loops first, point block fast; default 4) [MIK_SPARSE_GROUP] ;
  * "sparse_epilogue" 0/1 = k_contract_spg: a group's term of delta^T A_inv delta is formed from global memory after the K loop (0, default)
  *   or at the K step of the group's own 16 x 16 square, where its accumulators are final and the delta of its rows is that step's
  *   B tile in LDS (1: no operand reads in the epilogue; measured 1.7 % slower at BASELINE config 5) [MIK_SPARSE_EPILOGUE] ;

@@ -1703,18 +1703,19 @@ __global__ void __launch_bounds__(64) k_sp_lists_g(const unsigned char* __restri
 __global__ void __launch_bounds__(1024) k_sp_tiles_g(const int* __restrict__ ntiles, const int* __restrict__ kcount,
                                                      const unsigned short* __restrict__ klist, int nK16, int nTblk,
                                                      uint4* __restrict__ recs, int* __restrict__ xoff,
-                                                     unsigned long long* __restrict__ stats) {
-  __shared__ int gcnt[1024 / MIK_ST + 1], goff[1024 / MIK_ST + 1], xtot[9];
+                                                     unsigned long long* __restrict__ stats, int st) {
+  // st = point blocks per group (option "sparse_group", 1 .. 16; 4 by default = MIK_ST)
+  __shared__ int gcnt[1024 + 1], goff[1024 + 1], xtot[9];
   __shared__ unsigned long long ksum, dsum;
-  const int nG = (nTblk + MIK_ST - 1) / MIK_ST;
+  const int nG = (nTblk + st - 1) / st;
   const int g = threadIdx.x;
   if (g == 0) ksum = 0ULL, dsum = 0ULL;
   __syncthreads();
   if (g < nG) {
     int c = 0;
     unsigned long long ks = 0ULL, ds = 0ULL;
-    for (int q = 0; q < MIK_ST; ++q) {
-      const int tb = g * MIK_ST + q;
+    for (int q = 0; q < st; ++q) {
+      const int tb = g * st + q;
       if (tb >= nTblk) break;
       const int nk = kcount[tb], full = nk / 8, rem = nk - 8 * full;
       c += ntiles[tb];
@@ -1750,13 +1751,13 @@ __global__ void __launch_bounds__(1024) k_sp_tiles_g(const int* __restrict__ nti
   __syncthreads();
   const int tb = threadIdx.x;  // one thread per point block writes that block's records
   if (tb < nTblk) {
-    const int gg = tb / MIK_ST, q = tb % MIK_ST;
+    const int gg = tb / st, q = tb % st;
     int xbase = 0;
     for (int x = 0; x < (gg & 7); ++x) xbase += xtot[x];
-    int nr[MIK_ST];
-    for (int qq = 0; qq < MIK_ST; ++qq) {
-      const int t2 = gg * MIK_ST + qq;
-      nr[qq] = t2 < nTblk ? ntiles[t2] : 0;
+    int nr[16];
+    for (int qq = 0; qq < 16; ++qq) {
+      const int t2 = gg * st + qq;
+      nr[qq] = (qq < st && t2 < nTblk) ? ntiles[t2] : 0;
     }
     const int nk = kcount[tb];
     const unsigned short* kl = klist + (long)tb * nK16;
@@ -1764,7 +1765,7 @@ __global__ void __launch_bounds__(1024) k_sp_tiles_g(const int* __restrict__ nti
     int w = xbase + goff[gg];
     for (int r = 0; r < nr[q]; ++r) {  // (tiles of the other point blocks beyond nr[q] lie behind this block's last one or belong to them)
       int before = 0, all = 0;
-      for (int qq = 0; qq < MIK_ST; ++qq) {
+      for (int qq = 0; qq < 16; ++qq) {
         const int on = nr[qq] > r ? 1 : 0;
         all += on;
         if (qq < q) before += on;

@@ -268,6 +268,8 @@ struct mik_handle {
   DevBuf ps_key[2], ps_idx[2], ps_table, ps_box, ps_x, ps_y, ps_z, ps_zs, ps_sss;
   bool ps_valid = false;     // ps_idx[0] holds the order of the resident points for launches of ps_chunk points
   long ps_chunk = 0;
+  int opt_sparse_group = 4;  // "sparse_group": point blocks per group of k_sp_tiles_g's queue order (a group's tiles run on one XCD, tile position
+                             // ascending, point block fast): 1 .. 16
   int opt_sparse_epi = 0;    // "sparse_epilogue": k_contract_spg forms a group's term of the quadratic form from global memory after the K loop (0,
                              // default) or from the B tile in LDS at the group's own K step (1: no operand reads in the epilogue -- measured 1.7 %
                              // SLOWER at config 5, 43.1 against 42.4 ms of contraction: the extra registers of the triangle loop cost more)
@@ -868,6 +870,8 @@ static int create_one_body(mik_handle* h, int device) {
   if (env && atoi(env) >= -1 && atoi(env) <= 2) h->opt_sparse = atoi(env);
   env = getenv("MIK_SORT_POINTS");
   if (env && atoi(env) >= -1 && atoi(env) <= 1) h->opt_sort_points = atoi(env);
+  env = getenv("MIK_SPARSE_GROUP");
+  if (env && atoi(env) >= 1 && atoi(env) <= 16) h->opt_sparse_group = atoi(env);
   env = getenv("MIK_SPARSE_EPILOGUE");
   if (env) h->opt_sparse_epi = atoi(env) ? 1 : 0;
   env = getenv("MIK_SPARSE_ROWS");
@@ -1009,7 +1013,7 @@ static int set_group(mik_handle* h, int n) {
     k->opt_factor = h->opt_factor, k->opt_sym = h->opt_sym, k->opt_engine = h->opt_engine, k->opt_waves = h->opt_waves;
     k->opt_chunk = h->opt_chunk, k->opt_symsweep = h->opt_symsweep, k->opt_diag = h->opt_diag, k->opt_update_waves = h->opt_update_waves, k->opt_panel_rows = h->opt_panel_rows, k->opt_panel_stream = h->opt_panel_stream, k->opt_update_map = h->opt_update_map, k->opt_update_rev = h->opt_update_rev, k->opt_update_atomic = h->opt_update_atomic, k->opt_lookahead = h->opt_lookahead, k->opt_gate = h->opt_gate, k->opt_fuse_chain = h->opt_fuse_chain, k->opt_early_diag = h->opt_early_diag, k->opt_pinv_fast = h->opt_pinv_fast, k->opt_rhs_overlap = h->opt_rhs_overlap, k->opt_verify = h->opt_verify, k->verify_tol_z = h->verify_tol_z, k->verify_tol_inv = h->verify_tol_inv;
     k->opt_mw_class = h->opt_mw_class, k->opt_mw_knn_bound = h->opt_mw_knn_bound, k->opt_mw_pivot = h->opt_mw_pivot, k->opt_mw_lds_cap = h->opt_mw_lds_cap, k->opt_pairs = h->opt_pairs, k->opt_tri = h->opt_tri, k->opt_prefetch = h->opt_prefetch, k->opt_symmetrize = h->opt_symmetrize, k->opt_mw_solver = h->opt_mw_solver;
-    k->opt_sparse = h->opt_sparse, k->opt_sparse_lanes = h->opt_sparse_lanes, k->opt_sparse_rows = h->opt_sparse_rows, k->opt_sparse_epi = h->opt_sparse_epi, k->opt_sort_points = h->opt_sort_points, k->opt_drift_eq = h->opt_drift_eq;
+    k->opt_sparse = h->opt_sparse, k->opt_sparse_lanes = h->opt_sparse_lanes, k->opt_sparse_rows = h->opt_sparse_rows, k->opt_sparse_epi = h->opt_sparse_epi, k->opt_sparse_group = h->opt_sparse_group, k->opt_sort_points = h->opt_sort_points, k->opt_drift_eq = h->opt_drift_eq;
     k->custom_fn = h->custom_fn, k->custom_user = h->custom_user;
     h->kids.push_back(k);
   }
@@ -1096,6 +1100,9 @@ int mik_set_option(mik_handle* h, const char* key, double value) {
   } else if (!strcmp(key, "sort_points")) {
     if (value != -1.0 && value != 0.0 && value != 1.0) return fail(MIK_EINVAL, "sort_points must be -1 (auto), 0 or 1");
     h->opt_sort_points = (int)value;
+  } else if (!strcmp(key, "sparse_group")) {
+    if (!(value >= 1.0 && value <= 16.0)) return fail(MIK_EINVAL, "sparse_group must be 1 .. 16");
+    h->opt_sparse_group = (int)value;
   } else if (!strcmp(key, "sparse_epilogue")) {
     h->opt_sparse_epi = value != 0.0;
   } else if (!strcmp(key, "sparse_rows")) {
@@ -3506,7 +3513,7 @@ static int one_predict(mik_handle* h) {
                            ln.klist->as<unsigned short>(), ln.kcount->as<int>(), ln.nrows->as<int>());
         hipLaunchKernelGGL(k_sp_tiles_g, dim3(1), dim3(1024), 0, sc, (const int*)ln.nrows->as<int>(), (const int*)ln.kcount->as<int>(),
                            (const unsigned short*)ln.klist->as<unsigned short>(), nK16, nTb, ln.recs->as<uint4>(), ln.xoff->as<int>(),
-                           h->sp_stats.as<unsigned long long>() + 4 * c);
+                           h->sp_stats.as<unsigned long long>() + 4 * c, h->opt_sparse_group);
       } else {
         hipLaunchKernelGGL(k_sp_lists, dim3(nTb), dim3(64), 0, sc, (const unsigned char*)ln.flags->as<unsigned char>(), nK16, nIblk,
                            ln.klist->as<unsigned short>(), ln.kcount->as<int>(), ln.rows->as<unsigned short>(),
