@@ -125,6 +125,53 @@ def test_gathered_row_groups_reproduce_the_quadratic_form():
         assert [slots[i] for i in range(len(order))] == order, nr
 
 
+def test_point_sort_restated_in_numpy():
+    """The device sort of the points (k_ps_hist / k_ps_scan / k_ps_scatter), restated: per launch segment, two passes of a stable counting
+    sort over 10-bit digits -- digit counts per block of 4096 keys, exclusive scan digit-major / block-minor, every (wavefront = 1024
+    consecutive keys, digit) gets a base, keys take ranks in index order.  Result = a stable argsort of the 20-bit keys inside every
+    segment, whatever the segment length (no multiple of the block size, shorter than a block, a single key).  The keys themselves:
+    the stations' Hilbert key on a 10-bit lattice -- a walk whose consecutive lattice points are neighbours."""
+    rng = np.random.default_rng(8)
+    DB, TILE = 10, 4096
+
+    def radix_pass(key, idx, chunk, shift):
+        npt = key.size
+        kout, iout = np.empty_like(key), np.empty_like(idx)
+        for seg in range((npt + chunk - 1) // chunk):
+            lo, hi = seg * chunk, min(npt, (seg + 1) * chunk)
+            bps = (chunk + TILE - 1) // TILE
+            dig = (key[lo:hi] >> shift) & ((1 << DB) - 1)
+            table = np.zeros((1 << DB, bps), dtype=np.int64)
+            for b in range(bps):
+                blk = dig[b * TILE:(b + 1) * TILE]
+                table[:, b] = np.bincount(blk, minlength=1 << DB)
+            base = np.concatenate([[0], np.cumsum(table.ravel())[:-1]]).reshape(table.shape)  # digit major, block minor
+            for b in range(bps):
+                run = base[:, b].copy()
+                for w0 in range(b * TILE, min((b + 1) * TILE, hi - lo), 1024):  # a wavefront's 1024 keys, 64 at a time = index order
+                    for t in range(w0, min(w0 + 1024, (b + 1) * TILE, hi - lo)):
+                        d = dig[t]
+                        kout[lo + run[d]], iout[lo + run[d]] = key[lo + t], idx[lo + t]
+                        run[d] += 1
+        return kout, iout
+
+    for npt, chunk in ((10000, 4096 + 128), (3000, 131072), (1, 128), (9000, 2048)):
+        key = rng.integers(0, 1 << 20, npt).astype(np.int64)
+        key[::7] = key[0]  # ties: stability matters
+        k1, i1 = radix_pass(key, np.arange(npt), chunk, 0)
+        k2, i2 = radix_pass(k1, i1, chunk, DB)
+        for seg in range((npt + chunk - 1) // chunk):
+            lo, hi = seg * chunk, min(npt, (seg + 1) * chunk)
+            want = lo + np.argsort(key[lo:hi], kind="stable")
+            assert np.array_equal(i2[lo:hi], want), (npt, chunk, seg)
+    from pykrige_amd import _lib
+
+    k = 32  # a 2^5 lattice inside the 10-bit one: consecutive points of the order are lattice neighbours
+    gx, gy = np.meshgrid(np.arange(k, dtype=float), np.arange(k, dtype=float))
+    o = _lib.station_order(gx.ravel(), gy.ravel())
+    assert np.all(np.abs(np.diff(gx.ravel()[o])) + np.abs(np.diff(gy.ravel()[o])) == 1.0)
+
+
 # ---------------------------------------------------------------------------------------------- GPU
 def _run(m, style, args, sparse, chunk=None, rows=None, **kw):
     h = m._get_handle()
@@ -261,6 +308,36 @@ def test_sorted_points_make_any_point_order_compact(ndim):
         mask = rng.random((axes[1].size, axes[0].size)) < 0.3
         z, ss, t = _run(m, "masked", axes, 1, mask=mask)
         assert np.abs(z - zg)[~mask].max() <= Z_TOL and np.abs(ss - sg)[~mask].max() <= SS_TOL
+
+
+@pytest.mark.gpu
+def test_sorted_points_carry_host_evaluated_drift_values():
+    """Specified and functional drift terms are evaluated on the host, one value per point in the caller's order (uk.py:949-979); the
+    sorted contraction reaches them through the permutation like the coordinates.  Sorted = unsorted = dense, 2-D and 3-D."""
+    import pykrige_amd as pa
+
+    rng = np.random.default_rng(57)
+    (x, y), v = fx.synth(21, 900, 2)
+    px, py = rng.random(6000), rng.random(6000)
+    m2 = pa.UniversalKriging(x, y, v, variogram_model="spherical", variogram_parameters=[1.0, 0.25, 0.02],
+                             drift_terms=["regional_linear", "specified", "functional"], specified_drift=[np.sin(3 * x) * y],
+                             functional_drift=[lambda a, b: a * b])
+    kw2 = dict(specified_drift_arrays=[np.sin(3 * px) * py])
+    (x3, y3, z3), v3 = fx.synth(22, 900, 3)
+    qx, qy, qz = rng.random(5000), rng.random(5000), rng.random(5000)
+    m3 = pa.UniversalKriging3D(x3, y3, z3, v3, variogram_model="spherical", variogram_parameters=[1.0, 0.4, 0.02],
+                               drift_terms=["specified"], specified_drift=[x3 * z3 + y3])
+    kw3 = dict(specified_drift_arrays=[qx * qz + qy])
+    for m, pts, kw in ((m2, [px, py], kw2), (m3, [qx, qy, qz], kw3)):
+        zd, sd, td = _run(m, "points", pts, 0, **kw)
+        out = {}
+        for sort in (0, 1):
+            m._get_handle().set_option("sort_points", sort)
+            zs, ss, ts = _run(m, "points", pts, 1, chunk=2048, **kw)
+            assert ts["sparse"] == 1 and ts["points_sorted"] == sort
+            assert np.abs(zs - zd).max() <= Z_TOL and np.abs(ss - sd).max() <= SS_TOL, (sort, np.abs(zs - zd).max(), np.abs(ss - sd).max())
+            out[sort] = (zs, ss)
+        assert np.array_equal(out[0][0], out[1][0])  # z is a per-point sum: the order of the points does not touch it
 
 
 @pytest.mark.gpu
