@@ -173,10 +173,11 @@ def test_point_sort_restated_in_numpy():
 
 
 # ---------------------------------------------------------------------------------------------- GPU
-def _run(m, style, args, sparse, chunk=None, rows=None, **kw):
+def _run(m, style, args, sparse, chunk=None, rows=None, lanes=1, **kw):
     h = m._get_handle()
     h.set_option("sparse", sparse)
     h.set_option("sparse_rows", -1 if rows is None else rows)
+    h.set_option("sparse_lanes", lanes)
     if chunk:
         h.set_option("chunk", chunk)
     z, ss = m.execute(style, *args, **kw)
@@ -244,6 +245,12 @@ def test_sparse_contraction_against_oracle_and_dense(case):
             t16 = ts
     # gathered groups never execute more than aligned blocks do: fewer or equal off-diagonal K tiles and triangle products
     assert t16["sparse_ktiles"] <= t128["sparse_ktiles"] and t16["sparse_diag_products"] <= t128["sparse_diag_products"], (t16, t128)
+    # two launch lanes (two streams, two sets of work buffers; the second lane waits for the sort of the points)
+    m._get_handle().set_option("sort_points", 1)
+    zs, ss, ts = _run(m, "grid", axes, 1, chunk=1024, lanes=2)
+    m._get_handle().set_option("sort_points", -1)
+    assert ts["sparse"] == 1 and ts["points_sorted"] == 1
+    assert np.abs(zs - zr).max() <= Z_TOL and np.abs(ss - sr).max() <= SS_TOL, (np.abs(zs - zr).max(), np.abs(ss - sr).max())
     if case == "ok2d_short_range":
         assert ts["sparse_tiles"] < 0.6 * ts["sparse_tiles_dense"], ts  # range 0.08 of the unit square: most tiles are skipped
     # Hilbert-ordered stations with the dense contraction (option 2): the order alone changes nothing beyond rounding
