@@ -23,6 +23,29 @@ from . import core
 from . import variogram_models
 
 
+class _Cols:
+    """The coordinate arrays of style='points' as they came (float64, one array per axis), behind the two-dimensional indexing the
+    rest of this module uses on an (n, d) point array: cols[:, k], cols[rows, k], cols[slice], cols.shape.  Nothing is copied: the
+    library reads the caller's arrays (it stages them in page-locked memory itself) -- the reference's np.array(..., copy=True)
+    (ok.py:872-873) protects arrays it goes on to modify; these are only read."""
+
+    __slots__ = ("cols", "shape")
+
+    def __init__(self, cols):
+        self.cols = list(cols)
+        self.shape = (self.cols[0].shape[0], len(self.cols))
+
+    def __getitem__(self, key):
+        if isinstance(key, tuple):
+            rows, k = key
+            return self.cols[k][rows]
+        return _Cols([c[key] for c in self.cols])
+
+    def __array__(self, dtype=None, copy=None):  # np.asarray(cols): the (n, d) array (a copy; nothing on the execute path asks for it)
+        a = np.stack(self.cols, axis=1)
+        return a if dtype is None else a.astype(dtype, copy=False)
+
+
 class _Pts:
     """The prediction points of one execute(): adjusted coordinate arrays (style='points', or a grid whose drift callables
     need the adjusted coordinates on the host), or a grid described by its axes and generated on the device (mik_set_grid:
@@ -478,24 +501,24 @@ class _KrigingBase:
 
     def _points_from(self, style, axes, mask, columns=False):
         """Reference meshgrid order and mask handling (ok.py:849-878; ok3d.py:841-876).  columns=True (style='points' whose
-        coordinates go to the device raw): the (n, d) array is laid out column by column, so that the three coordinate arrays
-        the C ABI takes are contiguous views of it (no second host copy of npt x d doubles)."""
+        coordinates go to the device raw): the coordinate arrays stay the caller's (_Cols: no host copy of npt x d doubles;
+        round 3 made one F-ordered copy, rounds 1-2 two copies)."""
         if style != "grid" and style != "masked" and style != "points":
             raise ValueError("style argument must be 'grid', 'points', or 'masked'")
         if style in ("grid", "masked"):
             axes, shape, mask = self._grid_from(style, axes, mask)
             pts = self._meshgrid(axes)
         else:
-            axes = [np.atleast_1d(np.squeeze(np.array(a, copy=True, dtype=np.float64))) for a in axes]
+            # columns (the coordinates go to the device as they are): no host copy at all -- views of the caller's arrays (_Cols)
+            axes = [np.atleast_1d(np.squeeze(np.asarray(a, dtype=np.float64) if columns else np.array(a, copy=True, dtype=np.float64)))
+                    for a in axes]
             sizes = [a.size for a in axes]
             if len(set(sizes)) != 1:
                 raise ValueError("xpoints and ypoints%s must have same dimensions when treated as listing "
                                  "discrete points." % (", zpoints" if self._ndim == 3 else ""))
             shape = (sizes[0],)
             if columns:
-                pts = np.empty((sizes[0], len(axes)), dtype=np.float64, order="F")
-                for k, a in enumerate(axes):
-                    pts[:, k] = a
+                pts = _Cols([a.reshape(-1) for a in axes])
             else:
                 pts = np.stack(axes, axis=1)
             mask = None
