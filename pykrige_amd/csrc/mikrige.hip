@@ -3794,7 +3794,9 @@ static int one_predict_mw(mik_handle* h, int n_closest) {
         npt >= 4096) {
       const double spacing = h->pts_extent / std::pow((double)npt, 1.0 / h->ndim);  // of a sorted list: a wavefront's 64 points are a patch
       if (12.0 * spacing <= 10.0 * h->grid.cell) {                                   // ~8 spacings across
-        const long schunk = std::min<long>(((npt + 127) / 128) * 128, 1L << 20);
+        // (segments of 131 072 points like the contraction's launches: the bounding box and the scan of a segment are ONE workgroup
+        // each -- a single 2^20-point segment spent 0.53 + 2 x 0.39 ms in them, eight segments side by side 0.2 ms in all)
+        const long schunk = std::min<long>(((npt + 127) / 128) * 128, 131072L);
         if (!(h->ps_valid && h->ps_chunk == schunk)) MIKC(sort_points(h, schunk, (npt + schunk - 1) / schunk));
         const size_t nbp = sizeof(double) * (size_t)npt;
         MIKC(h->ps_x.ensure(nbp));
