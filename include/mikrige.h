@@ -180,7 +180,7 @@ int  mik_slab_of(int64_t n, int members, int i, int64_t *lo, int64_t *count); /*
  *   beyond its range, variogram_models.py:56-70).  With u = [1_N; 0] and s = psill + nugget the right-hand side is b = -s u + delta,
  *   delta_k = s - gamma(d_k) = 0 for every station beyond the range, and because A e_last = u:  z = c . delta  and
  *   sigma^2 = 2 s - delta^T A_inv delta  exactly.  The stations are laid out along a Hilbert curve, K3a writes delta and flags the
- *   (128 points x 16 stations) tiles that hold a nonzero, K3b contracts only those (k_contract_sp).  -1 (default) = 1 = on for the
+ *   (128 points x 16 stations) tiles that hold a nonzero, K3b contracts only those (k_contract_spg; see "sparse_rows").  -1 (default) = 1 = on for the
  *   spherical model (not with pseudo_inv, a caller's a_inv or geographic coordinates: those run the dense contraction), 0 = off,
  *   2 = Hilbert-ordered stations with the dense contraction (A/B of the order alone).  Takes effect at the
  *   next mik_factor [MIK_SPARSE] ;
