@@ -441,6 +441,37 @@ def test_kernel_register_budgets_of_the_built_library():
             assert k["private_segment_fixed_size"] <= 260, ((g, ri, model), k)  # {16,14} spills 33 registers, the others at most a handful
 
 
+def test_point_lists_are_not_copied_on_the_host():
+    """style='points' with coordinates that go to the device raw: _prepare hands the library views of the caller's arrays (kriging._Cols:
+    the (n, d) indexing the module uses, no copy of npt x d doubles); a list or an int array is converted once; the host-adjusted route
+    (functional drift) still builds its own array."""
+    import pykrige_amd as pa
+    from pykrige_amd import kriging
+
+    rng = np.random.default_rng(2)
+    x, y, v = rng.random(30), rng.random(30), rng.random(30)
+    px, py = rng.random(1000), rng.random(1000)
+    ok = pa.OrdinaryKriging(x, y, v, variogram_model="linear", variogram_parameters=[1.0, 0.1])
+    P = ok._prepare("points", (px, py), None)
+    c = P.arrays
+    assert isinstance(c, kriging._Cols) and c.shape == (1000, 2) and P.raw
+    assert np.shares_memory(c[:, 0], px) and np.shares_memory(c[:, 1], py)
+    assert c[:, 0].flags["C_CONTIGUOUS"]
+    sub = c[100:300]
+    assert sub.shape == (200, 2) and np.shares_memory(sub[:, 1], py) and np.array_equal(sub[:, 1], py[100:300])
+    keep = rng.random(1000) < 0.5
+    assert np.array_equal(c[keep, 0], px[keep])
+    assert np.array_equal(np.asarray(c), np.stack((px, py), 1))
+    P2 = ok._prepare("points", (list(px[:5]), np.arange(5)), None)  # converted, same values
+    assert np.array_equal(P2.arrays[:, 0], px[:5]) and P2.arrays[:, 1].dtype == np.float64
+    with pytest.raises(ValueError):
+        ok._prepare("points", (px, py[:10]), None)
+    uk = pa.UniversalKriging(x, y, v, variogram_model="linear", variogram_parameters=[1.0, 0.1], drift_terms=["functional"],
+                             functional_drift=[lambda a, b: a + b])
+    P3 = uk._prepare("points", (px, py), None)
+    assert isinstance(P3.arrays, np.ndarray) and not P3.raw and not np.shares_memory(P3.arrays, px)
+
+
 def test_reference_private_core_helpers_and_their_known_answers():
     """pykrige_amd.core carries the reference's private host helpers under their own names (core.py:100, 120, 196, 379, 538, 582); the
     reference's tests of them hold known answers (test_core.py:184-376 variogram estimation, 2691-2747 great-circle code with
