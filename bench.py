@@ -457,6 +457,30 @@ def other_config_line(cno, window=None, steps=3, warmup=1):
     return line
 
 
+def compact_other(line):
+    """What of an other_configs line goes under config["other_configs"] (the driver's record keeps `config` in full)."""
+    roof = line.get("roofline") or {}
+    c = {"value": line.get("value"), "ms_per_step": line.get("ms_per_step"), "frac": roof.get("frac"), "kernel": roof.get("kernel"),
+         "max_abs_dz": line.get("max_abs_dz"), "max_abs_dss": line.get("max_abs_dss")}
+    inv = (line.get("phases_ms_per_step") or {}).get("invert")
+    if inv is not None:
+        c["invert_ms"] = inv
+    for k in ("error", "parity_error"):
+        if line.get(k):
+            c[k] = line[k]
+    return c
+
+
+def compact_multi_gpu(mg):
+    """config["multi_gpu"]: which exchange ran, on how many RCCL ranks, and what every device's prediction took."""
+    per = mg.get("per_device_predict_ms")
+    if per is None and mg.get("ranks"):
+        per = [r.get("predict_ms") for r in mg["ranks"]]
+    return {"rccl_ranks": mg.get("rccl_ranks"), "exchange_path": mg.get("exchange_path"), "per_device_predict_ms": per,
+            "exchange_ms": mg.get("exchange_ms"), "exchange_wait_ms": mg.get("exchange_wait_ms"),
+            "exchange_fallbacks": mg.get("exchange_fallbacks"), "exchange_note": mg.get("exchange_note")}
+
+
 MW_KERNELS = {1: "k_mw_chol", 2: "k_mw_solve", 3: "k_mw_solve_big", 4: "k_mw_chol_blocked"}
 FACTOR_PATHS = {1: "spd-shift block sweep", 2: "pivoted block gauss-jordan", 3: "caller-supplied inverse", 4: "device pseudo-inverse (jacobi)",
                 5: "deflated inverse (pseudo-inverse of duplicated stations)", 6: "deflated inverse (numerically found null space)"}
@@ -810,6 +834,7 @@ def main():
                "phases_ms_per_step": {"assemble": tsum["assemble_ms"] / K, "invert": tsum["invert_ms"] / K,
                                       "exchange": tsum["exchange_ms"] / K, "exchange_not_overlapped": tsum["exchange_wait_ms"] / K,
                                       "rhs": tsum["rhs_ms"] / K, "contract": tsum["contract_ms"] / K, "predict_total": tsum["predict_ms"] / K}}
+        config["phases_ms_per_step"] = dict(out["phases_ms_per_step"])  # (the driver's record keeps `config` in full)
         dev_ms = (tsum["assemble_ms"] + tsum["invert_ms"] + tsum["exchange_wait_ms"] + tsum["predict_ms"]) / K
         out["host_overhead"] = {"vs_device_phases_ms": dt / K * 1e3 - dev_ms,
                                 "what": "ms_per_step / frac (filled in below): execute() minus the `resident` step (mik_factor + mik_predict on "
@@ -831,6 +856,8 @@ def main():
         elif world > 1:
             allp = pg.all_gather_object({"rank": rank, "device": int(os.environ["MIK_DEVICE"]), "predict_ms": last.get("predict_ms")})
             out["multi_gpu"] = {"ranks": allp, "exchange_path": exchange, "rccl_ranks": world if exchange == "rccl_bcast" else 0}
+        if "multi_gpu" in out:
+            config["multi_gpu"] = compact_multi_gpu(out["multi_gpu"])
         # ---- roofline.traffic: live PMC passes over one step of this benchmark, else the committed profile (labelled)
         if n_gpus == 1 and not inner and args.pmc != "off":
             progress["stage"] = "live PMC passes (rocprofv3)"
@@ -918,6 +945,8 @@ def main():
                     out["other_configs"][key] = other_config_line(cno, win)
                 except Exception as e:  # noqa: BLE001
                     out["other_configs"][key] = {"value": None, "error": repr(e)[:300]}
+            # the driver's BENCH record keeps `config` verbatim but only the NAMES of other top-level keys: a compact copy goes there
+            config["other_configs"] = {key: compact_other(line) for key, line in out["other_configs"].items()}
         if n_gpus == 1 and not args.no_cpu and not inner:
             progress["stage"] = "cpu_baseline leg"
             try:

@@ -32,6 +32,12 @@
 extern "C" {
 #endif
 
+/* ABI version: bumped whenever the meaning of a field or an argument changes under an unchanged signature.
+ *   4 -> 5  mik_grid.cell_count == 0 is an EMPTY range (it used to mean "the whole grid", which is now -1): a caller that
+ *           zero-initialises mik_grid must set cell_count = -1.  mik_abi_version() returns the library's value; the Python
+ *           loader (pykrige_amd/_lib.py) refuses a library whose version differs from the header it was written against. */
+#define MIK_ABI_VERSION 5
+
 #define MIK_OK          0
 #define MIK_EINVAL     (-1) /* bad argument            -> Python ValueError                  */
 #define MIK_ESINGULAR  (-2) /* singular kriging matrix -> numpy.linalg.LinAlgError (what scipy.linalg.inv raises) */
@@ -154,6 +160,7 @@ typedef struct mik_timing {
 } mik_timing;
 
 int  mik_device_count(void);
+int  mik_abi_version(void); /* MIK_ABI_VERSION of the built library */
 int  mik_create(int device, mik_handle **out);
 void mik_destroy(mik_handle *h);
 
@@ -183,7 +190,10 @@ int  mik_slab_of(int64_t n, int members, int i, int64_t *lo, int64_t *count); /*
  *   (128 points x 16 stations) tiles that hold a nonzero, K3b contracts only those (k_contract_spg; see "sparse_rows").  -1 (default) = 1 = on for the
  *   spherical model (not with pseudo_inv, a caller's a_inv or geographic coordinates: those run the dense contraction), 0 = off,
  *   2 = Hilbert-ordered stations with the dense contraction (A/B of the order alone).  Takes effect at the
- *   next mik_factor [MIK_SPARSE] ;
+ *   next mik_factor [MIK_SPARSE].  REPRODUCIBILITY: the set of K tiles a point meets depends on the 128-point block it falls
+ *   into, so with this option on (with or without "sort_points") sigma^2 depends TO ROUNDING (~1e-13) on how the points are cut
+ *   into launches, slabs and device-group members; z does not.  "sparse" 0 is bit-identical across device counts
+ *   (tests/test_device_group.py::test_spherical_model_across_device_counts) ;
  * "sparse_rows" -1/16/128 = range-aware contraction: a tile's 128 rows of A_inv are eight GATHERED active 16-row groups of the point
  *   block's list (16: k_contract_spg -- the list of active K tiles is also the list of active row groups; tile r takes entries
  *   [8r, 8r + 8) as rows, the entries beyond as K tiles, then its own groups as a triangle) or an ALIGNED block of 128 rows that is

@@ -69,10 +69,12 @@ class MikTiming(C.Structure):
 
 
 _lib = None
+ABI_VERSION = 5  # include/mikrige.h MIK_ABI_VERSION
 
 # every entry point include/mikrige.h declares: name -> (restype, argtypes)
 SIGNATURES = {
     "mik_device_count": (C.c_int, []),
+    "mik_abi_version": (C.c_int, []),
     "mik_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "mik_destroy": (None, [C.c_void_p]),
     "mik_set_devices": (C.c_int, [C.c_int]),
@@ -128,6 +130,9 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    if lib.mik_abi_version() != ABI_VERSION:
+        raise ImportError("pykrige_amd: %s has ABI version %d, this package was written against %d -- rebuild it "
+                          "(`python -m pykrige_amd.build --force`)" % (LIB_PATH, lib.mik_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 

@@ -32,7 +32,11 @@ class _Cols:
     __slots__ = ("cols", "shape")
 
     def __init__(self, cols):
-        self.cols = list(cols)
+        self.cols = []
+        for c in cols:  # read-only VIEWS of the caller's arrays: an accidental in-place write raises instead of reaching user data
+            c = c.view()
+            c.flags.writeable = False
+            self.cols.append(c)
         self.shape = (self.cols[0].shape[0], len(self.cols))
 
     def __getitem__(self, key):
@@ -42,6 +46,8 @@ class _Cols:
         return _Cols([c[key] for c in self.cols])
 
     def __array__(self, dtype=None, copy=None):  # np.asarray(cols): the (n, d) array (a copy; nothing on the execute path asks for it)
+        if copy is False:  # NumPy 2 protocol: a caller that forbids copying cannot be served (the columns are separate arrays)
+            raise ValueError("the (n, d) array of a point list is always a copy")
         a = np.stack(self.cols, axis=1)
         return a if dtype is None else a.astype(dtype, copy=False)
 
@@ -60,7 +66,9 @@ class _Pts:
         self.npt = int(np.prod(shape))
 
     def load(self, h, ndim, cell_range=None, with_extra=True):
-        """H2D (arrays) or device-side generation (grid) of the points, optionally only cells [first, first + count)."""
+        """H2D (arrays) or device-side generation (grid) of the points, optionally only cells [first, first + count).  The library
+        stages host arrays synchronously (mik_set_points returns after its copy into page-locked memory): views of the caller's
+        arrays (_Cols) are not referenced after this call returns, and must not be if the upload ever becomes asynchronous."""
         extra = self.extra if with_extra else None
         if cell_range is None:
             mask = self.mask

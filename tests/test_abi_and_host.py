@@ -381,22 +381,26 @@ def _kernel_metadata():
     if not (os.path.exists(readelf) and os.path.exists(lib)):
         pytest.skip("needs the built library and ROCm's llvm-readelf")
     blob = open(lib, "rb").read()
-    at = blob.find(b"__CLANG_OFFLOAD_BUNDLE__")
+    elfs, at = [], blob.find(b"__CLANG_OFFLOAD_BUNDLE__")
     assert at >= 0
-    n = struct.unpack_from("<Q", blob, at + 24)[0]
-    off, elf = at + 32, None
-    for _ in range(n):
-        o, s, ts = struct.unpack_from("<QQQ", blob, off)
-        off += 24
-        triple = blob[off:off + ts].decode()
-        off += ts
-        if "gfx950" in triple:
-            elf = blob[at + o:at + o + s]
-    assert elf is not None and elf[:4] == b"\x7fELF", "no gfx950 code object in the library"
-    with tempfile.NamedTemporaryFile(suffix=".co") as f:
-        f.write(elf)
-        f.flush()
-        notes = subprocess.run([readelf, "--notes", f.name], capture_output=True, text=True, check=True).stdout
+    while at >= 0:  # one bundle per translation unit of the library (pykrige_amd/build.py)
+        n = struct.unpack_from("<Q", blob, at + 24)[0]
+        off = at + 32
+        for _ in range(n):
+            o, s, ts = struct.unpack_from("<QQQ", blob, off)
+            off += 24
+            triple = blob[off:off + ts].decode()
+            off += ts
+            if "gfx950" in triple:
+                elfs.append(blob[at + o:at + o + s])
+        at = blob.find(b"__CLANG_OFFLOAD_BUNDLE__", at + 24)
+    assert elfs and all(e[:4] == b"\x7fELF" for e in elfs), "no gfx950 code object in the library"
+    notes = ""
+    for elf in elfs:
+        with tempfile.NamedTemporaryFile(suffix=".co") as f:
+            f.write(elf)
+            f.flush()
+            notes += subprocess.run([readelf, "--notes", f.name], capture_output=True, text=True, check=True).stdout
     out = {}
     for block in notes.split("\n  - .agpr_count:")[1:]:
         block = ".agpr_count:" + block

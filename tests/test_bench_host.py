@@ -134,6 +134,18 @@ def test_other_configs_key_set_and_trial_flags_are_pinned():
     for field in ('"value"', '"ms_per_step"', '"roofline"', '"max_abs_dz"', '"max_abs_dss"', '"parity_source"'):
         assert field in src[src.index("def other_config_line"):src.index("MW_KERNELS = {")]
     assert 'out["other_configs"]' in src
+    # round 5: compact copies under `config`, the one object the driver's BENCH record keeps verbatim
+    assert 'config["other_configs"] = {key: compact_other(line)' in src and 'config["multi_gpu"] = compact_multi_gpu(' in src
+    line = {"value": 3.0e7, "ms_per_step": 500.0, "roofline": {"frac": 0.78, "kernel": "k_contract_spg"}, "max_abs_dz": 1e-11, "max_abs_dss": 2e-11,
+            "phases_ms_per_step": {"invert": 10.0}, "parity_source": "x"}
+    assert bench.compact_other(line) == {"value": 3.0e7, "ms_per_step": 500.0, "frac": 0.78, "kernel": "k_contract_spg", "max_abs_dz": 1e-11,
+                                         "max_abs_dss": 2e-11, "invert_ms": 10.0}
+    assert bench.compact_other({"value": None, "error": "boom"}) == {"value": None, "ms_per_step": None, "frac": None, "kernel": None,
+                                                                     "max_abs_dz": None, "max_abs_dss": None, "error": "boom"}
+    mg = bench.compact_multi_gpu({"ranks": [{"rank": 0, "predict_ms": 5.0}, {"rank": 1, "predict_ms": 6.0}], "exchange_path": "rccl_bcast", "rccl_ranks": 2})
+    assert mg["rccl_ranks"] == 2 and mg["exchange_path"] == "rccl_bcast" and mg["per_device_predict_ms"] == [5.0, 6.0]
+    mg = bench.compact_multi_gpu({"per_device_predict_ms": [1.0, 2.0], "exchange_path": "peer_scatter_allgather", "rccl_ranks": 0, "exchange_ms": 3.0})
+    assert set(mg) == {"rccl_ranks", "exchange_path", "per_device_predict_ms", "exchange_ms", "exchange_wait_ms", "exchange_fallbacks", "exchange_note"}
     for flag in ("--no-trials", "--pretrial-budget", "--no-other", "--sparse", "--sparse-rows", "--sort-points", "--sparse-lanes", "MIK_BENCH_TRIALS"):
         assert flag in src
     # the stored slabs those checks read exist and are the configs' own

@@ -198,3 +198,42 @@ def test_environment_variable_alone_makes_execute_multi_device():
         outs.append(r.stdout.strip().splitlines()[-1].split())
     assert outs[0][0] == "1" and outs[1][0] == "3"
     assert outs[0][1:] == outs[1][1:]  # bit-identical sums
+
+
+@pytest.mark.gpu
+def test_spherical_model_across_device_counts():
+    """The range-aware contraction (default for the spherical model, option `sparse`) forms sigma^2 over the K tiles within range of a
+    128-point block: how points fall into blocks and slabs changes the tile set, so sigma^2 depends on the device count TO ROUNDING
+    (documented in include/mikrige.h, option "sparse").  Pinned here: 1 vs 3 devices agree to 1e-12 by default, and bit for bit with
+    MIK_SPARSE=0 (the dense contraction)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "import pykrige_amd as pa\n"
+        "rng = np.random.default_rng(5); x, y, v = rng.random(300), rng.random(300), rng.random(300)\n"
+        "ok = pa.OrdinaryKriging(x, y, v, variogram_model='spherical', variogram_parameters=[1.0, 0.25, 0.05])\n"
+        "z, ss = ok.execute('grid', np.linspace(0, 1, 40), np.linspace(0, 1, 30), backend='loop')\n"
+        "np.save(sys.argv[1], np.stack([np.asarray(z).ravel(), np.asarray(ss).ravel()]))\n"
+        "print(ok.last_timing['n_devices'], ok.last_timing['sparse'])\n" % root)
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as tmp:
+        res = {}
+        for sparse in ("1", "0"):
+            for ndev in (1, 3):
+                env = dict(os.environ, MIK_SPARSE=sparse)
+                env.pop("MIK_NGPU", None)
+                if ndev > 1:
+                    env.update(MIK_NGPU=str(ndev), MIK_ALIAS_DEVICES="1")
+                out = os.path.join(tmp, "r_%s_%d.npy" % (sparse, ndev))
+                r = subprocess.run([sys.executable, "-c", script, out], capture_output=True, text=True, timeout=300, env=env)
+                assert r.returncode == 0, r.stderr[-500:]
+                assert r.stdout.strip().splitlines()[-1].split() == [str(ndev), sparse]
+                res[sparse, ndev] = np.load(out)
+        assert np.array_equal(res["0", 1], res["0", 3])  # dense contraction: bit-identical across device counts
+        assert np.array_equal(res["1", 1][0], res["1", 3][0])  # z does not go through the contraction
+        assert np.abs(res["1", 1][1] - res["1", 3][1]).max() <= 1e-12
+        assert np.abs(res["1", 1] - res["0", 1]).max() <= 1e-11
