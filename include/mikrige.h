@@ -260,6 +260,19 @@ int  mik_slab_of(int64_t n, int members, int i, int64_t *lo, int64_t *count); /*
  *   whole upper block triangle once per step (260 MB at N = 8000: more than the 256 MB memory-side cache holds); a cyclic stream
  *   leaves nothing behind in an LRU cache, a back-and-forth one most of it.  Same tiles, same bits; measured N = 8000 14.0 -> 13.45 ms, a
  *   tie at N <= 5000: -1 (default) = on from 45 block columns [MIK_UPDATE_REV] ;
+ * "update_deep" 0/1 = panel-stream sweep: the rest of every trailing update by k_update_deep -- one 16-wavefront block per CU, the
+ *   block's T tile loaded into registers BEFORE its K loop, operands through four LDS buffers with three K tiles in flight,
+ *   "update_tpb" tiles per block run as one pipeline.  Same K order and the same subtraction per entry: same bits.  Measured
+ *   SLOWER (N = 8000 13.5 -> 16.3 ms; profiles/r05_update_deep_ab.txt): default 0 [MIK_UPDATE_DEEP] ;
+ * "update_tpb" 0..64 = tiles per block of k_update_deep; 0 (default) = two rounds of blocks per step [MIK_UPDATE_TPB] ;
+ * "update_pf" 0/1 = half sweep: the rest of every trailing update on blocks of four wavefronts that take HALF tiles (64 x 128) and load
+ *   their part of T into registers before the K loop (k_update_w PF; same bits).  A tie in the 128-wide sweep, default 0 ;
+ * "pivot256" 0/1 = half sweep with pivot blocks of 256 columns (one read-modify-write of T per TWO block columns; the 256 x 256 diagonal
+ *   block by a Schur split over two runs of the 128-block kernel; equal to the 128-wide sweep to rounding).  Measured a tie at
+ *   N = 8000 and slower below (profiles/r05_wide_sweep_timeline.txt): opt-in, default off [MIK_PIVOT256] ;
+ * "wide_reserve" 0..128 = CUs (multiple of 8) the wide sweep's update stream leaves to the kernels of the next pivot's chain through a
+ *   CU mask (hipExtStreamCreateWithCUMask: bit i = CU i / 8 of XCD i % 8); default 16 ;
+ * "wide_colstream" 0/1 = wide sweep: the column part of an update on a stream of its own beside the rest (measured slower: 0) ;
  * "panel_stream" 0/1/-1 = early-diagonal sweep: the panel kernel and the update of the next block column (+ the diagonal tile
  *   after next) run on a third stream beside the rest of the previous step's trailing update, ordered by events only (default
  *   -1 = from 24 block columns on; same bits) [MIK_PANEL_STREAM] ;

@@ -343,6 +343,25 @@ struct mik_handle {
   // trailing update: tiles without a panel / diagonal copy go to memory as fp64 atomic adds (k_update atomic_rmw; same bits).
   // Measured SLOWER (N=5000 4.39 -> 4.84 ms, N=8000 13.98 -> 15.96 ms: the L2's fp64 atomic rate, not latency, is the bound): off.
   int opt_update_atomic = 0;
+  // "pivot256": half sweep with pivot blocks of 256 columns (run_block_inverse_wide; half the read-modify-write traffic of T per eliminated
+  // column).  Measured a TIE at N = 8000 (13.1 - 13.3 ms both: the K = 256 update is 338 us per pair against 2 x 201, but its column part and
+  // the 256 x 256 diagonal inverse eat the difference) and slower below (N = 5000: 5.4 - 6.3 against 4.3 ms: the chain is the step there):
+  // profiles/r05_wide_sweep_*.txt.  Opt-in: 1 = on wherever the half sweep runs, 0 / -1 (default) = off.
+  int opt_pivot256 = -1;
+  DevBuf Wide;            // its 256 x 256 diagonal inverses and 128 x 128 scratch blocks
+  int opt_wide_reserve = 16;  // "wide_reserve": CUs (a multiple of 8: the same number on every XCD) the wide sweep's update stream leaves to the chain's kernels (0 = none)
+  int opt_update_pf = 0;      // "update_pf": trailing update with its part of T in registers before the K loop (half tiles on four wavefronts, k_update_w PF;
+                              // same bits).  Measured a tie in the 128-wide sweep (N = 5000 4.25 / 4.22 ms, N = 8000 13.31 / 13.23) and -9 % .. -34 % of the
+                              // wide sweep below N = 5000, +11 % of its update at N = 8000: off
+  int opt_wide_colstream = 0; // "wide_colstream": 1 = the wide sweep's column part on a stream of its own beside the rest of the update (A/B)
+  hipStream_t stream_upd = nullptr;  // the wide sweep's update stream: created with a CU mask (hipExtStreamCreateWithCUMask)
+  int stream_upd_reserve = -1;
+  // round 5: the rest of every trailing update by k_update_deep (one 16-wave block per CU, T tile in registers before the K loop, four
+  // LDS stages, several tiles per block as one pipeline; same bits).  Measured SLOWER (profiles/r05_update_deep_ab.txt: N = 8000 13.5 ->
+  // 16.3 ms, N = 5000 4.3 -> 5.1 ms; tools/update_bench: 268 us per step against 197 -- the T loads are HBM misses, and because a
+  // wavefront's vector-memory operations retire in order the operand DMAs behind them cannot be waited for separately): off (0); 1 = on.
+  int opt_update_deep = 0;
+  int opt_update_tpb = 0;  // "update_tpb": tiles per block of k_update_deep (0 = auto: two rounds of blocks per step)
   int opt_panel_rows = 32;  // rows of the column panel one block of k_panel forms: 32 (round 3), 64 or 128 (one tile, the round-1 form)
   int opt_update_waves = 8; // trailing-update kernel of the block sweep: 4 waves (wave tile 64 x 64) or 8 (32 x 64, default since round 3:
                             // -5 % at N=5000 / 8000, same bits: profiles/r03_update_waves_ab.txt) per 128 x 128 tile

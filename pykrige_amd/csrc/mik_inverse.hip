@@ -206,6 +206,155 @@ static int update_tile_map(mik_handle* h, int nblk, bool sym, int sb) {
   return MIK_OK;
 }
 
+// WIDE half sweep (round 5, option "pivot256"): unpivoted block Gauss-Jordan on the upper block triangle with pivot blocks of 256
+// columns (kernels and the why: mik_k_inverse.h, k_update_w).  Look-ahead schedule on two streams, the pivot block as the step:
+//   s1:  column part of update K (the block columns / rows of pivot K + 1)  ->  rest of update K  ->  [panel K + 1 ready] ...
+//   s2:  [column part K done]  diagonal block K + 1 (256 x 256: Schur split over two 128-block inverses)  ->  column panel  ->  panel kernel
+// Two panel sets alternate.  An odd last block column is a 128-wide pivot through the same kernels.
+static int run_block_inverse_wide(mik_handle* h, int nspd, int* flag_out) {
+  const int Mp = h->Mp, nblk = Mp / 128;
+  const long ld = Mp;
+  const size_t panel = sizeof(double) * (size_t)Mp * 256, blk = sizeof(double) * 128 * 128;
+  MIKC(h->Cold.ensure(panel));
+  MIKC(h->Cnew.ensure(panel));
+  MIKC(h->Rt.ensure(panel));
+  MIKC(h->Cold2.ensure(panel));
+  MIKC(h->Cnew2.ensure(panel));
+  MIKC(h->Rt2.ensure(panel));
+  MIKC(h->Wide.ensure(4 * blk * 2 + 4 * blk + 7 * blk));  // two 256 x 256 inverses, X, and seven 128 x 128 scratch blocks
+  MIKC(h->flag.ensure(sizeof(int) * (size_t)MIK_F_INTS));
+  HIPC(hipMemsetAsync(h->flag.p, 0, sizeof(int) * (size_t)MIK_F_INTS, h->stream));
+  const int nK = (nblk + 1) / 2;
+  while (h->la_events.size() < 3 * (size_t)nK + 4) {
+    hipEvent_t e;
+    HIPC(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    h->la_events.push_back(e);
+  }
+  double* T = h->T.as<double>();
+  double* cold[2] = {h->Cold.as<double>(), h->Cold2.as<double>()};
+  double* cnew[2] = {h->Cnew.as<double>(), h->Cnew2.as<double>()};
+  double* rt[2] = {h->Rt.as<double>(), h->Rt2.as<double>()};
+  double* w = h->Wide.as<double>();
+  double* dinv[2] = {w, w + 4 * 128 * 128};
+  double* X = w + 8 * 128 * 128;
+  double* sc = w + 12 * 128 * 128;
+  double *ainv = sc, *ainvT = sc + 16384, *W = sc + 2 * 16384, *Wt = sc + 3 * 16384, *S = sc + 4 * 16384, *sinv = sc + 5 * 16384, *sinvT = sc + 6 * 16384;
+  h->last_half_sweep = true;
+  const bool rev_on = h->opt_update_rev < 0 ? nblk >= 45 : h->opt_update_rev != 0;
+  const long ltiles = (long)nblk * (nblk + 1) / 2;
+  const unsigned ug = (unsigned)(8 * ((ltiles + 7) / 8));
+  auto np_of = [&](int K) { return 2 * K + 1 < nblk ? 2 : 1; };
+  // The update stream runs under a CU MASK that leaves `wide_reserve` CUs (the top mask bits: bit i is CU i / 8 of XCD i % 8,
+  // tools/probe_cumask) to the chain's kernels: with the chip full of 128-VGPR update blocks nothing else is placed until a block
+  // retires, and every small kernel of the chain waited 10 - 150 us for its slots (profiles/r05_wide_sweep_timeline.txt).
+  const int reserve = std::max(0, std::min(h->n_cu / 2, h->opt_wide_reserve)) & ~7;
+  if (reserve > 0 && (!h->stream_upd || h->stream_upd_reserve != reserve)) {
+    if (h->stream_upd) (void)hipStreamDestroy(h->stream_upd);
+    h->stream_upd = nullptr;
+    std::vector<uint32_t> mask((size_t)(h->n_cu + 31) / 32, 0u);
+    for (int i = 0; i < h->n_cu - reserve; ++i) mask[(size_t)i / 32] |= 1u << (i % 32);
+    if (hipExtStreamCreateWithCUMask(&h->stream_upd, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+      (void)hipGetLastError();
+      h->stream_upd = nullptr;  // no masks on this runtime: the update runs on the handle's stream
+    }
+    h->stream_upd_reserve = reserve;
+  }
+  const bool masked = reserve > 0 && h->stream_upd != nullptr;
+  auto P = [](const double* A, int lda, const double* Bt, int ldb, double alpha, const double* D, int ldd, double* O, int ldo) {
+    return Mm128{A, lda, Bt, ldb, alpha, D, ldd, O, ldo};
+  };
+  auto mm1 = [&](hipStream_t st, const Mm128& a0) { hipLaunchKernelGGL(k_mm128s, dim3(64, 1), dim3(256), 0, st, a0, a0); };
+  auto mm2 = [&](hipStream_t st, const Mm128& a0, const Mm128& a1) { hipLaunchKernelGGL(k_mm128s, dim3(64, 2), dim3(256), 0, st, a0, a1); };
+  // the serial chain of a pivot: inverse of its diagonal block from T, [its column panel from T, unless the column part of the update before
+  // left it in cold[set]], the panel kernel
+  auto chain = [&](hipStream_t st, int K, int set, bool have_cold) -> int {
+    const int a = 2 * K, np = np_of(K), k0 = a * 128;
+    const bool own = st == h->stream2;  // (the diagonal inverse padded to a CU of its own, launch_diag_inv)
+    if (np == 1) {
+      launch_diag_inv(h, st, (const double*)T, ld, k0, nspd, dinv[set], ainvT, own);  // [128][128]; symmetric to rounding: used as its own transpose
+    } else {
+      hipLaunchKernelGGL(k_loadx256, dim3(16), dim3(256), 0, st, (const double*)T, ld, a, X);
+      // [A B; B^T C]^-1 with S = C - B^T A^-1 B:  X22 = S^-1,  X12 = -W S^-1 (W = A^-1 B),  X21 = X12^T,  X11 = A^-1 - X12 W^T
+      const double* xa = (const double*)((uintptr_t)X - sizeof(double) * ((size_t)k0 * 256 + (size_t)k0));  // the diagonal kernels index T[(k0 + r) ld + k0 + c]
+      launch_diag_inv(h, st, xa, 256L, k0, nspd, ainv, ainvT, own);
+      const double* Bt = X + 128 * 256;  // B^T (rows 128 .., columns 0 .. 127)
+      mm2(st, P(ainv, 128, Bt, 256, 1.0, nullptr, 0, W, 128),                 // W[i][n] = sum_m Ainv[i][m] B[m][n]
+          P(Bt, 256, ainvT, 128, 1.0, nullptr, 0, Wt, 128));                  // Wt = W^T
+      mm1(st, P(Bt, 256, Wt, 128, -1.0, X + 128 * 256 + 128, 256, S, 128));   // S = C - B^T W
+      const int k1 = k0 + 128;
+      const double* xs = (const double*)((uintptr_t)S - sizeof(double) * ((size_t)k1 * 128 + (size_t)k1));
+      double* D = dinv[set];
+      launch_diag_inv(h, st, xs, 128L, k1, nspd, sinv, sinvT, own);
+      mm2(st, P(W, 128, sinvT, 128, -1.0, nullptr, 0, D + 128, 256),          // X12 = -W S^-1
+          P(sinv, 128, W, 128, -1.0, nullptr, 0, D + 128 * 256, 256));        // X21 = -S^-1 W^T
+      mm2(st, P(D + 128, 256, W, 128, -1.0, ainv, 128, D, 256),               // X11 = A^-1 - X12 W^T
+          P(W, 128, W, 128, 0.0, sinv, 128, D + 128 * 256 + 128, 256));       // X22 = S^-1 (a copy: alpha = 0)
+    }
+    if (!have_cold) hipLaunchKernelGGL(k_copy_panel_w, dim3(Mp / 64, np), dim3(256), 0, st, (const double*)T, ld, a, np, cold[set]);
+    hipLaunchKernelGGL(k_panel_w, dim3(Mp / 32, np), dim3(256), 0, st, (const double*)cold[set], (const double*)dinv[set], np, -1.0, cnew[set], rt[set], k0);
+    return MIK_OK;
+  };
+  // three streams, events only:
+  //   s1 (CU mask):  [panel K]                         rest of update K                                   -> evR(K)
+  //   s3:            [panel K, rest K - 1]             column part of update K (leaves cold[set ^ 1])     -> evC(K)
+  //   s2:            [column part K]                   diagonal block K + 1, panel kernel K + 1           -> evP(K + 1)
+  hipStream_t s1 = masked ? h->stream_upd : h->stream, s2 = h->stream2, s3 = h->stream3;
+  const bool pf = h->opt_update_pf != 0;  // "update_pf": T loaded before the K loop, half tiles on four wavefronts (k_update_w PF)
+  auto evC = [&](int K) { return h->la_events[3 * K]; };
+  auto evP = [&](int K) { return h->la_events[3 * K + 1]; };
+  auto evR = [&](int K) { return h->la_events[3 * K + 2]; };
+  MIKC(chain(h->stream, 0, 0, false));
+  HIPC(hipEventRecord(evP(0), h->stream));
+  for (int K = 0; K < nK; ++K) {
+    const int set = K & 1, a = 2 * K, np = np_of(K);
+    const int rev = rev_on && (K & 1);
+    HIPC(hipStreamWaitEvent(s1, evP(K), 0));
+    if (K + 1 < nK) {
+      const int na = a + 2, nn = np_of(K + 1);
+      hipStream_t sc = h->opt_wide_colstream ? s3 : s1;  // "wide_colstream" 1: the column part beside the rest (measured slower: the rest's blocks fill the chip first)
+      if (sc == s3) {
+        HIPC(hipStreamWaitEvent(s3, evP(K), 0));
+        if (K > 0) HIPC(hipStreamWaitEvent(s3, evR(K - 1), 0));
+      }
+      if (pf)
+        hipLaunchKernelGGL((k_update_w<1, true>), dim3(2 * nn * nblk), dim3(256), 0, sc, T, ld, nblk, a, np, (const double*)cold[set], (const double*)cnew[set],
+                           (const double*)rt[set], (const double*)dinv[set], na, nn, 0, cold[set ^ 1]);
+      else
+        hipLaunchKernelGGL((k_update_w<1, false>), dim3(nn * nblk), dim3(512), 0, sc, T, ld, nblk, a, np, (const double*)cold[set], (const double*)cnew[set],
+                           (const double*)rt[set], (const double*)dinv[set], na, nn, 0, cold[set ^ 1]);
+      HIPC(hipEventRecord(evC(K), sc));
+      HIPC(hipStreamWaitEvent(s2, evC(K), 0));
+      MIKC(chain(s2, K + 1, set ^ 1, true));
+      HIPC(hipEventRecord(evP(K + 1), s2));
+      if (pf)
+        hipLaunchKernelGGL((k_update_w<2, true>), dim3(2 * ug), dim3(256), 0, s1, T, ld, nblk, a, np, (const double*)cold[set], (const double*)cnew[set],
+                           (const double*)rt[set], (const double*)dinv[set], na, nn, rev, (double*)nullptr);
+      else
+        hipLaunchKernelGGL((k_update_w<2, false>), dim3(ug), dim3(512), 0, s1, T, ld, nblk, a, np, (const double*)cold[set], (const double*)cnew[set],
+                           (const double*)rt[set], (const double*)dinv[set], na, nn, rev, (double*)nullptr);
+      HIPC(hipEventRecord(evR(K), s1));
+    } else {
+      if (pf)
+        hipLaunchKernelGGL((k_update_w<0, true>), dim3(2 * ug), dim3(256), 0, s1, T, ld, nblk, a, np, (const double*)cold[set], (const double*)cnew[set],
+                           (const double*)rt[set], (const double*)dinv[set], -8, 0, rev, (double*)nullptr);
+      else
+        hipLaunchKernelGGL((k_update_w<0, false>), dim3(ug), dim3(512), 0, s1, T, ld, nblk, a, np, (const double*)cold[set], (const double*)cnew[set],
+                           (const double*)rt[set], (const double*)dinv[set], -8, 0, rev, (double*)nullptr);
+    }
+  }
+  {
+    HIPC(hipEventRecord(evR(nK - 1), s1));
+    HIPC(hipStreamWaitEvent(h->stream, evR(nK - 1), 0));
+  }
+  hipLaunchKernelGGL(k_mirror_upper, dim3(Mp / 64, Mp / 64), dim3(256), 0, h->stream, T, ld, Mp / 64);
+  HIPC(hipGetLastError());
+  int flag = 0;
+  HIPC(hipMemcpyAsync(&flag, h->flag.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPC(hipStreamSynchronize(h->stream));
+  *flag_out = flag;
+  return MIK_OK;
+}
+
 // unpivoted (path 1) or pivoted (path 2) block Gauss-Jordan on T in place
 static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_out) {
   const int Mp = h->Mp, nblk = Mp / 128;
@@ -238,6 +387,8 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
   // full-size fixtures) and from 24 block columns on, where it pays
   const bool symsweep = !pivoted && (h->opt_symsweep > 0 || (h->opt_symsweep < 0 && !h->no_half_sweep && (h->model == 3 || h->model == 4) && nblk >= 24));
   h->last_half_sweep = symsweep;
+  // "pivot256" 1: the half sweep with 256-wide pivot blocks (opt-in: measured a tie at N = 8000, slower below)
+  if (symsweep && nblk >= 3 && h->opt_pivot256 > 0) return run_block_inverse_wide(h, nspd, flag_out);
   const long ltiles = symsweep ? (long)nblk * (nblk + 1) / 2 : tiles;
   const unsigned ug = (unsigned)(8 * ((ltiles + 7) / 8));
   const bool upd8 = h->opt_update_waves == 8;
@@ -371,6 +522,15 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
         auto evC = [&](int kb) { return h->ps_events[4 * kb + 2]; };  // column part of update kb done (s3)
         auto evR = [&](int kb) { return h->ps_events[4 * kb + 3]; };  // rest of update kb done (s1)
         hipStream_t s1 = h->stream, s2 = h->stream2, s3 = h->stream3;
+        // "update_deep" 1: the rest of every update by k_update_deep (off by default: measured slower); tiles per block: "update_tpb" (0 = auto: one round
+        // of blocks per step would hold every CU for the whole step and starve the chain's kernels, so two rounds)
+        const bool deep = h->opt_update_deep > 0 && !tmap && !(uatomic & 1);
+        const bool pf_rest = symsweep && h->opt_update_pf != 0 && !deep && !tmap && !(uatomic & 1);  // "update_pf"
+        const int deep_tpb = h->opt_update_tpb > 0 ? h->opt_update_tpb : (int)std::max<long>(1, (ltiles + 2 * h->n_cu - 1) / (2 * h->n_cu));
+        if (deep) {
+          (void)hipFuncSetAttribute((const void*)k_update_deep<true>, hipFuncAttributeMaxDynamicSharedMemorySize, MIK_UD_LDS_BYTES);
+          (void)hipFuncSetAttribute((const void*)k_update_deep<false>, hipFuncAttributeMaxDynamicSharedMemorySize, MIK_UD_LDS_BYTES);
+        }
         HIPC(hipStreamWaitEvent(s3, h->la_events[0], 0));  // panel set 0, diagonal inverse 0 (dv[0]) and dcopy[0] are there
         for (int kb = 0; kb < nblk; ++kb) {
           const int set = kb & 1, k0 = kb * 128, k1 = k0 + 128, d3 = kb % 3, d3n = (kb + 1) % 3;
@@ -401,7 +561,29 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
           }
           if (kb > 0) HIPC(hipStreamWaitEvent(s1, evP(kb), 0));  // s1: the rest (last step: everything)
           const int part = kb + 1 < nblk ? 4 : 0, colarg = kb + 1 < nblk ? kb + 1 : -2;
-          if (symsweep)
+          if (pf_rest) {
+            // the block's part of T in registers before the K loop, half tiles on four wavefronts (k_update_w PF; same bits)
+            const int rev = (uatomic & 2) && (kb & 1);
+            if (kb + 1 < nblk)
+              hipLaunchKernelGGL((k_update_w<2, true>), dim3(2 * ug), dim3(256), 0, s1, T, ld, nblk, kb, 1, (const double*)cold[set], (const double*)cnew[set],
+                                 (const double*)rt[set], (const double*)dv[d3], kb + 1, 1, rev, (double*)nullptr, kb + 2);
+            else
+              hipLaunchKernelGGL((k_update_w<0, true>), dim3(2 * ug), dim3(256), 0, s1, T, ld, nblk, kb, 1, (const double*)cold[set], (const double*)cnew[set],
+                                 (const double*)rt[set], (const double*)dv[d3], -8, 0, rev, (double*)nullptr, -1);
+          } else if (deep) {
+            // deep form (k_update_deep): one 16-wave block per CU, T tile in registers before the K loop, four LDS stages, `tpb`
+            // tiles per block as one pipeline; the pivot's own block row / column are copied by the blocks behind the first gdeep
+            const long per = (ltiles + 7) / 8;
+            const int gdeep = (int)(8 * ((per + deep_tpb - 1) / deep_tpb));
+            const int ncopy = symsweep ? nblk : 2 * nblk - 1;
+            const int rev = (uatomic & 2) && (kb & 1);
+            if (symsweep)
+              hipLaunchKernelGGL((k_update_deep<true>), dim3(gdeep + ncopy), dim3(1024), MIK_UD_LDS_BYTES, s1, T, ld, nblk, kb, (const double*)cold[set],
+                                 (const double*)cnew[set], (const double*)rt[set], (const double*)dv[d3], part, colarg, deep_tpb, rev, gdeep);
+            else
+              hipLaunchKernelGGL((k_update_deep<false>), dim3(gdeep + ncopy), dim3(1024), MIK_UD_LDS_BYTES, s1, T, ld, nblk, kb, (const double*)cold[set],
+                                 (const double*)cnew[set], (const double*)rt[set], (const double*)dv[d3], part, colarg, deep_tpb, rev, gdeep);
+          } else if (symsweep)
             UPDK(true, dim3(ug), s1, T, ld, nblk, kb, (const double*)cold[set], (const double*)cnew[set], (const double*)rt[set],
                  (const double*)dv[d3], part, colarg, (double*)nullptr, (double*)nullptr, (int*)nullptr);
           else

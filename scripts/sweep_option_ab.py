@@ -17,6 +17,9 @@ for cfgid in cfgs:
     for val in vals:
         h = _lib.Handle(0)
         h.set_option(opt, val)
+        for kv in [a for a in sys.argv[1:] if a.startswith("--set=")]:
+            k, v = kv[6:].split("=")
+            h.set_option(k, float(v))
         h.set_problem(ndim=nd, xs=coords[0], ys=coords[1], zs=coords[2] if nd == 3 else None, values=values,
                       model_id=_lib.MODEL_IDS[cfg["model"]], params=internal_params(cfg["model"], cfg["params"]),
                       regional_linear=bool(cfg.get("rl")), wells=np.array(cfg["wells"]) if cfg.get("wells") else None)

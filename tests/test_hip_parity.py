@@ -291,6 +291,16 @@ def test_panel_stream_and_tile_map_return_the_same_bits():
                 ref = a
             else:
                 np.testing.assert_array_equal(a, ref)
+        # round 5: the deep form of the trailing update (k_update_deep: T tile in registers before the K loop, four LDS stages, several
+        # tiles per block as one pipeline) -- same K order per entry, same subtraction: the same bits, whatever the tiles per block
+        for deep, tpb, rev in ((0, 0, 0), (1, 0, 0), (1, 1, 0), (1, 3, 1), (1, 64, 1), (1, 2, 0)):
+            for key, val in (("symsweep", sym), ("panel_stream", 1), ("update_map", 0), ("early_diag", 1), ("lookahead", 1), ("update_deep", deep),
+                             ("update_tpb", tpb), ("update_rev", rev)):
+                h.set_option(key, val)
+            h.factor()
+            np.testing.assert_array_equal(h.get_matrix(1), ref)
+        for key, val in (("update_deep", -1), ("update_tpb", 0), ("update_rev", -1)):
+            h.set_option(key, val)
     # as eliminated (symmetrize = 0) the full sweep's triangles differ by rounding, and the average is what the default returns
     for key, val in (("symsweep", 0), ("panel_stream", 1), ("update_map", 0), ("symmetrize", 0)):
         h.set_option(key, val)
@@ -300,6 +310,49 @@ def test_panel_stream_and_tile_map_return_the_same_bits():
     h.set_option("symmetrize", 1)
     h.factor()
     np.testing.assert_array_equal(h.get_matrix(1), 0.5 * (raw + raw.T))
+
+
+@pytest.mark.parametrize("n", [1150, 2000])
+def test_wide_half_sweep_matches_lapack_and_its_variants_agree(n):
+    """Round 5, option pivot256 (opt-in): the half sweep with pivot blocks of 256 columns -- a Schur split of the 256 x 256 diagonal block
+    over two runs of the 128-block kernel, rank-256 trailing updates, the column part leaving the next panel, even (16) and odd (9, 11,
+    17: a 128-wide last pivot) numbers of block columns -- against LAPACK and against the 128-wide sweep; the
+    update with its part of T in registers before the K loop (update_pf) and the CU mask of the update stream (wide_reserve) are
+    schedules: the same bits."""
+    import scipy.linalg
+
+    rng = np.random.default_rng(n)
+    x, y = rng.random(n), rng.random(n)
+    v = np.sin(6 * x) * np.cos(4 * y) + 0.1 * rng.standard_normal(n)
+    lib = _lib()
+    ref = None
+    for mat_n in (n, n + 130):  # a second station count: an odd number of block columns (the last pivot is 128 wide)
+        xs, ys, vs = (x, y, v) if mat_n == n else (np.r_[x, rng.random(130)], np.r_[y, rng.random(130)], np.r_[v, rng.random(130)])
+        outs = {}
+        for key in ("narrow", "wide", "wide_pf", "wide_nomask", "narrow_pf"):
+            h = lib.Handle(0)
+            for k, val in (("factor", 1), ("symsweep", 1), ("pivot256", int(key.startswith("wide"))), ("update_pf", int(key.endswith("pf"))),
+                           ("wide_reserve", 0 if key == "wide_nomask" else 16), ("panel_stream", 1)):
+                h.set_option(k, val)
+            h.set_problem(ndim=2, xs=xs, ys=ys, zs=None, values=vs, model_id=lib.MODEL_IDS["exponential"], params=[1.0, 0.1, 0.01])
+            h.factor()
+            outs[key] = h.get_matrix(1)
+            h.close()
+        np.testing.assert_array_equal(outs["wide"], outs["wide_pf"])
+        np.testing.assert_array_equal(outs["wide"], outs["wide_nomask"])
+        np.testing.assert_array_equal(outs["narrow"], outs["narrow_pf"])
+        scale = np.abs(outs["narrow"]).max()
+        assert np.array_equal(outs["wide"], outs["wide"].T)
+        assert np.abs(outs["wide"] - outs["narrow"]).max() <= 1e-10 * scale
+        # against LAPACK on the matrix the library assembled
+        h = lib.Handle(0)
+        h.set_problem(ndim=2, xs=xs, ys=ys, zs=None, values=vs, model_id=lib.MODEL_IDS["exponential"], params=[1.0, 0.1, 0.01])
+        h.assemble_only()
+        amat = h.get_matrix(0)
+        h.close()
+        lap = scipy.linalg.inv(amat)
+        assert np.abs(outs["wide"] - lap).max() <= 1e-9 * np.abs(lap).max()
+        assert np.abs(amat @ outs["wide"] - np.eye(amat.shape[0])).max() <= 1e-8
 
 
 def test_triangular_diagonal_blocks_of_the_contraction():

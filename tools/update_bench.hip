@@ -1,0 +1,55 @@
+// Standalone timing of the block sweep's trailing update (K2): k_update (8 waves per tile, two blocks per CU) against
+// k_update_deep (round 5) and its ablations, on a half sweep's upper block triangle.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I pykrige_amd/csrc tools/update_bench.hip -o tools/update_bench
+// Run:   tools/update_bench [Mp = 8064] [tpb ...]
+#include "mik_k_inverse.h"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+using namespace mik;
+#define CK(x) do{hipError_t e=(x); if(e!=hipSuccess){printf("HIP error %s at %d\n",hipGetErrorString(e),__LINE__);return 1;}}while(0)
+template<class F> float timeit(F f, int reps){
+  hipEvent_t e0,e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  f(); f(); hipDeviceSynchronize();
+  hipEventRecord(e0); for(int i=0;i<reps;i++) f(); hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms,e0,e1); return ms/reps;
+}
+template <int ABL> float run_deep(double* T, int Mp, int nblk, int kb, const double* Cold, const double* Cnew, const double* Rt, const double* Dinv, int tpb) {
+  const long lt = (long)nblk * (nblk + 1) / 2, per = (lt + 7) / 8;
+  const int gdeep = (int)(8 * ((per + tpb - 1) / tpb));
+  (void)hipFuncSetAttribute((const void*)k_update_deep<true, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, MIK_UD_LDS_BYTES);
+  int step = 0;
+  return timeit([&]{ hipLaunchKernelGGL((k_update_deep<true, ABL>), dim3(gdeep + nblk), dim3(1024), MIK_UD_LDS_BYTES, 0, T, (long)Mp, nblk, kb, Cold, Cnew, Rt, Dinv, 0, -2, tpb, (step++) & 1, gdeep); }, 10);
+}
+int main(int argc,char**argv){
+  const int Mp = argc>1? atoi(argv[1]) : 8064, nblk = Mp/128, kb = nblk/2;
+  double *T,*Dinv,*Cold,*Cnew,*Rt;
+  CK(hipMalloc(&T,sizeof(double)*(size_t)Mp*Mp)); CK(hipMalloc(&Dinv,131072));
+  CK(hipMalloc(&Cold,sizeof(double)*(size_t)Mp*128)); CK(hipMalloc(&Cnew,sizeof(double)*(size_t)Mp*128)); CK(hipMalloc(&Rt,sizeof(double)*(size_t)Mp*128));
+  { std::vector<double> b((size_t)Mp*128); srand(1);
+    for(size_t i=0;i<b.size();++i) b[i]=(rand()/(double)RAND_MAX-0.5)*1e-3;
+    CK(hipMemcpy(Cold,b.data(),b.size()*8,hipMemcpyHostToDevice)); CK(hipMemcpy(Cnew,b.data(),b.size()*8,hipMemcpyHostToDevice));
+    CK(hipMemcpy(Rt,b.data(),b.size()*8,hipMemcpyHostToDevice)); CK(hipMemcpy(Dinv,b.data(),131072,hipMemcpyHostToDevice));
+    CK(hipMemset(T,0,sizeof(double)*(size_t)Mp*Mp)); }
+  const long lt=(long)nblk*(nblk+1)/2; const unsigned ug=(unsigned)(8*((lt+7)/8));
+  const double fl = 2.0*128*128*128*(double)(lt - nblk);
+  printf("Mp = %d, %d block columns, %ld upper tiles (%ld take a rank-128 update: %.2f GFLOP, %.0f MB read + written of T)\n", Mp, nblk, lt, lt - nblk, fl*1e-9, (lt - nblk)*0.262144);
+  int step = 0;
+  float ms=timeit([&]{hipLaunchKernelGGL((k_update<true,2>),dim3(ug),dim3(512),0,0,T,(long)Mp,nblk,kb,(const double*)Cold,(const double*)Cnew,(const double*)Rt,(const double*)Dinv,0,-2,(double*)nullptr,(double*)nullptr,(int*)nullptr,(const int2*)nullptr,((step++)&1)?2:0);},10);
+  printf("k_update<true,2> (two 8-wave blocks per CU)        : %7.1f us  %5.1f TFLOP/s\n",ms*1e3, fl/ms*1e-9);
+  std::vector<int> tpbs; for(int a=2;a<argc;++a) tpbs.push_back(atoi(argv[a])); if(tpbs.empty()) tpbs={1,2,4,8};
+  for(int tpb: tpbs){
+    printf("k_update_deep, %d tiles per block:\n", tpb);
+#define RUN(ABL, WHAT) ms = run_deep<ABL>(T, Mp, nblk, kb, Cold, Cnew, Rt, Dinv, tpb); printf("   %-50s: %7.1f us  %5.1f TFLOP/s\n", WHAT, ms*1e3, fl/ms*1e-9);
+    RUN(0, "as in the library");
+    RUN(8, "no stagger");
+    RUN(1, "no T loads");
+    RUN(33, "no T loads, no stores");
+    RUN(2, "no LDS-DMA");
+    RUN(35, "no T loads, no stores, no LDS-DMA");
+    RUN(12, "no stagger, no MFMAs");
+    RUN(28, "no stagger, no MFMAs, no fragment reads");
+    RUN(63, "nothing but barriers and waits");
+  }
+  return 0;
+}
