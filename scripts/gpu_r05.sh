@@ -3,6 +3,7 @@
 #   bash scripts/gpu_r05.sh STAGE [TAG]      -> output under gpurun_out/r05_TAG/
 # STAGES
 #   k2      the sweep tests + A/B of the deep trailing update (update_deep, update_tpb) at bench configs 3, 4, 2, 5
+#   largen  parity beyond N = 8000 against the oracle (tests/test_large_n.py with MIK_SLOW_TESTS=1)
 #   tests   the whole GPU suite
 #   bench   bench.py at config 2 (default run, incl. other_configs + CPU leg + live PMC)
 #   evidence  tests + bench + rocprofv3 kernel stats of the bench (profiles for the round)
@@ -17,6 +18,9 @@ k2)
   ;;
 tests)
   timeout 1500 python -m pytest tests -m gpu -q --tb=short > $OUT/pytest_gpu.txt 2>&1; echo "pytest exit $?" >> $OUT/pytest_gpu.txt; tail -5 $OUT/pytest_gpu.txt
+  ;;
+largen)
+  MIK_SLOW_TESTS=1 timeout 1500 python -m pytest tests/test_large_n.py -m gpu -q -s > $OUT/pytest_large_n.txt 2>&1; grep -E "^n[0-9]|passed|failed|Error" $OUT/pytest_large_n.txt
   ;;
 bench)
   timeout 900 python bench.py > $OUT/bench_c2.json 2> $OUT/bench_c2.err; tail -c 1500 $OUT/bench_c2.json

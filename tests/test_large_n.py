@@ -1,0 +1,73 @@
+"""Round 5: parity beyond N = 8000 (the reference handles such N -- scipy.linalg.inv at ok.py:663 -- slowly).  Regimes of the library
+that no earlier test reached, each against the oracle (oracle/kriging_oracle.py: the reference's arithmetic, scipy.linalg.inv of the
+whole (N + 1) x (N + 1) matrix on the host) on 2048 random points + 8 exact hits, at the bar of north_star (|dz| <= 1e-8,
+|dsigma^2| <= 1e-6), with cond_1(A) printed:
+
+  * N = 12 000 exponential: dense contraction at 94 block columns;
+  * N = 16 000 spherical, range 0.15: k_contract_spg (gathered 16-row groups) with its 32-bit DMA offsets close to their limit (matrix order
+    16 128 of at most 23 168);
+  * N = 24 000 spherical, range 0.1: matrix order 24 064 > 23 168 -- the library switches to k_contract_sp (aligned 128-row blocks) by
+    itself, and every byte offset into the inverse exceeds 4 GiB;
+  * N = 24 000 exponential: k_contract + the block sweep at 188 block columns.
+
+The CPU side is one scipy.linalg.inv per case (0.5 - 2 minutes on the GPU box's 64 cores), so only the N = 24 000 spherical case runs in
+the default `-m gpu` set; the others run with MIK_SLOW_TESTS=1 (scripts/gpu_r05.sh largen)."""
+import os
+import time
+
+import numpy as np
+import pytest
+
+from oracle import kriging_oracle as ko
+
+Z_TOL, SS_TOL = 1e-8, 1e-6
+CASES = {
+    "n12000_exponential": (12000, "exponential", [1.0, 0.3, 0.0], dict(sparse=0), False),
+    "n16000_spherical": (16000, "spherical", [1.0, 0.15, 0.01], dict(sparse=1, sparse_rows=16), False),
+    "n24000_spherical": (24000, "spherical", [1.0, 0.1, 0.01], dict(sparse=1, sparse_rows=128), True),
+    "n24000_exponential": (24000, "exponential", [1.0, 0.3, 0.01], dict(sparse=0), False),
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_parity_beyond_8000_stations(name):
+    import scipy.linalg
+
+    import pykrige_amd as pa
+
+    n, model, params, expect, default_set = CASES[name]
+    if not default_set and os.environ.get("MIK_SLOW_TESTS", "0") != "1":
+        pytest.skip("slow (one scipy.linalg.inv of order %d on the host): set MIK_SLOW_TESTS=1" % (n + 1))
+    rng = np.random.default_rng(n + len(model))
+    x, y = rng.random(n), rng.random(n)
+    v = np.sin(6 * x) * np.cos(4 * y) + 0.1 * rng.standard_normal(n)
+    npt = 2048
+    px, py = rng.random(npt + 8), rng.random(npt + 8)
+    px[:8], py[:8] = x[:8], y[:8]  # exact hits: the eps rule (ok.py:672-676) at this size
+    # ---- the library
+    t0 = time.perf_counter()
+    ok = pa.OrdinaryKriging(x, y, v, variogram_model=model, variogram_parameters=params)
+    z, ss = ok.execute("points", px, py, backend="loop")
+    t_gpu = time.perf_counter() - t0
+    tm = ok.last_timing
+    assert tm["sparse"] == expect["sparse"], tm
+    if expect["sparse"]:
+        assert tm["sparse_rows"] == expect["sparse_rows"], tm
+    # ---- the oracle
+    t0 = time.perf_counter()
+    st = ko.KrigingState(ndim=2, coords_orig=np.stack([x, y], 1), values=v, model=model, params=ko.internal_parameters(model, params))
+    a = ko.kriging_matrix(st)
+    norm_a = np.abs(a).sum(axis=0).max()
+    a_inv = scipy.linalg.inv(a, overwrite_a=True)
+    del a
+    cond1 = norm_a * np.abs(a_inv).sum(axis=0).max()
+    zr, sr = ko.solve_points(st, np.stack([px, py], 1), a_inv=a_inv)
+    t_cpu = time.perf_counter() - t0
+    dz, ds = float(np.abs(np.asarray(z) - zr).max()), float(np.abs(np.asarray(ss) - sr).max())
+    print("\n%s: N = %d, matrix order %d (%d block columns), cond_1 %.2e, max|dz| %.2e max|dss| %.2e (exact hits: |z - v| %.1e, sigma^2 %.1e); "
+          "invert %.1f ms, execute %.2f s, oracle %.1f s; contraction %s" % (
+              name, n, n + 1, (n + 1 + 127) // 128, cond1, dz, ds, float(np.abs(np.asarray(z)[:8] - v[:8]).max()), float(np.abs(np.asarray(ss)[:8]).max()),
+              tm["invert_ms"], t_gpu, t_cpu, "range-aware, rows %d" % tm["sparse_rows"] if tm["sparse"] else "dense"))
+    assert dz <= Z_TOL and ds <= SS_TOL, (dz, ds, cond1)
+    np.testing.assert_allclose(np.asarray(z)[:8], v[:8], rtol=0, atol=1e-8)
