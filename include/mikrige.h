@@ -188,7 +188,9 @@ int  mik_slab_of(int64_t n, int members, int i, int64_t *lo, int64_t *count); /*
  *   delta_k = s - gamma(d_k) = 0 for every station beyond the range, and because A e_last = u:  z = c . delta  and
  *   sigma^2 = 2 s - delta^T A_inv delta  exactly.  The stations are laid out along a Hilbert curve, K3a writes delta and flags the
  *   (128 points x 16 stations) tiles that hold a nonzero, K3b contracts only those (k_contract_spg; see "sparse_rows").  -1 (default) = 1 = on for the
- *   spherical model (not with pseudo_inv, a caller's a_inv or geographic coordinates: those run the dense contraction), 0 = off,
+ *   spherical model (not with pseudo_inv or a caller's a_inv: those run the dense contraction; geographic coordinates since round 5:
+ *   candidates by boxes of the stations' / points' UNIT VECTORS against the chord 2 sin(range / 2) -- monotone in the great-circle
+ *   distance ok.py:634-640, 990-996 take --, delta from the great-circle distance as in the dense path), 0 = off,
  *   2 = Hilbert-ordered stations with the dense contraction (A/B of the order alone).  Takes effect at the
  *   next mik_factor [MIK_SPARSE].  REPRODUCIBILITY: the set of K tiles a point meets depends on the 128-point block it falls
  *   into, so with this option on (with or without "sort_points") sigma^2 depends TO ROUNDING (~1e-13) on how the points are cut

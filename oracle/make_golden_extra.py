@@ -357,3 +357,34 @@ def anisotropy():
 if __name__ == "__main__" and "--aniso" in sys.argv:
     _import_reference(False)
     anisotropy()
+
+
+def geographic_spherical():
+    """Round 5: coordinates_type='geographic' with the SPHERICAL model (ok.py:634-640, 990-996; variogram_models.py:56-70) -- the case
+    the range-aware contraction takes since round 5 (candidates by boxes of the unit vectors).  Stations across the date line and
+    up to 85 degrees of latitude, range 25 degrees: most stations are beyond the range of any grid node."""
+    from pykrige.ok import OrdinaryKriging
+
+    def arr(x):
+        return np.ma.getdata(x).astype(np.float64)
+
+    rng = np.random.default_rng(96)
+    n = 500
+    lon = rng.uniform(100.0, 260.0, n)  # 100 E .. 100 W through the date line
+    lon = np.where(lon > 180.0, lon - 360.0, lon)
+    lat = rng.uniform(-70.0, 85.0, n)
+    v = np.sin(np.radians(lon) * 2) * np.cos(np.radians(lat) * 3) + 0.1 * rng.standard_normal(n)
+    glon = np.concatenate([np.linspace(100.0, 180.0, 12), np.linspace(-175.0, -100.0, 11)])
+    glat = np.linspace(-70.0, 85.0, 17)
+    lon[:4], lat[:4] = glon[[2, 6, 13, 20]], glat[[1, 4, 8, 15]]
+    params = [1.0, 25.0, 0.02]
+    ok = OrdinaryKriging(lon, lat, v, variogram_model="spherical", variogram_parameters=params, coordinates_type="geographic")
+    z, ss = ok.execute("grid", glon, glat, backend="vectorized")
+    np.savez_compressed(os.path.join(OUT, "geo_ok2d_spherical.npz"), x=lon, y=lat, v=v, model="spherical", params_user=params, gridx=glon,
+                        gridy=glat, geographic=True, z=arr(z), ss=arr(ss), A=ok._get_kriging_matrix(n))
+    print("wrote geo_ok2d_spherical")
+
+
+if __name__ == "__main__" and "--geo-spherical" in sys.argv:
+    _import_reference(False)
+    geographic_spherical()

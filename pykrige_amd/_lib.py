@@ -427,13 +427,15 @@ class Handle:
         return (self._lib.mik_exchange_note(self._h) or b"").decode("utf-8", "replace")
 
 
-def station_order(xs, ys, zs=None):
+def station_order(xs, ys, zs=None, geographic=False):
     """The Hilbert-curve order option "sparse" lays the stations out in (mik_station_order): order[i] = index of the station at
-    position i.  Diagnostic; needs no GPU."""
+    position i (geographic: the same curve through (lon, lat); only the boxes of the range test are boxes of unit vectors).  Diagnostic;
+    needs no GPU."""
     xs, ys = _f64(xs), _f64(ys)
     zs = _f64(zs) if zs is not None else None
     p = MikProblem()
     p.ndim, p.n = (3 if zs is not None else 2), xs.size
+    p.geographic = 1 if geographic else 0
     p.xs, p.ys, p.zs = _ptr(xs), _ptr(ys), _ptr(zs)
     out = np.zeros(xs.size, dtype=np.int32)
     check(load().mik_station_order(C.byref(p), out.ctypes.data_as(C.POINTER(C.c_int32))))

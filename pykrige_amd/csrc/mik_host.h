@@ -267,6 +267,7 @@ struct mik_handle {
   DevBuf sp_cand, sp_flags, sp_klist, sp_kcount, sp_nrows, sp_rows, sp_rstart, sp_tiles, sp_xoff, sp_stats, sp_recs;
   int opt_sort_points = -1;  // "sort_points": range-aware contraction over the points of every launch in Hilbert-curve order (k_ps_*): -1 = auto = 1, 0 = off
   DevBuf ps_key[2], ps_idx[2], ps_table, ps_box, ps_x, ps_y, ps_z, ps_zs, ps_sss;
+  DevBuf gu;  // geographic problems, range-aware contraction: unit vectors of the resident points (3 x npt)
   bool ps_valid = false;     // ps_idx[0] holds the order of the resident points for launches of ps_chunk points
   long ps_chunk = 0;
   int opt_sparse_group = 4;  // "sparse_group": point blocks per group of k_sp_tiles_g's queue order (a group's tiles run on one XCD, tile position

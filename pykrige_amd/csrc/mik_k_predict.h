@@ -563,6 +563,19 @@ __global__ void __launch_bounds__(128) k_sp_cand(const double* __restrict__ px, 
   }
 }
 
+// geographic points (lon, lat in degrees) as unit vectors: what k_sp_cand's boxes and the point sort's keys are built from
+// (coordinates_type = 'geographic' with the range-aware contraction, round 5)
+__global__ void __launch_bounds__(256) k_geo_unit_p(const double* __restrict__ lon, const double* __restrict__ lat, long n,
+                                                    double* __restrict__ ux, double* __restrict__ uy, double* __restrict__ uz) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n) return;
+  const double lo = lon[t] * MIK_PI / 180.0, la = lat[t] * MIK_PI / 180.0;
+  const double c = cos(la);
+  ux[t] = c * cos(lo);
+  uy[t] = c * sin(lo);
+  uz[t] = sin(la);
+}
+
 // flags (one byte per point block and K tile, written by k_rhs SP) -> per point block: the ascending list of active K tiles
 // (klist, as k / 16), the ascending list of active ROW blocks (rows: a row block is active when any of its 8 K tiles is), and
 // for each active row block the position in klist of the first K tile beyond it (rstart).  One wavefront per point block.
@@ -811,7 +824,6 @@ __device__ __forceinline__ void gemm_core_sp(const double* __restrict__ Ag, long
     buf ^= 1;
   }
 }
-
 
 struct SpArgs {
   const double* Ainv;
@@ -1405,32 +1417,6 @@ __global__ void __launch_bounds__(64 * 2 * (8 / NAI), 2 * (4 / NAI)) k_contract_
 // by side in every launch (k_ps_bbox, k_ps_keys, then k_ps_hist / k_ps_scan / k_ps_scatter per pass).  Stable + keys that only
 // depend on the coordinates = the same order on every device, run and rank.
 // ------------------------------------------------------------------------------------------------
-
-
-
-
-
-
-
-
-
-
-
-
-
-
-
-
-
-
-
-
-
-
-
-
-
-
 
 #define MIK_PS_DB 10                 // digit bits of the radix sort
 #define MIK_PS_TILE 4096             // keys per block of the histogram / scatter kernels (4 wavefronts x 1024 consecutive keys)

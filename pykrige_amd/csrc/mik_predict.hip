@@ -5,9 +5,20 @@
 
 // Hilbert-curve order of the resident points inside every launch of `chunk` points (k_ps_*, mik_kernels.h): ps_idx[0][s] = index of
 // the point at sorted position s.  On the handle's stream; two radix passes of 10-bit digits, all segments side by side.
+// unit vectors of the resident (geographic) points, gu[0 .. npt) x, [npt .. 2 npt) y, [2 npt .. 3 npt) z; on the handle's stream
+static int geo_point_vectors(mik_handle* h) {
+  const long npt = h->npt;
+  MIKC(h->gu.ensure(sizeof(double) * 3 * (size_t)npt));
+  double* u = h->gu.as<double>();
+  hipLaunchKernelGGL(k_geo_unit_p, dim3((unsigned)((npt + 255) / 256)), dim3(256), 0, h->stream, (const double*)h->px.as<double>(),
+                     (const double*)h->py.as<double>(), npt, u, u + npt, u + 2 * npt);
+  return MIK_OK;
+}
+
 int sort_points(mik_handle* h, long chunk, long nchunks) {
   const long npt = h->npt;
-  const int bits = ps_bits(h->ndim), bps = (int)((chunk + MIK_PS_TILE - 1) / MIK_PS_TILE);
+  const int kd = h->ndim;  // (geographic points: the curve runs through (lon, lat), like the stations' -- mikrige.hip, station_order)
+  const int bits = ps_bits(kd), bps = (int)((chunk + MIK_PS_TILE - 1) / MIK_PS_TILE);
   for (int q = 0; q < 2; ++q) {
     MIKC(h->ps_key[q].ensure(sizeof(unsigned) * (size_t)npt));
     MIKC(h->ps_idx[q].ensure(sizeof(unsigned) * (size_t)npt));
@@ -17,7 +28,7 @@ int sort_points(mik_handle* h, long chunk, long nchunks) {
   const double *px = h->px.as<double>(), *py = h->py.as<double>(), *pz = h->ndim == 3 ? h->pz.as<double>() : nullptr;
   hipStream_t st = h->stream;
   hipLaunchKernelGGL(k_ps_bbox, dim3((unsigned)nchunks), dim3(1024), 0, st, px, py, pz, npt, chunk, bits, h->ps_box.as<double>());
-  hipLaunchKernelGGL(k_ps_keys, dim3((unsigned)((npt + 255) / 256)), dim3(256), 0, st, px, py, pz, npt, chunk, h->ndim, bits,
+  hipLaunchKernelGGL(k_ps_keys, dim3((unsigned)((npt + 255) / 256)), dim3(256), 0, st, px, py, pz, npt, chunk, kd, bits,
                      (const double*)h->ps_box.as<double>(), h->ps_key[0].as<unsigned>(), h->ps_idx[0].as<unsigned>());
   for (int pass = 0; pass < 2; ++pass) {
     const unsigned* kin = h->ps_key[pass].as<unsigned>();
@@ -132,6 +143,7 @@ int one_predict(mik_handle* h) {
   hipStream_t sc = h->stream;                  // contraction, reduction
   hipStream_t sr = two ? h->stream2 : h->stream;  // right-hand sides
   HIPC(hipStreamWaitEvent(h->stream, h->ev_d2h, 0));  // an earlier predict's result copies still read z / ss
+  if (sparse && h->geo) MIKC(geo_point_vectors(h));  // what the candidate boxes of a geographic problem are built from
   HIPC(hipEventRecord(h->evpool[0], h->stream));
   bool sorted_now = false;
   if (sortpts && !(h->ps_valid && h->ps_chunk == chunk)) {
@@ -194,11 +206,21 @@ int one_predict(mik_handle* h) {
         a.zout = h->z.as<double>();
       }
       HIPC(hipEventRecord(h->evpool[2 + 4 * nchunks + 2 * c], ss));
-      hipLaunchKernelGGL(k_sp_cand, dim3(palloc / 128), dim3(128), 0, ss, a.px, a.py, a.pz, nvalid, (const double*)h->sbox.as<double>(), nK16,
-                         h->N / 16, (h->M + 15) / 16, std::max(h->v.p1, h->eps), ln.cand->as<unsigned char>(), a.perm, gathered ? 0 : 1);
+      // candidates by bounding boxes: Euclidean coordinates against the range; geographic: unit vectors against the CHORD of the range
+      // (2 sin(arc / 2), the range being degrees of arc; beyond 180 degrees everything is in range)
+      const double *cx = a.px, *cy = a.py, *cz = a.pz;
+      double radius = std::max(h->v.p1, h->eps);
+      if (h->geo) {
+        const long off = perm_all ? 0 : t0;
+        cx = h->gu.as<double>() + off, cy = cx + npt, cz = cy + npt;
+        radius = radius >= 180.0 ? 4.0 : 2.0 * std::sin(radius * 3.14159265358979323846 / 360.0) * (1.0 + 1e-12) + 1e-15;
+      }
+      hipLaunchKernelGGL(k_sp_cand, dim3(palloc / 128), dim3(128), 0, ss, cx, cy, cz, nvalid, (const double*)h->sbox.as<double>(), nK16,
+                         h->N / 16, (h->M + 15) / 16, radius, ln.cand->as<unsigned char>(), a.perm, gathered ? 0 : 1);
       HIPC(hipMemsetAsync(ln.flags->p, 0, (size_t)(palloc / 128) * nK16, ss));
       HIPC(hipEventRecord(h->evpool[2 + 4 * c], ss));
-      if (h->ndim == 3) hipLaunchKernelGGL((k_rhs<3, 3, true>), dim3(palloc / MIK_TP), dim3(256), 0, ss, a);
+      if (h->geo) hipLaunchKernelGGL((k_rhs<3, 1, true>), dim3(palloc / MIK_TP), dim3(256), 0, ss, a);
+      else if (h->ndim == 3) hipLaunchKernelGGL((k_rhs<3, 3, true>), dim3(palloc / MIK_TP), dim3(256), 0, ss, a);
       else hipLaunchKernelGGL((k_rhs<3, 2, true>), dim3(palloc / MIK_TP), dim3(256), 0, ss, a);
       HIPC(hipEventRecord(h->evpool[3 + 4 * c], ss));
       return MIK_OK;

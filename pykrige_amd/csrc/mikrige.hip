@@ -430,19 +430,40 @@ static void hilbert_order(int ndim, long n, const double* xs, const double* ys, 
   for (long i = 0; i < n; ++i) order[(size_t)i] = keys[(size_t)i].second;
 }
 
+// geographic stations (lon, lat in degrees) as unit vectors: the chord |u_i - u_j| = 2 sin(arc / 2) is monotone in the great-circle
+// distance the reference's variogram takes (core.py:36-97), so boxes of the unit vectors bound it
+static void geo_unit_vectors(long n, const double* lon, const double* lat, std::vector<double>& u) {
+  u.resize(3 * (size_t)n);
+  const double rad = 3.14159265358979323846 / 180.0;
+  for (long i = 0; i < n; ++i) {
+    const double lo = lon[i] * rad, la = lat[i] * rad;
+    u[(size_t)i] = std::cos(la) * std::cos(lo);
+    u[(size_t)n + i] = std::cos(la) * std::sin(lo);
+    u[2 * (size_t)n + i] = std::sin(la);
+  }
+}
+// The order itself is the 2-D curve through (lon, lat) also for geographic problems: a plane curve on a surface keeps 16 consecutive
+// stations closer together ON THE SPHERE than a space curve through the unit vectors, which meets the surface in pieces (measured on
+// 4096 stations uniform on the sphere, largest box edge of a tile in chord units: median 0.26 / 90 % 0.35 / max 0.51 against
+// 0.28 / 0.45 / 1.23) -- lon / lat -> sphere is continuous, so a tile that is compact in lon / lat is compact on the sphere; only the
+// BOXES must be boxes of the unit vectors (a lon / lat box is not a distance box at the date line and the poles).
+static void station_order(const mik_problem* p, std::vector<int>& order) { hilbert_order(p->ndim, p->n, p->xs, p->ys, p->zs, order); }
+
 int mik_station_order(const mik_problem* p, int32_t* order_out) {
   if (!p || !order_out) return fail(MIK_EINVAL, "mik_station_order: NULL argument");
   if ((p->ndim != 2 && p->ndim != 3) || p->n < 1 || !p->xs || !p->ys || (p->ndim == 3 && !p->zs))
     return fail(MIK_EINVAL, "mik_station_order: station arrays missing");
   std::vector<int> order;
-  hilbert_order(p->ndim, p->n, p->xs, p->ys, p->zs, order);
+  station_order(p, order);
   for (long i = 0; i < p->n; ++i) order_out[i] = order[(size_t)i];
   return MIK_OK;
 }
 
 static int upload_sorted_stations(mik_handle* h, const mik_problem* p) {
   const long N = h->N;
-  if (!(h->stations_same && (long)h->sort_perm.size() == N)) hilbert_order(h->ndim, N, p->xs, p->ys, p->zs, h->sort_perm);
+  std::vector<double> unit;  // geographic: the stations' unit vectors (for the boxes below)
+  if (!(h->stations_same && (long)h->sort_perm.size() == N)) station_order(p, h->sort_perm);
+  if (h->geo) geo_unit_vectors(N, p->xs, p->ys, unit);
   const size_t nb = sizeof(double) * (size_t)N;
   std::vector<double> tmp((size_t)N);
   auto up = [&](DevBuf& dst, const double* src) -> int {
@@ -469,14 +490,16 @@ static int upload_sorted_stations(mik_handle* h, const mik_problem* p) {
   const int nIblk = h->Mp / 16;
   std::vector<double> box((size_t)nIblk * 6);
   const double* c[3] = {p->xs, p->ys, p->zs};
+  if (h->geo) c[0] = unit.data(), c[1] = unit.data() + N, c[2] = unit.data() + 2 * N;
+  const int bd = h->geo ? 3 : h->ndim;  // dimension of the boxes
   for (int b = 0; b < nIblk; ++b) {
     double* q = box.data() + (size_t)b * 6;
     for (int d = 0; d < 3; ++d) {
-      q[d] = d < h->ndim ? 1e300 : 0.0;
-      q[3 + d] = d < h->ndim ? -1e300 : 0.0;
+      q[d] = d < bd ? 1e300 : 0.0;
+      q[3 + d] = d < bd ? -1e300 : 0.0;
     }
     for (long i = (long)b * 16; i < std::min<long>(N, (long)(b + 1) * 16); ++i)
-      for (int d = 0; d < h->ndim; ++d) {
+      for (int d = 0; d < bd; ++d) {
         const double v = c[d][h->sort_perm[(size_t)i]];
         q[d] = std::min(q[d], v);
         q[3 + d] = std::max(q[3 + d], v);
@@ -586,9 +609,10 @@ static int one_set_problem(mik_handle* h, const mik_problem* p) {
   if (h->host_inv) h->host_ainv.assign(p->a_inv, p->a_inv + (size_t)h->M * h->M);
   else h->host_ainv.clear();
   // compact-support model (spherical: gamma constant beyond the range): a second copy of the stations in Hilbert-curve order for
-  // the range-aware contraction (k_contract_sp).  Not with a pseudo-inverse (A+ u != e_last), a caller's inverse (its order is the
-  // caller's) or geographic coordinates (lon / lat boxes are not distance boxes).
-  h->sort_ok = h->model == MIK_MODEL_SPHERICAL && !h->geo && !h->pinv && !h->host_inv && h->Mp / 16 <= MIK_SP_MAXK16 &&
+  // the range-aware contraction (k_contract_sp).  Not with a pseudo-inverse (A+ u != e_last) or a caller's inverse (its order is the
+  // caller's).  Geographic coordinates (round 5): the curve runs through (lon, lat), the BOXES are boxes of the stations' unit vectors --
+  // the chord is monotone in the great-circle distance, so a box test on chords is a superset test on arcs.
+  h->sort_ok = h->model == MIK_MODEL_SPHERICAL && !h->pinv && !h->host_inv && h->Mp / 16 <= MIK_SP_MAXK16 &&
                std::isfinite(v.p1) && v.p1 > 0.0 && std::isfinite(v.p0 + v.p2);
   h->factor_sorted = false;
   if (h->sort_ok) MIKC(upload_sorted_stations(h, p));

@@ -1,3 +1,1 @@
-timeout 300 ./tools/update_bench 8064 1 4 > gpurun_out/r05_update_bench.txt 2>&1; timeout 200 ./tools/update_bench 5120 1 >> gpurun_out/r05_update_bench.txt 2>&1
-bash scripts/gpu_r05.sh tests
-bash scripts/gpu_r05.sh bench
+timeout 900 python -m pytest tests/test_sparse_contraction.py tests/test_hip_parity.py -m gpu -q -x -k "geograph or geo_ok2d or sparse_path_on_the_reference" 2>&1 | tail -5

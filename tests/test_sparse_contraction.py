@@ -75,6 +75,26 @@ def test_station_order_is_a_hilbert_curve():
     assert np.median(diam) < 4.0 * np.sqrt(16 / 8000.0)  # a random 16-subset would span the unit square
 
 
+def test_station_order_of_geographic_problems_is_compact_on_the_sphere():
+    """coordinates_type = 'geographic' (round 5): the order is the plane curve through (lon, lat) -- lon / lat -> sphere is continuous, so
+    16 consecutive stations are neighbours ON THE SPHERE too, also at the date line and the poles (where only the BOXES must not be
+    lon / lat boxes: the library builds them from the unit vectors)."""
+    from pykrige_amd import _lib
+
+    rng = np.random.default_rng(12)
+    n = 4096
+    lon = rng.uniform(-180.0, 180.0, n)
+    lat = np.degrees(np.arcsin(rng.uniform(-1.0, 1.0, n)))  # uniform on the sphere
+    o = _lib.station_order(lon, lat, geographic=True)
+    assert sorted(o.tolist()) == list(range(n))
+    assert np.array_equal(o, _lib.station_order(lon, lat))
+    lo, la = np.radians(lon[o]), np.radians(lat[o])
+    u = np.stack([np.cos(la) * np.cos(lo), np.cos(la) * np.sin(lo), np.sin(la)], 1)
+    ext = np.array([np.ptp(u[i:i + 16], axis=0).max() for i in range(0, n, 16)])  # largest box edge of a tile of 16 stations (chord units)
+    # 4096 points on a sphere of area 4 pi: a compact patch of 16 has a diameter of ~ sqrt(16 * 4 pi / 4096) = 0.22
+    assert np.median(ext) < 0.3 and np.quantile(ext, 0.9) < 0.4 and ext.max() < 0.7, (np.median(ext), np.quantile(ext, 0.9), ext.max())
+
+
 def test_gathered_row_groups_reproduce_the_quadratic_form():
     """The tiling of k_contract_spg (option "sparse_rows" 16), restated in NumPy: the ascending list of a point block's active K tiles
     (16 stations each) is also the list of its active 16-row groups; tile r takes list entries [8r, 8r + 8) as its rows, walks the
@@ -425,3 +445,41 @@ def test_sparse_path_in_a_device_group():
             assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
         else:
             assert np.abs(outs[0][0] - outs[1][0]).max() <= 1e-11 and np.abs(outs[0][1] - outs[1][1]).max() <= 1e-11
+
+
+@pytest.mark.gpu
+def test_range_aware_contraction_on_geographic_coordinates():
+    """Round 5: spherical model + coordinates_type='geographic' (ok.py:634-640, 990-996) takes the range-aware contraction: candidates by
+    boxes of the unit vectors against the chord of the range, delta from the great-circle distance exactly as the dense path computes it.
+    2000 stations over a hemisphere, range 10 degrees, a 96 x 64 lon / lat grid + exact hits: the oracle's numbers, the dense path's
+    numbers to rounding, and fewer than 30 % of the dense tiles."""
+    import pykrige_amd as pa
+
+    rng = np.random.default_rng(31)
+    n = 2000
+    lon = rng.uniform(-170.0, 10.0, n)
+    lat = np.degrees(np.arcsin(rng.uniform(-0.3, 0.95, n)))
+    v = np.sin(np.radians(lon) * 2) * np.cos(np.radians(lat) * 3) + 0.1 * rng.standard_normal(n)
+    glon, glat = np.linspace(-170.0, 10.0, 96), np.linspace(-15.0, 70.0, 64)
+    lon[:4], lat[:4] = glon[[3, 30, 60, 90]], glat[[2, 20, 40, 60]]
+    par = [1.0, 10.0, 0.02]
+    outs = {}
+    for sparse in (1, 0):
+        ok = pa.OrdinaryKriging(lon, lat, v, variogram_model="spherical", variogram_parameters=par, coordinates_type="geographic")
+        ok._get_handle().set_option("sparse", sparse)
+        z, ss = ok.execute("grid", glon, glat, backend="loop")
+        tm = ok.last_timing
+        assert tm["sparse"] == sparse
+        if sparse:
+            frac = tm["sparse_tiles"] / tm["sparse_tiles_dense"]
+            assert frac < 0.3, frac
+            assert tm["points_sorted"] == 1  # 6144 points: sorted along a curve through their unit vectors
+        outs[sparse] = (np.ma.getdata(z).copy(), np.ma.getdata(ss).copy())
+    st = ko.KrigingState(ndim=2, coords_orig=np.stack([lon, lat], 1), values=v, model="spherical", params=ko.internal_parameters("spherical", par),
+                         geographic=True)
+    zr, sr = ko.execute(st, "grid", glon, glat)
+    for sparse in (1, 0):
+        assert np.abs(outs[sparse][0] - zr).max() <= Z_TOL and np.abs(outs[sparse][1] - sr).max() <= SS_TOL
+    assert np.abs(outs[1][0] - outs[0][0]).max() <= 1e-11 and np.abs(outs[1][1] - outs[0][1]).max() <= 1e-11
+    zg = outs[1][0]
+    assert abs(zg[2, 3] - v[0]) <= 1e-9 and abs(outs[1][1][2, 3]) <= 1e-9  # an exact hit: the value, sigma^2 = 0
