@@ -267,6 +267,9 @@ int  mik_slab_of(int64_t n, int members, int i, int64_t *lo, int64_t *count); /*
  *   "update_tpb" tiles per block run as one pipeline.  Same K order and the same subtraction per entry: same bits.  Measured
  *   SLOWER (N = 8000 13.5 -> 16.3 ms; profiles/r05_update_deep_ab.txt): default 0 [MIK_UPDATE_DEEP] ;
  * "update_tpb" 0..64 = tiles per block of k_update_deep; 0 (default) = two rounds of blocks per step [MIK_UPDATE_TPB] ;
+ * "update_token" 0/1 = half sweep: a per-CU token makes the two resident blocks of the trailing update alternate between K loop and
+ *   read-modify-write instead of running them in step (same bits).  Measured 7 - 9 % SLOWER (N = 5000 4.26 -> 4.55 ms, N = 8000 13.5 -> 14.8):
+ *   the two blocks of a CU do overlap each other already; what adds is chip-wide (HBM) -- default 0 ;
  * "update_pf" 0/1 = half sweep: the rest of every trailing update on blocks of four wavefronts that take HALF tiles (64 x 128) and load
  *   their part of T into registers before the K loop (k_update_w PF; same bits).  A tie in the 128-wide sweep, default 0 ;
  * "pivot256" 0/1 = half sweep with pivot blocks of 256 columns (one read-modify-write of T per TWO block columns; the 256 x 256 diagonal

@@ -351,6 +351,8 @@ struct mik_handle {
   int opt_pivot256 = -1;
   DevBuf Wide;            // its 256 x 256 diagonal inverses and 128 x 128 scratch blocks
   int opt_wide_reserve = 16;  // "wide_reserve": CUs (a multiple of 8: the same number on every XCD) the wide sweep's update stream leaves to the chain's kernels (0 = none)
+  int opt_update_token = 0;   // "update_token": per-CU token that makes the two resident update blocks of a CU alternate (k_update cu_tok)
+  DevBuf cu_token;
   int opt_update_pf = 0;      // "update_pf": trailing update with its part of T in registers before the K loop (half tiles on four wavefronts, k_update_w PF;
                               // same bits).  Measured a tie in the 128-wide sweep (N = 5000 4.25 / 4.22 ms, N = 8000 13.31 / 13.23) and -9 % .. -34 % of the
                               // wide sweep below N = 5000, +11 % of its update at N = 8000: off

@@ -524,6 +524,12 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
         hipStream_t s1 = h->stream, s2 = h->stream2, s3 = h->stream3;
         // "update_deep" 1: the rest of every update by k_update_deep (off by default: measured slower); tiles per block: "update_tpb" (0 = auto: one round
         // of blocks per step would hold every CU for the whole step and starve the chain's kernels, so two rounds)
+        int* tokbuf = nullptr;  // "update_token": the two resident blocks of a CU alternate between K loop and read-modify-write (k_update cu_tok)
+        if (h->opt_update_token) {
+          MIKC(h->cu_token.ensure(sizeof(int) * 2048));
+          HIPC(hipMemsetAsync(h->cu_token.p, 0, sizeof(int) * 2048, h->stream));
+          tokbuf = h->cu_token.as<int>();
+        }
         const bool deep = h->opt_update_deep > 0 && !tmap && !(uatomic & 1);
         const bool pf_rest = symsweep && h->opt_update_pf != 0 && !deep && !tmap && !(uatomic & 1);  // "update_pf"
         const int deep_tpb = h->opt_update_tpb > 0 ? h->opt_update_tpb : (int)std::max<long>(1, (ltiles + 2 * h->n_cu - 1) / (2 * h->n_cu));
@@ -583,6 +589,9 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
             else
               hipLaunchKernelGGL((k_update_deep<false>), dim3(gdeep + ncopy), dim3(1024), MIK_UD_LDS_BYTES, s1, T, ld, nblk, kb, (const double*)cold[set],
                                  (const double*)cnew[set], (const double*)rt[set], (const double*)dv[d3], part, colarg, deep_tpb, rev, gdeep);
+          } else if (symsweep && tokbuf && upd8) {
+            hipLaunchKernelGGL((k_update<true, 2>), dim3(ug), dim3(512), 0, s1, T, ld, nblk, kb, (const double*)cold[set], (const double*)cnew[set],
+                               (const double*)rt[set], (const double*)dv[d3], part, colarg, (double*)nullptr, (double*)nullptr, (int*)nullptr, tmap, uatomic, tokbuf);
           } else if (symsweep)
             UPDK(true, dim3(ug), s1, T, ld, nblk, kb, (const double*)cold[set], (const double*)cnew[set], (const double*)rt[set],
                  (const double*)dv[d3], part, colarg, (double*)nullptr, (double*)nullptr, (int*)nullptr);

@@ -142,7 +142,11 @@ __global__ void __launch_bounds__(64 * 2 * (8 / NAI), NAI == 2 ? 4 : 2)
 k_update(double* __restrict__ T, long ld, int nblk, int kb, const double* __restrict__ Cold,
          const double* __restrict__ Cnew, const double* __restrict__ Rt, const double* __restrict__ Dinv, int part, int col,
          double* __restrict__ Pout, double* __restrict__ Dcopy = nullptr, int* __restrict__ done_cnt = nullptr,
-         const int2* __restrict__ tilemap = nullptr, int atomic_rmw = 0) {
+         const int2* __restrict__ tilemap = nullptr, int atomic_rmw = 0, int* __restrict__ cu_tok = nullptr) {
+  // cu_tok (nullable; round 5, option "update_token"): one word per CU (indexed by XCC_ID and the SE / SH / CU fields of HW_ID), zeroed by the
+  // host.  A block takes its CU's token for the K loop and gives it back before its read-modify-write: the two resident blocks of a CU
+  // then ALTERNATE -- one feeds the matrix cores while the other loads, subtracts and stores -- instead of falling into step chip-wide
+  // (load-all, compute-all: the phases add, tools/update_bench).  Only a schedule: same tiles, same arithmetic, same bits.  Bounded wait.
   // atomic_rmw (round 3): a tile that only has to become T - C R^T (no panel copy, no diagonal copy) sends its 128 x 128 products
   // to memory as fp64 atomic adds of -acc (global_atomic_add_f64, no return value) instead of load / subtract / store: the
   // read-modify-write then happens in the L2 while the wavefronts are already in the next tile's K loop -- the epilogue's memory
@@ -232,7 +236,22 @@ k_update(double* __restrict__ T, long ld, int nblk, int kb, const double* __rest
   for (int x = 0; x < NAI; ++x)
 #pragma unroll
     for (int y = 0; y < 4; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
+  int* tok = nullptr;
+  if (cu_tok) {
+    unsigned xcc, hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    tok = cu_tok + (((xcc & 7u) << 8) | ((hw >> 8) & 0xffu));  // HW_ID: CU_ID 11:8, SH_ID 12, SE_ID 15:13
+    if (threadIdx.x == 0) {
+      for (int spin = 0; spin < 100000; ++spin) {
+        if (atomicCAS(tok, 0, 1) == 0) break;
+        __builtin_amdgcn_s_sleep(8);
+      }
+    }
+    __syncthreads();
+  }
   gemm_core<NAI>(Cold + (long)i0 * 128, 128, Rt + (long)j0 * 128, 128, 0, 128, acc, sm);
+  if (tok && threadIdx.x == 0) __hip_atomic_store(tok, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (gemm_core ended with a barrier)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 1, wn = wave & 1, lq = lane >> 4, lc = lane & 15;
   constexpr int WR = 16 * NAI;  // rows of the wave tile
