@@ -203,9 +203,6 @@ int  mik_slab_of(int64_t n, int members, int i, int64_t *lo, int64_t *count); /*
  *   5).  -1 (default) = 16 wherever 32-bit DMA offsets reach every row (Mp <= 23168), else 128 [MIK_SPARSE_ROWS] ;
  * "sparse_group" 1..16 = k_contract_spg's queue order: point blocks per group (a group's tiles run on one XCD, tile position ascending
  *   = longest K loops first, point block fast; default 4) [MIK_SPARSE_GROUP] ;
- * "sparse_epilogue" 0/1 = k_contract_spg: a group's term of delta^T A_inv delta is formed from global memory after the K loop (0, default)
- *   or at the K step of the group's own 16 x 16 square, where its accumulators are final and the delta of its rows is that step's
- *   B tile in LDS (1: no operand reads in the epilogue; measured 1.7 % slower at BASELINE config 5) [MIK_SPARSE_EPILOGUE] ;
  * "sort_points" -1/0/1 = range-aware contraction: the points of every launch (one chunk of the resident point list) are put in
  *   Hilbert-curve order among themselves on the device (k_ps_*: 20-bit keys, stable two-pass radix sort, all launches' segments
  *   side by side) and kriged in that order -- a block of 128 consecutive points is then a compact patch whatever order the caller's
@@ -224,12 +221,8 @@ int  mik_slab_of(int64_t n, int members, int i, int64_t *lo, int64_t *count); /*
  *   (the reference's own KT3D test case: cond(A) 3e14 -> 2e6; the unpivoted sweep's |dz| 6e-9 -> 2e-11).  Not with pseudo_inv
  *   (a pseudo-inverse is not invariant under S) or a caller's a_inv.  mik_get_matrix(1) hands out the inverse of the
  *   reference's matrix, S^T A'^-1 S ;
- * "pairs" 0/1 = symmetric contraction: work is handed out as single tiles (default 0) or as equal-length PAIRS of row
- *   blocks (higher L2 hit rate, measured 2.7 % slower: the kernel is not traffic-bound) ;
  * "tri" 0/1 = symmetric contraction (8-wave form): the diagonal block of a tile is contracted as a triangle of 16-row groups,
  *   36 of its 64 (row group, K tile) products (default 1: -1.5 % contraction time, partials equal to 1e-14) [MIK_TRI] ;
- * "prefetch" 0/1 = symmetric contraction with "tri": a block pops its next tile before the epilogue of the current one and sends
- *   that tile's first K tile to LDS meanwhile (same partial sums; measured a tie, default 0) [MIK_PREFETCH] ;
  * "symmetrize" 0/1 = after a full sweep, the pivoted elimination or a pseudo-inverse: A_inv <- (A_inv + A_inv^T) / 2 (default 1).
  *   The symmetric contraction reads one triangle of A_inv; a quadratic form sees only the symmetric part, so with the average
  *   in both triangles the half product equals b^T A_inv b of the matrix as eliminated (the half sweep mirrors its triangle
@@ -252,9 +245,8 @@ int  mik_slab_of(int64_t n, int members, int i, int64_t *lo, int64_t *count); /*
  * "update_waves" 4 | 8 = wavefronts per 128 x 128 tile of the block sweep's trailing update (wave tile 64 x 64 / 32 x 64; same bits;
  *   default 8)
  *   [MIK_UPDATE_WAVES] ;
- * "update_atomic" 0/1 = trailing update of the sweep: tiles that only become T - C R^T are written as fp64 atomic adds of the
- *   negated products (no load, no wait: the read-modify-write happens in the L2 while the block is in its next tile; same bits).
- *   Measured 10-14 % slower than load / subtract / store (the L2's fp64 atomic rate): default 0 [MIK_UPDATE_ATOMIC] ;
+ * (round 5: "pairs", "prefetch", "sparse_epilogue", "update_atomic" -- options every A/B of rounds 2-4 lost -- are gone; their kernels'
+ *   variants remain in the headers for tools/kernel_bench, their measurements in profiles/r02_*, r03_*, r04b_*.)
  * "update_map" 0/n = tile order of the sweep's trailing update: 0 = block column by block column (default), n > 1 = n x n
  *   super-blocks (the ~64 tiles an XCD has in flight share n + n operand panels in its L2 instead of one panel per tile) --
  *   measured a tie at N = 2000 .. 8000: the update is not bound by its panel reads; same bits [MIK_UPDATE_MAP] ;

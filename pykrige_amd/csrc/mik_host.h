@@ -272,9 +272,6 @@ struct mik_handle {
   long ps_chunk = 0;
   int opt_sparse_group = 4;  // "sparse_group": point blocks per group of k_sp_tiles_g's queue order (a group's tiles run on one XCD, tile position
                              // ascending, point block fast): 1 .. 16
-  int opt_sparse_epi = 0;    // "sparse_epilogue": k_contract_spg forms a group's term of the quadratic form from global memory after the K loop (0,
-                             // default) or from the B tile in LDS at the group's own K step (1: no operand reads in the epilogue -- measured 1.7 %
-                             // SLOWER at config 5, 43.1 against 42.4 ms of contraction: the extra registers of the triangle loop cost more)
   int opt_sparse_rows = -1;  // "sparse_rows": 16 = tiles of gathered 16-row groups (k_contract_spg), 128 = aligned row blocks (k_contract_sp),
                              // -1 = auto: 16 wherever 32-bit offsets address the inverse (Mp * Mp * 8 < 2^32)
   // second set (with Bt2): the launches of the range-aware contraction alternate between two lanes on two streams, so that the
@@ -341,9 +338,6 @@ struct mik_handle {
   int opt_update_map = 0;
   int opt_update_rev = -1;  // "update_rev": the half sweep's trailing update walks its tiles backwards on odd steps (k_update): -1 = auto =
                             // from 45 block columns on (the upper triangle no longer fits half of the 256 MB memory-side cache), 0 / 1
-  // trailing update: tiles without a panel / diagonal copy go to memory as fp64 atomic adds (k_update atomic_rmw; same bits).
-  // Measured SLOWER (N=5000 4.39 -> 4.84 ms, N=8000 13.98 -> 15.96 ms: the L2's fp64 atomic rate, not latency, is the bound): off.
-  int opt_update_atomic = 0;
   // "pivot256": half sweep with pivot blocks of 256 columns (run_block_inverse_wide; half the read-modify-write traffic of T per eliminated
   // column).  Measured a TIE at N = 8000 (13.1 - 13.3 ms both: the K = 256 update is 338 us per pair against 2 x 201, but its column part and
   // the 256 x 256 diagonal inverse eat the difference) and slower below (N = 5000: 5.4 - 6.3 against 4.3 ms: the chain is the step there):
@@ -385,16 +379,9 @@ struct mik_handle {
   int t_state = 0;  // what T holds: 0 nothing, 1 the kriging matrix A (shift 0), 2 its inverse
   // options
   int opt_waves = 8;  // waves per contraction block: 4 (wave tile 64x64) or 8 (32x64)
-  // symmetric contraction: the queue can hand out equal-length PAIRS of row blocks instead of single tiles.  Measured
-  // (profiles/r02_contract_pairs_vs_tiles.txt): L2 hit rate 28 % -> 47 %, fabric reads -19 %, and 2.7 % SLOWER -- co-resident
-  // blocks then reach their epilogues together and stop covering each other's bubbles; the kernel is not traffic-bound.  Off.
-  int opt_pairs = 0;
   // symmetric contraction (8-wave form): the diagonal block of a tile is contracted as a triangle of 16-row groups -- 36 of
   // its 64 (group, K tile) products (round 3; gemm_core TRI).  0 = the whole diagonal block.
   int opt_tri = 1;
-  // symmetric contraction with triangular diagonal blocks: the next tile is popped, and its first K tile sent to LDS, before the
-  // epilogue of the current one (k_contract PRE)
-  int opt_prefetch = 0;
   int opt_symmetrize = 1;  // T <- (T + T^T) / 2 after a full sweep / the pivoted elimination (k_symmetrize); 0 = as eliminated
   int opt_factor = 0, opt_sym = 1, opt_engine = 0;  // engine: 0 = v_mfma_f64 contraction, 1 = v_fma_f64 (VALU) contraction
   long opt_chunk = 131072;

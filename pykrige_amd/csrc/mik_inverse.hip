@@ -392,7 +392,7 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
   const long ltiles = symsweep ? (long)nblk * (nblk + 1) / 2 : tiles;
   const unsigned ug = (unsigned)(8 * ((ltiles + 7) / 8));
   const bool upd8 = h->opt_update_waves == 8;
-  const int uatomic = (pivoted ? 0 : h->opt_update_atomic) | ((h->opt_update_rev < 0 ? nblk >= 45 : h->opt_update_rev != 0) ? 2 : 0);  // bit 0: plain tiles of the trailing update as
+  const int uatomic = (h->opt_update_rev < 0 ? nblk >= 45 : h->opt_update_rev != 0) ? 2 : 0;  // bit 0: plain tiles of the trailing update as
                                                                                            // fp64 atomic adds, bit 1: odd steps backwards (k_update)
   // tile order of the trailing update: optionally n x n super-blocks (k_update's tilemap)
   const int2* tmap = nullptr;

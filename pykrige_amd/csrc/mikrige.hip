@@ -54,20 +54,14 @@ static int create_one_body(mik_handle* h, int device) {
   if (env && atol(env) >= 128) h->opt_chunk = (atol(env) / 128) * 128;
   env = getenv("MIK_SYMSWEEP");
   if (env) h->opt_symsweep = atoi(env) < 0 ? -1 : atoi(env) ? 1 : 0;
-  env = getenv("MIK_PAIRS");
-  if (env) h->opt_pairs = atoi(env) ? 1 : 0;
   env = getenv("MIK_SPARSE");
   if (env && atoi(env) >= -1 && atoi(env) <= 2) h->opt_sparse = atoi(env);
   env = getenv("MIK_SORT_POINTS");
   if (env && atoi(env) >= -1 && atoi(env) <= 1) h->opt_sort_points = atoi(env);
   env = getenv("MIK_SPARSE_GROUP");
   if (env && atoi(env) >= 1 && atoi(env) <= 16) h->opt_sparse_group = atoi(env);
-  env = getenv("MIK_SPARSE_EPILOGUE");
-  if (env) h->opt_sparse_epi = atoi(env) ? 1 : 0;
   env = getenv("MIK_SPARSE_ROWS");
   if (env && (atoi(env) == -1 || atoi(env) == 16 || atoi(env) == 128)) h->opt_sparse_rows = atoi(env);
-  env = getenv("MIK_UPDATE_ATOMIC");
-  if (env) h->opt_update_atomic = atoi(env) ? 1 : 0;
   env = getenv("MIK_UPDATE_REV");
   if (env) h->opt_update_rev = atoi(env) < 0 ? -1 : atoi(env) ? 1 : 0;
   env = getenv("MIK_UPDATE_MAP");
@@ -82,8 +76,6 @@ static int create_one_body(mik_handle* h, int device) {
   if (env) h->opt_panel_stream = atoi(env) < 0 ? -1 : atoi(env) ? 1 : 0;
   env = getenv("MIK_TRI");
   if (env) h->opt_tri = atoi(env) ? 1 : 0;
-  env = getenv("MIK_PREFETCH");
-  if (env) h->opt_prefetch = atoi(env) ? 1 : 0;
   env = getenv("MIK_EXCHANGE");
   if (env) h->opt_exchange = !strcmp(env, "rccl") ? 1 : !strcmp(env, "peer") ? 2 : !strcmp(env, "redundant") ? 3 : 0;
   env = getenv("MIK_ALIAS_DEVICES");
@@ -208,9 +200,9 @@ static int set_group(mik_handle* h, int n) {
     }
     k->is_kid = true;
     k->opt_factor = h->opt_factor, k->opt_sym = h->opt_sym, k->opt_engine = h->opt_engine, k->opt_waves = h->opt_waves;
-    k->opt_chunk = h->opt_chunk, k->opt_symsweep = h->opt_symsweep, k->opt_diag = h->opt_diag, k->opt_update_waves = h->opt_update_waves, k->opt_panel_rows = h->opt_panel_rows, k->opt_panel_stream = h->opt_panel_stream, k->opt_update_map = h->opt_update_map, k->opt_update_rev = h->opt_update_rev, k->opt_update_atomic = h->opt_update_atomic, k->opt_update_deep = h->opt_update_deep, k->opt_pivot256 = h->opt_pivot256, k->opt_update_token = h->opt_update_token, k->opt_update_pf = h->opt_update_pf, k->opt_wide_reserve = h->opt_wide_reserve, k->opt_update_tpb = h->opt_update_tpb, k->opt_lookahead = h->opt_lookahead, k->opt_gate = h->opt_gate, k->opt_fuse_chain = h->opt_fuse_chain, k->opt_early_diag = h->opt_early_diag, k->opt_pinv_fast = h->opt_pinv_fast, k->opt_rhs_overlap = h->opt_rhs_overlap, k->opt_verify = h->opt_verify, k->verify_tol_z = h->verify_tol_z, k->verify_tol_inv = h->verify_tol_inv;
-    k->opt_mw_class = h->opt_mw_class, k->opt_mw_knn_bound = h->opt_mw_knn_bound, k->opt_mw_pivot = h->opt_mw_pivot, k->opt_mw_lds_cap = h->opt_mw_lds_cap, k->opt_pairs = h->opt_pairs, k->opt_tri = h->opt_tri, k->opt_prefetch = h->opt_prefetch, k->opt_symmetrize = h->opt_symmetrize, k->opt_mw_solver = h->opt_mw_solver;
-    k->opt_sparse = h->opt_sparse, k->opt_sparse_lanes = h->opt_sparse_lanes, k->opt_sparse_rows = h->opt_sparse_rows, k->opt_sparse_epi = h->opt_sparse_epi, k->opt_sparse_group = h->opt_sparse_group, k->opt_sort_points = h->opt_sort_points, k->opt_drift_eq = h->opt_drift_eq;
+    k->opt_chunk = h->opt_chunk, k->opt_symsweep = h->opt_symsweep, k->opt_diag = h->opt_diag, k->opt_update_waves = h->opt_update_waves, k->opt_panel_rows = h->opt_panel_rows, k->opt_panel_stream = h->opt_panel_stream, k->opt_update_map = h->opt_update_map, k->opt_update_rev = h->opt_update_rev, k->opt_update_deep = h->opt_update_deep, k->opt_pivot256 = h->opt_pivot256, k->opt_update_token = h->opt_update_token, k->opt_update_pf = h->opt_update_pf, k->opt_wide_reserve = h->opt_wide_reserve, k->opt_update_tpb = h->opt_update_tpb, k->opt_lookahead = h->opt_lookahead, k->opt_gate = h->opt_gate, k->opt_fuse_chain = h->opt_fuse_chain, k->opt_early_diag = h->opt_early_diag, k->opt_pinv_fast = h->opt_pinv_fast, k->opt_rhs_overlap = h->opt_rhs_overlap, k->opt_verify = h->opt_verify, k->verify_tol_z = h->verify_tol_z, k->verify_tol_inv = h->verify_tol_inv;
+    k->opt_mw_class = h->opt_mw_class, k->opt_mw_knn_bound = h->opt_mw_knn_bound, k->opt_mw_pivot = h->opt_mw_pivot, k->opt_mw_lds_cap = h->opt_mw_lds_cap, k->opt_tri = h->opt_tri, k->opt_symmetrize = h->opt_symmetrize, k->opt_mw_solver = h->opt_mw_solver;
+    k->opt_sparse = h->opt_sparse, k->opt_sparse_lanes = h->opt_sparse_lanes, k->opt_sparse_rows = h->opt_sparse_rows, k->opt_sparse_group = h->opt_sparse_group, k->opt_sort_points = h->opt_sort_points, k->opt_drift_eq = h->opt_drift_eq;
     k->opt_pinv_block = h->opt_pinv_block, k->opt_mw_static = h->opt_mw_static, k->opt_mw_knn_lane = h->opt_mw_knn_lane;
     k->custom_fn = h->custom_fn, k->custom_user = h->custom_user;
     h->kids.push_back(k);
@@ -301,8 +293,6 @@ int mik_set_option(mik_handle* h, const char* key, double value) {
   } else if (!strcmp(key, "sparse_group")) {
     if (!(value >= 1.0 && value <= 16.0)) return fail(MIK_EINVAL, "sparse_group must be 1 .. 16");
     h->opt_sparse_group = (int)value;
-  } else if (!strcmp(key, "sparse_epilogue")) {
-    h->opt_sparse_epi = value != 0.0;
   } else if (!strcmp(key, "sparse_rows")) {
     if (value != -1.0 && value != 16.0 && value != 128.0) return fail(MIK_EINVAL, "sparse_rows must be -1 (auto), 16 or 128");
     h->opt_sparse_rows = (int)value;
@@ -311,12 +301,8 @@ int mik_set_option(mik_handle* h, const char* key, double value) {
     h->opt_sparse_lanes = (int)value;
   } else if (!strcmp(key, "drift_eq")) {
     h->opt_drift_eq = value != 0.0;
-  } else if (!strcmp(key, "pairs")) {
-    h->opt_pairs = value != 0.0;
   } else if (!strcmp(key, "tri")) {
     h->opt_tri = value != 0.0;
-  } else if (!strcmp(key, "prefetch")) {
-    h->opt_prefetch = value != 0.0;
   } else if (!strcmp(key, "symmetrize")) {
     h->opt_symmetrize = value != 0.0;
   } else if (!strcmp(key, "waves")) {
@@ -347,8 +333,6 @@ int mik_set_option(mik_handle* h, const char* key, double value) {
   } else if (!strcmp(key, "update_waves")) {
     if (value != 4.0 && value != 8.0) return fail(MIK_EINVAL, "update_waves must be 4 or 8");
     h->opt_update_waves = (int)value;
-  } else if (!strcmp(key, "update_atomic")) {
-    h->opt_update_atomic = value != 0.0;
   } else if (!strcmp(key, "update_rev")) {
     h->opt_update_rev = value < 0.0 ? -1 : value != 0.0 ? 1 : 0;
   } else if (!strcmp(key, "update_map")) {
