@@ -36,7 +36,8 @@ extern "C" {
  *   4 -> 5  mik_grid.cell_count == 0 is an EMPTY range (it used to mean "the whole grid", which is now -1): a caller that
  *           zero-initialises mik_grid must set cell_count = -1.  mik_abi_version() returns the library's value; the Python
  *           loader (pykrige_amd/_lib.py) refuses a library whose version differs from the header it was written against. */
-#define MIK_ABI_VERSION 5
+#define MIK_ABI_VERSION 6
+/*   5 -> 6  mik_timing grew by sparse_ktile + reserved2 (8 bytes appended; earlier fields unchanged). */
 
 #define MIK_OK          0
 #define MIK_EINVAL     (-1) /* bad argument            -> Python ValueError                  */
@@ -157,6 +158,9 @@ typedef struct mik_timing {
   int32_t points_sorted;       /* 1 = the range-aware contraction ran over the points of every launch in Hilbert-curve order (option
                                   "sort_points") */
   double sort_points_ms;       /* the device sort of the points (k_ps_*), when this mik_predict had to run it (part of predict_ms) */
+  int32_t sparse_ktile;        /* stations per candidate / list tile of the range-aware contraction: 16, or 8 (a K step is then a pair of
+                                  list-adjacent 8-station tiles: option "sparse_ktile"; ABI 5 -> 6: appended) ; 0 = dense */
+  int32_t reserved2;
 } mik_timing;
 
 int  mik_device_count(void);
@@ -201,6 +205,10 @@ int  mik_slab_of(int64_t n, int members, int i, int64_t *lo, int64_t *count); /*
  *   [8r, 8r + 8) as rows, the entries beyond as K tiles, then its own groups as a triangle) or an ALIGNED block of 128 rows that is
  *   contracted whole when any of its eight groups is active (128: k_contract_sp; active blocks are ~79 % full at BASELINE config
  *   5).  -1 (default) = 16 wherever 32-bit DMA offsets reach every row (Mp <= 23168), else 128 [MIK_SPARSE_ROWS] ;
+ * "sparse_ktile" 16/8 = range-aware contraction over gathered row groups: stations per candidate / flag / list tile.  8 (round 5): a K step
+ *   of the contraction is a PAIR of list-adjacent 8-station tiles staged into the two halves of the 16-wide LDS tile, a 16-row group is two
+ *   gathered 8-row groups, an odd last entry is half a K step: 718 instead of 780 stations in active tiles at BASELINE config 5 (work ~ n^2:
+ *   -15 %).  Same exact sum (skipped entries are exact zeros of delta) [MIK_SPARSE_KTILE] ;
  * "sparse_group" 1..16 = k_contract_spg's queue order: point blocks per group (a group's tiles run on one XCD, tile position ascending
  *   = longest K loops first, point block fast; default 4) [MIK_SPARSE_GROUP] ;
  * "sort_points" -1/0/1 = range-aware contraction: the points of every launch (one chunk of the resident point list) are put in

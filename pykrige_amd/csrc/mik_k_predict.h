@@ -39,11 +39,14 @@ struct RhsArgs {
   int nIblk, nK16;
   double sill;
   const double* dsc;  // drift equilibration, as in AsmArgs (nullptr = raw drift values)
+  int nKf;               // SP, F8 (round 5, option "sparse_ktile" 8): the flags are per 8 stations, nKf = Mp / 8 their row stride.  The candidates
+                         // stay per 16 stations: right-hand sides are computed and stored in whole 128-byte lines (per 8 stations k_rhs was
+                         // 12 % slower: half-line stores)
   const unsigned* perm;  // SP, nullable: the chunk's points in sorted order -- point t of the chunk is point perm[t] of the WHOLE list;
                          // px / py / pz / extra / zout are then the list's base pointers, not the chunk's (option "sort_points")
 };
 
-template <int MODEL, int NDIM, bool SP = false>
+template <int MODEL, int NDIM, bool SP = false, bool F8 = false>  // F8 (SP only): flags per 8 stations (row stride nKf) instead of per 16
 __global__ void __launch_bounds__(256) k_rhs(RhsArgs a) {
   __shared__ double red[4][MIK_TP];
   const int t0 = blockIdx.x * MIK_TP;
@@ -149,10 +152,14 @@ __global__ void __launch_bounds__(256) k_rhs(RhsArgs a) {
       zacc[q] += cj * v;
       if (SP) nz = nz || v != 0.0;
     }
-    if (SP) {  // 16 lanes = one K tile; every writer writes the same 1
+    if (SP) {  // 16 (8) lanes = one K tile; every writer writes the same 1
       const unsigned long long m = __ballot(nz);
       const int l = threadIdx.x & 63;
-      if ((l & 15) == 0 && ((m >> l) & 0xffffULL) != 0) a.flags[(long)(t0 >> 7) * a.nK16 + (j >> 4)] = 1;
+      if (F8) {
+        if ((l & 7) == 0 && ((m >> l) & 0xffULL) != 0) a.flags[(long)(t0 >> 7) * a.nKf + (j >> 3)] = 1;
+      } else if ((l & 15) == 0 && ((m >> l) & 0xffffULL) != 0) {
+        a.flags[(long)(t0 >> 7) * a.nK16 + (j >> 4)] = 1;
+      }
     }
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -950,9 +957,11 @@ __global__ void __launch_bounds__(64 * 2 * (8 / NAI), 2 * (4 / NAI)) k_contract_
 // ------------------------------------------------------------------------------------------------
 
 // flags -> klist / kcount as k_sp_lists, and the number of 128-row tiles of gathered groups: ceil(nk / 8)
+// h8 (round 5, "sparse_ktile" 8): the flags and the list are per 8 stations; a list POSITION of the contraction is then a PAIR of
+// list-adjacent 8-station tiles (entries 2 w, 2 w + 1 -- one dword), an odd last entry is paired with 0xffff; kcount = positions.
 __global__ void __launch_bounds__(64) k_sp_lists_g(const unsigned char* __restrict__ flags, int nK16,
                                                    unsigned short* __restrict__ klist, int* __restrict__ kcount,
-                                                   int* __restrict__ ntiles) {
+                                                   int* __restrict__ ntiles, int h8 = 0) {
   const int tb = blockIdx.x, lane = threadIdx.x;
   const unsigned char* f = flags + (long)tb * nK16;
   unsigned short* kl = klist + (long)tb * nK16;
@@ -965,6 +974,10 @@ __global__ void __launch_bounds__(64) k_sp_lists_g(const unsigned char* __restri
     nk += __popcll(m);
   }
   if (lane == 0) {
+    if (h8) {
+      if (nk & 1) kl[nk] = (unsigned short)0xffffu;  // (nk odd < nK16, which is even: the slot exists)
+      nk = (nk + 1) >> 1;
+    }
     kcount[tb] = nk;
     ntiles[tb] = (nk + 7) / 8;
   }
@@ -974,6 +987,8 @@ __global__ void __launch_bounds__(64) k_sp_lists_g(const unsigned char* __restri
 // position ascending = longest K loops first, point block fast).  Record (two uint4):
 //   [0] = {tblk << 10 | r, nk, klist[nk - 1], klist[nk - 2]}      [1] = the eight row groups klist[8 r .. 8 r + 7] (u16 each)
 // stats: [0] tiles, [1] off-diagonal K tiles summed over the tiles, [2] (row group, K tile) products of the triangular parts.
+// H8: a position is a dword of the list (two 8-station tiles), the record has three uint4: [1], [2] = the eight positions of the tile.
+template <bool H8 = false>
 __global__ void __launch_bounds__(1024) k_sp_tiles_g(const int* __restrict__ ntiles, const int* __restrict__ kcount,
                                                      const unsigned short* __restrict__ klist, int nK16, int nTblk,
                                                      uint4* __restrict__ recs, int* __restrict__ xoff,
@@ -1035,7 +1050,8 @@ __global__ void __launch_bounds__(1024) k_sp_tiles_g(const int* __restrict__ nti
     }
     const int nk = kcount[tb];
     const unsigned short* kl = klist + (long)tb * nK16;
-    const unsigned k1 = nk >= 1 ? kl[nk - 1] : 0u, k2 = nk >= 2 ? kl[nk - 2] : 0u;
+    const unsigned* kl32 = reinterpret_cast<const unsigned*>(kl);
+    const unsigned k1 = nk >= 1 ? (H8 ? kl32[nk - 1] : (unsigned)kl[nk - 1]) : 0u, k2 = nk >= 2 ? (H8 ? kl32[nk - 2] : (unsigned)kl[nk - 2]) : 0u;
     int w = xbase + goff[gg];
     for (int r = 0; r < nr[q]; ++r) {  // (tiles of the other point blocks beyond nr[q] lie behind this block's last one or belong to them)
       int before = 0, all = 0;
@@ -1044,9 +1060,14 @@ __global__ void __launch_bounds__(1024) k_sp_tiles_g(const int* __restrict__ nti
         all += on;
         if (qq < q) before += on;
       }
-      uint4* out = recs + 2L * (w + before);
+      uint4* out = recs + (H8 ? 3L : 2L) * (w + before);
       out[0] = make_uint4(((unsigned)tb << 10) | (unsigned)r, (unsigned)nk, k1, k2);
-      out[1] = *reinterpret_cast<const uint4*>(kl + 8 * r);  // 16-byte aligned: nK16 is a multiple of 8
+      if (H8) {
+        out[1] = *reinterpret_cast<const uint4*>(kl + 16 * r);  // 32-byte aligned: the list stride is a multiple of 16
+        out[2] = *reinterpret_cast<const uint4*>(kl + 16 * r + 8);
+      } else {
+        out[1] = *reinterpret_cast<const uint4*>(kl + 8 * r);  // 16-byte aligned: nK16 is a multiple of 8
+      }
       w += all;
     }
   }
@@ -1069,14 +1090,23 @@ struct SpgArgs {
 // group's own 16 x 16 square -- its accumulators are final there, and the delta it needs IS that step's B tile in LDS -- instead of
 // from global memory after the K loop: no operand reads in the epilogue (a tenth of the kernel's fabric traffic, two memory round
 // trips per tile).  Measured 1.7 % slower (config 5: 43.1 against 42.4 ms): the sums live in registers through the triangle loop.
-template <int NAI, bool EPI = false>
+// H8 (round 5, option "sparse_ktile" 8): the list is per 8 stations and a list POSITION is a dword = a pair (h0, h1) of list-adjacent
+// 8-station tiles: a K step stages columns 8 h0 .. + 7 into the lower half of the 16-wide LDS tile and 8 h1 .. + 7 into the upper half
+// (the per-lane DMA offset of the lanes that feed the upper half is shifted by 8 (h1 - h0) columns: one v_add + one v_cndmask by a
+// constant lane mask per DMA), a 16-row group is two gathered 8-row groups, and an odd last entry (h1 = 0xffff) is a K step of its
+// lower half alone (the m = 1 MFMAs are skipped) and a row group whose upper eight rows are left out of the epilogue.  Everything else
+// -- positions, tiles of eight positions, the triangle, the queue -- is the 16-station form's.  -15 % work at BASELINE config 5 by the
+// CPU model (profiles/r04b_sparse_granularity_model_cpu.txt: 718 instead of 780 stations in active tiles, work ~ n^2).
+template <int NAI, bool EPI = false, bool H8 = false>
 __global__ void __launch_bounds__(64 * 2 * (8 / NAI), 2 * (4 / NAI)) k_contract_spg(SpgArgs a) {
+  static_assert(!(EPI && H8), "the LDS epilogue exists for the 16-station form only");
   static_assert(NAI == 2, "8 waves: 4 wave-rows of two 16-row groups x 2 wave-columns of 64 points");
   constexpr int WROWS = 16 * NAI, NWM = 128 / WROWS;
   constexpr int NTHR = 64 * 2 * (MIK_BM / WROWS), PROWS = NTHR / 8, NPASS = MIK_BM / PROWS;
   constexpr unsigned LDS_PASS = PROWS * MIK_BK * 8, LDS_BUF = MIK_BM * MIK_BK * 8;
   __shared__ GemmSmem sm;
-  __shared__ uint4 srec[4];  // two tile records: the current tile's and the next one's
+  constexpr int RW = H8 ? 3 : 2;  // uint4 per tile record
+  __shared__ uint4 srec[2 * RW];  // two tile records: the current tile's and the next one's
   __shared__ int sst[4];     // thread 0's queue state: [0] sequences tried, [1] first record and [2] record count of the current sequence
   unsigned xcc;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -1108,7 +1138,8 @@ __global__ void __launch_bounds__(64 * 2 * (8 / NAI), 2 * (4 / NAI)) k_contract_
   {
     const int lane = (int)(threadIdx.x & 63), tid = wave * 64 + lane;
     const int lrow = tid >> 3, slot = tid & 7;
-    boffb = (unsigned)(((long)lrow * a.ldb + ((slot ^ ((lrow >> 1) & 7)) << 1)) * 8);
+    // (H8: the source slot without its half bit, as for aoffb -- see stage())
+    boffb = (unsigned)(((long)lrow * a.ldb + (((slot ^ ((lrow >> 1) & 7)) & (H8 ? 3 : 7)) << 1)) * 8);
     const int kq = lane >> 4, ia = lane & 3, jb = lane & 15;
     aoff = (wm * WROWS + ia) * MIK_BK + ((kq ^ (ia & 2)) << 1);          // m = 1: (4 + kq) ^ (ia & 2) = 4 + (kq ^ (ia & 2))
     boff = (wn * 64 + jb) * MIK_BK + ((kq ^ ((jb >> 1) & 7)) << 1);      // m = 1: ((4 + kq) ^ s) << 1 = ((kq ^ s) << 1) ^ 8
@@ -1123,18 +1154,43 @@ __global__ void __launch_bounds__(64 * 2 * (8 / NAI), 2 * (4 / NAI)) k_contract_
     const unsigned w = gi < 2 ? r1.x : gi < 4 ? r1.y : gi < 6 ? r1.z : r1.w;
     return (w >> (16 * (gi & 1))) & 0xffffu;
   };
-  auto stage = [&](const double* Bgu, int k, int b) {
+  auto pair_of = [](const uint4& r1, const uint4& r2, int gi) -> unsigned {  // H8: the dword (h0 | h1 << 16) of position gi of the tile
+    return gi == 0 ? r1.x : gi == 1 ? r1.y : gi == 2 ? r1.z : gi == 3 ? r1.w : gi == 4 ? r2.x : gi == 5 ? r2.y : gi == 6 ? r2.z : r2.w;
+  };
+  // lanes whose DMA piece lands in the UPPER half (k 8 .. 15) of a row of the LDS tile: source slot c = slot ^ swizzle >= 4.  A image:
+  // swizzle = row & 2 -> bit 2 of the lane; B image: swizzle = (row >> 1) & 7 -> bit 2 of the lane XOR bit 0 of the wave (row bit 3)
+  const unsigned long long upA = 0xF0F0F0F0F0F0F0F0ULL, upB = (wave & 1) ? 0x0F0F0F0F0F0F0F0FULL : 0xF0F0F0F0F0F0F0F0ULL;
+  auto sel = [](unsigned lo, unsigned hi, unsigned long long m) -> unsigned {  // per lane: m bit set ? hi : lo
+    unsigned r;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(lo), "v"(hi), "s"(m));  // (not volatile: a pure function of its operands)
+    return r;
+  };
+  // kc: the K position -- 16 k (16-station form) or the pair code h0 | h1 << 16 (H8)
+  auto stage = [&](const double* Bgu, int kc, int b) {
+    int k = kc;
+    unsigned dk = 0u;  // H8: byte shift of the upper-half lanes' source (their offsets carry no half bit): 8 (h1 - h0) columns; an odd
+                       // tail's h1 = 0xffff: the lower half once more (its m = 1 products are skipped)
+    if (H8) {
+      const unsigned h0 = (unsigned)kc & 0xffffu, h1 = (unsigned)kc >> 16;
+      k = 8 * (int)h0;
+      dk = (h1 == 0xffffu) ? 0u : 64u * (h1 - h0);
+    }
     const double* abase = uniform_ptr(Agu + k);
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
       const double* bbase = uniform_ptr(Bgu + (long)(PROWS * p) * a.ldb + k);
       const unsigned la = ldsA + b * LDS_BUF + p * LDS_PASS, lb = ldsB + b * LDS_BUF + p * LDS_PASS;
+      unsigned va = aoffb[p], vb = boffb;
+      if (H8) {
+        va = sel(va, va + dk, upA);
+        vb = sel(vb, vb + dk, upB);
+      }
       if (p == 0) {
-        asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(aoffb[p]), "s"(abase), "s"(la) : "memory");
-        asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(boffb), "s"(bbase), "s"(lb) : "memory");
+        asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(va), "s"(abase), "s"(la) : "memory");
+        asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(vb), "s"(bbase), "s"(lb) : "memory");
       } else {
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(aoffb[p]), "s"(abase), "s"(la) : "memory");
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(boffb), "s"(bbase), "s"(lb) : "memory");
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(va), "s"(abase), "s"(la) : "memory");
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(vb), "s"(bbase), "s"(lb) : "memory");
       }
     }
   };
@@ -1149,55 +1205,61 @@ __global__ void __launch_bounds__(64 * 2 * (8 / NAI), 2 * (4 / NAI)) k_contract_
   auto fetch_next = [&]() {
     if (threadIdx.x == 0) {
       const int steal = sst[0];
-      uint4 r0 = make_uint4(REC_END, 0u, 0u, 0u), r1 = make_uint4(0u, 0u, 0u, 0u);
+      uint4 r0 = make_uint4(REC_END, 0u, 0u, 0u), r1 = make_uint4(0u, 0u, 0u, 0u), r2 = make_uint4(0u, 0u, 0u, 0u);
       if (steal < 8) {
         const unsigned seq = fetch((xcd + steal) & 7);
         if (seq < (unsigned)sst[2]) {
-          const uint4* rp = a.recs + 2L * (sst[1] + (long)seq);
+          const uint4* rp = a.recs + (long)RW * (sst[1] + (long)seq);
           r0 = rp[0];
           r1 = rp[1];
+          if (H8) r2 = rp[2];
         } else {
           r0.x = REC_MORE;
         }
       }
-      srec[2 * (cur ^ 1)] = r0;
-      srec[2 * (cur ^ 1) + 1] = r1;
+      srec[RW * (cur ^ 1)] = r0;
+      srec[RW * (cur ^ 1) + 1] = r1;
+      if (H8) srec[RW * (cur ^ 1) + 2] = r2;
     }
   };
   auto acquire = [&]() -> bool {  // one barrier; block-uniform result
-    if (threadIdx.x == 0 && srec[2 * (cur ^ 1)].x == REC_MORE) {
-      uint4 r0 = make_uint4(REC_END, 0u, 0u, 0u), r1 = make_uint4(0u, 0u, 0u, 0u);
+    if (threadIdx.x == 0 && srec[RW * (cur ^ 1)].x == REC_MORE) {
+      uint4 r0 = make_uint4(REC_END, 0u, 0u, 0u), r1 = make_uint4(0u, 0u, 0u, 0u), r2 = make_uint4(0u, 0u, 0u, 0u);
       int steal = sst[0];
       while (++steal < 8) {
         const int xq = (xcd + steal) & 7;  // help the next XCD's sequence
         const int qlo = a.xoff[xq], qcnt = a.xoff[xq + 1] - qlo;
         const unsigned seq = fetch(xq);
         if (seq < (unsigned)qcnt) {
-          const uint4* rp = a.recs + 2L * (qlo + (long)seq);
+          const uint4* rp = a.recs + (long)RW * (qlo + (long)seq);
           r0 = rp[0];
           r1 = rp[1];
+          if (H8) r2 = rp[2];
           sst[1] = qlo;
           sst[2] = qcnt;
           break;
         }
       }
       sst[0] = steal;
-      srec[2 * (cur ^ 1)] = r0;
-      srec[2 * (cur ^ 1) + 1] = r1;
+      srec[RW * (cur ^ 1)] = r0;
+      srec[RW * (cur ^ 1) + 1] = r1;
+      if (H8) srec[RW * (cur ^ 1) + 2] = r2;
     }
     __syncthreads();
     cur ^= 1;
-    return __builtin_amdgcn_readfirstlane(srec[2 * cur].x) != REC_END;
+    return __builtin_amdgcn_readfirstlane(srec[RW * cur].x) != REC_END;
   };
   // the current tile's state: block- or wave-uniform values in scalar registers
   int tblk, rpos, n, ksec, erow[NAI];
+  int erow1[NAI];    // H8: first row of the upper eight rows of group ai (8 h1), -1 when the position's h1 is missing; erow = 8 h0
+  bool half_last;    // H8: the list's last position (w = n - 1) holds one 8-station tile only
   const mik_cu32_t* ksrc;  // the point block's list from this tile's first group on (16-byte aligned), as dwords in the CONSTANT address
                            // space: a uniform load from there is a scalar load (s_load_dword: no vector registers, no vmcnt); the list
                            // was written by an earlier kernel and is not modified during this one
   const double* Bgu;
-  auto list_at = [&](int i) -> int { return (int)((ksrc[i >> 1] >> (16 * (i & 1))) & 0xffffu); };
+  auto list_at = [&](int i) -> int { return H8 ? (int)ksrc[i] : (int)((ksrc[i >> 1] >> (16 * (i & 1))) & 0xffffu); };
   auto adopt = [&]() {  // srec -> the state above, first K tile into buffer 1 (nothing is waited for)
-    const uint4 r0 = srec[2 * cur], r1 = srec[2 * cur + 1];
+    const uint4 r0 = srec[RW * cur], r1 = srec[RW * cur + 1], r2 = H8 ? srec[RW * cur + 2] : srec[RW * cur + 1];
     const unsigned tile = __builtin_amdgcn_readfirstlane(r0.x);
     tblk = (int)(tile >> 10);
     rpos = (int)(tile & 1023u);
@@ -1206,6 +1268,7 @@ __global__ void __launch_bounds__(64 * 2 * (8 / NAI), 2 * (4 / NAI)) k_contract_
     n = nk - g0;  // K tiles of this tile: n - 8 off-diagonal ones, then its own min(n, 8) groups
     ksec = __builtin_amdgcn_readfirstlane((int)r0.w);
     const int ng = n < 8 ? n : 8;
+    half_last = H8 && ((unsigned)kfirst >> 16) == 0xffffu;
     {  // byte offsets (relative to A_inv) of this thread's two staged rows
       const int tid = wave * 64 + lane_now(), lrow = tid >> 3, slot = tid & 7;
 #pragma unroll
@@ -1213,19 +1276,32 @@ __global__ void __launch_bounds__(64 * 2 * (8 / NAI), 2 * (4 / NAI)) k_contract_
         const int R = lrow + PROWS * p, s = R >> 4;
         int gi = (s >> 1) + 4 * (s & 1);
         gi = gi < ng ? gi : ng - 1;  // a short last tile: the missing groups alias its last one (their accumulators stay zero)
-        const long grow = 16L * (long)group_of(r1, gi) + (R & 15);
-        aoffb[p] = (unsigned)((grow * a.lda + ((slot ^ (lrow & 2)) << 1)) * 8);
+        long grow;
+        if (H8) {
+          const unsigned pc = pair_of(r1, r2, gi), h0 = pc & 0xffffu, h1 = pc >> 16;
+          grow = 8L * (long)(((R & 8) && h1 != 0xffffu) ? h1 : h0) + (R & 7);  // (a missing upper half aliases the lower one: left out of the epilogue)
+        } else {
+          grow = 16L * (long)group_of(r1, gi) + (R & 15);
+        }
+        // H8: the source slot WITHOUT its half bit -- stage() adds the upper half's column shift to the lanes of the upper half
+        aoffb[p] = (unsigned)((grow * a.lda + (((H8 ? (slot & 3) : slot) ^ (lrow & 2)) << 1)) * 8);
       }
     }
 #pragma unroll
     for (int ai = 0; ai < NAI; ++ai) {
       int gi = wm + 4 * ai;
       gi = gi < ng ? gi : ng - 1;
-      erow[ai] = __builtin_amdgcn_readfirstlane(16 * (int)group_of(r1, gi));  // wave-uniform (wm)
+      if (H8) {
+        const unsigned pc = pair_of(r1, r2, gi), h0 = pc & 0xffffu, h1 = pc >> 16;
+        erow[ai] = __builtin_amdgcn_readfirstlane(8 * (int)h0);
+        erow1[ai] = __builtin_amdgcn_readfirstlane(h1 == 0xffffu ? -1 : 8 * (int)h1);
+      } else {
+        erow[ai] = __builtin_amdgcn_readfirstlane(16 * (int)group_of(r1, gi));  // wave-uniform (wm)
+      }
     }
-    ksrc = (const mik_cu32_t*)(uintptr_t)(a.klist + (long)tblk * a.nK16 + g0);
+    ksrc = (const mik_cu32_t*)(uintptr_t)(a.klist + (long)tblk * a.nK16 + (H8 ? 2 * g0 : g0));
     Bgu = uniform_ptr(a.Bt + (long)tblk * MIK_BN * a.ldb);
-    stage(Bgu, 16 * kfirst, 1);
+    stage(Bgu, H8 ? kfirst : 16 * kfirst, 1);
   };
   if (threadIdx.x == 0) {
     const int lo = a.xoff[xcd];
@@ -1249,14 +1325,16 @@ __global__ void __launch_bounds__(64 * 2 * (8 / NAI), 2 * (4 / NAI)) k_contract_
     __syncthreads();
     fetch_next();
     for (; w >= 8; --w) {
-      stage(Bgu, 16 * kn, buf ^ 1);
+      stage(Bgu, H8 ? kn : 16 * kn, buf ^ 1);
       int kn2 = 0;
       if (w >= 2) kn2 = list_at(w - 2);  // scalar load, in flight during this step's MFMAs
+      const bool skip_hi = H8 && half_last && w == n - 1;  // an odd tail: only its lower eight stations exist
       const double* as = &sm.As[buf][0][0] + aoff;
       const double* bs = &sm.Bs[buf][0][0];
       const int bo[2] = {boff, boff_hi()};
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
+        if (H8 && m == 1 && skip_hi) continue;
         double2 fa[4 * NAI], fb[4];
 #pragma unroll
         for (int x = 0; x < 4 * NAI; ++x) fa[x] = *reinterpret_cast<const double2*>(as + 8 * m + 4 * x * MIK_BK);
@@ -1286,9 +1364,10 @@ __global__ void __launch_bounds__(64 * 2 * (8 / NAI), 2 * (4 / NAI)) k_contract_
     // loop reaches its own 16 x 16 square (everything above it counts twice)
     double cs[4] = {0.0, 0.0, 0.0, 0.0};  // EPI: this lane's sums over its rows of delta_ti W_it, points wn * 64 + bi * 16 + (lane & 15)
     for (; w >= 0; --w) {
-      if (w >= 1) stage(Bgu, 16 * kn, buf ^ 1);
+      if (w >= 1) stage(Bgu, H8 ? kn : 16 * kn, buf ^ 1);
       int kn2 = 0;
       if (w >= 2) kn2 = list_at(w - 2);
+      const bool skip_hi = H8 && half_last && w == n - 1;
       const double* as = &sm.As[buf][0][0] + aoff;
       const double* bs = &sm.Bs[buf][0][0];
       const int bo[2] = {boff, boff_hi()};
@@ -1301,6 +1380,7 @@ __global__ void __launch_bounds__(64 * 2 * (8 / NAI), 2 * (4 / NAI)) k_contract_
       if (w >= wm) {
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
+          if (H8 && m == 1 && skip_hi) continue;
           double2 fb[4];
 #pragma unroll
           for (int x = 0; x < 4; ++x) fb[x] = *reinterpret_cast<const double2*>(bs + bo[m] + 16 * x * MIK_BK);
@@ -1347,9 +1427,9 @@ __global__ void __launch_bounds__(64 * 2 * (8 / NAI), 2 * (4 / NAI)) k_contract_
     }
     // the next tile: record -> LDS (one barrier), its first K tile on the way to buffer 1 while this tile's epilogue runs
     const int t0 = tblk * MIK_BN, rp = rpos;
-    int er[NAI];
+    int er[NAI], er1[NAI];
 #pragma unroll
-    for (int ai = 0; ai < NAI; ++ai) er[ai] = erow[ai];
+    for (int ai = 0; ai < NAI; ++ai) er[ai] = erow[ai], er1[ai] = H8 ? erow1[ai] : 0;
     have = acquire();
     if (have) adopt();
     // epilogue (k_contract's): part[r][t] = sum over this tile's rows of delta_ti W_it
@@ -1371,7 +1451,11 @@ __global__ void __launch_bounds__(64 * 2 * (8 / NAI), 2 * (4 / NAI)) k_contract_
 #pragma unroll
         for (int ai = 0; ai < NAI; ++ai)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) bv[b2][ai * 4 + r] = brow[er[ai] + 4 * r];
+          for (int r = 0; r < 4; ++r) {
+            if (!H8) bv[b2][ai * 4 + r] = brow[er[ai] + 4 * r];
+            else if (r < 2) bv[b2][ai * 4 + r] = brow[er[ai] + 4 * r];                           // rows lq + 4 r < 8: the lower eight (8 h0 ..)
+            else bv[b2][ai * 4 + r] = er1[ai] >= 0 ? brow[er1[ai] + 4 * r - 8] : 0.0;           // the upper eight (8 h1 ..), or none
+          }
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

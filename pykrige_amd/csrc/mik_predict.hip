@@ -69,6 +69,11 @@ int one_predict(mik_handle* h) {
   const int nK16 = Mp / 16;
   // tiles of gathered 16-row groups (k_contract_spg) wherever 32-bit LDS-DMA offsets reach every row of the inverse
   const bool gathered = sparse && h->opt_sparse_rows != 128 && (double)Mp * (double)Mp * 8.0 < 4294967296.0;
+  // "sparse_ktile" 8 (round 5; with gathered row groups only): flags and lists per 8 stations (candidates stay per 16), a K step = a pair of list-adjacent
+  // 8-station tiles (k_contract_spg H8).  nKt = tiles per point block in the units of this launch's lists.
+  const bool h8 = gathered && h->opt_sparse_ktile == 8;
+  const int nKt = h8 ? Mp / 8 : nK16;
+  h->tm.sparse_ktile = !sparse ? 0 : h8 ? 8 : 16;
   h->tm.sparse = sparse ? 1 : 0;
   h->tm.sparse_rows = sparse ? (gathered ? 16 : 128) : 0;
   h->tm.stations_sorted = h->factor_sorted ? 1 : 0;
@@ -113,12 +118,12 @@ int one_predict(mik_handle* h) {
     const size_t nTb = (size_t)chunk / 128;
     for (int L = 0; L < (lanes2 ? 2 : 1); ++L) {
       MIKC(lane[L].cand->ensure(nTb * nK16));
-      MIKC(lane[L].flags->ensure(nTb * nK16));
-      MIKC(lane[L].klist->ensure(sizeof(unsigned short) * nTb * nK16));
+      MIKC(lane[L].flags->ensure(nTb * nKt));
+      MIKC(lane[L].klist->ensure(sizeof(unsigned short) * nTb * nKt));
       MIKC(lane[L].kcount->ensure(sizeof(int) * nTb));
       MIKC(lane[L].nrows->ensure(sizeof(int) * nTb));
       if (gathered) {
-        MIKC(lane[L].recs->ensure(32 * nTb * nIblk));  // ceil(nk / 8) <= nK16 / 8 = nIblk tiles per point block
+        MIKC(lane[L].recs->ensure((h8 ? 48 : 32) * nTb * nIblk));  // ceil(nk / 8) <= nK16 / 8 = nIblk tiles per point block
       } else {
         MIKC(lane[L].rows->ensure(sizeof(unsigned short) * nTb * nIblk));
         MIKC(lane[L].rstart->ensure(sizeof(unsigned short) * nTb * nIblk));
@@ -196,6 +201,7 @@ int one_predict(mik_handle* h) {
       a.flags = ln.flags->as<unsigned char>();
       a.nIblk = nIblk;
       a.nK16 = nK16;
+      a.nKf = nKt;
       a.sill = h->v.p0 + h->v.p2;
       if (perm_all) {  // sorted order: the chunk's points are reached through perm, from the list's base pointers
         a.perm = perm_all + t0;
@@ -217,9 +223,13 @@ int one_predict(mik_handle* h) {
       }
       hipLaunchKernelGGL(k_sp_cand, dim3(palloc / 128), dim3(128), 0, ss, cx, cy, cz, nvalid, (const double*)h->sbox.as<double>(), nK16,
                          h->N / 16, (h->M + 15) / 16, radius, ln.cand->as<unsigned char>(), a.perm, gathered ? 0 : 1);
-      HIPC(hipMemsetAsync(ln.flags->p, 0, (size_t)(palloc / 128) * nK16, ss));
+      HIPC(hipMemsetAsync(ln.flags->p, 0, (size_t)(palloc / 128) * nKt, ss));
       HIPC(hipEventRecord(h->evpool[2 + 4 * c], ss));
-      if (h->geo) hipLaunchKernelGGL((k_rhs<3, 1, true>), dim3(palloc / MIK_TP), dim3(256), 0, ss, a);
+      if (h8) {
+        if (h->geo) hipLaunchKernelGGL((k_rhs<3, 1, true, true>), dim3(palloc / MIK_TP), dim3(256), 0, ss, a);
+        else if (h->ndim == 3) hipLaunchKernelGGL((k_rhs<3, 3, true, true>), dim3(palloc / MIK_TP), dim3(256), 0, ss, a);
+        else hipLaunchKernelGGL((k_rhs<3, 2, true, true>), dim3(palloc / MIK_TP), dim3(256), 0, ss, a);
+      } else if (h->geo) hipLaunchKernelGGL((k_rhs<3, 1, true>), dim3(palloc / MIK_TP), dim3(256), 0, ss, a);
       else if (h->ndim == 3) hipLaunchKernelGGL((k_rhs<3, 3, true>), dim3(palloc / MIK_TP), dim3(256), 0, ss, a);
       else hipLaunchKernelGGL((k_rhs<3, 2, true>), dim3(palloc / MIK_TP), dim3(256), 0, ss, a);
       HIPC(hipEventRecord(h->evpool[3 + 4 * c], ss));
@@ -254,11 +264,16 @@ int one_predict(mik_handle* h) {
       const SpLane& ln = lane[lanes2 ? (c & 1) : 0];
       hipStream_t sc = ln.st;  // (shadows the dense path's stream: this launch lives on its lane's)
       if (gathered) {
-        hipLaunchKernelGGL(k_sp_lists_g, dim3(nTb), dim3(64), 0, sc, (const unsigned char*)ln.flags->as<unsigned char>(), nK16,
-                           ln.klist->as<unsigned short>(), ln.kcount->as<int>(), ln.nrows->as<int>());
-        hipLaunchKernelGGL(k_sp_tiles_g, dim3(1), dim3(1024), 0, sc, (const int*)ln.nrows->as<int>(), (const int*)ln.kcount->as<int>(),
-                           (const unsigned short*)ln.klist->as<unsigned short>(), nK16, nTb, ln.recs->as<uint4>(), ln.xoff->as<int>(),
-                           h->sp_stats.as<unsigned long long>() + 4 * c, h->opt_sparse_group);
+        hipLaunchKernelGGL(k_sp_lists_g, dim3(nTb), dim3(64), 0, sc, (const unsigned char*)ln.flags->as<unsigned char>(), nKt,
+                           ln.klist->as<unsigned short>(), ln.kcount->as<int>(), ln.nrows->as<int>(), h8 ? 1 : 0);
+        if (h8)
+          hipLaunchKernelGGL(k_sp_tiles_g<true>, dim3(1), dim3(1024), 0, sc, (const int*)ln.nrows->as<int>(), (const int*)ln.kcount->as<int>(),
+                             (const unsigned short*)ln.klist->as<unsigned short>(), nKt, nTb, ln.recs->as<uint4>(), ln.xoff->as<int>(),
+                             h->sp_stats.as<unsigned long long>() + 4 * c, h->opt_sparse_group);
+        else
+          hipLaunchKernelGGL(k_sp_tiles_g<false>, dim3(1), dim3(1024), 0, sc, (const int*)ln.nrows->as<int>(), (const int*)ln.kcount->as<int>(),
+                             (const unsigned short*)ln.klist->as<unsigned short>(), nK16, nTb, ln.recs->as<uint4>(), ln.xoff->as<int>(),
+                             h->sp_stats.as<unsigned long long>() + 4 * c, h->opt_sparse_group);
       } else {
         hipLaunchKernelGGL(k_sp_lists, dim3(nTb), dim3(64), 0, sc, (const unsigned char*)ln.flags->as<unsigned char>(), nK16, nIblk,
                            ln.klist->as<unsigned short>(), ln.kcount->as<int>(), ln.rows->as<unsigned short>(),
@@ -295,12 +310,13 @@ int one_predict(mik_handle* h) {
         ga.ldb = Mp;
         ga.part = sa.part;
         ga.palloc = palloc;
-        ga.nK16 = nK16;
+        ga.nK16 = nKt;
         ga.klist = sa.klist;
         ga.recs = ln.recs->as<uint4>();
         ga.xoff = sa.xoff;
         ga.queue = sa.queue;
-        hipLaunchKernelGGL((k_contract_spg<2, false>), dim3((unsigned)std::min<long>(2L * h->n_cu, (long)nTb * nIblk)), dim3(512), 0, sc, ga);
+        if (h8) hipLaunchKernelGGL((k_contract_spg<2, false, true>), dim3((unsigned)std::min<long>(2L * h->n_cu, (long)nTb * nIblk)), dim3(512), 0, sc, ga);
+        else hipLaunchKernelGGL((k_contract_spg<2, false>), dim3((unsigned)std::min<long>(2L * h->n_cu, (long)nTb * nIblk)), dim3(512), 0, sc, ga);
       } else {
         hipLaunchKernelGGL((k_contract_sp<2>), dim3((unsigned)std::min<long>(2L * h->n_cu, (long)nTb * nIblk)), dim3(512), 0, sc, sa);
       }

@@ -193,11 +193,12 @@ def test_point_sort_restated_in_numpy():
 
 
 # ---------------------------------------------------------------------------------------------- GPU
-def _run(m, style, args, sparse, chunk=None, rows=None, lanes=1, **kw):
+def _run(m, style, args, sparse, chunk=None, rows=None, lanes=1, ktile=8, **kw):
     h = m._get_handle()
     h.set_option("sparse", sparse)
     h.set_option("sparse_rows", -1 if rows is None else rows)
     h.set_option("sparse_lanes", lanes)
+    h.set_option("sparse_ktile", ktile)  # round 5: 8 = the default (a K step is a pair of 8-station tiles), 16 = round 4's tiles
     if chunk:
         h.set_option("chunk", chunk)
     z, ss = m.execute(style, *args, **kw)
@@ -252,19 +253,24 @@ def test_sparse_contraction_against_oracle_and_dense(case):
     zr, sr = ko.execute(st, "grid", *axes)
     zd, sd, td = _run(m, "grid", axes, 0)
     assert td["sparse"] == 0 and td["stations_sorted"] == 0
-    for chunk, rows in ((131072, None), (2048, None), (131072, 128), (2048, 16)):
-        zs, ss, ts = _run(m, "grid", axes, 1, chunk=chunk, rows=rows)
+    for chunk, rows, ktile in ((131072, None, 8), (2048, None, 8), (131072, 128, 8), (2048, 16, 8), (131072, 16, 16), (2048, None, 16)):
+        zs, ss, ts = _run(m, "grid", axes, 1, chunk=chunk, rows=rows, ktile=ktile)
         assert ts["sparse"] == 1 and ts["stations_sorted"] == 1
         assert ts["sparse_rows"] == (rows or 16)  # gathered 16-row groups are the default
+        assert ts["sparse_ktile"] == (16 if rows == 128 else ktile)  # (aligned row blocks keep their 16-station lists)
         assert 0 < ts["sparse_tiles"] <= ts["sparse_tiles_dense"]
         assert np.abs(zs - zr).max() <= Z_TOL and np.abs(ss - sr).max() <= SS_TOL, (np.abs(zs - zr).max(), np.abs(ss - sr).max())
         assert np.abs(zs - zd).max() <= Z_TOL and np.abs(ss - sd).max() <= SS_TOL
         if rows == 128:
             t128 = ts
-        elif chunk == 131072:
+        elif chunk == 131072 and ktile == 16:
             t16 = ts
-    # gathered groups never execute more than aligned blocks do: fewer or equal off-diagonal K tiles and triangle products
+        elif chunk == 131072:
+            t8 = ts
+    # gathered groups never execute more than aligned blocks do: fewer or equal off-diagonal K tiles and triangle products;
+    # and pairs of 8-station tiles never more K steps than 16-station tiles (a pair covers at most the stations of two of those)
     assert t16["sparse_ktiles"] <= t128["sparse_ktiles"] and t16["sparse_diag_products"] <= t128["sparse_diag_products"], (t16, t128)
+    assert t8["sparse_ktiles"] <= t16["sparse_ktiles"] and t8["sparse_tiles"] <= t16["sparse_tiles"], (t8, t16)
     # two launch lanes (two streams, two sets of work buffers; the second lane waits for the sort of the points)
     m._get_handle().set_option("sort_points", 1)
     zs, ss, ts = _run(m, "grid", axes, 1, chunk=1024, lanes=2)
