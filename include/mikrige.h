@@ -389,6 +389,8 @@ int  mik_get_points(mik_handle *h, double *px_out, double *py_out, double *pz_ou
                                             (diagnostic: what mik_set_grid generated), mik_points_resident() doubles each */
 int  mik_get_timing(mik_handle *h, mik_timing *out);   /* device group: the leader's phases, predict_ms = slowest member */
 int  mik_get_device_timing(mik_handle *h, int member, mik_timing *out); /* one member of a device group (0 = the handle's own device) */
+int  mik_selftest_exp(int device, const double *x, double *out, int n); /* out[i] = the library's 19-instruction exp (x[i] <= 0: the moving
+                                                                          window's matrix set-up), for comparison with the caller's exp */
 int  mik_selftest_mfma(int device); /* 0 if the v_mfma_f64_4x4x4_4b_f64 (and 16x16x4) fragment layouts are what the kernels assume */
 
 /* Multi-GPU (one process per GPU): grid points are sharded by the caller; the factored matrix is

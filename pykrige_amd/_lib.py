@@ -106,6 +106,7 @@ SIGNATURES = {
     "mik_get_points": (C.c_int, [C.c_void_p, _dp, _dp, _dp]),
     "mik_get_timing": (C.c_int, [C.c_void_p, C.POINTER(MikTiming)]),
     "mik_selftest_mfma": (C.c_int, [C.c_int]),
+    "mik_selftest_exp": (C.c_int, [C.c_int, _dp, _dp, C.c_int]),
     "mik_comm_unique_id": (C.c_int, [C.c_char_p]),
     "mik_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_char_p]),
     "mik_bcast_factor": (C.c_int, [C.c_void_p, C.c_int]),
@@ -465,3 +466,11 @@ def selftest_exchange(members, init_limit_s, bcast_limit_s):
 
 def selftest_mfma(device=0):
     check(load().mik_selftest_mfma(int(device)))
+
+
+def selftest_exp(x, device=0):
+    """The library's 19-instruction exponential (exp_neg_lean: the moving window's matrix set-up) evaluated on the device at x (<= 0)."""
+    x = _f64(x).ravel()
+    out = np.empty_like(x)
+    check(load().mik_selftest_exp(int(device), _ptr(x), _ptr(out), int(x.size)))
+    return out

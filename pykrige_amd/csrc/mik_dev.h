@@ -36,15 +36,67 @@ struct Vario {
   double sa, sb; // spherical: 3/(2 range), 1/(2 range^3)
 };
 
+// exp(x) for x <= 0 in 19 instructions (round 5): Cody-Waite reduction by ln 2 (the high part has 21 trailing zero bits: n ln2_hi is exact
+// for |n| < 2^11), degree-13 Taylor polynomial on |r| <= ln 2 / 2 (remainder r^14 / 14! < 5e-18), v_ldexp_f64.  Within 1 ulp of the
+// library's exp (tests/test_hip_parity.py::test_lean_exp...); that one is ~45 instructions plus its 64-bit literals, and the moving
+// window's set-up evaluates it once per register-tile element (5 800 times per point at k = 100: half of the kernel's instructions).
+// (The constants are handed to the FMAs as SCALAR register pairs -- inline asm, "s" operands: a v_fma_f64 takes no 64-bit literal, and left
+// to itself hipcc materialises every coefficient with two v_mov_b32 per use: 26 vector moves per call beside 16 FMAs.)
+__device__ __forceinline__ double fma_sc(double a, double b, double c_scalar) {  // a * b + c, c wave-uniform
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c_scalar));
+  return d;
+}
+// The sixteen constants, read ONCE per kernel from constant memory (scalar loads) and kept in scalar registers: materialised per call they were
+// 28 s_mov_b32 beside the 19 vector instructions.
+struct ExpTab {
+  double log2e, ln2hi, ln2lo, c[13];  // c[k] = 1 / (13 - k)!  for k = 0 .. 12  (c[11] = 1/2, c[12] = 1 is folded: see below)
+};
+static __constant__ double MIK_EXP_TAB[16] = {1.44269504088896338700e+00, -6.93147180369123816490e-01, -1.90821492927058770002e-10,
+                                              1.6059043836821613e-10, 2.08767569878681e-09, 2.505210838544172e-08, 2.755731922398589e-07,
+                                              2.7557319223985893e-06, 2.48015873015873e-05, 1.984126984126984e-04, 1.388888888888889e-03,
+                                              8.333333333333333e-03, 4.1666666666666664e-02, 1.6666666666666666e-01, 0.5, 1.0};
+__device__ __forceinline__ ExpTab exp_tab_load() {
+  ExpTab t;
+  const double* q = MIK_EXP_TAB;
+  t.log2e = q[0], t.ln2hi = q[1], t.ln2lo = q[2];
+#pragma unroll
+  for (int k = 0; k < 13; ++k) t.c[k] = q[3 + k];
+  // opaque to the optimiser: otherwise it folds the known initialisers back into literals and re-materialises them at every use
+  asm volatile("" : "+s"(t.log2e), "+s"(t.ln2hi), "+s"(t.ln2lo));
+#pragma unroll
+  for (int k = 0; k < 12; ++k) asm volatile("" : "+s"(t.c[k]));
+  return t;
+}
+__device__ __forceinline__ double exp_neg_lean(double x, const ExpTab& T) {
+  double t;
+  asm("v_mul_f64 %0, %1, %2" : "=v"(t) : "s"(T.log2e), "v"(x));
+  const double n = __builtin_rint(t);
+  double r;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(n), "s"(T.ln2hi), "v"(x));
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(n), "s"(T.ln2lo), "v"(r));
+  double p;
+  asm("v_mul_f64 %0, %1, %2" : "=v"(p) : "s"(T.c[0]), "v"(r));   // r / 13!  (one scalar operand per instruction)
+  asm("v_add_f64 %0, %1, %2" : "=v"(p) : "s"(T.c[1]), "v"(p));   // + 1 / 12!
+#pragma unroll
+  for (int k = 2; k < 12; ++k) p = fma_sc(p, r, T.c[k]);         // 1 / 11! .. 1 / 2!
+  p = __builtin_fma(p, r, 1.0);                                    // (1.0 is an inline constant)
+  p = __builtin_fma(p, r, 1.0);
+  return ldexp(p, (int)n);
+}
+__device__ __forceinline__ double exp_neg_lean(double x) { return exp_neg_lean(x, exp_tab_load()); }
+
 // FAST = the per-point right-hand-side path (5e9 evaluations at config 2, VALU-bound): divisions by
 // the model constants become multiplications by their host-computed reciprocals (<= 1 ulp change of the
 // exp argument; 1e-16 relative on gamma, tolerance is 1e-8).  FAST = false keeps the reference's operation
 // order and is used where it is free (the N x N matrix assembly).
-template <int MODEL, bool FAST>
-__device__ __forceinline__ double vario(const Vario& v, double d, double d2) {
+// LEAN (with FAST; the moving window's matrix set-up, round 5): exp_neg_lean for the two models that take an exponential.
+template <int MODEL, bool FAST, bool LEAN = false>
+__device__ __forceinline__ double vario(const Vario& v, double d, double d2, const ExpTab* tab = nullptr) {
   if (MODEL == 0) return v.p0 * d + v.p1;                               // linear   :25-29
   if (MODEL == 1) return v.p0 * pow(d, v.p1) + v.p2;                    // power    :32-37
   if (MODEL == 2) {                                                     // gaussian :40-45 (needs d^2 only)
+    if (LEAN) return v.p0 * (1.0 - (tab ? exp_neg_lean(-d2 * v.c0inv, *tab) : exp_neg_lean(-d2 * v.c0inv))) + v.p2;
     return v.p0 * (1.0 - exp(FAST ? -d2 * v.c0inv : -d2 / v.c0)) + v.p2;
   }
   if (MODEL == 3) {                                                     // spherical:56-70 (d <= range)
@@ -55,6 +107,7 @@ __device__ __forceinline__ double vario(const Vario& v, double d, double d2) {
     }
     return v.p0 + v.p2;
   }
+  if (MODEL == 4 && LEAN) return v.p0 * (1.0 - (tab ? exp_neg_lean(-d * v.c0inv, *tab) : exp_neg_lean(-d * v.c0inv))) + v.p2;
   if (MODEL == 4) return v.p0 * (1.0 - exp(FAST ? -d * v.c0inv : -d / v.c0)) + v.p2;  // exponential :48-53
   {                                                                     // hole-effect :73-81
     const double q = FAST ? d * v.c0inv : d / v.c0;

@@ -291,6 +291,12 @@ __global__ void k_selftest_mfma(double* out /*16x16 row-major*/) {
 
 
 // v_mfma_f64_4x4x4_4b_f64 as the kernels use it: A replicated over blocks, B = 4 x 16 columns
+// exp_neg_lean (mik_dev.h) on n arguments: the moving window's 19-instruction exponential against the caller's reference
+__global__ void __launch_bounds__(256) k_selftest_exp(const double* __restrict__ x, double* __restrict__ out, int n) {
+  const ExpTab tab = exp_tab_load();
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = exp_neg_lean(x[i], tab);
+}
 __global__ void k_selftest_mfma4(double* out /*4x16 row-major*/) {
   const int l = threadIdx.x;
   const double a = (double)((l & 3) * 7 + (l >> 4) * 3 + 1);    // A[i=l&3][k=l>>4], same for every block

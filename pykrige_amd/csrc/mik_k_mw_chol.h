@@ -55,11 +55,14 @@ __device__ __forceinline__ double mw_entry(const Vario& v, int mode, double x1, 
 // element: its {8,13} class was 195 000 instructions (1.26 MB) of straight-line set-up code in front of a 4 000-instruction
 // elimination loop, every point streaming it through a 64 KB instruction cache.  With the model fixed an entry is ~40 instructions.
 template <int MODEL>
-__device__ __forceinline__ double mw_entry_t(const Vario& v, int mode, double x1, double y1, double z1, double x2, double y2, double z2) {
+__device__ __forceinline__ double mw_entry_t(const Vario& v, int mode, double x1, double y1, double z1, double x2, double y2, double z2,
+                                             const ExpTab* tab = nullptr) {
   if (MODEL < 0) return mw_entry(v, mode, x1, y1, z1, x2, y2, z2);
   const double dx = x1 - x2, dy = y1 - y2, dz = z1 - z2;  // z = 0 in 2-D
   const double d2 = dx * dx + dy * dy + dz * dz;
-  return -vario<(MODEL < 0 ? 0 : MODEL), false>(v, sqrt(d2), d2);
+  // (round 5: reciprocal-multiply form and the 19-instruction exp -- <= 2 ulp on an entry, 1e-16 relative, against a 1e-8 bar; the
+  // entry was ~124 instructions with the library's exp and the reference's divisions: half of a point's instructions at k = 100)
+  return -vario<(MODEL < 0 ? 0 : MODEL), true, true>(v, sqrt(d2), d2, tab);
 }
 
 // Per-point solve WITHOUT pivot search, default of the moving window: LDL^T of the SPD-shifted station block in registers.
@@ -141,6 +144,10 @@ __global__ void __launch_bounds__((G * G < 256) ? 256 : G * G, MIK_MWC_WAVES(G, 
     shift = 4.0 * gmax;
   }
   if (!(shift > 0.0)) shift = 1.0;
+  ExpTab etab;  // the lean exp's constants in scalar registers for the whole set-up -- only where the model takes an exponential (in the
+                // dynamic form and the others the sixteen register pairs cost more than they save: k = 100 dynamic 54 -> 64 ms)
+  constexpr bool USE_TAB = MODEL == 2 || MODEL == 4;
+  if (USE_TAB) etab = exp_tab_load();
   double m[RI][RI], rhs[RI];
 #pragma unroll
   for (int i = 0; i < RI; ++i) {
@@ -150,7 +157,7 @@ __global__ void __launch_bounds__((G * G < 256) ? 256 : G * G, MIK_MWC_WAVES(G, 
       const int col = tx + G * j;
       double v = (row == col) ? 1.0 : 0.0;  // padding rows / columns: identity
       if (row < K && col < K)
-        v = (row == col) ? shift : shift + mw_entry_t<MODEL>(a.v, a.mode, csx[row], csy[row], csz[row], csx[col], csy[col], csz[col]);
+        v = (row == col) ? shift : shift + mw_entry_t<MODEL>(a.v, a.mode, csx[row], csy[row], csz[row], csx[col], csy[col], csz[col], USE_TAB ? &etab : nullptr);
       m[i][j] = v;
     }
   }

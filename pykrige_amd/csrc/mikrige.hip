@@ -1911,6 +1911,20 @@ int mik_selftest_mfma(int device) {
   return MIK_OK;
 }
 
+int mik_selftest_exp(int device, const double* x, double* out, int n) {
+  if (!x || !out || n < 0) return fail(MIK_EINVAL, "mik_selftest_exp: bad argument");
+  if (n == 0) return MIK_OK;
+  HIPC(hipSetDevice(device));
+  DevBuf dx, dy;
+  MIKC(dx.ensure(sizeof(double) * (size_t)n));
+  MIKC(dy.ensure(sizeof(double) * (size_t)n));
+  HIPC(hipMemcpy(dx.p, x, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_selftest_exp, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, (const double*)dx.as<double>(), dy.as<double>(), n);
+  HIPC(hipGetLastError());
+  HIPC(hipMemcpy(out, dy.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+  return MIK_OK;
+}
+
 // ---- multi-GPU ---------------------------------------------------------------------------------
 int mik_comm_unique_id(char id_out[128]) {
   MIKC(rccl_load());

@@ -355,6 +355,37 @@ def test_wide_half_sweep_matches_lapack_and_its_variants_agree(n):
         assert np.abs(amat @ outs["wide"] - np.eye(amat.shape[0])).max() <= 1e-8
 
 
+def test_lean_exp_of_the_moving_window_set_up_is_within_an_ulp_and_a_half():
+    """Round 5: k_mw_chol's matrix set-up evaluates the variogram's exponential with exp_neg_lean (mik_dev.h: Cody-Waite reduction, degree-13
+    polynomial, 19 instructions) instead of the library's exp.  Over the whole range an exponential / gaussian variogram can produce -- 0 down
+    to underflow -- it stays within 1.5 ulp of NumPy's exp; exp(0) = 1 exactly; no NaN at the ends."""
+    lib = _lib()
+    rng = np.random.default_rng(3)
+    x = -np.concatenate([[0.0, 1e-300, 1e-17, 0.5 * np.log(2.0), np.log(2.0), 1.0, 708.0, 745.0, 745.2, 800.0, 1e6],
+                         10.0 ** rng.uniform(-12, 2.9, 200000), rng.uniform(0.0, 50.0, 200000)])
+    got = lib.selftest_exp(x)
+    ref = np.exp(x)
+    assert got[0] == 1.0 and np.all(np.isfinite(got)) and np.all(got >= 0.0)
+    normal = ref > 1e-300
+    ulp = np.spacing(ref[normal])
+    err = np.abs(got[normal] - ref[normal]) / ulp
+    assert err.max() <= 1.5, err.max()
+    assert np.abs(got[~normal] - ref[~normal]).max() <= 1e-300  # towards underflow: absolute
+    # and where it is used: the LDL^T kernel with the model compiled in against the dynamic form (library exp, the reference's divisions)
+    import pykrige_amd as pa
+
+    g = fx.load("mw_ok2d")
+    ext = float(max(np.ptp(g["x"]), np.ptp(g["y"])))
+    for model, par in (("exponential", [1.0, 0.4 * ext, 0.02]), ("gaussian", [1.0, 0.3 * ext, 0.05]), ("spherical", [1.0, 0.5 * ext, 0.0])):
+        outs = []
+        for static in (1, 0):
+            m = pa.OrdinaryKriging(g["x"], g["y"], g["v"], variogram_model=model, variogram_parameters=par)
+            m._get_handle().set_option("mw_static", static)
+            z, ss = m.execute("grid", g["gridx"], g["gridy"], backend="loop", n_closest_points=20)
+            outs.append((np.ma.getdata(z).copy(), np.ma.getdata(ss).copy()))
+        assert np.abs(outs[0][0] - outs[1][0]).max() <= 1e-11 and np.abs(outs[0][1] - outs[1][1]).max() <= 1e-11, model
+
+
 def test_triangular_diagonal_blocks_of_the_contraction():
     """Round 3: the symmetric contraction takes the diagonal block of a tile as a triangle of 16-row groups (option tri): sigma^2
     equal to the whole-block form to rounding, z untouched (it is a separate dot product), for a station count that leaves a short last
