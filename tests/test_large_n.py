@@ -10,8 +10,10 @@ whole (N + 1) x (N + 1) matrix on the host) on 2048 random points + 8 exact hits
     itself, and every byte offset into the inverse exceeds 4 GiB;
   * N = 24 000 exponential: k_contract + the block sweep at 188 block columns.
 
-The CPU side is one scipy.linalg.inv per case (0.5 - 2 minutes on the GPU box's 64 cores), so only the N = 24 000 spherical case runs in
-the default `-m gpu` set; the others run with MIK_SLOW_TESTS=1 (scripts/gpu_r05.sh largen)."""
+The CPU side is one scipy.linalg.inv per case (20 - 90 s on the GPU box's 64 cores), so the four oracle comparisons run with
+MIK_SLOW_TESTS=1 (scripts/gpu_r05.sh largen / evidence; profiles/r05_parity_beyond_8000_stations.txt).  The default `-m gpu` set holds the
+regime with the most to go wrong -- N = 24 000 spherical: aligned row blocks, byte offsets beyond 4 GiB -- as a comparison of the range-aware
+path with the library's own DENSE contraction (independent kernels, 64-bit addressing; itself oracle-checked at this size in the slow set)."""
 import os
 import time
 
@@ -24,7 +26,7 @@ Z_TOL, SS_TOL = 1e-8, 1e-6
 CASES = {
     "n12000_exponential": (12000, "exponential", [1.0, 0.3, 0.0], dict(sparse=0), False),
     "n16000_spherical": (16000, "spherical", [1.0, 0.15, 0.01], dict(sparse=1, sparse_rows=16), False),
-    "n24000_spherical": (24000, "spherical", [1.0, 0.1, 0.01], dict(sparse=1, sparse_rows=128), True),
+    "n24000_spherical": (24000, "spherical", [1.0, 0.1, 0.01], dict(sparse=1, sparse_rows=128), False),
     "n24000_exponential": (24000, "exponential", [1.0, 0.3, 0.01], dict(sparse=0), False),
 }
 
@@ -71,3 +73,31 @@ def test_parity_beyond_8000_stations(name):
               tm["invert_ms"], t_gpu, t_cpu, "range-aware, rows %d" % tm["sparse_rows"] if tm["sparse"] else "dense"))
     assert dz <= Z_TOL and ds <= SS_TOL, (dz, ds, cond1)
     np.testing.assert_allclose(np.asarray(z)[:8], v[:8], rtol=0, atol=1e-8)
+
+
+@pytest.mark.gpu
+def test_range_aware_path_beyond_4_gib_of_inverse_against_the_dense_path():
+    """N = 24 000 spherical in the default set: matrix order 24 064 > 23 168, so the library takes k_contract_sp (aligned 128-row blocks) and
+    every byte offset into the inverse exceeds 32 bits; against the dense contraction of the same library on the same factor-independent
+    problem (`sparse` = 0): agreement to 1e-9 / 1e-8 (a wrong offset is an O(1) error), exact hits reproduce the station values, sigma^2 = 0 there."""
+    import pykrige_amd as pa
+
+    n, model, params, _, _ = CASES["n24000_spherical"]
+    rng = np.random.default_rng(n + len(model))
+    x, y = rng.random(n), rng.random(n)
+    v = np.sin(6 * x) * np.cos(4 * y) + 0.1 * rng.standard_normal(n)
+    px, py = rng.random(2056), rng.random(2056)
+    px[:8], py[:8] = x[:8], y[:8]
+    out = {}
+    for sparse in (1, 0):
+        ok = pa.OrdinaryKriging(x, y, v, variogram_model=model, variogram_parameters=params)
+        ok._get_handle().set_option("sparse", sparse)
+        z, ss = ok.execute("points", px, py, backend="loop")
+        tm = ok.last_timing
+        assert tm["sparse"] == sparse and (not sparse or tm["sparse_rows"] == 128), tm
+        out[sparse] = (np.asarray(z).copy(), np.asarray(ss).copy())
+        ok._get_handle().close()
+    # (2e-10 seen on sigma^2: the dense form -b.A_inv.b cancels across the whole vector, the range-aware one only across the stations in range)
+    assert np.abs(out[1][0] - out[0][0]).max() <= 1e-9 and np.abs(out[1][1] - out[0][1]).max() <= 1e-8
+    np.testing.assert_allclose(out[1][0][:8], v[:8], rtol=0, atol=1e-8)
+    assert np.abs(out[1][1][:8]).max() <= 1e-8
