@@ -369,6 +369,7 @@ def sparse_summary(t):
             "list_kernels_ms": t["sparse_lists_ms"], "stations_in_hilbert_order": bool(t["stations_sorted"]),
             "tile_rows": ("eight gathered 16-row groups (k_contract_spg)" if t.get("sparse_rows") == 16
                           else "aligned blocks of 128 rows (k_contract_sp)"),
+            "stations_per_list_tile": t.get("sparse_ktile", 16),  # 8 (round 5): a K step is a pair of list-adjacent 8-station tiles
             "triangle_products_16x16x128": t.get("sparse_diag_products", 0.0),
             "points_in_hilbert_order_per_launch": bool(t.get("points_sorted")), "sort_points_ms": t.get("sort_points_ms", 0.0)}
 
