@@ -35,7 +35,8 @@ def test_library_exports_every_declared_symbol():
 def test_every_option_and_environment_variable_of_the_library_is_documented():
     """mik_set_option keys and MIK_* environment variables the library reads (csrc/mikrige.hip) appear in the header's option
     list (include/mikrige.h) / INTEGRATION.md's environment table: the boundary's documentation cannot fall behind the code."""
-    src = open(os.path.join(ROOT, "pykrige_amd", "csrc", "mikrige.hip")).read()
+    csrc = os.path.join(ROOT, "pykrige_amd", "csrc")
+    src = "".join(open(os.path.join(csrc, f)).read() for f in sorted(os.listdir(csrc)) if f.endswith(".hip"))  # every translation unit (round 5)
     header = open(os.path.join(ROOT, "include", "mikrige.h")).read()
     integration = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     keys = sorted(set(re.findall(r'strcmp\(key, "([a-z_0-9]+)"\)', src)))
