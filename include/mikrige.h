@@ -198,7 +198,9 @@ int  mik_slab_of(int64_t n, int members, int i, int64_t *lo, int64_t *count); /*
  *   2 = Hilbert-ordered stations with the dense contraction (A/B of the order alone).  Takes effect at the
  *   next mik_factor [MIK_SPARSE].  REPRODUCIBILITY: the set of K tiles a point meets depends on the 128-point block it falls
  *   into, so with this option on (with or without "sort_points") sigma^2 depends TO ROUNDING (~1e-13) on how the points are cut
- *   into launches, slabs and device-group members; z does not.  "sparse" 0 is bit-identical across device counts
+ *   into launches, slabs and device-group members; so does z since round 5 (~1e-16 relative: k_rhs walks the block's list of candidate
+ *   tiles, which lane adds which station follows the list).  Cuts at multiples of 128 points in the caller's order (device groups with
+ *   "sort_points" 0) keep the blocks, hence the bits.  "sparse" 0 is bit-identical across device counts
  *   (tests/test_device_group.py::test_spherical_model_across_device_counts) ;
  * "sparse_rows" -1/16/128 = range-aware contraction: a tile's 128 rows of A_inv are eight GATHERED active 16-row groups of the point
  *   block's list (16: k_contract_spg -- the list of active K tiles is also the list of active row groups; tile r takes entries

@@ -70,10 +70,31 @@ __global__ void __launch_bounds__(256) k_rhs(RhsArgs a) {
   double zacc[MIK_TP];
 #pragma unroll
   for (int q = 0; q < MIK_TP; ++q) zacc[q] = 0.0;
+  // SP (round 5): the block walks the COMPACT list of its point block's candidate K tiles, sixteen tiles per iteration -- every lane has
+  // a station to work on.  (Striding over all Mp columns and skipping the non-candidates, as rounds 4 did, left three quarters of the
+  // lanes of an iteration idle at config 5 -- 10 % of the tiles are candidates -- and paid a dependent flag load per iteration.)
+  __shared__ unsigned short slist[SP ? MIK_SP_MAXK16 : 16];
+  __shared__ int sncand;
+  if (SP) {
+    if (threadIdx.x < 64) {  // wavefront 0: ascending list by ballot / popcount
+      const unsigned char* crow = a.cand + (long)(t0 >> 7) * a.nK16;
+      int nc = 0;
+      for (int base = 0; base < a.nK16; base += 64) {
+        const int k = base + (int)threadIdx.x;
+        const bool on = k < a.nK16 && crow[k] != 0;
+        const unsigned long long m = __ballot(on);
+        if (on) slist[nc + __popcll(m & ((1ULL << threadIdx.x) - 1ULL))] = (unsigned short)k;
+        nc += __popcll(m);
+      }
+      if (threadIdx.x == 0) sncand = nc;
+    }
+    __syncthreads();
+  }
+  const int nit = SP ? sncand : a.Mp;
 
-  for (int j = threadIdx.x; j < a.Mp; j += 256) {
+  for (int it = SP ? (int)(threadIdx.x >> 4) : (int)threadIdx.x; it < nit; it += SP ? 16 : 256) {
+    const int j = SP ? 16 * (int)slist[it] + (int)(threadIdx.x & 15) : it;
     double val[MIK_TP];
-    if (SP && !a.cand[(long)(t0 >> 7) * a.nK16 + (j >> 4)]) continue;  // per K tile: 16 consecutive lanes leave or stay together
     if (j < a.N) {
       const double sx = a.xs[j];
       double sy = a.ys[j];

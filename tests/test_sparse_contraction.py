@@ -370,7 +370,9 @@ def test_sorted_points_carry_host_evaluated_drift_values():
             assert ts["sparse"] == 1 and ts["points_sorted"] == sort
             assert np.abs(zs - zd).max() <= Z_TOL and np.abs(ss - sd).max() <= SS_TOL, (sort, np.abs(zs - zd).max(), np.abs(ss - sd).max())
             out[sort] = (zs, ss)
-        assert np.array_equal(out[0][0], out[1][0])  # z is a per-point sum: the order of the points does not touch it
+        # z is a per-point sum over the stations; since round 5 k_rhs walks the point block's list of candidate tiles, so WHICH lane adds
+        # which station follows the block the point falls into: equal to rounding across point orders, no longer bit for bit
+        assert np.abs(out[0][0] - out[1][0]).max() <= 1e-13
 
 
 @pytest.mark.gpu
