@@ -211,6 +211,9 @@ int  mik_slab_of(int64_t n, int members, int i, int64_t *lo, int64_t *count); /*
  *   of the contraction is a PAIR of list-adjacent 8-station tiles staged into the two halves of the 16-wide LDS tile, a 16-row group is two
  *   gathered 8-row groups, an odd last entry is half a K step: 718 instead of 780 stations in active tiles at BASELINE config 5 (work ~ n^2:
  *   -15 %).  Same exact sum (skipped entries are exact zeros of delta) [MIK_SPARSE_KTILE] ;
+ * "sparse_epilogue" 0/1 = 8-station form: 1 (default) = a row group's term sum_i delta_ti W_it is formed at the K step of the group's own
+ *   square from that step's B tile in LDS (sixteen LDS reads in one batch); 0 = from global memory behind the K loop (two memory round
+ *   trips per tile with the other wavefronts at a barrier): BASELINE config 5 contraction 38.0 -> 36.3 ms per 2.1 M points ;
  * "sparse_group" 1..16 = k_contract_spg's queue order: point blocks per group (a group's tiles run on one XCD, tile position ascending
  *   = longest K loops first, point block fast; default 4) [MIK_SPARSE_GROUP] ;
  * "sort_points" -1/0/1 = range-aware contraction: the points of every launch (one chunk of the resident point list) are put in

@@ -273,6 +273,7 @@ struct mik_handle {
   int opt_sparse_group = 4;  // "sparse_group": point blocks per group of k_sp_tiles_g's queue order (a group's tiles run on one XCD, tile position
                              // ascending, point block fast): 1 .. 16
   int opt_sparse_ktile = 8;  // "sparse_ktile": 16 = candidate / flag / list tiles of 16 stations (round 4), 8 = of 8 stations, a K step a pair of them (round 5)
+  int opt_sparse_epi = 1;    // "sparse_epilogue": 1 = a row group's term of part[r][t] is formed from the B tile in LDS at the K step of its own square (8-station form), 0 = from global memory behind the K loop
   int opt_sparse_rows = -1;  // "sparse_rows": 16 = tiles of gathered 16-row groups (k_contract_spg), 128 = aligned row blocks (k_contract_sp),
                              // -1 = auto: 16 wherever 32-bit offsets address the inverse (Mp * Mp * 8 < 2^32)
   // second set (with Bt2): the launches of the range-aware contraction alternate between two lanes on two streams, so that the

@@ -1105,12 +1105,16 @@ struct SpgArgs {
   const uint4* recs;            // tile records (k_sp_tiles_g)
   const int* xoff;              // [9]
   unsigned long long* queue;    // [8], zeroed per launch (the low words are the counters)
+  unsigned long long* prof;     // PROF: [block][wave][10] cycle sums per phase (diagnostic instantiation only)
 };
 
-// EPI (option "sparse_epilogue" 1; not the default): a group's term of part[r][t] = sum_i delta_ti W_it is formed at the K step of the
-// group's own 16 x 16 square -- its accumulators are final there, and the delta it needs IS that step's B tile in LDS -- instead of
-// from global memory after the K loop: no operand reads in the epilogue (a tenth of the kernel's fabric traffic, two memory round
-// trips per tile).  Measured 1.7 % slower (config 5: 43.1 against 42.4 ms): the sums live in registers through the triangle loop.
+// EPI (option "sparse_epilogue", default 1 in the 8-station form): a group's term of part[r][t] = sum_i delta_ti W_it is formed at the K
+// step of the group's own 16 x 16 square -- its accumulators are final there, and the delta it needs IS that step's B tile in LDS --
+// instead of from global memory after the K loop: no operand reads in the epilogue (a tenth of the kernel's fabric traffic, two memory
+// round trips per tile during which the block issues no matrix instruction).  Round 4 measured it 1.7 % slower (its LDS reads were
+// issued one by one, each waited for); round 5 (reads in one batch, the queue look-ahead out of the first K step): config 5 contraction
+// 38.0 -> 36.3 ms per 2.1 M points.  PROF: the diagnostic instantiation (MIK_SPG_PROF=1: cycle sums per phase of the tile loop and per
+// triangle step, printed per launch; profiles/r05_spg_tile_phases.txt).
 // H8 (round 5, option "sparse_ktile" 8): the list is per 8 stations and a list POSITION is a dword = a pair (h0, h1) of list-adjacent
 // 8-station tiles: a K step stages columns 8 h0 .. + 7 into the lower half of the 16-wide LDS tile and 8 h1 .. + 7 into the upper half
 // (the per-lane DMA offset of the lanes that feed the upper half is shifted by 8 (h1 - h0) columns: one v_add + one v_cndmask by a
@@ -1118,9 +1122,8 @@ struct SpgArgs {
 // lower half alone (the m = 1 MFMAs are skipped) and a row group whose upper eight rows are left out of the epilogue.  Everything else
 // -- positions, tiles of eight positions, the triangle, the queue -- is the 16-station form's.  -15 % work at BASELINE config 5 by the
 // CPU model (profiles/r04b_sparse_granularity_model_cpu.txt: 718 instead of 780 stations in active tiles, work ~ n^2).
-template <int NAI, bool EPI = false, bool H8 = false>
+template <int NAI, bool EPI = false, bool H8 = false, bool PROF = false>
 __global__ void __launch_bounds__(64 * 2 * (8 / NAI), 2 * (4 / NAI)) k_contract_spg(SpgArgs a) {
-  static_assert(!(EPI && H8), "the LDS epilogue exists for the 16-station form only");
   static_assert(NAI == 2, "8 waves: 4 wave-rows of two 16-row groups x 2 wave-columns of 64 points");
   constexpr int WROWS = 16 * NAI, NWM = 128 / WROWS;
   constexpr int NTHR = 64 * 2 * (MIK_BM / WROWS), PROWS = NTHR / 8, NPASS = MIK_BM / PROWS;
@@ -1128,7 +1131,7 @@ __global__ void __launch_bounds__(64 * 2 * (8 / NAI), 2 * (4 / NAI)) k_contract_
   __shared__ GemmSmem sm;
   constexpr int RW = H8 ? 3 : 2;  // uint4 per tile record
   __shared__ uint4 srec[2 * RW];  // two tile records: the current tile's and the next one's
-  __shared__ int sst[4];     // thread 0's queue state: [0] sequences tried, [1] first record and [2] record count of the current sequence
+  __shared__ int sst[4];     // the queue owner's state: [0] sequences tried, [1] first record and [2] record count of the current sequence
   unsigned xcc;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
   const int xcd = (int)(xcc & 7);
@@ -1215,16 +1218,20 @@ __global__ void __launch_bounds__(64 * 2 * (8 / NAI), 2 * (4 / NAI)) k_contract_
       }
     }
   };
-  // Thread 0 owns the queue, one tile ahead.  fetch_next() sits right behind the first barrier of a tile's K loop: it pops the position
-  // of the NEXT tile (atomic) and reads that tile's record into the other half of srec -- wavefront 0 waits two L2 round trips there
-  // while the other wavefronts of its SIMD use the matrix pipe, and catches up inside the same K step.  (Keeping the atomic's result
-  // in a register until the tile ends does not work: hipcc waits for it at once and spills it.)  acquire(), after the K loop, then
-  // finds the record in LDS; only when a sequence has run out does it walk on to the next XCD's (a few times per block and launch).
+  // One thread owns the queue, one tile ahead: lane 0 of wavefront 6.  fetch_next() pops the position of the NEXT tile (atomic) and reads
+  // that tile's record into the other half of srec: two L2 round trips.  It runs in triangle step min(n - 1, 2) of the current tile, where
+  // wave-row 3 (positions 3 and 7) has no products left: the wait costs no matrix instruction, and the step's barrier comes when the
+  // other wave-rows have finished theirs.  (Round 4 had thread 0 do it in the tile's first K step: wavefront 0 reached that step's
+  // barrier two round trips late and the other seven waited; 40 - 44 us per tile beyond its K steps at BASELINE config 5.  Keeping the
+  // atomic's result in a register until the tile ends does not work: hipcc waits for it at once and spills it.)  acquire(), after the
+  // K loop, then finds the record in LDS; only when a sequence has run out does it walk on to the next XCD's (a few times per block
+  // and launch).
   constexpr unsigned REC_END = 0xffffffffu, REC_MORE = 0xfffffffeu;
+  constexpr unsigned QOWNER = 64 * 6;  // lane 0 of wavefront 6 (wave-row 3)
   auto fetch = [&](int xq) { return __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(&a.queue[xq]), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
   int cur = 1;  // srec[2 cur], srec[2 cur + 1] = the current tile's record
   auto fetch_next = [&]() {
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == QOWNER) {
       const int steal = sst[0];
       uint4 r0 = make_uint4(REC_END, 0u, 0u, 0u), r1 = make_uint4(0u, 0u, 0u, 0u), r2 = make_uint4(0u, 0u, 0u, 0u);
       if (steal < 8) {
@@ -1244,7 +1251,7 @@ __global__ void __launch_bounds__(64 * 2 * (8 / NAI), 2 * (4 / NAI)) k_contract_
     }
   };
   auto acquire = [&]() -> bool {  // one barrier; block-uniform result
-    if (threadIdx.x == 0 && srec[RW * (cur ^ 1)].x == REC_MORE) {
+    if (threadIdx.x == QOWNER && srec[RW * (cur ^ 1)].x == REC_MORE) {
       uint4 r0 = make_uint4(REC_END, 0u, 0u, 0u), r1 = make_uint4(0u, 0u, 0u, 0u), r2 = make_uint4(0u, 0u, 0u, 0u);
       int steal = sst[0];
       while (++steal < 8) {
@@ -1324,7 +1331,7 @@ __global__ void __launch_bounds__(64 * 2 * (8 / NAI), 2 * (4 / NAI)) k_contract_
     Bgu = uniform_ptr(a.Bt + (long)tblk * MIK_BN * a.ldb);
     stage(Bgu, H8 ? kfirst : 16 * kfirst, 1);
   };
-  if (threadIdx.x == 0) {
+  if (threadIdx.x == QOWNER) {
     const int lo = a.xoff[xcd];
     sst[0] = 0;
     sst[1] = lo;
@@ -1333,6 +1340,18 @@ __global__ void __launch_bounds__(64 * 2 * (8 / NAI), 2 * (4 / NAI)) k_contract_
   fetch_next();
   bool have = acquire();
   if (have) adopt();
+  __shared__ unsigned long long sprof[PROF ? 16 : 1];  // PROF: cycles and visits per triangle step w (wavefront 0's view)
+  unsigned long long tstep = 0ULL;
+  if (PROF && threadIdx.x < 16) sprof[threadIdx.x] = 0ULL;
+  unsigned long long tp[10] = {0ULL, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL}, tm0 = 0ULL;
+  auto mark = [&](int i) {  // PROF: the cycles since the previous mark go to phase i
+    if (PROF) {
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      tp[i] += t - tm0;
+      tm0 = t;
+    }
+  };
+  if (PROF) tm0 = __builtin_amdgcn_s_memtime();
   while (have) {
     d4 acc[NAI][4];
 #pragma unroll
@@ -1344,7 +1363,9 @@ __global__ void __launch_bounds__(64 * 2 * (8 / NAI), 2 * (4 / NAI)) k_contract_
     int kn = ksec;  // K tile of position w - 1
     drain();
     __syncthreads();
-    fetch_next();
+    const int fstep = n - 1 < 2 ? n - 1 : 2;  // the triangle step at which the queue's owner looks ahead (see fetch_next)
+    mark(0);
+    if (PROF) tp[8] += 1ULL, tp[9] += (unsigned long long)(n > 8 ? n - 8 : 0);
     for (; w >= 8; --w) {
       stage(Bgu, H8 ? kn : 16 * kn, buf ^ 1);
       int kn2 = 0;
@@ -1383,11 +1404,14 @@ __global__ void __launch_bounds__(64 * 2 * (8 / NAI), 2 * (4 / NAI)) k_contract_
     }
     // the tile's own groups: position w's K tile meets the groups of positions <= w; a group's accumulators are doubled when the
     // loop reaches its own 16 x 16 square (everything above it counts twice)
+    mark(1);
+    if (PROF) tstep = __builtin_amdgcn_s_memtime();
     double cs[4] = {0.0, 0.0, 0.0, 0.0};  // EPI: this lane's sums over its rows of delta_ti W_it, points wn * 64 + bi * 16 + (lane & 15)
     for (; w >= 0; --w) {
       if (w >= 1) stage(Bgu, H8 ? kn : 16 * kn, buf ^ 1);
       int kn2 = 0;
       if (w >= 2) kn2 = list_at(w - 2);
+      if (w == fstep) fetch_next();
       const bool skip_hi = H8 && half_last && w == n - 1;
       const double* as = &sm.As[buf][0][0] + aoff;
       const double* bs = &sm.Bs[buf][0][0];
@@ -1428,7 +1452,10 @@ __global__ void __launch_bounds__(64 * 2 * (8 / NAI), 2 * (4 / NAI)) k_contract_
 #pragma unroll
         for (int ai = 0; ai < NAI; ++ai)
           if (w == wm + 4 * ai) {  // the group's square was its last K tile: W is final, and delta of its rows is this step's B tile
+            // (sixteen LDS reads in one batch, into the registers the step's fragments have left, then four independent chains of four
+            // multiply-adds: read - wait - multiply-add one by one cost this step 4000 cycles with everybody else at the barrier)
             const int ln = lane_now(), lq2 = ln >> 4, lc2 = ln & 15;
+            double dv[4][4];
 #pragma unroll
             for (int bi = 0; bi < 4; ++bi) {
               const int pnt = wn * 64 + bi * 16 + lc2, sw = (pnt >> 1) & 7;  // B image: element (point, k) in slot (k >> 1) ^ sw of its row
@@ -1436,8 +1463,16 @@ __global__ void __launch_bounds__(64 * 2 * (8 / NAI), 2 * (4 / NAI)) k_contract_
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
                 const int k = 4 * r + lq2;
-                cs[bi] += brow[(((k >> 1) ^ sw) << 1) | (k & 1)] * acc[ai][bi][r];
+                dv[bi][r] = brow[(((k >> 1) ^ sw) << 1) | (k & 1)];
               }
+            }
+            // an odd tail has no upper eight rows: their K columns and their rows alias the lower eight (finite numbers), weight 0
+            const double up = (H8 && erow1[ai] < 0) ? 0.0 : 1.0;
+#pragma unroll
+            for (int bi = 0; bi < 4; ++bi) {
+              const double lo2 = dv[bi][0] * acc[ai][bi][0] + dv[bi][1] * acc[ai][bi][1];
+              const double hi2 = dv[bi][2] * acc[ai][bi][2] + dv[bi][3] * acc[ai][bi][3];
+              cs[bi] += lo2 + up * hi2;
             }
           }
       }
@@ -1445,14 +1480,23 @@ __global__ void __launch_bounds__(64 * 2 * (8 / NAI), 2 * (4 / NAI)) k_contract_
       __syncthreads();
       buf ^= 1;
       kn = kn2;
+      if (PROF && threadIdx.x == 0) {
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        sprof[w] += t - tstep;
+        sprof[8 + w] += 1ULL;
+        tstep = t;
+      }
     }
+    mark(2);
     // the next tile: record -> LDS (one barrier), its first K tile on the way to buffer 1 while this tile's epilogue runs
     const int t0 = tblk * MIK_BN, rp = rpos;
     int er[NAI], er1[NAI];
 #pragma unroll
     for (int ai = 0; ai < NAI; ++ai) er[ai] = erow[ai], er1[ai] = H8 ? erow1[ai] : 0;
     have = acquire();
+    mark(3);
     if (have) adopt();
+    mark(4);
     // epilogue (k_contract's): part[r][t] = sum over this tile's rows of delta_ti W_it
     const int lane = lane_now(), lq = lane >> 4, lc = lane & 15;
     if (EPI) {
@@ -1494,6 +1538,11 @@ __global__ void __launch_bounds__(64 * 2 * (8 / NAI), 2 * (4 / NAI)) k_contract_
       __builtin_amdgcn_sched_barrier(0);
     }
     }
+    if (PROF) {
+      double keep = cs[0] + cs[1] + cs[2] + cs[3];
+      asm volatile("" : "+v"(keep));  // (the sums exist before the mark)
+    }
+    mark(5);
     double* red = &sm.As[0][0][0];  // the K loop ended with a barrier; buffer 1 is being filled for the next tile
     if (lq == 0) {
 #pragma unroll
@@ -1507,7 +1556,13 @@ __global__ void __launch_bounds__(64 * 2 * (8 / NAI), 2 * (4 / NAI)) k_contract_
       for (int x = 0; x < NWM; ++x) v += red[x * 128 + c];
       a.part[(long)rp * a.palloc + t0 + c] = v;
     }
+    mark(6);
   }
+  if (PROF && (threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) a.prof[((long)blockIdx.x * 8 + wave) * 10 + i] = tp[i];
+  }
+  if (PROF && threadIdx.x < 16) a.prof[(long)gridDim.x * 80 + (long)blockIdx.x * 16 + threadIdx.x] = sprof[threadIdx.x];
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -315,7 +315,39 @@ int one_predict(mik_handle* h) {
         ga.recs = ln.recs->as<uint4>();
         ga.xoff = sa.xoff;
         ga.queue = sa.queue;
-        if (h8) hipLaunchKernelGGL((k_contract_spg<2, false, true>), dim3((unsigned)std::min<long>(2L * h->n_cu, (long)nTb * nIblk)), dim3(512), 0, sc, ga);
+        static const bool spg_prof = getenv("MIK_SPG_PROF") && atoi(getenv("MIK_SPG_PROF")) != 0;
+        if (spg_prof && h8 && h->opt_sparse_epi) {  // diagnostic (MIK_SPG_PROF=1): cycle sums per phase of the tile loop, one launch, printed to stderr
+          const unsigned nb = (unsigned)std::min<long>(2L * h->n_cu, (long)nTb * nIblk);
+          static DevBuf pb;
+          MIKC(pb.ensure(sizeof(unsigned long long) * nb * 96));
+          HIPC(hipMemsetAsync(pb.p, 0, pb.bytes, sc));
+          ga.prof = pb.as<unsigned long long>();
+          hipLaunchKernelGGL((k_contract_spg<2, true, true, true>), dim3(nb), dim3(512), 0, sc, ga);
+          std::vector<unsigned long long> hp((size_t)nb * 96);
+          HIPC(hipMemcpyAsync(hp.data(), pb.p, sizeof(unsigned long long) * hp.size(), hipMemcpyDeviceToHost, sc));
+          HIPC(hipStreamSynchronize(sc));
+          static const char* names[8] = {"top drain+barrier", "off-diagonal K steps", "triangle K steps", "acquire", "adopt", "epilogue loads+sums", "reduce+store", "-"};
+          {
+            double c[16] = {0};
+            for (unsigned b = 0; b < nb; ++b)
+              for (int i = 0; i < 16; ++i) c[i] += (double)hp[(size_t)nb * 80 + (size_t)b * 16 + i];
+            fprintf(stderr, "spg triangle steps (cycles per visit):");
+            for (int w = 7; w >= 0; --w) fprintf(stderr, "  w=%d %.0f", w, c[w] / std::max(1.0, c[8 + w]));
+            fprintf(stderr, "\n");
+          }
+          for (int wv : {0, 6}) {
+            double sum[10] = {0};
+            for (unsigned b = 0; b < nb; ++b)
+              for (int i = 0; i < 10; ++i) sum[i] += (double)hp[((size_t)b * 8 + wv) * 10 + i];
+            double tot = 0;
+            for (int i = 0; i < 7; ++i) tot += sum[i];
+            fprintf(stderr, "spg phases, wavefront %d: %.0f tiles per block, %.1f off-diagonal steps per tile, %.0f cycles per tile\n", wv, sum[8] / nb, sum[9] / std::max(1.0, sum[8]), tot / std::max(1.0, sum[8]));
+            for (int i = 0; i < 7; ++i) fprintf(stderr, "   %-22s %8.0f cycles per tile  %5.1f %%\n", names[i], sum[i] / std::max(1.0, sum[8]), 100.0 * sum[i] / tot);
+            fprintf(stderr, "   per off-diagonal step %.0f cycles\n", sum[1] / std::max(1.0, sum[9]));
+          }
+        } else
+        if (h8 && h->opt_sparse_epi) hipLaunchKernelGGL((k_contract_spg<2, true, true>), dim3((unsigned)std::min<long>(2L * h->n_cu, (long)nTb * nIblk)), dim3(512), 0, sc, ga);
+        else if (h8) hipLaunchKernelGGL((k_contract_spg<2, false, true>), dim3((unsigned)std::min<long>(2L * h->n_cu, (long)nTb * nIblk)), dim3(512), 0, sc, ga);
         else hipLaunchKernelGGL((k_contract_spg<2, false>), dim3((unsigned)std::min<long>(2L * h->n_cu, (long)nTb * nIblk)), dim3(512), 0, sc, ga);
       } else {
         hipLaunchKernelGGL((k_contract_sp<2>), dim3((unsigned)std::min<long>(2L * h->n_cu, (long)nTb * nIblk)), dim3(512), 0, sc, sa);

@@ -204,7 +204,7 @@ static int set_group(mik_handle* h, int n) {
     k->opt_factor = h->opt_factor, k->opt_sym = h->opt_sym, k->opt_engine = h->opt_engine, k->opt_waves = h->opt_waves;
     k->opt_chunk = h->opt_chunk, k->opt_symsweep = h->opt_symsweep, k->opt_diag = h->opt_diag, k->opt_update_waves = h->opt_update_waves, k->opt_panel_rows = h->opt_panel_rows, k->opt_panel_stream = h->opt_panel_stream, k->opt_update_map = h->opt_update_map, k->opt_update_rev = h->opt_update_rev, k->opt_update_deep = h->opt_update_deep, k->opt_pivot256 = h->opt_pivot256, k->opt_update_token = h->opt_update_token, k->opt_update_pf = h->opt_update_pf, k->opt_wide_reserve = h->opt_wide_reserve, k->opt_update_tpb = h->opt_update_tpb, k->opt_lookahead = h->opt_lookahead, k->opt_gate = h->opt_gate, k->opt_fuse_chain = h->opt_fuse_chain, k->opt_early_diag = h->opt_early_diag, k->opt_pinv_fast = h->opt_pinv_fast, k->opt_rhs_overlap = h->opt_rhs_overlap, k->opt_verify = h->opt_verify, k->verify_tol_z = h->verify_tol_z, k->verify_tol_inv = h->verify_tol_inv;
     k->opt_mw_class = h->opt_mw_class, k->opt_mw_knn_bound = h->opt_mw_knn_bound, k->opt_mw_pivot = h->opt_mw_pivot, k->opt_mw_lds_cap = h->opt_mw_lds_cap, k->opt_tri = h->opt_tri, k->opt_symmetrize = h->opt_symmetrize, k->opt_mw_solver = h->opt_mw_solver;
-    k->opt_sparse = h->opt_sparse, k->opt_sparse_lanes = h->opt_sparse_lanes, k->opt_sparse_rows = h->opt_sparse_rows, k->opt_sparse_ktile = h->opt_sparse_ktile, k->opt_sparse_group = h->opt_sparse_group, k->opt_sort_points = h->opt_sort_points, k->opt_drift_eq = h->opt_drift_eq;
+    k->opt_sparse = h->opt_sparse, k->opt_sparse_lanes = h->opt_sparse_lanes, k->opt_sparse_rows = h->opt_sparse_rows, k->opt_sparse_ktile = h->opt_sparse_ktile, k->opt_sparse_epi = h->opt_sparse_epi, k->opt_sparse_group = h->opt_sparse_group, k->opt_sort_points = h->opt_sort_points, k->opt_drift_eq = h->opt_drift_eq;
     k->opt_pinv_block = h->opt_pinv_block, k->opt_mw_static = h->opt_mw_static, k->opt_mw_knn_lane = h->opt_mw_knn_lane;
     k->custom_fn = h->custom_fn, k->custom_user = h->custom_user;
     h->kids.push_back(k);
@@ -295,6 +295,9 @@ int mik_set_option(mik_handle* h, const char* key, double value) {
   } else if (!strcmp(key, "sparse_ktile")) {
     if (value != 8.0 && value != 16.0) return fail(MIK_EINVAL, "sparse_ktile: 16 or 8 stations");
     h->opt_sparse_ktile = (int)value;
+  } else if (!strcmp(key, "sparse_epilogue")) {
+    if (value != 0.0 && value != 1.0) return fail(MIK_EINVAL, "sparse_epilogue: 0 or 1");
+    h->opt_sparse_epi = (int)value;
   } else if (!strcmp(key, "sparse_group")) {
     if (!(value >= 1.0 && value <= 16.0)) return fail(MIK_EINVAL, "sparse_group must be 1 .. 16");
     h->opt_sparse_group = (int)value;
