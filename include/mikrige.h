@@ -213,9 +213,9 @@ int  mik_slab_of(int64_t n, int members, int i, int64_t *lo, int64_t *count); /*
  *   -15 %).  Same exact sum (skipped entries are exact zeros of delta) [MIK_SPARSE_KTILE] ;
  * "sparse_epilogue" 0/1 = 8-station form: 1 (default) = a row group's term sum_i delta_ti W_it is formed at the K step of the group's own
  *   square from that step's B tile in LDS (sixteen LDS reads in one batch); 0 = from global memory behind the K loop (two memory round
- *   trips per tile with the other wavefronts at a barrier): BASELINE config 5 contraction 38.0 -> 36.3 ms per 2.1 M points ;
+ *   trips per tile with the other wavefronts at a barrier): BASELINE config 5 contraction 38.0 -> 36.3 ms per 2.1 M points (profiles/r05_spg_tile_phases.txt) ;
  * "sparse_group" 1..16 = k_contract_spg's queue order: point blocks per group (a group's tiles run on one XCD, tile position ascending
- *   = longest K loops first, point block fast; default 4) [MIK_SPARSE_GROUP] ;
+ *   = longest K loops first, point block fast; default 16) [MIK_SPARSE_GROUP] ;
  * "sort_points" -1/0/1 = range-aware contraction: the points of every launch (one chunk of the resident point list) are put in
  *   Hilbert-curve order among themselves on the device (k_ps_*: 20-bit keys, stable two-pass radix sort, all launches' segments
  *   side by side) and kriged in that order -- a block of 128 consecutive points is then a compact patch whatever order the caller's
@@ -225,8 +225,8 @@ int  mik_slab_of(int64_t n, int members, int i, int64_t *lo, int64_t *count); /*
  *   of the range-aware path depends to rounding (~1e-13) on how the points are cut into launches and slabs [MIK_SORT_POINTS] ;
  * "sparse_lanes" 1/2 = range-aware contraction: its launches alternate between two lanes (two streams, two sets of work buffers and
  *   right-hand-side panels), so that the candidate / right-hand-side / list kernels of a launch and the tail of the previous
- *   launch's tile queue overlap.  Measured 2 % faster at config 5 for a second right-hand-side panel: default 1 = one launch after
- *   the other ;
+ *   launch's tile queue overlap.  Default 2 (round 5: prediction 43.1 -> 41.6 ms per 2.1 M points at BASELINE config 5, for a second
+ *   right-hand-side panel); 1 = one launch after the other.  With two lanes a kernel's event-timed duration includes what ran beside it ;
  * "drift_eq" 0/1 = drift equilibration (default 1): every drift term enters the matrix and the right-hand sides as s_j (f_j - c_j),
  *   c_j = its mean and 1 / s_j = its largest deviation over the stations (wells excepted).  With the unbiasedness row present
  *   span{1, f_j} = span{1, s_j (f_j - c_j)}: the stations' kriging weights, z and sigma^2 are those of the reference's system

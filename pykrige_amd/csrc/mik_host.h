@@ -270,8 +270,8 @@ struct mik_handle {
   DevBuf gu;  // geographic problems, range-aware contraction: unit vectors of the resident points (3 x npt)
   bool ps_valid = false;     // ps_idx[0] holds the order of the resident points for launches of ps_chunk points
   long ps_chunk = 0;
-  int opt_sparse_group = 4;  // "sparse_group": point blocks per group of k_sp_tiles_g's queue order (a group's tiles run on one XCD, tile position
-                             // ascending, point block fast): 1 .. 16
+  int opt_sparse_group = 16; // "sparse_group": point blocks per group of k_sp_tiles_g's queue order (a group's tiles run on one XCD, tile position
+                             // ascending, point block fast): 1 .. 16 (round 5: 4 -> 16, contraction 35.7 -> 35.3 ms at config 5)
   int opt_sparse_ktile = 8;  // "sparse_ktile": 16 = candidate / flag / list tiles of 16 stations (round 4), 8 = of 8 stations, a K step a pair of them (round 5)
   int opt_sparse_epi = 1;    // "sparse_epilogue": 1 = a row group's term of part[r][t] is formed from the B tile in LDS at the K step of its own square (8-station form), 0 = from global memory behind the K loop
   int opt_sparse_rows = -1;  // "sparse_rows": 16 = tiles of gathered 16-row groups (k_contract_spg), 128 = aligned row blocks (k_contract_sp),
@@ -279,9 +279,9 @@ struct mik_handle {
   // second set (with Bt2): the launches of the range-aware contraction alternate between two lanes on two streams, so that the
   // candidate / right-hand-side / list kernels of one launch and the tail of the previous launch's tile queue overlap
   DevBuf sp2_cand, sp2_flags, sp2_klist, sp2_kcount, sp2_nrows, sp2_rows, sp2_rstart, sp2_tiles, sp2_xoff, part2, queue2, sp2_recs;
-  int opt_sparse_lanes = 1;  // "sparse_lanes": 1 = one launch after the other on one stream (default), 2 = two lanes.  Measured
-                             // (profiles/r04_sparse_lanes_ab.txt): config-5 slab 64.6 -> 63.4 ms, bench grid 96.3 -> 94.0 ms -- 2 % for a
-                             // second 8.4 GB panel and per-launch times that no longer add up: off
+  int opt_sparse_lanes = 2;  // "sparse_lanes": 2 = two lanes (default since round 5), 1 = one launch after the other on one stream.  Round 4
+                             // (profiles/r04_sparse_lanes_ab.txt): config-5 slab 64.6 -> 63.4 ms, 2 % for a second 8.4 GB panel: off.  Round 5, with
+                             // the contraction 15 % shorter, what runs beside it weighs more: prediction 43.1 -> 41.6 ms (bench 35.3 -> 36.3 M points/s)
   std::vector<double> hxs, hys, hzs;  // host copies of the station coordinates (the moving-window cell grid is built on the host)
   // moving-window neighbour search: stations sorted into a uniform grid of cells
   struct MwGrid {

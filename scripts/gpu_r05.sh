@@ -34,9 +34,10 @@ evidence)
   timeout 1500 python -m pytest tests -m gpu -q --tb=short > $OUT/pytest_gpu.txt 2>&1; echo "pytest exit $?" >> $OUT/pytest_gpu.txt; grep -E "passed|failed" $OUT/pytest_gpu.txt | tail -2
   ( time timeout 900 python bench.py ) > $OUT/bench_c2.json 2> $OUT/bench_c2.err; cut -c1-160 $OUT/bench_c2.json; tail -3 $OUT/bench_c2.err
   timeout 500 python bench.py --steps 3 --warmup 1 --config 5 --no-other > $OUT/bench_c5.json 2>> $OUT/bench.err; cut -c1-160 $OUT/bench_c5.json
-  timeout 300 ./tools/update_bench 8064 1 > $OUT/update_bench.txt 2>&1
+  [ -n "$EVIDENCE_LITE" ] || timeout 300 ./tools/update_bench 8064 1 > $OUT/update_bench.txt 2>&1
   cd /tmp
-  for c in 2 5; do
+  CFGS="2 5"; [ -n "$EVIDENCE_LITE" ] && CFGS="5"   # EVIDENCE_LITE=1: only what changed after the full run (config 5's kernels)
+  for c in $CFGS; do
     timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ks_c$c -o ks -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu --pmc off --no-other --config $c > $OUT/ks_c$c.json 2> $OUT/ks_c$c.err
     run() { local name=$1; shift; timeout 400 rocprofv3 "$@" --output-format csv -d $OUT/prof$c/$name -o $name -- python $REPO/bench.py --steps 1 --warmup 1 --no-cpu --pmc off --no-other --config $c > $OUT/prof${c}_$name.json 2> $OUT/prof${c}_$name.err; }
     run pmc_sq --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY
@@ -47,9 +48,9 @@ evidence)
   done
   cd $REPO
   MIK_SLOW_TESTS=1 timeout 1200 python -m pytest tests/test_large_n.py -m gpu -q -s > $OUT/pytest_large_n.txt 2>&1; grep -E "^n[0-9]|passed|failed" $OUT/pytest_large_n.txt
-  { echo "MIK_FUZZ_CASES=2000 python -m pytest tests/test_randomized_parity.py -m gpu -q -s   (MI355X, HEAD of round 5)"; MIK_FUZZ_CASES=2000 timeout 900 python -m pytest tests/test_randomized_parity.py -m gpu -q -s 2>&1 | tail -4; } > $OUT/randomized.txt 2>&1; tail -3 $OUT/randomized.txt
+  [ -n "$EVIDENCE_LITE" ] || { echo "MIK_FUZZ_CASES=2000 python -m pytest tests/test_randomized_parity.py -m gpu -q -s   (MI355X, HEAD of round 5)"; MIK_FUZZ_CASES=2000 timeout 900 python -m pytest tests/test_randomized_parity.py -m gpu -q -s 2>&1 | tail -4; } > $OUT/randomized.txt 2>&1; tail -3 $OUT/randomized.txt
   timeout 400 python bench.py --gpus 8 --config 5 --steps 2 --warmup 1 --no-cpu > $OUT/bench_g8_c5.json 2>> $OUT/bench.err; cut -c1-120 $OUT/bench_g8_c5.json
-  timeout 300 python scripts/mw_static_ab.py > $OUT/mw_static_ab.txt 2>&1; grep -E "k=100|k= 50" $OUT/mw_static_ab.txt | head -4
+  [ -n "$EVIDENCE_LITE" ] || timeout 300 python scripts/mw_static_ab.py > $OUT/mw_static_ab.txt 2>&1; grep -E "k=100|k= 50" $OUT/mw_static_ab.txt | head -4
   rm -rf $OUT/prof*/*/*.db $OUT/ks_c*/*.db 2>/dev/null
   ;;
 *) echo "unknown stage $STAGE"; exit 2;;

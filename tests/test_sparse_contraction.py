@@ -193,7 +193,7 @@ def test_point_sort_restated_in_numpy():
 
 
 # ---------------------------------------------------------------------------------------------- GPU
-def _run(m, style, args, sparse, chunk=None, rows=None, lanes=1, ktile=8, epi=1, **kw):
+def _run(m, style, args, sparse, chunk=None, rows=None, lanes=2, ktile=8, epi=1, **kw):
     h = m._get_handle()
     h.set_option("sparse", sparse)
     h.set_option("sparse_epilogue", epi)  # 1 = the default (a row group's term from the B tile in LDS), 0 = from global memory behind the K loop
@@ -254,9 +254,10 @@ def test_sparse_contraction_against_oracle_and_dense(case):
     zr, sr = ko.execute(st, "grid", *axes)
     zd, sd, td = _run(m, "grid", axes, 0)
     assert td["sparse"] == 0 and td["stations_sorted"] == 0
-    for chunk, rows, ktile, epi in ((131072, None, 8, 1), (2048, None, 8, 1), (131072, 128, 8, 1), (2048, 16, 8, 0), (131072, 16, 16, 1), (2048, None, 16, 0),
-                                    (4096, None, 8, 0)):
-        zs, ss, ts = _run(m, "grid", axes, 1, chunk=chunk, rows=rows, ktile=ktile, epi=epi)
+    # (lanes: 2 = the default since round 5 -- the launches alternate between two streams and two sets of work buffers --, 1 = one stream)
+    for chunk, rows, ktile, epi, lanes in ((131072, None, 8, 1, 2), (2048, None, 8, 1, 2), (131072, 128, 8, 1, 1), (2048, 16, 8, 0, 1), (131072, 16, 16, 1, 2),
+                                           (2048, None, 16, 0, 2), (4096, None, 8, 0, 2), (1024, None, 8, 1, 1), (1024, 128, 8, 1, 2)):
+        zs, ss, ts = _run(m, "grid", axes, 1, chunk=chunk, rows=rows, ktile=ktile, epi=epi, lanes=lanes)
         assert ts["sparse"] == 1 and ts["stations_sorted"] == 1
         assert ts["sparse_rows"] == (rows or 16)  # gathered 16-row groups are the default
         assert ts["sparse_ktile"] == (16 if rows == 128 else ktile)  # (aligned row blocks keep their 16-station lists)
