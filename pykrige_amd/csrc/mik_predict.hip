@@ -341,7 +341,7 @@ int one_predict(mik_handle* h) {
               for (int i = 0; i < 10; ++i) sum[i] += (double)hp[((size_t)b * 8 + wv) * 10 + i];
             double tot = 0;
             for (int i = 0; i < 7; ++i) tot += sum[i];
-            fprintf(stderr, "spg phases, wavefront %d: %.0f tiles per block, %.1f off-diagonal steps per tile, %.0f cycles per tile\n", wv, sum[8] / nb, sum[9] / std::max(1.0, sum[8]), tot / std::max(1.0, sum[8]));
+            fprintf(stderr, "spg phases, wavefront %d: %.0f tiles of the launch, %.1f per block, %.1f off-diagonal steps per tile, %.0f cycles per tile\n", wv, sum[8], sum[8] / nb, sum[9] / std::max(1.0, sum[8]), tot / std::max(1.0, sum[8]));
             for (int i = 0; i < 7; ++i) fprintf(stderr, "   %-22s %8.0f cycles per tile  %5.1f %%\n", names[i], sum[i] / std::max(1.0, sum[8]), 100.0 * sum[i] / tot);
             fprintf(stderr, "   per off-diagonal step %.0f cycles\n", sum[1] / std::max(1.0, sum[9]));
           }

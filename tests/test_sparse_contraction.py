@@ -5,11 +5,15 @@ variogram_models.py:56-70): sigma^2 = 2 s - delta^T A_inv delta, z = c . delta w
 CPU: the identity itself on the oracle's matrices, and the Hilbert-curve station order (mik_station_order needs no GPU).
 GPU: the sparse path against the oracle, against the dense path of the same library, and against the reference's stored answers
 (every spherical fixture; the full-size config-5 slab), at BASELINE's tolerances |dz| <= 1e-8, |dsigma^2| <= 1e-6."""
+import os
+
 import numpy as np
 import pytest
 
 from oracle import kriging_oracle as ko
 from tests import _fixtures as fx
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 Z_TOL, SS_TOL = 1e-8, 1e-6
 
@@ -494,3 +498,39 @@ def test_range_aware_contraction_on_geographic_coordinates():
     assert np.abs(outs[1][0] - outs[0][0]).max() <= 1e-11 and np.abs(outs[1][1] - outs[0][1]).max() <= 1e-11
     zg = outs[1][0]
     assert abs(zg[2, 3] - v[0]) <= 1e-9 and abs(outs[1][1][2, 3]) <= 1e-9  # an exact hit: the value, sigma^2 = 0
+
+
+@pytest.mark.gpu
+def test_profiling_instantiation_of_the_range_aware_contraction_gives_the_same_answers():
+    """MIK_SPG_PROF=1 (read once per process: a child process) runs k_contract_spg's profiling instantiation -- s_memtime sums per phase of the
+    tile loop and per triangle step, printed per launch to stderr (profiles/r05_spg_tile_phases.txt) --: same z / sigma^2 as the oracle, and
+    the report accounts for every tile of the launch."""
+    import subprocess
+    import sys
+
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+import pykrige_amd as pa
+from tests import _fixtures as fx
+from oracle import kriging_oracle as ko
+(x, y), v = fx.synth(2, 1500, 2)
+par = [1.0, 0.2, 0.01]
+m = pa.OrdinaryKriging(x, y, v, variogram_model="spherical", variogram_parameters=par)
+st = ko.KrigingState(ndim=2, coords_orig=np.stack([x, y], 1), values=v, model="spherical", params=ko.internal_parameters("spherical", par))
+axes = [np.linspace(0, 1, 161), np.linspace(0, 1, 53)]
+z, ss = m.execute("grid", *axes)
+zr, sr = ko.execute(st, "grid", *axes)
+t = dict(m.last_timing)
+print("RESULT", t["sparse"], t["sparse_ktile"], float(np.abs(np.ma.getdata(z) - zr).max()), float(np.abs(np.ma.getdata(ss) - sr).max()), int(t["sparse_tiles"]))
+""" % ROOT
+    env = dict(os.environ, MIK_SPG_PROF="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][0].split()
+    assert res[1] == "1" and res[2] == "8", res
+    assert float(res[3]) <= Z_TOL and float(res[4]) <= SS_TOL, res
+    assert "spg triangle steps (cycles per visit)" in r.stderr and "off-diagonal K steps" in r.stderr, r.stderr[-2000:]
+    import re
+    tiles = [int(v) for v in re.findall(r"spg phases, wavefront 0: (\d+) tiles of the launch", r.stderr)]
+    assert tiles and sum(tiles) == int(res[5]), (tiles, res)  # every tile of every launch went through the profiled loop
