@@ -137,6 +137,9 @@ k_panel(const double* __restrict__ A, long lda, const double* __restrict__ Bt, d
 #ifndef MIK_UPD_NTV
 #define MIK_UPD_NTV(NAI) ((NAI) == 4 ? 2 : 1)
 #endif
+#ifdef MIK_UPD_PROF
+__device__ unsigned long long* mik_upd_prof = nullptr;
+#endif
 template <bool SYM, int NAI = 4>
 __global__ void __launch_bounds__(64 * 2 * (8 / NAI), NAI == 2 ? 4 : 2)
 k_update(double* __restrict__ T, long ld, int nblk, int kb, const double* __restrict__ Cold,
@@ -163,6 +166,10 @@ k_update(double* __restrict__ T, long ld, int nblk, int kb, const double* __rest
   // done_cnt (nullable): every block of the launch adds one when its stores are out (release): the other stream waits for
   // gridDim.x of them instead of for an event
   __shared__ GemmSmem sm;
+#ifdef MIK_UPD_PROF
+  const unsigned long long pts = __builtin_amdgcn_s_memtime();
+  const unsigned long long prs = __builtin_amdgcn_s_memrealtime();
+#endif
   auto finish = [&]() {
     if (done_cnt) {
       __syncthreads();
@@ -250,7 +257,13 @@ k_update(double* __restrict__ T, long ld, int nblk, int kb, const double* __rest
     }
     __syncthreads();
   }
+#ifdef MIK_UPD_PROF  // tools/update_bench only: s_memtime at the phase boundaries of one tile, per block
+  const unsigned long long pt0 = __builtin_amdgcn_s_memtime();
+#endif
   gemm_core<NAI>(Cold + (long)i0 * 128, 128, Rt + (long)j0 * 128, 128, 0, 128, acc, sm);
+#ifdef MIK_UPD_PROF
+  const unsigned long long pt1 = __builtin_amdgcn_s_memtime();
+#endif
   if (tok && threadIdx.x == 0) __hip_atomic_store(tok, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (gemm_core ended with a barrier)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 1, wn = wave & 1, lq = lane >> 4, lc = lane & 15;
@@ -301,6 +314,21 @@ k_update(double* __restrict__ T, long ld, int nblk, int kb, const double* __rest
       }
     __builtin_amdgcn_sched_barrier(0);
   }
+#ifdef MIK_UPD_PROF
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const unsigned long long pt2 = __builtin_amdgcn_s_memtime();
+  if (threadIdx.x == 0 && mik_upd_prof) {
+    unsigned long long* o = mik_upd_prof + 4L * blockIdx.x;
+    unsigned xcc_id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+    o[0] = pt0, o[1] = pt1, o[2] = pt2, o[3] = ((pt0 - pts) << 8) | (xcc_id & 7);
+    if (blockIdx.x == 0) {  // calibration: s_memrealtime counts at 100 MHz
+      const unsigned long long pre = __builtin_amdgcn_s_memrealtime();
+      mik_upd_prof[4L * gridDim.x] = pt2 - pts, mik_upd_prof[4L * gridDim.x + 1] = pre - prs;
+      mik_upd_prof[4L * gridDim.x + 2] = prs;
+    }
+  }
+#endif
   finish();
 }
 

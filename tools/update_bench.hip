@@ -2,7 +2,9 @@
 // k_update_deep (round 5) and its ablations, on a half sweep's upper block triangle.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I pykrige_amd/csrc tools/update_bench.hip -o tools/update_bench
 // Run:   tools/update_bench [Mp = 8064] [tpb ...]
+#define MIK_UPD_PROF 1
 #include "mik_k_inverse.h"
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -37,6 +39,25 @@ int main(int argc,char**argv){
   int step = 0;
   float ms=timeit([&]{hipLaunchKernelGGL((k_update<true,2>),dim3(ug),dim3(512),0,0,T,(long)Mp,nblk,kb,(const double*)Cold,(const double*)Cnew,(const double*)Rt,(const double*)Dinv,0,-2,(double*)nullptr,(double*)nullptr,(int*)nullptr,(const int2*)nullptr,((step++)&1)?2:0);},10);
   printf("k_update<true,2> (two 8-wave blocks per CU)        : %7.1f us  %5.1f TFLOP/s\n",ms*1e3, fl/ms*1e-9);
+  {  // one profiled launch: when each block's K loop and read-modify-write began and ended
+    unsigned long long* pb; CK(hipMalloc(&pb, sizeof(unsigned long long) * (4 * ug + 4))); CK(hipMemset(pb, 0, sizeof(unsigned long long) * (4 * ug + 4)));
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(mik_upd_prof), &pb, sizeof(pb)));
+    hipLaunchKernelGGL((k_update<true,2>),dim3(ug),dim3(512),0,0,T,(long)Mp,nblk,kb,(const double*)Cold,(const double*)Cnew,(const double*)Rt,(const double*)Dinv,0,-2,(double*)nullptr,(double*)nullptr,(int*)nullptr,(const int2*)nullptr,0);
+    CK(hipDeviceSynchronize());
+    std::vector<unsigned long long> hp(4 * (size_t)ug + 4); CK(hipMemcpy(hp.data(), pb, hp.size() * 8, hipMemcpyDeviceToHost));
+    unsigned long long* none = nullptr; CK(hipMemcpyToSymbol(HIP_SYMBOL(mik_upd_prof), &none, sizeof(none)));
+    unsigned long long tmin = ~0ULL, tmax = 0; double kl = 0, rm = 0; long nb = 0;
+    std::vector<double> kls, rms;
+    for (unsigned b = 0; b < ug; ++b) { if (!hp[4*b]) continue; tmin = std::min(tmin, hp[4*b]); tmax = std::max(tmax, hp[4*b+2]); kl += (double)(hp[4*b+1]-hp[4*b]); rm += (double)(hp[4*b+2]-hp[4*b+1]); kls.push_back((double)(hp[4*b+1]-hp[4*b])); rms.push_back((double)(hp[4*b+2]-hp[4*b+1])); ++nb; }
+    std::sort(kls.begin(), kls.end()); std::sort(rms.begin(), rms.end());
+    (void)tmin; (void)tmax;
+    printf("   profile of one launch (s_memtime ticks; %ld tiles with a product; the counters of different CUs are not aligned: sums only)\n", nb);
+    printf("     K loop per tile: mean %.0f (median %.0f, 10 %% %.0f, 90 %% %.0f)   read-modify-write: mean %.0f (median %.0f, 10 %% %.0f, 90 %% %.0f)\n", kl/nb, kls[nb/2], kls[nb/10], kls[nb*9/10], rm/nb, rms[nb/2], rms[nb/10], rms[nb*9/10]);
+    printf("     sum over tiles / 512 resident blocks = %.0f ticks of K loop + %.0f ticks of read-modify-write per slot\n", kl/512, rm/512);
+    { double pro = 0; for (unsigned b = 0; b < ug; ++b) if (hp[4*b]) pro += (double)(hp[4*b+3] >> 8);
+      printf("     kernel entry -> K loop: mean %.0f ticks per block\n", pro/nb); }
+    printf("     calibration (block 0): %llu s_memtime ticks in %llu ticks of the 100 MHz clock = %.3f ns per tick\n", hp[4*(size_t)ug], hp[4*(size_t)ug+1], 10.0 * (double)hp[4*(size_t)ug+1] / (double)hp[4*(size_t)ug]);
+  }
   std::vector<int> tpbs; for(int a=2;a<argc;++a) tpbs.push_back(atoi(argv[a])); if(tpbs.empty()) tpbs={1,2,4,8};
   for(int tpb: tpbs){
     printf("k_update_deep, %d tiles per block:\n", tpb);
