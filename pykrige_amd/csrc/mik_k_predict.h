@@ -1014,7 +1014,7 @@ __global__ void __launch_bounds__(1024) k_sp_tiles_g(const int* __restrict__ nti
                                                      const unsigned short* __restrict__ klist, int nK16, int nTblk,
                                                      uint4* __restrict__ recs, int* __restrict__ xoff,
                                                      unsigned long long* __restrict__ stats, int st) {
-  // st = point blocks per group (option "sparse_group", 1 .. 16; 4 by default = MIK_ST)
+  // st = point blocks per group (option "sparse_group", 1 .. 16; 16 by default since round 5)
   __shared__ int gcnt[1024 + 1], goff[1024 + 1], xtot[9];
   __shared__ unsigned long long ksum, dsum;
   const int nG = (nTblk + st - 1) / st;
