@@ -836,6 +836,10 @@ def main():
                                       "exchange": tsum["exchange_ms"] / K, "exchange_not_overlapped": tsum["exchange_wait_ms"] / K,
                                       "rhs": tsum["rhs_ms"] / K, "contract": tsum["contract_ms"] / K, "predict_total": tsum["predict_ms"] / K}}
         config["phases_ms_per_step"] = dict(out["phases_ms_per_step"])  # (the driver's record keeps `config` in full)
+        if last.get("sparse"):
+            config["phases_note"] = ("range-aware contraction on two launch lanes (option sparse_lanes 2): the right-hand-side / list kernels of one "
+                                     "launch run beside the other lane's contraction; rhs and contract are per-kernel HIP-event sums and may "
+                                     "add up to more than predict_total (the wall time of the prediction on the device)")
         dev_ms = (tsum["assemble_ms"] + tsum["invert_ms"] + tsum["exchange_wait_ms"] + tsum["predict_ms"]) / K
         out["host_overhead"] = {"vs_device_phases_ms": dt / K * 1e3 - dev_ms,
                                 "what": "ms_per_step / frac (filled in below): execute() minus the `resident` step (mik_factor + mik_predict on "
