@@ -383,7 +383,6 @@ def _kernel_metadata():
         pytest.skip("needs the built library and ROCm's llvm-readelf")
     blob = open(lib, "rb").read()
     elfs, at = [], blob.find(b"__CLANG_OFFLOAD_BUNDLE__")
-    assert at >= 0
     while at >= 0:  # one bundle per translation unit of the library (pykrige_amd/build.py)
         n = struct.unpack_from("<Q", blob, at + 24)[0]
         off = at + 32
@@ -395,6 +394,21 @@ def _kernel_metadata():
             if "gfx950" in triple:
                 elfs.append(blob[at + o:at + o + s])
         at = blob.find(b"__CLANG_OFFLOAD_BUNDLE__", at + 24)
+    # --offload-compress (round 5, pykrige_amd/build.py): the bundles are zstd-compressed ("CCOB", version 3: magic, u16 version, u16
+    # method, u64 file size, u64 uncompressed size, u64 hash); clang-offload-bundler unpacks them
+    bundler = "/opt/rocm/lib/llvm/bin/clang-offload-bundler"
+    at = blob.find(b"CCOB")
+    while at >= 0:
+        ver = struct.unpack_from("<H", blob, at + 4)[0]
+        assert ver == 3 and os.path.exists(bundler), ("compressed offload bundle version", ver)
+        size = struct.unpack_from("<Q", blob, at + 8)[0]
+        with tempfile.TemporaryDirectory() as d:
+            src, dst = os.path.join(d, "b.hipfb"), os.path.join(d, "b.co")
+            open(src, "wb").write(blob[at:at + size])
+            subprocess.run([bundler, "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + src, "--output=" + dst],
+                           check=True, capture_output=True)
+            elfs.append(open(dst, "rb").read())
+        at = blob.find(b"CCOB", at + size)
     assert elfs and all(e[:4] == b"\x7fELF" for e in elfs), "no gfx950 code object in the library"
     notes = ""
     for elf in elfs:
