@@ -1114,7 +1114,9 @@ struct SpgArgs {
 // round trips per tile during which the block issues no matrix instruction).  Round 4 measured it 1.7 % slower (its LDS reads were
 // issued one by one, each waited for); round 5 (reads in one batch, the queue look-ahead out of the first K step): config 5 contraction
 // 38.0 -> 36.3 ms per 2.1 M points.  PROF: the diagnostic instantiation (MIK_SPG_PROF=1: cycle sums per phase of the tile loop and per
-// triangle step, printed per launch; profiles/r05_spg_tile_phases.txt).
+// triangle step, printed per launch; profiles/r05_spg_tile_phases.txt).  Last: two of a tile's barriers are gone -- the queue record needs none
+// on the fast path (it was written barriers ago), and the wave-rows' sums wait in LDS of their own (sred) for the barrier at the top of
+// the next tile, where wavefronts 0 and 1 add and store them: 36.1 - 36.5 -> 36.7 - 37.2 M points/s at config 5.
 // H8 (round 5, option "sparse_ktile" 8): the list is per 8 stations and a list POSITION is a dword = a pair (h0, h1) of list-adjacent
 // 8-station tiles: a K step stages columns 8 h0 .. + 7 into the lower half of the 16-wide LDS tile and 8 h1 .. + 7 into the upper half
 // (the per-lane DMA offset of the lanes that feed the upper half is shifted by 8 (h1 - h0) columns: one v_add + one v_cndmask by a
@@ -1250,8 +1252,12 @@ __global__ void __launch_bounds__(64 * 2 * (8 / NAI), 2 * (4 / NAI)) k_contract_
       if (H8) srec[RW * (cur ^ 1) + 2] = r2;
     }
   };
-  auto acquire = [&]() -> bool {  // one barrier; block-uniform result
-    if (threadIdx.x == QOWNER && srec[RW * (cur ^ 1)].x == REC_MORE) {
+  // (round 5: the record was written in a triangle step, several barriers ago: only the first call -- fetch_next() right before it --
+  // and the walk to another XCD's sequence need a barrier of their own; the test on the LDS word is the same for every thread)
+  auto acquire = [&](bool first) -> bool {  // block-uniform result
+    const bool slow = first || __builtin_amdgcn_readfirstlane(srec[RW * (cur ^ 1)].x) == REC_MORE;
+    if (slow) __syncthreads();  // every wavefront has read the word (the owner rewrites the record below) / the first record is published
+    if (slow && threadIdx.x == QOWNER && srec[RW * (cur ^ 1)].x == REC_MORE) {
       uint4 r0 = make_uint4(REC_END, 0u, 0u, 0u), r1 = make_uint4(0u, 0u, 0u, 0u), r2 = make_uint4(0u, 0u, 0u, 0u);
       int steal = sst[0];
       while (++steal < 8) {
@@ -1273,7 +1279,7 @@ __global__ void __launch_bounds__(64 * 2 * (8 / NAI), 2 * (4 / NAI)) k_contract_
       srec[RW * (cur ^ 1) + 1] = r1;
       if (H8) srec[RW * (cur ^ 1) + 2] = r2;
     }
-    __syncthreads();
+    if (slow) __syncthreads();
     cur ^= 1;
     return __builtin_amdgcn_readfirstlane(srec[RW * cur].x) != REC_END;
   };
@@ -1338,8 +1344,19 @@ __global__ void __launch_bounds__(64 * 2 * (8 / NAI), 2 * (4 / NAI)) k_contract_
     sst[2] = a.xoff[xcd + 1] - lo;
   }
   fetch_next();
-  bool have = acquire();
+  bool have = acquire(true);
   if (have) adopt();
+  long pend_off = -1;  // the finished tile's row of part + its point block's first point: its sums wait in sred until the next barrier
+  __shared__ double sred[NWM * 128];
+  auto flush_sums = [&]() {
+    if (wave < 2 && pend_off >= 0) {
+      const int c = wave * 64 + lane_now();
+      double v = 0.0;
+#pragma unroll
+      for (int x = 0; x < NWM; ++x) v += sred[x * 128 + c];
+      a.part[pend_off + c] = v;
+    }
+  };
   __shared__ unsigned long long sprof[PROF ? 16 : 1];  // PROF: cycles and visits per triangle step w (wavefront 0's view)
   unsigned long long tstep = 0ULL;
   if (PROF && threadIdx.x < 16) sprof[threadIdx.x] = 0ULL;
@@ -1363,6 +1380,7 @@ __global__ void __launch_bounds__(64 * 2 * (8 / NAI), 2 * (4 / NAI)) k_contract_
     int kn = ksec;  // K tile of position w - 1
     drain();
     __syncthreads();
+    flush_sums();
     const int fstep = n - 1 < 2 ? n - 1 : 2;  // the triangle step at which the queue's owner looks ahead (see fetch_next)
     mark(0);
     if (PROF) tp[8] += 1ULL, tp[9] += (unsigned long long)(n > 8 ? n - 8 : 0);
@@ -1493,7 +1511,7 @@ __global__ void __launch_bounds__(64 * 2 * (8 / NAI), 2 * (4 / NAI)) k_contract_
     int er[NAI], er1[NAI];
 #pragma unroll
     for (int ai = 0; ai < NAI; ++ai) er[ai] = erow[ai], er1[ai] = H8 ? erow1[ai] : 0;
-    have = acquire();
+    have = acquire(false);
     mark(3);
     if (have) adopt();
     mark(4);
@@ -1543,21 +1561,17 @@ __global__ void __launch_bounds__(64 * 2 * (8 / NAI), 2 * (4 / NAI)) k_contract_
       asm volatile("" : "+v"(keep));  // (the sums exist before the mark)
     }
     mark(5);
-    double* red = &sm.As[0][0][0];  // the K loop ended with a barrier; buffer 1 is being filled for the next tile
+    // the four wave-rows' sums meet in LDS; wavefronts 0 and 1 add them and store the tile's row of part BEHIND the next barrier the block
+    // passes anyway (the top of the next tile, or the one behind the loop): no barrier and no wait of the other six for this
     if (lq == 0) {
 #pragma unroll
-      for (int bi = 0; bi < 4; ++bi) red[wm * 128 + wn * 64 + bi * 16 + lc] = cs[bi];
+      for (int bi = 0; bi < 4; ++bi) sred[wm * 128 + wn * 64 + bi * 16 + lc] = cs[bi];
     }
-    __syncthreads();
-    if (wave < 2) {
-      const int c = wave * 64 + lane;
-      double v = 0.0;
-#pragma unroll
-      for (int x = 0; x < NWM; ++x) v += red[x * 128 + c];
-      a.part[(long)rp * a.palloc + t0 + c] = v;
-    }
+    pend_off = (long)rp * a.palloc + t0;
     mark(6);
   }
+  __syncthreads();
+  flush_sums();
   if (PROF && (threadIdx.x & 63) == 0) {
 #pragma unroll
     for (int i = 0; i < 10; ++i) a.prof[((long)blockIdx.x * 8 + wave) * 10 + i] = tp[i];

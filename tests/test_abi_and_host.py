@@ -446,7 +446,7 @@ def test_kernel_register_budgets_of_the_built_library():
     # tile in LDS; the profiling instantiation of the default (MIK_SPG_PROF=1)
     for epi, h8, prof in ((0, 0, 0), (0, 1, 0), (1, 1, 0), (1, 1, 1)):
         k = one(r"_ZN3mik14k_contract_spgILi2ELb%dELb%dELb%dEEEvNS_7SpgArgsE" % (epi, h8, prof))
-        assert k["vgpr_count"] <= 128 and k["agpr_count"] == 0 and k["private_segment_fixed_size"] <= 32 and k["group_segment_fixed_size"] <= 65900, k
+        assert k["vgpr_count"] <= 128 and k["agpr_count"] == 0 and k["private_segment_fixed_size"] <= 32 and k["group_segment_fixed_size"] <= 70100, k  # staging 64 KB + the four wave-rows' sums 4 KB + records
     # round 5: the trailing-update variants of the K2 experiments stay inside the budgets they were designed for, none of them spills
     k = one(r"_ZN3mik13k_update_deepILb1ELi0EEEv.*")
     assert k["vgpr_count"] <= 128 and k["private_segment_fixed_size"] == 0, k
