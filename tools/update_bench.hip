@@ -1,5 +1,6 @@
 // Standalone timing of the block sweep's trailing update (K2): k_update (8 waves per tile, two blocks per CU) against
-// k_update_deep (round 5) and its ablations, on a half sweep's upper block triangle.
+// k_update_deep (round 5) and its ablations, on a half sweep's upper block triangle; one profiled launch of k_update (MIK_UPD_PROF hooks: s_memtime at kernel
+// entry, K loop start / end, last store; profiles/r05_update_kernel_phases.txt).
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I pykrige_amd/csrc tools/update_bench.hip -o tools/update_bench
 // Run:   tools/update_bench [Mp = 8064] [tpb ...]
 #define MIK_UPD_PROF 1
