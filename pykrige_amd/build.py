@@ -86,6 +86,9 @@ def build_library(force=False, verbose=False, jobs=None):
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0 and "--offload-compress" in cmd and "offload-compress" in r.stderr:
+            # a hipcc that does not know the flag (before ROCm 6.1): the same objects, uncompressed
+            r = subprocess.run([c for c in cmd if c != "--offload-compress"], capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("compiling %s failed:\n%s" % (name, r.stderr[-4000:]))
         return name
