@@ -32,6 +32,15 @@ def test_library_exports_every_declared_symbol():
     assert set(_lib.SIGNATURES) == set(names)
 
 
+def test_library_size_stays_under_ten_megabytes():
+    """Round 5: eight translation units, code objects compressed in the fat binary (pykrige_amd/build.py): the round-4 review's bar for the
+    library (16.9 MB then) is 10 MB."""
+    from pykrige_amd import build
+
+    build.build_library()
+    assert os.path.getsize(build.OUT) <= 10 * 1024 * 1024, os.path.getsize(build.OUT)
+
+
 def test_every_option_and_environment_variable_of_the_library_is_documented():
     """mik_set_option keys and MIK_* environment variables the library reads (csrc/mikrige.hip) appear in the header's option
     list (include/mikrige.h) / INTEGRATION.md's environment table: the boundary's documentation cannot fall behind the code."""
