@@ -458,8 +458,62 @@ def other_config_line(cno, window=None, steps=3, warmup=1):
     return line
 
 
+# ------------------------------------------------------------------------------------------------- parity over whole grids
+# points per reference slab (whole rows / z planes: the reference's npt x N temporaries bd, b, x stay at a few GB) and, for
+# config 5, the 4096 x 64 strip of the full 4096 x 4096 grid that straddles the cut between the slabs of GPUs 0 and 1 (row 512)
+FULL_GRID = {2: dict(target=50000), 3: dict(target=40000), 4: dict(target=49152), 5: dict(target=32768, strip=(480, 544))}
+
+
+def full_grid_axes(cno):
+    cfg = CONFIGS[cno]
+    if cno == 5:
+        r0, r1 = FULL_GRID[5]["strip"]
+        return [np.linspace(0.0, 1.0, 4096), np.linspace(0.0, 1.0, 4096)[r0:r1]]
+    return grid_axes(cfg, 1)
+
+
+def full_grid_parity(cno, budget_s=None, log=None):
+    """Every point of ONE execute('grid') of the drop-in class over the config's own grid (configs 2, 3, 4: the whole grid; config 5:
+    a 4096 x 64 strip across the cut between two GPUs' slabs) against the REAL reference kriging the same grid slab by slab
+    (oracle/full_grid.py; ok.py:650-683, uk.py:922-1009, ok3d.py:624-657 as written upstream).  `budget_s` bounds the CPU side: what
+    fits is spread over the grid and `coverage` says how much it was."""
+    from oracle import full_grid as fg
+    from oracle import ref_package as rp
+
+    cfg = CONFIGS[cno]
+    coords, values = synth(cfg["seed"], cfg["n"], cfg["ndim"])
+    axes = full_grid_axes(cno)
+    m = make_model(cfg, coords, values)
+    t0 = time.perf_counter()
+    z, ss = m.execute("grid", *axes, backend="vectorized")
+    t_gpu = time.perf_counter() - t0
+    tm = dict(m.last_timing)
+    m._get_handle().close()
+    pk = rp.import_reference(stub_statistics=True)
+    rm = reference_model(pk, cfg, coords, values)
+    n = cfg["n"]
+    extra = ((2 if cfg.get("rl") else 0) + (len(cfg["wells"]) if cfg.get("wells") else 0)) if cfg["ndim"] == 2 else 0
+    res = {"workload": cfg["name"] + (" -- rows %d:%d of the 4096 x 4096 grid" % FULL_GRID[5]["strip"] if cno == 5 else ""),
+           "grid": [int(a.size) for a in axes], "gpu_execute_s": t_gpu, "gpu_contraction": "range-aware" if tm.get("sparse") else "dense",
+           "cond_1": fg.cond_1(rm, *((n, n + extra) if extra else (n,)))}
+    res.update(fg.compare(rm, z, ss, axes, FULL_GRID[cno]["target"], budget_s=budget_s, log=log))
+    if cno == 2 and rp.c_available():
+        # the reference's two CPU paths against each other on two rows of the same grid (cok.pyx:56-94 vs ok.py:650-683): the
+        # size of the disagreement the reference itself lives with, next to the GPU-vs-reference one
+        mid = axes[1].size // 2
+        sl = [axes[0], axes[1][mid:mid + 2]]
+        zc, sc = rm.execute("grid", *sl, backend="C")
+        zv, sv = rm.execute("grid", *sl, backend="vectorized")
+        res["reference_c_vs_vectorized_max_abs_dz"] = float(np.abs(np.ma.getdata(zc) - np.ma.getdata(zv)).max())
+        res["reference_c_vs_vectorized_max_abs_dss"] = float(np.abs(np.ma.getdata(sc) - np.ma.getdata(sv)).max())
+    res["host_cpus"] = os.cpu_count()
+    res["tolerance"] = {"z": 1e-8, "ss": 1e-6}
+    res["ok"] = bool(res["max_abs_dz"] <= 1e-8 and res["max_abs_dss"] <= 1e-6)
+    return res
+
+
 def compact_other(line):
-    """What of an other_configs line goes under config["other_configs"] (the driver's record keeps `config` in full)."""
+    """The scalars of an other_configs line that scalars_for_driver() puts under `config` as c3_*, c4_*, c5_*, mw_k10_*, mw_k100_*."""
     roof = line.get("roofline") or {}
     c = {"value": line.get("value"), "ms_per_step": line.get("ms_per_step"), "frac": roof.get("frac"), "kernel": roof.get("kernel"),
          "max_abs_dz": line.get("max_abs_dz"), "max_abs_dss": line.get("max_abs_dss")}
@@ -473,13 +527,55 @@ def compact_other(line):
 
 
 def compact_multi_gpu(mg):
-    """config["multi_gpu"]: which exchange ran, on how many RCCL ranks, and what every device's prediction took."""
+    """The multi-GPU facts scalars_for_driver() puts under `config`: which exchange ran, on how many RCCL ranks, and what every device's prediction took."""
     per = mg.get("per_device_predict_ms")
     if per is None and mg.get("ranks"):
         per = [r.get("predict_ms") for r in mg["ranks"]]
     return {"rccl_ranks": mg.get("rccl_ranks"), "exchange_path": mg.get("exchange_path"), "per_device_predict_ms": per,
-            "exchange_ms": mg.get("exchange_ms"), "exchange_wait_ms": mg.get("exchange_wait_ms"),
+            "exchange_ms": mg.get("exchange_ms"), "exchange_wait_ms": mg.get("exchange_wait_ms"), "exchange_bytes": mg.get("exchange_bytes"),
             "exchange_fallbacks": mg.get("exchange_fallbacks"), "exchange_note": mg.get("exchange_note")}
+
+
+SHORT = {"config3": "c3", "config4": "c4", "config5": "c5", "moving_window_k10": "mw_k10", "moving_window_k100": "mw_k100"}
+
+
+def scalars_for_driver(out):
+    """The driver's BENCH record keeps the SCALAR keys of `config` and nothing else of the line (round-5 review: the nested
+    other_configs / multi_gpu / phases dicts it was given were dropped).  Everything the record must hold goes here as flat scalar
+    keys; the key set is pinned by tests/test_bench_host.py.  The full objects stay at the top level of the line."""
+    c = {}
+    for k, v in (out.get("phases_ms_per_step") or {}).items():
+        c["phase_%s_ms" % k] = v
+    for key, line in (out.get("other_configs") or {}).items():
+        p = SHORT.get(key, key)
+        for f, v in compact_other(line).items():
+            if v is not None or f in ("value", "max_abs_dz", "max_abs_dss"):
+                c["%s_%s" % (p, f)] = v
+    mg = out.get("multi_gpu")
+    if mg:
+        cm = compact_multi_gpu(mg)
+        for k in ("rccl_ranks", "exchange_path", "exchange_ms", "exchange_wait_ms", "exchange_bytes", "exchange_fallbacks", "exchange_note"):
+            c[k] = cm.get(k)
+        per = [p for p in (cm.get("per_device_predict_ms") or []) if p is not None]
+        if per:
+            c["predict_ms_slowest_device"], c["predict_ms_fastest_device"] = max(per), min(per)
+            c["per_device_predict_ms"] = ",".join("%.2f" % p for p in per)
+    for k, v in (out.get("factor_exchange_trial") or {}).items():
+        c["trial_" + k] = v if isinstance(v, (int, float, str, bool)) or v is None else json.dumps(v)
+    cb = out.get("cpu_baseline")
+    if cb:
+        for k in ("value", "kind", "cores", "cond_1", "gpu_vs_cpu_max_abs_dz", "gpu_vs_cpu_max_abs_dss", "slab_points"):
+            c["cpu_" + k if not k.startswith("gpu_") else k] = cb.get(k)
+    fgp = out.get("full_grid_parity")
+    if fgp:
+        for k in ("points_checked", "points_total", "coverage", "max_abs_dz", "max_abs_dss", "cond_1", "reference_points_per_s", "ok", "error"):
+            if k in fgp:
+                c["c2_fullgrid_" + k] = fgp[k]
+    roof = out.get("roofline") or {}
+    for k in ("kernel", "avg_launch_ms", "traffic", "algorithmic_bytes_per_launch"):
+        if roof.get(k) is not None:
+            c["roofline_" + k] = roof[k]
+    return c
 
 
 MW_KERNELS = {1: "k_mw_chol", 2: "k_mw_solve", 3: "k_mw_solve_big", 4: "k_mw_chol_blocked"}
@@ -522,10 +618,27 @@ def main():
     ap.add_argument("--pretrial-budget", type=float, default=float(os.environ.get("MIK_BENCH_PRETRIAL_BUDGET", "60")), metavar="S",
                     help="device groups: wall-clock seconds the trials before the timed loop may take in total (default 60); what "
                          "does not fit is skipped and config.factor_exchange_trial says so")
+    ap.add_argument("--full-parity", nargs="?", const="2,4,3,5", default=None, metavar="CONFIGS",
+                    help="instead of timing: krige the WHOLE grid of each listed config (default 2,4,3,5; config 5: a 4096 x 64 strip across "
+                         "the cut between two GPUs' slabs) with the drop-in class and with the staged reference (backend='vectorized', "
+                         "slab by slab on the host cores) and compare every point at 1e-8 / 1e-6; one JSON line per config")
+    ap.add_argument("--full-parity-budget", type=float, default=None, metavar="S",
+                    help="--full-parity: wall-clock bound of the reference side per config (default: none, the whole grid)")
+    ap.add_argument("--full-grid-budget", type=float, default=float(os.environ.get("MIK_BENCH_FULLGRID_BUDGET", "90")), metavar="S",
+                    help="default run: seconds the reference may spend on the headline's WHOLE-grid parity check after the timed steps "
+                         "(slabs spread over the grid; config.c2_fullgrid_* say how many points that covered; 0 = skip)")
     ap.add_argument("--no-other", action="store_true",
                     help="default run (config 2, 1 GPU): do not time BASELINE configs 3-5 and the moving window after the headline")
     args = ap.parse_args()
     inner = os.environ.get("MIK_BENCH_INNER") == "1"  # a rocprofv3 pass of collect_traffic_live: no CPU leg, no recursion
+    if args.full_parity:
+        os.environ["MIK_FACTOR_CACHE"] = "0"
+        bad = 0
+        for cno in [int(c) for c in args.full_parity.split(",")]:
+            res = full_grid_parity(cno, budget_s=args.full_parity_budget, log=lambda m: print(m, file=sys.stderr, flush=True))
+            bad += not res["ok"]
+            print(json.dumps(dict(full_grid_parity="config%d" % cno, **res)), flush=True)
+        sys.exit(1 if bad else 0)
 
     # Keep stdout clean for the ONE JSON line: RCCL prints banners from C++ to fd 1, so fd 1 points at
     # stderr while the benchmark runs and is restored just before the JSON is printed.
@@ -819,7 +932,7 @@ def main():
                       else "kriged grid-points/sec (z + sigma^2), " + cfg["name"])
             config = {"workload": cfg["name"], "stations": cfg["n"], "matrix_order": M,
                       "grid_points_per_gpu": npt_total // n_gpus, "grid_points_total": npt_total, "variogram": cfg["model"],
-                      "variogram_parameters": cfg["params"], "factor_exchange": exchange, "factor_exchange_trial": trial,
+                      "variogram_parameters": ",".join(str(p) for p in cfg["params"]), "factor_exchange": exchange,
                       "factor_path": FACTOR_PATHS.get(last.get("factor_path"), "?"),
                       "symmetric_contraction": bool(last.get("symmetric"))}
             kernel_prefix = "void mik::k_contract"
@@ -835,7 +948,8 @@ def main():
                "phases_ms_per_step": {"assemble": tsum["assemble_ms"] / K, "invert": tsum["invert_ms"] / K,
                                       "exchange": tsum["exchange_ms"] / K, "exchange_not_overlapped": tsum["exchange_wait_ms"] / K,
                                       "rhs": tsum["rhs_ms"] / K, "contract": tsum["contract_ms"] / K, "predict_total": tsum["predict_ms"] / K}}
-        config["phases_ms_per_step"] = dict(out["phases_ms_per_step"])  # (the driver's record keeps `config` in full)
+        if trial:
+            out["factor_exchange_trial"] = trial
         if last.get("sparse"):
             config["phases_note"] = ("range-aware contraction on two launch lanes (option sparse_lanes 2): the right-hand-side / list kernels of one "
                                      "launch run beside the other lane's contraction; rhs and contract are per-kernel HIP-event sums and may "
@@ -861,8 +975,6 @@ def main():
         elif world > 1:
             allp = pg.all_gather_object({"rank": rank, "device": int(os.environ["MIK_DEVICE"]), "predict_ms": last.get("predict_ms")})
             out["multi_gpu"] = {"ranks": allp, "exchange_path": exchange, "rccl_ranks": world if exchange == "rccl_bcast" else 0}
-        if "multi_gpu" in out:
-            config["multi_gpu"] = compact_multi_gpu(out["multi_gpu"])
         # ---- roofline.traffic: live PMC passes over one step of this benchmark, else the committed profile (labelled)
         if n_gpus == 1 and not inner and args.pmc != "off":
             progress["stage"] = "live PMC passes (rocprofv3)"
@@ -950,8 +1062,6 @@ def main():
                     out["other_configs"][key] = other_config_line(cno, win)
                 except Exception as e:  # noqa: BLE001
                     out["other_configs"][key] = {"value": None, "error": repr(e)[:300]}
-            # the driver's BENCH record keeps `config` verbatim but only the NAMES of other top-level keys: a compact copy goes there
-            config["other_configs"] = {key: compact_other(line) for key, line in out["other_configs"].items()}
         if n_gpus == 1 and not args.no_cpu and not inner:
             progress["stage"] = "cpu_baseline leg"
             try:
@@ -971,6 +1081,15 @@ def main():
             except Exception as e:  # the bench line must still come out
                 out["cpu_baseline"] = {"value": None, "unit": "grid-points/s", "cores": None, "kind": "port",
                                        "sample": "failed: %r" % (e,)}
+        if n_gpus == 1 and world == 1 and not inner and not kw and args.config == 2 and not args.no_cpu and args.full_grid_budget > 0:
+            # parity over the WHOLE headline grid: one execute('grid') of all 10^6 points against the reference kriging the same grid
+            # slab by slab for --full-grid-budget seconds (spread over the grid; `bench.py --full-parity` = without the bound)
+            progress["stage"] = "whole-grid parity against the reference"
+            try:
+                out["full_grid_parity"] = full_grid_parity(2, budget_s=args.full_grid_budget)
+            except Exception as e:  # noqa: BLE001
+                out["full_grid_parity"] = {"ok": None, "error": repr(e)[:300]}
+        config.update(scalars_for_driver(out))  # what the driver's record keeps: flat scalar keys of `config`
         emit(json.dumps(out))
     elif world > 1:
         pg.all_gather_object({"rank": rank, "device": int(os.environ["MIK_DEVICE"]), "predict_ms": last.get("predict_ms")})

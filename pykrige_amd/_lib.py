@@ -127,13 +127,23 @@ def load():
             "pykrige_amd: %s is missing -- build it with `python -m pykrige_amd.build` "
             "(needs hipcc; there is no CPU fallback)" % LIB_PATH)
     lib = C.CDLL(LIB_PATH)
+    # the version first: a library from before a symbol was added must end in the "rebuild it" message, not in a bare AttributeError
+    have = getattr(lib, "mik_abi_version", None)
+    version = None
+    if have is not None:
+        have.restype, have.argtypes = SIGNATURES["mik_abi_version"]
+        version = have()
+    stale = "pykrige_amd: %s %%s, this package was written against ABI version %d -- rebuild it (`python -m pykrige_amd.build --force`)" % (
+        LIB_PATH, ABI_VERSION)
+    if version != ABI_VERSION:
+        raise ImportError(stale % ("has no mik_abi_version" if version is None else "has ABI version %d" % version))
     for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise ImportError(stale % ("does not export %s" % name)) from None
         fn.restype = res
         fn.argtypes = args
-    if lib.mik_abi_version() != ABI_VERSION:
-        raise ImportError("pykrige_amd: %s has ABI version %d, this package was written against %d -- rebuild it "
-                          "(`python -m pykrige_amd.build --force`)" % (LIB_PATH, lib.mik_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 

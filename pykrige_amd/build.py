@@ -1,7 +1,9 @@
 """Builds pykrige_amd/libmikrige.so (HIP, gfx950) in-tree.  `python -m pykrige_amd.build [--force] [-j N]`.
 
 The library is eight translation units compiled in parallel (objects under pykrige_amd/csrc/build/, git- and gpurun-ignored) and
-linked into one shared object; only the units whose sources changed are recompiled:
+linked into one shared object; only the units whose sources or flags changed are recompiled (the command line of every object is
+kept beside it as <name>.flags).  Safe against concurrent callers (pytest-xdist, one process per GPU calling __graft_entry__.build):
+the whole build holds an flock on csrc/build/.lock, and objects / the library are written under a per-process name and renamed into place.
 
     mikrige.hip       C ABI, handles, device groups + factor exchange, K1 assembly, points / grids / masks, statistics
     mik_inverse.hip   K2: block Gauss-Jordan sweep and its schedules, probes, pseudo-inverses
@@ -33,7 +35,7 @@ UNITS = {
     "mik_mw_chol2": ("mik_mw_chol.hip", ["mik_k_mw_chol.h"], ["-DMIK_MWC_PART=2"]),
     "mik_mw_chol3": ("mik_mw_chol.hip", ["mik_k_mw_chol.h"], ["-DMIK_MWC_PART=3"]),
 }
-# --offload-compress: the code objects travel zstd-compressed inside the fat binary (16.6 -> 5 MB of .so; the HIP runtime unpacks them at load)
+# --offload-compress: the code objects travel zstd-compressed inside the fat binary (16.9 -> 2.6 MB of .so; the HIP runtime unpacks them at load)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "--offload-compress", "-I" + os.path.join(ROOT, "include")]
 
 
@@ -58,11 +60,18 @@ def all_sources():
     return seen
 
 
-def _stale(target, deps):
+def _stale(target, deps, flags=None):
     if not os.path.exists(target):
         return True
     t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+    if any(os.path.getmtime(d) > t for d in deps):
+        return True
+    if flags is not None:  # built with another command line (e.g. the fallback without --offload-compress): stale
+        try:
+            return open(target[:-2] + ".flags").read() != " ".join(flags)
+        except OSError:
+            return True
+    return False
 
 
 def up_to_date():
@@ -74,34 +83,55 @@ def build_library(force=False, verbose=False, jobs=None):
     if not force and up_to_date():
         return OUT
     os.makedirs(OBJ, exist_ok=True)
+    import fcntl
+
+    with open(os.path.join(OBJ, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)  # one builder at a time; the others find the work done when they get the lock
+        if not force and up_to_date():
+            return OUT
+        return _build_locked(force, verbose, jobs)
+
+
+def _build_locked(force, verbose, jobs):
     cc = hipcc()
+    pid = ".%d.tmp" % os.getpid()
     todo = []
     for name, (src, _, extra) in UNITS.items():
         obj = os.path.join(OBJ, name + ".o")
-        if force or _stale(obj, unit_deps(name)):
-            todo.append((name, [cc] + FLAGS + extra + ["-c", os.path.join(CSRC, src), "-o", obj]))
+        flags = FLAGS + extra
+        if force or _stale(obj, unit_deps(name), flags):
+            todo.append((name, flags, [cc] + flags + ["-c", os.path.join(CSRC, src), "-o", obj + pid]))
 
     def run(job):
-        name, cmd = job
+        name, flags, cmd = job
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0 and "--offload-compress" in cmd and "offload-compress" in r.stderr:
-            # a hipcc that does not know the flag (before ROCm 6.1): the same objects, uncompressed
+            # a hipcc that does not know the flag (before ROCm 6.1): the same objects, uncompressed -- and recorded as such, so that
+            # a later build with a newer hipcc sees them as stale (the library is several times larger without the compression)
+            flags = [c for c in flags if c != "--offload-compress"]
+            print("pykrige_amd.build: this hipcc does not know --offload-compress; %s is built uncompressed" % name, file=sys.stderr)
             r = subprocess.run([c for c in cmd if c != "--offload-compress"], capture_output=True, text=True)
+        obj = os.path.join(OBJ, name + ".o")
         if r.returncode != 0:
+            if os.path.exists(obj + pid):
+                os.remove(obj + pid)
             raise RuntimeError("compiling %s failed:\n%s" % (name, r.stderr[-4000:]))
+        os.replace(obj + pid, obj)
+        with open(obj[:-2] + ".flags", "w") as f:
+            f.write(" ".join(flags))
         return name
 
     # the four mik_mw_chol units are the long ones: start them first
     todo.sort(key=lambda j: 0 if j[0].startswith("mik_mw_chol") else 1)
     with ThreadPoolExecutor(max_workers=jobs or min(len(UNITS), os.cpu_count() or 4)) as ex:
         list(ex.map(run, todo))
-    link = [cc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [os.path.join(OBJ, n + ".o") for n in UNITS] + ["-o", OUT + ".tmp", "-ldl"]
+    link = [cc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [os.path.join(OBJ, n + ".o") for n in UNITS] + ["-o", OUT + pid, "-ldl"]
     if verbose:
         print(" ".join(link), flush=True)
     subprocess.run(link, check=True)
-    os.replace(OUT + ".tmp", OUT)
+    os.replace(OUT + pid, OUT)
     return OUT
 
 

@@ -69,6 +69,9 @@ __device__ __forceinline__ ExpTab exp_tab_load() {
   return t;
 }
 __device__ __forceinline__ double exp_neg_lean(double x, const ExpTab& T) {
+  // one v_max_f64: far-apart / huge coordinates give d or d^2 = inf or 1e300 -> x = -inf would make the reduction inf - inf = NaN and (int)n is
+  // undefined beyond 2^31; at -800 the result has already underflowed to 0 (gamma = sill, as libm's exp and the reference give)
+  x = __builtin_fmax(x, -800.0);
   double t;
   asm("v_mul_f64 %0, %1, %2" : "=v"(t) : "s"(T.log2e), "v"(x));
   const double n = __builtin_rint(t);

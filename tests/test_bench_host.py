@@ -134,8 +134,8 @@ def test_other_configs_key_set_and_trial_flags_are_pinned():
     for field in ('"value"', '"ms_per_step"', '"roofline"', '"max_abs_dz"', '"max_abs_dss"', '"parity_source"'):
         assert field in src[src.index("def other_config_line"):src.index("MW_KERNELS = {")]
     assert 'out["other_configs"]' in src
-    # round 5: compact copies under `config`, the one object the driver's BENCH record keeps verbatim
-    assert 'config["other_configs"] = {key: compact_other(line)' in src and 'config["multi_gpu"] = compact_multi_gpu(' in src
+    # round 6: the driver's record keeps only SCALAR keys of `config`: everything it must hold is flattened there (scalars_for_driver)
+    assert "config.update(scalars_for_driver(out))" in src
     line = {"value": 3.0e7, "ms_per_step": 500.0, "roofline": {"frac": 0.78, "kernel": "k_contract_spg"}, "max_abs_dz": 1e-11, "max_abs_dss": 2e-11,
             "phases_ms_per_step": {"invert": 10.0}, "parity_source": "x"}
     assert bench.compact_other(line) == {"value": 3.0e7, "ms_per_step": 500.0, "frac": 0.78, "kernel": "k_contract_spg", "max_abs_dz": 1e-11,
@@ -145,7 +145,8 @@ def test_other_configs_key_set_and_trial_flags_are_pinned():
     mg = bench.compact_multi_gpu({"ranks": [{"rank": 0, "predict_ms": 5.0}, {"rank": 1, "predict_ms": 6.0}], "exchange_path": "rccl_bcast", "rccl_ranks": 2})
     assert mg["rccl_ranks"] == 2 and mg["exchange_path"] == "rccl_bcast" and mg["per_device_predict_ms"] == [5.0, 6.0]
     mg = bench.compact_multi_gpu({"per_device_predict_ms": [1.0, 2.0], "exchange_path": "peer_scatter_allgather", "rccl_ranks": 0, "exchange_ms": 3.0})
-    assert set(mg) == {"rccl_ranks", "exchange_path", "per_device_predict_ms", "exchange_ms", "exchange_wait_ms", "exchange_fallbacks", "exchange_note"}
+    assert set(mg) == {"rccl_ranks", "exchange_path", "per_device_predict_ms", "exchange_ms", "exchange_wait_ms", "exchange_bytes", "exchange_fallbacks",
+                       "exchange_note"}
     for flag in ("--no-trials", "--pretrial-budget", "--no-other", "--sparse", "--sparse-rows", "--sort-points", "--sparse-lanes", "MIK_BENCH_TRIALS"):
         assert flag in src
     # the stored slabs those checks read exist and are the configs' own
@@ -155,6 +156,73 @@ def test_other_configs_key_set_and_trial_flags_are_pinned():
         assert str(g["model"]) == bench.CONFIGS[cno]["model"] and g["params_user"].tolist() == bench.CONFIGS[cno]["params"]
     mw = np.load(os.path.join(ROOT, "tests", "golden", "fullsize", "mw_c2.npz"))
     assert mw["x"].size == bench.CONFIGS[2]["n"] and mw["windows"].tolist() == [10, 100]
+
+
+def test_driver_record_keys_are_flat_scalars_and_pinned():
+    """Round 6: what the driver's BENCH record keeps of the line is the scalar keys of `config`.  A fabricated line of the default run
+    (other configs, CPU leg, whole-grid parity) and of an 8-GPU run must flatten into scalars only, under these names."""
+    other = {"value": 3.0e7, "ms_per_step": 56.0, "roofline": {"frac": 0.78, "kernel": "k_contract_spg"}, "max_abs_dz": 1e-11, "max_abs_dss": 2e-11,
+             "phases_ms_per_step": {"invert": 13.0}}
+    out = {"phases_ms_per_step": {"assemble": 0.1, "invert": 4.3, "exchange": 0.0, "exchange_not_overlapped": 0.0, "rhs": 73.0, "contract": 356.0,
+                                  "predict_total": 365.0},
+           "other_configs": {k: dict(other) for k in bench.SHORT},
+           "cpu_baseline": {"value": 1466.0, "kind": "reference", "cores": 16, "cond_1": 4.6e6, "gpu_vs_cpu_max_abs_dz": 1e-10,
+                            "gpu_vs_cpu_max_abs_dss": 3e-10, "slab_points": 17000, "host": {"nested": 1}},
+           "full_grid_parity": {"points_checked": 10 ** 6, "points_total": 10 ** 6, "coverage": 1.0, "max_abs_dz": 1e-10, "max_abs_dss": 3e-10,
+                                "cond_1": 4.6e6, "reference_points_per_s": 8000.0, "ok": True, "worst_dz_at": [0.1, 0.2]},
+           "roofline": {"kernel": "k_contract", "avg_launch_ms": 44.5, "traffic": 1.1e11, "algorithmic_bytes_per_launch": 5.2e9, "note": "x"}}
+    c = bench.scalars_for_driver(out)
+    assert all(v is None or isinstance(v, (int, float, str, bool)) for v in c.values()), c
+    for key in ("phase_invert_ms", "phase_contract_ms", "phase_predict_total_ms", "c3_value", "c3_frac", "c4_value", "c5_value", "c5_frac", "c5_kernel",
+                "c5_max_abs_dz", "c5_max_abs_dss", "c5_invert_ms", "mw_k10_value", "mw_k100_value", "mw_k100_frac", "cpu_value", "cpu_kind", "cpu_cores",
+                "cpu_cond_1", "gpu_vs_cpu_max_abs_dz", "gpu_vs_cpu_max_abs_dss", "c2_fullgrid_points_checked", "c2_fullgrid_coverage",
+                "c2_fullgrid_max_abs_dz", "c2_fullgrid_max_abs_dss", "c2_fullgrid_ok", "roofline_kernel", "roofline_avg_launch_ms", "roofline_traffic"):
+        assert key in c, key
+    mg = {"multi_gpu": {"per_device_predict_ms": [41.0, 42.5, None], "exchange_path": "rccl_bcast", "rccl_ranks": 8, "exchange_ms": 6.0,
+                        "exchange_wait_ms": 1.0, "exchange_bytes": 2.6e8},
+          "factor_exchange_trial": {"budget_s": 60.0, "rccl_exchange_ms": 6.1, "skipped_for_budget": ["overlap"]}}
+    c = bench.scalars_for_driver(mg)
+    assert all(v is None or isinstance(v, (int, float, str, bool)) for v in c.values()), c
+    assert c["rccl_ranks"] == 8 and c["exchange_path"] == "rccl_bcast" and c["exchange_bytes"] == 2.6e8
+    assert c["predict_ms_slowest_device"] == 42.5 and c["per_device_predict_ms"] == "41.00,42.50"
+    assert c["trial_rccl_exchange_ms"] == 6.1 and c["trial_skipped_for_budget"] == '["overlap"]'
+    # and nothing nested is put under `config` by main() any more
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for gone in ('config["other_configs"]', 'config["multi_gpu"]', 'config["phases_ms_per_step"]', '"factor_exchange_trial": trial'):
+        assert gone not in src, gone
+
+
+def test_whole_grid_parity_plan_covers_every_point_once_and_spreads():
+    """oracle/full_grid.py (round 6): slabs are whole rows / z planes that tile the grid exactly; the visiting order spreads any prefix."""
+    from oracle import full_grid as fg
+
+    for cno in (2, 3, 4, 5):
+        axes = bench.full_grid_axes(cno)
+        plan = fg.slab_plan(axes, bench.FULL_GRID[cno]["target"])
+        seen = np.zeros(axes[-1].size, dtype=int)
+        for ax, sl in plan:
+            assert all(np.array_equal(a, b) for a, b in zip(ax[:-1], axes[:-1])) and np.array_equal(ax[-1], axes[-1][sl])
+            seen[sl] += 1
+            assert int(np.prod([a.size for a in ax])) <= max(bench.FULL_GRID[cno]["target"], int(np.prod([a.size for a in axes[:-1]])))
+        assert (seen == 1).all()
+    assert [a.size for a in bench.full_grid_axes(5)] == [4096, 64] and bench.FULL_GRID[5]["strip"][0] < 512 < bench.FULL_GRID[5]["strip"][1]
+    o = fg.spread_order(20)
+    assert sorted(o) == list(range(20)) and o[:4] == [0, 16, 8, 4]
+
+    class Fake:  # a "reference" that returns f(x, y) on the slab: compare() must index the whole-grid arrays the same way
+        def execute(self, style, gx, gy, backend):
+            X, Y = np.meshgrid(gx, gy)
+            return X + 10 * Y, X - Y
+
+    gx, gy = np.linspace(0, 1, 7), np.linspace(0, 1, 11)
+    X, Y = np.meshgrid(gx, gy)
+    zz, ss = X + 10 * Y, X - Y
+    zz[6, 3] += 1e-3
+    r = fg.compare(Fake(), zz, ss, [gx, gy], 14)
+    assert r["points_checked"] == 77 and r["coverage"] == 1.0 and abs(r["max_abs_dz"] - 1e-3) < 1e-12 and r["max_abs_dss"] == 0.0
+    assert np.allclose(r["worst_dz_at"], [gx[3], gy[6]])
+    r = fg.compare(Fake(), zz, ss, [gx, gy], 14, budget_s=0.0)
+    assert r["slabs_checked"] == 1 and 0 < r["coverage"] < 1
 
 
 def test_cpu_leg_times_the_reference_itself_where_it_is_staged():

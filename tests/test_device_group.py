@@ -234,6 +234,8 @@ def test_spherical_model_across_device_counts():
                 assert r.stdout.strip().splitlines()[-1].split() == [str(ndev), sparse]
                 res[sparse, ndev] = np.load(out)
         assert np.array_equal(res["0", 1], res["0", 3])  # dense contraction: bit-identical across device counts
-        assert np.array_equal(res["1", 1][0], res["1", 3][0])  # z does not go through the contraction
+        # z = c . delta is summed by k_rhs in candidate-list order, which follows the 128-point blocks like the tile set does: across device
+        # counts it agrees to rounding (include/mikrige.h, option "sparse"), not by construction bit for bit
+        assert np.abs(res["1", 1][0] - res["1", 3][0]).max() <= 1e-13
         assert np.abs(res["1", 1][1] - res["1", 3][1]).max() <= 1e-12
         assert np.abs(res["1", 1] - res["0", 1]).max() <= 1e-11

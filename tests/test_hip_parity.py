@@ -361,7 +361,7 @@ def test_lean_exp_of_the_moving_window_set_up_is_within_an_ulp_and_a_half():
     to underflow -- it stays within 1.5 ulp of NumPy's exp; exp(0) = 1 exactly; no NaN at the ends."""
     lib = _lib()
     rng = np.random.default_rng(3)
-    x = -np.concatenate([[0.0, 1e-300, 1e-17, 0.5 * np.log(2.0), np.log(2.0), 1.0, 708.0, 745.0, 745.2, 800.0, 1e6],
+    x = -np.concatenate([[0.0, 1e-300, 1e-17, 0.5 * np.log(2.0), np.log(2.0), 1.0, 708.0, 745.0, 745.2, 800.0, 1e6, 3e9, 1e300, np.inf],
                          10.0 ** rng.uniform(-12, 2.9, 200000), rng.uniform(0.0, 50.0, 200000)])
     got = lib.selftest_exp(x)
     ref = np.exp(x)
