@@ -600,7 +600,6 @@ def main():
                     help="how the inverted matrix reaches the other GPUs (auto: RCCL broadcast, else peer copies)")
     ap.add_argument("--symmetric", type=int, default=None)
     ap.add_argument("--chunk", type=int, default=None)
-    ap.add_argument("--engine", choices=["mfma", "valu"], default=None)
     ap.add_argument("--factor", choices=["auto", "sweep", "lu"], default=None, help="force the inverse path")
     ap.add_argument("--moving-window", type=int, default=None, metavar="K",
                     help="time moving-window kriging (n_closest_points=K) on the same workload instead (not the headline metric)")
@@ -731,8 +730,6 @@ def main():
             hh.set_option("symmetric", args.symmetric)
         if args.chunk is not None:
             hh.set_option("chunk", args.chunk)
-        if args.engine is not None:
-            hh.set_option("engine", 1 if args.engine == "valu" else 0)
         if args.factor is not None:
             hh.set_option("factor", {"auto": 0, "sweep": 1, "lu": 2}[args.factor])
         if args.sparse is not None:
@@ -904,7 +901,7 @@ def main():
             algo_flops_per_launch = 2.0 * M * M * pts_per_launch  # 2 M^2 per point for w = A_inv . b
             effective = algo_flops_per_launch / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0
             executed = tsum["contract_flops_executed"] / (tsum["contract_ms"] * 1e-3) / 1e12 if tsum["contract_ms"] > 0 else 0.0
-            roof = {"bound": "mfma", "kernel": "k_contract_valu" if last.get("engine") else sparse_kernel(last) if last.get("sparse") else "k_contract",
+            roof = {"bound": "mfma", "kernel": sparse_kernel(last) if last.get("sparse") else "k_contract",
                     "achieved": executed, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": executed / FP64_MFMA_PEAK_TFLOPS,
                     "peak_measured": FP64_MFMA_MEASURED_TFLOPS, "frac_of_measured_peak": executed / FP64_MFMA_MEASURED_TFLOPS,
                     "effective_tflops": effective, "effective_frac": effective / FP64_MFMA_PEAK_TFLOPS,
@@ -981,7 +978,7 @@ def main():
             tail = ["--steps", "1", "--warmup", "0", "--no-cpu", "--pmc", "off", "--config", str(args.config)]
             if kw:
                 tail += ["--moving-window", str(kw)]
-            for flag, val in (("--symmetric", args.symmetric), ("--chunk", args.chunk), ("--engine", args.engine), ("--factor", args.factor)):
+            for flag, val in (("--symmetric", args.symmetric), ("--chunk", args.chunk), ("--factor", args.factor)):
                 if val is not None:
                     tail += [flag, str(val)]
             live, why = collect_traffic_live(tail, kernel_prefix)
@@ -994,13 +991,13 @@ def main():
         if roof.get("traffic") is None and not kw:
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", "k_contract_traffic.json")))
-                if tj["workload"] == cfg["name"] and not last.get("engine") and last.get("symmetric"):
+                if tj["workload"] == cfg["name"] and last.get("symmetric"):
                     roof["traffic"] = tj["hbm_bytes_per_launch"] * (pts_per_launch / tj["points_per_launch"])
                     roof["traffic_source"] = ("from_profile (NOT collected in this run): " + tj["source"]
                                               + ("; " + roof["traffic_source"] if roof.get("traffic_source") else ""))
             except Exception:
                 pass
-        if not kw and not last.get("sparse") and not last.get("engine") and last.get("symmetric"):
+        if not kw and not last.get("sparse") and last.get("symmetric"):
             # how much of `traffic` is HBM: no Infinity-Cache hit / miss counter exists on gfx950, so the split is made by L2-miss latency
             # in a run of its own (scripts/gpu_hbm_split.sh) and quoted from its tracked summary, scaled to this launch's points
             try:

@@ -185,8 +185,13 @@ int  mik_handle_devices(mik_handle *h);          /* members of the handle's devi
 int  mik_slab_of(int64_t n, int members, int i, int64_t *lo, int64_t *count); /* the slab of n unmasked points member i gets
                                                     (contiguous, cut at multiples of 128 points); needs no GPU */
 
-/* options: "factor" 0=auto 1=sweep 2=pivoted ; "symmetric" 0/1 (contraction uses A_inv symmetry) ;
- * "engine" 0 = MFMA f64 contraction, 1 = VALU (v_fma_f64) contraction ; "waves" 4 | 8 = wavefronts per contraction block ;
+/* options (round 6: every option is either a documented fallback, a cross-check kernel of the parity tests, or a schedule switch of a default
+ * path; the experiments of rounds 2-5 -- "engine", "waves", "update_waves", "update_deep", "update_tpb", "update_pf", "update_token",
+ * "update_map", "pivot256", "wide_reserve", "wide_colstream", "panel_rows", "diag", "early_diag", "fuse_chain", "sparse_ktile",
+ * "sparse_epilogue", and before them "pairs", "prefetch", "update_atomic" -- are refused as unknown; their kernels live in
+ * tools/mik_k_experiments.h or git history, their measurements in profiles/ and DESIGN_HISTORY.md):
+ * "factor" 0=auto 1=sweep 2=pivoted ; "symmetric" 0/1 (1 = the contraction forms b^T A_inv b over one triangle of A_inv; 0 = the reference's
+ *   full product w = A_inv b, ok.py:679: the cross-check kernel of the parity tests) ;
  * "sparse" -1/0/1/2 = range-aware contraction for variograms with compact support (the reference's spherical model is constant
  *   beyond its range, variogram_models.py:56-70).  With u = [1_N; 0] and s = psill + nugget the right-hand side is b = -s u + delta,
  *   delta_k = s - gamma(d_k) = 0 for every station beyond the range, and because A e_last = u:  z = c . delta  and
@@ -207,13 +212,10 @@ int  mik_slab_of(int64_t n, int members, int i, int64_t *lo, int64_t *count); /*
  *   [8r, 8r + 8) as rows, the entries beyond as K tiles, then its own groups as a triangle) or an ALIGNED block of 128 rows that is
  *   contracted whole when any of its eight groups is active (128: k_contract_sp; active blocks are ~79 % full at BASELINE config
  *   5).  -1 (default) = 16 wherever 32-bit DMA offsets reach every row (Mp <= 23168), else 128 [MIK_SPARSE_ROWS] ;
- * "sparse_ktile" 16/8 = range-aware contraction over gathered row groups: stations per candidate / flag / list tile.  8 (round 5): a K step
- *   of the contraction is a PAIR of list-adjacent 8-station tiles staged into the two halves of the 16-wide LDS tile, a 16-row group is two
- *   gathered 8-row groups, an odd last entry is half a K step: 718 instead of 780 stations in active tiles at BASELINE config 5 (work ~ n^2:
- *   -15 %).  Same exact sum (skipped entries are exact zeros of delta) [MIK_SPARSE_KTILE] ;
- * "sparse_epilogue" 0/1 = 8-station form: 1 (default) = a row group's term sum_i delta_ti W_it is formed at the K step of the group's own
- *   square from that step's B tile in LDS (sixteen LDS reads in one batch); 0 = from global memory behind the K loop (two memory round
- *   trips per tile with the other wavefronts at a barrier): BASELINE config 5 contraction 38.0 -> 36.3 ms per 2.1 M points (profiles/r05_spg_tile_phases.txt) ;
+ *   With gathered row groups the flags and lists are per 8 stations (round 5): a K step of the contraction is a PAIR of list-adjacent
+ *   8-station tiles staged into the two halves of the 16-wide LDS tile, a 16-row group is two gathered 8-row groups, an odd last entry is
+ *   half a K step (718 instead of 780 stations in active tiles at BASELINE config 5; work ~ n^2); a row group's term sum_i delta_ti W_it
+ *   is formed at the K step of the group's own square from that step's B tile in LDS.  Aligned blocks keep 16-station lists ;
  * "sparse_group" 1..16 = k_contract_spg's queue order: point blocks per group (a group's tiles run on one XCD, tile position ascending
  *   = longest K loops first, point block fast; default 16) [MIK_SPARSE_GROUP] ;
  * "sort_points" -1/0/1 = range-aware contraction: the points of every launch (one chunk of the resident point list) are put in
@@ -234,7 +236,7 @@ int  mik_slab_of(int64_t n, int members, int i, int64_t *lo, int64_t *count); /*
  *   (the reference's own KT3D test case: cond(A) 3e14 -> 2e6; the unpivoted sweep's |dz| 6e-9 -> 2e-11).  Not with pseudo_inv
  *   (a pseudo-inverse is not invariant under S) or a caller's a_inv.  mik_get_matrix(1) hands out the inverse of the
  *   reference's matrix, S^T A'^-1 S ;
- * "tri" 0/1 = symmetric contraction (8-wave form): the diagonal block of a tile is contracted as a triangle of 16-row groups,
+ * "tri" 0/1 = symmetric contraction: the diagonal block of a tile is contracted as a triangle of 16-row groups,
  *   36 of its 64 (row group, K tile) products (default 1: -1.5 % contraction time, partials equal to 1e-14) [MIK_TRI] ;
  * "symmetrize" 0/1 = after a full sweep, the pivoted elimination or a pseudo-inverse: A_inv <- (A_inv + A_inv^T) / 2 (default 1).
  *   The symmetric contraction reads one triangle of A_inv; a quadratic form sees only the symmetric part, so with the average
@@ -244,50 +246,16 @@ int  mik_slab_of(int64_t n, int members, int i, int64_t *lo, int64_t *count); /*
  * "rhs_overlap" 0/1 = two right-hand-side panels: K3a of the next chunk runs on a second stream while the current chunk is
  *   contracted (default 0: measured a tie -- the contraction slows down by what K3a takes) [MIK_RHS_OVERLAP] ;
  * "lookahead" 0/1/-1 = overlap the next panel's serial chain with the current trailing update in the block sweep
- *   (default -1: from 3 block columns on with the early-diagonal schedule, else from 24) ;
- * "early_diag" -1/0/1/2/4/5 = look-ahead sweep: the next diagonal block is built from 128 panel rows (two distributed 128^3
- *   products) and inverted on the second stream AHEAD of the panel kernel and update of its step (default -1 = 1 = on, the two
- *   streams ordered by events; 0 = the round-1 look-ahead; 2 = with one-block tile kernels; 5 / 4 = the update stream / both
- *   streams ordered by in-kernel flag waits instead -- 6 % faster at N=5000, but not for runs under tools that serialise
- *   kernel dispatches such as rocprofv3 --pmc: there the wait runs out and mik_factor returns MIK_EHIP).  Environment:
- *   MIK_EARLY_DIAG.  Every setting returns the bit-identical inverse ;
- * "fuse_chain" 0/1 = the block-column update leaves the next panel copy in place and the
- *   panel kernel writes R^T itself: two kernels on the serial chain instead of four (default 1) ; "diag" 0..4 = diagonal-block inverse kernel variant: 0..3 = 128 barrier-separated
- *   pivot steps on different thread grids (the same bits), 4 = blocked, 8 sub-steps of 16 pivots with the rank-16 updates on the matrix
- *   cores (default; equal to rounding, 62 us against 86 us per 128 x 128 block) ;
- * "update_waves" 4 | 8 = wavefronts per 128 x 128 tile of the block sweep's trailing update (wave tile 64 x 64 / 32 x 64; same bits;
- *   default 8)
- *   [MIK_UPDATE_WAVES] ;
- * (round 5: "pairs", "prefetch", "sparse_epilogue", "update_atomic" -- options every A/B of rounds 2-4 lost -- are gone; their kernels'
- *   variants remain in the headers for tools/kernel_bench, their measurements in profiles/r02_*, r03_*, r04b_*.)
- * "update_map" 0/n = tile order of the sweep's trailing update: 0 = block column by block column (default), n > 1 = n x n
- *   super-blocks (the ~64 tiles an XCD has in flight share n + n operand panels in its L2 instead of one panel per tile) --
- *   measured a tie at N = 2000 .. 8000: the update is not bound by its panel reads; same bits [MIK_UPDATE_MAP] ;
+ *   (default -1: from 3 block columns on).  The look-ahead schedule is the "early diagonal" one: the next diagonal block is built from 128
+ *   panel rows (two distributed 128^3 products) and inverted on the second stream AHEAD of the panel kernel and update of its step; the
+ *   streams are ordered by events only; every schedule returns the bit-identical inverse ;
  * "update_rev" -1/0/1 = half sweep: on odd steps the trailing update walks every XCD's range of tiles from its end.  The sweep streams the
  *   whole upper block triangle once per step (260 MB at N = 8000: more than the 256 MB memory-side cache holds); a cyclic stream
  *   leaves nothing behind in an LRU cache, a back-and-forth one most of it.  Same tiles, same bits; measured N = 8000 14.0 -> 13.45 ms, a
  *   tie at N <= 5000: -1 (default) = on from 45 block columns [MIK_UPDATE_REV] ;
- * "update_deep" 0/1 = panel-stream sweep: the rest of every trailing update by k_update_deep -- one 16-wavefront block per CU, the
- *   block's T tile loaded into registers BEFORE its K loop, operands through four LDS buffers with three K tiles in flight,
- *   "update_tpb" tiles per block run as one pipeline.  Same K order and the same subtraction per entry: same bits.  Measured
- *   SLOWER (N = 8000 13.5 -> 16.3 ms; profiles/r05_update_deep_ab.txt): default 0 [MIK_UPDATE_DEEP] ;
- * "update_tpb" 0..64 = tiles per block of k_update_deep; 0 (default) = two rounds of blocks per step [MIK_UPDATE_TPB] ;
- * "update_token" 0/1 = half sweep: a per-CU token makes the two resident blocks of the trailing update alternate between K loop and
- *   read-modify-write instead of running them in step (same bits).  Measured 7 - 9 % SLOWER (N = 5000 4.26 -> 4.55 ms, N = 8000 13.5 -> 14.8):
- *   the two blocks of a CU do overlap each other already; what adds is chip-wide (HBM) -- default 0 ;
- * "update_pf" 0/1 = half sweep: the rest of every trailing update on blocks of four wavefronts that take HALF tiles (64 x 128) and load
- *   their part of T into registers before the K loop (k_update_w PF; same bits).  A tie in the 128-wide sweep, default 0 ;
- * "pivot256" 0/1 = half sweep with pivot blocks of 256 columns (one read-modify-write of T per TWO block columns; the 256 x 256 diagonal
- *   block by a Schur split over two runs of the 128-block kernel; equal to the 128-wide sweep to rounding).  Measured a tie at
- *   N = 8000 and slower below (profiles/r05_wide_sweep_timeline.txt): opt-in, default off [MIK_PIVOT256] ;
- * "wide_reserve" 0..128 = CUs (multiple of 8) the wide sweep's update stream leaves to the kernels of the next pivot's chain through a
- *   CU mask (hipExtStreamCreateWithCUMask: bit i = CU i / 8 of XCD i % 8); default 16 ;
- * "wide_colstream" 0/1 = wide sweep: the column part of an update on a stream of its own beside the rest (measured slower: 0) ;
  * "panel_stream" 0/1/-1 = early-diagonal sweep: the panel kernel and the update of the next block column (+ the diagonal tile
  *   after next) run on a third stream beside the rest of the previous step's trailing update, ordered by events only (default
  *   -1 = from 24 block columns on; same bits) [MIK_PANEL_STREAM] ;
- * "panel_rows" 32 | 64 | 128 = rows of the column panel one block of the sweep's panel kernel forms (same bits; default 32:
- *   four times the blocks of the one-tile form, the kernel sits on the update stream's critical path) [MIK_PANEL_ROWS] ;
  * "pinv_fast" 0/1 = pseudo_inv: try the deflated regular inverse before the Jacobi pseudo-inverse (default 1) ;
  * "pinv_block" -1/0/1 = the Jacobi pseudo-inverse (factor_path 4) in its block form (default -1 = from 1536 rows on; 1 = always): rows in blocks of 32 sorted by norm, per
  *   pair of blocks one pass for the 64 x 64 Gram matrix, its eigenproblem by a two-sided Jacobi in LDS, one pass for the block

@@ -1,10 +1,9 @@
 // mik_kernels.h -- gfx950 (CDNA4) device code of the kriging execute() path.  fp64 throughout.
 //
 //   K1  k_assemble            kriging matrix A (or its SPD-shifted form) from station coordinates
-//   K2  k_diag_inv, k_panel, k_update (+ k_piv_* for the pivoted path)   block Gauss-Jordan inverse, in place
+//   K2  k_diag_inv_b, k_panel, k_update (+ k_piv_* for the pivoted path)   block Gauss-Jordan inverse, in place
 //   K3a k_rhs                 right-hand sides b_g for a chunk of points (+ z_g = c.b_g), written point-major
 //   K3b k_contract            sigma^2_g = -b_g^T A_inv b_g as a dense contraction on v_mfma_f64_4x4x4_4b_f64
-//       (k_contract_valu: the same contraction on v_fma_f64, kept as an independent second engine)
 //       compact-support (spherical) variogram: k_rhs<.., SP> writes delta = b + s u, k_sp_cand / k_sp_lists_g / k_sp_tiles_g build the
 //       lists of active K tiles and the tile records, k_contract_spg contracts tiles of eight gathered 16-row groups (k_contract_sp:
 //       aligned 128-row blocks), k_ps_* put the points of every launch in Hilbert-curve order (device radix sort)

@@ -272,8 +272,6 @@ struct mik_handle {
   long ps_chunk = 0;
   int opt_sparse_group = 16; // "sparse_group": point blocks per group of k_sp_tiles_g's queue order (a group's tiles run on one XCD, tile position
                              // ascending, point block fast): 1 .. 16 (round 5: 4 -> 16, contraction 35.7 -> 35.3 ms at config 5)
-  int opt_sparse_ktile = 8;  // "sparse_ktile": 16 = candidate / flag / list tiles of 16 stations (round 4), 8 = of 8 stations, a K step a pair of them (round 5)
-  int opt_sparse_epi = 1;    // "sparse_epilogue": 1 = a row group's term of part[r][t] is formed from the B tile in LDS at the K step of its own square (8-station form), 0 = from global memory behind the K loop
   int opt_sparse_rows = -1;  // "sparse_rows": 16 = tiles of gathered 16-row groups (k_contract_spg), 128 = aligned row blocks (k_contract_sp),
                              // -1 = auto: 16 wherever 32-bit offsets address the inverse (Mp * Mp * 8 < 2^32)
   // second set (with Bt2): the launches of the range-aware contraction alternate between two lanes on two streams, so that the
@@ -296,11 +294,9 @@ struct mik_handle {
   DevBuf T, cvec, Cold, Cnew, Rt, TKt, Dinv, DinvT, P0, P1, cand0, cand1, pivall, flag;
   DevBuf Cold2, Cnew2, Rt2, Dinv2, DinvT2;  // second panel set of the look-ahead sweep
   DevBuf Dinv3, DinvT3;                     // third diagonal-inverse set (panel-stream schedule)
-  DevBuf tilemap;                           // k_update's tile order (update_tile_map)
-  int tilemap_key[3] = {0, 0, 0};
   hipStream_t stream3 = nullptr;            // panel stream of the sweep (panel kernel + block-column update), high priority
   std::vector<hipEvent_t> ps_events;
-  DevBuf Dnext, Dcopy, Cb, Rb;              // early-diagonal chain: 128 x 128 scratch (next diagonal block, its source tile, one block of panel rows)
+  DevBuf Dnext, Dcopy, Rb;                  // early-diagonal chain: 128 x 128 scratch (next diagonal block, its source tile, one block of R^T rows)
   hipStream_t stream2 = nullptr;            // the look-ahead branch (next panel) runs here
   std::vector<hipEvent_t> la_events;
   int opt_lookahead = -1;  // -1 = where it pays (>= 24 block columns), 0 = off, 1 = on
@@ -327,45 +323,18 @@ struct mik_handle {
   bool points_adjusted = false;   // mik_adjust_points has transformed the resident points (a second call would transform them twice)
   DevBuf Averify, vbuf;
   std::vector<double> hvals;   // host copy of the station values (the probe compares A c with them)
-  int opt_fuse_chain = 1;  // look-ahead sweep: the column update writes the next panel copy too (no copy kernel on the chain)
-  int opt_early_diag = -1; // look-ahead sweep: the next diagonal block is built and inverted ahead of the panel / update stream (-1 = with the look-ahead)
+  // look-ahead sweep (from 3 block columns on): the next diagonal block is built and inverted ahead of the panel / update stream
+  // ("early diagonal" schedule; the schedules it replaced -- rounds 1-2 -- and its flag-ordered variants left the library in round 6)
   int opt_gate = -1;       // look-ahead sweep: the trailing update waits until the next diagonal inverse has started and leaves
                            // it a CU of its own (k_gate); -1 = where the serial chain, not the update, is the step period
   // round 3: the panel kernel and the update of the NEXT block column run on a third stream beside the trailing update of the
   // step before (events only): -1 = from 24 block columns on, 0 = off, 1 = wherever the early-diagonal schedule runs
   int opt_panel_stream = -1;
-  // tile order of the trailing update: 0 = the kernel's own (column by column; default), n > 1 = n x n super-blocks (the tiles an
-  // XCD has in flight share n + n operand panels in its L2).  Measured a tie at every size (profiles/r03_k2_panel_stream_ab.txt):
-  // the update is not bound by its panel reads.
-  int opt_update_map = 0;
   int opt_update_rev = -1;  // "update_rev": the half sweep's trailing update walks its tiles backwards on odd steps (k_update): -1 = auto =
                             // from 45 block columns on (the upper triangle no longer fits half of the 256 MB memory-side cache), 0 / 1
-  // "pivot256": half sweep with pivot blocks of 256 columns (run_block_inverse_wide; half the read-modify-write traffic of T per eliminated
-  // column).  Measured a TIE at N = 8000 (13.1 - 13.3 ms both: the K = 256 update is 338 us per pair against 2 x 201, but its column part and
-  // the 256 x 256 diagonal inverse eat the difference) and slower below (N = 5000: 5.4 - 6.3 against 4.3 ms: the chain is the step there):
-  // profiles/r05_wide_sweep_*.txt.  Opt-in: 1 = on wherever the half sweep runs, 0 / -1 (default) = off.
-  int opt_pivot256 = -1;
-  DevBuf Wide;            // its 256 x 256 diagonal inverses and 128 x 128 scratch blocks
-  int opt_wide_reserve = 16;  // "wide_reserve": CUs (a multiple of 8: the same number on every XCD) the wide sweep's update stream leaves to the chain's kernels (0 = none)
-  int opt_update_token = 0;   // "update_token": per-CU token that makes the two resident update blocks of a CU alternate (k_update cu_tok)
-  DevBuf cu_token;
-  int opt_update_pf = 0;      // "update_pf": trailing update with its part of T in registers before the K loop (half tiles on four wavefronts, k_update_w PF;
-                              // same bits).  Measured a tie in the 128-wide sweep (N = 5000 4.25 / 4.22 ms, N = 8000 13.31 / 13.23) and -9 % .. -34 % of the
-                              // wide sweep below N = 5000, +11 % of its update at N = 8000: off
-  int opt_wide_colstream = 0; // "wide_colstream": 1 = the wide sweep's column part on a stream of its own beside the rest of the update (A/B)
-  hipStream_t stream_upd = nullptr;  // the wide sweep's update stream: created with a CU mask (hipExtStreamCreateWithCUMask)
-  int stream_upd_reserve = -1;
-  // round 5: the rest of every trailing update by k_update_deep (one 16-wave block per CU, T tile in registers before the K loop, four
-  // LDS stages, several tiles per block as one pipeline; same bits).  Measured SLOWER (profiles/r05_update_deep_ab.txt: N = 8000 13.5 ->
-  // 16.3 ms, N = 5000 4.3 -> 5.1 ms; tools/update_bench: 268 us per step against 197 -- the T loads are HBM misses, and because a
-  // wavefront's vector-memory operations retire in order the operand DMAs behind them cannot be waited for separately): off (0); 1 = on.
-  int opt_update_deep = 0;
-  int opt_update_tpb = 0;  // "update_tpb": tiles per block of k_update_deep (0 = auto: two rounds of blocks per step)
-  int opt_panel_rows = 32;  // rows of the column panel one block of k_panel forms: 32 (round 3), 64 or 128 (one tile, the round-1 form)
-  int opt_update_waves = 8; // trailing-update kernel of the block sweep: 4 waves (wave tile 64 x 64) or 8 (32 x 64, default since round 3:
-                            // -5 % at N=5000 / 8000, same bits: profiles/r03_update_waves_ab.txt) per 128 x 128 tile
-  int opt_diag = 4;        // diagonal-block inverse variant: 0 = 1024 threads (16 waves x 8 rows), 1 = 16x16 grid, 2 = 16x32, 3 = 32x32 (all four:
-                           // 128 barrier-separated pivots, the same bits), 4 = blocked, 8 x 16 pivots (round 3; equal to rounding)
+  // (Round 6 prune: the 256-column pivot sweep, the deep / prefetching / token-passing trailing updates, the tile map, the 4-wave update and
+  // the one-tile panel kernel, the scalar-pivot diagonal inverses -- every one bit- or LAPACK-exact, none faster than what is here -- are no
+  // longer in the library: DESIGN_HISTORY.md section 12, tools/mik_k_experiments.h, git history.)
   // points
   long npt_total = 0, npt = 0;
   bool masked = false;  // the caller's mask skipped at least one point: outputs are zero-filled before the scatter
@@ -380,12 +349,11 @@ struct mik_handle {
   int n_cu = 256;
   int t_state = 0;  // what T holds: 0 nothing, 1 the kriging matrix A (shift 0), 2 its inverse
   // options
-  int opt_waves = 8;  // waves per contraction block: 4 (wave tile 64x64) or 8 (32x64)
-  // symmetric contraction (8-wave form): the diagonal block of a tile is contracted as a triangle of 16-row groups -- 36 of
+  // symmetric contraction: the diagonal block of a tile is contracted as a triangle of 16-row groups -- 36 of
   // its 64 (group, K tile) products (round 3; gemm_core TRI).  0 = the whole diagonal block.
   int opt_tri = 1;
   int opt_symmetrize = 1;  // T <- (T + T^T) / 2 after a full sweep / the pivoted elimination (k_symmetrize); 0 = as eliminated
-  int opt_factor = 0, opt_sym = 1, opt_engine = 0;  // engine: 0 = v_mfma_f64 contraction, 1 = v_fma_f64 (VALU) contraction
+  int opt_factor = 0, opt_sym = 1;
   long opt_chunk = 131072;
   int opt_mw_pivot = 0;       // 1 = always solve the moving-window systems with partial pivoting
   int opt_mw_solver = 0;      // 0 = LDL^T of the shifted system in registers (default), 1 = the Gauss-Jordan kernels

@@ -161,198 +161,11 @@ int ensure_factor_buffers(mik_handle* h) {
 
 static void launch_diag_inv(mik_handle* h, hipStream_t st, const double* T, long ld, int k0, int nspd, double* dinv, double* dinvT,
                             bool own_cu = false) {
-  int* flag = h->flag.as<int>();
-  if (h->opt_diag == 4) {  // blocked (round 3): 86 KB of LDS of its own, padded like the others' when it wants the CU to itself
-    const int lds = own_cu ? 100 * 1024 : (int)(sizeof(double) * MIK_DIAGB_LDS_DOUBLES);
-    (void)hipFuncSetAttribute((const void*)k_diag_inv_b<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
-    hipLaunchKernelGGL(k_diag_inv_b<0>, dim3(1), dim3(256), lds, st, T, ld, k0, nspd, dinv, dinvT, flag);
-    return;
-  }
-  if (own_cu && h->opt_diag == 1) {  // keep trailing-update blocks (64 KB of LDS each) off this block's CU: see k_gate
-    constexpr int pad = 100 * 1024;
-    // per launch: the attribute belongs to the function object of the CURRENT device (device groups factor on several)
-    (void)hipFuncSetAttribute((const void*)k_diag_inv_t<16, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, pad);
-    hipLaunchKernelGGL((k_diag_inv_t<16, 16>), dim3(1), dim3(256), pad, st, T, ld, k0, nspd, dinv, dinvT, flag);
-    return;
-  }
-  switch (h->opt_diag) {
-    case 1: hipLaunchKernelGGL((k_diag_inv_t<16, 16>), dim3(1), dim3(256), 0, st, T, ld, k0, nspd, dinv, dinvT, flag); break;
-    case 2: hipLaunchKernelGGL((k_diag_inv_t<16, 32>), dim3(1), dim3(512), 0, st, T, ld, k0, nspd, dinv, dinvT, flag); break;
-    case 3: hipLaunchKernelGGL((k_diag_inv_t<32, 32>), dim3(1), dim3(1024), 0, st, T, ld, k0, nspd, dinv, dinvT, flag); break;
-    default: hipLaunchKernelGGL(k_diag_inv, dim3(1), dim3(1024), 0, st, T, ld, k0, nspd, dinv, dinvT, flag); break;
-  }
-}
-
-// k_update's tilemap: the tiles of the (upper triangle of the) block grid, super-block by super-block (sb x sb tiles, rows of
-// super-blocks, inside one column by column), invalid positions skipped -- a plain permutation of the kernel's own enumeration,
-// so xcd_tile() still hands every XCD an equal, contiguous share.  Cached per (nblk, sym, sb).
-static int update_tile_map(mik_handle* h, int nblk, bool sym, int sb) {
-  if (h->tilemap_key[0] == nblk && h->tilemap_key[1] == (int)sym && h->tilemap_key[2] == sb) return MIK_OK;
-  std::vector<int2> map;
-  map.reserve(sym ? (size_t)nblk * (nblk + 1) / 2 : (size_t)nblk * nblk);
-  const int ns = (nblk + sb - 1) / sb;
-  for (int I = 0; I < ns; ++I)
-    for (int J = sym ? I : 0; J < ns; ++J)
-      for (int dj = 0; dj < sb; ++dj)
-        for (int di = 0; di < sb; ++di) {
-          const int i = I * sb + di, j = J * sb + dj;
-          if (i >= nblk || j >= nblk || (sym && i > j)) continue;
-          map.push_back(make_int2(i, j));
-        }
-  MIKC(h->tilemap.ensure(sizeof(int2) * map.size()));
-  HIPC(hipMemcpyAsync(h->tilemap.p, map.data(), sizeof(int2) * map.size(), hipMemcpyHostToDevice, h->stream));
-  HIPC(hipStreamSynchronize(h->stream));  // (map is a local)
-  h->tilemap_key[0] = nblk, h->tilemap_key[1] = (int)sym, h->tilemap_key[2] = sb;
-  return MIK_OK;
-}
-
-// WIDE half sweep (round 5, option "pivot256"): unpivoted block Gauss-Jordan on the upper block triangle with pivot blocks of 256
-// columns (kernels and the why: mik_k_inverse.h, k_update_w).  Look-ahead schedule on two streams, the pivot block as the step:
-//   s1:  column part of update K (the block columns / rows of pivot K + 1)  ->  rest of update K  ->  [panel K + 1 ready] ...
-//   s2:  [column part K done]  diagonal block K + 1 (256 x 256: Schur split over two 128-block inverses)  ->  column panel  ->  panel kernel
-// Two panel sets alternate.  An odd last block column is a 128-wide pivot through the same kernels.
-static int run_block_inverse_wide(mik_handle* h, int nspd, int* flag_out) {
-  const int Mp = h->Mp, nblk = Mp / 128;
-  const long ld = Mp;
-  const size_t panel = sizeof(double) * (size_t)Mp * 256, blk = sizeof(double) * 128 * 128;
-  MIKC(h->Cold.ensure(panel));
-  MIKC(h->Cnew.ensure(panel));
-  MIKC(h->Rt.ensure(panel));
-  MIKC(h->Cold2.ensure(panel));
-  MIKC(h->Cnew2.ensure(panel));
-  MIKC(h->Rt2.ensure(panel));
-  MIKC(h->Wide.ensure(4 * blk * 2 + 4 * blk + 7 * blk));  // two 256 x 256 inverses, X, and seven 128 x 128 scratch blocks
-  MIKC(h->flag.ensure(sizeof(int) * (size_t)MIK_F_INTS));
-  HIPC(hipMemsetAsync(h->flag.p, 0, sizeof(int) * (size_t)MIK_F_INTS, h->stream));
-  const int nK = (nblk + 1) / 2;
-  while (h->la_events.size() < 3 * (size_t)nK + 4) {
-    hipEvent_t e;
-    HIPC(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    h->la_events.push_back(e);
-  }
-  double* T = h->T.as<double>();
-  double* cold[2] = {h->Cold.as<double>(), h->Cold2.as<double>()};
-  double* cnew[2] = {h->Cnew.as<double>(), h->Cnew2.as<double>()};
-  double* rt[2] = {h->Rt.as<double>(), h->Rt2.as<double>()};
-  double* w = h->Wide.as<double>();
-  double* dinv[2] = {w, w + 4 * 128 * 128};
-  double* X = w + 8 * 128 * 128;
-  double* sc = w + 12 * 128 * 128;
-  double *ainv = sc, *ainvT = sc + 16384, *W = sc + 2 * 16384, *Wt = sc + 3 * 16384, *S = sc + 4 * 16384, *sinv = sc + 5 * 16384, *sinvT = sc + 6 * 16384;
-  h->last_half_sweep = true;
-  const bool rev_on = h->opt_update_rev < 0 ? nblk >= 45 : h->opt_update_rev != 0;
-  const long ltiles = (long)nblk * (nblk + 1) / 2;
-  const unsigned ug = (unsigned)(8 * ((ltiles + 7) / 8));
-  auto np_of = [&](int K) { return 2 * K + 1 < nblk ? 2 : 1; };
-  // The update stream runs under a CU MASK that leaves `wide_reserve` CUs (the top mask bits: bit i is CU i / 8 of XCD i % 8,
-  // tools/probe_cumask) to the chain's kernels: with the chip full of 128-VGPR update blocks nothing else is placed until a block
-  // retires, and every small kernel of the chain waited 10 - 150 us for its slots (profiles/r05_wide_sweep_timeline.txt).
-  const int reserve = std::max(0, std::min(h->n_cu / 2, h->opt_wide_reserve)) & ~7;
-  if (reserve > 0 && (!h->stream_upd || h->stream_upd_reserve != reserve)) {
-    if (h->stream_upd) (void)hipStreamDestroy(h->stream_upd);
-    h->stream_upd = nullptr;
-    std::vector<uint32_t> mask((size_t)(h->n_cu + 31) / 32, 0u);
-    for (int i = 0; i < h->n_cu - reserve; ++i) mask[(size_t)i / 32] |= 1u << (i % 32);
-    if (hipExtStreamCreateWithCUMask(&h->stream_upd, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
-      (void)hipGetLastError();
-      h->stream_upd = nullptr;  // no masks on this runtime: the update runs on the handle's stream
-    }
-    h->stream_upd_reserve = reserve;
-  }
-  const bool masked = reserve > 0 && h->stream_upd != nullptr;
-  auto P = [](const double* A, int lda, const double* Bt, int ldb, double alpha, const double* D, int ldd, double* O, int ldo) {
-    return Mm128{A, lda, Bt, ldb, alpha, D, ldd, O, ldo};
-  };
-  auto mm1 = [&](hipStream_t st, const Mm128& a0) { hipLaunchKernelGGL(k_mm128s, dim3(64, 1), dim3(256), 0, st, a0, a0); };
-  auto mm2 = [&](hipStream_t st, const Mm128& a0, const Mm128& a1) { hipLaunchKernelGGL(k_mm128s, dim3(64, 2), dim3(256), 0, st, a0, a1); };
-  // the serial chain of a pivot: inverse of its diagonal block from T, [its column panel from T, unless the column part of the update before
-  // left it in cold[set]], the panel kernel
-  auto chain = [&](hipStream_t st, int K, int set, bool have_cold) -> int {
-    const int a = 2 * K, np = np_of(K), k0 = a * 128;
-    const bool own = st == h->stream2;  // (the diagonal inverse padded to a CU of its own, launch_diag_inv)
-    if (np == 1) {
-      launch_diag_inv(h, st, (const double*)T, ld, k0, nspd, dinv[set], ainvT, own);  // [128][128]; symmetric to rounding: used as its own transpose
-    } else {
-      hipLaunchKernelGGL(k_loadx256, dim3(16), dim3(256), 0, st, (const double*)T, ld, a, X);
-      // [A B; B^T C]^-1 with S = C - B^T A^-1 B:  X22 = S^-1,  X12 = -W S^-1 (W = A^-1 B),  X21 = X12^T,  X11 = A^-1 - X12 W^T
-      const double* xa = (const double*)((uintptr_t)X - sizeof(double) * ((size_t)k0 * 256 + (size_t)k0));  // the diagonal kernels index T[(k0 + r) ld + k0 + c]
-      launch_diag_inv(h, st, xa, 256L, k0, nspd, ainv, ainvT, own);
-      const double* Bt = X + 128 * 256;  // B^T (rows 128 .., columns 0 .. 127)
-      mm2(st, P(ainv, 128, Bt, 256, 1.0, nullptr, 0, W, 128),                 // W[i][n] = sum_m Ainv[i][m] B[m][n]
-          P(Bt, 256, ainvT, 128, 1.0, nullptr, 0, Wt, 128));                  // Wt = W^T
-      mm1(st, P(Bt, 256, Wt, 128, -1.0, X + 128 * 256 + 128, 256, S, 128));   // S = C - B^T W
-      const int k1 = k0 + 128;
-      const double* xs = (const double*)((uintptr_t)S - sizeof(double) * ((size_t)k1 * 128 + (size_t)k1));
-      double* D = dinv[set];
-      launch_diag_inv(h, st, xs, 128L, k1, nspd, sinv, sinvT, own);
-      mm2(st, P(W, 128, sinvT, 128, -1.0, nullptr, 0, D + 128, 256),          // X12 = -W S^-1
-          P(sinv, 128, W, 128, -1.0, nullptr, 0, D + 128 * 256, 256));        // X21 = -S^-1 W^T
-      mm2(st, P(D + 128, 256, W, 128, -1.0, ainv, 128, D, 256),               // X11 = A^-1 - X12 W^T
-          P(W, 128, W, 128, 0.0, sinv, 128, D + 128 * 256 + 128, 256));       // X22 = S^-1 (a copy: alpha = 0)
-    }
-    if (!have_cold) hipLaunchKernelGGL(k_copy_panel_w, dim3(Mp / 64, np), dim3(256), 0, st, (const double*)T, ld, a, np, cold[set]);
-    hipLaunchKernelGGL(k_panel_w, dim3(Mp / 32, np), dim3(256), 0, st, (const double*)cold[set], (const double*)dinv[set], np, -1.0, cnew[set], rt[set], k0);
-    return MIK_OK;
-  };
-  // three streams, events only:
-  //   s1 (CU mask):  [panel K]                         rest of update K                                   -> evR(K)
-  //   s3:            [panel K, rest K - 1]             column part of update K (leaves cold[set ^ 1])     -> evC(K)
-  //   s2:            [column part K]                   diagonal block K + 1, panel kernel K + 1           -> evP(K + 1)
-  hipStream_t s1 = masked ? h->stream_upd : h->stream, s2 = h->stream2, s3 = h->stream3;
-  const bool pf = h->opt_update_pf != 0;  // "update_pf": T loaded before the K loop, half tiles on four wavefronts (k_update_w PF)
-  auto evC = [&](int K) { return h->la_events[3 * K]; };
-  auto evP = [&](int K) { return h->la_events[3 * K + 1]; };
-  auto evR = [&](int K) { return h->la_events[3 * K + 2]; };
-  MIKC(chain(h->stream, 0, 0, false));
-  HIPC(hipEventRecord(evP(0), h->stream));
-  for (int K = 0; K < nK; ++K) {
-    const int set = K & 1, a = 2 * K, np = np_of(K);
-    const int rev = rev_on && (K & 1);
-    HIPC(hipStreamWaitEvent(s1, evP(K), 0));
-    if (K + 1 < nK) {
-      const int na = a + 2, nn = np_of(K + 1);
-      hipStream_t sc = h->opt_wide_colstream ? s3 : s1;  // "wide_colstream" 1: the column part beside the rest (measured slower: the rest's blocks fill the chip first)
-      if (sc == s3) {
-        HIPC(hipStreamWaitEvent(s3, evP(K), 0));
-        if (K > 0) HIPC(hipStreamWaitEvent(s3, evR(K - 1), 0));
-      }
-      if (pf)
-        hipLaunchKernelGGL((k_update_w<1, true>), dim3(2 * nn * nblk), dim3(256), 0, sc, T, ld, nblk, a, np, (const double*)cold[set], (const double*)cnew[set],
-                           (const double*)rt[set], (const double*)dinv[set], na, nn, 0, cold[set ^ 1]);
-      else
-        hipLaunchKernelGGL((k_update_w<1, false>), dim3(nn * nblk), dim3(512), 0, sc, T, ld, nblk, a, np, (const double*)cold[set], (const double*)cnew[set],
-                           (const double*)rt[set], (const double*)dinv[set], na, nn, 0, cold[set ^ 1]);
-      HIPC(hipEventRecord(evC(K), sc));
-      HIPC(hipStreamWaitEvent(s2, evC(K), 0));
-      MIKC(chain(s2, K + 1, set ^ 1, true));
-      HIPC(hipEventRecord(evP(K + 1), s2));
-      if (pf)
-        hipLaunchKernelGGL((k_update_w<2, true>), dim3(2 * ug), dim3(256), 0, s1, T, ld, nblk, a, np, (const double*)cold[set], (const double*)cnew[set],
-                           (const double*)rt[set], (const double*)dinv[set], na, nn, rev, (double*)nullptr);
-      else
-        hipLaunchKernelGGL((k_update_w<2, false>), dim3(ug), dim3(512), 0, s1, T, ld, nblk, a, np, (const double*)cold[set], (const double*)cnew[set],
-                           (const double*)rt[set], (const double*)dinv[set], na, nn, rev, (double*)nullptr);
-      HIPC(hipEventRecord(evR(K), s1));
-    } else {
-      if (pf)
-        hipLaunchKernelGGL((k_update_w<0, true>), dim3(2 * ug), dim3(256), 0, s1, T, ld, nblk, a, np, (const double*)cold[set], (const double*)cnew[set],
-                           (const double*)rt[set], (const double*)dinv[set], -8, 0, rev, (double*)nullptr);
-      else
-        hipLaunchKernelGGL((k_update_w<0, false>), dim3(ug), dim3(512), 0, s1, T, ld, nblk, a, np, (const double*)cold[set], (const double*)cnew[set],
-                           (const double*)rt[set], (const double*)dinv[set], -8, 0, rev, (double*)nullptr);
-    }
-  }
-  {
-    HIPC(hipEventRecord(evR(nK - 1), s1));
-    HIPC(hipStreamWaitEvent(h->stream, evR(nK - 1), 0));
-  }
-  hipLaunchKernelGGL(k_mirror_upper, dim3(Mp / 64, Mp / 64), dim3(256), 0, h->stream, T, ld, Mp / 64);
-  HIPC(hipGetLastError());
-  int flag = 0;
-  HIPC(hipMemcpyAsync(&flag, h->flag.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-  HIPC(hipStreamSynchronize(h->stream));
-  *flag_out = flag;
-  return MIK_OK;
+  // k_diag_inv_b (round 3): 86 KB of LDS of its own, padded to 100 KB when it wants the CU to itself (no 64-KB update block fits beside it)
+  const int lds = own_cu ? 100 * 1024 : (int)(sizeof(double) * MIK_DIAGB_LDS_DOUBLES);
+  // per launch: the attribute belongs to the function object of the CURRENT device (device groups factor on several)
+  (void)hipFuncSetAttribute((const void*)k_diag_inv_b<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+  hipLaunchKernelGGL(k_diag_inv_b<0>, dim3(1), dim3(256), lds, st, T, ld, k0, nspd, dinv, dinvT, h->flag.as<int>());
 }
 
 // unpivoted (path 1) or pivoted (path 2) block Gauss-Jordan on T in place
@@ -387,43 +200,24 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
   // full-size fixtures) and from 24 block columns on, where it pays
   const bool symsweep = !pivoted && (h->opt_symsweep > 0 || (h->opt_symsweep < 0 && !h->no_half_sweep && (h->model == 3 || h->model == 4) && nblk >= 24));
   h->last_half_sweep = symsweep;
-  // "pivot256" 1: the half sweep with 256-wide pivot blocks (opt-in: measured a tie at N = 8000, slower below)
-  if (symsweep && nblk >= 3 && h->opt_pivot256 > 0) return run_block_inverse_wide(h, nspd, flag_out);
   const long ltiles = symsweep ? (long)nblk * (nblk + 1) / 2 : tiles;
   const unsigned ug = (unsigned)(8 * ((ltiles + 7) / 8));
-  const bool upd8 = h->opt_update_waves == 8;
-  const int uatomic = (h->opt_update_rev < 0 ? nblk >= 45 : h->opt_update_rev != 0) ? 2 : 0;  // bit 0: plain tiles of the trailing update as
-                                                                                           // fp64 atomic adds, bit 1: odd steps backwards (k_update)
-  // tile order of the trailing update: optionally n x n super-blocks (k_update's tilemap)
-  const int2* tmap = nullptr;
-  if (!pivoted && h->opt_update_map > 1) {
-    MIKC(update_tile_map(h, nblk, symsweep, h->opt_update_map));
-    tmap = h->tilemap.as<int2>();
-  }
-  // the panel kernel over all Mp rows: 32 * NAI rows per block (k_panel)
-#define PANEL(STREAM, ...)                                                                                                   \
-  do {                                                                                                                       \
-    if (h->opt_panel_rows == 32) hipLaunchKernelGGL((k_panel<1>), dim3(4 * nblk), dim3(256), 0, STREAM, __VA_ARGS__);        \
-    else if (h->opt_panel_rows == 64) hipLaunchKernelGGL((k_panel<2>), dim3(2 * nblk), dim3(256), 0, STREAM, __VA_ARGS__);   \
-    else hipLaunchKernelGGL((k_panel<4>), dim3(nblk), dim3(256), 0, STREAM, __VA_ARGS__);                                    \
-  } while (0)
-#define UPDK(SYMV, GRID, STREAM, ...)                                                                                       \
-  do {                                                                                                                      \
-    if (upd8) hipLaunchKernelGGL((k_update<SYMV, 2>), GRID, dim3(512), 0, STREAM, __VA_ARGS__, tmap, uatomic);              \
-    else hipLaunchKernelGGL((k_update<SYMV, 4>), GRID, dim3(256), 0, STREAM, __VA_ARGS__, tmap, uatomic);                   \
-  } while (0)
+  // "update_rev": odd steps of the half sweep walk the triangle backwards (k_update rev)
+  const int urev = (h->opt_update_rev < 0 ? nblk >= 45 : h->opt_update_rev != 0) ? 1 : 0;
+  // the panel kernel over all Mp rows, 32 rows per block (k_panel<1>); the trailing update on 8 wavefronts per tile (k_update<*, 2>)
+#define PANEL(STREAM, ...) hipLaunchKernelGGL((k_panel<1>), dim3(4 * nblk), dim3(256), 0, STREAM, __VA_ARGS__)
+#define UPDK(SYMV, GRID, STREAM, ...) hipLaunchKernelGGL((k_update<SYMV, 2>), GRID, dim3(512), 0, STREAM, __VA_ARGS__, urev)
 #define UPDX(GRID, STREAM, CO, CN, R, D, PART, COL, POUT, DCOPY)                                                             \
   do {                                                                                                                       \
     if (symsweep)                                                                                                            \
       UPDK(true, GRID, STREAM, T, ld, nblk, kb, (const double*)(CO), (const double*)(CN),                                    \
-           (const double*)(R), (const double*)(D), PART, COL, POUT, DCOPY, (int*)nullptr);                                   \
+           (const double*)(R), (const double*)(D), PART, COL, POUT, DCOPY);                                                  \
     else                                                                                                                     \
       UPDK(false, GRID, STREAM, T, ld, nblk, kb, (const double*)(CO), (const double*)(CN),                                   \
-           (const double*)(R), (const double*)(D), PART, COL, POUT, DCOPY, (int*)nullptr);                                   \
+           (const double*)(R), (const double*)(D), PART, COL, POUT, DCOPY);                                                  \
   } while (0)
 #define UPD(GRID, STREAM, CO, CN, R, D, PART, COL, POUT) UPDX(GRID, STREAM, CO, CN, R, D, PART, COL, POUT, (double*)nullptr)
-  const bool early_ok = h->opt_early_diag != 0;
-  const bool lookahead = h->opt_lookahead < 0 ? nblk >= (early_ok ? 3 : 24) : h->opt_lookahead != 0;
+  const bool lookahead = h->opt_lookahead < 0 ? nblk >= 3 : h->opt_lookahead != 0;
   // measured (profiles/r02_inverse_timeline.txt): with up to ~2400 update tiles per step (N=5000 full sweep: 1600, N=8000 half
   // sweep: 2016) the serial chain is the step period and giving its head a CU of its own pays (-14 % / -10 %); with 3969 tiles
   // (N=8000 full sweep) the update is, and holding it back costs 3 %
@@ -456,11 +250,10 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
         if (symsweep) hipLaunchKernelGGL(k_copy_panel_sym, dim3(Mp / 64), dim3(256), 0, st, (const double*)T, ld, k0, Mp, cold[set]);
         else hipLaunchKernelGGL(k_copy_panel, dim3(pgrid), dim3(256), 0, st, (const double*)T, ld, k0, Mp, cold[set]);
       }
-      PANEL(st, (const double*)cold[set], 128L, (const double*)dinvT[set], -1.0, cnew[set], rt[set], k0, 0, 0, (int*)nullptr, -1, -1);
+      PANEL(st, (const double*)cold[set], 128L, (const double*)dinvT[set], -1.0, cnew[set], rt[set], k0, (int*)nullptr, -1);
     };
-    const bool early = h->opt_early_diag < 0 ? true : h->opt_early_diag != 0;
     panel_chain(h->stream, 0, 0, false);
-    if (early) {
+    {
       // Early-diagonal schedule.  What the next diagonal inverse needs of step kb is ONE tile, D(kb+1) - C_b R_b^T, and that takes
       // only the 128 panel rows of block kb + 1.  The second stream therefore runs, per step,
       //     [wait: update kb-1 done]  k_gemm128<0> (R_b = C_b Dinv) -> k_gemm128<1> (the tile) -> diagonal inverse kb+1
@@ -471,32 +264,20 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
       // Same accumulation order per entry as k_panel / k_update: the inverse is bit-identical.
       MIKC(h->Dnext.ensure(sizeof(double) * 128 * 128));
       MIKC(h->Dcopy.ensure(sizeof(double) * 2 * 128 * 128));
-      MIKC(h->Cb.ensure(sizeof(double) * 128 * 128));
       MIKC(h->Rb.ensure(sizeof(double) * 128 * 128));
       double* dnext = h->Dnext.as<double>();
       double* dcopy[2] = {h->Dcopy.as<double>(), h->Dcopy.as<double>() + 128 * 128};  // [kb & 1] is read by step kb's chain
-      double* cb = h->Cb.as<double>();
       double* rb = h->Rb.as<double>();
       HIPC(hipMemcpy2DAsync(dcopy[0], sizeof(double) * 128, T + 128L * ld + 128, sizeof(double) * ld, sizeof(double) * 128, 128,
                             hipMemcpyDeviceToDevice, h->stream));  // tile (1, 1) as assembled: the second stream never reads T
       HIPC(hipEventRecord(h->la_events[0], h->stream));  // "update -1": the first panel set and diagonal inverse are there
       HIPC(hipStreamWaitEvent(h->stream2, h->la_events[0], 0));
-      // The two streams are ordered by events (default).  A satisfied hipStreamWaitEvent still costs ~12 us of barrier-packet
-      // latency per step and stream, so two opt-in modes order them through the flag buffer (MIK_F_*) instead:
-      //   early_diag = 5: update stream <- "diagonal inverse kb finished" by a flag the inverse releases, polled inside k_panel
-      //                   (N=5000: 5.35 -> 5.0 ms, N=8000: 15.1 -> 14.6 ms);
-      //   early_diag = 4: also chain stream <- "update kb-1 finished" by a count of finished blocks behind k_wait_ge -- every
-      //                   block's release writes its XCD's L2 back: good for small sweeps only (N=2000: 1.86 -> 1.76 ms; N=8000:
-      //                   15.1 -> 20.8 ms).
-      // They are NOT the default because a kernel that waits for a kernel of another stream needs both to be able to run
-      // concurrently: under tools that serialise dispatches (rocprofv3 --pmc, debuggers) the wait runs out (bounded: an error,
-      // not a hang).  (Also not beyond 128 block columns: k_panel's waiting blocks hold LDS, and with two of them on every CU
-      // a diagonal inverse that has not been placed yet could never start.)  What IS folded into k_panel in every mode is
-      // k_gate's poll: a hint with a bounded wait, harmless when serialised.
-      const bool flags_s1 = (h->opt_early_diag == 4 || h->opt_early_diag == 5) && nblk <= 128;
-      const bool flags_s2 = flags_s1 && h->opt_early_diag == 4;
+      // The streams are ordered by events only (a satisfied hipStreamWaitEvent costs ~12 us of barrier-packet latency per step and
+      // stream; the flag-ordered variants that avoided it -- a kernel waiting for a kernel of another stream -- break under tools
+      // that serialise dispatches and left the library in round 6).  What IS folded into k_panel is k_gate's poll: a hint with a
+      // bounded wait, harmless when serialised.
       int* fl = h->flag.as<int>();
-      const bool pstream = !flags_s1 && h->opt_early_diag != 2 && (h->opt_panel_stream < 0 ? nblk >= 24 : h->opt_panel_stream != 0);
+      const bool pstream = h->opt_panel_stream < 0 ? nblk >= 24 : h->opt_panel_stream != 0;
       if (pstream) {
         // Panel-stream schedule (round 3).  The update stream of the schedule below carries k_panel + the whole update, one after
         // the other, and from ~4000 stations on it is the step period.  Here the update of a step is cut into the tiles the NEXT
@@ -522,21 +303,6 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
         auto evC = [&](int kb) { return h->ps_events[4 * kb + 2]; };  // column part of update kb done (s3)
         auto evR = [&](int kb) { return h->ps_events[4 * kb + 3]; };  // rest of update kb done (s1)
         hipStream_t s1 = h->stream, s2 = h->stream2, s3 = h->stream3;
-        // "update_deep" 1: the rest of every update by k_update_deep (off by default: measured slower); tiles per block: "update_tpb" (0 = auto: one round
-        // of blocks per step would hold every CU for the whole step and starve the chain's kernels, so two rounds)
-        int* tokbuf = nullptr;  // "update_token": the two resident blocks of a CU alternate between K loop and read-modify-write (k_update cu_tok)
-        if (h->opt_update_token) {
-          MIKC(h->cu_token.ensure(sizeof(int) * 2048));
-          HIPC(hipMemsetAsync(h->cu_token.p, 0, sizeof(int) * 2048, h->stream));
-          tokbuf = h->cu_token.as<int>();
-        }
-        const bool deep = h->opt_update_deep > 0 && !tmap && !(uatomic & 1);
-        const bool pf_rest = symsweep && h->opt_update_pf != 0 && !deep && !tmap && !(uatomic & 1);  // "update_pf"
-        const int deep_tpb = h->opt_update_tpb > 0 ? h->opt_update_tpb : (int)std::max<long>(1, (ltiles + 2 * h->n_cu - 1) / (2 * h->n_cu));
-        if (deep) {
-          (void)hipFuncSetAttribute((const void*)k_update_deep<true>, hipFuncAttributeMaxDynamicSharedMemorySize, MIK_UD_LDS_BYTES);
-          (void)hipFuncSetAttribute((const void*)k_update_deep<false>, hipFuncAttributeMaxDynamicSharedMemorySize, MIK_UD_LDS_BYTES);
-        }
         HIPC(hipStreamWaitEvent(s3, h->la_events[0], 0));  // panel set 0, diagonal inverse 0 (dv[0]) and dcopy[0] are there
         for (int kb = 0; kb < nblk; ++kb) {
           const int set = kb & 1, k0 = kb * 128, k1 = k0 + 128, d3 = kb % 3, d3n = (kb + 1) % 3;
@@ -552,52 +318,27 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
           }
           if (kb > 0) {  // s3: panel kb (its column panel was left by the column part of update kb - 1, on this stream)
             HIPC(hipStreamWaitEvent(s3, evD(kb), 0));
-            PANEL(s3, (const double*)cold[set], 128L, (const double*)dvT[d3], -1.0, cnew[set], rt[set], k0, 0, 0, (int*)nullptr, -1, -1);
+            PANEL(s3, (const double*)cold[set], 128L, (const double*)dvT[d3], -1.0, cnew[set], rt[set], k0, (int*)nullptr, -1);
             HIPC(hipEventRecord(evP(kb), s3));
           }
           if (kb + 1 < nblk) {  // s3: column part of update kb
             if (kb > 0) HIPC(hipStreamWaitEvent(s3, evR(kb - 1), 0));
             if (symsweep)
               UPDK(true, dim3(nblk + 1), s3, T, ld, nblk, kb, (const double*)cold[set], (const double*)cnew[set], (const double*)rt[set],
-                   (const double*)dv[d3], 3, kb + 1, cold[set ^ 1], dcopy[set ^ 1], (int*)nullptr);
+                   (const double*)dv[d3], 3, kb + 1, cold[set ^ 1], dcopy[set ^ 1]);
             else
               UPDK(false, dim3(nblk + 1), s3, T, ld, nblk, kb, (const double*)cold[set], (const double*)cnew[set], (const double*)rt[set],
-                   (const double*)dv[d3], 3, kb + 1, cold[set ^ 1], dcopy[set ^ 1], (int*)nullptr);
+                   (const double*)dv[d3], 3, kb + 1, cold[set ^ 1], dcopy[set ^ 1]);
             HIPC(hipEventRecord(evC(kb), s3));
           }
           if (kb > 0) HIPC(hipStreamWaitEvent(s1, evP(kb), 0));  // s1: the rest (last step: everything)
           const int part = kb + 1 < nblk ? 4 : 0, colarg = kb + 1 < nblk ? kb + 1 : -2;
-          if (pf_rest) {
-            // the block's part of T in registers before the K loop, half tiles on four wavefronts (k_update_w PF; same bits)
-            const int rev = (uatomic & 2) && (kb & 1);
-            if (kb + 1 < nblk)
-              hipLaunchKernelGGL((k_update_w<2, true>), dim3(2 * ug), dim3(256), 0, s1, T, ld, nblk, kb, 1, (const double*)cold[set], (const double*)cnew[set],
-                                 (const double*)rt[set], (const double*)dv[d3], kb + 1, 1, rev, (double*)nullptr, kb + 2);
-            else
-              hipLaunchKernelGGL((k_update_w<0, true>), dim3(2 * ug), dim3(256), 0, s1, T, ld, nblk, kb, 1, (const double*)cold[set], (const double*)cnew[set],
-                                 (const double*)rt[set], (const double*)dv[d3], -8, 0, rev, (double*)nullptr, -1);
-          } else if (deep) {
-            // deep form (k_update_deep): one 16-wave block per CU, T tile in registers before the K loop, four LDS stages, `tpb`
-            // tiles per block as one pipeline; the pivot's own block row / column are copied by the blocks behind the first gdeep
-            const long per = (ltiles + 7) / 8;
-            const int gdeep = (int)(8 * ((per + deep_tpb - 1) / deep_tpb));
-            const int ncopy = symsweep ? nblk : 2 * nblk - 1;
-            const int rev = (uatomic & 2) && (kb & 1);
-            if (symsweep)
-              hipLaunchKernelGGL((k_update_deep<true>), dim3(gdeep + ncopy), dim3(1024), MIK_UD_LDS_BYTES, s1, T, ld, nblk, kb, (const double*)cold[set],
-                                 (const double*)cnew[set], (const double*)rt[set], (const double*)dv[d3], part, colarg, deep_tpb, rev, gdeep);
-            else
-              hipLaunchKernelGGL((k_update_deep<false>), dim3(gdeep + ncopy), dim3(1024), MIK_UD_LDS_BYTES, s1, T, ld, nblk, kb, (const double*)cold[set],
-                                 (const double*)cnew[set], (const double*)rt[set], (const double*)dv[d3], part, colarg, deep_tpb, rev, gdeep);
-          } else if (symsweep && tokbuf && upd8) {
-            hipLaunchKernelGGL((k_update<true, 2>), dim3(ug), dim3(512), 0, s1, T, ld, nblk, kb, (const double*)cold[set], (const double*)cnew[set],
-                               (const double*)rt[set], (const double*)dv[d3], part, colarg, (double*)nullptr, (double*)nullptr, (int*)nullptr, tmap, uatomic, tokbuf);
-          } else if (symsweep)
+          if (symsweep)
             UPDK(true, dim3(ug), s1, T, ld, nblk, kb, (const double*)cold[set], (const double*)cnew[set], (const double*)rt[set],
-                 (const double*)dv[d3], part, colarg, (double*)nullptr, (double*)nullptr, (int*)nullptr);
+                 (const double*)dv[d3], part, colarg, (double*)nullptr, (double*)nullptr);
           else
             UPDK(false, dim3(ug), s1, T, ld, nblk, kb, (const double*)cold[set], (const double*)cnew[set], (const double*)rt[set],
-                 (const double*)dv[d3], part, colarg, (double*)nullptr, (double*)nullptr, (int*)nullptr);
+                 (const double*)dv[d3], part, colarg, (double*)nullptr, (double*)nullptr);
           if (kb + 1 < nblk) HIPC(hipEventRecord(evR(kb), s1));
         }
       } else
@@ -605,16 +346,8 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
         const int set = kb & 1, k0 = kb * 128, k1 = k0 + 128;
         if (kb + 1 < nblk) {
           hipStream_t s2 = h->stream2;
-          if (kb > 0) {  // update kb-1 has left cold[set], dcopy[set]
-            if (flags_s2) hipLaunchKernelGGL(k_wait_ge, dim3(1), dim3(1), 0, s2, fl, MIK_F_UCNT + kb - 1, (int)ug);
-            else HIPC(hipStreamWaitEvent(s2, h->la_events[2 * kb], 0));
-          }
-          if (h->opt_early_diag == 2) {  // the library's one-block tile kernels (22 us each: a CU's MFMA rate), kept for comparison
-            hipLaunchKernelGGL((k_panel<4>), dim3(1), dim3(256), 0, s2, (const double*)cold[set], 128L, (const double*)dinvT[set], -1.0, cb, rb,
-                               k0, kb + 1, k1, (int*)nullptr, -1, -1);
-            hipLaunchKernelGGL(k_next_diag, dim3(1), dim3(256), 0, s2, (const double*)dcopy[set], 128L,
-                               (const double*)(cold[set] + (long)k1 * 128), (const double*)rb, dnext);
-          } else {  // the same accumulation streams, one per wavefront, over 64 blocks
+          if (kb > 0) HIPC(hipStreamWaitEvent(s2, h->la_events[2 * kb], 0));  // update kb-1 has left cold[set], dcopy[set]
+          {  // two 128^3 products, one accumulator stream per wavefront, over 64 blocks
             hipLaunchKernelGGL(k_gemm128<0>, dim3(64), dim3(256), 0, s2, (const double*)(cold[set] + (long)k1 * 128), (const double*)dinvT[set],
                                -1.0, (const double*)nullptr, 0L, rb);
             hipLaunchKernelGGL(k_gemm128<1>, dim3(64), dim3(256), 0, s2, (const double*)(cold[set] + (long)k1 * 128), (const double*)rb, 0.0,
@@ -623,52 +356,28 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
           // the diagonal-inverse kernels address T[(k0 + r) * ld + k0 + c]: hand them the 128 x 128 copy under that indexing
           const double* dview = (const double*)((uintptr_t)dnext - sizeof(double) * ((size_t)k1 * 128 + (size_t)k1));
           launch_diag_inv(h, s2, dview, 128L, k1, nspd, dinv[set ^ 1], dinvT[set ^ 1], gate);
-          if (!flags_s1) HIPC(hipEventRecord(h->la_events[2 * kb + 1], s2));
+          HIPC(hipEventRecord(h->la_events[2 * kb + 1], s2));
         }
         const bool gate_here = gate && kb + 1 < nblk;
         if (kb > 0) {
-          if (!flags_s1) HIPC(hipStreamWaitEvent(h->stream, h->la_events[2 * kb - 1], 0));  // diagonal inverse kb
+          HIPC(hipStreamWaitEvent(h->stream, h->la_events[2 * kb - 1], 0));  // diagonal inverse kb
           // (the per-wavefront form of k_gemm128 for ALL panel rows was tried here: 30 us against 26 us -- its strided fragment
           // loads do not coalesce -- and its 640 blocks delay the chain's 64)
-          // k_panel, leaving, polls for diagonal inverse kb+1 to have started (the gate); with flags_s1 it first waits for
-          // diagonal inverse kb itself
-          PANEL(h->stream, (const double*)cold[set], 128L, (const double*)dinvT[set], -1.0, cnew[set], rt[set], k0, 0, 0, fl, flags_s1 ? kb : -1,
-                gate_here ? kb + 1 : -1);
+          // k_panel, leaving, polls for diagonal inverse kb+1 to have started (the gate)
+          PANEL(h->stream, (const double*)cold[set], 128L, (const double*)dinvT[set], -1.0, cnew[set], rt[set], k0, fl, gate_here ? kb + 1 : -1);
         }
         if (kb + 1 < nblk) {
           if (gate_here && kb == 0) hipLaunchKernelGGL(k_gate, dim3(1), dim3(1), 0, h->stream, (const int*)fl, kb + 1, 20000);
           if (symsweep)
             UPDK(true, dim3(ug), h->stream, T, ld, nblk, kb, (const double*)cold[set], (const double*)cnew[set],
-                 (const double*)rt[set], (const double*)dinv[set], 0, kb + 1, cold[set ^ 1], dcopy[set ^ 1], flags_s2 ? fl + MIK_F_UCNT + kb : (int*)nullptr);
+                 (const double*)rt[set], (const double*)dinv[set], 0, kb + 1, cold[set ^ 1], dcopy[set ^ 1]);
           else
             UPDK(false, dim3(ug), h->stream, T, ld, nblk, kb, (const double*)cold[set], (const double*)cnew[set],
-                 (const double*)rt[set], (const double*)dinv[set], 0, kb + 1, cold[set ^ 1], dcopy[set ^ 1], flags_s2 ? fl + MIK_F_UCNT + kb : (int*)nullptr);
-          if (!flags_s2) HIPC(hipEventRecord(h->la_events[2 * kb + 2], h->stream));
+                 (const double*)rt[set], (const double*)dinv[set], 0, kb + 1, cold[set ^ 1], dcopy[set ^ 1]);
+          HIPC(hipEventRecord(h->la_events[2 * kb + 2], h->stream));
         } else {
           UPD(dim3(ug), h->stream, cold[set], cnew[set], rt[set], dinv[set], 0, -2, (double*)nullptr);
         }
-      }
-      if (flags_s1) {  // once per inverse: the second stream has drained before this one goes on (and before the next call's memset)
-        HIPC(hipEventRecord(h->la_events[1], h->stream2));
-        HIPC(hipStreamWaitEvent(h->stream, h->la_events[1], 0));
-      }
-    } else
-    for (int kb = 0; kb < nblk; ++kb) {
-      const int set = kb & 1;
-      if (kb + 1 < nblk) {
-        // the column update leaves the updated block column in the other panel set as well (its last reader, the rest of step
-        // kb-1, is earlier on this very stream): the chain below starts with the diagonal inverse
-        UPD(dim3(nblk), h->stream, cold[set], cnew[set], rt[set], dinv[set], 1, kb + 1, h->opt_fuse_chain ? cold[set ^ 1] : (double*)nullptr);
-        HIPC(hipEventRecord(h->la_events[2 * kb], h->stream));
-        HIPC(hipStreamWaitEvent(h->stream2, h->la_events[2 * kb], 0));
-        panel_chain(h->stream2, kb + 1, set ^ 1, h->opt_fuse_chain != 0);
-        HIPC(hipEventRecord(h->la_events[2 * kb + 1], h->stream2));
-        if (gate)  // hold the big update back until the next diagonal inverse sits on a CU (see k_gate)
-          hipLaunchKernelGGL(k_gate, dim3(1), dim3(1), 0, h->stream, (const int*)h->flag.as<int>(), kb + 1, 20000);
-        UPD(dim3(ug), h->stream, cold[set], cnew[set], rt[set], dinv[set], 2, kb + 1, (double*)nullptr);
-        HIPC(hipStreamWaitEvent(h->stream, h->la_events[2 * kb + 1], 0));
-      } else {
-        UPD(dim3(ug), h->stream, cold[set], cnew[set], rt[set], dinv[set], 0, 0, (double*)nullptr);
       }
     }
   } else
@@ -696,12 +405,12 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
                             h->Cold.as<double>());
     // unpivoted sweep: the panel kernel writes R^T = -sigma C_new as well (one launch less per step)
     PANEL(h->stream, (const double*)h->Cold.as<double>(), 128L, (const double*)h->DinvT.as<double>(), -1.0, h->Cnew.as<double>(),
-          pivoted ? (double*)nullptr : h->Rt.as<double>(), k0, 0, 0, (int*)nullptr, -1, -1);
+          pivoted ? (double*)nullptr : h->Rt.as<double>(), k0, (int*)nullptr, -1);
     if (pivoted) {
       hipLaunchKernelGGL(k_transpose_rows, dim3(Mp / 64, 2), dim3(256), 0, h->stream, (const double*)T, ld, k0, Mp,
                          h->TKt.as<double>());
-      PANEL(h->stream, (const double*)h->TKt.as<double>(), 128L, (const double*)h->Dinv.as<double>(), 1.0, h->Rt.as<double>(), (double*)nullptr, 0, 0, 0,
-            (int*)nullptr, -1, -1);
+      PANEL(h->stream, (const double*)h->TKt.as<double>(), 128L, (const double*)h->Dinv.as<double>(), 1.0, h->Rt.as<double>(), (double*)nullptr, 0,
+            (int*)nullptr, -1);
     }
     UPD(dim3(ug), h->stream, h->Cold.as<double>(), h->Cnew.as<double>(), h->Rt.as<double>(), h->Dinv.as<double>(), 0, 0, (double*)nullptr);
   }
@@ -714,11 +423,9 @@ static int run_block_inverse(mik_handle* h, bool pivoted, int nspd, int* flag_ou
     hipLaunchKernelGGL(k_swap_cols, dim3((Mp + 255) / 256), dim3(256), 0, h->stream, T, ld,
                        (const int*)h->pivall.as<int>(), Mp, Mp);
   HIPC(hipGetLastError());
-  int flag = 0, lost = 0;
+  int flag = 0;
   HIPC(hipMemcpyAsync(&flag, h->flag.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-  HIPC(hipMemcpyAsync(&lost, h->flag.as<int>() + MIK_F_ERR, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIPC(hipStreamSynchronize(h->stream));
-  if (lost) return fail(MIK_EHIP, "block sweep: a cross-stream wait ran out (a producer kernel never finished)");
   *flag_out = flag;
   return MIK_OK;
 }

@@ -34,35 +34,15 @@ __global__ void __launch_bounds__(256) k_cvec(const double* __restrict__ Ainv, l
 // The sweep's flag buffer (ints, zeroed before every inverse):
 //   [0]                      pivot status bits (1 = zero / non-finite pivot, 2 = non-positive pivot inside the station block)
 //   [MIK_F_START + kb]       diagonal inverse kb has STARTED        (relaxed: a scheduling hint, see k_gate)
-//   [MIK_F_DDONE + kb]       diagonal inverse kb has FINISHED       (release; its Dinv / DinvT are visible to an acquire)
-//   [MIK_F_UCNT + kb]        finished blocks of the update of step kb (release each)
-//   [MIK_F_ERR]              a bounded wait below ran out (never in a healthy run; the host turns it into an error)
-// The early-diagonal schedule orders its two streams through these instead of cross-stream events: a satisfied
-// hipStreamWaitEvent still costs ~12 us of barrier-packet latency per step and stream (profiles/r02_inverse_timeline.txt).
+// The streams of the sweep are ordered by events only.  (Rounds 2-5 also carried flag-ordered schedules -- "early_diag" 4 / 5: a kernel
+// of one stream waiting for a kernel of another -- which tools that serialise dispatches break; they lost their A/B at N >= 5000 and
+// left the library in round 6 with their done-flags and counters: DESIGN_HISTORY.md.)
 #define MIK_F_STRIDE 4096  // block columns a sweep can have (N x N matrices end long before 524 288 stations)
 #define MIK_F_START 1
-#define MIK_F_DDONE (1 + MIK_F_STRIDE)
-#define MIK_F_UCNT (1 + 2 * MIK_F_STRIDE)
-#define MIK_F_ERR (1 + 3 * MIK_F_STRIDE)
-#define MIK_F_INTS (2 + 3 * MIK_F_STRIDE)
-#define MIK_WAIT_POLLS 4000000  // x (s_sleep 8 + one L2 round trip) > 1 s: only a lost kernel gets there
+#define MIK_F_INTS (2 + MIK_F_STRIDE)
 
 __device__ __forceinline__ void diag_started(int* flag, int k0) {
   if (threadIdx.x == 0) __hip_atomic_store(flag + MIK_F_START + k0 / 128, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// last action of a diagonal inverse: publish Dinv / DinvT (every thread's stores, through the barrier) and raise the flag
-__device__ __forceinline__ void diag_done(int* flag, int k0) {
-  __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_store(flag + MIK_F_DDONE + k0 / 128, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-}
-// one thread waits until flag[idx] >= expect (acquire); false after MIK_WAIT_POLLS polls (and MIK_F_ERR is raised)
-__device__ __forceinline__ bool flag_wait_ge(int* flag, int idx, int expect) {
-  for (int i = 0; i < MIK_WAIT_POLLS; ++i) {
-    if (__hip_atomic_load(flag + idx, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= expect) return true;
-    __builtin_amdgcn_s_sleep(8);
-  }
-  __hip_atomic_store(flag + MIK_F_ERR, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return false;
 }
 __global__ void k_gate(const int* __restrict__ flag, int idx, int max_polls) {
   for (int i = 0; i < max_polls; ++i) {  // bounded: a late chain only costs this kernel's time, never a hang
@@ -70,31 +50,22 @@ __global__ void k_gate(const int* __restrict__ flag, int idx, int max_polls) {
     __builtin_amdgcn_s_sleep(8);
   }
 }
-// a dependency, not a hint: the kernels behind this one on its stream read what the counted / flagged producers wrote
-__global__ void k_wait_ge(int* __restrict__ flag, int idx, int expect) { (void)flag_wait_ge(flag, idx, expect); }
-
 // Out[i][n] = alpha * sum_m A[i][m] * Bt[n][m],  i over Mp rows, n < 128, m < 128 (one tile column)
 // NAI: a block does 32 * NAI rows (4 waves as 2 x 2, wave tile 16 NAI x 64).  NAI = 4 is one 128 x 128 tile per block: 22 us, a
-// CU's MFMA rate, whatever Mp is; NAI = 1 (round 3, the sweep's default) spreads the same accumulation streams over 4 x the
-// blocks -- the panel kernel sits on the update stream's critical path once per step.  Same k order per entry: same bits.
-template <int NAI = 4>
+// CU's MFMA rate, whatever Mp is; NAI = 1 (round 3; the only form the library instantiates since round 6) spreads the same
+// accumulation streams over 4 x the blocks -- the panel kernel sits on the update stream's critical path once per step.  Same k
+// order per entry: same bits.
+template <int NAI = 1>
 __global__ void __launch_bounds__(256, 2)
 k_panel(const double* __restrict__ A, long lda, const double* __restrict__ Bt, double alpha,
-        double* __restrict__ Out, double* __restrict__ RtOut = nullptr, int k0 = 0, int blk0 = 0, int orow = 0,
-        int* __restrict__ flag = nullptr, int wait_diag = -1, int gate_diag = -1) {
+        double* __restrict__ Out, double* __restrict__ RtOut = nullptr, int k0 = 0,
+        int* __restrict__ flag = nullptr, int gate_diag = -1) {
   // RtOut (symmetric sweep): also Rt[i][:] = -sigma_i Out[i][:], sigma_i = -1 for row blocks already swept
-  // blk0 / orow (early-diagonal chain): start at row block blk0 and store row i at Out / RtOut row i - orow (a one-block launch
-  // that leaves the 128 panel rows of one block in a 128 x 128 scratch)
-  // flag (early-diagonal schedule): wait_diag >= 0 -- Bt is the DinvT of diagonal inverse wait_diag, running on the other
-  // stream: wait for its flag before touching it; gate_diag >= 0 -- block 0 leaves only when diagonal inverse gate_diag has
-  // started (k_gate's hint without its launch: the update behind this kernel then finds that inverse already on its CU)
+  // flag (early-diagonal schedule): gate_diag >= 0 -- block 0 leaves only when diagonal inverse gate_diag has started (k_gate's
+  // hint without its launch: the update behind this kernel then finds that inverse already on its CU)
   constexpr int BMR = 32 * NAI;  // rows per block
   __shared__ GemmSmemT<BMR> sm;
-  if (flag && wait_diag >= 0) {
-    if (threadIdx.x == 0) (void)flag_wait_ge(flag, MIK_F_DDONE + wait_diag, 1);
-    __syncthreads();
-  }
-  const int i0 = blockIdx.x * BMR + blk0 * MIK_BM;
+  const int i0 = blockIdx.x * BMR;
   d4 acc[NAI][4];
 #pragma unroll
   for (int x = 0; x < NAI; ++x)
@@ -112,8 +83,8 @@ k_panel(const double* __restrict__ A, long lda, const double* __restrict__ Bt, d
         const int i = i0 + wm * (16 * NAI) + ai * 16 + lq + 4 * r;
         const int n = wn * 64 + bi * 16 + lc;
         const double v = alpha * acc[ai][bi][r];
-        Out[(long)(i - orow) * 128 + n] = v;
-        if (RtOut) RtOut[(long)(i - orow) * 128 + n] = (i < k0) ? v : -v;
+        Out[(long)i * 128 + n] = v;
+        if (RtOut) RtOut[(long)i * 128 + n] = (i < k0) ? v : -v;
       }
   if (flag && gate_diag >= 0 && blockIdx.x == 0 && threadIdx.x == 0) {
     for (int i = 0; i < 20000; ++i) {
@@ -129,9 +100,9 @@ k_panel(const double* __restrict__ A, long lda, const double* __restrict__ Bt, d
 // a, b has been swept), so only the UPPER block triangle i <= j is maintained (half the tiles): part 0 = all upper tiles,
 // part 1 = block column `col` (i <= col) and block row `col` (j >= col) -- what the next panel chain reads --, part 2 =
 // the upper tiles outside those.
-// NAI = 4: 4 waves per block, wave tile 64 x 64 (228 VGPRs, 2 waves per SIMD); NAI = 2 (round 3): 8 waves, wave tile 32 x 64
-// (<= 128 VGPRs, 4 waves per SIMD to cover the short K loop and the read-modify-write epilogue).  Same accumulation order per
-// entry: bit-identical results.
+// NAI = 4: 4 waves per block, wave tile 64 x 64 (228 VGPRs, 2 waves per SIMD); NAI = 2 (round 3; the only form the library
+// instantiates since round 6): 8 waves, wave tile 32 x 64 (<= 128 VGPRs, 4 waves per SIMD to cover the short K loop and the
+// read-modify-write epilogue).  Same accumulation order per entry: bit-identical results.
 // register sets of the read-modify-write epilogue: two for the 4-wave form; the 8-wave form (128-VGPR budget) keeps ONE -- with two
 // it spills 25 registers and the inverse is 12-14 % slower (N=5000 4.33 -> 4.90 ms; profiles/r03_k2_panel_stream_ab.txt)
 #ifndef MIK_UPD_NTV
@@ -140,51 +111,36 @@ k_panel(const double* __restrict__ A, long lda, const double* __restrict__ Bt, d
 #ifdef MIK_UPD_PROF
 __device__ unsigned long long* mik_upd_prof = nullptr;
 #endif
-template <bool SYM, int NAI = 4>
+template <bool SYM, int NAI = 2>
 __global__ void __launch_bounds__(64 * 2 * (8 / NAI), NAI == 2 ? 4 : 2)
 k_update(double* __restrict__ T, long ld, int nblk, int kb, const double* __restrict__ Cold,
          const double* __restrict__ Cnew, const double* __restrict__ Rt, const double* __restrict__ Dinv, int part, int col,
-         double* __restrict__ Pout, double* __restrict__ Dcopy = nullptr, int* __restrict__ done_cnt = nullptr,
-         const int2* __restrict__ tilemap = nullptr, int atomic_rmw = 0, int* __restrict__ cu_tok = nullptr) {
-  // cu_tok (nullable; round 5, option "update_token"): one word per CU (indexed by XCC_ID and the SE / SH / CU fields of HW_ID), zeroed by the
-  // host.  A block takes its CU's token for the K loop and gives it back before its read-modify-write: the two resident blocks of a CU
-  // then ALTERNATE -- one feeds the matrix cores while the other loads, subtracts and stores -- instead of falling into step chip-wide
-  // (load-all, compute-all: the phases add, tools/update_bench).  Only a schedule: same tiles, same arithmetic, same bits.  Bounded wait.
-  // atomic_rmw (round 3): a tile that only has to become T - C R^T (no panel copy, no diagonal copy) sends its 128 x 128 products
-  // to memory as fp64 atomic adds of -acc (global_atomic_add_f64, no return value) instead of load / subtract / store: the
-  // read-modify-write then happens in the L2 while the wavefronts are already in the next tile's K loop -- the epilogue's memory
-  // latency was not overlapped with anything before (the two resident blocks of a CU run their phases in step).  T + (-x) rounds
-  // exactly like T - x and every entry receives one update per launch: same bits.
-  // tilemap (nullable; round 3): position -> (iblk, jblk) of parts 0 / 2 / 4, written by the host (update_tile_map): the tiles in
-  // the order of 8 x 8 super-blocks, so that the ~64 tiles an XCD works on at a time share 8 + 8 operand panels (2 MB of its 4 MB
-  // L2) instead of a whole block column's worth (one C panel per tile: 8 MB at N = 8000, re-fetched over the fabric every column)
+         double* __restrict__ Pout, double* __restrict__ Dcopy = nullptr, int rev = 0) {
+  // rev (option "update_rev"): odd steps of the half sweep walk every XCD's tile range from its end -- the whole upper triangle is
+  // streamed once per step, cyclically; a memory-side cache smaller than it keeps nothing of a cyclic stream, but most of a
+  // back-and-forth one.
+  // (Rounds 3-5 carried four more schedules of this kernel -- fp64 atomic adds instead of the read-modify-write, a host-written tile
+  // map of 8 x 8 super-blocks, a per-CU token that made the two resident blocks alternate, a count of finished blocks for a waiting
+  // kernel of the other stream.  All bit-identical, none faster: DESIGN_HISTORY.md.)
   // Pout (nullable): the updated block column `col` is ALSO written as the next step's column panel
   // P[row][0..127] (what k_copy_panel / k_copy_panel_sym would read back out of T: tiles of the block row `col` go in transposed),
   // so that the next panel chain starts with the diagonal inverse instead of a copy kernel.
   // Dcopy (nullable): the updated diagonal tile (col + 1, col + 1) is also left there (128 x 128): the early-diagonal chain
   // builds the diagonal block after next from it without touching T.
-  // done_cnt (nullable): every block of the launch adds one when its stores are out (release): the other stream waits for
-  // gridDim.x of them instead of for an event
   __shared__ GemmSmem sm;
 #ifdef MIK_UPD_PROF
   const unsigned long long pts = __builtin_amdgcn_s_memtime();
   const unsigned long long prs = __builtin_amdgcn_s_memrealtime();
 #endif
-  auto finish = [&]() {
-    if (done_cnt) {
-      __syncthreads();
-      if (threadIdx.x == 0) __hip_atomic_fetch_add(done_cnt, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  };
   // part = 3 / 4 (round 3, the panel stream of the sweep): part 1 plus the diagonal tile (col + 1, col + 1) as block `nblk` of
   // the launch -- everything the next panel kernel AND the chain of the diagonal inverse after next read (Pout, Dcopy) -- /
   // part 2 without that tile.
   int iblk, jblk;
   if (part == 3 && (int)blockIdx.x == nblk) {
-    if (col + 1 >= nblk) return finish();
+    if (col + 1 >= nblk) return;
     iblk = jblk = col + 1;
   } else if (part == 1 || part == 3) {
-    if ((int)blockIdx.x >= nblk) return finish();
+    if ((int)blockIdx.x >= nblk) return;
     if (SYM && (int)blockIdx.x > col) {
       iblk = col;
       jblk = blockIdx.x;
@@ -192,32 +148,22 @@ k_update(double* __restrict__ T, long ld, int nblk, int kb, const double* __rest
       iblk = blockIdx.x;
       jblk = col;
     }
-  } else if (tilemap) {
-    const long L = xcd_tile(SYM ? (long)nblk * (nblk + 1) / 2 : (long)nblk * nblk);
-    if (L < 0) return finish();
-    const int2 ij = tilemap[L];
-    iblk = ij.x;
-    jblk = ij.y;
-    if ((part == 2 || part == 4) && (jblk == col || (SYM && iblk == col))) return finish();
-    if (part == 4 && iblk == col + 1 && jblk == col + 1) return finish();
   } else if (SYM) {
-    // (atomic_rmw bit 1, option "update_rev": odd steps walk every XCD's tile range from its end -- the whole upper triangle is streamed
-    // once per step, cyclically; a memory-side cache smaller than it keeps nothing of a cyclic stream, but most of a back-and-forth one)
-    const long L = ((atomic_rmw & 2) && (kb & 1)) ? xcd_tile_rev((long)nblk * (nblk + 1) / 2) : xcd_tile((long)nblk * (nblk + 1) / 2);
-    if (L < 0) return finish();
+    const long L = (rev && (kb & 1)) ? xcd_tile_rev((long)nblk * (nblk + 1) / 2) : xcd_tile((long)nblk * (nblk + 1) / 2);
+    if (L < 0) return;
     jblk = (int)((sqrt(8.0 * (double)L + 1.0) - 1.0) * 0.5);
     while ((long)jblk * (jblk + 1) / 2 > L) --jblk;            // guard the float estimate
     while ((long)(jblk + 1) * (jblk + 2) / 2 <= L) ++jblk;
     iblk = (int)(L - (long)jblk * (jblk + 1) / 2);             // i <= j: the upper block triangle
-    if ((part == 2 || part == 4) && (iblk == col || jblk == col)) return finish();
-    if (part == 4 && iblk == col + 1 && jblk == col + 1) return finish();
+    if ((part == 2 || part == 4) && (iblk == col || jblk == col)) return;
+    if (part == 4 && iblk == col + 1 && jblk == col + 1) return;
   } else {
     const long L = xcd_tile((long)nblk * nblk);
-    if (L < 0) return finish();
+    if (L < 0) return;
     iblk = (int)(L / nblk);
     jblk = (int)(L % nblk);
-    if ((part == 2 || part == 4) && jblk == col) return finish();
-    if (part == 4 && iblk == col + 1 && jblk == col + 1) return finish();
+    if ((part == 2 || part == 4) && jblk == col) return;
+    if (part == 4 && iblk == col + 1 && jblk == col + 1) return;
   }
   const int i0 = iblk * MIK_BM, j0 = jblk * MIK_BN, k0 = kb * 128;
   const bool ptrans = SYM && iblk == col && jblk != col;  // a tile of the block ROW col: panel rows = its columns
@@ -236,27 +182,13 @@ k_update(double* __restrict__ T, long ld, int nblk, int kb, const double* __rest
         else P[(long)(i0 + r) * 128 + c] = v;
       }
     }
-    return finish();
+    return;
   }
   d4 acc[NAI][4];
 #pragma unroll
   for (int x = 0; x < NAI; ++x)
 #pragma unroll
     for (int y = 0; y < 4; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
-  int* tok = nullptr;
-  if (cu_tok) {
-    unsigned xcc, hw;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-    tok = cu_tok + (((xcc & 7u) << 8) | ((hw >> 8) & 0xffu));  // HW_ID: CU_ID 11:8, SH_ID 12, SE_ID 15:13
-    if (threadIdx.x == 0) {
-      for (int spin = 0; spin < 100000; ++spin) {
-        if (atomicCAS(tok, 0, 1) == 0) break;
-        __builtin_amdgcn_s_sleep(8);
-      }
-    }
-    __syncthreads();
-  }
 #ifdef MIK_UPD_PROF  // tools/update_bench only: s_memtime at the phase boundaries of one tile, per block
   const unsigned long long pt0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -264,7 +196,6 @@ k_update(double* __restrict__ T, long ld, int nblk, int kb, const double* __rest
 #ifdef MIK_UPD_PROF
   const unsigned long long pt1 = __builtin_amdgcn_s_memtime();
 #endif
-  if (tok && threadIdx.x == 0) __hip_atomic_store(tok, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (gemm_core ended with a barrier)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 1, wn = wave & 1, lq = lane >> 4, lc = lane & 15;
   constexpr int WR = 16 * NAI;  // rows of the wave tile
@@ -273,18 +204,6 @@ k_update(double* __restrict__ T, long ld, int nblk, int kb, const double* __rest
   constexpr int NTV = MIK_UPD_NTV(NAI);  // register sets of the epilogue (the 8-wave form has a 128-VGPR budget for 4 waves per SIMD)
   double tv[NTV][4][4];
   auto tile_ptr = [&](int ai) { return T + (long)(i0 + wm * WR + ai * 16 + lq) * ld + j0 + wn * 64 + lc; };
-  if ((atomic_rmw & 1) && !P && !DC) {  // block-uniform
-#pragma unroll
-    for (int ai = 0; ai < NAI; ++ai) {
-      double* tp = tile_ptr(ai);
-#pragma unroll
-      for (int bi = 0; bi < 4; ++bi)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          (void)__hip_atomic_fetch_add(tp + (long)(4 * r) * ld + bi * 16, -acc[ai][bi][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    return finish();
-  }
   auto load_batch = [&](int ai, double (&dst)[4][4]) {
     const double* tp = tile_ptr(ai);
 #pragma unroll
@@ -329,246 +248,6 @@ k_update(double* __restrict__ T, long ld, int nblk, int kb, const double* __rest
     }
   }
 #endif
-  finish();
-}
-
-// ---- Trailing update, DEEP form (round 5; option "update_deep") -------------------------------------------------------------------
-// k_update's tile is a K = 128 MFMA loop followed by a read-modify-write of the 128 x 128 tile of T, and the two phases ADD: the T
-// loads are issued after the loop (no registers for them at 128 VGPRs / 4 wavefronts per SIMD) and the two resident blocks of a CU
-// fall into step.  Measured (profiles/r03_k2_panel_stream_ab.txt): 57 us per round of 512 resident blocks = 27 us of matrix-core
-// time + 32 us of memory time.  This form gives a CU ONE block of 16 wavefronts (wave tile 16 x 64: 32 accumulator registers) and
-//   * loads the block's T tile into registers BEFORE the K loop (32 more VGPRs): the epilogue is subtract + store, no load latency;
-//   * stages the operands through FOUR LDS buffers (128 KB) with three K tiles in flight -- counted s_waitcnt vmcnt(N), raw
-//     s_barrier: with one block per CU nothing else covers a DMA's latency;
-//   * runs up to `tpb` tiles per block as ONE pipeline: the first K tiles of the next tile are in flight while the current one
-//     finishes, its stores drain under the next tile's loop.
-// Same K order per entry (K tiles from the top down, within a tile k = 8m + 2kq + h in the order (m, h)) and the same final
-// subtraction as k_update: BIT-IDENTICAL inverses.  Only tiles that take a rank-128 update are handled here (part 4 / 0 without the
-// pivot's own block row / column, which are copies: k_update part 5).
-#define MIK_UD_NST 4
-#define MIK_UD_LDS_BYTES (MIK_UD_NST * 2 * 128 * MIK_BK * 8)
-__device__ __forceinline__ void ud_wait_vm(int n) {  // counted wait; n is block-uniform and one of a few values
-  switch (n) {
-    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(36)" ::: "memory"); break;  // 4 + 16 stores + 16 T loads issued after the awaited stage
-  }
-}
-template <bool SYM, int ABL = 0>
-__global__ void __launch_bounds__(1024)
-k_update_deep(double* __restrict__ T, long ld, int nblk, int kb, const double* __restrict__ Cold, const double* __restrict__ Cnew,
-              const double* __restrict__ Rt, const double* __restrict__ Dinv, int part, int col, int tpb, int rev, int gdeep) {
-  constexpr int abl = ABL;  // tools/update_bench only (0 in the library): 1 no T loads, 2 no LDS-DMA, 4 no MFMAs, 8 no stagger, 16 no fragment reads, 32 no stores
-  extern __shared__ double ud_lds[];  // As[NST][128][16] then Bs[NST][128][16]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if ((int)blockIdx.x >= gdeep) {
-    // the pivot's own block column / row (and Dinv): copies of the panels, one tile per block -- k_update's write-back path
-    const int t = (int)blockIdx.x - gdeep;
-    int iblk, jblk;
-    if (SYM) {
-      if (t >= nblk) return;
-      iblk = t <= kb ? t : kb;
-      jblk = t <= kb ? kb : t;
-    } else if (t < nblk) {
-      iblk = t;
-      jblk = kb;
-    } else {
-      int j = t - nblk;
-      if (j >= kb) ++j;
-      if (j >= nblk) return;
-      iblk = kb;
-      jblk = j;
-    }
-    if (part == 4 && (jblk == col || (SYM && iblk == col))) return;  // the column part (k_update part 3) has written those
-    const int i0 = iblk * 128, j0 = jblk * 128;
-    for (int e = tid; e < 128 * 128; e += 1024) {
-      const int r = e >> 7, c = e & 127;
-      double v;
-      if (iblk == kb && jblk == kb) v = Dinv[e];
-      else if (jblk == kb) v = Cnew[(long)(i0 + r) * 128 + c];
-      else v = Rt[(long)(j0 + c) * 128 + r];
-      T[(long)(i0 + r) * ld + j0 + c] = v;
-    }
-    return;
-  }
-  const int wm = wave >> 1, wn = wave & 1, lq = lane >> 4, lc = lane & 15;
-  const long total = SYM ? (long)nblk * (nblk + 1) / 2 : (long)nblk * nblk;
-  const long per = (total + 7) / 8;
-  const long xbeg = (long)(blockIdx.x % 8) * per, xend = xbeg + per < total ? xbeg + per : total;
-  const long first = (long)(blockIdx.x / 8) * tpb;  // offset inside the XCD's range
-  // position p (0 .. tpb - 1) of this block -> logical tile L (or -1), walked from the range's end when rev
-  auto tile_at = [&](int p, int& iblk, int& jblk) -> bool {
-    const long o = first + p;
-    if (p >= tpb || xbeg + o >= xend) return false;
-    const long L = rev ? xend - 1 - o : xbeg + o;
-    if (SYM) {
-      int j = (int)((sqrt(8.0 * (double)L + 1.0) - 1.0) * 0.5);
-      while ((long)j * (j + 1) / 2 > L) --j;
-      while ((long)(j + 1) * (j + 2) / 2 <= L) ++j;
-      jblk = __builtin_amdgcn_readfirstlane(j);
-      iblk = __builtin_amdgcn_readfirstlane((int)(L - (long)j * (j + 1) / 2));
-    } else {
-      iblk = __builtin_amdgcn_readfirstlane((int)(L / nblk));
-      jblk = __builtin_amdgcn_readfirstlane((int)(L % nblk));
-    }
-    if (iblk == kb || jblk == kb) return false;                                                   // copies: k_update part 5
-    if (part == 4 && (jblk == col || (SYM && iblk == col) || (iblk == col + 1 && jblk == col + 1))) return false;  // column part
-    return true;
-  };
-  // the next valid position at or after p (tpb if none)
-  auto next_valid = [&](int p, int& iblk, int& jblk) -> int {
-    while (p < tpb && !tile_at(p, iblk, jblk)) ++p;
-    return p;
-  };
-  // ---- staging (gemm_core's thread -> (row, slot) map, swizzles and LDS-DMA form; 1024 threads = one pass per operand)
-  const int lrow = tid >> 3, slot = tid & 7;
-  const unsigned aoffb = (unsigned)(((long)lrow * 128 + ((slot ^ (lrow & 2)) << 1)) * 8);
-  const unsigned boffb = (unsigned)(((long)lrow * 128 + ((slot ^ ((lrow >> 1) & 7)) << 1)) * 8);
-  constexpr unsigned BUF = 128 * MIK_BK * 8;  // bytes of one operand tile
-  const unsigned ldsA = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(ud_lds + (size_t)wave * 8 * MIK_BK));
-  const unsigned ldsB = ldsA + MIK_UD_NST * BUF;
-  auto uniform_ptr = [](const double* q) {
-    const unsigned long long v = (unsigned long long)(uintptr_t)q;
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-    return reinterpret_cast<const double*>((uintptr_t)(((unsigned long long)hi << 32) | lo));
-  };
-  auto stage = [&](int iblk, int jblk, int kk, int buf) {  // K tile kk (0 = the top one, k = 112) of tile (iblk, jblk) into buffer buf
-    const int k = 128 - MIK_BK * (kk + 1);
-    const double* abase = uniform_ptr(Cold + (long)iblk * 128 * 128 + k);
-    const double* bbase = uniform_ptr(Rt + (long)jblk * 128 * 128 + k);
-    const unsigned la = ldsA + buf * BUF, lb = ldsB + buf * BUF;
-    asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(aoffb), "s"(abase), "s"(la) : "memory");
-    asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(boffb), "s"(bbase), "s"(lb) : "memory");
-  };
-  // ---- fragment offsets (doubles, inside one operand tile)
-  const int kq = lane >> 4, ia = lane & 3, jb = lane & 15;
-  int aoff[2], boff[2];
-#pragma unroll
-  for (int m = 0; m < 2; ++m) {
-    aoff[m] = (wm * 16 + ia) * MIK_BK + (((4 * m + kq) ^ (ia & 2)) << 1);
-    boff[m] = (wn * 64 + jb) * MIK_BK + (((4 * m + kq) ^ ((jb >> 1) & 7)) << 1);
-  }
-  const double* As = ud_lds;
-  const double* Bs = ud_lds + (size_t)MIK_UD_NST * 128 * MIK_BK;
-  // ---- two cursors over the block's sequence of (tile, K tile): the DMA runs NST - 1 steps ahead of the matrix cores
-  int ci, cj, cp = next_valid(0, ci, cj);  // compute cursor: position, tile
-  if (cp >= tpb) return;                   // block-uniform
-  int si = ci, sj = cj, sp = cp, skk = 0;  // staging cursor
-  int issued = 0;                          // steps staged so far
-  auto stage_next = [&]() {                // stage the staging cursor's step and advance it (no-op at the end of the sequence)
-    if (sp >= tpb) return;
-    if (!(abl & 2)) stage(si, sj, skk, issued % MIK_UD_NST);
-    ++issued;
-    if (++skk == 128 / MIK_BK) {
-      skk = 0;
-      sp = next_valid(sp + 1, si, sj);
-    }
-  };
-  auto tile_ptr = [&](int iblk, int jblk) { return T + (long)(iblk * 128 + wm * 16 + lq) * ld + jblk * 128 + wn * 64 + lc; };
-  double tv[4][4] = {};
-  auto load_t = [&](int iblk, int jblk) {
-    const double* tp = tile_ptr(iblk, jblk);
-#pragma unroll
-    for (int bi = 0; bi < 4; ++bi)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) tv[bi][r] = tp[(long)(4 * r) * ld + bi * 16];
-  };
-  if (!(abl & 1)) load_t(ci, cj);
-#pragma unroll
-  for (int s = 0; s < MIK_UD_NST - 1; ++s) stage_next();
-  int step = 0;     // steps computed so far
-  bool firsttile = true;
-  const bool late = (wave >> 2) & 1;  // wave-uniform; SIMD = wave % 4 holds two early and two late wavefronts
-  double2 fa[4], fb[4];
-  d4 acc[4];
-  auto read_frags = [&](const double* as, const double* bs, int m) {
-#pragma unroll
-    for (int x = 0; x < 4; ++x) fa[x] = *reinterpret_cast<const double2*>(as + aoff[m] + 4 * x * MIK_BK);
-#pragma unroll
-    for (int x = 0; x < 4; ++x) fb[x] = *reinterpret_cast<const double2*>(bs + boff[m] + 16 * x * MIK_BK);
-  };
-  auto mfma_all = [&]() {
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int bi = 0; bi < 4; ++bi) acc[bi][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa[r].x, fb[bi].x, acc[bi][r], 0, 0, 0);
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int bi = 0; bi < 4; ++bi) acc[bi][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa[r].y, fb[bi].y, acc[bi][r], 0, 0, 0);
-  };
-  while (cp < tpb) {
-#pragma unroll
-    for (int y = 0; y < 4; ++y) acc[y] = (d4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll 1
-    for (int kk = 0; kk < 128 / MIK_BK; ++kk, ++step) {
-      // operations issued after the stage this step reads: the later stages in flight (2 DMAs each) and -- for the first three
-      // steps of a tile that follows another -- that tile's 16 stores and this tile's 16 T loads
-      const int ahead = issued - step - 1;  // 0 .. NST - 2
-      ud_wait_vm((!firsttile && kk < MIK_UD_NST - 1) ? 36 : 2 * ahead);
-      asm volatile("s_barrier" ::: "memory");  // every wavefront's share of the stage has landed; buffer (step - 1) % NST is free
-      stage_next();
-      const double* as = As + (size_t)(step % MIK_UD_NST) * 128 * MIK_BK;
-      const double* bs = Bs + (size_t)(step % MIK_UD_NST) * 128 * MIK_BK;
-      // STAGGER: with one barrier per K tile the 16 wavefronts of the block fall into step -- all read fragments, then all feed the
-      // matrix cores, and the two phases add (measured: 32 us per tile against 13.7 of matrix-core time).  Half of the wavefronts
-      // (two of the four on every SIMD) therefore run HALF A STEP LATE: they read the second half's fragments before the barrier
-      // and contract them after it, so that one group reads while the other multiplies.  The order of the products of an entry
-      // does not change.
-      if (abl & 8) {
-        if (!(abl & 16)) read_frags(as, bs, 0);
-        if (!(abl & 4)) mfma_all();
-        if (!(abl & 16)) read_frags(as, bs, 1);
-        if (!(abl & 4)) mfma_all();
-      } else {
-      if (late && kk > 0) mfma_all();
-      read_frags(as, bs, 0);
-      mfma_all();
-      read_frags(as, bs, 1);
-      if (!late || kk == 128 / MIK_BK - 1) mfma_all();
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wavefront's fragment reads are done before it reaches the next barrier
-    }
-    // epilogue: T tile (in registers since before the K loop) - acc
-    {
-      double* tp = tile_ptr(ci, cj);
-#pragma unroll
-      for (int bi = 0; bi < 4; ++bi)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (!(abl & 32)) tp[(long)(4 * r) * ld + bi * 16] = tv[bi][r] - acc[bi][r];
-    }
-    cp = next_valid(cp + 1, ci, cj);
-    firsttile = false;
-    if (cp < tpb && !(abl & 1)) load_t(ci, cj);
-  }
-}
-
-// Early-diagonal chain: the diagonal block kb + 1 as step kb's update will leave it, Dnext = Dsrc - Cb . Rb^T, from the 128 panel
-// rows of that block alone (Cb = rows of the column panel, Rb = the matching rows of R^T, see k_panel's blk0) -- the same tile
-// loop, operands and subtraction as k_update uses for this tile, hence the same bits.  One block.
-__global__ void __launch_bounds__(256, 2)
-k_next_diag(const double* __restrict__ Dsrc, long ldsrc, const double* __restrict__ Cb, const double* __restrict__ Rb,
-            double* __restrict__ Dnext) {
-  __shared__ GemmSmem sm;
-  d4 acc[4][4];
-#pragma unroll
-  for (int x = 0; x < 4; ++x)
-#pragma unroll
-    for (int y = 0; y < 4; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
-  gemm_core<4>(Cb, 128, Rb, 128, 0, 128, acc, sm);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = wave >> 1, wn = wave & 1, lq = lane >> 4, lc = lane & 15;
-#pragma unroll
-  for (int ai = 0; ai < 4; ++ai)
-#pragma unroll
-    for (int bi = 0; bi < 4; ++bi)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = wm * 64 + ai * 16 + lq + 4 * r, cc = wn * 64 + bi * 16 + lc;
-        Dnext[row * 128 + cc] = Dsrc[(long)row * ldsrc + cc] - acc[ai][bi][r];
-      }
 }
 
 // One 128 x 128 x 128 product C = A . Bt^T spread over the chip: 256 wavefronts (64 blocks), each ONE accumulator stream of
@@ -614,144 +293,6 @@ __global__ void __launch_bounds__(256) k_gemm128(const double* __restrict__ A, c
 // sweep it therefore gets a CU of its own: the big trailing update of a step is held back by k_gate until the diagonal inverse
 // of the next step HAS STARTED (flag[1 + block] is raised as its first action) -- it then sits on an empty CU --, and the
 // inverse is launched with ~100 KB of dynamic LDS it never touches, so that no 64-KB update block can join it there.
-
-// 128x128 in-register Gauss-Jordan inverse of the diagonal block, one 1024-thread workgroup.
-// Thread (w = wave 0..15, lane) owns rows 8w..8w+7, columns lane and lane+64.  Per elimination step
-// the owners publish the pivot row and pivot column through double-buffered LDS; one barrier per step.
-// flag bit0: zero / non-finite pivot (singular); bit1: non-positive pivot inside the station block
-// (the shifted matrix was not positive definite -> the unpivoted path is not trustworthy).
-__global__ void __launch_bounds__(1024) k_diag_inv(const double* __restrict__ T, long ld, int k0, int nspd,
-                                                   double* __restrict__ Dinv, double* __restrict__ DinvT,
-                                                   int* __restrict__ flag) {
-  __shared__ double rowk[2][128], colk[2][128];
-  diag_started(flag, k0);
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  double al[8], ah[8];  // columns lane / lane+64 of this thread's 8 rows (two arrays: never indexed dynamically)
-#pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    al[r] = T[(long)(k0 + w * 8 + r) * ld + k0 + lane];
-    ah[r] = T[(long)(k0 + w * 8 + r) * ld + k0 + lane + 64];
-  }
-  int bad = 0;
-  // k = 8*kb + kr with kr unrolled: the pivot row's owner is wave kb and its local row index kr is a
-  // compile-time constant, so a[][] is only ever indexed statically (no scratch).
-#pragma unroll 1
-  for (int kb = 0; kb < 16; ++kb) {
-#pragma unroll
-    for (int kr = 0; kr < 8; ++kr) {
-      const int k = kb * 8 + kr;
-      const int pb = kr & 1;
-      if (kb == w) {
-        rowk[pb][lane] = al[kr];
-        rowk[pb][lane + 64] = ah[kr];
-      }
-      if (lane == (k & 63)) {
-#pragma unroll
-        for (int r = 0; r < 8; ++r) colk[pb][w * 8 + r] = (kb < 8) ? al[r] : ah[r];
-      }
-      __syncthreads();
-      const double piv = rowk[pb][k];
-      if (!(fabs(piv) > 1e-300) || !isfinite(piv)) bad |= 1;
-      if ((k0 + k) < nspd && !(piv > 0.0)) bad |= 2;
-      const double pinv = pivot_recip(piv);
-      const double rk0 = rowk[pb][lane] * pinv, rk1 = rowk[pb][lane + 64] * pinv;
-      const bool c0 = (lane == k), c1 = (lane + 64 == k);
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const double f = colk[pb][w * 8 + r];
-        const double n0 = c0 ? -f * pinv : al[r] - f * rk0;
-        const double n1 = c1 ? -f * pinv : ah[r] - f * rk1;
-        const bool prow = (kb == w) && (r == kr);
-        al[r] = prow ? (c0 ? pinv : rk0) : n0;
-        ah[r] = prow ? (c1 ? pinv : rk1) : n1;
-      }
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    const int i = w * 8 + r;
-    Dinv[i * 128 + lane] = al[r];
-    Dinv[i * 128 + lane + 64] = ah[r];
-    DinvT[lane * 128 + i] = al[r];
-    DinvT[(lane + 64) * 128 + i] = ah[r];
-  }
-  if (bad && threadIdx.x == 0) atomicOr(flag, bad);
-  diag_done(flag, k0);
-}
-
-// The same 128x128 in-place Gauss-Jordan inverse on a NT-thread workgroup laid out as a GY x GX grid with a cyclic
-// (128/GY) x (128/GX) register tile per thread (rows ty + GY i, columns tx + GX j): fewer wavefronts per barrier and the
-// pivot row / column indices inside a thread are compile-time constants (kb outer, unrolled).  One barrier per step.
-template <int GY, int GX>
-__global__ void __launch_bounds__(GY * GX) k_diag_inv_t(const double* __restrict__ T, long ld, int k0, int nspd,
-                                                         double* __restrict__ Dinv, double* __restrict__ DinvT,
-                                                         int* __restrict__ flag) {
-  constexpr int RI = 128 / GY, CJ = 128 / GX, KBN = GY;  // steps per unrolled group
-  static_assert(GY <= GX && GX % GY == 0, "row groups nest in column groups");
-  // pivot row / column in OWNER-MAJOR order ([tx][j], [ty][i]): a thread's CJ + RI reads per step are contiguous (ds_read_b128)
-  __shared__ double rowk[2][128], colk[2][128];
-  diag_started(flag, k0);
-  const int ty = threadIdx.x / GX, tx = threadIdx.x % GX;
-  double a[RI][CJ];
-#pragma unroll
-  for (int i = 0; i < RI; ++i)
-#pragma unroll
-    for (int j = 0; j < CJ; ++j) a[i][j] = T[(long)(k0 + ty + GY * i) * ld + k0 + tx + GX * j];
-  int bad = 0;
-  // step k = GY * kb + kr: pivot row k is local row kb of the threads with ty == kr; pivot column k is local column
-  // jb = k / GX (constant within the group) of the threads with tx == k % GX
-#pragma unroll
-  for (int kb = 0; kb < 128 / KBN; ++kb) {
-    const int jb = (GY * kb) / GX, cbase = (GY * kb) % GX;  // compile-time after unrolling
-#pragma unroll 1
-    for (int kr = 0; kr < KBN; ++kr) {
-      const int pb = kr & 1, pc = cbase + kr;  // pc = k % GX: the tx that owns pivot column k
-      if (ty == kr) {
-#pragma unroll
-        for (int j = 0; j < CJ; ++j) rowk[pb][tx * CJ + j] = a[kb][j];
-      }
-      if (tx == pc) {
-#pragma unroll
-        for (int i = 0; i < RI; ++i) {
-#pragma unroll
-          for (int j = 0; j < CJ; ++j)
-            if (j == jb) colk[pb][ty * RI + i] = a[i][j];
-        }
-      }
-      __syncthreads();
-      const double piv = rowk[pb][pc * CJ + jb];  // element (k, k)
-      if (!(fabs(piv) > 1e-300) || !isfinite(piv)) bad |= 1;
-      if ((k0 + KBN * kb + kr) < nspd && !(piv > 0.0)) bad |= 2;
-      const double pinv = pivot_recip(piv);
-      double rk[CJ], ck[RI];
-#pragma unroll
-      for (int j = 0; j < CJ; ++j) rk[j] = rowk[pb][tx * CJ + j] * pinv;
-#pragma unroll
-      for (int i = 0; i < RI; ++i) ck[i] = colk[pb][ty * RI + i];
-      const bool prow = (ty == kr), pcol = (tx == pc);
-#pragma unroll
-      for (int i = 0; i < RI; ++i) {
-#pragma unroll
-        for (int j = 0; j < CJ; ++j) {
-          double v = a[i][j] - ck[i] * rk[j];
-          if (j == jb) v = pcol ? -ck[i] * pinv : v;               // pivot column: -a_ik / a_kk
-          if (i == kb) v = prow ? ((j == jb && pcol) ? pinv : rk[j]) : v;  // pivot row: a_kj / a_kk, corner 1 / a_kk
-          a[i][j] = v;
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < RI; ++i)
-#pragma unroll
-    for (int j = 0; j < CJ; ++j) {
-      const int r = ty + GY * i, c = tx + GX * j;
-      Dinv[r * 128 + c] = a[i][j];
-      DinvT[c * 128 + r] = a[i][j];
-    }
-  if (bad && threadIdx.x == 0) atomicOr(flag, bad);
-  diag_done(flag, k0);
-}
 
 // ------------------------------------------------------------------------------------------------
 // Round 3: the diagonal-block inverse BLOCKED -- 8 sub-steps of 16 pivots instead of 128 barrier-separated rank-1 steps.
@@ -977,7 +518,6 @@ __global__ void __launch_bounds__(256) k_diag_inv_b(const double* __restrict__ T
         DinvT[col * 128 + row] = acc[ai][bi][r];
       }
   if (bad && lane == 0) atomicOr(flag, bad);
-  diag_done(flag, k0);
 }
 
 // Out[j][m] = T[k0+m][j]   (transpose of a 128-row panel; general path)
@@ -1173,238 +713,6 @@ __global__ void __launch_bounds__(256) k_copy_panel_sym(const double* __restrict
     }
     __syncthreads();
   }
-}
-
-// ---- WIDE half sweep (round 5; option "pivot256"): pivot blocks of 256 columns = one read-modify-write of T per TWO 128-blocks -----
-// The half sweep's trailing update streams the whole upper block triangle once per pivot block (N = 8000: 512 MB read + written
-// per step, more than the memory-side cache holds -- tools/update_bench: 140 us of memory time against 105 us of matrix-core time,
-// and the two phases of a tile add).  With 256-wide pivot blocks the same tiles take K = 256 per pass: half the traffic per
-// eliminated column, the same flops.  The algebra is the plain block Gauss-Jordan step with B = 256 (no special tiles beyond the
-// pivot's own rows / columns); the 256 x 256 diagonal block is inverted by a Schur split over two runs of the 128-block kernel
-// (k_loadx256, k_mm128s below).  Panels are [row][PW], PW = 128 np (np = 1: the odd last block).
-
-// column panel of pivot blocks a .. a + np - 1 from the UPPER block triangle (plain symmetry below the pivot: nothing there is swept
-// yet; swept rows above are read in place).  64-row slab x 128-column half per block: grid (Mp / 64, np).
-__global__ void __launch_bounds__(256) k_copy_panel_w(const double* __restrict__ T, long ld, int a, int np, double* __restrict__ P) {
-  __shared__ double tile[64][65];
-  const int PW = 128 * np, r0 = blockIdx.x * 64, cb = a + blockIdx.y, c0 = cb * 128, ib = r0 >> 7;
-  double* Pq = P + (long)r0 * PW + blockIdx.y * 128;
-  if (ib <= cb) {  // stored tile (ib, cb)
-    for (int e = threadIdx.x; e < 64 * 128; e += 256) {
-      const int r = e >> 7, c = e & 127;
-      Pq[(long)r * PW + c] = T[(long)(r0 + r) * ld + c0 + c];
-    }
-    return;
-  }
-  for (int half = 0; half < 2; ++half) {  // transposed read of tile (cb, ib), 64 of the 128 columns at a time
-    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
-      const int c = e >> 6, r = e & 63;
-      tile[c][r] = T[(long)(c0 + half * 64 + c) * ld + r0 + r];
-    }
-    __syncthreads();
-    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
-      const int r = e >> 6, c = e & 63;
-      Pq[(long)r * PW + half * 64 + c] = tile[c][r];
-    }
-    __syncthreads();
-  }
-}
-
-// Out[i][nh 128 + n] = alpha sum_m A[i][m] Bt[nh 128 + n][m], m < PW; RtOut = -sigma_i Out (k_panel with the panel width a parameter).
-// grid (Mp / 32, np), 256 threads.
-__global__ void __launch_bounds__(256, 2)
-k_panel_w(const double* __restrict__ A, const double* __restrict__ Bt, int np, double alpha, double* __restrict__ Out,
-          double* __restrict__ RtOut, int k0) {
-  __shared__ GemmSmemT<32> sm;
-  const int PW = 128 * np, i0 = blockIdx.x * 32, nh = blockIdx.y;
-  d4 acc[1][4];
-#pragma unroll
-  for (int y = 0; y < 4; ++y) acc[0][y] = (d4){0.0, 0.0, 0.0, 0.0};
-  gemm_core<1, 0, 32>(A + (long)i0 * PW, PW, Bt + (long)nh * 128 * PW, PW, 0, PW, acc, sm);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = wave >> 1, wn = wave & 1, lq = lane >> 4, lc = lane & 15;
-#pragma unroll
-  for (int bi = 0; bi < 4; ++bi)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = i0 + wm * 16 + lq + 4 * r;
-      const int n = nh * 128 + wn * 64 + bi * 16 + lc;
-      const double v = alpha * acc[0][bi][r];
-      Out[(long)i * PW + n] = v;
-      RtOut[(long)i * PW + n] = (i < k0) ? v : -v;
-    }
-}
-
-// trailing update + write-back over the upper block triangle, pivot blocks a .. a + np - 1, 8 waves per 128 x 128 tile.
-//   PART 0: every upper tile;  PART 1: the tiles of block columns / rows na .. na + nn - 1 (the NEXT pivot: what its chain reads),
-//   grid nn * nblk;  PART 2: every upper tile outside those.
-// PF (round 5, the default): the block's part of T is loaded into registers BEFORE the K loop, so the epilogue is subtract + store
-// and the read-modify-write no longer adds a memory latency behind the matrix-core phase (with the loads behind the loop the two
-// resident blocks of a CU fall into step and the phases ADD: 54 + 32 us per round of K = 256 tiles).  64 more registers than the 128
-// a wavefront has at 4 per SIMD, hence blocks of FOUR wavefronts on HALF tiles (64 x 128, wave tile 32 x 64, <= 256 VGPRs, two
-// wavefronts per SIMD = two blocks per CU that cover each other's waits); blocks 2 q, 2 q + 1 of an XCD take the halves of a tile.
-template <int PART, bool PF>
-__global__ void __launch_bounds__(PF ? 256 : 512, PF ? 2 : 4)
-k_update_w(double* __restrict__ T, long ld, int nblk, int a, int np, const double* __restrict__ Cold, const double* __restrict__ Cnew,
-           const double* __restrict__ Rt, const double* __restrict__ Dinv, int na, int nn, int rev, double* __restrict__ Pout = nullptr,
-           int skipd = -1) {
-  // Pout (PART 1): the updated block columns / rows of the next pivot are ALSO left as its column panel, P[row][nn 128] (tiles of a
-  // block row go in transposed: below the pivot the matrix is plainly symmetric) -- no copy kernel on the next pivot's chain
-  // skipd (PART 2): the diagonal tile (skipd, skipd) is left out as well (the 128-wide sweep's column part, k_update part 3, takes it)
-  constexpr int BMR = PF ? 64 : 128, NT = PF ? 256 : 512;  // rows / threads of a block
-  __shared__ GemmSmemT<BMR> sm;
-  const int PW = 128 * np;
-  int iblk, jblk, half = 0;
-  if (PART == 1) {
-    const int bx = PF ? blockIdx.x >> 1 : blockIdx.x;
-    half = PF ? blockIdx.x & 1 : 0;
-    const int which = bx / nblk, t = bx % nblk, c = na + which;
-    if (which >= nn) return;
-    if (which > 0 && t >= na && t < c) return;  // tile (t, c) with t an earlier column of the next pivot: listed there as (t, c) already
-    iblk = t <= c ? t : c;
-    jblk = t <= c ? c : t;
-  } else {
-    const long total = (long)nblk * (nblk + 1) / 2, per = (total + 7) / 8;
-    const long x = blockIdx.x % 8;
-    long q = blockIdx.x / 8;
-    if (PF) {
-      half = (int)(q & 1);
-      q >>= 1;
-    }
-    const long cnt = total - x * per < per ? total - x * per : per;
-    if (q >= cnt) return;
-    const long L = x * per + (rev ? cnt - 1 - q : q);
-    jblk = (int)((sqrt(8.0 * (double)L + 1.0) - 1.0) * 0.5);
-    while ((long)jblk * (jblk + 1) / 2 > L) --jblk;
-    while ((long)(jblk + 1) * (jblk + 2) / 2 <= L) ++jblk;
-    iblk = (int)(L - (long)jblk * (jblk + 1) / 2);
-    if (PART == 2 && ((iblk >= na && iblk < na + nn) || (jblk >= na && jblk < na + nn) || (iblk == skipd && jblk == skipd))) return;
-  }
-  const int i0 = iblk * 128 + half * BMR, j0 = jblk * 128, ri = half * BMR;  // ri: the block's first row inside its tile
-  const bool ip = iblk >= a && iblk < a + np, jp = jblk >= a && jblk < a + np;
-  // PART 1: what of this tile the next pivot's column panel holds -- as a tile of block COLUMN jblk (rows i0 ..), as the transpose of a
-  // tile of block ROW iblk (rows j0 ..: only strictly right of the diagonal), or both (the off-diagonal tile of the next pivot itself)
-  const int PWn = 128 * nn;
-  const bool pcol = PART == 1 && jblk >= na && jblk < na + nn, prow = PART == 1 && iblk >= na && iblk < na + nn && jblk > iblk;
-  if (ip || jp) {  // the pivot's own rows / columns: copies of the panels
-    for (int e = threadIdx.x; e < BMR * 128; e += NT) {
-      const int r = e >> 7, c = e & 127;
-      double v;
-      if (ip && jp) v = Dinv[(long)((iblk - a) * 128 + ri + r) * PW + (jblk - a) * 128 + c];
-      else if (jp) v = Cnew[(long)(i0 + r) * PW + (jblk - a) * 128 + c];
-      else v = Rt[(long)(j0 + c) * PW + (iblk - a) * 128 + ri + r];
-      T[(long)(i0 + r) * ld + j0 + c] = v;
-      if (PART == 1 && Pout) {
-        if (pcol) Pout[(long)(i0 + r) * PWn + (jblk - na) * 128 + c] = v;
-        if (prow) Pout[(long)(j0 + c) * PWn + (iblk - na) * 128 + ri + r] = v;
-      }
-    }
-    return;
-  }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = wave >> 1, wn = wave & 1, lq = lane >> 4, lc = lane & 15;
-  auto tile_ptr = [&](int ai) { return T + (long)(i0 + wm * 32 + ai * 16 + lq) * ld + j0 + wn * 64 + lc; };
-  double tv[PF ? 2 : 1][4][4];
-  if (PF) {
-#pragma unroll
-    for (int ai = 0; ai < 2; ++ai) {
-      const double* tp = tile_ptr(ai);
-#pragma unroll
-      for (int bi = 0; bi < 4; ++bi)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) tv[PF ? ai : 0][bi][r] = tp[(long)(4 * r) * ld + bi * 16];
-    }
-  }
-  d4 acc[2][4];
-#pragma unroll
-  for (int x = 0; x < 2; ++x)
-#pragma unroll
-    for (int y = 0; y < 4; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
-  gemm_core<2, 0, BMR>(Cold + (long)i0 * PW, PW, Rt + (long)j0 * PW, PW, 0, PW, acc, sm);
-#pragma unroll
-  for (int ai = 0; ai < 2; ++ai) {
-    double* tp = tile_ptr(ai);
-    if (!PF) {
-#pragma unroll
-      for (int bi = 0; bi < 4; ++bi)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) tv[0][bi][r] = tp[(long)(4 * r) * ld + bi * 16];
-      __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int bi = 0; bi < 4; ++bi)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const double v = tv[PF ? ai : 0][bi][r] - acc[ai][bi][r];
-        tp[(long)(4 * r) * ld + bi * 16] = v;
-        if (PART == 1 && Pout) {
-          const int row = ri + wm * 32 + ai * 16 + lq + 4 * r, cc = wn * 64 + bi * 16 + lc;  // position inside the tile
-          if (pcol) Pout[(long)(iblk * 128 + row) * PWn + (jblk - na) * 128 + cc] = v;
-          if (prow) Pout[(long)(j0 + cc) * PWn + (iblk - na) * 128 + row] = v;
-        }
-      }
-    if (!PF) __builtin_amdgcn_sched_barrier(0);
-  }
-}
-
-// X (256 x 256, row stride 256) = the diagonal block of pivot blocks a, a + 1 as a full symmetric matrix: [A B; B^T C] from the
-// stored tiles (a, a), (a, a + 1), (a + 1, a + 1).  grid 16 (4 x 4 tiles of 64 x 64).
-__global__ void __launch_bounds__(256) k_loadx256(const double* __restrict__ T, long ld, int a, double* __restrict__ X) {
-  __shared__ double tile[64][65];
-  const int bi = blockIdx.x >> 2, bj = blockIdx.x & 3;  // 64 x 64 tile of X
-  const long base = (long)a * 128;
-  const bool lower = (bi >> 1) > (bj >> 1);              // block (1, 0): the transpose of the stored (0, 1)
-  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
-    const int r = e >> 6, c = e & 63;
-    tile[r][c] = lower ? T[(base + bj * 64 + r) * ld + base + bi * 64 + c] : T[(base + bi * 64 + r) * ld + base + bj * 64 + c];
-  }
-  __syncthreads();
-  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
-    const int r = e >> 6, c = e & 63;
-    X[(long)(bi * 64 + r) * 256 + bj * 64 + c] = lower ? tile[c][r] : tile[r][c];
-  }
-}
-
-// Out = Dsrc + alpha A . Bt^T, all 128 x 128 with row strides of their own (Dsrc nullable): k_gemm128's one accumulator stream per
-// wavefront (256 wavefronts, 64 blocks), K tiles from the top down.
-struct Mm128 {
-  const double* A;
-  int lda;
-  const double* Bt;
-  int ldb;
-  double alpha;
-  const double* Dsrc;
-  int ldd;
-  double* Out;
-  int ldo;
-};
-// (grid (64, 2): two independent products in one launch -- every launch of the chain costs 5 - 10 us beside the running update)
-__global__ void __launch_bounds__(256) k_mm128s(Mm128 p0, Mm128 p1) {
-  const Mm128& p = blockIdx.y ? p1 : p0;
-  const double* __restrict__ A = p.A;
-  const double* __restrict__ Bt = p.Bt;
-  const double* __restrict__ Dsrc = p.Dsrc;
-  double* __restrict__ Out = p.Out;
-  const int lda = p.lda, ldb = p.ldb, ldd = p.ldd, ldo = p.ldo;
-  const double alpha = p.alpha;
-  const int lane = threadIdx.x & 63, w = blockIdx.x * 4 + (threadIdx.x >> 6);  // 0 .. 255
-  const int R = w >> 3, Cg = w & 7, kq = lane >> 4;
-  const double* ap = A + (long)(4 * R + (lane & 3)) * lda + 2 * kq;
-  const double* bp = Bt + (long)(16 * Cg + (lane & 15)) * ldb + 2 * kq;
-  double2 fa[16], fb[16];
-#pragma unroll
-  for (int t = 0; t < 16; ++t) {
-    fa[t] = *reinterpret_cast<const double2*>(ap + 8 * t);
-    fb[t] = *reinterpret_cast<const double2*>(bp + 8 * t);
-  }
-  double acc = 0.0;
-#pragma unroll
-  for (int t = 15; t >= 0; --t) {
-    acc = __builtin_amdgcn_mfma_f64_4x4x4f64(fa[t].x, fb[t].x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f64_4x4x4f64(fa[t].y, fb[t].y, acc, 0, 0, 0);
-  }
-  const int row = 4 * R + (lane >> 4), col = 16 * Cg + (lane & 15);
-  Out[(long)row * ldo + col] = (Dsrc ? Dsrc[(long)row * ldd + col] : 0.0) + alpha * acc;
 }
 
 // after the symmetric sweep every block is swept: T is symmetric, fill the lower block triangle from the upper one

@@ -354,164 +354,6 @@ k_contract(const double* __restrict__ Ainv, long lda, const double* __restrict__
   }  // for (;;): next tile of this XCD's sequence
 }
 
-// ------------------------------------------------------------------------------------------------
-// K3b, VALU engine.  On gfx950 the fp64 vector FMA pipe sustains more than the fp64 matrix pipe
-// (tools/ubench_f64.hip, profiles/: v_fma_f64 64-72 TFLOP/s at 2-8 waves/SIMD vs 47-49 for
-// v_mfma_f64_16x16x4_f64), so the same contraction is also available as a classic register-tiled
-// FMA kernel: 256 threads as 16 x 16, each owning an 8 x 8 micro-tile of the 128 x 128 block tile,
-// interleaved in 16-byte chunks (rows ty*2 + 32a + {0,1}, columns tx*2 + 32b + {0,1}) so every
-// fragment read is a conflict-free ds_read_b128.  LDS holds the K tile TRANSPOSED (k-major):
-// As[k][i], Bs[k][t]; global -> LDS staging is one row per lane (conflict-free ds_write_b64).
-// Per k step and thread: 8 ds_read_b128 feed 64 v_fma_f64.
-// ------------------------------------------------------------------------------------------------
-#define MIK_VS 128  // LDS row stride (doubles) of the k-major tiles
-struct ValuSmem {  // one spare k row per tile: the register pipeline reads one row past the end (never used)
-  double As[2][MIK_BK + 1][MIK_VS];
-  double Bs[2][MIK_BK + 1][MIK_VS];
-};
-
-__device__ __forceinline__ void valu_core(const double* __restrict__ Ag, long lda, const double* __restrict__ Bg,
-                                          long ldb, int kbeg, int kend, double (&acc)[8][8], ValuSmem& sm) {
-  if (kbeg >= kend) return;  // block-uniform
-  const int tid = threadIdx.x;
-  const int tx = tid & 15, ty = tid >> 4;
-  const int srow = tid & 127, sk = (tid >> 7) * 8;  // staging: row srow, k offsets sk .. sk+7
-  const double* ap = Ag + (long)srow * lda + sk;
-  const double* bp = Bg + (long)srow * ldb + sk;
-  double2 ra[4], rb[4];
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    ra[p] = *reinterpret_cast<const double2*>(ap + kbeg + 2 * p);
-    rb[p] = *reinterpret_cast<const double2*>(bp + kbeg + 2 * p);
-  }
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    sm.As[0][sk + 2 * p][srow] = ra[p].x;
-    sm.As[0][sk + 2 * p + 1][srow] = ra[p].y;
-    sm.Bs[0][sk + 2 * p][srow] = rb[p].x;
-    sm.Bs[0][sk + 2 * p + 1][srow] = rb[p].y;
-  }
-  __syncthreads();
-  int buf = 0;
-  for (int k = kbeg; k < kend; k += MIK_BK) {
-    const bool more = (k + MIK_BK) < kend;
-    if (more) {
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        ra[p] = *reinterpret_cast<const double2*>(ap + k + MIK_BK + 2 * p);
-        rb[p] = *reinterpret_cast<const double2*>(bp + k + MIK_BK + 2 * p);
-      }
-    }
-    {
-      // fragments double-buffered in registers: the reads of step kk+1 are in flight behind the 64 FMAs of step kk
-      const double* asrc = &sm.As[buf][0][ty * 2];
-      const double* bsrc = &sm.Bs[buf][0][tx * 2];
-      double2 a0[4], b0[4], a1[4], b1[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        a0[c] = *reinterpret_cast<const double2*>(asrc + 32 * c);
-        b0[c] = *reinterpret_cast<const double2*>(bsrc + 32 * c);
-      }
-#pragma unroll 1
-      for (int kk = 0; kk < MIK_BK; kk += 2) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          a1[c] = *reinterpret_cast<const double2*>(asrc + (kk + 1) * MIK_VS + 32 * c);
-          b1[c] = *reinterpret_cast<const double2*>(bsrc + (kk + 1) * MIK_VS + 32 * c);
-        }
-#pragma unroll
-        for (int x = 0; x < 8; ++x)
-#pragma unroll
-          for (int y = 0; y < 8; ++y)
-            acc[x][y] = __builtin_fma((x & 1) ? a0[x >> 1].y : a0[x >> 1].x, (y & 1) ? b0[y >> 1].y : b0[y >> 1].x, acc[x][y]);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {  // kk + 2 == MIK_BK reads the spare row; those values are discarded
-          a0[c] = *reinterpret_cast<const double2*>(asrc + (kk + 2) * MIK_VS + 32 * c);
-          b0[c] = *reinterpret_cast<const double2*>(bsrc + (kk + 2) * MIK_VS + 32 * c);
-        }
-#pragma unroll
-        for (int x = 0; x < 8; ++x)
-#pragma unroll
-          for (int y = 0; y < 8; ++y)
-            acc[x][y] = __builtin_fma((x & 1) ? a1[x >> 1].y : a1[x >> 1].x, (y & 1) ? b1[y >> 1].y : b1[y >> 1].x, acc[x][y]);
-      }
-    }
-    if (more) {
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        sm.As[buf ^ 1][sk + 2 * p][srow] = ra[p].x;
-        sm.As[buf ^ 1][sk + 2 * p + 1][srow] = ra[p].y;
-        sm.Bs[buf ^ 1][sk + 2 * p][srow] = rb[p].x;
-        sm.Bs[buf ^ 1][sk + 2 * p + 1][srow] = rb[p].y;
-      }
-    }
-    __syncthreads();
-    buf ^= 1;
-  }
-}
-
-template <bool SYM>
-__global__ void __launch_bounds__(256, 2)
-k_contract_valu(const double* __restrict__ Ainv, long lda, const double* __restrict__ Bt, long ldb,
-                double* __restrict__ part, int palloc, int nIblk, int kend) {
-  __shared__ ValuSmem sm;
-  const long L = xcd_tile((long)nIblk * (palloc / MIK_BN));
-  if (L < 0) return;
-  const int iblk = (int)(L % nIblk), tblk = (int)(L / nIblk);
-  const int i0 = iblk * MIK_BM, t0 = tblk * MIK_BN;
-  double acc[8][8];
-#pragma unroll
-  for (int x = 0; x < 8; ++x)
-#pragma unroll
-    for (int y = 0; y < 8; ++y) acc[x][y] = 0.0;
-  const double* Ag = Ainv + (long)i0 * lda;
-  const double* Bg = Bt + (long)t0 * ldb;
-  if (SYM) {
-    const int kd = (i0 + MIK_BM) < kend ? (i0 + MIK_BM) : kend;
-    valu_core(Ag, lda, Bg, ldb, i0, kd, acc, sm);
-#pragma unroll
-    for (int x = 0; x < 8; ++x)
-#pragma unroll
-      for (int y = 0; y < 8; ++y) acc[x][y] *= 0.5;
-    valu_core(Ag, lda, Bg, ldb, i0 + MIK_BM, kend, acc, sm);
-  } else {
-    valu_core(Ag, lda, Bg, ldb, 0, kend, acc, sm);
-  }
-  // epilogue: thread (ty,tx) holds rows i0 + ty*2 + 32*(x>>1) + (x&1), columns t0 + tx*2 + 32*(y>>1) + (y&1)
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-  double* red = &sm.As[0][0][0];  // 16 x 128 doubles, free after the core's final barrier
-#pragma unroll
-  for (int yp = 0; yp < 2; ++yp) {
-    double2 bv[4][4];
-#pragma unroll
-    for (int y4 = 0; y4 < 4; ++y4) {
-      const int y = 4 * yp + y4;
-      const int tc = tx * 2 + 32 * (y >> 1) + (y & 1);
-      const double* brow = Bt + (long)(t0 + tc) * ldb + i0 + ty * 2;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) bv[y4][c] = *reinterpret_cast<const double2*>(brow + 32 * c);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int y4 = 0; y4 < 4; ++y4) {
-      const int y = 4 * yp + y4;
-      const int tc = tx * 2 + 32 * (y >> 1) + (y & 1);
-      double s = 0.0;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) s += bv[y4][c].x * acc[2 * c][y] + bv[y4][c].y * acc[2 * c + 1][y];
-      red[ty * 128 + tc] = s;
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  __syncthreads();
-  if (threadIdx.x < 128) {
-    double v = 0.0;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) v += red[r * 128 + threadIdx.x];
-    part[(long)iblk * palloc + t0 + threadIdx.x] = SYM ? 2.0 * v : v;
-  }
-}
-
 // ss[t] = -sum_iblk part[iblk][t]   (ok.py:681: sigmasq = sum(x * -b))
 __global__ void __launch_bounds__(256) k_ss_reduce(const double* __restrict__ part, int palloc, int nIblk, int nvalid,
                                                    double* __restrict__ ss) {

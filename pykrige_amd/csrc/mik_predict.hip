@@ -55,7 +55,7 @@ int one_predict(mik_handle* h) {
   h->tm.contract_launches = 0;
   h->tm.contract_flops_executed = 0.0;
   h->tm.symmetric = h->opt_sym;
-  h->tm.engine = h->opt_engine;
+  h->tm.engine = 0;  // (the v_fma_f64 contraction left the library in round 6: tools/kernel_bench)
   h->tm.mw_kernel = 0;
   if (npt == 0) {
     h->have_results = true;
@@ -64,14 +64,16 @@ int one_predict(mik_handle* h) {
   long chunk = std::min<long>(h->opt_chunk, ((npt + 127) / 128) * 128);
   if (h->model == MIK_MODEL_CUSTOM) chunk = std::min<long>(chunk, 16384);  // each chunk's distances visit the host
   // range-aware contraction (k_contract_sp): the factor is in Hilbert-curve station order and the variogram has compact support
-  const bool sparse = h->factor_sorted && h->opt_sparse != 2 && h->opt_sparse != 0 && h->opt_engine == 0;
+  const bool sparse = h->factor_sorted && h->opt_sparse != 2 && h->opt_sparse != 0;
   if (sparse) chunk = std::min<long>(chunk, 131072);  // k_sp_tiles: at most 1024 point blocks per launch
   const int nK16 = Mp / 16;
   // tiles of gathered 16-row groups (k_contract_spg) wherever 32-bit LDS-DMA offsets reach every row of the inverse
   const bool gathered = sparse && h->opt_sparse_rows != 128 && (double)Mp * (double)Mp * 8.0 < 4294967296.0;
-  // "sparse_ktile" 8 (round 5; with gathered row groups only): flags and lists per 8 stations (candidates stay per 16), a K step = a pair of list-adjacent
-  // 8-station tiles (k_contract_spg H8).  nKt = tiles per point block in the units of this launch's lists.
-  const bool h8 = gathered && h->opt_sparse_ktile == 8;
+  // gathered row groups (round 5): flags and lists per 8 stations (candidates stay per 16), a K step = a pair of list-adjacent 8-station tiles
+  // (k_contract_spg H8); the aligned-block fallback keeps 16-station lists.  nKt = tiles per point block in the units of this launch's lists.
+  // (Round 4's 16-station lists under gathered groups and the epilogue from global memory -- "sparse_ktile" 16, "sparse_epilogue" 0 -- lost
+  // their A/B in round 5 and left the library in round 6.)
+  const bool h8 = gathered;
   const int nKt = h8 ? Mp / 8 : nK16;
   h->tm.sparse_ktile = !sparse ? 0 : h8 ? 8 : 16;
   h->tm.sparse = sparse ? 1 : 0;
@@ -266,14 +268,9 @@ int one_predict(mik_handle* h) {
       if (gathered) {
         hipLaunchKernelGGL(k_sp_lists_g, dim3(nTb), dim3(64), 0, sc, (const unsigned char*)ln.flags->as<unsigned char>(), nKt,
                            ln.klist->as<unsigned short>(), ln.kcount->as<int>(), ln.nrows->as<int>(), h8 ? 1 : 0);
-        if (h8)
-          hipLaunchKernelGGL(k_sp_tiles_g<true>, dim3(1), dim3(1024), 0, sc, (const int*)ln.nrows->as<int>(), (const int*)ln.kcount->as<int>(),
-                             (const unsigned short*)ln.klist->as<unsigned short>(), nKt, nTb, ln.recs->as<uint4>(), ln.xoff->as<int>(),
-                             h->sp_stats.as<unsigned long long>() + 4 * c, h->opt_sparse_group);
-        else
-          hipLaunchKernelGGL(k_sp_tiles_g<false>, dim3(1), dim3(1024), 0, sc, (const int*)ln.nrows->as<int>(), (const int*)ln.kcount->as<int>(),
-                             (const unsigned short*)ln.klist->as<unsigned short>(), nK16, nTb, ln.recs->as<uint4>(), ln.xoff->as<int>(),
-                             h->sp_stats.as<unsigned long long>() + 4 * c, h->opt_sparse_group);
+        hipLaunchKernelGGL(k_sp_tiles_g<true>, dim3(1), dim3(1024), 0, sc, (const int*)ln.nrows->as<int>(), (const int*)ln.kcount->as<int>(),
+                           (const unsigned short*)ln.klist->as<unsigned short>(), nKt, nTb, ln.recs->as<uint4>(), ln.xoff->as<int>(),
+                           h->sp_stats.as<unsigned long long>() + 4 * c, h->opt_sparse_group);
       } else {
         hipLaunchKernelGGL(k_sp_lists, dim3(nTb), dim3(64), 0, sc, (const unsigned char*)ln.flags->as<unsigned char>(), nK16, nIblk,
                            ln.klist->as<unsigned short>(), ln.kcount->as<int>(), ln.rows->as<unsigned short>(),
@@ -316,7 +313,7 @@ int one_predict(mik_handle* h) {
         ga.xoff = sa.xoff;
         ga.queue = sa.queue;
         static const bool spg_prof = getenv("MIK_SPG_PROF") && atoi(getenv("MIK_SPG_PROF")) != 0;
-        if (spg_prof && h8 && h->opt_sparse_epi) {  // diagnostic (MIK_SPG_PROF=1): cycle sums per phase of the tile loop, one launch, printed to stderr
+        if (spg_prof) {  // diagnostic (MIK_SPG_PROF=1): cycle sums per phase of the tile loop, one launch, printed to stderr
           const unsigned nb = (unsigned)std::min<long>(2L * h->n_cu, (long)nTb * nIblk);
           static DevBuf pb;
           MIKC(pb.ensure(sizeof(unsigned long long) * nb * 96));
@@ -346,9 +343,7 @@ int one_predict(mik_handle* h) {
             fprintf(stderr, "   per off-diagonal step %.0f cycles\n", sum[1] / std::max(1.0, sum[9]));
           }
         } else
-        if (h8 && h->opt_sparse_epi) hipLaunchKernelGGL((k_contract_spg<2, true, true>), dim3((unsigned)std::min<long>(2L * h->n_cu, (long)nTb * nIblk)), dim3(512), 0, sc, ga);
-        else if (h8) hipLaunchKernelGGL((k_contract_spg<2, false, true>), dim3((unsigned)std::min<long>(2L * h->n_cu, (long)nTb * nIblk)), dim3(512), 0, sc, ga);
-        else hipLaunchKernelGGL((k_contract_spg<2, false>), dim3((unsigned)std::min<long>(2L * h->n_cu, (long)nTb * nIblk)), dim3(512), 0, sc, ga);
+        hipLaunchKernelGGL((k_contract_spg<2, true, true>), dim3((unsigned)std::min<long>(2L * h->n_cu, (long)nTb * nIblk)), dim3(512), 0, sc, ga);
       } else {
         hipLaunchKernelGGL((k_contract_sp<2>), dim3((unsigned)std::min<long>(2L * h->n_cu, (long)nTb * nIblk)), dim3(512), 0, sc, sa);
       }
@@ -376,27 +371,17 @@ int one_predict(mik_handle* h) {
       double* pp = h->part.as<double>();
       const long ldm = Mp;
       const unsigned sgrid = (unsigned)super_grid(nIblk, palloc / 128);
-      if (h->opt_engine == 1) {
-        if (h->opt_sym) hipLaunchKernelGGL(k_contract_valu<true>, dim3(grid), dim3(256), 0, sc, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend);
-        else hipLaunchKernelGGL(k_contract_valu<false>, dim3(grid), dim3(256), 0, sc, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend);
-      } else {
-        // persistent launch: 2 blocks per CU pop tiles from per-XCD sequences (8 counters, zeroed per launch)
-        MIKC(h->queue.ensure(8 * sizeof(unsigned long long)));
-        HIPC(hipMemsetAsync(h->queue.p, 0, 8 * sizeof(unsigned long long), sc));
-        unsigned long long* qp = h->queue.as<unsigned long long>();
-        const unsigned pgrid = (unsigned)std::min<long>(2L * h->n_cu, (long)sgrid);
-        // (round 5: the pair units, the popped-ahead tile and the LDS epilogue of the range-aware form -- options "pairs", "prefetch",
-        // "sparse_epilogue", every A/B of rounds 2-4 lost -- are no longer built into the library; tools/kernel_bench still times them)
-        if (h->opt_waves == 8) {
-          if (false) {}
-          else if (h->opt_sym && h->opt_tri) hipLaunchKernelGGL((k_contract<true, 2, true, false, true>), dim3(pgrid), dim3(512), 0, sc, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend, qp);
-          else if (h->opt_sym) hipLaunchKernelGGL((k_contract<true, 2>), dim3(pgrid), dim3(512), 0, sc, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend, qp);
-          else hipLaunchKernelGGL((k_contract<false, 2>), dim3(pgrid), dim3(512), 0, sc, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend, qp);
-        } else {
-          if (h->opt_sym) hipLaunchKernelGGL((k_contract<true, 4>), dim3(pgrid), dim3(256), 0, sc, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend, qp);
-          else hipLaunchKernelGGL((k_contract<false, 4>), dim3(pgrid), dim3(256), 0, sc, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend, qp);
-        }
-      }
+      // persistent launch: 2 blocks per CU pop tiles from per-XCD sequences (8 counters, zeroed per launch); 8 wavefronts per tile
+      // (wave tile 32 x 64).  Three forms: the symmetric half product with triangular diagonal blocks (default), with whole
+      // diagonal blocks ("tri" 0) and the reference's full product w = A_inv b ("symmetric" 0) -- the cross-checks of the parity tests.
+      // (The 4-wave tiles, the v_fma_f64 engine, pair units, popped-ahead tiles: every A/B of rounds 2-5 lost; tools/kernel_bench.)
+      MIKC(h->queue.ensure(8 * sizeof(unsigned long long)));
+      HIPC(hipMemsetAsync(h->queue.p, 0, 8 * sizeof(unsigned long long), sc));
+      unsigned long long* qp = h->queue.as<unsigned long long>();
+      const unsigned pgrid = (unsigned)std::min<long>(2L * h->n_cu, (long)sgrid);
+      if (h->opt_sym && h->opt_tri) hipLaunchKernelGGL((k_contract<true, 2, true, false, true>), dim3(pgrid), dim3(512), 0, sc, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend, qp);
+      else if (h->opt_sym) hipLaunchKernelGGL((k_contract<true, 2>), dim3(pgrid), dim3(512), 0, sc, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend, qp);
+      else hipLaunchKernelGGL((k_contract<false, 2>), dim3(pgrid), dim3(512), 0, sc, Ai, ldm, Bi, ldm, pp, palloc, nIblk, kend, qp);
     }
     HIPC(hipEventRecord(e2, sc));
     if (two) HIPC(hipEventRecord(h->pr_events[2 * c + 1], sc));
@@ -411,7 +396,7 @@ int one_predict(mik_handle* h) {
                         hipMemcpyDeviceToHost, h->stream_d2h));
     // executed flops of this launch: per tile 2*128*128*(k extent)
     // (triangular diagonal blocks: nt (nt + 1) / 2 products of 16 rows x 16 k instead of 8 nt, nt = K tiles of the block)
-    const bool tri = h->opt_engine != 1 && h->opt_waves == 8 && h->opt_sym && h->opt_tri;
+    const bool tri = h->opt_sym && h->opt_tri;
     double kext = 0.0;
     for (int ib = 0; ib < nIblk; ++ib) {
       const int ext = h->opt_sym ? std::max(0, kend - ib * 128) : kend;

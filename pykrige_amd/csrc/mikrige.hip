@@ -46,10 +46,6 @@ static int create_one_body(mik_handle* h, int device) {
   if (env) h->opt_factor = !strcmp(env, "sweep") ? 1 : (!strcmp(env, "lu") || !strcmp(env, "pivoted")) ? 2 : 0;
   env = getenv("MIK_SYMMETRIC");
   if (env) h->opt_sym = atoi(env) ? 1 : 0;
-  env = getenv("MIK_ENGINE");
-  if (env) h->opt_engine = (!strcmp(env, "valu") || !strcmp(env, "1")) ? 1 : 0;
-  env = getenv("MIK_WAVES");
-  if (env && (atoi(env) == 4 || atoi(env) == 8)) h->opt_waves = atoi(env);
   env = getenv("MIK_CHUNK");
   if (env && atol(env) >= 128) h->opt_chunk = (atol(env) / 128) * 128;
   env = getenv("MIK_SYMSWEEP");
@@ -60,20 +56,10 @@ static int create_one_body(mik_handle* h, int device) {
   if (env && atoi(env) >= -1 && atoi(env) <= 1) h->opt_sort_points = atoi(env);
   env = getenv("MIK_SPARSE_GROUP");
   if (env && atoi(env) >= 1 && atoi(env) <= 16) h->opt_sparse_group = atoi(env);
-  env = getenv("MIK_SPARSE_KTILE");
-  if (env) h->opt_sparse_ktile = atoi(env) == 16 ? 16 : 8;
   env = getenv("MIK_SPARSE_ROWS");
   if (env && (atoi(env) == -1 || atoi(env) == 16 || atoi(env) == 128)) h->opt_sparse_rows = atoi(env);
   env = getenv("MIK_UPDATE_REV");
   if (env) h->opt_update_rev = atoi(env) < 0 ? -1 : atoi(env) ? 1 : 0;
-  env = getenv("MIK_UPDATE_MAP");
-  if (env) h->opt_update_map = atoi(env);
-  env = getenv("MIK_PIVOT256");
-  if (env) h->opt_pivot256 = atoi(env) < 0 ? -1 : atoi(env) ? 1 : 0;
-  env = getenv("MIK_UPDATE_DEEP");
-  if (env) h->opt_update_deep = atoi(env) < 0 ? -1 : atoi(env) ? 1 : 0;
-  env = getenv("MIK_UPDATE_TPB");
-  if (env) h->opt_update_tpb = std::max(0, std::min(64, atoi(env)));
   env = getenv("MIK_PANEL_STREAM");
   if (env) h->opt_panel_stream = atoi(env) < 0 ? -1 : atoi(env) ? 1 : 0;
   env = getenv("MIK_TRI");
@@ -82,12 +68,6 @@ static int create_one_body(mik_handle* h, int device) {
   if (env) h->opt_exchange = !strcmp(env, "rccl") ? 1 : !strcmp(env, "peer") ? 2 : !strcmp(env, "redundant") ? 3 : 0;
   env = getenv("MIK_ALIAS_DEVICES");
   if (env) h->alias_ok = atoi(env) != 0;
-  env = getenv("MIK_EARLY_DIAG");
-  if (env) h->opt_early_diag = atoi(env) < 0 ? -1 : atoi(env);
-  env = getenv("MIK_UPDATE_WAVES");
-  if (env && (atoi(env) == 4 || atoi(env) == 8)) h->opt_update_waves = atoi(env);
-  env = getenv("MIK_PANEL_ROWS");
-  if (env && (atoi(env) == 32 || atoi(env) == 64 || atoi(env) == 128)) h->opt_panel_rows = atoi(env);
   env = getenv("MIK_RHS_OVERLAP");
   if (env) h->opt_rhs_overlap = atoi(env) ? 1 : 0;
   env = getenv("MIK_ASYNC_EXCHANGE");
@@ -128,7 +108,7 @@ static void destroy_one(mik_handle* h) {
   h->xsum.release();
   DevBuf* bufs[] = {&h->xs, &h->ys, &h->zs, &h->vals, &h->wells, &h->extra_cols, &h->T, &h->cvec, &h->Cold, &h->Cnew,
                     &h->Rt, &h->TKt, &h->Dinv, &h->DinvT, &h->P0, &h->P1, &h->cand0, &h->cand1, &h->pivall, &h->flag,
-                    &h->Cold2, &h->Cnew2, &h->Rt2, &h->Dinv2, &h->DinvT2, &h->Dinv3, &h->DinvT3, &h->tilemap, &h->Dnext, &h->Dcopy, &h->Cb, &h->Rb, &h->grid.gx, &h->grid.gy, &h->grid.gz, &h->grid.orig,
+                    &h->Cold2, &h->Cnew2, &h->Rt2, &h->Dinv2, &h->DinvT2, &h->Dinv3, &h->DinvT3, &h->Dnext, &h->Dcopy, &h->Rb, &h->grid.gx, &h->grid.gy, &h->grid.gz, &h->grid.orig,
                     &h->grid.cstart,
                     &h->px, &h->py, &h->pz, &h->grid_axes, &h->grid_idx, &h->Averify, &h->vbuf, &h->extra_rows, &h->z, &h->ss, &h->Bt, &h->Bt2, &h->part, &h->mw_idx, &h->mw_dist, &h->stat_S, &h->stat_x, &h->stat_out, &h->queue,
                     &h->xs_s, &h->ys_s, &h->zs_s, &h->vals_s, &h->extra_cols_s, &h->sbox, &h->sp_cand, &h->sp_flags, &h->sp_klist, &h->sp_kcount,
@@ -148,7 +128,6 @@ static void destroy_one(mik_handle* h) {
   if (h->stream_d2h) (void)hipStreamDestroy(h->stream_d2h);
   if (h->stream2) (void)hipStreamDestroy(h->stream2);
   if (h->stream3) (void)hipStreamDestroy(h->stream3);
-  if (h->stream_upd) (void)hipStreamDestroy(h->stream_upd);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -201,10 +180,10 @@ static int set_group(mik_handle* h, int n) {
       return rc;
     }
     k->is_kid = true;
-    k->opt_factor = h->opt_factor, k->opt_sym = h->opt_sym, k->opt_engine = h->opt_engine, k->opt_waves = h->opt_waves;
-    k->opt_chunk = h->opt_chunk, k->opt_symsweep = h->opt_symsweep, k->opt_diag = h->opt_diag, k->opt_update_waves = h->opt_update_waves, k->opt_panel_rows = h->opt_panel_rows, k->opt_panel_stream = h->opt_panel_stream, k->opt_update_map = h->opt_update_map, k->opt_update_rev = h->opt_update_rev, k->opt_update_deep = h->opt_update_deep, k->opt_pivot256 = h->opt_pivot256, k->opt_update_token = h->opt_update_token, k->opt_update_pf = h->opt_update_pf, k->opt_wide_reserve = h->opt_wide_reserve, k->opt_update_tpb = h->opt_update_tpb, k->opt_lookahead = h->opt_lookahead, k->opt_gate = h->opt_gate, k->opt_fuse_chain = h->opt_fuse_chain, k->opt_early_diag = h->opt_early_diag, k->opt_pinv_fast = h->opt_pinv_fast, k->opt_rhs_overlap = h->opt_rhs_overlap, k->opt_verify = h->opt_verify, k->verify_tol_z = h->verify_tol_z, k->verify_tol_inv = h->verify_tol_inv;
+    k->opt_factor = h->opt_factor, k->opt_sym = h->opt_sym;
+    k->opt_chunk = h->opt_chunk, k->opt_symsweep = h->opt_symsweep, k->opt_panel_stream = h->opt_panel_stream, k->opt_update_rev = h->opt_update_rev, k->opt_lookahead = h->opt_lookahead, k->opt_gate = h->opt_gate, k->opt_pinv_fast = h->opt_pinv_fast, k->opt_rhs_overlap = h->opt_rhs_overlap, k->opt_verify = h->opt_verify, k->verify_tol_z = h->verify_tol_z, k->verify_tol_inv = h->verify_tol_inv;
     k->opt_mw_class = h->opt_mw_class, k->opt_mw_knn_bound = h->opt_mw_knn_bound, k->opt_mw_pivot = h->opt_mw_pivot, k->opt_mw_lds_cap = h->opt_mw_lds_cap, k->opt_tri = h->opt_tri, k->opt_symmetrize = h->opt_symmetrize, k->opt_mw_solver = h->opt_mw_solver;
-    k->opt_sparse = h->opt_sparse, k->opt_sparse_lanes = h->opt_sparse_lanes, k->opt_sparse_rows = h->opt_sparse_rows, k->opt_sparse_ktile = h->opt_sparse_ktile, k->opt_sparse_epi = h->opt_sparse_epi, k->opt_sparse_group = h->opt_sparse_group, k->opt_sort_points = h->opt_sort_points, k->opt_drift_eq = h->opt_drift_eq;
+    k->opt_sparse = h->opt_sparse, k->opt_sparse_lanes = h->opt_sparse_lanes, k->opt_sparse_rows = h->opt_sparse_rows, k->opt_sparse_group = h->opt_sparse_group, k->opt_sort_points = h->opt_sort_points, k->opt_drift_eq = h->opt_drift_eq;
     k->opt_pinv_block = h->opt_pinv_block, k->opt_mw_static = h->opt_mw_static, k->opt_mw_knn_lane = h->opt_mw_knn_lane;
     k->custom_fn = h->custom_fn, k->custom_user = h->custom_user;
     h->kids.push_back(k);
@@ -283,21 +262,12 @@ int mik_set_option(mik_handle* h, const char* key, double value) {
     h->opt_factor = (int)value;
   } else if (!strcmp(key, "symmetric")) {
     h->opt_sym = value != 0.0;
-  } else if (!strcmp(key, "engine")) {
-    if (value != 0.0 && value != 1.0) return fail(MIK_EINVAL, "engine must be 0 (mfma) or 1 (valu)");
-    h->opt_engine = (int)value;
   } else if (!strcmp(key, "sparse")) {
     if (value != -1.0 && value != 0.0 && value != 1.0 && value != 2.0) return fail(MIK_EINVAL, "sparse must be -1 (auto), 0, 1 or 2");
     h->opt_sparse = (int)value;
   } else if (!strcmp(key, "sort_points")) {
     if (value != -1.0 && value != 0.0 && value != 1.0) return fail(MIK_EINVAL, "sort_points must be -1 (auto), 0 or 1");
     h->opt_sort_points = (int)value;
-  } else if (!strcmp(key, "sparse_ktile")) {
-    if (value != 8.0 && value != 16.0) return fail(MIK_EINVAL, "sparse_ktile: 16 or 8 stations");
-    h->opt_sparse_ktile = (int)value;
-  } else if (!strcmp(key, "sparse_epilogue")) {
-    if (value != 0.0 && value != 1.0) return fail(MIK_EINVAL, "sparse_epilogue: 0 or 1");
-    h->opt_sparse_epi = (int)value;
   } else if (!strcmp(key, "sparse_group")) {
     if (!(value >= 1.0 && value <= 16.0)) return fail(MIK_EINVAL, "sparse_group must be 1 .. 16");
     h->opt_sparse_group = (int)value;
@@ -313,9 +283,6 @@ int mik_set_option(mik_handle* h, const char* key, double value) {
     h->opt_tri = value != 0.0;
   } else if (!strcmp(key, "symmetrize")) {
     h->opt_symmetrize = value != 0.0;
-  } else if (!strcmp(key, "waves")) {
-    if (value != 4.0 && value != 8.0) return fail(MIK_EINVAL, "waves must be 4 or 8");
-    h->opt_waves = (int)value;
   } else if (!strcmp(key, "chunk")) {
     if (value < 128) return fail(MIK_EINVAL, "chunk must be >= 128");
     h->opt_chunk = ((long)value / 128) * 128;
@@ -332,42 +299,12 @@ int mik_set_option(mik_handle* h, const char* key, double value) {
     h->opt_pinv_fast = value != 0.0;
   } else if (!strcmp(key, "pinv_block")) {
     h->opt_pinv_block = value < 0.0 ? -1 : (value != 0.0);
-  } else if (!strcmp(key, "fuse_chain")) {
-    h->opt_fuse_chain = value != 0.0;
-  } else if (!strcmp(key, "early_diag")) {
-    h->opt_early_diag = value < 0.0 ? -1 : (int)value;  // 1 / 3 = on (streams ordered by events), 2 = with the one-block tile kernels, 4 / 5 = ordered by flags (both sides / update stream only)
   } else if (!strcmp(key, "gate")) {
     h->opt_gate = value < 0.0 ? -1 : (value != 0.0);
-  } else if (!strcmp(key, "update_waves")) {
-    if (value != 4.0 && value != 8.0) return fail(MIK_EINVAL, "update_waves must be 4 or 8");
-    h->opt_update_waves = (int)value;
   } else if (!strcmp(key, "update_rev")) {
     h->opt_update_rev = value < 0.0 ? -1 : value != 0.0 ? 1 : 0;
-  } else if (!strcmp(key, "update_map")) {
-    h->opt_update_map = (int)value;
-  } else if (!strcmp(key, "pivot256")) {
-    h->opt_pivot256 = value < 0.0 ? -1 : (value != 0.0);
-  } else if (!strcmp(key, "update_token")) {
-    h->opt_update_token = value != 0.0;
-  } else if (!strcmp(key, "update_pf")) {
-    h->opt_update_pf = value != 0.0;
-  } else if (!strcmp(key, "wide_colstream")) {
-    h->opt_wide_colstream = value != 0.0;
-  } else if (!strcmp(key, "wide_reserve")) {
-    if (value < 0.0 || value > 128.0) return fail(MIK_EINVAL, "wide_reserve: 0 .. 128 CUs");
-    h->opt_wide_reserve = (int)value;
-  } else if (!strcmp(key, "update_deep")) {
-    h->opt_update_deep = value < 0.0 ? -1 : (value != 0.0);
-  } else if (!strcmp(key, "update_tpb")) {
-    if (value < 0.0 || value > 64.0) return fail(MIK_EINVAL, "update_tpb: 0 (auto) .. 64 tiles per block");
-    h->opt_update_tpb = (int)value;
   } else if (!strcmp(key, "panel_stream")) {
     h->opt_panel_stream = value < 0.0 ? -1 : (value != 0.0);
-  } else if (!strcmp(key, "panel_rows")) {
-    if (value != 32.0 && value != 64.0 && value != 128.0) return fail(MIK_EINVAL, "panel_rows must be 32, 64 or 128");
-    h->opt_panel_rows = (int)value;
-  } else if (!strcmp(key, "diag")) {
-    h->opt_diag = (int)value;
   } else if (!strcmp(key, "lookahead")) {
     h->opt_lookahead = value < 0.0 ? -1 : (value != 0.0);
   } else if (!strcmp(key, "mw_solver")) {

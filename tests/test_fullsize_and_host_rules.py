@@ -143,7 +143,7 @@ def test_update_variogram_model_signatures_are_the_references():
 
 # ------------------------------------------------------------------------------------------- GPU
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", ["default", "full_sweep", "half_sweep", "pivoted", "wide_sweep"])
+@pytest.mark.parametrize("variant", ["default", "full_sweep", "half_sweep", "pivoted"])
 @pytest.mark.parametrize("name", CASES)
 def test_hip_matches_the_reference_on_a_full_size_slab(name, variant):
     g = _full(name)
@@ -155,9 +155,6 @@ def test_hip_matches_the_reference_on_a_full_size_slab(name, variant):
         h.set_option("symsweep", 0)
     elif variant == "pivoted":
         h.set_option("factor", 2)
-    elif variant == "wide_sweep":  # round 5: half sweep with 256-column pivot blocks (opt-in)
-        h.set_option("symsweep", 1)
-        h.set_option("pivot256", 1)
     z, ss = m.execute("grid", *fx.grid_args(g), backend="vectorized")
     dz = float(np.abs(np.ma.getdata(z) - g["z"]).max())
     ds = float(np.abs(np.ma.getdata(ss) - g["ss"]).max())

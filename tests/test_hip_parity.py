@@ -220,23 +220,21 @@ def test_block_jacobi_pseudo_inverse_against_scipy_and_the_scalar_form(case):
 
 
 def test_block_sweep_variants_agree():
-    """Options of the unpivoted block sweep: diagonal-block kernel variants and the look-ahead schedule return the
-    bit-identical inverse; the opt-in half (upper-triangle) sweep returns an exactly symmetric one within 1e-11 of it."""
+    """Schedules of the unpivoted block sweep that are still in the library (round 6 removed the scalar-pivot diagonal kernels, the
+    one-block / flag-ordered early-diagonal modes, the panel-row and tile-map variants with their options): the plain loop, the
+    look-ahead (early-diagonal) schedule with and without the gate and the panel stream, odd steps walked backwards or not, return
+    the bit-identical inverse; the half (upper-triangle) sweep an exactly symmetric one within 1e-11 of it."""
     g = fx.load("ok2d_n2000")
     st = fx.state_from("ok2d_n2000", g)
     h = _handle_for(st)
     h.set_option("factor", 1)
+    h.set_option("symmetrize", 0)  # the full sweep as eliminated: schedules must agree bit for bit before the triangles are averaged
     ref = None
-    # (look-ahead, diagonal kernel, half sweep, gate, fused chain, early-diagonal schedule)
-    for la, diag, sym, gate, fuse, early in ((0, 0, 0, 1, 1, 1), (1, 0, 0, 1, 1, 1), (0, 1, 0, 1, 1, 1), (1, 1, 0, 1, 1, 1), (1, 1, 0, 0, 1, 1), (1, 1, 0, 1, 1, 0),
-                                             (1, 1, 0, 0, 1, 0), (1, 1, 0, 1, 0, 0), (1, 2, 0, 1, 1, 1), (0, 3, 0, 1, 1, 1), (0, 1, 1, 1, 1, 1), (1, 1, 1, 1, 1, 1),
-                                             (1, 1, 1, 0, 1, 1), (1, 1, 1, 1, 1, 0), (1, 1, 1, 0, 1, 0), (1, 1, 1, 1, 0, 0), (1, 1, 0, 1, 1, 2), (1, 1, 1, 1, 1, 2), (1, 1, 0, 1, 1, 5), (1, 1, 1, 0, 1, 5), (1, 1, 0, 1, 1, 4), (1, 1, 1, 1, 1, 4)):
-        h.set_option("early_diag", early)  # the next diagonal block is built and inverted ahead of the panel / update stream (2: one-block kernels, 5 / 4: update stream / both streams ordered by flags instead of events)
-        h.set_option("lookahead", la)
-        h.set_option("fuse_chain", fuse)  # the column update also leaves the next panel copy, the panel kernel also writes R^T
-        h.set_option("diag", diag)
-        h.set_option("symsweep", sym)
-        h.set_option("gate", gate)  # schedule only (the update waits for the next diagonal inverse to start): same numbers
+    # (look-ahead, half sweep, gate, panel stream, update_rev)
+    for la, sym, gate, ps, rev in ((0, 0, 1, 0, 0), (1, 0, 1, 0, 0), (1, 0, 0, 0, 0), (1, 0, 1, 1, 0), (1, 0, 0, 1, 1), (0, 0, 1, 0, 1), (-1, 0, -1, -1, -1),
+                                   (0, 1, 1, 0, 0), (1, 1, 1, 0, 0), (1, 1, 0, 0, 1), (1, 1, 1, 1, 0), (1, 1, 0, 1, 1), (-1, 1, -1, -1, -1)):
+        for key, val in (("lookahead", la), ("symsweep", sym), ("gate", gate), ("panel_stream", ps), ("update_rev", rev)):
+            h.set_option(key, val)
         h.factor()
         a = h.get_matrix(1)
         if ref is None:
@@ -246,113 +244,25 @@ def test_block_sweep_variants_agree():
         else:
             assert np.array_equal(a, a.T)
             assert np.abs(a - ref).max() <= 1e-11 * np.abs(ref).max()
-    # rows per block of the panel kernel (32 by default, above): the same accumulation streams on more or fewer blocks
-    for la in (0, 1):
-        for rows in (128, 64, 32):
-            for key, val in (("early_diag", 1), ("lookahead", la), ("fuse_chain", 1), ("diag", 1), ("symsweep", 0), ("gate", 1), ("panel_rows", rows)):
-                h.set_option(key, val)
-            h.factor()
-            np.testing.assert_array_equal(h.get_matrix(1), ref)
-    # the blocked diagonal inverse (diag = 4, the default): the same elimination with the sums grouped by 16 pivots -- equal to
-    # rounding to the others, and bit-identical to itself under every schedule
-    ref4 = None
-    for la, sym, gate, fuse, early in ((0, 0, 1, 1, 1), (1, 0, 1, 1, 1), (1, 0, 0, 1, 0), (1, 0, 1, 0, 0), (1, 0, 1, 1, 2), (1, 0, 1, 1, 5), (1, 0, 1, 1, 4), (1, 1, 1, 1, 1), (1, 1, 0, 1, 0)):
-        for key, val in (("early_diag", early), ("lookahead", la), ("fuse_chain", fuse), ("diag", 4), ("symsweep", sym), ("gate", gate), ("panel_rows", 32)):
-            h.set_option(key, val)
-        h.factor()
-        a = h.get_matrix(1)
-        if ref4 is None:
-            ref4 = a
-            assert np.abs(a - ref).max() <= 1e-11 * np.abs(ref).max()
-        elif not sym:
-            np.testing.assert_array_equal(a, ref4)
-        else:
-            assert np.array_equal(a, a.T)
-            assert np.abs(a - ref4).max() <= 1e-11 * np.abs(ref4).max()
-
-
-def test_panel_stream_and_tile_map_return_the_same_bits():
-    """Round 3: the sweep's third stream (k_panel + the update of the next block column beside the rest of the previous update) and
-    the super-block tile order of the trailing update are schedules: bit-identical inverses, full and half sweep; a full sweep
-    ends symmetrized (A_inv = (A_inv + A_inv^T) / 2, what the symmetric contraction reads one triangle of)."""
-    g = fx.load("ok2d_n2000")
-    st = fx.state_from("ok2d_n2000", g)
-    h = _handle_for(st)
-    h.set_option("factor", 1)
-    for sym in (0, 1):
-        ref = None
-        for ps, umap, early in ((0, 0, 1), (1, 0, 1), (1, 8, 1), (0, 4, 1), (1, 16, 1), (1, 0, 0)):
-            for key, val in (("symsweep", sym), ("panel_stream", ps), ("update_map", umap), ("early_diag", early), ("lookahead", 1)):
-                h.set_option(key, val)
-            h.factor()
-            a = h.get_matrix(1)
-            assert np.array_equal(a, a.T)
-            if ref is None:
-                ref = a
-            else:
-                np.testing.assert_array_equal(a, ref)
-        # round 5: the deep form of the trailing update (k_update_deep: T tile in registers before the K loop, four LDS stages, several
-        # tiles per block as one pipeline) -- same K order per entry, same subtraction: the same bits, whatever the tiles per block
-        for deep, tpb, rev in ((0, 0, 0), (1, 0, 0), (1, 1, 0), (1, 3, 1), (1, 64, 1), (1, 2, 0)):
-            for key, val in (("symsweep", sym), ("panel_stream", 1), ("update_map", 0), ("early_diag", 1), ("lookahead", 1), ("update_deep", deep),
-                             ("update_tpb", tpb), ("update_rev", rev)):
-                h.set_option(key, val)
-            h.factor()
-            np.testing.assert_array_equal(h.get_matrix(1), ref)
-        for key, val in (("update_deep", -1), ("update_tpb", 0), ("update_rev", -1)):
-            h.set_option(key, val)
-    # as eliminated (symmetrize = 0) the full sweep's triangles differ by rounding, and the average is what the default returns
-    for key, val in (("symsweep", 0), ("panel_stream", 1), ("update_map", 0), ("symmetrize", 0)):
+    # as eliminated the full sweep's triangles differ by rounding; the default returns their average (what the symmetric contraction
+    # reads one triangle of)
+    assert not np.array_equal(ref, ref.T)
+    for key, val in (("lookahead", -1), ("symsweep", 0), ("gate", -1), ("panel_stream", -1), ("update_rev", -1), ("symmetrize", 1)):
         h.set_option(key, val)
     h.factor()
-    raw = h.get_matrix(1)
-    assert not np.array_equal(raw, raw.T)
-    h.set_option("symmetrize", 1)
-    h.factor()
-    np.testing.assert_array_equal(h.get_matrix(1), 0.5 * (raw + raw.T))
+    np.testing.assert_array_equal(h.get_matrix(1), 0.5 * (ref + ref.T))
 
 
-@pytest.mark.parametrize("n", [1150, 2000])
-def test_wide_half_sweep_matches_lapack_and_its_variants_agree(n):
-    """Round 5, option pivot256 (opt-in): the half sweep with pivot blocks of 256 columns -- a Schur split of the 256 x 256 diagonal block
-    over two runs of the 128-block kernel, rank-256 trailing updates, the column part leaving the next panel, even (16) and odd (9, 11,
-    17: a 128-wide last pivot) numbers of block columns -- against LAPACK and against the 128-wide sweep; the
-    update with its part of T in registers before the K loop (update_pf) and the CU mask of the update stream (wide_reserve) are
-    schedules: the same bits."""
-    import scipy.linalg
-
-    rng = np.random.default_rng(n)
-    x, y = rng.random(n), rng.random(n)
-    v = np.sin(6 * x) * np.cos(4 * y) + 0.1 * rng.standard_normal(n)
+def test_options_that_left_the_library_are_refused():
+    """Round 6 prune: the experiments of rounds 2-5 are no longer options of the library (tools/mik_k_experiments.h, DESIGN_HISTORY.md):
+    asking for one is an error, not a silent no-op."""
     lib = _lib()
-    ref = None
-    for mat_n in (n, n + 130):  # a second station count: an odd number of block columns (the last pivot is 128 wide)
-        xs, ys, vs = (x, y, v) if mat_n == n else (np.r_[x, rng.random(130)], np.r_[y, rng.random(130)], np.r_[v, rng.random(130)])
-        outs = {}
-        for key in ("narrow", "wide", "wide_pf", "wide_nomask", "narrow_pf"):
-            h = lib.Handle(0)
-            for k, val in (("factor", 1), ("symsweep", 1), ("pivot256", int(key.startswith("wide"))), ("update_pf", int(key.endswith("pf"))),
-                           ("wide_reserve", 0 if key == "wide_nomask" else 16), ("panel_stream", 1)):
-                h.set_option(k, val)
-            h.set_problem(ndim=2, xs=xs, ys=ys, zs=None, values=vs, model_id=lib.MODEL_IDS["exponential"], params=[1.0, 0.1, 0.01])
-            h.factor()
-            outs[key] = h.get_matrix(1)
-            h.close()
-        np.testing.assert_array_equal(outs["wide"], outs["wide_pf"])
-        np.testing.assert_array_equal(outs["wide"], outs["wide_nomask"])
-        np.testing.assert_array_equal(outs["narrow"], outs["narrow_pf"])
-        scale = np.abs(outs["narrow"]).max()
-        assert np.array_equal(outs["wide"], outs["wide"].T)
-        assert np.abs(outs["wide"] - outs["narrow"]).max() <= 1e-10 * scale
-        # against LAPACK on the matrix the library assembled
-        h = lib.Handle(0)
-        h.set_problem(ndim=2, xs=xs, ys=ys, zs=None, values=vs, model_id=lib.MODEL_IDS["exponential"], params=[1.0, 0.1, 0.01])
-        h.assemble_only()
-        amat = h.get_matrix(0)
-        h.close()
-        lap = scipy.linalg.inv(amat)
-        assert np.abs(outs["wide"] - lap).max() <= 1e-9 * np.abs(lap).max()
-        assert np.abs(amat @ outs["wide"] - np.eye(amat.shape[0])).max() <= 1e-8
+    h = lib.Handle(0)
+    for key in ("update_deep", "update_tpb", "pivot256", "update_pf", "update_token", "wide_reserve", "wide_colstream", "engine", "waves", "update_waves",
+                "panel_rows", "update_map", "diag", "early_diag", "fuse_chain", "sparse_ktile", "sparse_epilogue"):
+        with pytest.raises(ValueError, match="unknown option"):
+            h.set_option(key, 1)
+    h.close()
 
 
 def test_lean_exp_of_the_moving_window_set_up_is_within_an_ulp_and_a_half():
@@ -523,14 +433,13 @@ def test_synthetic_n1500_against_oracle(cfg):
     zr, sr = ko.execute(st, "grid", *axes)
     h = m._get_handle()
     outs = []
-    # symmetric half product on/off x MFMA (8- or 4-wave blocks) / VALU contraction
-    for sym, engine, waves in ((1, 0, 8), (0, 0, 8), (1, 0, 4), (0, 0, 4), (1, 1, 4), (0, 1, 4)):
+    # the symmetric half product with triangular / whole diagonal blocks, and the reference's full product w = A_inv b (three kernels)
+    for sym, tri in ((1, 1), (0, 1), (1, 0)):
         h.set_option("symmetric", sym)
-        h.set_option("engine", engine)
-        h.set_option("waves", waves)
+        h.set_option("tri", tri)
         h.set_option("chunk", 1024)
         z, ss = m.execute("grid", *axes, backend="loop")
-        assert m.last_timing["contract_launches"] >= 3 and m.last_timing["engine"] == engine
+        assert m.last_timing["contract_launches"] >= 3 and m.last_timing["symmetric"] == sym
         np.testing.assert_allclose(z, zr, rtol=0, atol=Z_TOL)
         np.testing.assert_allclose(ss, sr, rtol=0, atol=SS_TOL)
         outs.append((z, ss))

@@ -197,13 +197,11 @@ def test_point_sort_restated_in_numpy():
 
 
 # ---------------------------------------------------------------------------------------------- GPU
-def _run(m, style, args, sparse, chunk=None, rows=None, lanes=2, ktile=8, epi=1, **kw):
+def _run(m, style, args, sparse, chunk=None, rows=None, lanes=2, **kw):
     h = m._get_handle()
     h.set_option("sparse", sparse)
-    h.set_option("sparse_epilogue", epi)  # 1 = the default (a row group's term from the B tile in LDS), 0 = from global memory behind the K loop
-    h.set_option("sparse_rows", -1 if rows is None else rows)
+    h.set_option("sparse_rows", -1 if rows is None else rows)  # 16 (default): gathered row groups, lists per 8 stations; 128: aligned blocks, lists per 16
     h.set_option("sparse_lanes", lanes)
-    h.set_option("sparse_ktile", ktile)  # round 5: 8 = the default (a K step is a pair of 8-station tiles), 16 = round 4's tiles
     if chunk:
         h.set_option("chunk", chunk)
     z, ss = m.execute(style, *args, **kw)
@@ -259,25 +257,21 @@ def test_sparse_contraction_against_oracle_and_dense(case):
     zd, sd, td = _run(m, "grid", axes, 0)
     assert td["sparse"] == 0 and td["stations_sorted"] == 0
     # (lanes: 2 = the default since round 5 -- the launches alternate between two streams and two sets of work buffers --, 1 = one stream)
-    for chunk, rows, ktile, epi, lanes in ((131072, None, 8, 1, 2), (2048, None, 8, 1, 2), (131072, 128, 8, 1, 1), (2048, 16, 8, 0, 1), (131072, 16, 16, 1, 2),
-                                           (2048, None, 16, 0, 2), (4096, None, 8, 0, 2), (1024, None, 8, 1, 1), (1024, 128, 8, 1, 2)):
-        zs, ss, ts = _run(m, "grid", axes, 1, chunk=chunk, rows=rows, ktile=ktile, epi=epi, lanes=lanes)
+    for chunk, rows, lanes in ((131072, None, 2), (2048, None, 2), (131072, 128, 1), (2048, 16, 1), (4096, None, 2), (1024, None, 1), (1024, 128, 2)):
+        zs, ss, ts = _run(m, "grid", axes, 1, chunk=chunk, rows=rows, lanes=lanes)
         assert ts["sparse"] == 1 and ts["stations_sorted"] == 1
         assert ts["sparse_rows"] == (rows or 16)  # gathered 16-row groups are the default
-        assert ts["sparse_ktile"] == (16 if rows == 128 else ktile)  # (aligned row blocks keep their 16-station lists)
+        assert ts["sparse_ktile"] == (16 if rows == 128 else 8)  # (aligned row blocks keep their 16-station lists)
         assert 0 < ts["sparse_tiles"] <= ts["sparse_tiles_dense"]
         assert np.abs(zs - zr).max() <= Z_TOL and np.abs(ss - sr).max() <= SS_TOL, (np.abs(zs - zr).max(), np.abs(ss - sr).max())
         assert np.abs(zs - zd).max() <= Z_TOL and np.abs(ss - sd).max() <= SS_TOL
-        if rows == 128:
+        if rows == 128 and chunk == 131072:
             t128 = ts
-        elif chunk == 131072 and ktile == 16:
-            t16 = ts
         elif chunk == 131072:
             t8 = ts
-    # gathered groups never execute more than aligned blocks do: fewer or equal off-diagonal K tiles and triangle products;
-    # and pairs of 8-station tiles never more K steps than 16-station tiles (a pair covers at most the stations of two of those)
-    assert t16["sparse_ktiles"] <= t128["sparse_ktiles"] and t16["sparse_diag_products"] <= t128["sparse_diag_products"], (t16, t128)
-    assert t8["sparse_ktiles"] <= t16["sparse_ktiles"] and t8["sparse_tiles"] <= t16["sparse_tiles"], (t8, t16)
+    # gathered groups with pairs of 8-station tiles never execute more than aligned blocks with 16-station tiles do: fewer or equal
+    # off-diagonal K steps and triangle products
+    assert t8["sparse_ktiles"] <= t128["sparse_ktiles"] and t8["sparse_diag_products"] <= t128["sparse_diag_products"], (t8, t128)
     # two launch lanes (two streams, two sets of work buffers; the second lane waits for the sort of the points)
     m._get_handle().set_option("sort_points", 1)
     zs, ss, ts = _run(m, "grid", axes, 1, chunk=1024, lanes=2)

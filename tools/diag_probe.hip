@@ -2,6 +2,7 @@
 // switched off (results are then wrong; only the clock is read), plus bare loops of its synchronisation pattern.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I pykrige_amd/csrc tools/diag_probe.hip -o tools/diag_probe
 #include "mik_kernels.h"
+#include "mik_k_experiments.h"  // k_diag_inv_t: left the library in round 6
 #include <cstdio>
 #include <cstdlib>
 #include <vector>

@@ -1,6 +1,7 @@
 // Standalone timing of the library's kernels on BASELINE config-2 shapes (M=5001 -> Mp=5120) with
 // HIP events.  Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I pykrige_amd/csrc tools/kernel_bench.hip -o tools/kernel_bench
 #include "mik_kernels.h"
+#include "mik_k_experiments.h"  // kernels the library no longer instantiates (round 6)
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -142,12 +143,12 @@ int main(int argc,char**argv){
   printf("k_diag_inv_t<16,16> (scalar pivots) back-to-back: %.1f us\n",ms*1e3);
 
   const long ut=(long)nblk*nblk; const unsigned ug=(unsigned)(8*((ut+7)/8));
-  ms=timeit([&]{hipLaunchKernelGGL(k_update<false>,dim3(ug),dim3(256),0,0,T,(long)Mp,nblk,1,(const double*)Cold,(const double*)Cnew,(const double*)Rt,(const double*)Dinv,0,0,(double*)nullptr);},5);
+  ms=timeit([&]{hipLaunchKernelGGL((k_update<false,4>),dim3(ug),dim3(256),0,0,T,(long)Mp,nblk,1,(const double*)Cold,(const double*)Cnew,(const double*)Rt,(const double*)Dinv,0,0,(double*)nullptr);},5);
   printf("k_update: %.1f us  %.2f TF/s\n",ms*1e3, 2.0*Mp*(double)Mp*128/ms*1e-9);
-  ms=timeit([&]{hipLaunchKernelGGL((k_update<false,2>),dim3(ug),dim3(512),0,0,T,(long)Mp,nblk,1,(const double*)Cold,(const double*)Cnew,(const double*)Rt,(const double*)Dinv,0,0,(double*)nullptr,(double*)nullptr,(int*)nullptr);},5);
+  ms=timeit([&]{hipLaunchKernelGGL((k_update<false,2>),dim3(ug),dim3(512),0,0,T,(long)Mp,nblk,1,(const double*)Cold,(const double*)Cnew,(const double*)Rt,(const double*)Dinv,0,0,(double*)nullptr,(double*)nullptr);},5);
   printf("k_update, 8 waves per tile (round 3): %.1f us  %.2f TF/s\n",ms*1e3, 2.0*Mp*(double)Mp*128/ms*1e-9);
   ms=timeit([&]{hipLaunchKernelGGL(k_diag_inv,dim3(1),dim3(1024),0,0,(const double*)T,(long)Mp,0,0,Dinv,DinvT,flag);
-               hipLaunchKernelGGL(k_update<false>,dim3(ug),dim3(256),0,0,T,(long)Mp,nblk,1,(const double*)Cold,(const double*)Cnew,(const double*)Rt,(const double*)Dinv,0,0,(double*)nullptr);},5);
+               hipLaunchKernelGGL((k_update<false,4>),dim3(ug),dim3(256),0,0,T,(long)Mp,nblk,1,(const double*)Cold,(const double*)Cnew,(const double*)Rt,(const double*)Dinv,0,0,(double*)nullptr);},5);
   printf("k_diag_inv + k_update interleaved: %.1f us per pair\n",ms*1e3);
   ms=timeit([&]{hipLaunchKernelGGL(k_panel<4>,dim3(nblk),dim3(256),0,0,(const double*)Cold,128L,(const double*)DinvT,-1.0,Cnew);},5);
   printf("k_panel: %.1f us\n",ms*1e3);

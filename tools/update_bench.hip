@@ -5,6 +5,7 @@
 // Run:   tools/update_bench [Mp = 8064] [tpb ...]
 #define MIK_UPD_PROF 1
 #include "mik_k_inverse.h"
+#include "mik_k_experiments.h"  // k_update_deep: left the library in round 6
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -38,12 +39,12 @@ int main(int argc,char**argv){
   const double fl = 2.0*128*128*128*(double)(lt - nblk);
   printf("Mp = %d, %d block columns, %ld upper tiles (%ld take a rank-128 update: %.2f GFLOP, %.0f MB read + written of T)\n", Mp, nblk, lt, lt - nblk, fl*1e-9, (lt - nblk)*0.262144);
   int step = 0;
-  float ms=timeit([&]{hipLaunchKernelGGL((k_update<true,2>),dim3(ug),dim3(512),0,0,T,(long)Mp,nblk,kb,(const double*)Cold,(const double*)Cnew,(const double*)Rt,(const double*)Dinv,0,-2,(double*)nullptr,(double*)nullptr,(int*)nullptr,(const int2*)nullptr,((step++)&1)?2:0);},10);
+  float ms=timeit([&]{hipLaunchKernelGGL((k_update<true,2>),dim3(ug),dim3(512),0,0,T,(long)Mp,nblk,kb,(const double*)Cold,(const double*)Cnew,(const double*)Rt,(const double*)Dinv,0,-2,(double*)nullptr,(double*)nullptr,(step++)&1);},10);
   printf("k_update<true,2> (two 8-wave blocks per CU)        : %7.1f us  %5.1f TFLOP/s\n",ms*1e3, fl/ms*1e-9);
   {  // one profiled launch: when each block's K loop and read-modify-write began and ended
     unsigned long long* pb; CK(hipMalloc(&pb, sizeof(unsigned long long) * (4 * ug + 4))); CK(hipMemset(pb, 0, sizeof(unsigned long long) * (4 * ug + 4)));
     CK(hipMemcpyToSymbol(HIP_SYMBOL(mik_upd_prof), &pb, sizeof(pb)));
-    hipLaunchKernelGGL((k_update<true,2>),dim3(ug),dim3(512),0,0,T,(long)Mp,nblk,kb,(const double*)Cold,(const double*)Cnew,(const double*)Rt,(const double*)Dinv,0,-2,(double*)nullptr,(double*)nullptr,(int*)nullptr,(const int2*)nullptr,0);
+    hipLaunchKernelGGL((k_update<true,2>),dim3(ug),dim3(512),0,0,T,(long)Mp,nblk,kb,(const double*)Cold,(const double*)Cnew,(const double*)Rt,(const double*)Dinv,0,-2,(double*)nullptr,(double*)nullptr,0);
     CK(hipDeviceSynchronize());
     std::vector<unsigned long long> hp(4 * (size_t)ug + 4); CK(hipMemcpy(hp.data(), pb, hp.size() * 8, hipMemcpyDeviceToHost));
     unsigned long long* none = nullptr; CK(hipMemcpyToSymbol(HIP_SYMBOL(mik_upd_prof), &none, sizeof(none)));
