@@ -965,13 +965,15 @@ def main():
                                 "exchange_path": EXCHANGE_NAMES.get(last.get("exchange_path"), "?"), "rccl_ranks": last.get("rccl_ranks"),
                                 "exchange_fallbacks": last.get("exchange_fallbacks"), "exchange_note": h.exchange_note(),
                                 "exchange_ms": last.get("exchange_ms"), "exchange_wait_ms": last.get("exchange_wait_ms"),
+                                "exchange_bytes": last.get("exchange_bytes"),  # per member: the packed upper block triangle of the inverse + c
                                 "timeouts_s": {"rccl_init": float(os.environ.get("MIK_RCCL_INIT_TIMEOUT", "120")),
                                                "rccl_bcast": float(os.environ.get("MIK_RCCL_BCAST_TIMEOUT", "30")),
                                                "peer": float(os.environ.get("MIK_PEER_TIMEOUT", "30"))}}
             out["per_device_predict_ms"] = out["multi_gpu"]["per_device_predict_ms"]
         elif world > 1:
             allp = pg.all_gather_object({"rank": rank, "device": int(os.environ["MIK_DEVICE"]), "predict_ms": last.get("predict_ms")})
-            out["multi_gpu"] = {"ranks": allp, "exchange_path": exchange, "rccl_ranks": world if exchange == "rccl_bcast" else 0}
+            out["multi_gpu"] = {"ranks": allp, "exchange_path": exchange, "rccl_ranks": world if exchange == "rccl_bcast" else 0,
+                                "exchange_bytes": last.get("exchange_bytes"), "exchange_ms": getattr(executor, "exchange_ms", None)}
         # ---- roofline.traffic: live PMC passes over one step of this benchmark, else the committed profile (labelled)
         if n_gpus == 1 and not inner and args.pmc != "off":
             progress["stage"] = "live PMC passes (rocprofv3)"

@@ -36,8 +36,10 @@ extern "C" {
  *   4 -> 5  mik_grid.cell_count == 0 is an EMPTY range (it used to mean "the whole grid", which is now -1): a caller that
  *           zero-initialises mik_grid must set cell_count = -1.  mik_abi_version() returns the library's value; the Python
  *           loader (pykrige_amd/_lib.py) refuses a library whose version differs from the header it was written against. */
-#define MIK_ABI_VERSION 6
+#define MIK_ABI_VERSION 7
 /*   5 -> 6  mik_timing grew by sparse_ktile + reserved2 (8 bytes appended; earlier fields unchanged). */
+/*   6 -> 7  mik_timing grew by exchange_bytes (8 bytes appended); the factor exchange moves the packed upper block triangle of the inverse
+ *           (option "exchange_tri"); the option keys of the experiments of rounds 2-5 are refused (see the option list). */
 
 #define MIK_OK          0
 #define MIK_EINVAL     (-1) /* bad argument            -> Python ValueError                  */
@@ -161,6 +163,9 @@ typedef struct mik_timing {
   int32_t sparse_ktile;        /* stations per candidate / list tile of the range-aware contraction: 16, or 8 (a K step is then a pair of
                                   list-adjacent 8-station tiles: option "sparse_ktile"; ABI 5 -> 6: appended) ; 0 = dense */
   int32_t reserved2;
+  double exchange_bytes;       /* payload one group member / rank received in the last factor exchange: 8 (tri_len + Mp) with the packed upper block
+                                  triangle (Mp (Mp + 128) / 2 doubles; option "exchange_tri", the default wherever the symmetric contraction runs), 8 (Mp^2 + Mp)
+                                  with the whole square; 0 = no exchange.  ABI 6 -> 7: appended */
 } mik_timing;
 
 int  mik_device_count(void);
@@ -192,6 +197,11 @@ int  mik_slab_of(int64_t n, int members, int i, int64_t *lo, int64_t *count); /*
  * tools/mik_k_experiments.h or git history, their measurements in profiles/ and DESIGN_HISTORY.md):
  * "factor" 0=auto 1=sweep 2=pivoted ; "symmetric" 0/1 (1 = the contraction forms b^T A_inv b over one triangle of A_inv; 0 = the reference's
  *   full product w = A_inv b, ok.py:679: the cross-check kernel of the parity tests) ;
+ * "exchange_tri" 0/1 = device groups / ranks: the factor exchange moves the packed UPPER BLOCK TRIANGLE of the inverse (block row I keeps its
+ *   columns from 128 I on: Mp (Mp + 128) / 2 doubles, 264 MB instead of 520 MB at N = 8000) -- all the symmetric contraction reads, dense and
+ *   range-aware -- packed on the leader / root (k_tri_pack, 0.1 ms), checksummed, unpacked into the members' matrices; their lower block triangle
+ *   stays unwritten (mik_get_matrix mirrors it; "symmetric" 0 on such a member is refused).  1 (default) = wherever "symmetric" is 1, 0 = always
+ *   the whole square.  mik_timing.exchange_bytes says what travelled [MIK_EXCHANGE_TRI] ;
  * "sparse" -1/0/1/2 = range-aware contraction for variograms with compact support (the reference's spherical model is constant
  *   beyond its range, variogram_models.py:56-70).  With u = [1_N; 0] and s = psill + nugget the right-hand side is b = -s u + delta,
  *   delta_k = s - gamma(d_k) = 0 for every station beyond the range, and because A e_last = u:  z = c . delta  and

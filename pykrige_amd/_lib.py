@@ -61,7 +61,7 @@ class MikTiming(C.Structure):
         ("sparse_tiles", C.c_double), ("sparse_tiles_dense", C.c_double),
         ("sparse_ktiles", C.c_double), ("sparse_ktiles_dense", C.c_double), ("sparse_lists_ms", C.c_double),
         ("sparse_diag_products", C.c_double), ("sparse_rows", C.c_int32), ("points_sorted", C.c_int32),
-        ("sort_points_ms", C.c_double), ("sparse_ktile", C.c_int32), ("reserved2", C.c_int32),
+        ("sort_points_ms", C.c_double), ("sparse_ktile", C.c_int32), ("reserved2", C.c_int32), ("exchange_bytes", C.c_double),
     ]
 
     def as_dict(self):
@@ -69,7 +69,7 @@ class MikTiming(C.Structure):
 
 
 _lib = None
-ABI_VERSION = 6  # include/mikrige.h MIK_ABI_VERSION
+ABI_VERSION = 7  # include/mikrige.h MIK_ABI_VERSION
 
 # every entry point include/mikrige.h declares: name -> (restype, argtypes)
 SIGNATURES = {

@@ -396,6 +396,12 @@ struct mik_handle {
   std::shared_ptr<struct XchgJob> xjob;
   hipStream_t xstream = nullptr;  // this member's exchange stream (RCCL broadcast, checksums)
   DevBuf xsum;                 // 4 x u64: checksums of T and c after an exchange
+  // round 6: the exchange moves the packed upper block triangle of the inverse (k_tri_pack) when the contraction is the symmetric one
+  DevBuf xpack;                // tri_len(Mp) doubles: packed on the leader / root, received and unpacked into T on the others
+  int opt_exchange_tri = 1;    // "exchange_tri": 1 (default) = the triangle wherever the symmetric contraction runs, 0 = always the whole square
+  bool upper_only = false;     // this handle's T holds a received inverse whose lower block triangle was not sent (the full product must not read it)
+  bool xpack_valid = false;    // one process per GPU: xpack holds the packed triangle of the current factor (mik_factor_checksum sums it)
+  double exchange_bytes = 0.0; // payload one member / rank received in the last exchange
   std::chrono::steady_clock::time_point xchg_t0;
   double exchange_wait_ms = 0.0;  // of exchange_ms, what a caller really waited for (the rest overlapped the leader's prediction)
   int exchange_fallbacks = 0, rccl_ranks = 0;
@@ -474,6 +480,7 @@ inline bool want_sorted(const mik_handle* h) { return h->sort_ok && h->opt_spars
 int custom_roundtrip(mik_handle* h, double* dev, long rows, long cols, long ld);                                 // mikrige.hip
 int launch_assemble(mik_handle* h, double shift, double* dst = nullptr, bool sorted = false, bool eq = false);  // mikrige.hip
 int ensure_factor_buffers(mik_handle* h);                                                                        // mik_inverse.hip
+int mirror_upper_triangle(mik_handle* h);                                                                        // mik_inverse.hip
 int one_factor(mik_handle* h);                                                                                   // mik_inverse.hip
 int sort_points(mik_handle* h, long chunk, long nchunks);                                                        // mik_predict.hip
 int one_predict(mik_handle* h);                                                                                  // mik_predict.hip

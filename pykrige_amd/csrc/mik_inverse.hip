@@ -152,6 +152,15 @@ static int run_pseudo_inverse_scalar(mik_handle* h) {
   return MIK_OK;
 }
 
+// T's lower block triangle from its upper one (a rank that received the packed upper triangle hands out the whole inverse: mik_get_matrix)
+int mirror_upper_triangle(mik_handle* h) {
+  hipLaunchKernelGGL(k_mirror_upper, dim3(h->Mp / 64, h->Mp / 64), dim3(256), 0, h->stream, h->T.as<double>(), (long)h->Mp, h->Mp / 64);
+  HIPC(hipGetLastError());
+  HIPC(hipStreamSynchronize(h->stream));
+  h->upper_only = false;
+  return MIK_OK;
+}
+
 int ensure_factor_buffers(mik_handle* h) {
   const size_t Mp = h->Mp;
   MIKC(h->T.ensure(sizeof(double) * Mp * Mp));
@@ -858,6 +867,7 @@ int one_factor(mik_handle* h) {
   HIPC(hipSetDevice(h->device));
   h->t_state = 0;
   h->have_factor = false;
+  h->upper_only = h->xpack_valid = false;
   h->factor_sorted = want_sorted(h);
   h->factor_eq = h->drift_eq && h->opt_drift_eq;
   MIKC(ensure_factor_buffers(h));

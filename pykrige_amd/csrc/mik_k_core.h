@@ -140,6 +140,23 @@ __global__ void __launch_bounds__(256) k_checksum(const unsigned long long* __re
   }
 }
 
+// The factor exchange moves the UPPER BLOCK TRIANGLE of the inverse only (round 6): the symmetric contraction -- dense and range-aware --
+// reads A_inv[i][j] for block columns J >= I alone.  Packed layout: block row I (128 rows) keeps its columns [128 I, Mp), row-major, block
+// rows one after the other: tri_len(Mp) = Mp (Mp + 128) / 2 doubles (N = 8000: 264 MB instead of 520 MB).  One block per matrix row;
+// every segment starts on a 1 KB boundary and has an even length: double2 copies.  unpack = the way back into T (its lower block triangle
+// is left as it was: nothing on a group member reads it).
+__host__ __device__ inline size_t tri_off(size_t Mp, size_t I) { return 128 * I * Mp - 8192 * (I * (I > 0 ? I - 1 : 0)); }
+__host__ __device__ inline size_t tri_len(size_t Mp) { return tri_off(Mp, Mp / 128); }
+__global__ void __launch_bounds__(256) k_tri_pack(double* __restrict__ T, size_t Mp, double* __restrict__ P, int unpack) {
+  const size_t row = blockIdx.x, I = row >> 7, len = Mp - 128 * I;
+  double* t = T + row * Mp + 128 * I;
+  double* p = P + tri_off(Mp, I) + (row & 127) * len;
+  for (size_t i = 2 * threadIdx.x; i < len; i += 512) {
+    if (unpack) *reinterpret_cast<double2*>(t + i) = *reinterpret_cast<const double2*>(p + i);
+    else *reinterpret_cast<double2*>(p + i) = *reinterpret_cast<const double2*>(t + i);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Prediction points of style='grid' / 'masked' generated from the AXES (mik_set_grid): replaces np.meshgrid + the
 // anisotropy adjustment of every grid point on the host (ok.py:863-885, ok3d.py:866-883; core.py:120-193) and the H2D

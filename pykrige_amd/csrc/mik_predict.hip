@@ -48,6 +48,9 @@ int sort_points(mik_handle* h, long chunk, long nchunks) {
 int one_predict(mik_handle* h) {
   if (!h || !h->have_factor) return fail(MIK_ESTATE, "mik_predict: factor first");
   if (!h->have_points) return fail(MIK_ESTATE, "mik_predict: set points first");
+  if (h->upper_only && !h->opt_sym)
+    return fail(MIK_ESTATE, "mik_predict: this device received only the upper block triangle of the inverse (the factor was exchanged for the symmetric "
+                            "contraction); the full product (\"symmetric\" 0) needs mik_factor again, or \"exchange_tri\" 0");
   HIPC(hipSetDevice(h->device));
   const long npt = h->npt;
   const int Mp = h->Mp, nIblk = Mp / 128;

@@ -66,6 +66,8 @@ static int create_one_body(mik_handle* h, int device) {
   if (env) h->opt_tri = atoi(env) ? 1 : 0;
   env = getenv("MIK_EXCHANGE");
   if (env) h->opt_exchange = !strcmp(env, "rccl") ? 1 : !strcmp(env, "peer") ? 2 : !strcmp(env, "redundant") ? 3 : 0;
+  env = getenv("MIK_EXCHANGE_TRI");
+  if (env) h->opt_exchange_tri = atoi(env) ? 1 : 0;
   env = getenv("MIK_ALIAS_DEVICES");
   if (env) h->alias_ok = atoi(env) != 0;
   env = getenv("MIK_RHS_OVERLAP");
@@ -113,7 +115,7 @@ static void destroy_one(mik_handle* h) {
                     &h->px, &h->py, &h->pz, &h->grid_axes, &h->grid_idx, &h->Averify, &h->vbuf, &h->extra_rows, &h->z, &h->ss, &h->Bt, &h->Bt2, &h->part, &h->mw_idx, &h->mw_dist, &h->stat_S, &h->stat_x, &h->stat_out, &h->queue,
                     &h->xs_s, &h->ys_s, &h->zs_s, &h->vals_s, &h->extra_cols_s, &h->sbox, &h->sp_cand, &h->sp_flags, &h->sp_klist, &h->sp_kcount,
                     &h->sp_nrows, &h->sp_rows, &h->sp_rstart, &h->sp_tiles, &h->sp_xoff, &h->sp_stats, &h->sp2_cand, &h->sp2_flags, &h->sp2_klist, &h->sp2_kcount,
-                    &h->sp2_nrows, &h->sp2_rows, &h->sp2_rstart, &h->sp2_tiles, &h->sp2_xoff, &h->part2, &h->queue2, &h->dsc, &h->sp_recs, &h->sp2_recs, &h->ps_key[0], &h->ps_key[1], &h->ps_idx[0], &h->ps_idx[1], &h->ps_table, &h->ps_box, &h->ps_x, &h->ps_y, &h->ps_z, &h->ps_zs, &h->ps_sss};
+                    &h->sp2_nrows, &h->sp2_rows, &h->sp2_rstart, &h->sp2_tiles, &h->sp2_xoff, &h->part2, &h->queue2, &h->dsc, &h->sp_recs, &h->sp2_recs, &h->ps_key[0], &h->ps_key[1], &h->ps_idx[0], &h->ps_idx[1], &h->ps_table, &h->ps_box, &h->ps_x, &h->ps_y, &h->ps_z, &h->ps_zs, &h->ps_sss, &h->xpack};
   for (DevBuf* b : bufs) b->release();
   h->pin_in.release();
   h->pin_out.release();
@@ -255,6 +257,8 @@ int mik_set_option(mik_handle* h, const char* key, double value) {
   } else if (!strcmp(key, "exchange")) {
     if (value < 0 || value > 3) return fail(MIK_EINVAL, "exchange must be 0 (auto), 1 (rccl), 2 (peer copies) or 3 (redundant factorisation)");
     h->opt_exchange = (int)value;
+  } else if (!strcmp(key, "exchange_tri")) {
+    h->opt_exchange_tri = value != 0.0;
   } else if (!strcmp(key, "alias_devices")) {
     h->alias_ok = value != 0.0;
   } else if (!strcmp(key, "factor")) {
@@ -702,6 +706,7 @@ static int for_each_device(mik_handle* h, F fn) {
 struct XchgMember {
   int device = 0;
   double* T = nullptr;
+  double* X = nullptr;                   // what travels: T itself, or the packed upper block triangle (XchgJob::tri)
   double* cvec = nullptr;
   hipStream_t xs = nullptr;              // the member's exchange stream
   unsigned long long* sum_dev = nullptr; // 4 words on the member's device: checksums of T and of c
@@ -718,6 +723,8 @@ struct XchgJob {
   int path = 0;               // 1 = RCCL broadcast, 2 = peer copies
   bool dry = false;           // mik_selftest_exchange: no HIP calls (drives the control flow against a stand-in RCCL on CPU)
   size_t Mp = 0;
+  size_t xlen = 0;            // doubles of the matrix payload: Mp * Mp, or tri_len(Mp)
+  bool tri = false;           // the payload is the packed upper block triangle; members unpack it into T after the checksum
   std::vector<XchgMember> mem;
   std::vector<std::vector<hipStream_t>> xstreams;  // peer path: xstreams[i][k] = stream on device i for the copy to device k
   std::vector<hipEvent_t> xevents;
@@ -762,8 +769,9 @@ static int xchg_verify(XchgJob* j) {
     const XchgMember& d = j->mem[i];
     HIPC(hipSetDevice(d.device));
     HIPC(hipMemsetAsync(d.sum_dev, 0, 4 * sizeof(unsigned long long), d.xs));
-    hipLaunchKernelGGL(k_checksum, dim3(1024), dim3(256), 0, d.xs, (const unsigned long long*)d.T, Mp * Mp, d.sum_dev);
+    hipLaunchKernelGGL(k_checksum, dim3(1024), dim3(256), 0, d.xs, (const unsigned long long*)d.X, j->xlen, d.sum_dev);
     hipLaunchKernelGGL(k_checksum, dim3(4), dim3(256), 0, d.xs, (const unsigned long long*)d.cvec, Mp, d.sum_dev + 2);
+    if (j->tri) hipLaunchKernelGGL(k_tri_pack, dim3((unsigned)Mp), dim3(256), 0, d.xs, d.T, Mp, d.X, 1);  // (checked below before anybody reads T)
     HIPC(hipGetLastError());
     HIPC(hipMemcpyAsync(j->sums.data() + 4 * i, d.sum_dev, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, d.xs));
   }
@@ -816,7 +824,7 @@ static int xchg_rccl(XchgJob* j) {
       first_bad = ncclUnhandledCudaError;
       break;
     }
-    first_bad = g_rccl.Broadcast(d.T, d.T, j->Mp * j->Mp, ncclDouble, 0, (*comms)[i], d.xs);
+    first_bad = g_rccl.Broadcast(d.X, d.X, j->xlen, ncclDouble, 0, (*comms)[i], d.xs);
     if (first_bad == ncclSuccess) first_bad = g_rccl.Broadcast(d.cvec, d.cvec, j->Mp, ncclDouble, 0, (*comms)[i], d.xs);
   }
   const ncclResult_t end_rc = g_rccl.GroupEnd();
@@ -839,7 +847,7 @@ static int copy_between(void* dst, int ddev, const void* src, int sdev, size_t b
 // whole matrix on each of the leader's links for a direct fan-out: 3.5x less time on 8 GPUs.
 static int xchg_peer(XchgJob* j) {
   const int n = (int)j->mem.size();
-  const size_t Mp = j->Mp, S = Mp * Mp;
+  const size_t Mp = j->Mp, S = j->xlen;
   const size_t pieces = (size_t)(n - 1);
   const size_t per = ((S + pieces - 1) / pieces + 511) / 512 * 512;
   auto piece = [&](int k, size_t* off, size_t* len) {
@@ -853,7 +861,7 @@ static int xchg_peer(XchgJob* j) {
     size_t off, len;
     piece(k, &off, &len);
     hipStream_t st = j->xstreams[0][k];
-    MIKC(copy_between(dk.T + off, dk.device, d0.T + off, d0.device, sizeof(double) * len, st));
+    MIKC(copy_between(dk.X + off, dk.device, d0.X + off, d0.device, sizeof(double) * len, st));
     MIKC(copy_between(dk.cvec, dk.device, d0.cvec, d0.device, sizeof(double) * Mp, st));
     HIPC(hipEventRecord(j->xevents[k], st));
   }
@@ -867,7 +875,7 @@ static int xchg_peer(XchgJob* j) {
       const XchgMember& dk = j->mem[k];
       hipStream_t st = j->xstreams[q][k];
       HIPC(hipStreamWaitEvent(st, j->xevents[q], 0));
-      MIKC(copy_between(dk.T + off, dk.device, dq.T + off, dq.device, sizeof(double) * len, st));
+      MIKC(copy_between(dk.X + off, dk.device, dq.X + off, dq.device, sizeof(double) * len, st));
     }
   }
   for (int i = 0; i < n; ++i) {
@@ -950,11 +958,19 @@ static int start_exchange(mik_handle* h, int path) {
   auto j = std::make_shared<XchgJob>();
   j->path = path;
   j->Mp = (size_t)h->Mp;
+  // the symmetric contraction (dense and range-aware) reads the upper block triangle of the inverse only: that is what travels
+  j->tri = h->opt_exchange_tri && h->opt_sym && h->Mp > 128;
+  j->xlen = j->tri ? tri_len(j->Mp) : j->Mp * j->Mp;
   j->mem.resize(n);
   for (int i = 0; i < n; ++i) {
     mik_handle* d = member(h, i);
+    if (j->tri) {
+      HIPC(hipSetDevice(d->device));
+      MIKC(d->xpack.ensure(sizeof(double) * j->xlen));
+    }
     j->mem[i].device = d->device;
     j->mem[i].T = d->T.as<double>();
+    j->mem[i].X = j->tri ? d->xpack.as<double>() : d->T.as<double>();
     j->mem[i].cvec = d->cvec.as<double>();
     j->mem[i].xs = d->xstream;
     j->mem[i].sum_dev = d->xsum.as<unsigned long long>();
@@ -970,7 +986,8 @@ static int start_exchange(mik_handle* h, int path) {
     unsigned long long* sd = h->xsum.as<unsigned long long>();
     HIPC(hipSetDevice(h->device));
     HIPC(hipMemsetAsync(sd, 0, 4 * sizeof(unsigned long long), h->stream));
-    hipLaunchKernelGGL(k_checksum, dim3(1024), dim3(256), 0, h->stream, (const unsigned long long*)h->T.p, j->Mp * j->Mp, sd);
+    if (j->tri) hipLaunchKernelGGL(k_tri_pack, dim3((unsigned)j->Mp), dim3(256), 0, h->stream, h->T.as<double>(), j->Mp, j->mem[0].X, 0);
+    hipLaunchKernelGGL(k_checksum, dim3(1024), dim3(256), 0, h->stream, (const unsigned long long*)j->mem[0].X, j->xlen, sd);
     hipLaunchKernelGGL(k_checksum, dim3(4), dim3(256), 0, h->stream, (const unsigned long long*)h->cvec.p, j->Mp, sd + 2);
     HIPC(hipGetLastError());
     HIPC(hipMemcpyAsync(j->leader_sums, sd, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
@@ -990,6 +1007,7 @@ static void abandon_exchange(mik_handle* h, XchgJob* j) {
     if (i > 0) {      // the leader's matrix is only read by a transfer
       d->T.leak();
       d->cvec.leak();
+      d->xpack.leak();
     }
     d->xsum.leak();
   }
@@ -1050,7 +1068,9 @@ static int join_exchange(mik_handle* h) {
       h->exchange_used = path;
       h->rccl_ranks = j->rccl_ranks;
       h->exchange_ms = std::chrono::duration<double, std::milli>(j->t_done - h->xchg_t0).count();
+      h->exchange_bytes = sizeof(double) * (double)(j->xlen + j->Mp);
       mark_kids_factored(h);
+      for (mik_handle* k : h->kids) k->upper_only = j->tri;
       break;
     }
     ++h->exchange_fallbacks;
@@ -1101,7 +1121,7 @@ int mik_factor(mik_handle* h) {
   if (!h) return fail(MIK_ESTATE, "mik_factor: NULL handle");
   MIKC(join_exchange(h));  // an exchange nobody waited for yet still reads the leader's matrix
   h->exchange_used = 0;
-  h->exchange_ms = h->exchange_wait_ms = 0.0;
+  h->exchange_ms = h->exchange_wait_ms = h->exchange_bytes = 0.0;
   h->exchange_fallbacks = 0;
   h->rccl_ranks = 0;
   h->exchange_note.clear();
@@ -1174,6 +1194,11 @@ int mik_get_matrix(mik_handle* h, int which, double* out) {
   if (which == 1 && !h->have_factor) return fail(MIK_ESTATE, "mik_get_matrix: not factored");
   MIKC(join_exchange(h));
   HIPC(hipSetDevice(h->device));
+  if (which == 1 && h->upper_only) {
+    // this rank received the packed upper block triangle only (mik_bcast_factor): the inverse is symmetric -- the half sweep mirrors its
+    // triangle, every other path ends symmetrized -- so the lower one is its mirror image
+    MIKC(mirror_upper_triangle(h));
+  }
   if (which == 1 && (h->factor_sorted || h->factor_eq)) {
     // the factor is in Hilbert-curve station order and / or of the matrix with equilibrated drift rows A' = S A S^T: hand out
     // A^-1 = S^T A'^-1 S in the caller's station order.  S = I except S[N + j][N + j] = s_j, S[N + j][M - 1] = -s_j c_j.
@@ -1781,6 +1806,7 @@ int mik_get_timing(mik_handle* h, mik_timing* out) {
   out->exchange_path = h->exchange_used;
   out->exchange_ms = h->exchange_ms;
   out->exchange_wait_ms = h->exchange_wait_ms;
+  out->exchange_bytes = h->exchange_bytes;
   out->exchange_fallbacks = h->exchange_fallbacks;
   out->rccl_ranks = h->rccl_ranks;
   for (mik_handle* k : h->kids) out->predict_ms = std::max(out->predict_ms, k->tm.predict_ms);  // the group's predict = its slowest member
@@ -1796,6 +1822,7 @@ int mik_get_device_timing(mik_handle* h, int member_index, mik_timing* out) {
   out->exchange_path = h->exchange_used;
   out->exchange_ms = h->exchange_ms;
   out->exchange_wait_ms = h->exchange_wait_ms;
+  out->exchange_bytes = h->exchange_bytes;
   out->exchange_fallbacks = h->exchange_fallbacks;
   out->rccl_ranks = h->rccl_ranks;
   out->reserved = member(h, member_index)->device;
@@ -1946,15 +1973,29 @@ int mik_bcast_factor(mik_handle* h, int root) {
   HIPC(hipStreamSynchronize(h->stream));  // the broadcast runs on the exchange stream: the factor (root) / earlier reads are done
   const size_t Mp = h->Mp;
   const int dev = h->device;
+  // every rank decides by the same rule on the same options: the packed upper block triangle travels wherever the symmetric contraction runs
+  const bool tri = h->opt_exchange_tri && h->opt_sym && Mp > 128;
+  const size_t xlen = tri ? tri_len(Mp) : Mp * Mp;
+  if (tri) {
+    MIKC(h->xpack.ensure(sizeof(double) * xlen));
+    if (h->rank == root) {
+      hipLaunchKernelGGL(k_tri_pack, dim3((unsigned)Mp), dim3(256), 0, h->stream, h->T.as<double>(), Mp, h->xpack.as<double>(), 0);
+      HIPC(hipGetLastError());
+      HIPC(hipStreamSynchronize(h->stream));
+    }
+  }
   double* T = h->T.as<double>();
+  double* X = tri ? h->xpack.as<double>() : T;
   double* cv = h->cvec.as<double>();
   ncclComm_t comm = h->comm;
   hipStream_t xs = h->xstream;
+  const bool unpack = tri && h->rank != root;
   bool timed_out = false;
   const int rc = run_bounded([=] {
     HIPC(hipSetDevice(dev));
-    NCCLC(g_rccl.Broadcast(T, T, Mp * Mp, ncclDouble, root, comm, xs));
+    NCCLC(g_rccl.Broadcast(X, X, xlen, ncclDouble, root, comm, xs));
     NCCLC(g_rccl.Broadcast(cv, cv, Mp, ncclDouble, root, comm, xs));
+    if (unpack) hipLaunchKernelGGL(k_tri_pack, dim3((unsigned)Mp), dim3(256), 0, xs, T, Mp, X, 1);
     HIPC(hipStreamSynchronize(xs));
     return MIK_OK;
   }, h->rccl_bcast_limit, "ncclBroadcast of the factor", &timed_out);
@@ -1963,6 +2004,7 @@ int mik_bcast_factor(mik_handle* h, int root) {
     if (h->rank != root) {
       h->T.leak();
       h->cvec.leak();
+      h->xpack.leak();
     }
     h->comm = nullptr;
     g_rccl_dead_why = "a bounded wait on ncclBroadcast ran out";
@@ -1976,6 +2018,9 @@ int mik_bcast_factor(mik_handle* h, int root) {
   h->have_factor = true;
   h->t_state = 2;
   h->have_results = false;
+  h->xpack_valid = tri;
+  h->upper_only = unpack;
+  h->exchange_bytes = sizeof(double) * (double)(xlen + Mp);
   return MIK_OK;
 }
 
@@ -1990,7 +2035,9 @@ int mik_factor_checksum(mik_handle* h, uint64_t out[4]) {
   unsigned long long* sd = h->xsum.as<unsigned long long>();
   const size_t Mp = h->Mp;
   HIPC(hipMemsetAsync(sd, 0, 4 * sizeof(unsigned long long), h->stream));
-  hipLaunchKernelGGL(k_checksum, dim3(1024), dim3(256), 0, h->stream, (const unsigned long long*)h->T.p, Mp * Mp, sd);
+  // after a triangle broadcast (mik_bcast_factor) the ranks agree on the packed upper block triangle, not on the lower one nobody sent
+  if (h->xpack_valid) hipLaunchKernelGGL(k_checksum, dim3(1024), dim3(256), 0, h->stream, (const unsigned long long*)h->xpack.p, tri_len(Mp), sd);
+  else hipLaunchKernelGGL(k_checksum, dim3(1024), dim3(256), 0, h->stream, (const unsigned long long*)h->T.p, Mp * Mp, sd);
   hipLaunchKernelGGL(k_checksum, dim3(4), dim3(256), 0, h->stream, (const unsigned long long*)h->cvec.p, Mp, sd + 2);
   HIPC(hipGetLastError());
   unsigned long long host[4];

@@ -346,6 +346,7 @@ class ShardedExecutor:
         self.model = model
         self.rank, self.world = self.pg.rank, self.pg.world
         self.exchange = "none" if self.world == 1 else ("rccl_bcast" if use_rccl else "redundant_factor")
+        self.exchange_ms = 0.0
         self._handle = handle_factory() if handle_factory is not None else model._get_handle()
         if self.exchange == "rccl_bcast":
             self.exchange = init_rccl(self._handle, self.pg)
@@ -373,7 +374,9 @@ class ShardedExecutor:
             raise exc(msg if self.rank == 0 else "rank 0: " + msg)
         err, sums = None, None
         try:
+            t0 = time.perf_counter()
             h.bcast_factor(0)  # bounded inside the library (MIK_RCCL_BCAST_TIMEOUT): returns an error instead of hanging
+            self.exchange_ms = (time.perf_counter() - t0) * 1e3  # this rank's wall time inside the broadcast of the packed upper triangle + c
             sums = h.factor_checksum() if hasattr(h, "factor_checksum") else None
         except Exception as e:  # noqa: BLE001
             err = repr(e)[:200]

@@ -49,6 +49,7 @@ REACHABLE = {
     "k_assemble": "mik_factor: kriging matrix, 8 variogram ids x NDIM 1 (geographic) / 2 / 3", "k_geo_unit": "geographic stations -> unit vectors",
     "k_geo_unit_p": "geographic points -> unit vectors", "k_grid_points": "mik_set_grid: meshgrid + anisotropy on the device",
     "k_mask_count": "masked grids", "k_mask_scan": "masked grids", "k_mask_write": "masked grids", "k_checksum": "factor exchange: checksum of A^-1, c",
+    "k_tri_pack": "factor exchange: pack / unpack the upper block triangle of A^-1",
     # K2 default sweep
     "k_diag_inv_b": "sweep: blocked diagonal-block inverse", "k_panel": "sweep: column panel (32 rows per block)", "k_update": "sweep: trailing update, 8 waves",
     "k_gemm128": "sweep: early-diagonal chain (two 128^3 products)", "k_gate": "sweep: gate hint", "k_copy_panel": "sweep: column panel copy (full sweep, pivoted)",

@@ -95,6 +95,51 @@ def test_group_matches_one_device_bit_for_bit(members, exchange):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("members", [2, 3, 8])
+def test_the_exchange_moves_the_upper_block_triangle_only(members):
+    """Round 6: the symmetric contraction -- dense and range-aware -- reads block columns J >= I of the inverse only, so the exchange packs
+    the upper block triangle (k_tri_pack), moves Mp (Mp + 128) / 2 doubles instead of Mp^2, checksums the packed buffer and unpacks it on
+    the members.  Same bits as one device and as the whole-square exchange ("exchange_tri" 0); the bytes are reported and (nearly)
+    halved; a member that holds a triangle refuses the full product (its lower block triangle is never written: whatever the allocation held)."""
+    lib = _lib()
+    rng = np.random.default_rng(5)
+    pts = [rng.random(6000), rng.random(6000)]
+    for model, params, n in (("exponential", [0.9, 0.3, 0.1], 1300), ("spherical", [0.95, 0.25, 0.05], 1500)):  # 11 / 12 block columns; dense / range-aware
+        c, v, _, _ = _problem(n=n, seed=21)
+        h1 = lib.Handle(0)
+        z1, s1 = _run(h1, c, v, model, params, pts)
+        h1.close()
+        mp = 128 * ((n + 1 + 127) // 128)
+        out = {}
+        for tri in (1, 0):
+            hg = lib.Handle(0)
+            hg.set_devices(members, alias=True)
+            hg.set_option("exchange_tri", tri)
+            hg.set_option("sort_points", 0)  # (the range-aware path: slabs cut at multiples of 128 points in the caller's order keep the blocks, hence the bits)
+            zg, sg = _run(hg, c, v, model, params, pts)
+            t = hg.timing()
+            assert t["exchange_path"] in (1, 2) and t["exchange_fallbacks"] <= 1, t
+            assert t["exchange_bytes"] == 8.0 * ((mp * (mp + 128) // 2 if tri else mp * mp) + mp), (t["exchange_bytes"], mp)
+            out[tri] = (zg, sg)
+            if tri:
+                hg.set_option("symmetric", 0)  # the members hold a triangle: the full product must not run on it
+                with pytest.raises(RuntimeError, match="upper block triangle"):
+                    hg.predict()
+                hg.set_option("symmetric", 1)
+                hg.factor()  # and a new factor + exchange puts everything right again
+                hg.predict()
+                z2, s2 = hg.get_results()
+                assert np.array_equal(z2, zg) and np.array_equal(s2, sg)
+            hg.close()
+        assert np.array_equal(out[1][0], out[0][0]) and np.array_equal(out[1][1], out[0][1])
+        if model == "exponential":
+            assert np.array_equal(out[1][0], z1) and np.array_equal(out[1][1], s1)
+        else:  # range-aware: to rounding across device counts (include/mikrige.h, option "sparse")
+            assert np.abs(out[1][0] - z1).max() <= 1e-13 and np.abs(out[1][1] - s1).max() <= 1e-12
+    assert 8.0 * (mp * (mp + 128) // 2 + mp) < 0.55 * 8.0 * (mp * mp + mp)
+
+
+@pytest.mark.gpu
 def test_group_with_mask_drift_3d_and_moving_window():
     lib = _lib()
     rng = np.random.default_rng(4)

@@ -193,3 +193,59 @@ def test_bench_with_eight_members_survives_a_hanging_rccl_within_its_budget():
             # a trial in flight when the budget runs out finishes (its own waits are bounded by the library's limits); nothing new starts
             assert tr["budget_s"] == budget and tr["spent_s"] < budget + 45.0, tr
         assert wall < 300.0, wall
+
+
+_RANKS_SCRIPT = r"""
+import sys, json
+sys.path.insert(0, %(root)r)
+import numpy as np
+from pykrige_amd import _lib
+from tests import _fixtures as fx
+c, v = fx.synth(11, %(n)d, 2)
+rng = np.random.default_rng(3)
+pts = [rng.random(4000), rng.random(4000)]
+uid = _lib.Handle.comm_unique_id()
+hs = []
+for rank in range(2):  # two "ranks" in one process (the stand-in hands the root's buffer to the member: the root must call first)
+    h = _lib.Handle(0)
+    h.set_option("exchange_tri", %(tri)d)
+    h.set_problem(ndim=2, xs=c[0], ys=c[1], zs=None, values=v, model_id=_lib.MODEL_IDS[%(model)r], params=%(params)r)
+    h.comm_init(2, rank, uid)
+    hs.append(h)
+hs[0].factor()
+for h in hs:
+    h.bcast_factor(0)
+sums = [list(h.factor_checksum()) for h in hs]
+res = []
+for h in hs:
+    h.set_points(pts[0], pts[1])
+    h.predict()
+    res.append(h.get_results())
+a0, a1 = hs[0].get_matrix(1), hs[1].get_matrix(1)  # the member mirrors the triangle it received
+print("RESULT " + json.dumps(dict(sums_equal=sums[0] == sums[1], same=bool(np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])),
+                                  bytes=[h.timing()["exchange_bytes"] for h in hs], matrix_gap=float(np.abs(a0 - a1).max() / np.abs(a0).max()),
+                                  symmetric=bool(np.array_equal(a1, a1.T)))))
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,params,n", [("exponential", [0.9, 0.3, 0.1], 1300), ("spherical", [0.95, 0.25, 0.05], 3300)])
+def test_rank_broadcast_moves_the_upper_block_triangle(model, params, n):
+    """One process per GPU (mik_comm_init + mik_bcast_factor, what `torch.distributed.run bench.py` drives): round 6 broadcasts the packed upper
+    block triangle.  Two ranks in one process over the stand-in RCCL: the ranks' checksums (of the packed triangle) agree, the non-root
+    rank kriges bit-identically from the unpacked triangle (dense contraction at 11 block columns, range-aware and the half sweep at 26),
+    mik_get_matrix on it mirrors the triangle, and the bytes are those of the triangle; "exchange_tri" 0 moves the square."""
+    import json
+
+    _, hip = _standins()
+    mp = 128 * ((n + 1 + 127) // 128)
+    for tri in (1, 0):
+        env = dict(os.environ, MIK_RCCL_LIB=hip, STANDIN_RCCL_MODE="ok")
+        r = subprocess.run([sys.executable, "-c", _RANKS_SCRIPT % dict(root=ROOT, n=n, tri=tri, model=model, params=params)], capture_output=True,
+                           text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stderr[-800:]
+        o = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
+        assert o["sums_equal"] and o["same"], o
+        want = 8.0 * ((mp * (mp + 128) // 2 if tri else mp * mp) + mp)
+        assert o["bytes"] == [want, want], (o, want)
+        assert o["matrix_gap"] <= 1e-12, o  # (exact zero for the half sweep: its triangle is mirrored on the root too)
