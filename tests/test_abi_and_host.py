@@ -141,7 +141,7 @@ def test_ctypes_structs_match_header_layout():
     # mik_problem: 2 x int32, int64, 4 pointers, 3 doubles, double, 4 x int32, 3 pointers = 120 bytes on LP64
     assert ctypes.sizeof(_lib.MikProblem) == 4 + 4 + 8 + 4 * 8 + 3 * 8 + 8 + 4 * 4 + 3 * 8 + 2 * 4
     assert ctypes.sizeof(_lib.MikPoints) == 8 + 5 * 8
-    assert ctypes.sizeof(_lib.MikTiming) == 5 * 8 + 8 + 8 + 4 * 4 + 8 + 2 * 4 + 8 + 2 * 4 + 6 * 4 + 3 * 8 + 2 * 4 + 5 * 8 + 8 + 2 * 4 + 8 + 2 * 4
+    assert ctypes.sizeof(_lib.MikTiming) == 5 * 8 + 8 + 8 + 4 * 4 + 8 + 2 * 4 + 8 + 2 * 4 + 6 * 4 + 3 * 8 + 2 * 4 + 5 * 8 + 8 + 2 * 4 + 8 + 2 * 4 + 8  # (ABI 7: + exchange_bytes)
     # mik_grid: 2 x int32, 3 x int64, 3 pointers, 3 + 9 + 3 doubles, 2 x int64, 2 pointers
     assert ctypes.sizeof(_lib.MikGrid) == 2 * 4 + 3 * 8 + 3 * 8 + 15 * 8 + 2 * 8 + 2 * 8
 
