@@ -186,12 +186,18 @@ def test_bench_with_eight_members_survives_a_hanging_rccl_within_its_budget():
         assert o["value"] and o["n_gpus"] == 8 and o["config"]["grid_points_total"] == 8 * 4096 * 512
         fx_ = o["config"]["factor_exchange"]
         assert fx_.startswith("peer_scatter_allgather") and ("did not finish within" in fx_ or "rccl disabled" in fx_), fx_
-        tr = o["config"]["factor_exchange_trial"]
+        tr = o["factor_exchange_trial"]  # (top level; the driver's record keeps the flat scalar copies config["trial_*"])
         if budget is None:
-            assert "skipped" in tr
+            assert "skipped" in tr and "trial_skipped" in o["config"]
         else:
             # a trial in flight when the budget runs out finishes (its own waits are bounded by the library's limits); nothing new starts
             assert tr["budget_s"] == budget and tr["spent_s"] < budget + 45.0, tr
+            assert o["config"]["trial_budget_s"] == budget
+        # what an 8-GPU record must show: which exchange ran, on how many RCCL ranks, what it moved (the packed upper triangle + c)
+        cfg = o["config"]
+        assert all(v is None or isinstance(v, (int, float, str, bool)) for v in cfg.values()), cfg
+        assert cfg["exchange_path"].startswith("peer") and cfg["rccl_ranks"] == 0 and cfg["exchange_bytes"] == 8.0 * (8064 * (8064 + 128) // 2 + 8064), cfg
+        assert cfg["predict_ms_slowest_device"] >= cfg["predict_ms_fastest_device"] > 0.0
         assert wall < 300.0, wall
 
 
