@@ -164,7 +164,7 @@ typedef struct mik_timing {
                                   list-adjacent 8-station tiles: option "sparse_ktile"; ABI 5 -> 6: appended) ; 0 = dense */
   int32_t reserved2;
   double exchange_bytes;       /* payload one group member / rank received in the last factor exchange: 8 (tri_len + Mp) with the packed upper block
-                                  triangle (Mp (Mp + 128) / 2 doubles; option "exchange_tri", the default wherever the symmetric contraction runs), 8 (Mp^2 + Mp)
+                                  triangle (Mp (Mp + 128) / 2 doubles; option "exchange_tri", the default for every inverse the device computed), 8 (Mp^2 + Mp)
                                   with the whole square; 0 = no exchange.  ABI 6 -> 7: appended */
 } mik_timing;
 
@@ -198,10 +198,12 @@ int  mik_slab_of(int64_t n, int members, int i, int64_t *lo, int64_t *count); /*
  * "factor" 0=auto 1=sweep 2=pivoted ; "symmetric" 0/1 (1 = the contraction forms b^T A_inv b over one triangle of A_inv; 0 = the reference's
  *   full product w = A_inv b, ok.py:679: the cross-check kernel of the parity tests) ;
  * "exchange_tri" 0/1 = device groups / ranks: the factor exchange moves the packed UPPER BLOCK TRIANGLE of the inverse (block row I keeps its
- *   columns from 128 I on: Mp (Mp + 128) / 2 doubles, 264 MB instead of 520 MB at N = 8000) -- all the symmetric contraction reads, dense and
- *   range-aware -- packed on the leader / root (k_tri_pack, 0.1 ms), checksummed, unpacked into the members' matrices; their lower block triangle
- *   stays unwritten (mik_get_matrix mirrors it; "symmetric" 0 on such a member is refused).  1 (default) = wherever "symmetric" is 1, 0 = always
- *   the whole square.  mik_timing.exchange_bytes says what travelled [MIK_EXCHANGE_TRI] ;
+ *   columns from 128 I on: Mp (Mp + 128) / 2 doubles, 264 MB instead of 520 MB at N = 8000), packed on the leader / root (k_tri_pack, 0.1 ms),
+ *   checksummed, and on every member unpacked into its matrix and MIRRORED into the lower block triangle (two local kernels, 0.3 ms): the member
+ *   then holds the leader's matrix bit for bit.  That needs an inverse that is exactly symmetric by construction: every inverse the device computes
+ *   is (the half sweep mirrors its triangle; the full sweep, the pivoted elimination and the pseudo-inverses end in k_symmetrize).  1 (default) = the
+ *   triangle unless the inverse is the caller's (mik_problem.a_inv: used as handed over) or "symmetrize" is 0; 0 = always the whole square.
+ *   mik_timing.exchange_bytes says what travelled [MIK_EXCHANGE_TRI] ;
  * "sparse" -1/0/1/2 = range-aware contraction for variograms with compact support (the reference's spherical model is constant
  *   beyond its range, variogram_models.py:56-70).  With u = [1_N; 0] and s = psill + nugget the right-hand side is b = -s u + delta,
  *   delta_k = s - gamma(d_k) = 0 for every station beyond the range, and because A e_last = u:  z = c . delta  and

@@ -334,7 +334,7 @@ struct mik_handle {
                             // from 45 block columns on (the upper triangle no longer fits half of the 256 MB memory-side cache), 0 / 1
   // (Round 6 prune: the 256-column pivot sweep, the deep / prefetching / token-passing trailing updates, the tile map, the 4-wave update and
   // the one-tile panel kernel, the scalar-pivot diagonal inverses -- every one bit- or LAPACK-exact, none faster than what is here -- are no
-  // longer in the library: DESIGN_HISTORY.md section 12, tools/mik_k_experiments.h, git history.)
+  // longer in the library: DESIGN_HISTORY.md section 10, tools/mik_k_experiments.h, git history.)
   // points
   long npt_total = 0, npt = 0;
   bool masked = false;  // the caller's mask skipped at least one point: outputs are zero-filled before the scatter
@@ -396,10 +396,9 @@ struct mik_handle {
   std::shared_ptr<struct XchgJob> xjob;
   hipStream_t xstream = nullptr;  // this member's exchange stream (RCCL broadcast, checksums)
   DevBuf xsum;                 // 4 x u64: checksums of T and c after an exchange
-  // round 6: the exchange moves the packed upper block triangle of the inverse (k_tri_pack) when the contraction is the symmetric one
-  DevBuf xpack;                // tri_len(Mp) doubles: packed on the leader / root, received and unpacked into T on the others
-  int opt_exchange_tri = 1;    // "exchange_tri": 1 (default) = the triangle wherever the symmetric contraction runs, 0 = always the whole square
-  bool upper_only = false;     // this handle's T holds a received inverse whose lower block triangle was not sent (the full product must not read it)
+  // round 6: the exchange moves the packed upper block triangle of the inverse (k_tri_pack) wherever the inverse is exactly symmetric
+  DevBuf xpack;                // tri_len(Mp) doubles: packed on the leader / root; received, unpacked into T and mirrored on the others
+  int opt_exchange_tri = 1;    // "exchange_tri": 1 (default) = the triangle wherever the device computed the inverse (exactly symmetric), 0 = always the whole square
   bool xpack_valid = false;    // one process per GPU: xpack holds the packed triangle of the current factor (mik_factor_checksum sums it)
   double exchange_bytes = 0.0; // payload one member / rank received in the last exchange
   std::chrono::steady_clock::time_point xchg_t0;
@@ -480,7 +479,7 @@ inline bool want_sorted(const mik_handle* h) { return h->sort_ok && h->opt_spars
 int custom_roundtrip(mik_handle* h, double* dev, long rows, long cols, long ld);                                 // mikrige.hip
 int launch_assemble(mik_handle* h, double shift, double* dst = nullptr, bool sorted = false, bool eq = false);  // mikrige.hip
 int ensure_factor_buffers(mik_handle* h);                                                                        // mik_inverse.hip
-int mirror_upper_triangle(mik_handle* h);                                                                        // mik_inverse.hip
+int launch_mirror_upper(double* T, long Mp, hipStream_t st);                                                         // mik_inverse.hip
 int one_factor(mik_handle* h);                                                                                   // mik_inverse.hip
 int sort_points(mik_handle* h, long chunk, long nchunks);                                                        // mik_predict.hip
 int one_predict(mik_handle* h);                                                                                  // mik_predict.hip

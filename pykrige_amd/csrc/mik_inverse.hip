@@ -152,12 +152,12 @@ static int run_pseudo_inverse_scalar(mik_handle* h) {
   return MIK_OK;
 }
 
-// T's lower block triangle from its upper one (a rank that received the packed upper triangle hands out the whole inverse: mik_get_matrix)
-int mirror_upper_triangle(mik_handle* h) {
-  hipLaunchKernelGGL(k_mirror_upper, dim3(h->Mp / 64, h->Mp / 64), dim3(256), 0, h->stream, h->T.as<double>(), (long)h->Mp, h->Mp / 64);
+// T's lower block triangle from its upper one, on `st` of the current device: a group member / rank that received the packed upper block
+// triangle of an EXACTLY symmetric inverse (the half sweep mirrors its triangle, every other device path ends in k_symmetrize) rebuilds the
+// matrix the leader holds, bit for bit
+int launch_mirror_upper(double* T, long Mp, hipStream_t st) {
+  hipLaunchKernelGGL(k_mirror_upper, dim3((unsigned)(Mp / 64), (unsigned)(Mp / 64)), dim3(256), 0, st, T, Mp, (int)(Mp / 64));
   HIPC(hipGetLastError());
-  HIPC(hipStreamSynchronize(h->stream));
-  h->upper_only = false;
   return MIK_OK;
 }
 
@@ -867,7 +867,7 @@ int one_factor(mik_handle* h) {
   HIPC(hipSetDevice(h->device));
   h->t_state = 0;
   h->have_factor = false;
-  h->upper_only = h->xpack_valid = false;
+  h->xpack_valid = false;
   h->factor_sorted = want_sorted(h);
   h->factor_eq = h->drift_eq && h->opt_drift_eq;
   MIKC(ensure_factor_buffers(h));

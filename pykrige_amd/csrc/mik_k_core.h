@@ -140,11 +140,10 @@ __global__ void __launch_bounds__(256) k_checksum(const unsigned long long* __re
   }
 }
 
-// The factor exchange moves the UPPER BLOCK TRIANGLE of the inverse only (round 6): the symmetric contraction -- dense and range-aware --
-// reads A_inv[i][j] for block columns J >= I alone.  Packed layout: block row I (128 rows) keeps its columns [128 I, Mp), row-major, block
+// The factor exchange moves the UPPER BLOCK TRIANGLE of the inverse only (round 6): an inverse the device computed is exactly symmetric, the
+// receiver mirrors the lower block triangle (k_mirror_upper) and holds the sender's matrix bit for bit.  Packed layout: block row I (128 rows) keeps its columns [128 I, Mp), row-major, block
 // rows one after the other: tri_len(Mp) = Mp (Mp + 128) / 2 doubles (N = 8000: 264 MB instead of 520 MB).  One block per matrix row;
-// every segment starts on a 1 KB boundary and has an even length: double2 copies.  unpack = the way back into T (its lower block triangle
-// is left as it was: nothing on a group member reads it).
+// every segment starts on a 1 KB boundary and has an even length: double2 copies.  unpack = the way back into T.
 __host__ __device__ inline size_t tri_off(size_t Mp, size_t I) { return 128 * I * Mp - 8192 * (I * (I > 0 ? I - 1 : 0)); }
 __host__ __device__ inline size_t tri_len(size_t Mp) { return tri_off(Mp, Mp / 128); }
 __global__ void __launch_bounds__(256) k_tri_pack(double* __restrict__ T, size_t Mp, double* __restrict__ P, int unpack) {

@@ -389,9 +389,13 @@ __global__ void __launch_bounds__(256) k_ss_reduce(const double* __restrict__ pa
 __global__ void __launch_bounds__(128) k_sp_cand(const double* __restrict__ px, const double* __restrict__ py,
                                                  const double* __restrict__ pz, int nvalid, const double* __restrict__ sbox,
                                                  int nK16, int nforced_from, int nforced_to, double radius,
-                                                 unsigned char* __restrict__ cand, const unsigned* __restrict__ perm, int whole128) {
+                                                 unsigned char* __restrict__ cand, const unsigned* __restrict__ perm, int whole128,
+                                                 unsigned char* __restrict__ flags, int nKf) {
   __shared__ double red[6][2];
   const int tb = blockIdx.x, t = tb * 128 + threadIdx.x;
+  // the point block's row of flags (one byte per K tile of nKf, set by k_rhs behind this kernel on the stream): cleared here instead of by a
+  // memset of its own (round 6: one dispatch less on every launch's chain; nKf is a multiple of 8, the rows are 8-byte aligned)
+  for (int w = threadIdx.x; w < nKf / 8; w += 128) reinterpret_cast<unsigned long long*>(flags + (long)tb * nKf)[w] = 0ULL;
   const bool ok = t < nvalid;
   double lo[3], hi[3];
   const long ti = (ok && perm) ? (long)perm[t] : t;
@@ -851,87 +855,98 @@ __global__ void __launch_bounds__(64) k_sp_lists_g(const unsigned char* __restri
 //   [0] = {tblk << 10 | r, nk, klist[nk - 1], klist[nk - 2]}      [1] = the eight row groups klist[8 r .. 8 r + 7] (u16 each)
 // stats: [0] tiles, [1] off-diagonal K tiles summed over the tiles, [2] (row group, K tile) products of the triangular parts.
 // H8: a position is a dword of the list (two 8-station tiles), the record has three uint4: [1], [2] = the eight positions of the tile.
+// Round 6: one block per GROUP (round 5: one 1024-thread block for the whole launch, every thread writing its point block's records one after the
+// other -- 40 us alone, 280 us beside the other lane's k_rhs, on the critical chain of every launch: profiles/r06_predict_timeline_c5.txt).  Every
+// block recomputes the group offsets (8 KB of counts, L2-resident), then writes its own group's records, one (point block, tile) pair per thread;
+// block 0 also writes xoff / stats and zeroes the tile queues (the memset that used to sit between this kernel and the contraction).
 template <bool H8 = false>
-__global__ void __launch_bounds__(1024) k_sp_tiles_g(const int* __restrict__ ntiles, const int* __restrict__ kcount,
-                                                     const unsigned short* __restrict__ klist, int nK16, int nTblk,
-                                                     uint4* __restrict__ recs, int* __restrict__ xoff,
-                                                     unsigned long long* __restrict__ stats, int st) {
+__global__ void __launch_bounds__(256) k_sp_tiles_g(const int* __restrict__ ntiles, const int* __restrict__ kcount,
+                                                    const unsigned short* __restrict__ klist, int nK16, int nTblk,
+                                                    uint4* __restrict__ recs, int* __restrict__ xoff,
+                                                    unsigned long long* __restrict__ stats, int st, unsigned long long* __restrict__ queue) {
   // st = point blocks per group (option "sparse_group", 1 .. 16; 16 by default since round 5)
-  __shared__ int gcnt[1024 + 1], goff[1024 + 1], xtot[9];
+  __shared__ int gcnt[1024 + 1], goff[1024 + 1], xtot[9], nr[16], rowbase[256 + 1];
   __shared__ unsigned long long ksum, dsum;
   const int nG = (nTblk + st - 1) / st;
-  const int g = threadIdx.x;
-  if (g == 0) ksum = 0ULL, dsum = 0ULL;
-  __syncthreads();
-  if (g < nG) {
+  const int gg = blockIdx.x;
+  if (threadIdx.x == 0) ksum = 0ULL, dsum = 0ULL;
+  for (int g = threadIdx.x; g < nG; g += 256) {
     int c = 0;
-    unsigned long long ks = 0ULL, ds = 0ULL;
     for (int q = 0; q < st; ++q) {
       const int tb = g * st + q;
       if (tb >= nTblk) break;
-      const int nk = kcount[tb], full = nk / 8, rem = nk - 8 * full;
       c += ntiles[tb];
+    }
+    gcnt[g] = c;
+  }
+  if (threadIdx.x < 16) {
+    const int t2 = gg * st + (int)threadIdx.x;
+    nr[threadIdx.x] = ((int)threadIdx.x < st && t2 < nTblk) ? ntiles[t2] : 0;
+  }
+  __syncthreads();
+  if (threadIdx.x < 8) {  // exclusive scan of the groups of XCD x
+    int sum = 0;
+    for (int q = threadIdx.x; q < nG; q += 8) {
+      goff[q] = sum;
+      sum += gcnt[q];
+    }
+    xtot[threadIdx.x] = sum;
+  }
+  int maxnr = 0;
+#pragma unroll
+  for (int qq = 0; qq < 16; ++qq) maxnr = nr[qq] > maxnr ? nr[qq] : maxnr;
+  if (maxnr > 256) maxnr = 256;  // (ntiles <= Mp / 128 <= 181 while 32-bit DMA offsets address the inverse: the gathered form's own limit)
+  for (int r = threadIdx.x; r <= maxnr; r += 256) {  // rowbase[r] = records of this group in the tile positions below r
+    int b = 0;
+    for (int rr = 0; rr < r; ++rr)
+#pragma unroll
+      for (int qq = 0; qq < 16; ++qq) b += nr[qq] > rr ? 1 : 0;
+    rowbase[r] = b;
+  }
+  __syncthreads();
+  if (blockIdx.x == 0) {
+    unsigned long long ks = 0ULL, ds = 0ULL;
+    for (int tb = threadIdx.x; tb < nTblk; tb += 256) {
+      const int nk = kcount[tb], full = nk / 8, rem = nk - 8 * full;
       ks += (unsigned long long)((long)full * nk - 4L * full * (full + 1));  // sum over full tiles r of nk - 8 (r + 1)
       ds += (unsigned long long)(36 * full + rem * (rem + 1) / 2);
     }
-    gcnt[g] = c;
     atomicAdd(&ksum, ks);
     atomicAdd(&dsum, ds);
-  }
-  __syncthreads();
-  if (g < 8) {  // exclusive scan of the groups of XCD g
-    int s = 0;
-    for (int q = g; q < nG; q += 8) {
-      goff[q] = s;
-      s += gcnt[q];
+    if (threadIdx.x < 8) queue[threadIdx.x] = 0ULL;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int sum = 0;
+      for (int x = 0; x < 8; ++x) {
+        xoff[x] = sum;
+        sum += xtot[x];
+      }
+      xoff[8] = sum;
+      stats[0] = (unsigned long long)sum;
+      stats[1] = ksum;
+      stats[2] = dsum;
     }
-    xtot[g] = s;
   }
-  __syncthreads();
-  if (g == 0) {
-    int s = 0;
-    for (int x = 0; x < 8; ++x) {
-      const int c = xtot[x];
-      xoff[x] = s;
-      s += c;
-    }
-    xoff[8] = s;
-    stats[0] = (unsigned long long)s;
-    stats[1] = ksum;
-    stats[2] = dsum;
-  }
-  __syncthreads();
-  const int tb = threadIdx.x;  // one thread per point block writes that block's records
-  if (tb < nTblk) {
-    const int gg = tb / st, q = tb % st;
-    int xbase = 0;
-    for (int x = 0; x < (gg & 7); ++x) xbase += xtot[x];
-    int nr[16];
-    for (int qq = 0; qq < 16; ++qq) {
-      const int t2 = gg * st + qq;
-      nr[qq] = (qq < st && t2 < nTblk) ? ntiles[t2] : 0;
-    }
+  int w0 = goff[gg];
+  for (int x = 0; x < (gg & 7); ++x) w0 += xtot[x];
+  for (int idx = threadIdx.x; idx < 16 * maxnr; idx += 256) {  // one (point block q of the group, tile r) pair per thread, point block fast
+    const int q = idx & 15, r = idx >> 4;
+    if (r >= nr[q]) continue;
+    const int tb = gg * st + q;
+    int before = 0;
+#pragma unroll
+    for (int qq = 0; qq < 16; ++qq) before += (qq < q && nr[qq] > r) ? 1 : 0;
     const int nk = kcount[tb];
     const unsigned short* kl = klist + (long)tb * nK16;
     const unsigned* kl32 = reinterpret_cast<const unsigned*>(kl);
     const unsigned k1 = nk >= 1 ? (H8 ? kl32[nk - 1] : (unsigned)kl[nk - 1]) : 0u, k2 = nk >= 2 ? (H8 ? kl32[nk - 2] : (unsigned)kl[nk - 2]) : 0u;
-    int w = xbase + goff[gg];
-    for (int r = 0; r < nr[q]; ++r) {  // (tiles of the other point blocks beyond nr[q] lie behind this block's last one or belong to them)
-      int before = 0, all = 0;
-      for (int qq = 0; qq < 16; ++qq) {
-        const int on = nr[qq] > r ? 1 : 0;
-        all += on;
-        if (qq < q) before += on;
-      }
-      uint4* out = recs + (H8 ? 3L : 2L) * (w + before);
-      out[0] = make_uint4(((unsigned)tb << 10) | (unsigned)r, (unsigned)nk, k1, k2);
-      if (H8) {
-        out[1] = *reinterpret_cast<const uint4*>(kl + 16 * r);  // 32-byte aligned: the list stride is a multiple of 16
-        out[2] = *reinterpret_cast<const uint4*>(kl + 16 * r + 8);
-      } else {
-        out[1] = *reinterpret_cast<const uint4*>(kl + 8 * r);  // 16-byte aligned: nK16 is a multiple of 8
-      }
-      w += all;
+    uint4* out = recs + (H8 ? 3L : 2L) * (w0 + rowbase[r] + before);
+    out[0] = make_uint4(((unsigned)tb << 10) | (unsigned)r, (unsigned)nk, k1, k2);
+    if (H8) {
+      out[1] = *reinterpret_cast<const uint4*>(kl + 16 * r);  // 32-byte aligned: the list stride is a multiple of 16
+      out[2] = *reinterpret_cast<const uint4*>(kl + 16 * r + 8);
+    } else {
+      out[1] = *reinterpret_cast<const uint4*>(kl + 8 * r);  // 16-byte aligned: nK16 is a multiple of 8
     }
   }
 }

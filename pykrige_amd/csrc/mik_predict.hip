@@ -48,9 +48,6 @@ int sort_points(mik_handle* h, long chunk, long nchunks) {
 int one_predict(mik_handle* h) {
   if (!h || !h->have_factor) return fail(MIK_ESTATE, "mik_predict: factor first");
   if (!h->have_points) return fail(MIK_ESTATE, "mik_predict: set points first");
-  if (h->upper_only && !h->opt_sym)
-    return fail(MIK_ESTATE, "mik_predict: this device received only the upper block triangle of the inverse (the factor was exchanged for the symmetric "
-                            "contraction); the full product (\"symmetric\" 0) needs mik_factor again, or \"exchange_tri\" 0");
   HIPC(hipSetDevice(h->device));
   const long npt = h->npt;
   const int Mp = h->Mp, nIblk = Mp / 128;
@@ -227,8 +224,7 @@ int one_predict(mik_handle* h) {
         radius = radius >= 180.0 ? 4.0 : 2.0 * std::sin(radius * 3.14159265358979323846 / 360.0) * (1.0 + 1e-12) + 1e-15;
       }
       hipLaunchKernelGGL(k_sp_cand, dim3(palloc / 128), dim3(128), 0, ss, cx, cy, cz, nvalid, (const double*)h->sbox.as<double>(), nK16,
-                         h->N / 16, (h->M + 15) / 16, radius, ln.cand->as<unsigned char>(), a.perm, gathered ? 0 : 1);
-      HIPC(hipMemsetAsync(ln.flags->p, 0, (size_t)(palloc / 128) * nKt, ss));
+                         h->N / 16, (h->M + 15) / 16, radius, ln.cand->as<unsigned char>(), a.perm, gathered ? 0 : 1, ln.flags->as<unsigned char>(), nKt);
       HIPC(hipEventRecord(h->evpool[2 + 4 * c], ss));
       if (h8) {
         if (h->geo) hipLaunchKernelGGL((k_rhs<3, 1, true, true>), dim3(palloc / MIK_TP), dim3(256), 0, ss, a);
@@ -271,9 +267,9 @@ int one_predict(mik_handle* h) {
       if (gathered) {
         hipLaunchKernelGGL(k_sp_lists_g, dim3(nTb), dim3(64), 0, sc, (const unsigned char*)ln.flags->as<unsigned char>(), nKt,
                            ln.klist->as<unsigned short>(), ln.kcount->as<int>(), ln.nrows->as<int>(), h8 ? 1 : 0);
-        hipLaunchKernelGGL(k_sp_tiles_g<true>, dim3(1), dim3(1024), 0, sc, (const int*)ln.nrows->as<int>(), (const int*)ln.kcount->as<int>(),
-                           (const unsigned short*)ln.klist->as<unsigned short>(), nKt, nTb, ln.recs->as<uint4>(), ln.xoff->as<int>(),
-                           h->sp_stats.as<unsigned long long>() + 4 * c, h->opt_sparse_group);
+        hipLaunchKernelGGL(k_sp_tiles_g<true>, dim3((unsigned)((nTb + h->opt_sparse_group - 1) / h->opt_sparse_group)), dim3(256), 0, sc, (const int*)ln.nrows->as<int>(),
+                           (const int*)ln.kcount->as<int>(), (const unsigned short*)ln.klist->as<unsigned short>(), nKt, nTb, ln.recs->as<uint4>(),
+                           ln.xoff->as<int>(), h->sp_stats.as<unsigned long long>() + 4 * c, h->opt_sparse_group, ln.queue->as<unsigned long long>());
       } else {
         hipLaunchKernelGGL(k_sp_lists, dim3(nTb), dim3(64), 0, sc, (const unsigned char*)ln.flags->as<unsigned char>(), nK16, nIblk,
                            ln.klist->as<unsigned short>(), ln.kcount->as<int>(), ln.rows->as<unsigned short>(),
@@ -283,7 +279,7 @@ int one_predict(mik_handle* h) {
                            ln.xoff->as<int>(), h->sp_stats.as<unsigned long long>() + 4 * c);
       }
       HIPC(hipEventRecord(h->evpool[3 + 4 * nchunks + 2 * c], sc));
-      HIPC(hipMemsetAsync(ln.queue->p, 0, 8 * sizeof(unsigned long long), sc));
+      if (!gathered) HIPC(hipMemsetAsync(ln.queue->p, 0, 8 * sizeof(unsigned long long), sc));  // (gathered: k_sp_tiles_g zeroes the queues)
       SpArgs sa{};
       sa.Ainv = h->T.as<double>();
       sa.lda = Mp;

@@ -703,6 +703,11 @@ static int for_each_device(mik_handle* h, F fn) {
 // exchange = auto:  RCCL broadcast -> peer copies -> every member factors the matrix itself.  A forced path ("exchange"
 // 1 / 2) returns the error instead.  After every transfer each member's copy is CHECKSUMMED on its device against the
 // leader's (k_checksum: order-independent 2 x 64-bit sums of T and c); a mismatch counts as a failed exchange.
+// does the factor exchange move the packed upper block triangle?  Only an inverse that is exactly symmetric by construction: computed on the
+// device (not mik_problem.a_inv) with "symmetrize" on -- the half sweep mirrors its triangle whatever that option says, but whether it ran is known
+// on the root only, so the rule every rank can evaluate is the option.
+static bool exchange_triangle(const mik_handle* h) { return h->opt_exchange_tri && h->Mp > 128 && !h->host_inv && h->opt_symmetrize; }
+
 struct XchgMember {
   int device = 0;
   double* T = nullptr;
@@ -771,7 +776,10 @@ static int xchg_verify(XchgJob* j) {
     HIPC(hipMemsetAsync(d.sum_dev, 0, 4 * sizeof(unsigned long long), d.xs));
     hipLaunchKernelGGL(k_checksum, dim3(1024), dim3(256), 0, d.xs, (const unsigned long long*)d.X, j->xlen, d.sum_dev);
     hipLaunchKernelGGL(k_checksum, dim3(4), dim3(256), 0, d.xs, (const unsigned long long*)d.cvec, Mp, d.sum_dev + 2);
-    if (j->tri) hipLaunchKernelGGL(k_tri_pack, dim3((unsigned)Mp), dim3(256), 0, d.xs, d.T, Mp, d.X, 1);  // (checked below before anybody reads T)
+    if (j->tri) {  // (the sums are compared below, before anybody reads T) unpack, then the lower block triangle as the mirror image
+      hipLaunchKernelGGL(k_tri_pack, dim3((unsigned)Mp), dim3(256), 0, d.xs, d.T, Mp, d.X, 1);
+      MIKC(launch_mirror_upper(d.T, (long)Mp, d.xs));
+    }
     HIPC(hipGetLastError());
     HIPC(hipMemcpyAsync(j->sums.data() + 4 * i, d.sum_dev, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, d.xs));
   }
@@ -958,8 +966,10 @@ static int start_exchange(mik_handle* h, int path) {
   auto j = std::make_shared<XchgJob>();
   j->path = path;
   j->Mp = (size_t)h->Mp;
-  // the symmetric contraction (dense and range-aware) reads the upper block triangle of the inverse only: that is what travels
-  j->tri = h->opt_exchange_tri && h->opt_sym && h->Mp > 128;
+  // an inverse the device computed is EXACTLY symmetric (the half sweep mirrors its triangle; the full sweep, the pivoted elimination and the
+  // pseudo-inverses end in k_symmetrize): its upper block triangle travels, the members mirror it.  Not a caller's inverse (used as handed
+  // over, never symmetrized) nor "symmetrize" 0.
+  j->tri = exchange_triangle(h);
   j->xlen = j->tri ? tri_len(j->Mp) : j->Mp * j->Mp;
   j->mem.resize(n);
   for (int i = 0; i < n; ++i) {
@@ -1070,7 +1080,6 @@ static int join_exchange(mik_handle* h) {
       h->exchange_ms = std::chrono::duration<double, std::milli>(j->t_done - h->xchg_t0).count();
       h->exchange_bytes = sizeof(double) * (double)(j->xlen + j->Mp);
       mark_kids_factored(h);
-      for (mik_handle* k : h->kids) k->upper_only = j->tri;
       break;
     }
     ++h->exchange_fallbacks;
@@ -1194,11 +1203,6 @@ int mik_get_matrix(mik_handle* h, int which, double* out) {
   if (which == 1 && !h->have_factor) return fail(MIK_ESTATE, "mik_get_matrix: not factored");
   MIKC(join_exchange(h));
   HIPC(hipSetDevice(h->device));
-  if (which == 1 && h->upper_only) {
-    // this rank received the packed upper block triangle only (mik_bcast_factor): the inverse is symmetric -- the half sweep mirrors its
-    // triangle, every other path ends symmetrized -- so the lower one is its mirror image
-    MIKC(mirror_upper_triangle(h));
-  }
   if (which == 1 && (h->factor_sorted || h->factor_eq)) {
     // the factor is in Hilbert-curve station order and / or of the matrix with equilibrated drift rows A' = S A S^T: hand out
     // A^-1 = S^T A'^-1 S in the caller's station order.  S = I except S[N + j][N + j] = s_j, S[N + j][M - 1] = -s_j c_j.
@@ -1973,8 +1977,9 @@ int mik_bcast_factor(mik_handle* h, int root) {
   HIPC(hipStreamSynchronize(h->stream));  // the broadcast runs on the exchange stream: the factor (root) / earlier reads are done
   const size_t Mp = h->Mp;
   const int dev = h->device;
-  // every rank decides by the same rule on the same options: the packed upper block triangle travels wherever the symmetric contraction runs
-  const bool tri = h->opt_exchange_tri && h->opt_sym && Mp > 128;
+  // every rank decides by the same rule on the same problem and options: the packed upper block triangle of an exactly symmetric inverse
+  // (exchange_triangle; the half-sweep choice is a function of the model and the size, the same on every rank)
+  const bool tri = exchange_triangle(h);
   const size_t xlen = tri ? tri_len(Mp) : Mp * Mp;
   if (tri) {
     MIKC(h->xpack.ensure(sizeof(double) * xlen));
@@ -1995,7 +2000,10 @@ int mik_bcast_factor(mik_handle* h, int root) {
     HIPC(hipSetDevice(dev));
     NCCLC(g_rccl.Broadcast(X, X, xlen, ncclDouble, root, comm, xs));
     NCCLC(g_rccl.Broadcast(cv, cv, Mp, ncclDouble, root, comm, xs));
-    if (unpack) hipLaunchKernelGGL(k_tri_pack, dim3((unsigned)Mp), dim3(256), 0, xs, T, Mp, X, 1);
+    if (unpack) {
+      hipLaunchKernelGGL(k_tri_pack, dim3((unsigned)Mp), dim3(256), 0, xs, T, Mp, X, 1);
+      MIKC(launch_mirror_upper(T, (long)Mp, xs));
+    }
     HIPC(hipStreamSynchronize(xs));
     return MIK_OK;
   }, h->rccl_bcast_limit, "ncclBroadcast of the factor", &timed_out);
@@ -2019,7 +2027,6 @@ int mik_bcast_factor(mik_handle* h, int root) {
   h->t_state = 2;
   h->have_results = false;
   h->xpack_valid = tri;
-  h->upper_only = unpack;
   h->exchange_bytes = sizeof(double) * (double)(xlen + Mp);
   return MIK_OK;
 }

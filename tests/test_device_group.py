@@ -97,10 +97,12 @@ def test_group_matches_one_device_bit_for_bit(members, exchange):
 @pytest.mark.gpu
 @pytest.mark.parametrize("members", [2, 3, 8])
 def test_the_exchange_moves_the_upper_block_triangle_only(members):
-    """Round 6: the symmetric contraction -- dense and range-aware -- reads block columns J >= I of the inverse only, so the exchange packs
-    the upper block triangle (k_tri_pack), moves Mp (Mp + 128) / 2 doubles instead of Mp^2, checksums the packed buffer and unpacks it on
-    the members.  Same bits as one device and as the whole-square exchange ("exchange_tri" 0); the bytes are reported and (nearly)
-    halved; a member that holds a triangle refuses the full product (its lower block triangle is never written: whatever the allocation held)."""
+    """Round 6: an inverse the device computed is exactly symmetric (the half sweep mirrors its triangle, every other path ends in
+    k_symmetrize), so the exchange packs the upper block triangle (k_tri_pack), moves Mp (Mp + 128) / 2 doubles instead of Mp^2, checksums
+    the packed buffer, and the members unpack it and mirror it (two local kernels).  Same bits as one device and as the whole-square
+    exchange ("exchange_tri" 0) -- also for the kernels that read below the diagonal (the full product "symmetric" 0; the range-aware
+    contraction's 16 x 16 squares of 8-station pairs from different row blocks, on grid-ordered points); the bytes are reported and
+    (nearly) halved; "symmetrize" 0 (an inverse that is symmetric only to rounding) moves the square."""
     lib = _lib()
     rng = np.random.default_rng(5)
     pts = [rng.random(6000), rng.random(6000)]
@@ -116,20 +118,38 @@ def test_the_exchange_moves_the_upper_block_triangle_only(members):
             hg.set_devices(members, alias=True)
             hg.set_option("exchange_tri", tri)
             hg.set_option("sort_points", 0)  # (the range-aware path: slabs cut at multiples of 128 points in the caller's order keep the blocks, hence the bits)
+            hg.set_option("symmetrize", 1)
+            hg.set_option("symsweep", -1)
             zg, sg = _run(hg, c, v, model, params, pts)
             t = hg.timing()
             assert t["exchange_path"] in (1, 2) and t["exchange_fallbacks"] <= 1, t
             assert t["exchange_bytes"] == 8.0 * ((mp * (mp + 128) // 2 if tri else mp * mp) + mp), (t["exchange_bytes"], mp)
             out[tri] = (zg, sg)
             if tri:
-                hg.set_option("symmetric", 0)  # the members hold a triangle: the full product must not run on it
-                with pytest.raises(RuntimeError, match="upper block triangle"):
-                    hg.predict()
-                hg.set_option("symmetric", 1)
-                hg.factor()  # and a new factor + exchange puts everything right again
+                # the full product reads the whole matrix: the members' mirrored lower triangles are the leader's, bit for bit
+                h1 = lib.Handle(0)
+                h1.set_option("symmetric", 0)
+                zf1, sf1 = _run(h1, c, v, model, params, pts)
+                h1.close()
+                hg.set_option("symmetric", 0)
                 hg.predict()
-                z2, s2 = hg.get_results()
-                assert np.array_equal(z2, zg) and np.array_equal(s2, sg)
+                zf, sf = hg.get_results()
+                assert np.array_equal(zf, zf1) and np.array_equal(sf, sf1)
+                hg.set_option("symmetric", 1)
+                # points in grid order (partial station lists per 128-point block: the range-aware contraction pairs 8-station tiles of different row blocks)
+                gx, gy = np.meshgrid(np.linspace(0, 1, 140), np.linspace(0, 1, 37))
+                gp = [gx.ravel(), gy.ravel()]
+                h1 = lib.Handle(0)
+                h1.set_option("sort_points", 0)
+                zq1, sq1 = _run(h1, c, v, model, params, gp)
+                h1.close()
+                zq, sq = _run(hg, c, v, model, params, gp)
+                assert np.array_equal(zq, zq1) and np.array_equal(sq, sq1)
+                # an inverse that is symmetric only to rounding travels whole
+                hg.set_option("symmetrize", 0)
+                hg.set_option("symsweep", 0)
+                _run(hg, c, v, model, params, pts)
+                assert hg.timing()["exchange_bytes"] == 8.0 * (mp * mp + mp)
             hg.close()
         assert np.array_equal(out[1][0], out[0][0]) and np.array_equal(out[1][1], out[0][1])
         if model == "exponential":

@@ -227,7 +227,7 @@ for h in hs:
     h.set_points(pts[0], pts[1])
     h.predict()
     res.append(h.get_results())
-a0, a1 = hs[0].get_matrix(1), hs[1].get_matrix(1)  # the member mirrors the triangle it received
+a0, a1 = hs[0].get_matrix(1), hs[1].get_matrix(1)  # the member mirrored the triangle it received: the root's matrix, bit for bit
 print("RESULT " + json.dumps(dict(sums_equal=sums[0] == sums[1], same=bool(np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])),
                                   bytes=[h.timing()["exchange_bytes"] for h in hs], matrix_gap=float(np.abs(a0 - a1).max() / np.abs(a0).max()),
                                   symmetric=bool(np.array_equal(a1, a1.T)))))
@@ -239,8 +239,8 @@ print("RESULT " + json.dumps(dict(sums_equal=sums[0] == sums[1], same=bool(np.ar
 def test_rank_broadcast_moves_the_upper_block_triangle(model, params, n):
     """One process per GPU (mik_comm_init + mik_bcast_factor, what `torch.distributed.run bench.py` drives): round 6 broadcasts the packed upper
     block triangle.  Two ranks in one process over the stand-in RCCL: the ranks' checksums (of the packed triangle) agree, the non-root
-    rank kriges bit-identically from the unpacked triangle (dense contraction at 11 block columns, range-aware and the half sweep at 26),
-    mik_get_matrix on it mirrors the triangle, and the bytes are those of the triangle; "exchange_tri" 0 moves the square."""
+    rank unpacks and mirrors it and kriges bit-identically (dense contraction at 11 block columns, range-aware and the half sweep at 26),
+    its matrix is the root's bit for bit, and the bytes are those of the triangle; "exchange_tri" 0 moves the square."""
     import json
 
     _, hip = _standins()
@@ -254,4 +254,4 @@ def test_rank_broadcast_moves_the_upper_block_triangle(model, params, n):
         assert o["sums_equal"] and o["same"], o
         want = 8.0 * ((mp * (mp + 128) // 2 if tri else mp * mp) + mp)
         assert o["bytes"] == [want, want], (o, want)
-        assert o["matrix_gap"] <= 1e-12, o  # (exact zero for the half sweep: its triangle is mirrored on the root too)
+        assert o["matrix_gap"] == 0.0 and o["symmetric"], o
