@@ -297,6 +297,11 @@ int one_predict(mik_handle* h) {
       sa.tiles = ln.tiles->as<unsigned>();
       sa.xoff = ln.xoff->as<int>();
       sa.queue = ln.queue->as<unsigned long long>();
+      // two lanes: the CONTRACTIONS run one after the other (this one behind the other lane's previous one); what overlaps a contraction is the
+      // other lane's candidate / right-hand-side / list kernels in its tail.  Two persistent launches side by side share every CU and mix two
+      // tile queues in every XCD's L2: measured 3.5 % slower per pair (profiles/r06_predict_timeline_c5.txt; rounds 4-5 got this order by accident:
+      // the queue memset in front of the contraction waited for a free CU).
+      if (lanes2 && c > 0) HIPC(hipStreamWaitEvent(sc, h->evpool[5 + 4 * (c - 1)], 0));
       HIPC(hipEventRecord(e1, sc));
       if (gathered) {
         SpgArgs ga{};

@@ -127,14 +127,15 @@ def test_the_exchange_moves_the_upper_block_triangle_only(members):
             out[tri] = (zg, sg)
             if tri:
                 # the full product reads the whole matrix: the members' mirrored lower triangles are the leader's, bit for bit
-                h1 = lib.Handle(0)
-                h1.set_option("symmetric", 0)
-                zf1, sf1 = _run(h1, c, v, model, params, pts)
-                h1.close()
+                hf = lib.Handle(0)
+                hf.set_option("symmetric", 0)
+                zf1, sf1 = (a.copy() for a in _run(hf, c, v, model, params, pts))
                 hg.set_option("symmetric", 0)
                 hg.predict()
                 zf, sf = hg.get_results()
-                assert np.array_equal(zf, zf1) and np.array_equal(sf, sf1)
+                assert np.array_equal(zf, zf1) and np.array_equal(sf, sf1), (np.abs(zf - zf1).max(), np.abs(sf - sf1).max(), np.abs(zf - zg).max(),
+                                                                             np.abs(zf1 - z1).max())
+                hf.close()
                 hg.set_option("symmetric", 1)
                 # points in grid order (partial station lists per 128-point block: the range-aware contraction pairs 8-station tiles of different row blocks)
                 gx, gy = np.meshgrid(np.linspace(0, 1, 140), np.linspace(0, 1, 37))
