@@ -39,10 +39,12 @@ __host__ __device__ inline double entry(int k, int n4, int r, int c, int pt) {
 
 template <int NB> struct Lay {
   static constexpr int NG = (NB + 3) / 4;
-  static constexpr int base(int J) { int s = 0; for (int j = 0; j < J; ++j) s += NG - j / 4; return s; }
+  // slots before row J: sum_{j < J} (NG - j / 4), in closed form (q = J / 4 whole groups of four rows, then J % 4 rows of the next)
+  static constexpr int base(int J) { return 4 * (J / 4) * NG - 2 * (J / 4) * (J / 4 - 1) + (J % 4) * (NG - J / 4); }
   static constexpr int idx(int J, int Ig) { return base(J) + Ig - J / 4; }
   static constexpr int NSLOT = base(NB);
 };
+static_assert(Lay<26>::NSLOT == 110 && Lay<14>::NSLOT == 38 && Lay<26>::base(5) == 4 * 7 + 6, "slot layout");
 
 __device__ __forceinline__ double bperm(int addr, double v) {
   const int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(v)), hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(v));
@@ -77,8 +79,6 @@ __global__ void __launch_bounds__(256, WPS) k_ldl(int k, int npts, double* __res
     for (int p = 0; p < NB - 1; ++p) {
       // ---- S = A_pp^-1: the block sits in slot (p, p / 4), position p % 4, lanes 16 i + 4 (p % 4) + j
       const double d = s[L::idx(p, p / 4)];
-      constexpr int dummy = 0;
-      (void)dummy;
       const int b0 = 4 * (p & 3);
       double S00, S01, S02, S03, S11, S12, S13, S22, S23, S33;
       if (MODE == 2) {
