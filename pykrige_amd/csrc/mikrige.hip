@@ -1796,16 +1796,17 @@ void mik_release_results(double* z) {
   if (it == g_pin_lent.end()) return;
   const size_t bytes = it->second;
   g_pin_lent.erase(it);
-  // the pool keeps the most recently returned buffers (at most 6, 2 GB together): a full pool gives up its OLDEST entries for the newcomer.
-  // (Round 5 refused the newcomer instead: after a run over several grid sizes the pool held six stale sizes, and every call of the current
-  // size paid a hipHostFree + hipHostMalloc of its landing zone -- 3 ms per execute() of 10^6 points, the "host side" of the k = 10 bench line.)
-  if (bytes > (size_t)2 << 30) {
+  // the pool keeps the most recently returned buffers (at most 16, 4 GB together): a full pool gives up its OLDEST entries for the newcomer.
+  // (Round 5 kept six and refused the newcomer: after a run over several grid sizes the pool held six stale sizes, and every call of the
+  // current size paid a hipHostFree + hipHostMalloc of its landing zone -- both synchronise the device -- 3 ms per execute() of 10^6 points: the
+  // "host side" of the k = 10 bench line, scripts/r06_diag_mw10.py.)
+  if (bytes > (size_t)4 << 30) {
     (void)hipHostFree(z);
     return;
   }
   size_t pooled = bytes;
   for (auto& e : g_pin_pool) pooled += e.second;
-  while (!g_pin_pool.empty() && (g_pin_pool.size() >= 6 || pooled > (size_t)2 << 30)) {
+  while (!g_pin_pool.empty() && (g_pin_pool.size() >= 16 || pooled > (size_t)4 << 30)) {
     pooled -= g_pin_pool.front().second;
     (void)hipHostFree(g_pin_pool.front().first);
     g_pin_pool.erase(g_pin_pool.begin());

@@ -38,6 +38,24 @@ line("again")
 for cno in (3, 4, 5):
     bench.other_config_line(cno, None, steps=1, warmup=1)
     line("after config %d" % cno)
+# where the time of a step goes in that state: cProfile over 8 more calls
+import cProfile, io, pstats
+cfg2 = bench.CONFIGS[2]
+co, va = bench.synth(cfg2["seed"], cfg2["n"], 2)
+mm = bench.make_model(cfg2, co, va)
+ax = bench.grid_axes(cfg2, 1)
+for _ in range(2):
+    mm.execute("grid", *ax, backend="loop", n_closest_points=10)
+pr = cProfile.Profile()
+t0 = time.perf_counter()
+pr.enable()
+for _ in range(8):
+    mm.execute("grid", *ax, backend="loop", n_closest_points=10)
+pr.disable()
+print("8 calls: %.3f ms per call" % ((time.perf_counter() - t0) / 8 * 1e3))
+st = io.StringIO()
+pstats.Stats(pr, stream=st).sort_stats("tottime").print_stats(12)
+print("\n".join(st.getvalue().splitlines()[4:26]))
 cfg = bench.CONFIGS[2]
 coords, values = bench.synth(cfg["seed"], cfg["n"], 2)
 m = bench.make_model(cfg, coords, values)
