@@ -30,26 +30,97 @@ def slab_plan(axes, target_points):
     return [(list(axes[:-1]) + [slow[s:s + step]], slice(s, min(s + step, slow.size))) for s in range(0, slow.size, step)]
 
 
-def compare(ref_model, z_gpu, ss_gpu, axes, target_points, budget_s=None, backend="vectorized", log=None):
+# ---- several reference processes side by side.  The reference's _exec_vector is mostly SINGLE-THREADED NumPy / SciPy (cdist, the variogram's exp
+# over npt x N, three passes over the npt x N products: ok.py:669-681); only its np.dot uses the BLAS threads.  One process therefore leaves a 64-core
+# host idle most of the time (5.6 k points/s at config 2); W processes with cores / W BLAS threads each krige W slabs at once.  Every process builds
+# the reference model from the same recipe and runs the reference's own execute() unmodified.
+_WORKER = {}
+
+
+def _worker_init(recipe, threads):
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    try:
+        import threadpoolctl
+
+        _WORKER["limit"] = threadpoolctl.threadpool_limits(limits=max(1, int(threads)))
+    except Exception:  # noqa: BLE001
+        pass
+    import bench
+    from oracle import ref_package as rp
+
+    cfg, coords, values = recipe
+    _WORKER["model"] = bench.reference_model(rp.import_reference(stub_statistics=True), cfg, coords, values)
+
+
+def _worker_slab(job):
+    i, slab_axes, backend = job
+    t1 = time.perf_counter()
+    zr, sr = _WORKER["model"].execute("grid", *slab_axes, backend=backend)
+    return i, np.ma.getdata(zr), np.ma.getdata(sr), time.perf_counter() - t1
+
+
+def _slab_results(ref_model, plan, order, backend, budget_s, recipe, workers):
+    """(i, zr, sr, seconds) of the slabs in `order`, as far as `budget_s` reaches (whole slabs, at least one)."""
+    t0 = time.perf_counter()
+    if not recipe or workers <= 1 or len(order) < 2:
+        last, n = 0.0, 0
+        for i in order:
+            if budget_s is not None and n and time.perf_counter() - t0 + last > budget_s:
+                return
+            t1 = time.perf_counter()
+            zr, sr = ref_model.execute("grid", *plan[i][0], backend=backend)
+            last = time.perf_counter() - t1
+            n += 1
+            yield i, np.ma.getdata(zr), np.ma.getdata(sr), last
+        return
+    import multiprocessing as mp
+    import os
+
+    workers = min(workers, len(order))
+    threads = max(1, (os.cpu_count() or 1) // workers)
+    ctx = mp.get_context("spawn")  # (never fork a process that holds a HIP runtime)
+    pool = ctx.Pool(workers, initializer=_worker_init, initargs=(recipe, threads))
+    try:
+        pending, it, longest = [], iter(order), 0.0
+        for _ in range(workers):
+            i = next(it, None)
+            if i is not None:
+                pending.append(pool.apply_async(_worker_slab, ((i, plan[i][0], backend),)))
+        done = 0
+        while pending:
+            res = pending.pop(0).get()
+            longest = max(longest, res[3])
+            done += 1
+            yield res
+            # a new slab only if it can be expected to finish inside the budget (slabs take about as long as the longest one seen)
+            if budget_s is None or time.perf_counter() - t0 + longest <= budget_s:
+                i = next(it, None)
+                if i is not None:
+                    pending.append(pool.apply_async(_worker_slab, ((i, plan[i][0], backend),)))
+    finally:
+        pool.terminate()
+        pool.join()
+
+
+def compare(ref_model, z_gpu, ss_gpu, axes, target_points, budget_s=None, backend="vectorized", log=None, recipe=None, workers=1):
     """Krige the grid `axes` with the reference model slab by slab and compare with the drop-in's whole-grid result (arrays shaped
     as the reference returns them: [y, x] or [z, y, x]).  Returns a dict of scalars; stops early (whole slabs only, at least one)
-    when the next slab would overrun `budget_s`."""
+    when the next slab would overrun `budget_s`.  recipe = (cfg, coords, values) + workers > 1: that many reference processes side by side
+    (each builds bench.reference_model(cfg, coords, values) and runs its execute() as written)."""
     plan = slab_plan(axes, target_points)
     z_gpu, ss_gpu = np.ma.getdata(z_gpu), np.ma.getdata(ss_gpu)
     total = int(np.prod([a.size for a in axes]))
     assert z_gpu.shape == tuple(a.size for a in reversed(axes)), (z_gpu.shape, [a.size for a in axes])
     out = {"points_total": total, "points_checked": 0, "slabs_total": len(plan), "slabs_checked": 0, "max_abs_dz": 0.0, "max_abs_dss": 0.0,
-           "worst_dz_at": None, "worst_dss_at": None, "backend": backend}
+           "worst_dz_at": None, "worst_dss_at": None, "backend": backend, "reference_processes": max(1, workers if recipe else 1)}
     t0 = time.perf_counter()
-    last = 0.0
-    for i in spread_order(len(plan)):
-        if budget_s is not None and out["slabs_checked"] and time.perf_counter() - t0 + last > budget_s:
-            break
+    for i, zr, sr, last in _slab_results(ref_model, plan, spread_order(len(plan)), backend, budget_s, recipe, workers):
         slab_axes, sl = plan[i]
-        t1 = time.perf_counter()
-        zr, sr = ref_model.execute("grid", *slab_axes, backend=backend)
-        last = time.perf_counter() - t1
-        zr, sr = np.ma.getdata(zr), np.ma.getdata(sr)
         dz, ds = np.abs(z_gpu[sl] - zr), np.abs(ss_gpu[sl] - sr)
         if not (np.isfinite(dz).all() and np.isfinite(ds).all()):
             dz, ds = np.where(np.isfinite(dz), dz, np.inf), np.where(np.isfinite(ds), ds, np.inf)
