@@ -82,9 +82,21 @@ def _slab_results(ref_model, plan, order, backend, budget_s, recipe, workers):
     import os
 
     workers = min(workers, len(order))
-    threads = max(1, (os.cpu_count() or 1) // workers)
+    # 8 BLAS threads per process, set through the ENVIRONMENT the children are born with: OpenBLAS then creates 8 threads, not 64 that spin between
+    # calls (8 processes x 32 threads limited after the fact took 1 000 s per slab instead of 9 on the 256-CPU box: profiles/r06_full_grid_parity.txt)
+    threads = max(1, min(8, (os.cpu_count() or 1) // workers))
+    saved = {k: os.environ.get(k) for k in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS")}
+    for k in saved:
+        os.environ[k] = str(threads)
     ctx = mp.get_context("spawn")  # (never fork a process that holds a HIP runtime)
-    pool = ctx.Pool(workers, initializer=_worker_init, initargs=(recipe, threads))
+    try:
+        pool = ctx.Pool(workers, initializer=_worker_init, initargs=(recipe, threads))
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     try:
         pending, it, longest = [], iter(order), 0.0
         for _ in range(workers):
