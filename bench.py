@@ -497,13 +497,13 @@ def full_grid_parity(cno, budget_s=None, log=None):
            "grid": [int(a.size) for a in axes], "gpu_execute_s": t_gpu, "gpu_contraction": "range-aware" if tm.get("sparse") else "dense",
            "cond_1": fg.cond_1(rm, *((n, n + extra) if extra else (n,)))}
     # the reference side: several reference processes side by side (its _exec_vector is mostly single-threaded NumPy: one process leaves a 64-core
-    # host idle), as many as cores / 32 and memory allow (6 temporaries of npt x N doubles per slab, ok.py:669-681)
+    # host idle), up to eight, as cores / 16 and memory allow (6 temporaries of npt x N doubles per slab, ok.py:669-681)
     need = 6 * 8 * FULL_GRID[cno]["target"] * (n + 1) * 1.5
     try:
         avail = [int(ln.split()[1]) * 1024 for ln in open("/proc/meminfo") if ln.startswith("MemAvailable")][0]
     except Exception:  # noqa: BLE001
         avail = 16 << 30
-    workers = int(max(1, min(8, (os.cpu_count() or 1) // 32, avail * 0.5 // need)))
+    workers = int(max(1, min(8, (os.cpu_count() or 1) // 16, avail * 0.5 // need)))
     if os.environ.get("MIK_FULLGRID_WORKERS"):
         workers = max(1, int(os.environ["MIK_FULLGRID_WORKERS"]))
     res.update(fg.compare(rm, z, ss, axes, FULL_GRID[cno]["target"], budget_s=budget_s, log=log, recipe=(cfg, coords, values), workers=workers))

@@ -64,10 +64,37 @@ def _worker_slab(job):
     return i, np.ma.getdata(zr), np.ma.getdata(sr), time.perf_counter() - t1
 
 
+def _make_pool(recipe, workers):
+    import multiprocessing as mp
+    import os
+
+    # 8 BLAS threads per process, set through the ENVIRONMENT the children are born with: OpenBLAS then creates 8 threads, not 64 that spin between
+    # calls (8 processes x 32 threads limited after the fact took 1 000 s per slab instead of 9 on the 256-CPU box: profiles/r06_full_grid_parity.txt)
+    threads = max(1, min(8, (os.cpu_count() or 1) // workers))
+    saved = {k: os.environ.get(k) for k in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS")}
+    for k in saved:
+        os.environ[k] = str(threads)
+    ctx = mp.get_context("spawn")  # (never fork a process that holds a HIP runtime)
+    try:
+        return ctx.Pool(workers, initializer=_worker_init, initargs=(recipe, threads))
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 def _slab_results(ref_model, plan, order, backend, budget_s, recipe, workers):
     """(i, zr, sr, seconds) of the slabs in `order`, as far as `budget_s` reaches (whole slabs, at least one)."""
     t0 = time.perf_counter()
-    if not recipe or workers <= 1 or len(order) < 2:
+    pool = None
+    if recipe and workers > 1 and len(order) >= 2:
+        try:
+            pool = _make_pool(recipe, min(workers, len(order)))
+        except Exception:  # noqa: BLE001  (no processes to be had: one process, as before)
+            pool = None
+    if pool is None:
         last, n = 0.0, 0
         for i in order:
             if budget_s is not None and n and time.perf_counter() - t0 + last > budget_s:
@@ -78,25 +105,6 @@ def _slab_results(ref_model, plan, order, backend, budget_s, recipe, workers):
             n += 1
             yield i, np.ma.getdata(zr), np.ma.getdata(sr), last
         return
-    import multiprocessing as mp
-    import os
-
-    workers = min(workers, len(order))
-    # 8 BLAS threads per process, set through the ENVIRONMENT the children are born with: OpenBLAS then creates 8 threads, not 64 that spin between
-    # calls (8 processes x 32 threads limited after the fact took 1 000 s per slab instead of 9 on the 256-CPU box: profiles/r06_full_grid_parity.txt)
-    threads = max(1, min(8, (os.cpu_count() or 1) // workers))
-    saved = {k: os.environ.get(k) for k in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS")}
-    for k in saved:
-        os.environ[k] = str(threads)
-    ctx = mp.get_context("spawn")  # (never fork a process that holds a HIP runtime)
-    try:
-        pool = ctx.Pool(workers, initializer=_worker_init, initargs=(recipe, threads))
-    finally:
-        for k, v in saved.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
     try:
         pending, it, longest = [], iter(order), 0.0
         for _ in range(workers):
@@ -105,7 +113,7 @@ def _slab_results(ref_model, plan, order, backend, budget_s, recipe, workers):
                 pending.append(pool.apply_async(_worker_slab, ((i, plan[i][0], backend),)))
         done = 0
         while pending:
-            res = pending.pop(0).get()
+            res = pending.pop(0).get(timeout=1800)  # (a worker that cannot start never answers: an error, not a hang)
             longest = max(longest, res[3])
             done += 1
             yield res
