@@ -6,6 +6,10 @@
 #   bench       the default bench run (config 2 + other configs + CPU leg + bounded whole-grid parity + live PMC)
 #   first       env + tests + fullparity + bench (the round's first contact)
 #   evidence    end-of-round: env, tests, bench, kernel stats + PMC passes of configs 2 and 5, aliased 8-member group at config 5
+#   timeline    kernel trace of a config-5 prediction -> scripts/predict_timeline.py (profiles/r06_predict_timeline_c5_*.txt)
+#   gates       tools/mw_ldl_bench (moving-window elimination on the matrix cores), tools/kernel_bench (B tile on the VALU), scripts/r06_diag_mw10.py
+# (the round's one-shot batches -- suite after the prune, exchange tests, A/Bs of the range-aware prediction -- ran through this script as
+#  scripts/r06_<stage>.sh files that are gone again; their outputs are under profiles/r06_*)
 STAGE=${1:-tests}; TAG=${2:-$STAGE}; OUT=$PWD/gpurun_out/r06_$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 REPO=$PWD
@@ -45,6 +49,18 @@ evidence)
   timeout 500 python bench.py --steps 3 --warmup 1 --config 5 --no-other > $OUT/bench_c5.json 2>> $OUT/bench.err; cut -c1-160 $OUT/bench_c5.json
   profile 2; profile 5
   timeout 400 python bench.py --gpus 8 --config 5 --steps 2 --warmup 1 --no-cpu > $OUT/bench_g8_c5.json 2>> $OUT/bench.err; cut -c1-160 $OUT/bench_g8_c5.json
+  ;;
+timeline)
+  cd /tmp
+  timeout 400 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_c5 -o t -- python $REPO/bench.py --config 5 --steps 2 --warmup 1 --no-cpu --pmc off --no-other > $OUT/trace_c5.json 2> $OUT/trace_c5.err
+  cd $REPO
+  python scripts/predict_timeline.py $OUT/trace_c5 full > $OUT/predict_timeline_c5.txt 2>&1; head -24 $OUT/predict_timeline_c5.txt | cut -c1-200
+  rm -rf $OUT/trace_c5
+  ;;
+gates)
+  timeout 300 ./tools/mw_ldl_bench 200000 > $OUT/mw_ldl_bench.txt 2>&1; cat $OUT/mw_ldl_bench.txt | cut -c1-300
+  timeout 300 ./tools/kernel_bench 5120 32768 > $OUT/kernel_bench_c2.txt 2>&1; grep -E "ablate 8-wave" $OUT/kernel_bench_c2.txt
+  timeout 900 python scripts/r06_diag_mw10.py > $OUT/diag_mw10.txt 2>&1; cut -c1-300 $OUT/diag_mw10.txt
   ;;
 *) if [ -f scripts/r06_$STAGE.sh ]; then OUT=$OUT bash scripts/r06_$STAGE.sh; else echo "unknown stage $STAGE"; exit 2; fi;;
 esac
