@@ -347,6 +347,8 @@ int one_predict(mik_handle* h) {
             fprintf(stderr, "   per off-diagonal step %.0f cycles\n", sum[1] / std::max(1.0, sum[9]));
           }
         } else
+        // (2 n_cu persistent blocks: leaving 32 .. 128 of the slots to the other lane's preparation kernels was tried -- they then run beside the
+        // contraction at a fraction of the chip -- and measured a tie at 32 and 1 - 3 % slower beyond: profiles/r06_predict_timeline_c5_after.txt)
         hipLaunchKernelGGL((k_contract_spg<2, true, true>), dim3((unsigned)std::min<long>(2L * h->n_cu, (long)nTb * nIblk)), dim3(512), 0, sc, ga);
       } else {
         hipLaunchKernelGGL((k_contract_sp<2>), dim3((unsigned)std::min<long>(2L * h->n_cu, (long)nTb * nIblk)), dim3(512), 0, sc, sa);
