@@ -225,6 +225,31 @@ def test_whole_grid_parity_plan_covers_every_point_once_and_spreads():
     assert r["slabs_checked"] == 1 and 0 < r["coverage"] < 1
 
 
+def test_whole_grid_checker_runs_several_reference_processes():
+    """oracle/full_grid.py: W reference processes side by side (spawned; each builds bench.reference_model from the recipe, 8 BLAS threads through its
+    environment) return the slabs of the one-process run to the rounding of the reference's own BLAS thread count; a budget of zero still checks one
+    slab per process."""
+    import pytest
+
+    from oracle import full_grid as fg
+    from oracle import ref_package as rp
+
+    if not rp.available():
+        pytest.skip("oracle/_ref/pykrige_py.zip not staged")
+    pk = rp.import_reference(stub_statistics=True)
+    cfg = dict(bench.CONFIGS[4], n=200)
+    coords, values = bench.synth(cfg["seed"], cfg["n"], 2)
+    rm = bench.reference_model(pk, cfg, coords, values)
+    axes = [np.linspace(0, 1, 40), np.linspace(0, 1, 21)]
+    z, ss = rm.execute("grid", *axes, backend="vectorized")
+    one = fg.compare(rm, z, ss, axes, 160)
+    two = fg.compare(rm, z, ss, axes, 160, recipe=(cfg, coords, values), workers=2)
+    assert one["points_checked"] == two["points_checked"] == 840 and one["reference_processes"] == 1 and two["reference_processes"] == 2
+    assert one["max_abs_dz"] <= 1e-11 and two["max_abs_dz"] <= 1e-11 and two["max_abs_dss"] <= 1e-11  # (the reference's own sums move in the 14th digit with slab shape and thread count)
+    few = fg.compare(rm, z, ss, axes, 160, recipe=(cfg, coords, values), workers=2, budget_s=0.0)
+    assert few["slabs_checked"] == 2 and 0 < few["coverage"] < 1
+
+
 def test_cpu_leg_times_the_reference_itself_where_it_is_staged():
     """cpu_baseline on a tiny stand-in config: with oracle/_ref/pykrige_py.zip staged (oracle/build_ref.sh) the vectorized leg is the
     reference's own execute() -- kind "reference" -- and agrees with the port; the slab axes are the slab's points."""
