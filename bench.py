@@ -618,7 +618,7 @@ def main():
     ap.add_argument("--sparse-rows", type=int, default=None, choices=[-1, 16, 128],
                     help="library option 'sparse_rows' (range-aware contraction: tiles of eight gathered 16-row groups, or aligned "
                          "128-row blocks; default: the library's, 16)")
-    ap.add_argument("--sparse-lanes", type=int, default=None, choices=[1, 2, 3], help="library option 'sparse_lanes' (default: the library's, 2)")
+    ap.add_argument("--sparse-lanes", type=int, default=None, choices=[1, 2], help="library option 'sparse_lanes' (default: the library's, 2)")
     ap.add_argument("--sort-points", type=int, default=None, choices=[-1, 0, 1],
                     help="library option 'sort_points' (range-aware contraction over the points of every launch in Hilbert-curve order; "
                          "default: the library's, on)")

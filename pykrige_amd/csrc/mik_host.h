@@ -277,7 +277,6 @@ struct mik_handle {
   // second set (with Bt2): the launches of the range-aware contraction alternate between two lanes on two streams, so that the
   // candidate / right-hand-side / list kernels of one launch and the tail of the previous launch's tile queue overlap
   DevBuf sp2_cand, sp2_flags, sp2_klist, sp2_kcount, sp2_nrows, sp2_rows, sp2_rstart, sp2_tiles, sp2_xoff, part2, queue2, sp2_recs;
-  struct SpBufs { DevBuf cand, flags, klist, kcount, nrows, rows, rstart, tiles, xoff, part, queue, Bt, recs; } sp3;  // third lane (EXPERIMENT)
   int opt_sparse_lanes = 2;  // "sparse_lanes": 2 = two lanes (default since round 5), 1 = one launch after the other on one stream.  Round 4
                              // (profiles/r04_sparse_lanes_ab.txt): config-5 slab 64.6 -> 63.4 ms, 2 % for a second 8.4 GB panel: off.  Round 5, with
                              // the contraction 15 % shorter, what runs beside it weighs more: prediction 43.1 -> 41.6 ms (bench 35.3 -> 36.3 M points/s)

@@ -90,13 +90,12 @@ int one_predict(mik_handle* h) {
   // "rhs_overlap" (off by default, see the option): two RHS panels, k_rhs of chunk c + 1 on a second stream while chunk c is
   // contracted.
   const bool overlap = h->opt_rhs_overlap && h->model != MIK_MODEL_CUSTOM && !sparse;
-  const int lanes_wanted = sparse ? h->opt_sparse_lanes : 1;  // 1 .. 3 launch lanes of the range-aware contraction
-  const bool lanes2_wanted = lanes_wanted >= 2;
+  const bool lanes2_wanted = sparse && h->opt_sparse_lanes == 2;
   // keep the RHS panels under ~1/4 of device memory
   size_t freeb = 0, totalb = 0;
   HIPC(hipMemGetInfo(&freeb, &totalb));
   const size_t have = h->Bt.bytes + h->Bt2.bytes;
-  while (chunk > 128 && (size_t)chunk * Mp * sizeof(double) * (lanes_wanted >= 2 ? lanes_wanted : overlap ? 2 : 1) > std::max(freeb + have, have) / 2) chunk = ((chunk / 2 + 127) / 128) * 128;
+  while (chunk > 128 && (size_t)chunk * Mp * sizeof(double) * ((overlap || lanes2_wanted) ? 2 : 1) > std::max(freeb + have, have) / 2) chunk = ((chunk / 2 + 127) / 128) * 128;
   // equal chunks: ceil(npt / chunk) launches of the same size (a short last launch drains as long as a full one)
   long nchunks = (npt + chunk - 1) / chunk;
   chunk = (((npt + nchunks - 1) / nchunks + 127) / 128) * 128;
@@ -109,20 +108,17 @@ int one_predict(mik_handle* h) {
   MIKC(get_events(h, 2 + 6 * (size_t)nchunks));
   std::vector<unsigned long long> sp_host;
   const bool lanes2 = lanes2_wanted && nchunks > 1;
-  const int nlanes = lanes2 ? (int)std::min<long>(lanes_wanted, nchunks) : 1;
   struct SpLane {
     DevBuf *cand, *flags, *klist, *kcount, *nrows, *rows, *rstart, *tiles, *xoff, *part, *queue, *Bt, *recs;
     hipStream_t st;
   };
-  SpLane lane[3] = {{&h->sp_cand, &h->sp_flags, &h->sp_klist, &h->sp_kcount, &h->sp_nrows, &h->sp_rows, &h->sp_rstart, &h->sp_tiles, &h->sp_xoff,
+  SpLane lane[2] = {{&h->sp_cand, &h->sp_flags, &h->sp_klist, &h->sp_kcount, &h->sp_nrows, &h->sp_rows, &h->sp_rstart, &h->sp_tiles, &h->sp_xoff,
                      &h->part, &h->queue, &h->Bt, &h->sp_recs, h->stream},
                     {&h->sp2_cand, &h->sp2_flags, &h->sp2_klist, &h->sp2_kcount, &h->sp2_nrows, &h->sp2_rows, &h->sp2_rstart, &h->sp2_tiles,
-                     &h->sp2_xoff, &h->part2, &h->queue2, &h->Bt2, &h->sp2_recs, h->stream2},
-                    {&h->sp3.cand, &h->sp3.flags, &h->sp3.klist, &h->sp3.kcount, &h->sp3.nrows, &h->sp3.rows, &h->sp3.rstart, &h->sp3.tiles,
-                     &h->sp3.xoff, &h->sp3.part, &h->sp3.queue, &h->sp3.Bt, &h->sp3.recs, h->stream3}};
+                     &h->sp2_xoff, &h->part2, &h->queue2, &h->Bt2, &h->sp2_recs, h->stream2}};
   if (sparse) {
     const size_t nTb = (size_t)chunk / 128;
-    for (int L = 0; L < nlanes; ++L) {
+    for (int L = 0; L < (lanes2 ? 2 : 1); ++L) {
       MIKC(lane[L].cand->ensure(nTb * nK16));
       MIKC(lane[L].flags->ensure(nTb * nKt));
       MIKC(lane[L].klist->ensure(sizeof(unsigned short) * nTb * nKt));
@@ -137,9 +133,9 @@ int one_predict(mik_handle* h) {
       }
       MIKC(lane[L].xoff->ensure(sizeof(int) * 9));
       MIKC(lane[L].queue->ensure(8 * sizeof(unsigned long long)));
-      if (L >= 1) {
-        MIKC(lane[L].Bt->ensure(sizeof(double) * (size_t)chunk * Mp));
-        MIKC(lane[L].part->ensure(sizeof(double) * (size_t)chunk * nIblk));
+      if (L == 1) {
+        MIKC(h->Bt2.ensure(sizeof(double) * (size_t)chunk * Mp));
+        MIKC(h->part2.ensure(sizeof(double) * (size_t)chunk * nIblk));
       }
     }
     MIKC(h->sp_stats.ensure(sizeof(unsigned long long) * 4 * (size_t)nchunks));
@@ -165,10 +161,6 @@ int one_predict(mik_handle* h) {
   const unsigned* perm_all = sortpts ? h->ps_idx[0].as<unsigned>() : nullptr;
   if (two || lanes2) HIPC(hipStreamWaitEvent(h->stream2, h->evpool[0], 0));
   if (lanes2 && sorted_now) HIPC(hipStreamWaitEvent(h->stream2, h->ev_sort, 0));
-  if (nlanes >= 3) {
-    HIPC(hipStreamWaitEvent(h->stream3, h->evpool[0], 0));
-    if (sorted_now) HIPC(hipStreamWaitEvent(h->stream3, h->ev_sort, 0));
-  }
   auto launch_rhs = [&](long c) -> int {
     const long t0 = c * chunk;
     const int nvalid = (int)std::min<long>(chunk, npt - t0);
@@ -204,7 +196,7 @@ int one_predict(mik_handle* h) {
     if (two && c >= 2) HIPC(hipStreamWaitEvent(sr, h->pr_events[2 * (c - 2) + 1], 0));  // the contraction that read this panel is done
     if (sparse) {
       // candidates (bounding boxes), cleared flags, then delta for the candidate blocks only
-      const SpLane& ln = lane[c % nlanes];
+      const SpLane& ln = lane[lanes2 ? (c & 1) : 0];
       hipStream_t ss = ln.st;
       a.Bt = ln.Bt->as<double>();
       a.cand = ln.cand->as<unsigned char>();
@@ -270,7 +262,7 @@ int one_predict(mik_handle* h) {
     hipEvent_t e1 = h->evpool[4 + 4 * c], e2 = h->evpool[5 + 4 * c];
     if (sparse) {
       const int nTb = palloc / 128;
-      const SpLane& ln = lane[c % nlanes];
+      const SpLane& ln = lane[lanes2 ? (c & 1) : 0];
       hipStream_t sc = ln.st;  // (shadows the dense path's stream: this launch lives on its lane's)
       if (gathered) {
         hipLaunchKernelGGL(k_sp_lists_g, dim3(nTb), dim3(64), 0, sc, (const unsigned char*)ln.flags->as<unsigned char>(), nKt,
@@ -325,7 +317,6 @@ int one_predict(mik_handle* h) {
         ga.xoff = sa.xoff;
         ga.queue = sa.queue;
         static const bool spg_prof = getenv("MIK_SPG_PROF") && atoi(getenv("MIK_SPG_PROF")) != 0;
-        static const long spg_reserve = getenv("MIK_SPG_RESERVE") ? atol(getenv("MIK_SPG_RESERVE")) : 32;  // EXPERIMENT (three lanes)
         if (spg_prof) {  // diagnostic (MIK_SPG_PROF=1): cycle sums per phase of the tile loop, one launch, printed to stderr
           const unsigned nb = (unsigned)std::min<long>(2L * h->n_cu, (long)nTb * nIblk);
           static DevBuf pb;
@@ -358,7 +349,7 @@ int one_predict(mik_handle* h) {
         } else
         // (2 n_cu persistent blocks: leaving 32 .. 128 of the slots to the other lane's preparation kernels was tried -- they then run beside the
         // contraction at a fraction of the chip -- and measured a tie at 32 and 1 - 3 % slower beyond: profiles/r06_predict_timeline_c5_after.txt)
-        hipLaunchKernelGGL((k_contract_spg<2, true, true>), dim3((unsigned)std::min<long>(2L * h->n_cu - (nlanes >= 3 ? spg_reserve : 0), (long)nTb * nIblk)), dim3(512), 0, sc, ga);
+        hipLaunchKernelGGL((k_contract_spg<2, true, true>), dim3((unsigned)std::min<long>(2L * h->n_cu, (long)nTb * nIblk)), dim3(512), 0, sc, ga);
       } else {
         hipLaunchKernelGGL((k_contract_sp<2>), dim3((unsigned)std::min<long>(2L * h->n_cu, (long)nTb * nIblk)), dim3(512), 0, sc, sa);
       }
@@ -366,7 +357,7 @@ int one_predict(mik_handle* h) {
       hipLaunchKernelGGL(k_ss_reduce_sp, dim3((nvalid + 255) / 256), dim3(256), 0, sc, (const double*)ln.part->as<double>(), palloc,
                          (const int*)ln.nrows->as<int>(), nvalid, 2.0 * (h->v.p0 + h->v.p2),
                          perm_all ? h->ss.as<double>() : h->ss.as<double>() + t0, perm_all ? perm_all + t0 : (const unsigned*)nullptr);
-      if (c % nlanes) HIPC(hipEventRecord(h->pr_events[c % nlanes], sc));  // lane 1's / lane 2's latest launch (joined below)
+      if (lanes2 && (c & 1)) HIPC(hipEventRecord(h->pr_events[0], sc));  // lane 1's latest launch (joined below)
       HIPC(hipEventRecord(h->ev_chunk, sc));
       HIPC(hipStreamWaitEvent(h->stream_d2h, h->ev_chunk, 0));
       HIPC(hipMemcpyAsync(h->pin_out.as<double>() + t0, h->z.as<double>() + t0, sizeof(double) * nvalid, hipMemcpyDeviceToHost,
@@ -423,7 +414,7 @@ int one_predict(mik_handle* h) {
     h->tm.contract_flops_executed += 2.0 * 128.0 * 128.0 * kext * (palloc / 128);
   }
   HIPC(hipGetLastError());
-  for (int L = 1; L < nlanes; ++L) HIPC(hipStreamWaitEvent(h->stream, h->pr_events[L], 0));  // the handle's stream ends behind every lane
+  if (lanes2) HIPC(hipStreamWaitEvent(h->stream, h->pr_events[0], 0));  // the handle's stream ends behind both lanes
   HIPC(hipEventRecord(h->evpool[1], h->stream));
   HIPC(hipEventRecord(h->ev_d2h, h->stream_d2h));
   HIPC(hipStreamSynchronize(h->stream));

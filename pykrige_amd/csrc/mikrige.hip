@@ -115,9 +115,7 @@ static void destroy_one(mik_handle* h) {
                     &h->px, &h->py, &h->pz, &h->grid_axes, &h->grid_idx, &h->Averify, &h->vbuf, &h->extra_rows, &h->z, &h->ss, &h->Bt, &h->Bt2, &h->part, &h->mw_idx, &h->mw_dist, &h->stat_S, &h->stat_x, &h->stat_out, &h->queue,
                     &h->xs_s, &h->ys_s, &h->zs_s, &h->vals_s, &h->extra_cols_s, &h->sbox, &h->sp_cand, &h->sp_flags, &h->sp_klist, &h->sp_kcount,
                     &h->sp_nrows, &h->sp_rows, &h->sp_rstart, &h->sp_tiles, &h->sp_xoff, &h->sp_stats, &h->sp2_cand, &h->sp2_flags, &h->sp2_klist, &h->sp2_kcount,
-                    &h->sp2_nrows, &h->sp2_rows, &h->sp2_rstart, &h->sp2_tiles, &h->sp2_xoff, &h->part2, &h->queue2, &h->dsc, &h->sp_recs, &h->sp2_recs, &h->ps_key[0], &h->ps_key[1], &h->ps_idx[0], &h->ps_idx[1], &h->ps_table, &h->ps_box, &h->ps_x, &h->ps_y, &h->ps_z, &h->ps_zs, &h->ps_sss, &h->xpack,
-                    &h->sp3.cand, &h->sp3.flags, &h->sp3.klist, &h->sp3.kcount, &h->sp3.nrows, &h->sp3.rows, &h->sp3.rstart, &h->sp3.tiles, &h->sp3.xoff, &h->sp3.part,
-                    &h->sp3.queue, &h->sp3.Bt, &h->sp3.recs};
+                    &h->sp2_nrows, &h->sp2_rows, &h->sp2_rstart, &h->sp2_tiles, &h->sp2_xoff, &h->part2, &h->queue2, &h->dsc, &h->sp_recs, &h->sp2_recs, &h->ps_key[0], &h->ps_key[1], &h->ps_idx[0], &h->ps_idx[1], &h->ps_table, &h->ps_box, &h->ps_x, &h->ps_y, &h->ps_z, &h->ps_zs, &h->ps_sss, &h->xpack};
   for (DevBuf* b : bufs) b->release();
   h->pin_in.release();
   h->pin_out.release();
@@ -281,7 +279,7 @@ int mik_set_option(mik_handle* h, const char* key, double value) {
     if (value != -1.0 && value != 16.0 && value != 128.0) return fail(MIK_EINVAL, "sparse_rows must be -1 (auto), 16 or 128");
     h->opt_sparse_rows = (int)value;
   } else if (!strcmp(key, "sparse_lanes")) {
-    if (value != 1.0 && value != 2.0 && value != 3.0) return fail(MIK_EINVAL, "sparse_lanes must be 1, 2 or 3");
+    if (value != 1.0 && value != 2.0) return fail(MIK_EINVAL, "sparse_lanes must be 1 or 2");
     h->opt_sparse_lanes = (int)value;
   } else if (!strcmp(key, "drift_eq")) {
     h->opt_drift_eq = value != 0.0;
