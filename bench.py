@@ -464,15 +464,15 @@ def other_config_line(cno, window=None, steps=3, warmup=1):
 FULL_GRID = {2: dict(target=50000), 3: dict(target=40000), 4: dict(target=49152), 5: dict(target=32768, strip=(480, 544))}
 
 
-def full_grid_axes(cno):
+def full_grid_axes(cno, strip=None):
     cfg = CONFIGS[cno]
     if cno == 5:
-        r0, r1 = FULL_GRID[5]["strip"]
+        r0, r1 = strip or FULL_GRID[5]["strip"]
         return [np.linspace(0.0, 1.0, 4096), np.linspace(0.0, 1.0, 4096)[r0:r1]]
     return grid_axes(cfg, 1)
 
 
-def full_grid_parity(cno, budget_s=None, log=None):
+def full_grid_parity(cno, budget_s=None, log=None, strip=None):
     """Every point of ONE execute('grid') of the drop-in class over the config's own grid (configs 2, 3, 4: the whole grid; config 5:
     a 4096 x 64 strip across the cut between two GPUs' slabs) against the REAL reference kriging the same grid slab by slab
     (oracle/full_grid.py; ok.py:650-683, uk.py:922-1009, ok3d.py:624-657 as written upstream).  `budget_s` bounds the CPU side: what
@@ -482,7 +482,7 @@ def full_grid_parity(cno, budget_s=None, log=None):
 
     cfg = CONFIGS[cno]
     coords, values = synth(cfg["seed"], cfg["n"], cfg["ndim"])
-    axes = full_grid_axes(cno)
+    axes = full_grid_axes(cno, strip)  # (strip: other rows of config 5's 4096 x 4096 grid, e.g. (0, 512) = the whole slab of GPU 0)
     m = make_model(cfg, coords, values)
     t0 = time.perf_counter()
     z, ss = m.execute("grid", *axes, backend="vectorized")
@@ -493,7 +493,7 @@ def full_grid_parity(cno, budget_s=None, log=None):
     rm = reference_model(pk, cfg, coords, values)
     n = cfg["n"]
     extra = ((2 if cfg.get("rl") else 0) + (len(cfg["wells"]) if cfg.get("wells") else 0)) if cfg["ndim"] == 2 else 0
-    res = {"workload": cfg["name"] + (" -- rows %d:%d of the 4096 x 4096 grid" % FULL_GRID[5]["strip"] if cno == 5 else ""),
+    res = {"workload": cfg["name"] + (" -- rows %d:%d of the 4096 x 4096 grid" % tuple(strip or FULL_GRID[5]["strip"]) if cno == 5 else ""),
            "grid": [int(a.size) for a in axes], "gpu_execute_s": t_gpu, "gpu_contraction": "range-aware" if tm.get("sparse") else "dense",
            "cond_1": fg.cond_1(rm, *((n, n + extra) if extra else (n,)))}
     # the reference side: several reference processes side by side (its _exec_vector is mostly single-threaded NumPy: one process leaves a 64-core
@@ -643,10 +643,12 @@ def main():
     if args.full_parity:
         os.environ["MIK_FACTOR_CACHE"] = "0"
         bad = 0
-        for cno in [int(c) for c in args.full_parity.split(",")]:
-            res = full_grid_parity(cno, budget_s=args.full_parity_budget, log=lambda m: print(m, file=sys.stderr, flush=True))
+        for key in args.full_parity.split(","):
+            # "5w" = config 5 with the WHOLE slab of GPU 0 (rows 0:512 of the 4096 x 4096 grid, 2.1 M points: about 8 minutes of reference time)
+            cno, strip = (5, (0, 512)) if key == "5w" else (int(key), None)
+            res = full_grid_parity(cno, budget_s=args.full_parity_budget, log=lambda m: print(m, file=sys.stderr, flush=True), strip=strip)
             bad += not res["ok"]
-            print(json.dumps(dict(full_grid_parity="config%d" % cno, **res)), flush=True)
+            print(json.dumps(dict(full_grid_parity="config" + key, **res)), flush=True)
         sys.exit(1 if bad else 0)
 
     # Keep stdout clean for the ONE JSON line: RCCL prints banners from C++ to fd 1, so fd 1 points at
