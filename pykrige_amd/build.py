@@ -1,6 +1,6 @@
 """Builds pykrige_amd/libmikrige.so (HIP, gfx950) in-tree.  `python -m pykrige_amd.build [--force] [-j N]`.
 
-The library is eight translation units compiled in parallel (objects under pykrige_amd/csrc/build/, git- and gpurun-ignored) and
+The library is ten translation units compiled in parallel (objects under pykrige_amd/csrc/build/, git- and gpurun-ignored) and
 linked into one shared object; only the units whose sources or flags changed are recompiled (the command line of every object is
 kept beside it as <name>.flags).  Safe against concurrent callers (pytest-xdist, one process per GPU calling __graft_entry__.build):
 the whole build holds an flock on csrc/build/.lock, and objects / the library are written under a per-process name and renamed into place.
@@ -8,7 +8,8 @@ the whole build holds an flock on csrc/build/.lock, and objects / the library ar
     mikrige.hip       C ABI, handles, device groups + factor exchange, K1 assembly, points / grids / masks, statistics
     mik_inverse.hip   K2: block Gauss-Jordan sweep and its schedules, probes, pseudo-inverses
     mik_predict.hip   K3: right-hand sides, dense and range-aware contraction, point sort
-    mik_mw.hip        moving window: neighbour search, Gauss-Jordan / blocked / HBM solvers, dispatch
+    mik_mw.hip        moving window: neighbour search, blocked / HBM solvers, dispatch
+    mik_mw_solve.hip  x 2 (-DMIK_MWS_PART=0 / 1): the register classes of the pivoting Gauss-Jordan solver (the LDL^T kernels' fallback)
     mik_mw_chol.hip   x 4 (-DMIK_MWC_PART=0..3): the register-tile classes of the moving window's LDL^T solver
 """
 import os
@@ -30,6 +31,8 @@ UNITS = {
     "mik_inverse": ("mik_inverse.hip", ["mik_k_inverse.h"], []),
     "mik_predict": ("mik_predict.hip", ["mik_k_predict.h"], []),
     "mik_mw": ("mik_mw.hip", ["mik_k_mw.h", "mik_k_mw_chol.h"], []),
+    "mik_mw_solve0": ("mik_mw_solve.hip", ["mik_k_mw_solve.h", "mik_k_mw_chol.h"], ["-DMIK_MWS_PART=0"]),
+    "mik_mw_solve1": ("mik_mw_solve.hip", ["mik_k_mw_solve.h", "mik_k_mw_chol.h"], ["-DMIK_MWS_PART=1"]),
     "mik_mw_chol0": ("mik_mw_chol.hip", ["mik_k_mw_chol.h"], ["-DMIK_MWC_PART=0"]),
     "mik_mw_chol1": ("mik_mw_chol.hip", ["mik_k_mw_chol.h"], ["-DMIK_MWC_PART=1"]),
     "mik_mw_chol2": ("mik_mw_chol.hip", ["mik_k_mw_chol.h"], ["-DMIK_MWC_PART=2"]),
@@ -123,8 +126,8 @@ def _build_locked(force, verbose, jobs):
             f.write(" ".join(flags))
         return name
 
-    # the four mik_mw_chol units are the long ones: start them first
-    todo.sort(key=lambda j: 0 if j[0].startswith("mik_mw_chol") else 1)
+    # the moving-window units are the long ones (19 - 29 s each): start them first
+    todo.sort(key=lambda j: 0 if j[0].startswith("mik_mw") else 1)
     with ThreadPoolExecutor(max_workers=jobs or min(len(UNITS), os.cpu_count() or 4)) as ex:
         list(ex.map(run, todo))
     link = [cc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [os.path.join(OBJ, n + ".o") for n in UNITS] + ["-o", OUT + pid, "-ldl"]

@@ -488,6 +488,7 @@ int one_predict_mw(mik_handle* h, int n_closest);
 #define MIK_MWC_PARTS 4
 #define MIK_MWC_NOCLASS (-9999)
 namespace mik { struct MwArgs; }
+int dispatch_mw_solve(mik_handle* h, const mik::MwArgs& a, long pc, bool piv);                                     // mik_mw_solve.hip
 int mw_chol_part0(int cls, hipStream_t stream, bool use_static, const mik::MwArgs& a, long pc);
 int mw_chol_part1(int cls, hipStream_t stream, bool use_static, const mik::MwArgs& a, long pc);
 int mw_chol_part2(int cls, hipStream_t stream, bool use_static, const mik::MwArgs& a, long pc);

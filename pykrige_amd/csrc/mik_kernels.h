@@ -21,3 +21,4 @@
 #include "mik_k_predict.h"
 #include "mik_k_inverse.h"
 #include "mik_k_mw.h"
+#include "mik_k_mw_solve.h"

@@ -3,24 +3,6 @@
 #include "mik_k_mw.h"
 #include "mik_host.h"
 
-template <int GY, int GX, int RI, int CJ>
-static int launch_mw_solve(mik_handle* h, const MwArgs& a, long pc, bool piv) {
-  constexpr int T = GY * GX, PPB = 256 / T, CJP = (CJ + 1) & ~1;
-  const int nb = a.K + 1;
-  if (nb > GY * RI || nb + 1 > GX * CJ) return fail(MIK_EINVAL, "moving-window solve class too small for this window");
-  const size_t per = (2 * ((size_t)GX * CJP + (size_t)GY * RI) + 16 + 5 * (size_t)nb + (2 * (size_t)nb + 1) / 2 + 1) & ~(size_t)1;
-  const size_t lds = sizeof(double) * per * PPB;
-  const dim3 grid((unsigned)((pc + PPB - 1) / PPB));
-  if (piv) {
-    HIPC(hipFuncSetAttribute((const void*)k_mw_solve<GY, GX, RI, CJ, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_mw_solve<GY, GX, RI, CJ, true>), grid, dim3(256), lds, h->stream, a);
-  } else {
-    HIPC(hipFuncSetAttribute((const void*)k_mw_solve<GY, GX, RI, CJ, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_mw_solve<GY, GX, RI, CJ, false>), grid, dim3(256), lds, h->stream, a);
-  }
-  return MIK_OK;
-}
-
 // Sort the stations into a uniform grid of cells for the moving-window neighbour search (counting sort on the host, O(N)).
 // The cell edge aims at `target` stations per cell; geographic problems are binned by their unit-sphere vectors.
 static int build_mw_grid(mik_handle* h, int target) {
@@ -105,19 +87,7 @@ static int build_mw_grid(mik_handle* h, int target) {
   return MIK_OK;
 }
 
-// thread-grid / register-tile classes of k_mw_solve, {GY, GX, RI, CJ} covers nb <= GY*RI and nb + 1 <= GX*CJ.  Measured
-// on MI355X (scripts/mw_classes.py history in DESIGN.md): the classes whose tile fits the VGPR file without AGPR spills
-// win, and among those the one with the fewest threads per point.
-static int dispatch_mw_solve(mik_handle* h, const MwArgs& a, long pc, bool piv) {
-  const int nb = a.K + 1;
-  if (nb <= 16) return launch_mw_solve<4, 4, 4, 5>(h, a, pc, piv);   // 16 threads per point
-  if (nb <= 32) return launch_mw_solve<8, 8, 4, 5>(h, a, pc, piv);   // 64
-  if (nb <= 48) return launch_mw_solve<8, 8, 6, 7>(h, a, pc, piv);   // 64
-  if (nb <= 64) return launch_mw_solve<8, 8, 8, 9>(h, a, pc, piv);   // 64
-  if (nb <= 96) return launch_mw_solve<16, 16, 6, 7>(h, a, pc, piv); // 256
-  return launch_mw_solve<16, 16, 8, 9>(h, a, pc, piv);               // 256, nb <= 128
-}
-
+// (dispatch_mw_solve: mik_mw_solve.hip)
 // the classes of k_mw_chol live in mik_mw_chol.hip (four translation units): class = 100 G + RI
 static int launch_mw_chol_class(mik_handle* h, const MwArgs& a, long pc, int cls) {
   for (int part = 0; part < MIK_MWC_PARTS; ++part) {
