@@ -284,8 +284,6 @@ int  mik_slab_of(int64_t n, int members, int i, int64_t *lo, int64_t *count); /*
  *   itself for exponential / spherical from 24 block columns on ;
  * "mw_pivot" 0/1 = always solve the moving-window systems with partial pivoting (default 0: SPD-shifted, no pivot search,
  *   falling back to pivoting when a local system is not positive definite) ;
- * "mw_solver" 0/1 = moving-window systems by the register-tile LDL^T kernel (default 0, K <= 256) or by the Gauss-Jordan / HBM-LU
- *   kernels of round 1 (1; also what larger windows use) ;
  * "mw_knn_bound" 0/1 = moving-window neighbour search: the first pass takes only stations within the radius expected to hold
  *   K + 4 sqrt(K) + 2 of them (one scan of the 3 x 3 cells, one sort), falling back to the unbounded ring walk where that
  *   finds fewer than K (default 1) ;

@@ -9,8 +9,8 @@ the whole build holds an flock on csrc/build/.lock, and objects / the library ar
     mik_inverse.hip   K2: block Gauss-Jordan sweep and its schedules, probes, pseudo-inverses
     mik_predict.hip   K3: right-hand sides, dense and range-aware contraction, point sort
     mik_mw.hip        moving window: neighbour search, blocked / HBM solvers, dispatch
-    mik_mw_solve.hip  x 2 (-DMIK_MWS_PART=0 / 1): the register classes of the pivoting Gauss-Jordan solver (the LDL^T kernels' fallback)
-    mik_mw_chol.hip   x 4 (-DMIK_MWC_PART=0..3): the register-tile classes of the moving window's LDL^T solver
+    mik_mw_solve.hip  moving window: the register classes of the pivoting Gauss-Jordan solver (the LDL^T kernels' fallback)
+    mik_mw_chol.hip   x 5 (-DMIK_MWC_PART=0..4): the register-tile classes of the moving window's LDL^T solver
 """
 import os
 import shutil
@@ -31,15 +31,19 @@ UNITS = {
     "mik_inverse": ("mik_inverse.hip", ["mik_k_inverse.h"], []),
     "mik_predict": ("mik_predict.hip", ["mik_k_predict.h"], []),
     "mik_mw": ("mik_mw.hip", ["mik_k_mw.h", "mik_k_mw_chol.h"], []),
-    "mik_mw_solve0": ("mik_mw_solve.hip", ["mik_k_mw_solve.h", "mik_k_mw_chol.h"], ["-DMIK_MWS_PART=0"]),
-    "mik_mw_solve1": ("mik_mw_solve.hip", ["mik_k_mw_solve.h", "mik_k_mw_chol.h"], ["-DMIK_MWS_PART=1"]),
+    "mik_mw_solve": ("mik_mw_solve.hip", ["mik_k_mw_solve.h", "mik_k_mw_chol.h"], []),
     "mik_mw_chol0": ("mik_mw_chol.hip", ["mik_k_mw_chol.h"], ["-DMIK_MWC_PART=0"]),
     "mik_mw_chol1": ("mik_mw_chol.hip", ["mik_k_mw_chol.h"], ["-DMIK_MWC_PART=1"]),
     "mik_mw_chol2": ("mik_mw_chol.hip", ["mik_k_mw_chol.h"], ["-DMIK_MWC_PART=2"]),
     "mik_mw_chol3": ("mik_mw_chol.hip", ["mik_k_mw_chol.h"], ["-DMIK_MWC_PART=3"]),
+    "mik_mw_chol4": ("mik_mw_chol.hip", ["mik_k_mw_chol.h"], ["-DMIK_MWC_PART=4"]),
 }
-# --offload-compress: the code objects travel zstd-compressed inside the fat binary (16.9 -> 2.6 MB of .so; the HIP runtime unpacks them at load)
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "--offload-compress", "-I" + os.path.join(ROOT, "include")]
+# --offload-compress: the code objects travel zstd-compressed inside the fat binary (16.9 -> 2.3 MB of .so; the HIP runtime unpacks them at load);
+# level 19 instead of the default 3 takes another 3 % off and no measurable compile time (the time is in code generation)
+COMPRESS = ["--offload-compress", "--offload-compression-level=19"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + COMPRESS + ["-I" + os.path.join(ROOT, "include")]
+# seconds of one core per unit (hipcc of ROCm 7.2): the order the units are started in, longest first
+COST = {"mik_mw_chol": 23, "mik_mw_solve": 15, "mik_predict": 12, "mikrige": 9, "mik_inverse": 6, "mik_mw": 4}
 
 
 def hipcc():
@@ -110,12 +114,17 @@ def _build_locked(force, verbose, jobs):
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0 and "--offload-compress" in cmd and "offload-compress" in r.stderr:
+        if r.returncode != 0 and COMPRESS[1] in cmd and "offload-compress" in r.stderr:
+            # a hipcc that knows --offload-compress but not the level: the default level
+            flags = [c for c in flags if c != COMPRESS[1]]
+            cmd = [c for c in cmd if c != COMPRESS[1]]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0 and COMPRESS[0] in cmd and "offload-compress" in r.stderr:
             # a hipcc that does not know the flag (before ROCm 6.1): the same objects, uncompressed -- and recorded as such, so that
             # a later build with a newer hipcc sees them as stale (the library is several times larger without the compression)
-            flags = [c for c in flags if c != "--offload-compress"]
+            flags = [c for c in flags if c not in COMPRESS]
             print("pykrige_amd.build: this hipcc does not know --offload-compress; %s is built uncompressed" % name, file=sys.stderr)
-            r = subprocess.run([c for c in cmd if c != "--offload-compress"], capture_output=True, text=True)
+            r = subprocess.run([c for c in cmd if c not in COMPRESS], capture_output=True, text=True)
         obj = os.path.join(OBJ, name + ".o")
         if r.returncode != 0:
             if os.path.exists(obj + pid):
@@ -126,11 +135,11 @@ def _build_locked(force, verbose, jobs):
             f.write(" ".join(flags))
         return name
 
-    # the moving-window units are the long ones (19 - 29 s each): start them first
-    todo.sort(key=lambda j: 0 if j[0].startswith("mik_mw") else 1)
+    todo.sort(key=lambda j: -COST.get(j[0].rstrip("0123456789"), 0))
     with ThreadPoolExecutor(max_workers=jobs or min(len(UNITS), os.cpu_count() or 4)) as ex:
         list(ex.map(run, todo))
-    link = [cc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [os.path.join(OBJ, n + ".o") for n in UNITS] + ["-o", OUT + pid, "-ldl"]
+    link = [cc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [os.path.join(OBJ, n + ".o") for n in UNITS] + ["-o", OUT + pid, "-ldl", "-Wl,-s"]
+    # (-s: no static symbol table -- 90 kB; the C ABI and the kernels' host stubs are dynamic symbols, `nm -D` lists them)
     if verbose:
         print(" ".join(link), flush=True)
     subprocess.run(link, check=True)

@@ -356,7 +356,6 @@ struct mik_handle {
   int opt_factor = 0, opt_sym = 1;
   long opt_chunk = 131072;
   int opt_mw_pivot = 0;       // 1 = always solve the moving-window systems with partial pivoting
-  int opt_mw_solver = 0;      // 0 = LDL^T of the shifted system in registers (default), 1 = the Gauss-Jordan kernels
   bool mw_force_piv = false;
   int opt_mw_lds_cap = 8192;  // largest candidate buffer the moving-window neighbour search keeps in LDS
   int opt_mw_knn_bound = 1;   // neighbour search: first pass over the 3 x 3 cells with a distance bound (see k_mw_knn)
@@ -485,19 +484,21 @@ int sort_points(mik_handle* h, long chunk, long nchunks);                       
 int one_predict(mik_handle* h);                                                                                  // mik_predict.hip
 int one_predict_mw(mik_handle* h, int n_closest);
 // mik_mw_chol.hip, part N: launches class 100 G + RI of k_mw_chol if it holds it, else returns MIK_MWC_NOCLASS
-#define MIK_MWC_PARTS 4
+#define MIK_MWC_PARTS 5
 #define MIK_MWC_NOCLASS (-9999)
 namespace mik { struct MwArgs; }
-int dispatch_mw_solve(mik_handle* h, const mik::MwArgs& a, long pc, bool piv);                                     // mik_mw_solve.hip
+int dispatch_mw_solve(mik_handle* h, const mik::MwArgs& a, long pc);                                               // mik_mw_solve.hip
 int mw_chol_part0(int cls, hipStream_t stream, bool use_static, const mik::MwArgs& a, long pc);
 int mw_chol_part1(int cls, hipStream_t stream, bool use_static, const mik::MwArgs& a, long pc);
 int mw_chol_part2(int cls, hipStream_t stream, bool use_static, const mik::MwArgs& a, long pc);
 int mw_chol_part3(int cls, hipStream_t stream, bool use_static, const mik::MwArgs& a, long pc);
+int mw_chol_part4(int cls, hipStream_t stream, bool use_static, const mik::MwArgs& a, long pc);
 inline int mw_chol_part(int part, int cls, hipStream_t stream, bool use_static, const mik::MwArgs& a, long pc) {
   switch (part) {
     case 0: return mw_chol_part0(cls, stream, use_static, a, pc);
     case 1: return mw_chol_part1(cls, stream, use_static, a, pc);
     case 2: return mw_chol_part2(cls, stream, use_static, a, pc);
-    default: return mw_chol_part3(cls, stream, use_static, a, pc);
+    case 3: return mw_chol_part3(cls, stream, use_static, a, pc);
+    default: return mw_chol_part4(cls, stream, use_static, a, pc);
   }
 }                                                                // mik_mw.hip

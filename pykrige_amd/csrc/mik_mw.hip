@@ -172,12 +172,12 @@ int one_predict_mw(mik_handle* h, int n_closest) {
   // of this call hit a bad pivot
   const bool mw_piv = custom || h->model == MIK_MODEL_HOLE_EFFECT || h->mw_force_piv || h->opt_mw_pivot;
   // three solvers: LDL^T of the shifted system in registers (no pivot search; windows up to 256), Gauss-Jordan in registers
-  // with or without implicit partial pivoting (opt_mw_solver = 1, or when the model cannot promise a positive definite
+  // with implicit partial pivoting (when the model cannot promise a positive definite
   // station block; windows up to 127), LU with partial pivoting in HBM scratch (any window)
-  const bool chol = !mw_piv && h->opt_mw_solver == 0 && K <= MIK_MW_CHOL_KMAX && h->opt_mw_class != 1;
+  const bool chol = !mw_piv && K <= MIK_MW_CHOL_KMAX && h->opt_mw_class != 1;
   // beyond the register classes: blocked Cholesky of the shifted system (one block per point, panels of 64 in LDS, the matrix
   // in an L2-resident scratch slot); "mw_class" 1 forces it for smaller windows too (A/B runs)
-  const bool cholb = !mw_piv && h->opt_mw_solver == 0 && !chol && K >= 8;
+  const bool cholb = !mw_piv && !chol && K >= 8;
   const bool big = !chol && !cholb && K > MIK_MW_KMAX;
   long chunk = npt;
   if (K > MIK_MW_KMAX) {  // neighbour lists of 12 K bytes per point: bound them to ~2 GB
@@ -405,7 +405,7 @@ int one_predict_mw(mik_handle* h, int n_closest) {
     } else if (chol) {
       MIKC(dispatch_mw_chol(h, a, pc));
     } else {
-      MIKC(dispatch_mw_solve(h, a, pc, mw_piv));
+      MIKC(dispatch_mw_solve(h, a, pc));  // (always the pivoting form: valid for every window, the only one built)
     }
     HIPC(hipEventRecord(h->evpool[3 + 2 * solve_chunks], h->stream));
     ++solve_chunks;

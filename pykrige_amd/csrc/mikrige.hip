@@ -184,7 +184,7 @@ static int set_group(mik_handle* h, int n) {
     k->is_kid = true;
     k->opt_factor = h->opt_factor, k->opt_sym = h->opt_sym;
     k->opt_chunk = h->opt_chunk, k->opt_symsweep = h->opt_symsweep, k->opt_panel_stream = h->opt_panel_stream, k->opt_update_rev = h->opt_update_rev, k->opt_lookahead = h->opt_lookahead, k->opt_gate = h->opt_gate, k->opt_pinv_fast = h->opt_pinv_fast, k->opt_rhs_overlap = h->opt_rhs_overlap, k->opt_verify = h->opt_verify, k->verify_tol_z = h->verify_tol_z, k->verify_tol_inv = h->verify_tol_inv;
-    k->opt_mw_class = h->opt_mw_class, k->opt_mw_knn_bound = h->opt_mw_knn_bound, k->opt_mw_pivot = h->opt_mw_pivot, k->opt_mw_lds_cap = h->opt_mw_lds_cap, k->opt_tri = h->opt_tri, k->opt_symmetrize = h->opt_symmetrize, k->opt_mw_solver = h->opt_mw_solver;
+    k->opt_mw_class = h->opt_mw_class, k->opt_mw_knn_bound = h->opt_mw_knn_bound, k->opt_mw_pivot = h->opt_mw_pivot, k->opt_mw_lds_cap = h->opt_mw_lds_cap, k->opt_tri = h->opt_tri, k->opt_symmetrize = h->opt_symmetrize;
     k->opt_sparse = h->opt_sparse, k->opt_sparse_lanes = h->opt_sparse_lanes, k->opt_sparse_rows = h->opt_sparse_rows, k->opt_sparse_group = h->opt_sparse_group, k->opt_sort_points = h->opt_sort_points, k->opt_drift_eq = h->opt_drift_eq;
     k->opt_pinv_block = h->opt_pinv_block, k->opt_mw_static = h->opt_mw_static, k->opt_mw_knn_lane = h->opt_mw_knn_lane;
     k->custom_fn = h->custom_fn, k->custom_user = h->custom_user;
@@ -311,9 +311,6 @@ int mik_set_option(mik_handle* h, const char* key, double value) {
     h->opt_panel_stream = value < 0.0 ? -1 : (value != 0.0);
   } else if (!strcmp(key, "lookahead")) {
     h->opt_lookahead = value < 0.0 ? -1 : (value != 0.0);
-  } else if (!strcmp(key, "mw_solver")) {
-    if (value != 0.0 && value != 1.0) return fail(MIK_EINVAL, "mw_solver must be 0 (LDL^T) or 1 (Gauss-Jordan)");
-    h->opt_mw_solver = (int)value;
   } else if (!strcmp(key, "mw_knn_bound")) {
     h->opt_mw_knn_bound = value != 0.0;
   } else if (!strcmp(key, "mw_knn_lane")) {

@@ -1,5 +1,5 @@
 """Time the moving-window path for a range of window sizes on config-2 stations (GPU box): the LDL^T solver (default)
-beside the Gauss-Jordan / HBM-LU kernels it replaces (option mw_solver = 1), whole call and solve kernels alone."""
+beside the pivoting Gauss-Jordan / HBM-LU fallback (option mw_pivot = 1), whole call and solve kernels alone."""
 import sys, time
 import numpy as np
 sys.path.insert(0, ".")
@@ -19,7 +19,7 @@ for k, npt in ((10, 1000000), (16, 1000000), (32, 1000000), (50, 1000000), (64, 
     h.set_points(px, py, None)
     row, zs = [], []
     for solver in ((0,) if "--ldlt-only" in sys.argv else (0, 1)):
-        h.set_option("mw_solver", solver)
+        h.set_option("mw_pivot", solver)
         h.predict_moving_window(k)
         t0 = time.perf_counter()
         h.predict_moving_window(k)
@@ -30,7 +30,7 @@ for k, npt in ((10, 1000000), (16, 1000000), (32, 1000000), (50, 1000000), (64, 
         print("%5d %9d | %12.2f %12.2f %14.0f |" % (k, npt, *row), flush=True)
         continue
     print("%5d %9d | %12.2f %12.2f %14.0f | %12.2f %12.2f %14.0f | %9.2e" % (k, npt, *row, np.abs(zs[0] - zs[1]).max()), flush=True)
-h.set_option("mw_solver", 0)
+h.set_option("mw_pivot", 0)
 
 # many stations: only coordinates live on the device (no N x N matrix on this path)
 for n, k in ((100000, 10), (1000000, 10), (1000000, 32)):

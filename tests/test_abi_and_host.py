@@ -32,13 +32,17 @@ def test_library_exports_every_declared_symbol():
     assert set(_lib.SIGNATURES) == set(names)
 
 
-def test_library_size_stays_under_ten_megabytes():
-    """Round 5: eight (round 6: ten) translation units, code objects compressed in the fat binary (pykrige_amd/build.py): the round-4 review's bar for the
-    library (16.9 MB then) is 10 MB."""
+def test_library_size_stays_under_the_bar():
+    """Ten translation units, code objects compressed in the fat binary (pykrige_amd/build.py).  The round-4 review's bar for the library (16.9 MB
+    then) was 10 MB, the round-5 review's 2.2 MB (2.62 MB then); 1.88 MB at the end of round 6.  (A hipcc without --offload-compress builds it
+    uncompressed and several times larger: that build is recorded in the .flags stamps and not held to the bar.)"""
     from pykrige_amd import build
 
     build.build_library()
-    assert os.path.getsize(build.OUT) <= 10 * 1024 * 1024, os.path.getsize(build.OUT)
+    stamps = [open(os.path.join(build.OBJ, n + ".flags")).read() for n in build.UNITS if os.path.exists(os.path.join(build.OBJ, n + ".flags"))]
+    if stamps and not all("--offload-compress" in st.split() for st in stamps):
+        pytest.skip("this hipcc does not compress code objects")
+    assert os.path.getsize(build.OUT) <= 2_200_000, os.path.getsize(build.OUT)
 
 
 # Every kernel template the library may instantiate, with the DEFAULT code path or the documented fallback that launches it (round 6: "keep
@@ -102,7 +106,7 @@ def test_every_kernel_in_the_library_is_reachable_from_a_default_path_or_a_docum
     if not shutil.which("nm"):
         pytest.skip("binutils nm not on PATH")
     build.build_library()
-    out = subprocess.run(["nm", "-C", build.OUT], capture_output=True, text=True, check=True).stdout
+    out = subprocess.run(["nm", "-D", "-C", build.OUT], capture_output=True, text=True, check=True).stdout
     inst = sorted({m.group(1) for m in re.finditer(r"__device_stub__([A-Za-z_0-9]+(?:<[^(]*>)?)\(", out)})
     assert len(inst) >= 200, len(inst)
     fam = {}
