@@ -8,6 +8,7 @@ from .kriging import OrdinaryKriging, OrdinaryKriging3D, UniversalKriging, Unive
 from . import _lib, core, variogram_models  # noqa: F401
 from ._lib import set_devices  # noqa: F401  (single-process multi-GPU: handles span n GPUs; MIK_NGPU does the same)
 from . import kriging_tools as kt  # noqa: F401  (the reference's alias)
+from . import ok, ok3d, uk, uk3d  # noqa: F401,E402  (`import pykrige; pykrige.ok.OrdinaryKriging` works upstream: pykrige/__init__.py:44-48 binds the submodules)
 
-__all__ = ["OrdinaryKriging", "UniversalKriging", "OrdinaryKriging3D", "UniversalKriging3D"]
+__all__ = ["OrdinaryKriging", "UniversalKriging", "OrdinaryKriging3D", "UniversalKriging3D", "kt", "ok", "uk", "ok3d", "uk3d", "kriging_tools", "__version__"]
 __version__ = "0.1.0"

@@ -145,6 +145,10 @@ class _KrigingBase:
         else:  # the reference bins the experimental variogram even when parameters are given; here on first use
             self.__dict__.pop("lags", None)
             self.__dict__.pop("semivariance", None)
+            if np.size(self._values()) < 2:
+                # ... and therefore cannot be constructed on a single station: the maximum over its (empty) pair distances raises
+                # (core.py:465 dmax = np.amax(d)); the lazy binning here would let the object through
+                raise ValueError("zero-size array to reduction operation maximum which has no identity")
         self._nlags = nlags
         for name in self._LAZY_STATS:  # a new variogram invalidates the statistics
             if self.__dict__.get(name, 0) is not None:
@@ -304,6 +308,7 @@ class _KrigingBase:
         """Everything execute() does on the host before the solve -> _Pts.  Grids ('grid' / 'masked') are handed to the
         device as axes + the anisotropy matrices unless a drift callable needs the adjusted coordinates on the host
         (functional drifts) or MIK_DEVICE_GRID=0 asks for the host meshgrid."""
+        self._point_dtype = self._narrow_dtype(axes)
         if (style not in ("grid", "masked") or _os.environ.get("MIK_DEVICE_GRID", "1") == "0"
                 or getattr(self, "functional_drift", False)):
             # coordinate arrays.  Round 3: they too are adjusted on the device (mik_adjust_points; the host only stacks them) unless
@@ -315,13 +320,41 @@ class _KrigingBase:
             if not raw:
                 return _Pts(shape, mask, extra, arrays=pts)
             rot, stretch = core.anisotropy_matrices(self._ndim, self._scaling(), self._angle())
-            return _Pts(shape, mask, extra, arrays=pts, center=self._center(), rot=rot, stretch=stretch, raw=True)
+            return _Pts(shape, mask, extra, arrays=self._as_centred(pts), center=self._center(), rot=rot, stretch=stretch, raw=True)
         axes, shape, mask = self._grid_from(style, axes, mask)
         extra = self._grid_rows(style, axes, shape, mask, specified_drift_arrays, backend)
         if getattr(self, "coordinates_type", "euclidean") == "geographic":
             return _Pts(shape, mask, extra, axes=axes)  # no anisotropy correction in spherical coordinates (ok.py:892-896)
         rot, stretch = core.anisotropy_matrices(self._ndim, self._scaling(), self._angle())
-        return _Pts(shape, mask, extra, axes=axes, center=self._center(), rot=rot, stretch=stretch)
+        return _Pts(shape, mask, extra, axes=self._as_centred(axes), center=self._center(), rot=rot, stretch=stretch)
+
+    _point_dtype = None
+
+    def _narrow_dtype(self, axes):
+        """The reference never casts the prediction coordinates (ok.py:849-850: np.array(xpoints, copy=True)) and centres them IN PLACE
+        (core.py:146 `X -= center`, X = np.vstack of the coordinate arrays): when every array is float32 (or float16) the centred
+        coordinates are rounded to that type -- 1e-7 relative, 1.7e-7 on z in the differential run of scripts/edge_forms_vs_reference.py --
+        before the rotation continues in float64.  Returns that dtype, or None when the arrays promote to float64 (integer arrays: the
+        reference's in-place subtract raises UFuncTypeError; here they are kriged as float64).  Geographic coordinates are not centred."""
+        if getattr(self, "coordinates_type", "euclidean") == "geographic":
+            return None
+        try:
+            rt = np.result_type(*[a.dtype if isinstance(a, np.ndarray) else np.asarray(a).dtype for a in axes])
+        except Exception:  # noqa: BLE001  (ragged / object input: the float64 cast that follows raises what it raises)
+            return None
+        return rt if rt.kind == "f" and rt.itemsize < 8 else None
+
+    def _as_centred(self, pts):
+        """pts (float64: a list of axes, an (n, d) array or _Cols) as the reference's narrower in-place centring leaves them:
+        x -> float64(narrow(x - c)) + c.  (The `+ c`, undone by the adjustment's own `- c`, costs an ulp of float64: nine orders below the effect.)"""
+        nd = self._point_dtype
+        if nd is None:
+            return pts
+        cen = self._center()
+        if isinstance(pts, list):
+            return [(a - c).astype(nd).astype(np.float64) + c for a, c in zip(pts, cen)]
+        cols = [(np.asarray(pts[:, k]) - c).astype(nd).astype(np.float64) + c for k, c in enumerate(cen)]
+        return _Cols(cols) if isinstance(pts, _Cols) else np.stack(cols, axis=1)
 
     def _grid_rows(self, style, axes, shape, mask, specified_drift_arrays, backend):
         return None  # host-evaluated drift rows of a grid: universal kriging only
@@ -332,7 +365,7 @@ class _KrigingBase:
         pts, shape, mask = self._points_from(style, axes, mask, columns=not adjust)
         if getattr(self, "coordinates_type", "euclidean") == "geographic" or not adjust:
             return pts, shape, mask, None  # no anisotropy correction in spherical coordinates (ok.py:892-896)
-        return core.adjust_for_anisotropy(pts, self._center(), self._scaling(), self._angle()), shape, mask, None
+        return core.adjust_for_anisotropy(self._as_centred(pts), self._center(), self._scaling(), self._angle()), shape, mask, None
 
     # ---------------------------------------------------------------- variogram-fit statistics (core.py:759-851)
     _LAZY_STATS = ("delta", "sigma", "epsilon", "Q1", "Q2", "cR")
@@ -524,6 +557,9 @@ class _KrigingBase:
             if len(set(sizes)) != 1:
                 raise ValueError("xpoints and ypoints%s must have same dimensions when treated as listing "
                                  "discrete points." % (", zpoints" if self._ndim == 3 else ""))
+            if any(a.ndim > 1 for a in axes):
+                # the reference stacks xpts[:, np.newaxis] columns (ok.py:886-888) and hands them to cdist, which refuses anything but (n, d)
+                raise ValueError("XB must be a 2-dimensional array.")
             shape = (sizes[0],)
             if columns:
                 pts = _Cols([a.reshape(-1) for a in axes])
@@ -536,8 +572,8 @@ class _KrigingBase:
         if style == "masked":
             z = np.ma.array(z, mask=mask)
             ss = np.ma.array(ss, mask=mask)
-        elif backend == "vectorized":
-            # reference quirk: _exec_vector returns MaskedArrays (all-False mask) in every style
+        elif backend == "vectorized" and z.size:
+            # reference quirk: _exec_vector returns MaskedArrays (all-False mask) in every style (an EMPTY point list comes back as plain arrays)
             z = np.ma.array(z, mask=np.zeros(z.shape, dtype=bool))
             ss = np.ma.array(ss, mask=np.zeros(ss.shape, dtype=bool))
         return z.reshape(shape), ss.reshape(shape)
@@ -794,7 +830,7 @@ class UniversalKriging(OrdinaryKriging):
         rows.extend(self._spec_rows(style, shape, pts.shape[0], specified_drift_arrays))
         if not adjust:  # (never with functional drifts: _prepare) the device adjusts the coordinates
             return pts, shape, mask, (np.array(rows, dtype=np.float64) if rows else None)
-        pts_adj = core.adjust_for_anisotropy(pts, self._center(), self._scaling(), self._angle())
+        pts_adj = core.adjust_for_anisotropy(self._as_centred(pts), self._center(), self._scaling(), self._angle())
         if self.functional_drift:
             rows.extend(np.asarray(f(pts_adj[:, 0], pts_adj[:, 1]), dtype=np.float64) for f in self.functional_drift_terms)
         return pts_adj, shape, mask, (np.array(rows, dtype=np.float64) if rows else None)
@@ -953,7 +989,7 @@ class UniversalKriging3D(OrdinaryKriging3D):
         rows = self._spec_rows(style, shape, pts.shape[0], specified_drift_arrays)
         if not adjust:  # (never with functional drifts: _prepare) the device adjusts the coordinates
             return pts, shape, mask, (np.array(rows, dtype=np.float64) if rows else None)
-        pts_adj = core.adjust_for_anisotropy(pts, self._center(), self._scaling(), self._angle())
+        pts_adj = core.adjust_for_anisotropy(self._as_centred(pts), self._center(), self._scaling(), self._angle())
         if self.functional_drift:
             rows.extend(np.asarray(f(pts_adj[:, 0], pts_adj[:, 1], pts_adj[:, 2]), dtype=np.float64)
                         for f in self.functional_drift_terms)

@@ -397,6 +397,67 @@ def test_module_paths_of_the_reference_resolve():
     import pykrige_amd.compat, pykrige_amd.core, pykrige_amd.variogram_models  # noqa: F401
 
 
+def test_bare_import_binds_the_submodules_like_upstream():
+    """`import pykrige; pykrige.ok.OrdinaryKriging(...)` works upstream (pykrige/__init__.py:44-48 imports from the submodules, which binds them,
+    and lists them in __all__): the same with the package name swapped, in a fresh interpreter."""
+    import subprocess
+    import sys
+
+    code = ("import pykrige_amd as p; assert p.ok.OrdinaryKriging is p.OrdinaryKriging and p.uk.UniversalKriging is p.UniversalKriging; "
+            "assert p.ok3d.OrdinaryKriging3D is p.OrdinaryKriging3D and p.uk3d.UniversalKriging3D is p.UniversalKriging3D; "
+            "assert p.kriging_tools is p.kt and p.__version__; assert all(hasattr(p, n) for n in p.__all__)")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-1500:]
+
+
+def test_narrow_float_points_are_centred_as_the_reference_centres_them():
+    """The reference never casts the prediction coordinates (ok.py:849-850) and centres them in place (core.py:146 `X -= center`): float32 coordinate
+    arrays are rounded to float32 AFTER the subtraction (float64 arithmetic, float32 store), then rotated in float64.  _narrow_dtype / _as_centred restate
+    that for every route the points take (host adjustment, raw columns and grid axes for the device); the differential run against the real reference is
+    tests/test_input_forms_vs_reference.py (GPU).  Also here: the forms the reference refuses (2-D point arrays, a single station)."""
+    import pykrige_amd as pa
+    from pykrige_amd import core
+
+    rng = np.random.default_rng(5)
+    x, y, v = rng.random(30) * 7 + 3, rng.random(30) * 2 - 9, rng.random(30)
+    m = pa.OrdinaryKriging(x, y, v, variogram_model="exponential", variogram_parameters=[1.0, 2.0, 0.1], anisotropy_scaling=2.5, anisotropy_angle=33.0)
+    px, py = (rng.random(200) * 7 + 3).astype(np.float32), (rng.random(200) * 2 - 9).astype(np.float32)
+    # the reference's operations, as written (core.py:142-146, 190-193)
+    X = np.vstack((px, py)).T
+    assert X.dtype == np.float32
+    X -= np.asarray(m._center())[None, :]
+    rot, stretch = core.anisotropy_matrices(2, m._scaling(), m._angle())
+    want = np.dot(np.diag(stretch), np.dot(rot, X.T)).T + np.asarray(m._center())[None, :]  # (anisotropy_matrices returns the stretch diagonal)
+    assert m._narrow_dtype((px, py)) == np.float32
+    assert m._narrow_dtype((px, py.astype(np.float64))) is None and m._narrow_dtype((px.tolist(), py.tolist())) is None  # (Python floats are float64)
+    assert m._narrow_dtype((list(px), list(py))) == np.float32  # (a list of np.float32 scalars becomes a float32 array upstream as well)
+    assert m._narrow_dtype((np.arange(3), np.arange(3))) is None and m._narrow_dtype((0.5, 0.25)) is None
+    for style_axes, route in (((px, py), "points"),):
+        P = m._prepare(route, style_axes, None)
+        got_raw = np.stack([np.asarray(P.arrays[:, 0]), np.asarray(P.arrays[:, 1])], axis=1)  # raw columns: what the device adjusts
+        got = core.adjust_for_anisotropy(got_raw.copy(), m._center(), m._scaling(), m._angle())
+        plain = core.adjust_for_anisotropy(np.stack([px.astype(np.float64), py.astype(np.float64)], axis=1), m._center(), m._scaling(), m._angle())
+        assert np.abs(got - want).max() <= 4e-15, np.abs(got - want).max()
+        assert np.abs(plain - want).max() > 1e-8  # (what kriging the float32 values as exact doubles would have been off by)
+    os.environ["MIK_DEVICE_POINTS"] = "0"  # the host-adjustment route
+    try:
+        P = m._prepare("points", (px, py), None)
+        assert np.abs(np.asarray(P.arrays) - want).max() <= 4e-15
+    finally:
+        del os.environ["MIK_DEVICE_POINTS"]
+    gx, gy = np.linspace(3, 10, 9, dtype=np.float32), np.linspace(-9, -7, 5, dtype=np.float32)
+    P = m._prepare("grid", (gx, gy), None)  # grid axes for the device: centring is per axis
+    for got, ax, c in zip(P.axes, (gx, gy), m._center()):
+        assert np.array_equal(got, (ax.astype(np.float64) - c).astype(np.float32).astype(np.float64) + c)
+    assert m._prepare("grid", (gx.astype(np.float64), gy), None).axes[1].tolist() == gy.astype(np.float64).tolist()  # mixed dtypes promote to float64: no rounding
+    geo = pa.OrdinaryKriging(x, y, v, variogram_model="exponential", variogram_parameters=[1.0, 2.0, 0.1], coordinates_type="geographic")
+    assert geo._narrow_dtype((px, py)) is None  # geographic coordinates are not centred (ok.py:892-896)
+    with pytest.raises(ValueError):
+        m._prepare("points", (px.reshape(20, 10), py.reshape(20, 10)), None)  # cdist refuses them upstream
+    with pytest.raises(ValueError, match="zero-size array"):
+        pa.OrdinaryKriging(x[:1], y[:1], v[:1], variogram_model="exponential", variogram_parameters=[1.0, 2.0, 0.1])
+
+
 def test_anisotropy_adjustment_is_bit_identical_to_the_reference():
     """core.adjust_for_anisotropy (reference core.py:120-193): same NumPy operations in the same order, so the adjusted
     coordinates -- which decide the `abs(bd) <= eps` exact-hit rule -- equal the real reference's bit for bit
