@@ -136,6 +136,7 @@ class _KrigingBase:
 
     def _set_variogram_parameters(self, variogram_parameters, nlags, weight):
         plist = core.make_variogram_parameter_list(self.variogram_model, variogram_parameters)
+        fitted = plist is None
         if plist is None:
             from . import variogram_fit  # constructor-time only; never on the execute() path
 
@@ -153,7 +154,8 @@ class _KrigingBase:
         for name in self._LAZY_STATS:  # a new variogram invalidates the statistics
             if self.__dict__.get(name, 0) is not None:
                 self.__dict__.pop(name, None)
-        self.variogram_model_parameters = [float(v) for v in plist]
+        # a FITTED parameter set is the least-squares solution as it comes, an ndarray (core.py:575-627 returns res.x); a given one is a list (core.py:353-357)
+        self.variogram_model_parameters = np.array([float(v) for v in plist]) if fitted else [float(v) for v in plist]
         if self.verbose:
             print("Using '%s' Variogram Model" % self.variogram_model)
             print("Parameters:", self.variogram_model_parameters, "\n")

@@ -26,3 +26,17 @@ def test_unusual_input_forms_behave_as_in_the_reference():
     bad = [ln for ln in lines if "DISAGREE" in ln or "DIFFERENT TYPES" in ln]
     assert r.returncode == 0 and not bad, "\n".join(bad + lines[-3:] + [r.stderr[-2000:]])
     assert len(agree) >= 185, len(agree)  # (the cases that compare or raise alike; the rest are notes: forms the reference itself fails on by accident)
+
+
+@pytest.mark.gpu
+def test_constructed_objects_carry_the_reference_attributes():
+    """Every attribute of the reference's instances (name, type, dtype, shape, value: X_ADJUSTED, lags, semivariance, the FITTED variogram parameters as
+    the ndarray the least-squares solver returns, delta / sigma / epsilon, Q1 / Q2 / cR ...) and its accessor methods, for eight constructor forms."""
+    sys.path.insert(0, ROOT)
+    from oracle import ref_package as rp
+
+    if not rp.available():
+        pytest.skip("the staged reference (oracle/_ref) is not here")
+    r = subprocess.run([sys.executable, "-u", os.path.join(ROOT, "scripts", "attributes_vs_reference.py")], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1500:]
+    assert r.stdout.count("missing []; differing []") == 8, r.stdout[-3000:]
