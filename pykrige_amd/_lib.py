@@ -199,6 +199,8 @@ class Handle:
         self.device = int(device)
         self._keep = []
         self.option_epoch = 0  # bumped by every option / device-group change (callers that cache a factor watch it)
+        self.env_sig = _env_sig()  # the MIK_* environment the library read its defaults from when it created the handle
+        self.pid = os.getpid()
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
@@ -422,6 +424,7 @@ class Handle:
     def comm_init(self, nranks, rank, uid):
         if len(uid) != 128:
             raise ValueError("unique id must be 128 bytes")
+        self.option_epoch += 1  # (a handle with a communicator is never parked)
         check(self._lib.mik_comm_init(self._h, int(nranks), int(rank), C.create_string_buffer(uid, 128)))
 
     def bcast_factor(self, root=0):
@@ -463,7 +466,60 @@ def slab_of(n, members, i):
 def set_devices(n):
     """Process-wide default: every handle created from now on spans `n` GPUs of the node (0 = all visible, 1 = one).  The
     environment variable MIK_NGPU does the same without touching the script."""
+    flush_handle_pool()  # (parked handles were created under the old default)
     check(load().mik_set_devices(int(n)))
+
+
+# ---- parked handles.  mik_create + mik_destroy cost 20 - 30 ms (four HIP streams with their queues, events, later the buffers' hipFree) where a whole
+# execute() of a few hundred stations takes 1 - 3 ms: code that builds many small kriging objects (cross-validation, sliding windows) spent 95 % of its time
+# there (scripts/small_object_breakdown.py).  A kriging object that goes away therefore PARKS its handle instead of destroying it, and the next object takes
+# it over -- but only a handle nobody touched: no option or device group set through it, no custom variogram callback, created by this process under the same
+# MIK_* environment (the library reads its option defaults from it at mik_create), and holding little device memory (the caller's estimate against
+# MIK_HANDLE_POOL_BYTES, default 512 MiB).  MIK_HANDLE_POOL = how many may be parked (default 4, 0 = off).  Every call that uses a handle first replaces
+# what the previous owner left in it: mik_set_problem, mik_set_points / mik_set_grid.
+import threading as _threading  # noqa: E402
+
+_pool_lock = _threading.Lock()
+_pool = []
+
+
+def _env_sig():
+    return tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("MIK_") or k == "LOCAL_RANK"))
+
+
+def acquire_handle():
+    """A parked handle that fits the current process and environment, else a new one."""
+    sig, pid = _env_sig(), os.getpid()
+    with _pool_lock:
+        for i, h in enumerate(_pool):
+            if h.pid == pid and h.env_sig == sig:
+                return _pool.pop(i)
+    return Handle()
+
+
+def release_handle(h, device_bytes):
+    """Park `h` for the next kriging object, or destroy it (touched, large, pool full or switched off)."""
+    if h is None or not getattr(h, "_h", None):
+        return
+    try:
+        limit = int(os.environ.get("MIK_HANDLE_POOL", "4"))
+        cap = float(os.environ.get("MIK_HANDLE_POOL_BYTES", str(512 * 2 ** 20)))
+    except ValueError:
+        limit, cap = 0, 0.0
+    if limit > 0 and h.option_epoch == 0 and getattr(h, "_custom_cb", None) is None and h.pid == os.getpid() and device_bytes <= cap:
+        with _pool_lock:
+            if len(_pool) < limit:
+                h._keep = []  # (the previous owner's arrays: set_problem copied them to the device long ago)
+                _pool.append(h)
+                return
+    h.close()
+
+
+def flush_handle_pool():
+    with _pool_lock:
+        parked, _pool[:] = list(_pool), []
+    for h in parked:
+        h.close()
 
 
 def selftest_exchange(members, init_limit_s, bcast_limit_s):

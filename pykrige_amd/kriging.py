@@ -146,10 +146,6 @@ class _KrigingBase:
         else:  # the reference bins the experimental variogram even when parameters are given; here on first use
             self.__dict__.pop("lags", None)
             self.__dict__.pop("semivariance", None)
-            if np.size(self._values()) < 2:
-                # ... and therefore cannot be constructed on a single station: the maximum over its (empty) pair distances raises
-                # (core.py:465 dmax = np.amax(d)); the lazy binning here would let the object through
-                raise ValueError("zero-size array to reduction operation maximum which has no identity")
         self._nlags = nlags
         for name in self._LAZY_STATS:  # a new variogram invalidates the statistics
             if self.__dict__.get(name, 0) is not None:
@@ -230,8 +226,27 @@ class _KrigingBase:
     # ---------------------------------------------------------------- device plumbing
     def _get_handle(self):
         if self._handle is None:
-            self._handle = _lib.Handle()
+            self._handle = _lib.acquire_handle()  # a parked one if there is (mik_create + mik_destroy: 20 - 30 ms; _lib.release_handle)
         return self._handle
+
+    _max_points = 0  # most points one call of this object handed to its handle
+
+    def _handle_bytes(self):
+        """Device memory the handle holds at most after this object's calls, for the parking rule: matrix, its probe copy and panels (3 Mp^2) + the
+        right-hand sides of two launches of <= 131 072 points (2 npt Mp) + stations and results."""
+        n = int(np.size(self._values())) + 16
+        mp = -(-n // 128) * 128
+        npt = min(int(self._max_points), 131072)
+        return 8.0 * (3.0 * mp * mp + 2.0 * npt * mp + 8.0 * self._max_points + 8.0 * n)
+
+    def __del__(self):
+        h = self.__dict__.get("_handle")
+        if h is not None:
+            self._handle = None
+            try:
+                _lib.release_handle(h, self._handle_bytes())
+            except Exception:  # noqa: BLE001  (interpreter shutdown: the handle's own __del__ closes it)
+                pass
 
     def _values(self):
         return self.VALUES if self._ndim == 3 else self.Z
@@ -301,6 +316,7 @@ class _KrigingBase:
 
     def _solve(self, P):
         h = self._upload_and_factor()
+        self._max_points = max(self._max_points, int(np.prod(P.shape)))
         P.load(h, self._ndim)
         h.predict()
         self.last_timing = h.timing()
@@ -498,6 +514,7 @@ class _KrigingBase:
         """cKDTree.query + _exec_loop_moving_window / _c_exec_loop_moving_window on the device."""
         h = self._get_handle()
         self._set_problem(h)
+        self._max_points = max(self._max_points, int(np.prod(P.shape)))
         P.load(h, self._ndim, with_extra=False)
         try:
             h.predict_moving_window(int(n_closest_points))

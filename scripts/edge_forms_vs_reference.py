@@ -29,7 +29,7 @@ def run(make, call):
 def same(name, make, call, tol=(1e-8, 1e-6)):
     (ka, ra), (kb, rb) = run(make, call)
     deliberate = (ValueError, OSError, np.linalg.LinAlgError)  # what the reference raises on purpose; its TypeError / IndexError / UFuncTypeError are accidents
-    if ka != kb and ka == "raise" and not isinstance(ra, deliberate):
+    if ka != kb and ka == "raise" and (not isinstance(ra, deliberate) or "zero-size array" in str(ra)):  # (np.amax of no pair distances: one station)
         print("%-58s note: the reference fails with %s (%s); the drop-in returns values" % (name, type(ra).__name__, str(ra)[:60]))
         return
     if ka != kb:

@@ -40,3 +40,102 @@ def test_constructed_objects_carry_the_reference_attributes():
     r = subprocess.run([sys.executable, "-u", os.path.join(ROOT, "scripts", "attributes_vs_reference.py")], cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1500:]
     assert r.stdout.count("missing []; differing []") == 8, r.stdout[-3000:]
+
+
+@pytest.mark.gpu
+def test_a_kriging_object_that_goes_away_parks_its_handle_for_the_next_one(monkeypatch):
+    """mik_create + mik_destroy cost 20 - 30 ms, a whole execute() of a few hundred stations 1 - 3 ms (scripts/small_object_breakdown.py): an object that is
+    garbage-collected parks its handle (pykrige_amd/_lib.py: release_handle) and the next object takes it over -- same results bit for bit as on a fresh
+    handle; never a handle somebody set an option, a device group or a custom variogram on, never across a change of the MIK_* environment (the library
+    reads its option defaults from it at mik_create), never one that holds much device memory."""
+    import gc
+
+    import numpy as np
+
+    sys.path.insert(0, ROOT)
+    import pykrige_amd as pa
+    from pykrige_amd import _lib
+
+    rng = np.random.default_rng(3)
+    gx = np.linspace(0, 1, 40)
+
+    def model(n=300, seed=0, **kw):
+        r = np.random.default_rng(seed)
+        return pa.OrdinaryKriging(r.random(n), r.random(n), r.random(n), variogram_model=kw.pop("variogram_model", "exponential"), variogram_parameters=[1.0, 0.3, 0.05], **kw)
+
+    _lib.flush_handle_pool()
+    monkeypatch.setenv("MIK_HANDLE_POOL", "0")  # reference results on handles of their own
+    want = [tuple(np.array(a) for a in model(seed=s).execute("grid", gx, gx)) for s in range(3)]
+    want_mw = tuple(np.array(a) for a in model(seed=7).execute("grid", gx, gx, backend="loop", n_closest_points=9))
+    monkeypatch.setenv("MIK_HANDLE_POOL", "4")
+    gc.collect()
+    assert not _lib._pool
+    m = model(seed=0)
+    got = m.execute("grid", gx, gx)
+    first = m._get_handle()._h.value
+    del m
+    gc.collect()
+    assert len(_lib._pool) == 1 and _lib._pool[0]._h.value == first
+    # the next objects -- other stations, another model, a moving window, a 3-D problem -- run on the parked handle and get what fresh handles gave
+    for s in (1, 2, 0):
+        m = model(seed=s)
+        got = m.execute("grid", gx, gx)
+        assert m._get_handle()._h.value == first
+        assert np.array_equal(got[0], want[s][0]) and np.array_equal(got[1], want[s][1])
+        del m
+        gc.collect()
+    m = model(seed=7)
+    got = m.execute("grid", gx, gx, backend="loop", n_closest_points=9)
+    assert m._get_handle()._h.value == first and np.array_equal(got[0], want_mw[0]) and np.array_equal(got[1], want_mw[1])
+    del m
+    m3 = pa.OrdinaryKriging3D(rng.random(100), rng.random(100), rng.random(100), rng.random(100), variogram_model="gaussian", variogram_parameters=[1.0, 0.4, 0.02])
+    m3.execute("grid", gx[:6], gx[:5], gx[:4])
+    assert m3._get_handle()._h.value == first
+    del m3
+    gc.collect()
+    assert len(_lib._pool) == 1
+    # two live objects: two handles; both come back
+    a, b = model(seed=1), model(seed=2)
+    ra, rb = a.execute("grid", gx, gx), b.execute("grid", gx, gx)
+    assert a._get_handle()._h.value != b._get_handle()._h.value
+    assert np.array_equal(ra[0], want[1][0]) and np.array_equal(rb[0], want[2][0])
+    del a, b
+    gc.collect()
+    assert len(_lib._pool) == 2
+    # touched handles are destroyed, not parked
+    _lib.flush_handle_pool()
+    m = model(seed=1)
+    m._get_handle().set_option("symmetric", 0)
+    m.execute("grid", gx, gx)
+    del m
+    gc.collect()
+    assert not _lib._pool
+    m = model(seed=1, variogram_model="custom", variogram_function=lambda p, d: p[0] * (1 - np.exp(-d / p[1])) + p[2])
+    m.execute("grid", gx, gx)
+    del m
+    gc.collect()
+    assert not _lib._pool
+    # a handle parked under another MIK_* environment is not taken over
+    m = model(seed=1)
+    m.execute("grid", gx, gx)
+    del m
+    gc.collect()
+    assert len(_lib._pool) == 1
+    parked = _lib._pool[0]._h.value
+    monkeypatch.setenv("MIK_FACTOR", "lu")
+    m = model(seed=1)
+    got = m.execute("grid", gx, gx)
+    assert m._get_handle()._h.value != parked and m.last_timing["factor_path"] == 2
+    assert np.abs(got[0] - want[1][0]).max() < 1e-9
+    del m
+    monkeypatch.delenv("MIK_FACTOR")
+    gc.collect()
+    # a large problem's handle is not kept
+    _lib.flush_handle_pool()
+    monkeypatch.setenv("MIK_HANDLE_POOL_BYTES", str(8 * 2 ** 20))
+    m = model(n=1500, seed=4)
+    m.execute("grid", gx, gx)
+    del m
+    gc.collect()
+    assert not _lib._pool
+    _lib.flush_handle_pool()
