@@ -239,6 +239,14 @@ class _KrigingBase:
         npt = min(int(self._max_points), 131072)
         return 8.0 * (3.0 * mp * mp + 2.0 * npt * mp + 8.0 * self._max_points + 8.0 * n)
 
+    def __getstate__(self):
+        """Pickling / copy.deepcopy (sklearn's clone, joblib workers, cached models): upstream's objects are plain Python attributes and travel; here the
+        device side -- the library handle and the note of what is factored in it -- stays behind and the copy builds its own on its first execute()."""
+        state = dict(self.__dict__)
+        state["_handle"] = None
+        state.pop("_factor_key", None)
+        return state
+
     def __del__(self):
         h = self.__dict__.get("_handle")
         if h is not None:

@@ -139,3 +139,72 @@ def test_a_kriging_object_that_goes_away_parks_its_handle_for_the_next_one(monke
     gc.collect()
     assert not _lib._pool
     _lib.flush_handle_pool()
+
+
+def test_kriging_objects_pickle_and_deepcopy_without_their_device_state():
+    """Upstream's objects are plain attributes: sklearn's clone, joblib workers and model caches pickle / deepcopy them -- also AFTER an execute().  Here the
+    library handle (ctypes) and the note of what is factored in it stay behind (CPU: a stand-in handle; the GPU twin is below)."""
+    import copy
+    import ctypes as C
+    import pickle
+
+    import numpy as np
+
+    sys.path.insert(0, ROOT)
+    import pykrige_amd as pa
+
+    class StandIn:
+        def __init__(self):
+            self._h, self.option_epoch, self.pid, self._custom_cb = C.c_void_p(123), 1, -1, None
+
+        def close(self):
+            pass
+
+    rng = np.random.default_rng(0)
+    for m in (pa.OrdinaryKriging(rng.random(30), rng.random(30), rng.random(30), variogram_model="exponential", variogram_parameters=[1.0, 0.3, 0.05]),
+              pa.UniversalKriging3D(rng.random(30), rng.random(30), rng.random(30), rng.random(30), variogram_model="linear", drift_terms=["regional_linear"])):
+        m._handle, m._factor_key = StandIn(), ("key", 0)
+        for c in (pickle.loads(pickle.dumps(m)), copy.deepcopy(m), copy.copy(m)):
+            assert c._handle is None and not hasattr(c, "_factor_key") and type(c) is type(m)
+            assert np.array_equal(c._coords_adj, m._coords_adj) and list(c.variogram_model_parameters) == list(m.variogram_model_parameters)
+        assert m._handle is not None  # the original keeps its own
+        m._handle = None
+
+
+@pytest.mark.gpu
+def test_kriging_objects_travel_and_change_style_between_calls():
+    """On the device: a pickled / deep-copied object kriges what the original kriges, and one object asked for a grid, a point list, a masked grid, a moving
+    window and the grid again answers each as a fresh object would (nothing of a call is left in the handle for the next)."""
+    import copy
+    import pickle
+
+    import numpy as np
+
+    sys.path.insert(0, ROOT)
+    import pykrige_amd as pa
+
+    rng = np.random.default_rng(11)
+    x, y, v = rng.random(200), rng.random(200), rng.random(200)
+    gx, gy = np.linspace(0, 1, 21), np.linspace(0, 1, 17)
+    mask = rng.random((17, 21)) < 0.3
+
+    def fresh():
+        return pa.UniversalKriging(x, y, v, variogram_model="spherical", variogram_parameters=[1.0, 0.35, 0.02], drift_terms=["regional_linear"])
+
+    calls = [lambda m: m.execute("grid", gx, gy), lambda m: m.execute("points", gx[:17], gy), lambda m: m.execute("masked", gx, gy, mask=mask),
+             lambda m: m.execute("grid", gx[:5], gy[:3], backend="loop"), lambda m: m.execute("grid", gx, gy)]
+    want = [c(fresh()) for c in calls]
+    one = fresh()
+    for c, w in zip(calls, want):
+        got = c(one)
+        for a, b in zip(got, w):
+            assert np.array_equal(np.ma.getdata(a), np.ma.getdata(b)) and np.array_equal(np.ma.getmaskarray(a), np.ma.getmaskarray(b))
+    for trav in (pickle.loads(pickle.dumps(one)), copy.deepcopy(one)):
+        assert trav._handle is None
+        got = trav.execute("grid", gx, gy)
+        assert np.array_equal(np.ma.getdata(got[0]), np.ma.getdata(want[0][0])) and np.array_equal(np.ma.getdata(got[1]), np.ma.getdata(want[0][1]))
+    ok = pa.OrdinaryKriging(x, y, v, variogram_model="exponential", variogram_parameters=[1.0, 0.35, 0.02])
+    w1 = ok.execute("grid", gx, gy, backend="loop", n_closest_points=12)
+    w2 = ok.execute("grid", gx, gy)
+    w3 = pickle.loads(pickle.dumps(ok)).execute("grid", gx, gy, backend="loop", n_closest_points=12)
+    assert np.array_equal(w1[0], w3[0]) and np.array_equal(w1[1], w3[1]) and not np.array_equal(w1[0], np.ma.getdata(w2[0]))
