@@ -233,5 +233,25 @@ same("parameter list too long", lambda mod: ok2(mod, variogram_parameters=[1.0, 
 same("exact_values not a bool", lambda mod: ok2(mod, exact_values=1), lambda m: m.execute("grid", gx, gy))
 same("update_variogram_model, then execute", ok2, lambda m: (m.update_variogram_model("spherical", {"sill": 0.8, "range": 0.5, "nugget": 0.1}), m.execute("grid", gx, gy))[1])
 same("update_variogram_model with new anisotropy", ok2, lambda m: (m.update_variogram_model("gaussian", [0.8, 0.5, 0.1], anisotropy_scaling=2.0, anisotropy_angle=45.0), m.execute("grid", gx, gy))[1])
+# third batch: attributes changed on a live object between two execute() calls (upstream reads them at every call: ok.py:898-927)
+def mutate(change):
+    def call(m):
+        m.execute("grid", gx, gy)
+        change(m)
+        return m.execute("grid", gx, gy)
+    return call
+
+
+same("variogram_model_parameters replaced between calls", ok2, mutate(lambda m: setattr(m, "variogram_model_parameters", [0.7, 0.25, 0.1])))
+same("variogram_model_parameters changed in place", ok2, mutate(lambda m: m.variogram_model_parameters.__setitem__(1, 0.2)))
+same("station values changed in place", ok2, mutate(lambda m: m.Z.__setitem__(slice(0, 5), 3.0)))
+same("station values replaced", ok2, mutate(lambda m: setattr(m, "Z", m.Z * 2.0 + 1.0)))
+same("exact_values switched off between calls", lambda mod: ok2(mod, xs=np.r_[x, gx[3]], ys=np.r_[y, gy[2]], vs=np.r_[v, 5.0]), mutate(lambda m: setattr(m, "exact_values", False)))
+same("adjusted station coordinates changed in place", ok2, mutate(lambda m: m.X_ADJUSTED.__setitem__(0, 0.5)))
+same("variogram function swapped between calls", ok2, mutate(lambda m: (setattr(m, "variogram_function", m.variogram_dict["gaussian"]), setattr(m, "variogram_model", "gaussian"))))
+same("pseudo_inv switched on between calls", lambda mod: ok2(mod, xd, yd, vd, variogram_parameters={"sill": 1.0, "range": 0.4, "nugget": 0.0}, pseudo_inv=False),
+     lambda m: (setattr(m, "pseudo_inv", True), m.execute("grid", gx, gy))[1], tol=(1e-6, 1e-6))
+same("UK: drift switched off between calls", lambda mod: uk2(mod, drift_terms=["regional_linear"]), mutate(lambda m: setattr(m, "regional_linear_drift", False)))
+same("3-D: values changed in place", ok3, lambda m: (m.execute("grid", gx[:5], gy[:4], gx[:3]), m.VALUES.__setitem__(0, 9.0), m.execute("grid", gx[:5], gy[:4], gx[:3]))[2])
 print("\n%d case(s) disagree%s" % (len(FAIL), ": " + "; ".join(FAIL) if FAIL else ""))
 sys.exit(1 if FAIL else 0)
