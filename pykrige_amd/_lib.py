@@ -204,7 +204,8 @@ class Handle:
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
-            self._lib.mik_destroy(self._h)
+            if getattr(self, "pid", os.getpid()) == os.getpid():  # (a forked child only forgets the parent's handle: its HIP objects are not the child's to destroy)
+                self._lib.mik_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -519,7 +520,15 @@ def flush_handle_pool():
     with _pool_lock:
         parked, _pool[:] = list(_pool), []
     for h in parked:
-        h.close()
+        if h.pid == os.getpid():  # (a forked child must not tear down the parent's HIP objects)
+            h.close()
+        else:
+            h._h = None
+
+
+import atexit as _atexit  # noqa: E402
+
+_atexit.register(flush_handle_pool)  # parked handles go while the HIP runtime is still there, not at module teardown
 
 
 def selftest_exchange(members, init_limit_s, bcast_limit_s):
