@@ -370,10 +370,12 @@ class _KrigingBase:
             return None
         return rt if rt.kind == "f" and rt.itemsize < 8 else None
 
-    def _as_centred(self, pts):
+    def _as_centred(self, pts, nd="points"):
         """pts (float64: a list of axes, an (n, d) array or _Cols) as the reference's narrower in-place centring leaves them:
-        x -> float64(narrow(x - c)) + c.  (The `+ c`, undone by the adjustment's own `- c`, costs an ulp of float64: nine orders below the effect.)"""
-        nd = self._point_dtype
+        x -> float64(narrow(x - c)) + c.  (The `+ c`, undone by the adjustment's own `- c`, costs an ulp of float64: nine orders below the effect.)
+        nd: the narrow dtype (default: the one of this call's prediction points, _narrow_dtype)."""
+        if isinstance(nd, str):
+            nd = self._point_dtype
         if nd is None:
             return pts
         cen = self._center()
@@ -766,6 +768,9 @@ class UniversalKriging(OrdinaryKriging):
         if self.point_log_drift:
             if point_drift is None:
                 raise ValueError("Must specify location(s) and strength(s) of point drift terms.")
+            raw = np.asarray(point_drift)
+            # (the wells go through the same in-place centring as the prediction points, uk.py:450-459: a float32 point_drift array is rounded there)
+            self._point_log_dtype = raw.dtype if raw.dtype.kind == "f" and raw.dtype.itemsize < 8 else None
             point_log = np.atleast_2d(np.squeeze(np.array(point_drift, copy=True, dtype=np.float64)))
             self._point_log_user = point_log
             self._adjust_wells()
@@ -794,8 +799,8 @@ class UniversalKriging(OrdinaryKriging):
         pl = self._point_log_user
         self.point_log_array = np.zeros(pl.shape)
         self.point_log_array[:, 2] = pl[:, 2]
-        self.point_log_array[:, :2] = core.adjust_for_anisotropy(np.vstack((pl[:, 0], pl[:, 1])).T, self._center(),
-                                                                 self._scaling(), self._angle())
+        self.point_log_array[:, :2] = core.adjust_for_anisotropy(self._as_centred(np.vstack((pl[:, 0], pl[:, 1])).T, getattr(self, "_point_log_dtype", None)),
+                                                                 self._center(), self._scaling(), self._angle())
 
     def _calculate_data_point_zscalars(self, x, y, type_="array"):
         return core.bilinear_zscalars(self.external_Z_array, self.external_Z_array_x, self.external_Z_array_y, x, y)

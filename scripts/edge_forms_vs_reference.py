@@ -253,6 +253,16 @@ same("pseudo_inv switched on between calls", lambda mod: ok2(mod, xd, yd, vd, va
      lambda m: (setattr(m, "pseudo_inv", True), m.execute("grid", gx, gy))[1], tol=(1e-6, 1e-6))
 same("UK: drift switched off between calls", lambda mod: uk2(mod, drift_terms=["regional_linear"]), mutate(lambda m: setattr(m, "regional_linear_drift", False)))
 same("3-D: values changed in place", ok3, lambda m: (m.execute("grid", gx[:5], gy[:4], gx[:3]), m.VALUES.__setitem__(0, 9.0), m.execute("grid", gx[:5], gy[:4], gx[:3]))[2])
+ext32 = (rng.random((9, 11)) * 3).astype(np.float32)
+ex32, ey32 = np.linspace(-0.1, 1.1, 11).astype(np.float32), np.linspace(-0.1, 1.1, 9).astype(np.float32)
+for b in ("vectorized", "loop"):
+    same("UK external_Z drift grid and its axes in float32 [%s]" % b, lambda mod: uk2(mod, drift_terms=["external_Z"], external_drift=ext32, external_drift_x=ex32, external_drift_y=ey32),
+         lambda m, b=b: m.execute("grid", gx, gy, backend=b))
+    same("UK external_Z as nested lists, descending y axis [%s]" % b, lambda mod: uk2(mod, drift_terms=["external_Z"], external_drift=ext32[::-1].astype(float).tolist(), external_drift_x=list(ex32.astype(float)),
+                                                                                    external_drift_y=list(ey32.astype(float)[::-1])), lambda m, b=b: m.execute("points", gx[:7], gy, backend=b))
+    same("UK point_drift as a float32 array [%s]" % b, lambda mod: uk2(mod, drift_terms=["point_log"], point_drift=np.array([[0.31, 0.32, 1.0], [0.8, 0.1, -0.5]], dtype=np.float32)),
+         lambda m, b=b: m.execute("grid", gx, gy, backend=b))
+    same("UK point_drift, a single well as a flat list [%s]" % b, lambda mod: uk2(mod, drift_terms=["point_log"], point_drift=[0.31, 0.32, 1.0]), lambda m, b=b: m.execute("grid", gx, gy, backend=b))
 # geographic coordinates in float32: upstream's great-circle arithmetic then runs in float32 on the point side (core.py:81-97: lat1 * pi / 180, cos, sin stay
 # float32) -- an accuracy loss of its own, 1e-7 relative, that cannot be restated through the (lon, lat) the library takes; reported, not held to the bar
 geo = lambda mod: mod.ok.OrdinaryKriging(lon, lat, v, variogram_model="spherical", variogram_parameters={"sill": 1.0, "range": 15.0, "nugget": 0.02}, coordinates_type="geographic")  # noqa: E731
