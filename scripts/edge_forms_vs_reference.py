@@ -253,6 +253,24 @@ same("pseudo_inv switched on between calls", lambda mod: ok2(mod, xd, yd, vd, va
      lambda m: (setattr(m, "pseudo_inv", True), m.execute("grid", gx, gy))[1], tol=(1e-6, 1e-6))
 same("UK: drift switched off between calls", lambda mod: uk2(mod, drift_terms=["regional_linear"]), mutate(lambda m: setattr(m, "regional_linear_drift", False)))
 same("3-D: values changed in place", ok3, lambda m: (m.execute("grid", gx[:5], gy[:4], gx[:3]), m.VALUES.__setitem__(0, 9.0), m.execute("grid", gx[:5], gy[:4], gx[:3]))[2])
+# 3-D forms
+for b in ("vectorized", "loop"):
+    same("3-D points, empty [%s]" % b, ok3, lambda m, b=b: m.execute("points", np.array([]), np.array([]), np.array([]), backend=b))
+    same("3-D one point as scalars [%s]" % b, ok3, lambda m, b=b: m.execute("points", 0.3, 0.7, 0.2, backend=b))
+    same("3-D points, z of another length [%s]" % b, ok3, lambda m, b=b: m.execute("points", gx[:5], gy[:5], gx[:4], backend=b))
+    same("3-D points, x of another length [%s]" % b, ok3, lambda m, b=b: m.execute("points", gx[:4], gy[:5], gx[:5], backend=b))
+    same("3-D grid 1 x 1 x 1 [%s]" % b, ok3, lambda m, b=b: m.execute("grid", [0.5], [0.25], [0.75], backend=b))
+    same("3-D anisotropy + float32 points [%s]" % b, lambda mod: ok3(mod, anisotropy_scaling_y=2.0, anisotropy_scaling_z=0.5, anisotropy_angle_x=10.0, anisotropy_angle_y=20.0, anisotropy_angle_z=30.0),
+         lambda m, b=b: m.execute("points", gx[:5].astype(np.float32), gy[:5].astype(np.float32), gx[2:7].astype(np.float32), backend=b))
+    same("3-D float32 x, float64 y, z (no rounding) [%s]" % b, ok3, lambda m, b=b: m.execute("grid", gx[:5].astype(np.float32), gy[:4], gx[:3], backend=b))
+    same("3-D masked, 2-D mask [%s]" % b, ok3, lambda m, b=b: m.execute("masked", gx[:5], gy[:4], gx[:3], mask=mask3[0], backend=b))
+    same("3-D points on stations [%s]" % b, ok3, lambda m, b=b: m.execute("points", x[:6], y[:6], zc[:6], backend=b))
+    same("3-D moving window k = n [%s]" % b, ok3, lambda m, b=b: m.execute("grid", gx[:5], gy[:4], gx[:3], backend=b, n_closest_points=n)) if b == "loop" else None
+    same("UK3D specified drift, points [%s]" % b, lambda mod: mod.uk3d.UniversalKriging3D(x, y, zc, v, variogram_model="linear", drift_terms=["specified"], specified_drift=[x - zc]),
+         lambda m, b=b: m.execute("points", gx[:5], gy[:5], gx[2:7], backend=b, specified_drift_arrays=[gx[:5] - gx[2:7]])) if b == "vectorized" else None
+    same("UK3D functional drift, float32 grid [%s]" % b, lambda mod: mod.uk3d.UniversalKriging3D(x, y, zc, v, variogram_model="linear", drift_terms=["functional"], functional_drift=[lambda a, c, d: a + d]),
+         lambda m, b=b: m.execute("grid", gx[:5].astype(np.float32), gy[:4].astype(np.float32), gx[:3].astype(np.float32), backend=b))
+    same("UK3D unknown drift term [%s]" % b, lambda mod: mod.uk3d.UniversalKriging3D(x, y, zc, v, variogram_model="linear", drift_terms=["point_log"]), lambda m, b=b: m.execute("grid", gx[:5], gy[:4], gx[:3], backend=b))
 ext32 = (rng.random((9, 11)) * 3).astype(np.float32)
 ex32, ey32 = np.linspace(-0.1, 1.1, 11).astype(np.float32), np.linspace(-0.1, 1.1, 9).astype(np.float32)
 for b in ("vectorized", "loop"):
