@@ -130,11 +130,15 @@ class _KrigingBase:
         self.exact_values = exact_values
         self.verbose = verbose
         self.enable_plotting = enable_plotting
+        if self.enable_plotting and self.verbose:
+            print("Plotting Enabled\n")
         self._user_parameters = variogram_parameters
         self._handle = None
         return variogram_parameters
 
-    def _set_variogram_parameters(self, variogram_parameters, nlags, weight):
+    def _set_variogram_parameters(self, variogram_parameters, nlags, weight, updating=False):
+        if self.verbose:  # (verbose=True narrates what upstream narrates, line for line: ok.py:310-375, 488-553 and the three siblings)
+            print("Updating variogram mode..." if updating else "Initializing variogram model...")
         plist = core.make_variogram_parameter_list(self.variogram_model, variogram_parameters)
         fitted = plist is None
         if plist is None:
@@ -153,10 +157,34 @@ class _KrigingBase:
         # a FITTED parameter set is the least-squares solution as it comes, an ndarray (core.py:575-627 returns res.x); a given one is a list (core.py:353-357)
         self.variogram_model_parameters = np.array([float(v) for v in plist]) if fitted else [float(v) for v in plist]
         if self.verbose:
-            print("Using '%s' Variogram Model" % self.variogram_model)
-            print("Parameters:", self.variogram_model_parameters, "\n")
+            par = self.variogram_model_parameters
+            if type(self) is OrdinaryKriging:
+                print("Coordinates type: '%s'" % self.coordinates_type, "\n")
+            if self.variogram_model == "linear":
+                print("Using '%s' Variogram Model" % "linear")
+                print("Slope:", par[0])
+                print("Nugget:", par[1], "\n")
+            elif self.variogram_model == "power":
+                print("Using '%s' Variogram Model" % "power")
+                print("Scale:", par[0])
+                print("Exponent:", par[1])
+                print("Nugget:", par[2], "\n")
+            elif self.variogram_model == "custom":
+                print("Using Custom Variogram Model")
+            else:
+                print("Using '%s' Variogram Model" % self.variogram_model)
+                print("Partial Sill:", par[0])
+                print("Full Sill:", par[0] + par[2])
+                print("Range:", par[1])
+                print("Nugget:", par[2], "\n")
         if getattr(self, "enable_plotting", False):  # ok.py:355-356, 534-535
             self.display_variogram_model()
+        if self.verbose:
+            print("Calculating statistics on variogram model fit...")
+            # upstream computes them here (always in update_variogram_model and in the UK / 3-D constructors, on request in OrdinaryKriging's) and
+            # prints them; without verbose they stay lazy (_LAZY_STATS)
+            if updating or type(self) is not OrdinaryKriging or getattr(self, "_enable_statistics", False):
+                self._compute_statistics()
 
     def _device_variogram(self, nlags):
         """Experimental semivariogram on the GPU (mik_experimental_variogram) when one is visible and the O(N^2) pair
@@ -212,10 +240,12 @@ class _KrigingBase:
                 warnings.warn("Anisotropy is not compatible with geographic coordinates. Ignoring user set anisotropy.",
                               UserWarning)  # ok.py:478-487
         elif any(v != getattr(self, k) for k, v in anisotropy.items()):
+            if self.verbose:
+                print("Adjusting data for anisotropy...")
             for k, v in anisotropy.items():
                 setattr(self, k, v)
             self._adjust_stations()
-        self._set_variogram_parameters(variogram_parameters, nlags, weight)
+        self._set_variogram_parameters(variogram_parameters, nlags, weight, updating=True)
 
     def update_variogram_model(self, variogram_model, variogram_parameters=None, variogram_function=None, nlags=6,
                                weight=False, anisotropy_scaling=1.0, anisotropy_angle=0.0):
@@ -440,7 +470,9 @@ class _KrigingBase:
         self.Q2 = np.sum(self.epsilon**2) / (self.epsilon.shape[0] - 1)
         self.cR = self.Q2 * np.exp(np.sum(np.log(self.sigma**2)) / self.sigma.shape[0])
         if self.verbose:
-            print("Q1 =", self.Q1, "\nQ2 =", self.Q2, "\ncR =", self.cR, "\n")
+            print("Q1 =", self.Q1)
+            print("Q2 =", self.Q2)
+            print("cR =", self.cR, "\n")
 
     def __getattr__(self, name):
         # UK / 3-D constructors of the reference run _find_statistics unconditionally (uk.py:380, ok3d.py:352,
@@ -674,6 +706,8 @@ class OrdinaryKriging(_KrigingBase):
             self.YCENTER = (np.amax(self.Y_ORIG) + np.amin(self.Y_ORIG)) / 2.0
             self.anisotropy_scaling = anisotropy_scaling
             self.anisotropy_angle = anisotropy_angle
+            if self.verbose:
+                print("Adjusting data for anisotropy...")
             self._adjust_stations()
         else:  # ok.py:289-304: coordinates stay as they are; anisotropy is ambiguous on the sphere
             if anisotropy_scaling != 1.0:
@@ -686,7 +720,7 @@ class OrdinaryKriging(_KrigingBase):
         self._set_variogram_parameters(variogram_parameters, nlags, weight)
         if type(self) is OrdinaryKriging and not self._enable_statistics:  # ok.py:360-377: statistics only on request
             self.delta = self.sigma = self.epsilon = self.Q1 = self.Q2 = self.cR = None
-        elif type(self) is OrdinaryKriging:
+        elif type(self) is OrdinaryKriging and self.__dict__.get("Q1") is None:  # (verbose: _set_variogram_parameters has computed and printed them)
             self._compute_statistics()
 
     def _center(self):
@@ -745,7 +779,11 @@ class UniversalKriging(OrdinaryKriging):
             specified_drift = []
         if functional_drift is None:
             functional_drift = []
+        if self.verbose:  # uk.py:396-466
+            print("Initializing drift terms...")
         self.regional_linear_drift = "regional_linear" in drift_terms
+        if self.regional_linear_drift and self.verbose:
+            print("Implementing regional linear drift.")
         self.external_Z_drift = "external_Z" in drift_terms
         if self.external_Z_drift:
             if external_drift is None:
@@ -764,6 +802,8 @@ class UniversalKriging(OrdinaryKriging):
             self.external_Z_array_x = np.array(ex).flatten()
             self.external_Z_array_y = np.array(ey).flatten()
             self.z_scalars = self._calculate_data_point_zscalars(self.X_ORIG, self.Y_ORIG)
+            if self.verbose:
+                print("Implementing external Z drift.")
         self.point_log_drift = "point_log" in drift_terms
         if self.point_log_drift:
             if point_drift is None:
@@ -774,6 +814,8 @@ class UniversalKriging(OrdinaryKriging):
             point_log = np.atleast_2d(np.squeeze(np.array(point_drift, copy=True, dtype=np.float64)))
             self._point_log_user = point_log
             self._adjust_wells()
+            if self.verbose:
+                print("Implementing external point-logarithmic drift; number of points =", self.point_log_array.shape[0], "\n")
         self.specified_drift = "specified" in drift_terms
         if self.specified_drift:
             if type(specified_drift) is not list:
@@ -900,6 +942,8 @@ class OrdinaryKriging3D(_KrigingBase):
         self.anisotropy_angle_x = anisotropy_angle_x
         self.anisotropy_angle_y = anisotropy_angle_y
         self.anisotropy_angle_z = anisotropy_angle_z
+        if self.verbose:
+            print("Adjusting data for anisotropy...")
         self._adjust_stations()
         self._set_variogram_parameters(variogram_parameters, nlags, weight)
 
@@ -968,6 +1012,10 @@ class UniversalKriging3D(OrdinaryKriging3D):
             specified_drift = []
         if functional_drift is None:
             functional_drift = []
+        if self.verbose:  # uk3d.py:396-406
+            print("Initializing drift terms...")
+            if "regional_linear" in drift_terms:
+                print("Implementing regional linear drift.")
         self.regional_linear_drift = "regional_linear" in drift_terms
         self.specified_drift = "specified" in drift_terms
         if self.specified_drift:

@@ -208,3 +208,27 @@ def test_kriging_objects_travel_and_change_style_between_calls():
     w2 = ok.execute("grid", gx, gy)
     w3 = pickle.loads(pickle.dumps(ok)).execute("grid", gx, gy, backend="loop", n_closest_points=12)
     assert np.array_equal(w1[0], w3[0]) and np.array_equal(w1[1], w3[1]) and not np.array_equal(w1[0], np.ma.getdata(w2[0]))
+
+
+def _verbose_run(args):
+    sys.path.insert(0, ROOT)
+    from oracle import ref_package as rp
+
+    if not rp.available():
+        pytest.skip("the staged reference (oracle/_ref) is not here")
+    r = subprocess.run([sys.executable, "-u", os.path.join(ROOT, "scripts", "verbose_vs_reference.py")] + args, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "0 case(s) differ" in r.stdout, r.stdout[-3000:] + r.stderr[-1500:]
+    return r.stdout
+
+
+def test_verbose_narration_of_ordinary_kriging_is_upstreams_line_by_line():
+    """verbose=True prints what upstream prints (ok.py:273-375): the anisotropy / variogram / statistics headings, the coordinates type, the model's parameters
+    under their names (Slope, Scale, Exponent, Partial Sill, Full Sill, Range, Nugget).  The device-free cases: OrdinaryKriging without statistics."""
+    assert _verbose_run(["--cpu"]).count(" same (") == 6
+
+
+@pytest.mark.gpu
+def test_verbose_narration_of_all_four_classes_is_upstreams_line_by_line():
+    """... and with the statistics (computed at once under verbose, as upstream computes them, and printed as Q1 / Q2 / cR), the drift headings of the universal
+    classes, update_variogram_model, execute and print_statistics: eleven cases, every line."""
+    assert _verbose_run([]).count(" same (") == 11
