@@ -16,18 +16,32 @@ rng = np.random.default_rng(2026)
 FAIL = []
 
 
+WARN = []
+
+
 def run(make, call):
-    out = []
+    import warnings
+
+    out, warned = [], []
     for mod in (pk, pa):
-        try:
-            out.append(("ok", call(make(mod))))
-        except Exception as e:  # noqa: BLE001
-            out.append(("raise", e))
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            try:
+                out.append(("ok", call(make(mod))))
+            except Exception as e:  # noqa: BLE001
+                out.append(("raise", e))
+        # the warnings the PACKAGE issues on purpose (warnings.warn in its own modules), not NumPy's floating-point ones from inside its arithmetic
+        warned.append(sorted({(w.category.__name__, str(w.message)[:60]) for w in rec if "pykrige" in w.filename and "invalid value" not in str(w.message)
+                              and "divide by zero" not in str(w.message) and "overflow" not in str(w.message)}))
+    WARN.append(warned)
     return out
 
 
 def same(name, make, call, tol=(1e-8, 1e-6)):
     (ka, ra), (kb, rb) = run(make, call)
+    if WARN[-1][0] != WARN[-1][1]:
+        print("%-58s warnings differ: reference %s, drop-in %s" % (name, WARN[-1][0], WARN[-1][1]))
+        FAIL.append(name + " (warnings)")
     deliberate = (ValueError, OSError, np.linalg.LinAlgError)  # what the reference raises on purpose; its TypeError / IndexError / UFuncTypeError are accidents
     if ka != kb and ka == "raise" and (not isinstance(ra, deliberate) or "zero-size array" in str(ra)):  # (np.amax of no pair distances: one station)
         print("%-58s note: the reference fails with %s (%s); the drop-in returns values" % (name, type(ra).__name__, str(ra)[:60]))
