@@ -527,9 +527,11 @@ class _KrigingBase:
         ax.axhline(y=0.0)
         plt.show()
 
-    def _get_kriging_matrix(self, n=None):
+    def _get_kriging_matrix(self, n=None, n_withdrifts=None):
         """The kriging matrix as the reference's method of the same name returns it (ok.py:626-648, uk.py:861-920,
-        3-D twins), assembled by K1 on the device and copied back -- for inspection; execute() never brings it to the host."""
+        3-D twins), assembled by K1 on the device and copied back -- for inspection; execute() never brings it to the host.
+        (n, and n_withdrifts of the universal classes, are upstream's positional arguments: the station count and the count with drift
+        columns -- both follow from the object and are accepted for the call's sake.)"""
         h = self._get_handle()
         self._set_problem(h)
         h.assemble_only()
