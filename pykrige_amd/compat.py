@@ -11,10 +11,12 @@ from .kriging import OrdinaryKriging, OrdinaryKriging3D, UniversalKriging, Unive
 
 try:
     from sklearn.base import BaseEstimator, ClassifierMixin, RegressorMixin
+    from sklearn.model_selection import train_test_split  # noqa: F401  (kept importable from here, as upstream keeps it: compat.py:11-13)
 
     SKLEARN_INSTALLED = True
 except ImportError:  # same degradation as the reference (compat.py:13-25): the classes exist, the checks fail
     SKLEARN_INSTALLED = False
+    train_test_split = None
 
     class RegressorMixin:
         pass
