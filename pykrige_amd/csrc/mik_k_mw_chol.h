@@ -176,8 +176,10 @@ __global__ void __launch_bounds__((G * G < 256) ? 256 : G * G, MIK_MWC_WAVES(G, 
       if (c >= K) break;  // uniform over the block
       double* ab = acol + (c & 1) * ACOL;
       if (tx == cx) {
+        // rows <= c of the diagonal local tile are finished: their column entries are published as zeros, so that neither the row factors
+        // nor the column factors read back need a select of their own (round 6: one select at the G publishers instead of two in every thread)
 #pragma unroll
-        for (int i = cc; i < RI; ++i) ab[ty + G * i] = m[i][cc];
+        for (int i = cc; i < RI; ++i) ab[ty + G * i] = (i == cc && ty <= cx) ? 0.0 : m[i][cc];
         if (ty < 3) ab[NB + ty] = rhs[cc];
         // the pivot's owner (thread (cx, cx), local tile element (cc, cc)) publishes its reciprocal as well: one wavefront
         // per step pays for it instead of every one (this kernel is instruction-issue bound: round 3)
@@ -192,8 +194,6 @@ __global__ void __launch_bounds__((G * G < 256) ? 256 : G * G, MIK_MWC_WAVES(G, 
         if (!MIK_MWC_LEAN(G, RI)) u[i] = ab[ty + G * i] * inv;
         w[i] = ab[tx + G * i];
       }
-      if (!MIK_MWC_LEAN(G, RI) && ty <= cx) u[cc] = 0.0;  // rows / columns <= c of the diagonal local tile are finished
-      if (tx <= cx) w[cc] = 0.0;
       const double ur = (ty < 3 ? ab[NB + ty] : 0.0) * inv;
       // the five inner products z and sigma^2 are made of, sum_c y_p(c) y_q(c) / d(c), are formed ONCE at the end from this log
       // (every thread used to accumulate all five in every step)
@@ -201,8 +201,7 @@ __global__ void __launch_bounds__((G * G < 256) ? 256 : G * G, MIK_MWC_WAVES(G, 
       if (MIK_MWC_LEAN(G, RI)) {  // the largest one-wavefront tiles: the row factors are read as they are used (RI fewer live doubles)
 #pragma unroll
         for (int i = cc; i < RI; ++i) {
-          double ui = ab[ty + G * i] * inv;
-          if (i == cc && ty <= cx) ui = 0.0;
+          const double ui = ab[ty + G * i] * inv;
 #pragma unroll
           for (int j = cc; j <= i; ++j) m[i][j] -= ui * w[j];
         }
