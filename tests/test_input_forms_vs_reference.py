@@ -232,3 +232,51 @@ def test_verbose_narration_of_all_four_classes_is_upstreams_line_by_line():
     """... and with the statistics (computed at once under verbose, as upstream computes them, and printed as Q1 / Q2 / cR), the drift headings of the universal
     classes, update_variogram_model, execute and print_statistics: eleven cases, every line."""
     assert _verbose_run([]).count(" same (") == 11
+
+
+def test_handle_parking_rules_without_a_device(monkeypatch):
+    """_lib.release_handle / acquire_handle on stand-in handles (no GPU): what is parked, what is destroyed, what is taken over."""
+    sys.path.insert(0, ROOT)
+    from pykrige_amd import _lib
+
+    closed = []
+
+    class StandIn:
+        def __init__(self, epoch=0, custom=None, pid=None, sig=None):
+            self._h, self.option_epoch, self._custom_cb, self._keep = object(), epoch, custom, [1]
+            self.pid = os.getpid() if pid is None else pid
+            self.env_sig = _lib._env_sig() if sig is None else sig
+
+        def close(self):
+            closed.append(self)
+            self._h = None
+
+    monkeypatch.setattr(_lib, "_pool", [])
+    monkeypatch.setenv("MIK_HANDLE_POOL", "2")
+    a, b, c = StandIn(), StandIn(), StandIn()
+    for h in (a, b, c):
+        _lib.release_handle(h, 1e6)
+    assert _lib._pool == [a, b] and closed == [c] and a._keep == []  # the pool holds two; the third is destroyed; the previous owner's arrays are let go
+    monkeypatch.setattr(_lib, "Handle", lambda: "fresh")
+    assert _lib.acquire_handle() is a and _lib.acquire_handle() is b and _lib.acquire_handle() == "fresh"
+    for h, why in ((StandIn(epoch=1), "an option was set"), (StandIn(custom=print), "a custom variogram"), (StandIn(pid=-5), "another process")):
+        _lib.release_handle(h, 1e6)
+        assert not _lib._pool and closed[-1] is h, why
+    big = StandIn()
+    _lib.release_handle(big, 1e12)
+    assert not _lib._pool and closed[-1] is big  # too much device memory to keep around
+    monkeypatch.setenv("MIK_HANDLE_POOL", "0")
+    off = StandIn()
+    _lib.release_handle(off, 1.0)
+    assert not _lib._pool and closed[-1] is off
+    monkeypatch.setenv("MIK_HANDLE_POOL", "2")
+    other_env = StandIn()
+    _lib.release_handle(other_env, 1.0)
+    monkeypatch.setenv("MIK_FACTOR", "lu")  # the library reads its option defaults from the environment at mik_create
+    assert _lib.acquire_handle() == "fresh" and _lib._pool == [other_env]
+    monkeypatch.delenv("MIK_FACTOR")
+    assert _lib.acquire_handle() is other_env
+    _lib.release_handle(StandIn(), 1.0)
+    n = len(closed)
+    _lib.flush_handle_pool()
+    assert not _lib._pool and len(closed) == n + 1
