@@ -96,68 +96,73 @@ def case(i):
     return name, make, (lambda m: m.execute(style, *axes, **ekw)), float(np.abs(v).max())
 
 
-bad, agree, raised, noted, illcond = [], 0, 0, 0, 0
-worst = [0.0, 0.0]
-for i in range(N):
-    name, make, call, scale = case(i)
-    out = []
-    for mod in (pk, pa):
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            try:
-                out.append(("ok", call(make(mod))))
-            except Exception as e:  # noqa: BLE001
-                out.append(("raise", e))
-    (ka, ra), (kb, rb) = out
-    if ka == "raise" and isinstance(ra, NotImplementedError) and kb == "ok":
-        noted += 1  # backend='C' knows five models (lib/variogram_models.pyx:9-20): a deliberate deviation, the drop-in kriges
-        continue
-    cond = None
-    if kb == "ok":
-        try:  # the conditioning of the system both solved (the drop-in's assembled matrix): beyond 1e9 the reference's own digits are gone
+def main():
+    bad, agree, raised, noted, illcond = [], 0, 0, 0, 0
+    worst = [0.0, 0.0]
+    for i in range(N):
+        name, make, call, scale = case(i)
+        out = []
+        for mod in (pk, pa):
             with warnings.catch_warnings():
                 warnings.simplefilter("ignore")
-                cond = float(np.linalg.cond(make(pa)._get_kriging_matrix()))
-        except Exception:  # noqa: BLE001
-            cond = None
-    if cond is not None and not cond < 1e9:
-        illcond += 1
-        if ka == kb == "ok" and "-v" in sys.argv:  # reported only: what the two made of a system whose digits are gone
-            dz = float(np.nanmax(np.abs(np.ma.filled(np.ma.asarray(ra[0]), 0.0) - np.ma.filled(np.ma.asarray(rb[0]), 0.0)))) if np.size(ra[0]) else 0.0
-            print("%4d %-90s ill-conditioned: cond_2 %.1e, max|dz| %.1e (cond x 1e-16 x |z| = %.1e)" % (i, name, cond, dz, cond * 1e-16 * scale))
-        elif ka != kb and "-v" in sys.argv:
-            print("%4d %-90s ill-conditioned: cond_2 %.1e, reference %s, drop-in %s" % (i, name, cond, ka if ka == "ok" else type(ra).__name__, kb if kb == "ok" else type(rb).__name__))
-        continue
-    if ka != kb:
-        bad.append(name)
-        print("%4d %-90s DISAGREE: reference %s, drop-in %s" % (i, name, ka if ka == "ok" else type(ra).__name__ + ": " + str(ra)[:60], kb if kb == "ok" else type(rb).__name__ + ": " + str(rb)[:80]))
-        continue
-    if ka == "raise":
-        raised += 1
-        if not (isinstance(rb, type(ra)) or isinstance(ra, type(rb))):
-            bad.append(name)
-            print("%4d %-90s raise DIFFERENT kinds: %s / %s" % (i, name, type(ra).__name__, type(rb).__name__))
-        continue
-    msg = []
-    for j, (a, b, tol) in enumerate(((ra[0], rb[0], 1e-8), (ra[1], rb[1], 1e-6))):
-        if np.shape(a) != np.shape(b) or np.ma.isMaskedArray(a) != np.ma.isMaskedArray(b) or not np.array_equal(np.ma.getmaskarray(a), np.ma.getmaskarray(b)):
-            msg.append("shape / mask of output %d" % j)
+                try:
+                    out.append(("ok", call(make(mod))))
+                except Exception as e:  # noqa: BLE001
+                    out.append(("raise", e))
+        (ka, ra), (kb, rb) = out
+        if ka == "raise" and isinstance(ra, NotImplementedError) and kb == "ok":
+            noted += 1  # backend='C' knows five models (lib/variogram_models.pyx:9-20): a deliberate deviation, the drop-in kriges
             continue
-        da, db = np.ma.filled(np.ma.asarray(a), 0.0), np.ma.filled(np.ma.asarray(b), 0.0)
-        if da.size:
-            d = np.abs(da - db)
-            fin = np.isfinite(da) & np.isfinite(db)
-            if not (np.isfinite(da) == np.isfinite(db)).all():
-                msg.append("non-finite pattern of output %d" % j)
-            m = float(d[fin].max()) if fin.any() else 0.0
-            worst[j] = max(worst[j], m / max(1.0, scale if j == 0 else 1.0))
-            if m > tol * max(1.0, scale if j == 0 else 1.0, float(np.abs(da[fin]).max()) if fin.any() else 1.0):
-                msg.append("output %d max|d| %.2e (values up to %.2e)" % (j, m, float(np.abs(da[fin]).max())))
-    if msg:
-        bad.append(name)
-        print("%4d %-90s DISAGREE: %s" % (i, name, "; ".join(msg)))
-    else:
-        agree += 1
-print("%d cases (seed %d): %d agree in value, %d raise alike, %d disagree; %d left out as ill-conditioned (cond_2 >= 1e9), %d where backend='C' does not know the model upstream; "
-      "worst |dz| %.2e, |dsigma^2| %.2e" % (N, SEED, agree, raised, len(bad), illcond, noted, worst[0], worst[1]))
-sys.exit(1 if bad else 0)
+        cond = None
+        if kb == "ok":
+            try:  # the conditioning of the system both solved (the drop-in's assembled matrix): beyond 1e9 the reference's own digits are gone
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    cond = float(np.linalg.cond(make(pa)._get_kriging_matrix()))
+            except Exception:  # noqa: BLE001
+                cond = None
+        if cond is not None and not cond < 1e9:
+            illcond += 1
+            if ka == kb == "ok" and "-v" in sys.argv:  # reported only: what the two made of a system whose digits are gone
+                dz = float(np.nanmax(np.abs(np.ma.filled(np.ma.asarray(ra[0]), 0.0) - np.ma.filled(np.ma.asarray(rb[0]), 0.0)))) if np.size(ra[0]) else 0.0
+                print("%4d %-90s ill-conditioned: cond_2 %.1e, max|dz| %.1e (cond x 1e-16 x |z| = %.1e)" % (i, name, cond, dz, cond * 1e-16 * scale))
+            elif ka != kb and "-v" in sys.argv:
+                print("%4d %-90s ill-conditioned: cond_2 %.1e, reference %s, drop-in %s" % (i, name, cond, ka if ka == "ok" else type(ra).__name__, kb if kb == "ok" else type(rb).__name__))
+            continue
+        if ka != kb:
+            bad.append(name)
+            print("%4d %-90s DISAGREE: reference %s, drop-in %s" % (i, name, ka if ka == "ok" else type(ra).__name__ + ": " + str(ra)[:60], kb if kb == "ok" else type(rb).__name__ + ": " + str(rb)[:80]))
+            continue
+        if ka == "raise":
+            raised += 1
+            if not (isinstance(rb, type(ra)) or isinstance(ra, type(rb))):
+                bad.append(name)
+                print("%4d %-90s raise DIFFERENT kinds: %s / %s" % (i, name, type(ra).__name__, type(rb).__name__))
+            continue
+        msg = []
+        for j, (a, b, tol) in enumerate(((ra[0], rb[0], 1e-8), (ra[1], rb[1], 1e-6))):
+            if np.shape(a) != np.shape(b) or np.ma.isMaskedArray(a) != np.ma.isMaskedArray(b) or not np.array_equal(np.ma.getmaskarray(a), np.ma.getmaskarray(b)):
+                msg.append("shape / mask of output %d" % j)
+                continue
+            da, db = np.ma.filled(np.ma.asarray(a), 0.0), np.ma.filled(np.ma.asarray(b), 0.0)
+            if da.size:
+                d = np.abs(da - db)
+                fin = np.isfinite(da) & np.isfinite(db)
+                if not (np.isfinite(da) == np.isfinite(db)).all():
+                    msg.append("non-finite pattern of output %d" % j)
+                m = float(d[fin].max()) if fin.any() else 0.0
+                worst[j] = max(worst[j], m / max(1.0, scale if j == 0 else 1.0))
+                if m > tol * max(1.0, scale if j == 0 else 1.0, float(np.abs(da[fin]).max()) if fin.any() else 1.0):
+                    msg.append("output %d max|d| %.2e (values up to %.2e)" % (j, m, float(np.abs(da[fin]).max())))
+        if msg:
+            bad.append(name)
+            print("%4d %-90s DISAGREE: %s" % (i, name, "; ".join(msg)))
+        else:
+            agree += 1
+    print("%d cases (seed %d): %d agree in value, %d raise alike, %d disagree; %d left out as ill-conditioned (cond_2 >= 1e9), %d where backend='C' does not know the model upstream; "
+          "worst |dz| %.2e, |dsigma^2| %.2e" % (N, SEED, agree, raised, len(bad), illcond, noted, worst[0], worst[1]))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
