@@ -36,7 +36,22 @@ def case(i):
     v = np.sin(3 * (xs[0] - xs[0].min()) / span[0]) + (xs[1] - xs[1].min()) / span[1] + 0.1 * r.standard_normal(n)
     model = str(r.choice(MODELS))
     kw = {"variogram_model": model}
-    if r.random() < 0.8:
+    geographic = (not dim3) and (not universal) and r.random() < 0.2
+    if geographic:  # lon / lat in degrees, ranges in degrees of arc; no anisotropy on the sphere
+        xs = [r.uniform(-180, 180, n) if r.random() < 0.5 else r.uniform(150, 210, n) % 360, r.uniform(-70, 70, n)]
+        span = [40.0, 40.0]
+        v = np.sin(np.radians(xs[0])) + np.cos(np.radians(xs[1])) + 0.1 * r.standard_normal(n)
+        kw["coordinates_type"] = "geographic"
+    custom = r.random() < 0.08
+    if custom:
+        model = "custom"
+        kw["variogram_model"] = "custom"
+        c0, c1, c2 = float(r.uniform(0.5, 2)), float(np.mean(span) * r.uniform(0.2, 0.8)), float(r.uniform(0.0, 0.2))
+        kw["variogram_parameters"] = [c0, c1, c2]
+        kw["variogram_function"] = lambda p, d: p[0] * (1.0 - np.exp(-d / p[1])) + p[2]
+    if custom:
+        pass
+    elif r.random() < 0.8:
         p = params_for(model, r)
         if model not in ("linear", "power"):
             p[1] *= float(np.mean(span))  # a range in the units of the coordinates
@@ -53,7 +68,7 @@ def case(i):
         if r.random() < 0.5:
             kw.update(anisotropy_scaling_y=float(r.uniform(0.5, 3)), anisotropy_scaling_z=float(r.uniform(0.5, 3)), anisotropy_angle_x=float(r.uniform(0, 90)),
                       anisotropy_angle_y=float(r.uniform(0, 90)), anisotropy_angle_z=float(r.uniform(0, 90)))
-    elif r.random() < 0.5:
+    elif r.random() < 0.5 and not geographic:
         kw.update(anisotropy_scaling=float(r.uniform(0.5, 3)), anisotropy_angle=float(r.uniform(0, 180)))
     drift_note = ""
     if universal:
@@ -68,13 +83,29 @@ def case(i):
             # (bounded and NOT a linear function of the coordinates: beside regional_linear a linear one makes the matrix singular)
             x0, s0, y0, s1 = float(xs[0].min()), float(span[0]), float(xs[1].min()), float(span[1])
             kw["functional_drift"] = [(lambda a, b, c: np.sin(2.0 * (a - x0) / s0) * np.cos((b - y0) / s1)) if dim3 else (lambda a, b: np.sin(2.0 * (a - x0) / s0) * np.cos((b - y0) / s1))]
+        spec = r.random() < 0.2
+        if spec:
+            terms.append("specified")
+            kw["specified_drift"] = [np.cos(3.0 * (xs[0] - xs[0].min()) / span[0])]
+        ext = (not dim3) and r.random() < 0.2
+        if ext:
+            terms.append("external_Z")
+            ex = np.linspace(xs[0].min() - 0.2 * span[0], xs[0].max() + 0.2 * span[0], int(r.integers(4, 12)))
+            ey = np.linspace(xs[1].min() - 0.2 * span[1], xs[1].max() + 0.2 * span[1], int(r.integers(4, 12)))
+            kw.update(external_drift=r.random((ey.size, ex.size)), external_drift_x=ex, external_drift_y=ey)
         kw["drift_terms"] = terms
         drift_note = "+".join(terms) or "no terms"
     dt = r.choice([np.float64, np.float64, np.float32])
     style = str(r.choice(["grid", "points", "masked"]))
     backend = str(r.choice(["vectorized", "loop"] if (universal or dim3) else ["vectorized", "loop", "C"]))
     axes = [np.linspace(a.min() - 0.05 * s, a.max() + 0.05 * s, int(r.integers(2, 9))).astype(dt) for a, s in zip(xs, span)]
+    if geographic:
+        dt = np.float64  # (float32 lon / lat: upstream's great-circle arithmetic runs in float32 on the point side -- reported by edge_forms_vs_reference.py, not restated)
+        axes = [np.linspace(xs[0].min(), xs[0].max(), int(r.integers(2, 9))), np.linspace(-60, 60, int(r.integers(2, 9)))]
     ekw = {"backend": backend}
+    if universal and "specified" in kw.get("drift_terms", ()):
+        backend = "vectorized"  # (the loop backend indexes the specified drift by the matrix row upstream: uk.py:1070)
+        ekw["backend"] = backend
     if style == "points":
         m = int(r.integers(1, 30))
         axes = [(a.min() + s * r.random(m)).astype(dt) for a, s in zip(xs, span)]
@@ -84,10 +115,16 @@ def case(i):
                 ax[:k] = a[:k].astype(dt)
     if style == "masked":
         ekw["mask"] = r.random(tuple(a.size for a in reversed(axes))) < 0.4
+    if universal and "specified" in kw.get("drift_terms", ()):
+        if style == "points":
+            ekw["specified_drift_arrays"] = [np.cos(3.0 * (axes[0].astype(np.float64) - xs[0].min()) / span[0])]
+        else:
+            g = np.cos(3.0 * (axes[0].astype(np.float64) - xs[0].min()) / span[0])
+            ekw["specified_drift_arrays"] = [np.broadcast_to(g, tuple(a.size for a in reversed(axes))).copy()]
     if not universal and backend != "vectorized" and r.random() < 0.35:
         ekw["n_closest_points"] = int(r.integers(2, min(n, 20) + 1))
     name = "%s%s %s n=%d %s %s[%s]%s %s%s" % ("UK" if universal else "OK", "3D" if dim3 else "2D", model, n, "given" if "variogram_parameters" in kw else "fitted", style, backend,
-                                           " k=%d" % ekw["n_closest_points"] if "n_closest_points" in ekw else "", np.dtype(dt).name, " " + drift_note if universal else "")
+                                           " k=%d" % ekw["n_closest_points"] if "n_closest_points" in ekw else "", np.dtype(dt).name, (" " + drift_note if universal else "") + (" geographic" if geographic else ""))
 
     def make(mod):
         cls = {(False, False): mod.ok.OrdinaryKriging, (True, False): mod.uk.UniversalKriging, (False, True): mod.ok3d.OrdinaryKriging3D, (True, True): mod.uk3d.UniversalKriging3D}[(universal, dim3)]

@@ -284,7 +284,7 @@ def test_handle_parking_rules_without_a_device(monkeypatch):
 
 @pytest.mark.gpu
 def test_random_constructor_and_execute_cases_against_the_real_reference():
-    """150 random cases (class, model, given / fitted variogram, anisotropy, drifts, exactness, pseudo-inverse, float32 / float64 coordinates, style, backend,
+    """150 random cases (class, model incl. custom callables, given / fitted variogram, geographic coordinates, anisotropy, every drift kind, exactness, pseudo-inverse, float32 / float64 coordinates, style, backend,
     window) through the real reference and the drop-in: same values at 1e-8 / 1e-6, same shapes and masks -- the randomized campaign of
     test_randomized_parity.py checks against the oracle restatement, this one against upstream itself, host-side quirks included
     (profiles/r06_random_vs_reference_400_cases.txt: 400 cases).  Systems with cond_2 >= 1e9 are left out (reported by the script's -v)."""
